@@ -1,0 +1,190 @@
+/*
+ * rs_asr.h — C ABI of librs_asr.so, the MI355X (gfx950) FastConformer-RNNT inference path.
+ *
+ * The reference (reazon-research/ReazonSpeech) has NO FFI / plugin boundary for this path:
+ * its only interface is the Python pair load_model()/transcribe()
+ * (pkg/nemo-asr/src/transcribe.py:9-28, :30-60) which hands everything to NeMo at two call
+ * sites (EncDecRNNTBPEModel.from_pretrained :26-28, model.transcribe :48-53).  This header is
+ * the boundary introduced *underneath* that pair: each entry point below names
+ * the reference-side step it replaces.  INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / C++ types.
+ *   - The CALLER owns every device buffer (weights, activations, workspace); the library never
+ *     allocates or frees device memory.  All pointers are device pointers unless named host_*.
+ *   - Every function returns RS_OK (0) or a negative RS_E* code; rs_last_error() returns a
+ *     message for the last failure on that context (thread-compatible, not re-entrant: one
+ *     context per stream).  No exit/abort, no C++ exception crosses the ABI.
+ *   - Work is enqueued asynchronously on the given hipStream_t (passed as void*; NULL = the
+ *     default stream).  Nothing synchronises unless stated.
+ *   - bf16 tensors are raw uint16 bit patterns (round-to-nearest-even of the f32 value).
+ */
+#ifndef RS_ASR_H
+#define RS_ASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_ABI_VERSION 1
+
+enum {
+    RS_OK = 0,
+    RS_EINVAL = -1,      /* bad argument / shape */
+    RS_EMISSING = -2,    /* a required weight tensor was not registered */
+    RS_EWORKSPACE = -3,  /* workspace too small */
+    RS_EHIP = -4,        /* a HIP runtime call failed */
+    RS_EOVERFLOW = -5,   /* decode output buffer (u_max) too small for some utterance */
+    RS_ESTATE = -6       /* call order violated (e.g. forward before rs_finalize) */
+};
+
+typedef struct rs_ctx rs_ctx;
+
+/* Model dimensions: what NeMo reads from model_config.yaml inside the .nemo checkpoint
+ * (reference: pkg/nemo-asr/src/transcribe.py:26-28 [UPSTREAM]). */
+typedef struct rs_dims {
+    int32_t n_mels;        /* 80 */
+    int32_t n_fft;         /* 512 (only 512 is built) */
+    int32_t win_length;    /* 400 */
+    int32_t hop_length;    /* 160 */
+    float preemph;         /* 0.97, 0 disables */
+    float log_guard;       /* 2^-24 */
+    float norm_eps;        /* 1e-5, added to the per-feature std */
+    int32_t d_model;       /* 1024 */
+    int32_t n_heads;       /* 8 (head_dim must be 128) */
+    int32_t ff_dim;        /* 4096 */
+    int32_t n_layers;      /* 24 */
+    int32_t conv_kernel;   /* 9 */
+    int32_t sub_channels;  /* 256 */
+    int32_t sub_stages;    /* 3 (x8) */
+    int32_t xscaling;      /* 1: multiply the subsampling output by sqrt(d_model) */
+    float ln_eps;          /* 1e-5 */
+    int32_t att_left;      /* -1 = unlimited */
+    int32_t att_right;     /* -1 = unlimited */
+    int32_t n_global;      /* global tokens of the local-attention variant (0 = none) */
+    int32_t n_logits;      /* vocab + 1 (3001) */
+    int32_t blank_id;      /* 3000 */
+    int32_t pred_hidden;   /* 640 */
+    int32_t pred_layers;   /* 2 */
+    int32_t joint_hidden;  /* 640 */
+    int32_t max_symbols;   /* 10 */
+} rs_dims;
+
+/* ---- context ------------------------------------------------------------------------- */
+
+/* Replaces: model object construction inside EncDecRNNTBPEModel.from_pretrained
+ * (pkg/nemo-asr/src/transcribe.py:26-28).  `device` is the HIP device ordinal. */
+int rs_create(rs_ctx** out, int device, const rs_dims* dims);
+void rs_destroy(rs_ctx* ctx);
+const char* rs_last_error(const rs_ctx* ctx);
+int rs_abi_version(void);
+
+/* Register one prepared weight tensor by name (device pointer, caller-owned, must outlive the
+ * context).  Names and layouts: DESIGN.md §"Weights in HBM".  Replaces: load_state_dict inside
+ * from_pretrained (transcribe.py:26-28). */
+int rs_set_tensor(rs_ctx* ctx, const char* name, const void* dev_ptr, size_t nbytes);
+/* Check that every tensor the dims require is present; must precede any forward call. */
+int rs_finalize(rs_ctx* ctx);
+
+/* Bytes of scratch the three stage functions need for a batch of B utterances whose padded
+ * sample count is at most max_samples (pad included). */
+size_t rs_workspace_bytes(const rs_ctx* ctx, int B, int max_samples);
+
+/* Shape helpers (host arithmetic, no device work). */
+int rs_mel_frames(const rs_ctx* ctx, int n_samples);   /* floor(L / hop) */
+int rs_enc_frames(const rs_ctx* ctx, int n_mel_frames); /* three k3 s2 p1 convs */
+
+/* ---- stage 1: log-mel front-end -------------------------------------------------------
+ * Replaces: pad_audio (pkg/nemo-asr/src/audio.py:70-83, folded into the load: the kernel
+ * reads `audio[b][i - pad_left]` and treats everything outside [0, lens[b]) as 0) and NeMo's
+ * AudioToMelSpectrogramPreprocessor reached through model.transcribe (transcribe.py:48-53):
+ * pre-emphasis, STFT(512, hann 400, hop 160, centre, zero pad), power, Slaney mel 80,
+ * log(x + 2^-24), per-feature normalisation over the valid frames, zeroed padding.
+ *
+ *   audio   f32[B][audio_stride]   raw (un-padded) samples
+ *   lens    i32[B]                  valid samples per utterance (un-padded)
+ *   feats   f32[B][t_max][n_mels]   t_max = rs_mel_frames(max(lens) + pad_left + pad_right)
+ *   n_frames i32[B]                 valid frames per utterance (written)
+ */
+int rs_frontend_logmel(rs_ctx* ctx, const float* audio, const int32_t* lens, int B,
+                       int audio_stride, int pad_left, int pad_right, int t_max,
+                       float* feats, int32_t* n_frames, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---- stage 2: FastConformer encoder + joint encoder projection --------------------------
+ * Replaces: ConformerEncoder.forward and RNNTJoint.enc inside model.transcribe
+ * (transcribe.py:48-53): dw-striding x8 subsampling, 24 x [1/2 FFN, rel-pos MHSA, conv
+ * module, 1/2 FFN, LayerNorm], Linear d_model -> joint_hidden.
+ *
+ *   feats, n_frames      as produced by rs_frontend_logmel
+ *   enc_out  f32[B][tp_max][d_model]      (may be NULL if not wanted) tp_max = rs_enc_frames(t_max)
+ *   joint_enc f32[B][tp_max][joint_hidden]
+ *   enc_lens i32[B]
+ */
+int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames, int B, int t_max,
+                       float* enc_out, float* joint_enc, int32_t* enc_lens,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- stage 3: RNN-T greedy decode -------------------------------------------------------
+ * Replaces: decoding.rnnt_decoder_predictions_tensor inside model.transcribe
+ * (transcribe.py:48-53) — prediction network (Embedding + LSTM), joint (ReLU + Linear),
+ * argmax, max_symbols loop — in its batched-greedy form (the north-star's decode strategy;
+ * the reference post-processing expects ALSD-shaped output, see Hypothesis.from_greedy).
+ *
+ *   joint_enc f32[B][tp_max][joint_hidden], enc_lens i32[B]
+ *   ids     i32[B][u_max]   emitted token ids
+ *   frames  i32[B][u_max]   encoder frame index each token was emitted at
+ *   n_ids   i32[B]
+ * Synchronises the stream internally (the trip count is data dependent).  Returns
+ * RS_EOVERFLOW if an utterance would emit more than u_max tokens.
+ */
+int rs_rnnt_greedy(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max,
+                   int u_max, int32_t* ids, int32_t* frames, int32_t* n_ids,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- profiling hooks for bench.py (roofline.achieved) ------------------------------------
+ * When enabled, the launcher brackets every launch of the selected kernel class with HIP
+ * events on the launch stream.  rs_profile_read synchronises those events and returns the
+ * accumulated milliseconds, launch count and algorithmic FLOPs / bytes since the last reset. */
+enum { RS_PROF_NONE = 0, RS_PROF_GEMM = 1, RS_PROF_ATTN = 2, RS_PROF_FRONTEND = 4,
+       RS_PROF_DECODE = 8, RS_PROF_ELEMENTWISE = 16, RS_PROF_SUBSAMPLE = 32 };
+int rs_profile_enable(rs_ctx* ctx, int class_mask);
+int rs_profile_read(rs_ctx* ctx, int klass, double* ms, int64_t* launches, double* flops,
+                    double* bytes);
+int rs_profile_reset(rs_ctx* ctx);
+
+/* ---- single-operator entry points (parity tests call these one by one) -------------------*/
+
+/* C[M][N] = epilogue(A[M][K] . W[N][K]^T); A, W bf16 row-major, K % 64 == 0.
+ * flags: see RS_GEMM_* ; bias f32[N]; residual f32[M][ldc] (may alias out when out is f32). */
+enum { RS_GEMM_BIAS = 1, RS_GEMM_RELU = 2, RS_GEMM_SILU = 4, RS_GEMM_RESIDUAL = 8,
+       RS_GEMM_OUT_F32 = 16, RS_GEMM_ROWMASK = 32 };
+int rs_gemm_bf16(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int ldw,
+                 void* out, int ldc, int M, int N, int K, int flags, const float* bias, float alpha,
+                 const float* residual, const int32_t* mask_lens, int mask_rows_per_step,
+                 int mask_steps, void* stream);
+
+/* y = LayerNorm(x) over the last dim (d); x f32[M][d]; out_bf16 and/or out_f32 may be NULL. */
+int rs_layernorm(rs_ctx* ctx, const float* x, const float* gamma, const float* beta, int M, int d,
+                 float eps, uint16_t* out_bf16, float* out_f32, void* stream);
+
+/* Relative-position multi-head attention core.
+ *   qkv bf16[B*T][3*d_model] (q | k | v), pos bf16[2T-1][d_model] (linear_pos of the table),
+ *   bias_u/bias_v f32[n_heads][128], lens i32[B]; ctx_out bf16[B*T][d_model]. */
+int rs_relpos_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, const float* bias_u,
+                        const float* bias_v, const int32_t* lens, int B, int T, uint16_t* ctx_out,
+                        void* stream);
+
+/* Conv-module middle: GLU -> zero padded frames -> depthwise k (BatchNorm folded) -> SiLU.
+ *   x bf16[B*T][2*d], dw_w f32[k][d] (tap-major), dw_b f32[d]; out bf16[B*T][d]. */
+int rs_glu_dwconv_silu(rs_ctx* ctx, const uint16_t* x, const float* dw_w, const float* dw_b,
+                       const int32_t* lens, int B, int T, int d, int k, uint16_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RS_ASR_H */

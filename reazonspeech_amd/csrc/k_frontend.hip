@@ -1,0 +1,174 @@
+// k_frontend.hip — log-mel front-end.
+//
+// [UPSTREAM] AudioToMelSpectrogramPreprocessor / FilterbankFeatures.forward:
+//   pre-emphasis 0.97 -> STFT(n_fft 512, hann 400 centred in the frame, hop 160, center=True with
+//   zero edge padding) -> |.|^2 -> Slaney mel (80 banded filters) -> log(x + 2^-24)
+//   -> per-utterance, per-feature (mean, unbiased std) normalisation over the valid frames
+//   -> zero the padding frames.
+// pad_audio (pkg/nemo-asr/src/audio.py:70-83) is folded into the sample fetch: the kernel reads
+// raw[i - pad_left] and everything outside [0, len) is 0.0, which is what np.pad would have stored.
+//
+// HBM-bound by construction: the audio is read once (each sample is touched by ~3 overlapping
+// frames, served by L2), the 257-bin spectrum lives only in LDS, and 80 floats per frame go out.
+// The 512-point FFT is a radix-2 in-LDS transform, one frame per wave; this is integer/float
+// streaming work, deliberately NOT reshaped into a DFT GEMM.
+#include "rs_common.h"
+
+namespace {
+
+constexpr int NFFT = 512;
+constexpr int NBIN = 257;
+constexpr int FB_MAXW = 32;          // widest Slaney filter has 18 taps at 80 mels / 512 fft
+constexpr int WAVES = 4;
+constexpr int FRAMES_PER_WAVE = 4;   // frames per block = 16
+
+struct FrontParams {
+    const float* audio; const int32_t* lens; float* raw; int32_t* n_frames;
+    const float* window;   // [win_length]
+    const float* twiddle;  // [256][2] cos, -sin of 2*pi*j/512
+    const int32_t* fb_idx; // [n_mels][2] first bin, tap count
+    const float* fb_w;     // [n_mels][FB_MAXW]
+    int audio_stride, pad_left, pad_right, t_max, n_mels, win_length, hop;
+    float preemph, log_guard;
+};
+
+__device__ __forceinline__ float fetch_sample(const float* __restrict__ a, int i, int pad_left, int len) {
+    const int j = i - pad_left;
+    return (j >= 0 && j < len) ? a[j] : 0.0f;
+}
+
+__device__ __forceinline__ int bitrev9(int v) { return (int)(__brev((unsigned)v) >> 23); }
+
+__global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
+    __shared__ float2 buf[WAVES][NFFT];
+    __shared__ float pw[WAVES][NBIN + 3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int len = p.lens[b];
+    const int Lp = len + p.pad_left + p.pad_right;       // padded length (reference: after pad_audio)
+    const int n_valid = Lp / p.hop;                       // floor((Lp + 2*(n_fft/2) - n_fft) / hop)
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.n_frames[b] = n_valid;
+    const float* a = p.audio + (size_t)b * p.audio_stride;
+    if ((int)blockIdx.x * WAVES * FRAMES_PER_WAVE >= min(n_valid, p.t_max)) return;  // block-uniform
+    const int frame_base = (blockIdx.x * WAVES + wave) * FRAMES_PER_WAVE;
+    const int centre_off = (NFFT - p.win_length) / 2;     // 56: window centred in the 512 frame
+
+    for (int fi = 0; fi < FRAMES_PER_WAVE; ++fi) {
+        const int t = frame_base + fi;
+        const bool active = t < n_valid && t < p.t_max;
+        // ---- windowed, pre-emphasised samples -> bit-reversed LDS order.  A circular shift of the
+        // FFT input only changes the phase, so the 400 samples go to slots 0..399 directly.
+        float2* z = buf[wave];
+#pragma unroll
+        for (int q = 0; q < NFFT / 64; ++q) {
+            const int n = q * 64 + lane;
+            float v = 0.0f;
+            if (active && n < p.win_length) {
+                const int i = t * p.hop - NFFT / 2 + centre_off + n;  // index in the padded signal
+                if (i >= 0 && i < Lp) {
+                    const float x0 = fetch_sample(a, i, p.pad_left, len);
+                    const float x1 = (i >= 1) ? fetch_sample(a, i - 1, p.pad_left, len) : 0.0f;
+                    const float y = (i >= 1) ? x0 - p.preemph * x1 : x0;
+                    v = y * p.window[n];
+                }
+            }
+            z[bitrev9(n)] = make_float2(v, 0.0f);
+        }
+        __syncthreads();
+        // ---- 9 radix-2 DIT stages, 256 butterflies each (4 per lane)
+#pragma unroll 1
+        for (int s = 0; s < 9; ++s) {
+            const int half = 1 << s;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tb = q * 64 + lane;
+                const int pos = tb & (half - 1);
+                const int i0 = ((tb >> s) << (s + 1)) + pos;
+                const int i1 = i0 + half;
+                const float2 w = reinterpret_cast<const float2*>(p.twiddle)[pos << (8 - s)];
+                const float2 u = z[i0], v = z[i1];
+                const float tr = v.x * w.x - v.y * w.y;
+                const float ti = v.x * w.y + v.y * w.x;
+                z[i0] = make_float2(u.x + tr, u.y + ti);
+                z[i1] = make_float2(u.x - tr, u.y - ti);
+            }
+            __syncthreads();
+        }
+        // ---- power spectrum bins 0..256
+        for (int k = lane; k < NBIN; k += 64) {
+            const float2 c = z[k];
+            pw[wave][k] = c.x * c.x + c.y * c.y;
+        }
+        __syncthreads();
+        // ---- banded mel filterbank + log
+        if (active) {
+            for (int m = lane; m < p.n_mels; m += 64) {
+                const int k0 = p.fb_idx[2 * m], cnt = p.fb_idx[2 * m + 1];
+                const float* w = p.fb_w + m * FB_MAXW;
+                float acc = 0.0f;
+                for (int j = 0; j < cnt; ++j) acc = fmaf(w[j], pw[wave][k0 + j], acc);
+                p.raw[((size_t)b * p.t_max + t) * p.n_mels + m] = logf(acc + p.log_guard);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// per utterance: mean / unbiased std over the valid frames, normalise, zero the padding
+__global__ __launch_bounds__(256) void feat_normalize_kernel(const float* __restrict__ raw,
+                                                             const int32_t* __restrict__ n_frames, int t_max,
+                                                             int n_mels, float eps, float* __restrict__ out) {
+    __shared__ float red[8][128];
+    __shared__ float mean_s[128], rstd_s[128];
+    const int b = blockIdx.x;
+    const int n = min(n_frames[b], t_max);
+    const int m = threadIdx.x & 127 , tl = threadIdx.x >> 7;  // 2 time lanes x 128 feature slots
+    const bool mv = m < n_mels;
+    const float* r = raw + (size_t)b * t_max * n_mels;
+    float s = 0.0f;
+    if (mv) for (int t = tl; t < n; t += 2) s += r[(size_t)t * n_mels + m];
+    red[tl][m] = s;
+    __syncthreads();
+    if (tl == 0) mean_s[m] = (red[0][m] + red[1][m]) / (float)n;
+    __syncthreads();
+    const float mean = mean_s[m];
+    float q = 0.0f;
+    if (mv) for (int t = tl; t < n; t += 2) { const float dlt = r[(size_t)t * n_mels + m] - mean; q += dlt * dlt; }
+    red[tl][m] = q;
+    __syncthreads();
+    if (tl == 0) rstd_s[m] = 1.0f / (sqrtf((red[0][m] + red[1][m]) / (float)(n - 1)) + eps);
+    __syncthreads();
+    float* o = out + (size_t)b * t_max * n_mels;
+    const int total = t_max * n_mels;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int t = idx / n_mels, mm = idx - t * n_mels;
+        o[idx] = (t < n) ? (r[idx] - mean_s[mm]) * rstd_s[mm] : 0.0f;
+    }
+}
+
+}  // namespace
+
+int rs_launch_frontend(rs_ctx* ctx, const float* audio, const int32_t* lens, int B, int audio_stride,
+                       int pad_left, int pad_right, int t_max, float* feats, int32_t* n_frames, float* raw,
+                       hipStream_t s) {
+    const rs_dims& d = ctx->d;
+    if (B <= 0 || t_max <= 0) return RS_OK;
+    if (d.n_fft != NFFT) return rs_fail(ctx, RS_EINVAL, "frontend: only n_fft=512 is built");
+    if (d.n_mels > 128 || d.win_length > NFFT) return rs_fail(ctx, RS_EINVAL, "frontend: n_mels<=128, win<=512");
+    FrontParams p;
+    p.audio = audio; p.lens = lens; p.raw = raw; p.n_frames = n_frames;
+    p.window = ctx->fe_window; p.twiddle = ctx->fe_twiddle; p.fb_idx = ctx->fe_fb_idx; p.fb_w = ctx->fe_fb_w;
+    p.audio_stride = audio_stride; p.pad_left = pad_left; p.pad_right = pad_right; p.t_max = t_max;
+    p.n_mels = d.n_mels; p.win_length = d.win_length; p.hop = d.hop_length;
+    p.preemph = d.preemph; p.log_guard = d.log_guard;
+    const int fpb = WAVES * FRAMES_PER_WAVE;
+    const dim3 grid((t_max + fpb - 1) / fpb, B), block(64 * WAVES);
+    const double bytes = (double)B * ((double)t_max * d.hop_length * 4.0 + (double)t_max * d.n_mels * 4.0 * 3.0);
+    rs_prof_begin(ctx, RS_PROF_FRONTEND, s, (double)B * t_max * (5.0 * 512 * 9 + 3 * 257 + 2 * 600), bytes);
+    hipLaunchKernelGGL(logmel_kernel, grid, block, 0, s, p);
+    hipLaunchKernelGGL(feat_normalize_kernel, dim3(B), dim3(256), 0, s, raw, n_frames, t_max, d.n_mels, d.norm_eps,
+                       feats);
+    rs_prof_end(ctx, RS_PROF_FRONTEND, s);
+    RS_CHECK_LAUNCH(ctx, "frontend");
+    return RS_OK;
+}

@@ -1,0 +1,151 @@
+// k_layernorm.hip — LayerNorm over the model dimension and the fused
+// conv-module middle (row L6: GLU -> frame mask -> depthwise conv + folded BatchNorm -> SiLU).
+// Both are HBM-bound: one pass over the data, 16-byte accesses, wave-shuffle reductions.
+#include "rs_common.h"
+
+namespace {
+
+// One wave per row; d = 256 * NV (NV float4 per lane).  Two-pass statistics in registers:
+// mean, then sum((x-mean)^2) — the same formulation torch.layer_norm uses in float32.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, int M, float eps,
+                                                        uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    float4 v[NV];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = xr[i * 64 + lane];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, dd = v[i].w - mean;
+        q += (a * a + bb * bb) + (c * c + dd * dd);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+    const float4* gr = reinterpret_cast<const float4*>(g);
+    const float4* br = reinterpret_cast<const float4*>(b);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 gg = gr[i * 64 + lane], bb = br[i * 64 + lane];
+        float4 y;
+        y.x = (v[i].x - mean) * rstd * gg.x + bb.x;
+        y.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+        y.z = (v[i].z - mean) * rstd * gg.z + bb.z;
+        y.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+        if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[i * 64 + lane] = y;
+        if (out_bf16) {
+            u16x4_t o;
+            o[0] = f32_to_bf16(y.x); o[1] = f32_to_bf16(y.y); o[2] = f32_to_bf16(y.z); o[3] = f32_to_bf16(y.w);
+            reinterpret_cast<u16x4_t*>(out_bf16 + (size_t)row * D)[i * 64 + lane] = o;
+        }
+    }
+}
+
+// GLU + mask + depthwise conv (BatchNorm folded) + SiLU.
+//   x  bf16 [B*T][2d]  (a | gate),  w f32 [k][d] tap-major, bias f32 [d]  ->  out bf16 [B*T][d]
+// Workgroup = 256 threads = 32 channel groups (8 channels, one 16-B load) x 8 time lanes; it
+// produces a tile of TT frames x 256 channels.  The GLU'd, masked input tile (TT + k - 1 frames)
+// is staged once in LDS as f32, so every pw1 output element is read from HBM exactly once.
+constexpr int CT = 256;  // channels per workgroup
+constexpr int TT = 32;   // output frames per workgroup
+constexpr int KMAX = 31;
+
+__global__ __launch_bounds__(256) void glu_dwconv_silu_kernel(const uint16_t* __restrict__ x,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              const int32_t* __restrict__ lens, int T, int d, int k,
+                                                              uint16_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);  // [(TT + k - 1)][CT]
+    const int b = blockIdx.z, c0 = blockIdx.y * CT, t0 = blockIdx.x * TT;
+    const int cg = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int len = lens[b];
+    const int half = (k - 1) >> 1;
+    const int rows = TT + k - 1;
+    const int c = c0 + cg * 8;
+    for (int r = tl; r < rows; r += 8) {
+        const int t = t0 + r - half;
+        float u[8];
+        if (t >= 0 && t < T && t < len) {
+            const uint16_t* px = x + ((size_t)b * T + t) * (2 * d) + c;
+            const u16x8_t a = *reinterpret_cast<const u16x8_t*>(px);
+            const u16x8_t gt = *reinterpret_cast<const u16x8_t*>(px + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = bf16_to_f32(a[e]) * sigmoid_f(bf16_to_f32(gt[e]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = 0.0f;
+        }
+        float4* dst = reinterpret_cast<float4*>(tile + r * CT + cg * 8);
+        dst[0] = make_float4(u[0], u[1], u[2], u[3]);
+        dst[1] = make_float4(u[4], u[5], u[6], u[7]);
+    }
+    __syncthreads();
+    float bb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bb[e] = bias[c + e];
+    for (int tt = tl; tt < TT; tt += 8) {
+        const int t = t0 + tt;
+        if (t >= T) break;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bb[e];
+        for (int j = 0; j < k; ++j) {
+            const float4* src = reinterpret_cast<const float4*>(tile + (tt + j) * CT + cg * 8);
+            const float4 x0 = src[0], x1 = src[1];
+            const float4* wj = reinterpret_cast<const float4*>(w + (size_t)j * d + c);
+            const float4 w0 = wj[0], w1 = wj[1];
+            acc[0] = fmaf(x0.x, w0.x, acc[0]); acc[1] = fmaf(x0.y, w0.y, acc[1]);
+            acc[2] = fmaf(x0.z, w0.z, acc[2]); acc[3] = fmaf(x0.w, w0.w, acc[3]);
+            acc[4] = fmaf(x1.x, w1.x, acc[4]); acc[5] = fmaf(x1.y, w1.y, acc[5]);
+            acc[6] = fmaf(x1.z, w1.z, acc[6]); acc[7] = fmaf(x1.w, w1.w, acc[7]);
+        }
+        u16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(silu_f(acc[e]));
+        *reinterpret_cast<u16x8_t*>(out + ((size_t)b * T + t) * d + c) = o;
+    }
+}
+
+}  // namespace
+
+int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float* b, int M, int d, float eps,
+                        uint16_t* out_bf16, float* out_f32, hipStream_t s) {
+    if (M <= 0) return RS_OK;
+    if (d % 256 || d > 2048) return rs_fail(ctx, RS_EINVAL, "layernorm: d=%d must be a multiple of 256, <= 2048", d);
+    const dim3 grid((M + 3) / 4), block(256);
+    const double bytes = (double)M * d * (4.0 + (out_bf16 ? 2.0 : 0.0) + (out_f32 ? 4.0 : 0.0));
+    rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, 8.0 * M * d, bytes);
+    switch (d / 256) {
+#define LN_CASE(NV) case NV: hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, s, x, g, b, M, eps, out_bf16, out_f32); break;
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+#undef LN_CASE
+    }
+    rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
+    RS_CHECK_LAUNCH(ctx, "layernorm");
+    return RS_OK;
+}
+
+int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, const float* w, const float* b, const int32_t* lens,
+                         int B, int T, int d, int k, uint16_t* out, hipStream_t s) {
+    if (B <= 0 || T <= 0) return RS_OK;
+    if (d % CT) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: d=%d must be a multiple of %d", d, CT);
+    if (k < 1 || k > KMAX || !(k & 1)) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: kernel size %d unsupported", k);
+    const dim3 grid((T + TT - 1) / TT, d / CT, B), block(256);
+    const size_t lds = (size_t)(TT + k - 1) * CT * sizeof(float);
+    const double bytes = (double)B * T * d * (4.0 + 2.0);
+    rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, (double)B * T * d * (2.0 * k + 12.0), bytes);
+    hipLaunchKernelGGL(glu_dwconv_silu_kernel, grid, block, lds, s, x, w, b, lens, T, d, k, out);
+    rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
+    RS_CHECK_LAUNCH(ctx, "glu_dwconv_silu");
+    return RS_OK;
+}

@@ -1,0 +1,420 @@
+// rs_api.hip — the C ABI of librs_asr.so (include/rs_asr.h): context, weight registry, workspace
+// carving and the stage orchestrators that enqueue the kernels of k_*.hip on the caller's stream.
+#include <stdarg.h>
+#include <string.h>
+
+#include "rs_common.h"
+
+size_t rs_rnnt_workspace_bytes(const rs_ctx* ctx, int B);
+int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int u_max,
+                        int32_t* ids, int32_t* frames, int32_t* n_ids, void* workspace, size_t workspace_bytes,
+                        hipStream_t s);
+
+int rs_fail(rs_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+int rs_prof_class_index(int klass) {
+    int i = 0;
+    while (klass > 1) { klass >>= 1; ++i; }
+    return i;
+}
+void rs_prof_begin(rs_ctx* ctx, int klass, hipStream_t s, double flops, double bytes) {
+    if (!(ctx->prof_mask & klass)) return;
+    rs_prof_slot& p = ctx->prof[rs_prof_class_index(klass)];
+    if (p.used + 2 > p.ev.size()) {
+        const size_t old = p.ev.size();
+        p.ev.resize(old + 512);
+        for (size_t i = old; i < p.ev.size(); ++i) hipEventCreate(&p.ev[i]);
+    }
+    hipEventRecord(p.ev[p.used], s);
+    p.flops += flops;
+    p.bytes += bytes;
+    p.launches += 1;
+}
+void rs_prof_end(rs_ctx* ctx, int klass, hipStream_t s) {
+    if (!(ctx->prof_mask & klass)) return;
+    rs_prof_slot& p = ctx->prof[rs_prof_class_index(klass)];
+    hipEventRecord(p.ev[p.used + 1], s);
+    p.used += 2;
+}
+
+extern "C" {
+
+int rs_abi_version(void) { return RS_ABI_VERSION; }
+
+int rs_create(rs_ctx** out, int device, const rs_dims* dims) {
+    if (!out || !dims) return RS_EINVAL;
+    *out = nullptr;
+    rs_ctx* ctx = new (std::nothrow) rs_ctx();
+    if (!ctx) return RS_EINVAL;
+    ctx->device = device;
+    ctx->d = *dims;
+    const rs_dims& d = ctx->d;
+    int rc = RS_OK;
+    if (d.n_heads <= 0 || d.d_model % d.n_heads || d.d_model / d.n_heads != 128)
+        rc = rs_fail(ctx, RS_EINVAL, "head_dim must be 128 (d_model %d, heads %d)", d.d_model, d.n_heads);
+    else if (d.d_model % 256 || d.ff_dim % 64) rc = rs_fail(ctx, RS_EINVAL, "d_model %% 256, ff_dim %% 64 required");
+    else if (d.sub_stages < 2 || d.sub_stages > 4) rc = rs_fail(ctx, RS_EINVAL, "2..4 subsampling stages supported");
+    else if (d.n_layers < 1) rc = rs_fail(ctx, RS_EINVAL, "n_layers");
+    else if (d.pred_layers < 1 || d.pred_layers > 4) rc = rs_fail(ctx, RS_EINVAL, "pred_layers");
+    if (rc != RS_OK) { *out = ctx; return rc; }  // caller can read rs_last_error, then rs_destroy
+    ctx->head_dim = 128;
+    int f = d.n_mels;
+    for (int s = 0; s < d.sub_stages; ++s) f = (f + 2 - 3) / 2 + 1;
+    ctx->sub_freq = f;
+    if (hipSetDevice(device) != hipSuccess) { *out = ctx; return rs_fail(ctx, RS_EHIP, "hipSetDevice(%d) failed", device); }
+    *out = ctx;
+    return RS_OK;
+}
+
+void rs_destroy(rs_ctx* ctx) {
+    if (!ctx) return;
+    for (auto& p : ctx->prof)
+        for (auto e : p.ev) hipEventDestroy(e);
+    delete ctx;
+}
+
+const char* rs_last_error(const rs_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rs_set_tensor(rs_ctx* ctx, const char* name, const void* dev_ptr, size_t nbytes) {
+    if (!ctx || !name || !dev_ptr) return RS_EINVAL;
+    ctx->tensors[name] = {dev_ptr, nbytes};
+    ctx->finalized = false;
+    return RS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Resolver {
+    rs_ctx* ctx;
+    int rc = RS_OK;
+    template <typename T>
+    void get(const std::string& name, size_t elems, const T*& out) {
+        if (rc != RS_OK) return;
+        auto it = ctx->tensors.find(name);
+        if (it == ctx->tensors.end()) { rc = rs_fail(ctx, RS_EMISSING, "weight tensor '%s' was not registered", name.c_str()); return; }
+        if (it->second.second != elems * sizeof(T)) {
+            rc = rs_fail(ctx, RS_EINVAL, "tensor '%s': expected %zu bytes, got %zu", name.c_str(), elems * sizeof(T),
+                         it->second.second);
+            return;
+        }
+        if ((uintptr_t)it->second.first & 15) { rc = rs_fail(ctx, RS_EINVAL, "tensor '%s' is not 16-byte aligned", name.c_str()); return; }
+        out = reinterpret_cast<const T*>(it->second.first);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rs_finalize(rs_ctx* ctx) {
+    if (!ctx) return RS_EINVAL;
+    const rs_dims& d = ctx->d;
+    Resolver r{ctx};
+    const size_t C = d.sub_channels, dm = d.d_model, ff = d.ff_dim, H = d.pred_hidden, J = d.joint_hidden, V = d.n_logits;
+    r.get("fe.window", (size_t)d.win_length, ctx->fe_window);
+    r.get("fe.twiddle", (size_t)512, ctx->fe_twiddle);
+    r.get("fe.fb_idx", (size_t)d.n_mels * 2, ctx->fe_fb_idx);
+    r.get("fe.fb_w", (size_t)d.n_mels * 32, ctx->fe_fb_w);
+    r.get("sub.conv0.w", 9 * C, ctx->sub_conv0_w);
+    r.get("sub.conv0.b", C, ctx->sub_conv0_b);
+    for (int s = 1; s < d.sub_stages; ++s) {
+        const std::string p = "sub.dw" + std::to_string(s), q = "sub.pw" + std::to_string(s);
+        r.get(p + ".w", 9 * C, ctx->sub_dw_w[s - 1]);
+        r.get(p + ".b", C, ctx->sub_dw_b[s - 1]);
+        r.get(q + ".w", C * C, ctx->sub_pw_w[s - 1]);
+        r.get(q + ".b", C, ctx->sub_pw_b[s - 1]);
+    }
+    r.get("sub.out.w", dm * C * ctx->sub_freq, ctx->sub_out_w);
+    r.get("sub.out.b", dm, ctx->sub_out_b);
+    ctx->layers.assign(d.n_layers, rs_layer_w{});
+    for (int i = 0; i < d.n_layers; ++i) {
+        rs_layer_w& L = ctx->layers[i];
+        const std::string p = "L" + std::to_string(i) + ".";
+        r.get(p + "ln_ff1.g", dm, L.ln_ff1_g); r.get(p + "ln_ff1.b", dm, L.ln_ff1_b);
+        r.get(p + "ff1.w1", ff * dm, L.ff1_w1); r.get(p + "ff1.b1", ff, L.ff1_b1);
+        r.get(p + "ff1.w2", dm * ff, L.ff1_w2); r.get(p + "ff1.b2", dm, L.ff1_b2);
+        r.get(p + "ln_att.g", dm, L.ln_att_g); r.get(p + "ln_att.b", dm, L.ln_att_b);
+        r.get(p + "att.qkv.w", 3 * dm * dm, L.qkv_w); r.get(p + "att.qkv.b", 3 * dm, L.qkv_b);
+        r.get(p + "att.out.w", dm * dm, L.out_w); r.get(p + "att.out.b", dm, L.out_b);
+        r.get(p + "att.pos.w", dm * dm, L.pos_w);
+        r.get(p + "att.bias_u", dm, L.bias_u); r.get(p + "att.bias_v", dm, L.bias_v);
+        r.get(p + "ln_conv.g", dm, L.ln_conv_g); r.get(p + "ln_conv.b", dm, L.ln_conv_b);
+        r.get(p + "conv.pw1.w", 2 * dm * dm, L.pw1_w); r.get(p + "conv.pw1.b", 2 * dm, L.pw1_b);
+        r.get(p + "conv.dw.w", (size_t)d.conv_kernel * dm, L.dw_w); r.get(p + "conv.dw.b", dm, L.dw_b);
+        r.get(p + "conv.pw2.w", dm * dm, L.pw2_w); r.get(p + "conv.pw2.b", dm, L.pw2_b);
+        r.get(p + "ln_ff2.g", dm, L.ln_ff2_g); r.get(p + "ln_ff2.b", dm, L.ln_ff2_b);
+        r.get(p + "ff2.w1", ff * dm, L.ff2_w1); r.get(p + "ff2.b1", ff, L.ff2_b1);
+        r.get(p + "ff2.w2", dm * ff, L.ff2_w2); r.get(p + "ff2.b2", dm, L.ff2_b2);
+        r.get(p + "ln_out.g", dm, L.ln_out_g); r.get(p + "ln_out.b", dm, L.ln_out_b);
+    }
+    r.get("joint.enc.w", J * dm, ctx->jenc_w); r.get("joint.enc.b", J, ctx->jenc_b);
+    r.get("pred.embed", V * H, ctx->embed);
+    for (int l = 0; l < d.pred_layers; ++l) {
+        const std::string p = "pred.lstm" + std::to_string(l);
+        r.get(p + ".w", 4 * H * 2 * H, ctx->lstm_w[l]);
+        r.get(p + ".b", 4 * H, ctx->lstm_b[l]);
+    }
+    r.get("joint.pred.w", J * H, ctx->jpred_w); r.get("joint.pred.b", J, ctx->jpred_b);
+    r.get("joint.out.w", V * J, ctx->jout_w); r.get("joint.out.b", V, ctx->jout_b);
+    if (r.rc != RS_OK) return r.rc;
+    auto it = ctx->tensors.find("pos.table");
+    if (it == ctx->tensors.end()) return rs_fail(ctx, RS_EMISSING, "weight tensor 'pos.table' was not registered");
+    const size_t rowb = dm * sizeof(uint16_t);
+    if (it->second.second % rowb || !((it->second.second / rowb) & 1))
+        return rs_fail(ctx, RS_EINVAL, "pos.table must be bf16 [2*Tcap-1][d_model]");
+    ctx->finalized = true;
+    return RS_OK;
+}
+
+int rs_mel_frames(const rs_ctx* ctx, int n_samples) { return n_samples / ctx->d.hop_length; }
+
+int rs_enc_frames(const rs_ctx* ctx, int n) {
+    for (int s = 0; s < ctx->d.sub_stages; ++s) n = n > 0 ? (n + 2 - 3) / 2 + 1 : 0;
+    return n;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct EncPlan {
+    int T[5], F[5];  // per stage time / freq extents (index 0 = mel)
+    size_t off_lens, off_sa, off_sb, off_x, off_hn, off_big, off_ctx, off_posp, total;
+};
+
+EncPlan plan_encoder(const rs_ctx* ctx, int B, int t_max) {
+    const rs_dims& d = ctx->d;
+    EncPlan p{};
+    p.T[0] = t_max; p.F[0] = d.n_mels;
+    for (int s = 1; s <= d.sub_stages; ++s) { p.T[s] = (p.T[s - 1] + 2 - 3) / 2 + 1; p.F[s] = (p.F[s - 1] + 2 - 3) / 2 + 1; }
+    const size_t C = d.sub_channels, dm = d.d_model;
+    const size_t Tp = p.T[d.sub_stages], M = (size_t)B * Tp;
+    size_t widest = (size_t)d.ff_dim;
+    if (3 * dm > widest) widest = 3 * dm;
+    size_t o = 0;
+    p.off_lens = o; o += rs_align((size_t)4 * B * 4);
+    const size_t sub_elems = (size_t)B * p.T[2] * p.F[2] * C;  // stage-2 extent is the largest stored one
+    p.off_sa = o; o += rs_align(sub_elems * 2);
+    p.off_sb = o; o += rs_align(sub_elems * 2);
+    p.off_x = o; o += rs_align(M * dm * 4);
+    p.off_hn = o; o += rs_align(M * dm * 2);
+    p.off_big = o; o += rs_align(M * widest * 2);
+    p.off_ctx = o; o += rs_align(M * dm * 2);
+    p.off_posp = o; o += rs_align((2 * Tp) * dm * 2);
+    p.total = o + 256;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rs_workspace_bytes(const rs_ctx* ctx, int B, int max_samples) {
+    if (!ctx || B <= 0 || max_samples < 0) return 0;
+    const int t_max = rs_mel_frames(ctx, max_samples);
+    const size_t fe = rs_align((size_t)B * (t_max > 0 ? t_max : 1) * ctx->d.n_mels * 4) + 256;
+    const size_t enc = plan_encoder(ctx, B, t_max > 0 ? t_max : 1).total;
+    const size_t dec = rs_rnnt_workspace_bytes(ctx, B);
+    size_t m = fe > enc ? fe : enc;
+    return m > dec ? m : dec;
+}
+
+int rs_frontend_logmel(rs_ctx* ctx, const float* audio, const int32_t* lens, int B, int audio_stride,
+                       int pad_left, int pad_right, int t_max, float* feats, int32_t* n_frames, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_frontend_logmel");
+    if (B < 0 || t_max < 0 || pad_left < 0 || pad_right < 0) return rs_fail(ctx, RS_EINVAL, "frontend: negative size");
+    if (B == 0 || t_max == 0) return RS_OK;
+    if (!audio || !lens || !feats || !n_frames || !workspace) return rs_fail(ctx, RS_EINVAL, "frontend: null pointer");
+    const size_t need = (size_t)B * t_max * ctx->d.n_mels * 4;
+    if (workspace_bytes < need) return rs_fail(ctx, RS_EWORKSPACE, "frontend: workspace %zu < %zu", workspace_bytes, need);
+    return rs_launch_frontend(ctx, audio, lens, B, audio_stride, pad_left, pad_right, t_max, feats, n_frames,
+                              reinterpret_cast<float*>(workspace), (hipStream_t)stream);
+}
+
+int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames, int B, int t_max, float* enc_out,
+                       float* joint_enc, int32_t* enc_lens, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_encoder_forward");
+    if (B <= 0 || t_max <= 0) return B < 0 || t_max < 0 ? rs_fail(ctx, RS_EINVAL, "encoder: negative size") : RS_OK;
+    if (!feats || !n_frames || !joint_enc || !enc_lens || !workspace) return rs_fail(ctx, RS_EINVAL, "encoder: null pointer");
+    const rs_dims& d = ctx->d;
+    hipStream_t s = (hipStream_t)stream;
+    const EncPlan pl = plan_encoder(ctx, B, t_max);
+    if (workspace_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "encoder: workspace %zu < %zu", workspace_bytes, pl.total);
+    char* ws = reinterpret_cast<char*>(workspace);
+    int32_t* lens_stage = reinterpret_cast<int32_t*>(ws + pl.off_lens);
+    uint16_t* sa = reinterpret_cast<uint16_t*>(ws + pl.off_sa);
+    uint16_t* sb = reinterpret_cast<uint16_t*>(ws + pl.off_sb);
+    float* x = reinterpret_cast<float*>(ws + pl.off_x);
+    uint16_t* hn = reinterpret_cast<uint16_t*>(ws + pl.off_hn);
+    uint16_t* big = reinterpret_cast<uint16_t*>(ws + pl.off_big);
+    uint16_t* ctxb = reinterpret_cast<uint16_t*>(ws + pl.off_ctx);
+    uint16_t* posp = reinterpret_cast<uint16_t*>(ws + pl.off_posp);
+    const int C = d.sub_channels, dm = d.d_model, ff = d.ff_dim, S = d.sub_stages;
+    const int Tp = pl.T[S], M = B * Tp;
+    int rc;
+#define RS_TRY(call) do { rc = (call); if (rc != RS_OK) return rc; } while (0)
+
+    // ---- subsampling -------------------------------------------------------------------------
+    RS_TRY(rs_launch_enc_lens(ctx, n_frames, B, lens_stage, s));
+    RS_TRY(rs_launch_sub_conv0_dw1(ctx, feats, lens_stage, B, t_max, pl.T[2], pl.F[2], sa, s));
+    for (int st = 2; st <= S; ++st) {
+        if (st > 2)
+            RS_TRY(rs_launch_sub_dw(ctx, sb, ctx->sub_dw_w[st - 2], ctx->sub_dw_b[st - 2], lens_stage + (st - 1) * B, st, B,
+                                    pl.T[st - 1], pl.F[st - 1], pl.T[st], pl.F[st], sa, s));
+        rs_gemm_args g{};
+        g.A = sa; g.lda = C; g.W = ctx->sub_pw_w[st - 2]; g.ldw = C; g.out = sb; g.ldc = C;
+        g.M = B * pl.T[st] * pl.F[st]; g.N = C; g.K = C;
+        g.flags = RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_ROWMASK; g.bias = ctx->sub_pw_b[st - 2]; g.alpha = 1.0f;
+        g.mask_lens = lens_stage + (st - 1) * B; g.mask_rows_per_step = pl.F[st]; g.mask_steps = pl.T[st];
+        RS_TRY(rs_launch_gemm(ctx, g, s));
+    }
+    {
+        rs_gemm_args g{};
+        const int K = C * pl.F[S];
+        g.A = sb; g.lda = K; g.W = ctx->sub_out_w; g.ldw = K; g.out = x; g.ldc = dm; g.M = M; g.N = dm; g.K = K;
+        g.flags = RS_GEMM_BIAS | RS_GEMM_OUT_F32; g.bias = ctx->sub_out_b;
+        g.alpha = d.xscaling ? sqrtf((float)dm) : 1.0f;
+        RS_TRY(rs_launch_gemm(ctx, g, s));
+    }
+    const int32_t* lens = lens_stage + (S - 1) * B;
+    RS_HIP(ctx, hipMemcpyAsync(enc_lens, lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+
+    // ---- position table slice for this T ---------------------------------------------------------
+    const auto& pt = ctx->tensors.at("pos.table");
+    const int tcap = (int)((pt.second / ((size_t)dm * 2) + 1) / 2);
+    if (Tp > tcap) return rs_fail(ctx, RS_EINVAL, "encoder: T'=%d exceeds the registered pos.table capacity %d", Tp, tcap);
+    const uint16_t* pos_slice = reinterpret_cast<const uint16_t*>(pt.first) + (size_t)(tcap - Tp) * dm;
+    const int npos = 2 * Tp - 1;
+
+    auto gemm = [&](const uint16_t* A, int lda, const uint16_t* W, int K, void* out, int ldc, int Mr, int N, int flags,
+                    const float* bias, float alpha, const float* res) -> int {
+        rs_gemm_args g{};
+        g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.out = out; g.ldc = ldc; g.M = Mr; g.N = N; g.K = K;
+        g.flags = flags; g.bias = bias; g.alpha = alpha; g.residual = res;
+        return rs_launch_gemm(ctx, g, s);
+    };
+    const int RES = RS_GEMM_BIAS | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32;
+
+    for (int i = 0; i < d.n_layers; ++i) {
+        const rs_layer_w& L = ctx->layers[i];
+        const bool last = i == d.n_layers - 1;
+        // 1/2 FFN
+        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_ff1_g, L.ln_ff1_b, M, dm, d.ln_eps, hn, nullptr, s));
+        RS_TRY(gemm(hn, dm, L.ff1_w1, dm, big, ff, M, ff, RS_GEMM_BIAS | RS_GEMM_SILU, L.ff1_b1, 1.0f, nullptr));
+        RS_TRY(gemm(big, ff, L.ff1_w2, ff, x, dm, M, dm, RES, L.ff1_b2, 0.5f, x));
+        // rel-pos MHSA
+        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_att_g, L.ln_att_b, M, dm, d.ln_eps, hn, nullptr, s));
+        RS_TRY(gemm(hn, dm, L.qkv_w, dm, big, 3 * dm, M, 3 * dm, RS_GEMM_BIAS, L.qkv_b, 1.0f, nullptr));
+        RS_TRY(gemm(pos_slice, dm, L.pos_w, dm, posp, dm, npos, dm, 0, nullptr, 1.0f, nullptr));
+        RS_TRY(rs_launch_attention(ctx, big, posp, L.bias_u, L.bias_v, lens, B, Tp, ctxb, s));
+        RS_TRY(gemm(ctxb, dm, L.out_w, dm, x, dm, M, dm, RES, L.out_b, 1.0f, x));
+        // conv module
+        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_conv_g, L.ln_conv_b, M, dm, d.ln_eps, hn, nullptr, s));
+        RS_TRY(gemm(hn, dm, L.pw1_w, dm, big, 2 * dm, M, 2 * dm, RS_GEMM_BIAS, L.pw1_b, 1.0f, nullptr));
+        RS_TRY(rs_launch_glu_dwconv(ctx, big, L.dw_w, L.dw_b, lens, B, Tp, dm, d.conv_kernel, ctxb, s));
+        RS_TRY(gemm(ctxb, dm, L.pw2_w, dm, x, dm, M, dm, RES, L.pw2_b, 1.0f, x));
+        // 1/2 FFN
+        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_ff2_g, L.ln_ff2_b, M, dm, d.ln_eps, hn, nullptr, s));
+        RS_TRY(gemm(hn, dm, L.ff2_w1, dm, big, ff, M, ff, RS_GEMM_BIAS | RS_GEMM_SILU, L.ff2_b1, 1.0f, nullptr));
+        RS_TRY(gemm(big, ff, L.ff2_w2, ff, x, dm, M, dm, RES, L.ff2_b2, 0.5f, x));
+        // output norm (in place on the residual stream; the last layer also emits the bf16 copy
+        // that feeds the joint's encoder projection)
+        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_out_g, L.ln_out_b, M, dm, d.ln_eps, last ? hn : nullptr, x, s));
+    }
+    if (enc_out) RS_HIP(ctx, hipMemcpyAsync(enc_out, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
+    RS_TRY(gemm(hn, dm, ctx->jenc_w, dm, joint_enc, d.joint_hidden, M, d.joint_hidden, RS_GEMM_BIAS | RS_GEMM_OUT_F32,
+                ctx->jenc_b, 1.0f, nullptr));
+#undef RS_TRY
+    return RS_OK;
+}
+
+int rs_rnnt_greedy(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int u_max,
+                   int32_t* ids, int32_t* frames, int32_t* n_ids, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_rnnt_greedy");
+    if (B < 0 || tp_max < 0 || u_max < 0) return rs_fail(ctx, RS_EINVAL, "rnnt: negative size");
+    if (B == 0) return RS_OK;
+    if (!joint_enc || !enc_lens || !ids || !frames || !n_ids || !workspace) return rs_fail(ctx, RS_EINVAL, "rnnt: null pointer");
+    if (tp_max == 0) { RS_HIP(ctx, hipMemsetAsync(n_ids, 0, (size_t)B * 4, (hipStream_t)stream)); return RS_OK; }
+    return rs_rnnt_greedy_impl(ctx, joint_enc, enc_lens, B, tp_max, u_max, ids, frames, n_ids, workspace,
+                               workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- profiling -------------------------------------------------------------------------------------
+int rs_profile_enable(rs_ctx* ctx, int class_mask) {
+    if (!ctx) return RS_EINVAL;
+    ctx->prof_mask = class_mask;
+    return RS_OK;
+}
+int rs_profile_reset(rs_ctx* ctx) {
+    if (!ctx) return RS_EINVAL;
+    for (auto& p : ctx->prof) { p.used = 0; p.flops = p.bytes = p.ms_acc = 0; p.launches = 0; }
+    return RS_OK;
+}
+int rs_profile_read(rs_ctx* ctx, int klass, double* ms, int64_t* launches, double* flops, double* bytes) {
+    if (!ctx || klass <= 0) return RS_EINVAL;
+    rs_prof_slot& p = ctx->prof[rs_prof_class_index(klass)];
+    double total = p.ms_acc;
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        RS_HIP(ctx, hipEventSynchronize(p.ev[i + 1]));
+        float t = 0;
+        RS_HIP(ctx, hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]));
+        total += t;
+    }
+    p.ms_acc = total;
+    p.used = 0;
+    if (ms) *ms = total;
+    if (launches) *launches = p.launches;
+    if (flops) *flops = p.flops;
+    if (bytes) *bytes = p.bytes;
+    return RS_OK;
+}
+
+// ---- single-operator entry points --------------------------------------------------------------------
+int rs_gemm_bf16(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int ldw, void* out, int ldc, int M, int N,
+                 int K, int flags, const float* bias, float alpha, const float* residual, const int32_t* mask_lens,
+                 int mask_rows_per_step, int mask_steps, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (M == 0 || N == 0) return RS_OK;
+    if (!A || !W || !out) return rs_fail(ctx, RS_EINVAL, "gemm: null pointer");
+    rs_gemm_args g{A, lda, W, ldw, out, ldc, M, N, K, flags, bias, alpha, residual, mask_lens, mask_rows_per_step, mask_steps};
+    return rs_launch_gemm(ctx, g, (hipStream_t)stream);
+}
+
+int rs_layernorm(rs_ctx* ctx, const float* x, const float* gamma, const float* beta, int M, int d, float eps,
+                 uint16_t* out_bf16, float* out_f32, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (!x || !gamma || !beta) return rs_fail(ctx, RS_EINVAL, "layernorm: null pointer");
+    return rs_launch_layernorm(ctx, x, gamma, beta, M, d, eps, out_bf16, out_f32, (hipStream_t)stream);
+}
+
+int rs_relpos_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, const float* bias_u, const float* bias_v,
+                        const int32_t* lens, int B, int T, uint16_t* ctx_out, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (!qkv || !pos || !bias_u || !bias_v || !lens || !ctx_out) return rs_fail(ctx, RS_EINVAL, "attention: null pointer");
+    return rs_launch_attention(ctx, qkv, pos, bias_u, bias_v, lens, B, T, ctx_out, (hipStream_t)stream);
+}
+
+int rs_glu_dwconv_silu(rs_ctx* ctx, const uint16_t* x, const float* dw_w, const float* dw_b, const int32_t* lens, int B,
+                       int T, int d, int k, uint16_t* out, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (!x || !dw_w || !dw_b || !lens || !out) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: null pointer");
+    return rs_launch_glu_dwconv(ctx, x, dw_w, dw_b, lens, B, T, d, k, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// rs_common.h — internal declarations shared by the HIP translation units of librs_asr.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/rs_asr.h"
+
+// ----------------------------------------------------------------------------------------
+// device helpers
+// ----------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short v) {
+    return __uint_as_float(((unsigned)v) << 16);
+}
+// round-to-nearest-even, NaN preserved as quiet NaN (same as torch .to(bfloat16))
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ----------------------------------------------------------------------------------------
+// host side: context
+// ----------------------------------------------------------------------------------------
+struct rs_prof_slot {
+    std::vector<hipEvent_t> ev;  // pairs (start, stop)
+    size_t used = 0;
+    double flops = 0, bytes = 0;
+    double ms_acc = 0;
+    int64_t launches = 0;
+};
+
+struct rs_layer_w {
+    const float *ln_ff1_g, *ln_ff1_b, *ln_att_g, *ln_att_b, *ln_conv_g, *ln_conv_b, *ln_ff2_g, *ln_ff2_b,
+        *ln_out_g, *ln_out_b;
+    const uint16_t *ff1_w1, *ff1_w2, *ff2_w1, *ff2_w2, *qkv_w, *out_w, *pos_w, *pw1_w, *pw2_w;
+    const float *ff1_b1, *ff1_b2, *ff2_b1, *ff2_b2, *qkv_b, *out_b, *bias_u, *bias_v, *pw1_b, *pw2_b;
+    const float *dw_w, *dw_b;
+};
+
+struct rs_ctx {
+    int device = 0;
+    rs_dims d{};
+    int head_dim = 0, sub_freq = 0;
+    bool finalized = false;
+    std::string err;
+    std::unordered_map<std::string, std::pair<const void*, size_t>> tensors;
+    // resolved weights
+    const float *fe_window = nullptr, *fe_fb_w = nullptr, *fe_twiddle = nullptr;
+    const int32_t* fe_fb_idx = nullptr;
+    const float *sub_conv0_w = nullptr, *sub_conv0_b = nullptr;
+    const float *sub_dw_w[4] = {}, *sub_dw_b[4] = {};
+    const uint16_t* sub_pw_w[4] = {};
+    const float* sub_pw_b[4] = {};
+    const uint16_t* sub_out_w = nullptr;
+    const float* sub_out_b = nullptr;
+    std::vector<rs_layer_w> layers;
+    const uint16_t* jenc_w = nullptr;
+    const float* jenc_b = nullptr;
+    const float *embed = nullptr, *lstm_w[8] = {}, *lstm_b[8] = {}, *jpred_w = nullptr, *jpred_b = nullptr,
+                *jout_w = nullptr, *jout_b = nullptr;
+    // position table cache: the caller registers "pos_table.<T>" tensors (bf16 [2T-1][d])
+    // profiling
+    int prof_mask = 0;
+    rs_prof_slot prof[8];
+};
+
+int rs_fail(rs_ctx* ctx, int code, const char* fmt, ...);
+
+#define RS_HIP(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t _e = (call);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return rs_fail((ctx), RS_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, \
+                           hipGetErrorString(_e));                                     \
+    } while (0)
+
+#define RS_CHECK_LAUNCH(ctx, what)                                                            \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess)                                                                 \
+            return rs_fail((ctx), RS_EHIP, "launch %s failed: %s", (what), hipGetErrorString(_e)); \
+    } while (0)
+
+// RAII-ish profiling bracket around kernel launches of one class
+int rs_prof_class_index(int klass);
+void rs_prof_begin(rs_ctx* ctx, int klass, hipStream_t s, double flops, double bytes);
+void rs_prof_end(rs_ctx* ctx, int klass, hipStream_t s);
+
+static inline size_t rs_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ----------------------------------------------------------------------------------------
+// kernel launchers (one per .hip file); all return RS_OK / RS_E*
+// ----------------------------------------------------------------------------------------
+struct rs_gemm_args {
+    const uint16_t* A; int lda;
+    const uint16_t* W; int ldw;
+    void* out; int ldc;
+    int M, N, K, flags;
+    const float* bias; float alpha;
+    const float* residual;
+    const int32_t* mask_lens; int mask_rows_per_step; int mask_steps;
+};
+int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s);
+int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float* b, int M, int d, float eps,
+                        uint16_t* out_bf16, float* out_f32, hipStream_t s);
+int rs_launch_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, const float* bias_u,
+                        const float* bias_v, const int32_t* lens, int B, int T, uint16_t* out, hipStream_t s);
+int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, const float* w, const float* b, const int32_t* lens,
+                         int B, int T, int d, int k, uint16_t* out, hipStream_t s);
+int rs_launch_frontend(rs_ctx* ctx, const float* audio, const int32_t* lens, int B, int audio_stride,
+                       int pad_left, int pad_right, int t_max, float* feats, int32_t* n_frames, float* raw,
+                       hipStream_t s);
+int rs_launch_sub_conv0_dw1(rs_ctx* ctx, const float* feats, const int32_t* lens_stage, int B, int t_max, int T2,
+                            int F2, uint16_t* out, hipStream_t s);
+int rs_launch_sub_dw(rs_ctx* ctx, const uint16_t* in, const float* w, const float* b, const int32_t* lens_out,
+                     int stage, int B, int t_in, int f_in, int t_out, int f_out, uint16_t* out, hipStream_t s);
+int rs_launch_enc_lens(rs_ctx* ctx, const int32_t* n_frames, int B, int32_t* lens_out, hipStream_t s);

@@ -1,0 +1,100 @@
+"""`load_model()` / `transcribe()` — the drop-in pair (pkg/nemo-asr/src/transcribe.py:9-60),
+plus the additive batched entry point `transcribe_batch()` the RTFx metric is quoted on.
+
+What changes underneath: NeMo's `EncDecRNNTBPEModel` is replaced by
+`reazonspeech_amd.runtime.model.AsrModel` (HIP kernels behind include/rs_asr.h); padding is
+folded into the front-end kernel instead of `np.pad`; decoding is batched greedy, adapted to
+the ALSD-shaped `Hypothesis` the reference post-processor expects (interface.Hypothesis).
+"""
+import os
+
+import torch
+
+from .interface import TranscribeConfig, Hypothesis
+from .decode import decode_hypothesis, PAD_SECONDS
+from .audio import norm_audio
+
+#: where a real checkpoint is looked for; the reference downloads
+#: 'reazon-research/reazonspeech-nemo-v2' from the HF hub (transcribe.py:26-28), which an
+#: offline box cannot do.
+CHECKPOINT_ENV = "REAZONSPEECH_NEMO_CHECKPOINT"
+
+
+def load_model(device=None, checkpoint=None, config=None, seed=0):
+    """Load the ReazonSpeech FastConformer-RNNT model onto a ROCm GPU.
+
+    Args:
+      device (str): "cuda" / "cuda:N" (ROCm devices report as cuda).  None picks "cuda" when
+        available, like the reference (transcribe.py:18-22); there is no CPU execution path
+        in this package, so "cpu" raises.
+      checkpoint (str): path of a `.nemo` archive.  Defaults to $REAZONSPEECH_NEMO_CHECKPOINT.
+        Without one, seeded synthetic weights of the 619M architecture are generated
+        (benchmarks / tests; transcripts are then meaningless).
+      config (ModelConfig): override the architecture for synthetic weights.
+      seed (int): seed of the synthetic weights.
+
+    Returns:
+      reazonspeech_amd.runtime.model.AsrModel
+    """
+    from ...runtime.config import FASTCONFORMER_619M
+    from ...runtime.model import AsrModel
+    from ...runtime.tokenizer import SentencePieceTokenizer, SyntheticTokenizer
+    from ...runtime import weights as W
+
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    if str(device).startswith("cpu"):
+        raise RuntimeError("reazonspeech_amd runs on MI355X (gfx950) only; no CPU path exists "
+                           "(use the reference package for CPU inference)")
+    checkpoint = checkpoint or os.environ.get(CHECKPOINT_ENV)
+    if checkpoint:
+        cfg, sd, tok_bytes = W.read_nemo(checkpoint)
+        tokenizer = SentencePieceTokenizer(tok_bytes) if tok_bytes else SyntheticTokenizer(cfg.vocab_size)
+    else:
+        cfg = config or FASTCONFORMER_619M
+        sd = W.synthetic_state_dict(cfg, seed)
+        tokenizer = SyntheticTokenizer(cfg.vocab_size, seed)
+    return AsrModel(cfg, sd, tokenizer, device=device, pad_seconds=PAD_SECONDS)
+
+
+def _prepare(audio):
+    """16 kHz mono float32 waveform (transcribe.py:44 minus the padding, which the kernel applies)"""
+    import numpy as np
+    return np.ascontiguousarray(norm_audio(audio).waveform, dtype=np.float32)
+
+
+def transcribe_batch(model, audios, config=None):
+    """Transcribe a list of AudioData in one batched pass.
+
+    Each utterance is processed exactly as `transcribe()` would process it alone
+    (per-utterance padding, masking and normalisation inside the kernels).
+
+    Returns:
+      list[TranscribeResult]
+    """
+    if config is None:
+        config = TranscribeConfig()
+    waves = [_prepare(a) for a in audios]
+    decoded = model.transcribe_waveforms(waves)
+    results = []
+    for ids, frames in zip(decoded.ids, decoded.frames):
+        hyp = Hypothesis.from_greedy(ids, frames, model.cfg.blank_id)
+        ret = decode_hypothesis(model, hyp)
+        if config.raw_hypothesis:
+            ret.hypothesis = hyp
+        results.append(ret)
+    return results
+
+
+def transcribe(model, audio, config=None):
+    """Inference of one utterance (transcribe.py:30-60).
+
+    Args:
+        model: what `load_model()` returned
+        audio (AudioData): audio to transcribe
+        config (TranscribeConfig): additional settings
+
+    Returns:
+        TranscribeResult
+    """
+    return transcribe_batch(model, [audio], config)[0]

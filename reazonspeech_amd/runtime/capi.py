@@ -1,0 +1,212 @@
+"""ctypes binding of librs_asr.so (include/rs_asr.h).
+
+There is exactly one backend: if the shared library is missing or fails to load this module
+raises — there is no CPU or PyTorch fallback (the CPU oracle under /oracle is test
+infrastructure and is never imported from here).
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_void_p)
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "librs_asr.so")
+
+RS_OK = 0
+RS_EOVERFLOW = -5
+ERRORS = {-1: "RS_EINVAL", -2: "RS_EMISSING", -3: "RS_EWORKSPACE", -4: "RS_EHIP", -5: "RS_EOVERFLOW",
+          -6: "RS_ESTATE"}
+
+GEMM_BIAS, GEMM_RELU, GEMM_SILU, GEMM_RESIDUAL, GEMM_OUT_F32, GEMM_ROWMASK = 1, 2, 4, 8, 16, 32
+PROF_GEMM, PROF_ATTN, PROF_FRONTEND, PROF_DECODE, PROF_ELEMENTWISE, PROF_SUBSAMPLE = 1, 2, 4, 8, 16, 32
+
+# every symbol include/rs_asr.h declares (tests/test_capi_exports.py checks the .so exports them)
+EXPORTS = [
+    "rs_abi_version", "rs_create", "rs_destroy", "rs_last_error", "rs_set_tensor", "rs_finalize",
+    "rs_workspace_bytes", "rs_mel_frames", "rs_enc_frames", "rs_frontend_logmel", "rs_encoder_forward",
+    "rs_rnnt_greedy", "rs_profile_enable", "rs_profile_read", "rs_profile_reset", "rs_gemm_bf16",
+    "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu",
+]
+
+
+class RsDims(Structure):
+    """mirror of `struct rs_dims`"""
+    _fields_ = [
+        ("n_mels", c_int32), ("n_fft", c_int32), ("win_length", c_int32), ("hop_length", c_int32),
+        ("preemph", c_float), ("log_guard", c_float), ("norm_eps", c_float),
+        ("d_model", c_int32), ("n_heads", c_int32), ("ff_dim", c_int32), ("n_layers", c_int32),
+        ("conv_kernel", c_int32), ("sub_channels", c_int32), ("sub_stages", c_int32), ("xscaling", c_int32),
+        ("ln_eps", c_float), ("att_left", c_int32), ("att_right", c_int32), ("n_global", c_int32),
+        ("n_logits", c_int32), ("blank_id", c_int32), ("pred_hidden", c_int32), ("pred_layers", c_int32),
+        ("joint_hidden", c_int32), ("max_symbols", c_int32),
+    ]
+
+    @classmethod
+    def from_config(cls, cfg):
+        return cls(cfg.n_mels, cfg.n_fft, cfg.win_length, cfg.hop_length, cfg.preemph, cfg.log_guard,
+                   cfg.norm_eps, cfg.d_model, cfg.n_heads, cfg.ff_dim, cfg.n_layers, cfg.conv_kernel,
+                   cfg.sub_channels, cfg.n_sub_stages, int(cfg.xscaling), cfg.ln_eps, cfg.att_left,
+                   cfg.att_right, cfg.n_global, cfg.n_logits, cfg.blank_id, cfg.pred_hidden, cfg.pred_layers,
+                   cfg.joint_hidden, cfg.max_symbols)
+
+
+class RsError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{ERRORS.get(code, code)}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load librs_asr.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} not found — build it with `python -m reazonspeech_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(_LIB_PATH)
+    vp = c_void_p
+    for name in EXPORTS:
+        getattr(lib, name).restype = c_int
+    lib.rs_create.argtypes = [POINTER(c_void_p), c_int, POINTER(RsDims)]
+    lib.rs_destroy.argtypes = [vp]
+    lib.rs_destroy.restype = None
+    lib.rs_last_error.argtypes = [vp]
+    lib.rs_last_error.restype = c_char_p
+    lib.rs_set_tensor.argtypes = [vp, c_char_p, vp, c_size_t]
+    lib.rs_finalize.argtypes = [vp]
+    lib.rs_workspace_bytes.argtypes = [vp, c_int, c_int]
+    lib.rs_workspace_bytes.restype = c_size_t
+    lib.rs_mel_frames.argtypes = [vp, c_int]
+    lib.rs_enc_frames.argtypes = [vp, c_int]
+    lib.rs_frontend_logmel.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_size_t, vp]
+    lib.rs_encoder_forward.argtypes = [vp, vp, vp, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
+    lib.rs_rnnt_greedy.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
+    lib.rs_profile_enable.argtypes = [vp, c_int]
+    lib.rs_profile_reset.argtypes = [vp]
+    lib.rs_profile_read.argtypes = [vp, c_int, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
+                                    POINTER(c_double)]
+    lib.rs_gemm_bf16.argtypes = [vp, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp,
+                                 c_float, vp, vp, c_int, c_int, vp]
+    lib.rs_layernorm.argtypes = [vp, vp, vp, vp, c_int, c_int, c_float, vp, vp, vp]
+    lib.rs_relpos_attention.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp]
+    lib.rs_glu_dwconv_silu.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
+    if lib.rs_abi_version() != 1:
+        raise ImportError("librs_asr.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    """pointer of a torch tensor (or NULL)"""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+class Context:
+    """Owns one rs_ctx.  Not thread safe; one context per stream."""
+
+    def __init__(self, cfg, device_index=0):
+        self.lib = load()
+        self.cfg = cfg
+        self._h = c_void_p()
+        self._keep = {}
+        dims = RsDims.from_config(cfg)
+        rc = self.lib.rs_create(byref(self._h), int(device_index), byref(dims))
+        if rc != RS_OK:
+            msg = self.lib.rs_last_error(self._h).decode() if self._h else "rs_create failed"
+            if self._h:
+                self.lib.rs_destroy(self._h)
+                self._h = c_void_p()
+            raise RsError(rc, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.rs_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != RS_OK:
+            raise RsError(rc, self.lib.rs_last_error(self._h).decode())
+
+    def set_tensor(self, name, tensor):
+        assert tensor.is_contiguous()
+        self._keep[name] = tensor   # the library does not own memory: keep it alive here
+        self.check(self.lib.rs_set_tensor(self._h, name.encode(), _ptr(tensor),
+                                          tensor.numel() * tensor.element_size()))
+
+    def finalize(self):
+        self.check(self.lib.rs_finalize(self._h))
+
+    def workspace_bytes(self, B, max_samples):
+        return int(self.lib.rs_workspace_bytes(self._h, int(B), int(max_samples)))
+
+    def mel_frames(self, n):
+        return int(self.lib.rs_mel_frames(self._h, int(n)))
+
+    def enc_frames(self, n):
+        return int(self.lib.rs_enc_frames(self._h, int(n)))
+
+    # ---- stages ----
+    def frontend(self, audio, lens, pad_left, pad_right, t_max, feats, n_frames, ws, stream):
+        self.check(self.lib.rs_frontend_logmel(self._h, _ptr(audio), _ptr(lens), audio.shape[0], audio.stride(0),
+                                               pad_left, pad_right, t_max, _ptr(feats), _ptr(n_frames), _ptr(ws),
+                                               ws.numel() * ws.element_size(), c_void_p(stream)))
+
+    def encoder(self, feats, n_frames, B, t_max, enc_out, joint_enc, enc_lens, ws, stream):
+        self.check(self.lib.rs_encoder_forward(self._h, _ptr(feats), _ptr(n_frames), B, t_max, _ptr(enc_out),
+                                               _ptr(joint_enc), _ptr(enc_lens), _ptr(ws),
+                                               ws.numel() * ws.element_size(), c_void_p(stream)))
+
+    def rnnt_greedy(self, joint_enc, enc_lens, B, tp_max, u_max, ids, frames, n_ids, ws, stream):
+        self.check(self.lib.rs_rnnt_greedy(self._h, _ptr(joint_enc), _ptr(enc_lens), B, tp_max, u_max, _ptr(ids),
+                                           _ptr(frames), _ptr(n_ids), _ptr(ws), ws.numel() * ws.element_size(),
+                                           c_void_p(stream)))
+
+    # ---- profiling ----
+    def profile_enable(self, mask):
+        self.check(self.lib.rs_profile_enable(self._h, int(mask)))
+
+    def profile_reset(self):
+        self.check(self.lib.rs_profile_reset(self._h))
+
+    def profile_read(self, klass):
+        ms, n, fl, by = c_double(), c_int64(), c_double(), c_double()
+        self.check(self.lib.rs_profile_read(self._h, int(klass), byref(ms), byref(n), byref(fl), byref(by)))
+        return dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+
+    # ---- single operators (used by the parity tests) ----
+    def gemm(self, A, W, out, flags=0, bias=None, alpha=1.0, residual=None, mask_lens=None, mask_rows=0,
+             mask_steps=0, stream=0):
+        M, K = A.shape
+        N = W.shape[0]
+        self.check(self.lib.rs_gemm_bf16(self._h, _ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(out),
+                                         out.stride(0), M, N, K, flags, _ptr(bias), float(alpha), _ptr(residual),
+                                         _ptr(mask_lens), mask_rows, mask_steps, c_void_p(stream)))
+
+    def layernorm(self, x, gamma, beta, eps, out_bf16=None, out_f32=None, stream=0):
+        M, d = x.shape
+        self.check(self.lib.rs_layernorm(self._h, _ptr(x), _ptr(gamma), _ptr(beta), M, d, float(eps),
+                                         _ptr(out_bf16), _ptr(out_f32), c_void_p(stream)))
+
+    def attention(self, qkv, pos, bias_u, bias_v, lens, B, T, out, stream=0):
+        self.check(self.lib.rs_relpos_attention(self._h, _ptr(qkv), _ptr(pos), _ptr(bias_u), _ptr(bias_v),
+                                                _ptr(lens), B, T, _ptr(out), c_void_p(stream)))
+
+    def glu_dwconv(self, x, w, b, lens, B, T, d, k, out, stream=0):
+        self.check(self.lib.rs_glu_dwconv_silu(self._h, _ptr(x), _ptr(w), _ptr(b), _ptr(lens), B, T, d, k,
+                                               _ptr(out), c_void_p(stream)))

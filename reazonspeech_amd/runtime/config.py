@@ -1,0 +1,167 @@
+"""Model dimensions of the FastConformer-RNNT path.
+
+The reference never states them: they live in `model_config.yaml` inside the `.nemo`
+checkpoint that `EncDecRNNTBPEModel.from_pretrained` downloads
+(pkg/nemo-asr/src/transcribe.py:26-28).  The defaults below are the FastConformer-XL
+shape that reproduces the published 619M parameters (README.rst:34-35)
+and the 0.08 s frame period (pkg/nemo-asr/src/decode.py:5).  Everything [UPSTREAM] is a
+field, not a constant, so a real checkpoint's YAML can override it (`from_nemo_yaml`).
+"""
+from dataclasses import dataclass, asdict, replace
+import math
+
+
+@dataclass(frozen=True)
+class ModelConfig:
+    # --- front-end (AudioToMelSpectrogramPreprocessor) ---
+    sample_rate: int = 16000
+    n_fft: int = 512
+    win_length: int = 400
+    hop_length: int = 160
+    n_mels: int = 80
+    preemph: float = 0.97
+    log_guard: float = 2.0 ** -24
+    norm_eps: float = 1e-5
+    # --- encoder (ConformerEncoder, dw_striding subsampling) ---
+    d_model: int = 1024
+    n_heads: int = 8
+    ff_dim: int = 4096
+    n_layers: int = 24
+    conv_kernel: int = 9
+    sub_channels: int = 256
+    sub_factor: int = 8
+    xscaling: bool = True
+    ln_eps: float = 1e-5
+    bn_eps: float = 1e-5
+    att_left: int = -1      # -1 = unlimited (full attention); SURVEY.md §8a row L5
+    att_right: int = -1
+    n_global: int = 0
+    # --- RNN-T decoder / joint ---
+    vocab_size: int = 3000  # blank id == vocab_size, logits are vocab_size + 1 wide
+    pred_hidden: int = 640
+    pred_layers: int = 2
+    joint_hidden: int = 640
+    max_symbols: int = 10
+
+    # ---- derived ----
+    @property
+    def head_dim(self) -> int:
+        return self.d_model // self.n_heads
+
+    @property
+    def blank_id(self) -> int:
+        return self.vocab_size
+
+    @property
+    def n_logits(self) -> int:
+        return self.vocab_size + 1
+
+    @property
+    def n_sub_stages(self) -> int:
+        return int(round(math.log2(self.sub_factor)))
+
+    @property
+    def sub_freq(self) -> int:
+        """mel bins left after the strided convs (80 -> 40 -> 20 -> 10)."""
+        f = self.n_mels
+        for _ in range(self.n_sub_stages):
+            f = (f + 2 - 3) // 2 + 1
+        return f
+
+    def mel_frames(self, n_samples: int) -> int:
+        """valid log-mel frames for `n_samples` samples: floor(L / hop)
+        ([UPSTREAM] FilterbankFeatures.get_seq_len with center=True)."""
+        return (n_samples + (self.n_fft // 2) * 2 - self.n_fft) // self.hop_length
+
+    def stft_frames(self, n_samples: int) -> int:
+        """frames torch.stft(center=True) produces: 1 + floor(L / hop)."""
+        return 1 + n_samples // self.hop_length
+
+    @staticmethod
+    def conv_out_len(n: int) -> int:
+        """k=3, s=2, p=1 output length."""
+        return (n + 2 - 3) // 2 + 1
+
+    def enc_frames(self, n_mel_frames: int) -> int:
+        n = n_mel_frames
+        for _ in range(self.n_sub_stages):
+            n = self.conv_out_len(n)
+        return n
+
+    def n_params(self) -> int:
+        d, f, c = self.d_model, self.ff_dim, self.sub_channels
+        sub = (c * 9 + c) + (self.n_sub_stages - 1) * ((c * 9 + c) + (c * c + c)) \
+            + (c * self.sub_freq * d + d)
+        layer = 2 * (d * f + f + f * d + d) + 4 * (d * d + d) + d * d + 2 * d \
+            + (2 * d * d + 2 * d) + (d * self.conv_kernel + d) + 2 * d + (d * d + d) + 5 * 2 * d
+        h = self.pred_hidden
+        pred = self.n_logits * h + self.pred_layers * (4 * h * h * 2 + 8 * h)
+        joint = (h * self.joint_hidden + self.joint_hidden) + (d * self.joint_hidden + self.joint_hidden) \
+            + (self.joint_hidden * self.n_logits + self.n_logits)
+        return sub + self.n_layers * layer + pred + joint
+
+    def to_dict(self):
+        return asdict(self)
+
+    def with_(self, **kw):
+        return replace(self, **kw)
+
+    def validate(self):
+        assert self.head_dim == 128, "attention kernel is built for head_dim 128"
+        assert self.d_model % 64 == 0 and self.ff_dim % 64 == 0
+        assert self.sub_channels % 64 == 0
+        assert self.pred_hidden % 16 == 0 and self.joint_hidden % 16 == 0
+        assert self.pred_hidden == self.joint_hidden or True
+        assert self.conv_kernel % 2 == 1 and self.conv_kernel <= 31
+        assert self.n_fft == 512 and self.win_length <= 512
+        return self
+
+
+# the configuration the metric is quoted on (BASELINE.json)
+FASTCONFORMER_619M = ModelConfig()
+
+# a shape small enough for CPU oracle runs and committed golden fixtures
+TINY = ModelConfig(d_model=256, n_heads=2, ff_dim=512, n_layers=2, sub_channels=64,
+                   vocab_size=63, pred_hidden=64, joint_hidden=64)
+
+
+def from_nemo_yaml(cfg: dict) -> ModelConfig:
+    """Map a NeMo `model_config.yaml` (already parsed to a dict) onto ModelConfig.
+    [UPSTREAM] key names follow NeMo >= 2.6 `EncDecRNNTBPEModel` configs."""
+    pre = cfg.get("preprocessor", {})
+    enc = cfg.get("encoder", {})
+    dec = cfg.get("decoder", {})
+    joint = cfg.get("joint", {})
+    sr = int(pre.get("sample_rate", 16000))
+    prednet = dec.get("prednet", {})
+    jn = joint.get("jointnet", {})
+    ctx = enc.get("att_context_size", [-1, -1]) or [-1, -1]
+    if ctx and isinstance(ctx[0], (list, tuple)):
+        ctx = ctx[0]
+    local = str(enc.get("self_attention_model", "rel_pos")) == "rel_pos_local_attn"
+    greedy = (cfg.get("decoding", {}) or {}).get("greedy", {}) or {}
+    vocab = int(dec.get("vocab_size", joint.get("num_classes", 3000)))
+    return ModelConfig(
+        sample_rate=sr,
+        n_fft=int(pre.get("n_fft", 512)),
+        win_length=int(round(float(pre.get("window_size", 0.025)) * sr)),
+        hop_length=int(round(float(pre.get("window_stride", 0.01)) * sr)),
+        n_mels=int(pre.get("features", 80)),
+        preemph=float(pre.get("preemph", 0.97) or 0.0),
+        d_model=int(enc.get("d_model", 1024)),
+        n_heads=int(enc.get("n_heads", 8)),
+        ff_dim=int(enc.get("d_model", 1024)) * int(enc.get("ff_expansion_factor", 4)),
+        n_layers=int(enc.get("n_layers", 24)),
+        conv_kernel=int(enc.get("conv_kernel_size", 9)),
+        sub_channels=int(enc.get("subsampling_conv_channels", 256)),
+        sub_factor=int(enc.get("subsampling_factor", 8)),
+        xscaling=bool(enc.get("xscaling", True)),
+        att_left=int(ctx[0]) if local else -1,
+        att_right=int(ctx[1]) if local else -1,
+        n_global=int(enc.get("global_tokens", 0)) if local else 0,
+        vocab_size=vocab,
+        pred_hidden=int(prednet.get("pred_hidden", 640)),
+        pred_layers=int(prednet.get("pred_rnn_layers", 2)),
+        joint_hidden=int(jn.get("joint_hidden", 640)),
+        max_symbols=int(greedy.get("max_symbols", 10) or 10),
+    ).validate()

@@ -1,0 +1,139 @@
+"""The model object `load_model()` returns: FastConformer-RNNT on one MI355X.
+
+It owns (through torch) every device buffer — weights, activations, workspace — and drives the
+three stage entry points of librs_asr.so on torch's current HIP stream.  It stands where NeMo's
+`EncDecRNNTBPEModel` stands in the reference (pkg/nemo-asr/src/transcribe.py:26-28, :48-53)
+and exposes the one attribute the reference's post-processing touches: `.tokenizer`
+(pkg/nemo-asr/src/decode.py:41,47).
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import capi
+from .config import ModelConfig
+from .weights import prepare_weights, DEFAULT_POS_CAP
+
+
+@dataclass
+class DecodedBatch:
+    """host-side result of one batch: token ids and emission frames per utterance"""
+    ids: List[List[int]]
+    frames: List[List[int]]
+    enc_lens: List[int]
+
+
+class _Buffers:
+    """activation / workspace buffers for one (B, Lmax) geometry"""
+
+    def __init__(self, model, B, l_max):
+        cfg, dev, ctx = model.cfg, model.device, model.ctx
+        self.B, self.l_max = B, l_max
+        self.l_pad = l_max + model.pad_left + model.pad_right
+        self.t_max = max(ctx.mel_frames(self.l_pad), 1)
+        self.tp_max = max(ctx.enc_frames(self.t_max), 1)
+        self.u_max = self.tp_max * cfg.max_symbols
+        i32, f32 = torch.int32, torch.float32
+        self.audio = torch.zeros((B, l_max), dtype=f32, device=dev)
+        self.lens = torch.zeros((B,), dtype=i32, device=dev)
+        self.feats = torch.empty((B, self.t_max, cfg.n_mels), dtype=f32, device=dev)
+        self.n_frames = torch.zeros((B,), dtype=i32, device=dev)
+        self.joint_enc = torch.empty((B, self.tp_max, cfg.joint_hidden), dtype=f32, device=dev)
+        self.enc_lens = torch.zeros((B,), dtype=i32, device=dev)
+        self.ids = torch.zeros((B, self.u_max), dtype=i32, device=dev)
+        self.frames = torch.zeros((B, self.u_max), dtype=i32, device=dev)
+        self.n_ids = torch.zeros((B,), dtype=i32, device=dev)
+        self.ws = torch.empty((ctx.workspace_bytes(B, self.l_pad),), dtype=torch.uint8, device=dev)
+        # pinned staging for the host boundary
+        self.h_audio = torch.zeros((B, l_max), dtype=f32).pin_memory()
+        self.h_lens = torch.zeros((B,), dtype=i32).pin_memory()
+
+
+class AsrModel:
+    def __init__(self, cfg: ModelConfig, state_dict, tokenizer, device="cuda", pos_cap: int = DEFAULT_POS_CAP,
+                 pad_seconds: float = 0.5):
+        cfg.validate()
+        if not torch.cuda.is_available():
+            raise RuntimeError("reazonspeech_amd needs a ROCm GPU (MI355X / gfx950): torch.cuda.is_available() is "
+                               "False and there is no CPU fallback for this path")
+        self.cfg = cfg
+        self.tokenizer = tokenizer
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"device {device!r}: only ROCm ('cuda[:N]') devices are supported")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        self.pad_left = self.pad_right = int(pad_seconds * cfg.sample_rate)   # audio.py:80-82 via decode.py:4
+        with torch.cuda.device(self.device):
+            self.ctx = capi.Context(cfg, index)
+            self._upload(prepare_weights(cfg, state_dict, pos_cap))
+        self._bufs = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _upload(self, tensors):
+        for name, t in tensors.items():
+            self.ctx.set_tensor(name, t.to(self.device, non_blocking=False).contiguous())
+        self.ctx.finalize()
+
+    def buffers(self, B, l_max) -> _Buffers:
+        key = (B, l_max)
+        if key not in self._bufs:
+            if len(self._bufs) >= 4:       # keep HBM bounded: drop the oldest geometry
+                self._bufs.pop(next(iter(self._bufs)))
+            with torch.cuda.device(self.device):
+                self._bufs[key] = _Buffers(self, B, l_max)
+        return self._bufs[key]
+
+    @property
+    def n_params(self):
+        return self.cfg.n_params()
+
+    # ------------------------------------------------------------------------------------------
+    def run_device(self, buf: _Buffers, want_enc: Optional[torch.Tensor] = None):
+        """front-end -> encoder -> greedy decode on data already in `buf.audio`/`buf.lens` (HBM).
+        Outputs land in buf.ids / buf.frames / buf.n_ids.  rs_rnnt_greedy synchronises the stream."""
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            self.ctx.frontend(buf.audio, buf.lens, self.pad_left, self.pad_right, buf.t_max, buf.feats,
+                              buf.n_frames, buf.ws, stream)
+            self.ctx.encoder(buf.feats, buf.n_frames, buf.B, buf.t_max, want_enc, buf.joint_enc, buf.enc_lens,
+                             buf.ws, stream)
+            self.ctx.rnnt_greedy(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, buf.u_max, buf.ids, buf.frames,
+                                 buf.n_ids, buf.ws, stream)
+
+    def stage(self, waveforms: Sequence[np.ndarray], l_max: Optional[int] = None) -> _Buffers:
+        """copy host waveforms (16 kHz mono float32, un-padded) into a pinned buffer and on to HBM"""
+        B = len(waveforms)
+        longest = max((len(w) for w in waveforms), default=0)
+        l_max = max(int(l_max or 0), longest, 1)
+        l_max = (l_max + 63) // 64 * 64          # rows stay 256-B aligned
+        buf = self.buffers(B, l_max)
+        ha = buf.h_audio.numpy()
+        hl = buf.h_lens.numpy()
+        for b, w in enumerate(waveforms):
+            n = len(w)
+            ha[b, :n] = np.asarray(w, dtype=np.float32)
+            ha[b, n:] = 0.0
+            hl[b] = n
+        with torch.cuda.device(self.device):
+            buf.audio.copy_(buf.h_audio, non_blocking=True)
+            buf.lens.copy_(buf.h_lens, non_blocking=True)
+        return buf
+
+    def collect(self, buf: _Buffers) -> DecodedBatch:
+        n = buf.n_ids.cpu().numpy()
+        ids = buf.ids.cpu().numpy()
+        frames = buf.frames.cpu().numpy()
+        el = buf.enc_lens.cpu().numpy()
+        return DecodedBatch([ids[b, :n[b]].tolist() for b in range(buf.B)],
+                            [frames[b, :n[b]].tolist() for b in range(buf.B)], el.tolist())
+
+    def transcribe_waveforms(self, waveforms: Sequence[np.ndarray]) -> DecodedBatch:
+        """host float32 waveforms -> token ids / frames (the batched boundary)"""
+        if len(waveforms) == 0:
+            return DecodedBatch([], [], [])
+        buf = self.stage(waveforms)
+        self.run_device(buf)
+        return self.collect(buf)

@@ -1,0 +1,169 @@
+"""Generate tests/golden/parakeet_tiny.npz — run in the BUILD container only.
+
+Pins the oracle (oracle/model.py, oracle/rnnt_greedy.c) against an independent
+implementation of the same architecture that ships in this image:
+`transformers.models.parakeet` (ParakeetFeatureExtractor, ParakeetEncoder,
+ParakeetForRNNT.generate).  NeMo itself is not installable here, so this
+is the strongest anchor available; the fixture stores the *inputs* and the HF outputs so
+the comparison can be re-run anywhere without transformers.
+
+    python tests/golden/make_parakeet_golden.py
+"""
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from reazonspeech_amd.runtime.config import TINY, ModelConfig          # noqa: E402
+from reazonspeech_amd.runtime.weights import synthetic_state_dict, slaney_mel_filterbank  # noqa: E402
+
+SEED = 7
+BLANK_BIAS = 2.0
+
+
+def _fake(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__version__ = "0.10.0"
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def _install_librosa_stub():
+    """HF's extractor needs librosa only for the Slaney filterbank (HF feature_extraction
+    _parakeet.py:96-98); provide that one function from our closed form, which equals
+    transformers.audio_utils.mel_filter_bank to 1e-9."""
+    def mel(sr, n_fft, n_mels, fmin, fmax, norm):
+        return slaney_mel_filterbank(ModelConfig(sample_rate=sr, n_fft=n_fft, n_mels=n_mels))
+    filt = _fake("librosa.filters", mel=mel)
+    _fake("librosa", filters=filt)
+    if "soxr" not in sys.modules:
+        try:
+            import soxr  # noqa: F401
+        except ImportError:
+            _fake("soxr")
+
+
+def hf_state_dict(cfg, sd):
+    out = {}
+    for i in (0, 2, 3, 5, 6):
+        for p in ("weight", "bias"):
+            out[f"encoder.subsampling.layers.{i}.{p}"] = sd[f"encoder.pre_encode.conv.{i}.{p}"]
+    for p in ("weight", "bias"):
+        out[f"encoder.subsampling.linear.{p}"] = sd[f"encoder.pre_encode.out.{p}"]
+    amap = {"q_proj": "linear_q", "k_proj": "linear_k", "v_proj": "linear_v", "o_proj": "linear_out"}
+    for i in range(cfg.n_layers):
+        L = f"encoder.layers.{i}."
+        for n in ("norm_feed_forward1", "norm_self_att", "norm_conv", "norm_feed_forward2", "norm_out",
+                  "feed_forward1.linear1", "feed_forward1.linear2",
+                  "feed_forward2.linear1", "feed_forward2.linear2",
+                  "conv.pointwise_conv1", "conv.depthwise_conv", "conv.pointwise_conv2"):
+            for p in ("weight", "bias"):
+                out[L + n + "." + p] = sd[L + n + "." + p]
+        for hf, ne in amap.items():
+            for p in ("weight", "bias"):
+                out[L + f"self_attn.{hf}.{p}"] = sd[L + f"self_attn.{ne}.{p}"]
+        out[L + "self_attn.relative_k_proj.weight"] = sd[L + "self_attn.linear_pos.weight"]
+        out[L + "self_attn.bias_u"] = sd[L + "self_attn.pos_bias_u"]
+        out[L + "self_attn.bias_v"] = sd[L + "self_attn.pos_bias_v"]
+        for p in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            out[L + "conv.norm." + p] = sd[L + "conv.batch_norm." + p]
+    out["encoder_projector.weight"] = sd["joint.enc.weight"]
+    out["encoder_projector.bias"] = sd["joint.enc.bias"]
+    out["decoder.embedding.weight"] = sd["decoder.prediction.embed.weight"]
+    for l in range(cfg.pred_layers):
+        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            out[f"decoder.lstm.{n}_l{l}"] = sd[f"decoder.prediction.dec_rnn.lstm.{n}_l{l}"]
+    out["decoder.decoder_projector.weight"] = sd["joint.pred.weight"]
+    out["decoder.decoder_projector.bias"] = sd["joint.pred.bias"]
+    out["joint.head.weight"] = sd["joint.joint_net.2.weight"]
+    out["joint.head.bias"] = sd["joint.joint_net.2.bias"]
+    return out
+
+
+def build_hf_model(cfg, sd):
+    from transformers.models.parakeet.configuration_parakeet import ParakeetEncoderConfig, ParakeetRNNTConfig
+    from transformers.models.parakeet.modeling_parakeet import ParakeetForRNNT
+    enc = ParakeetEncoderConfig(
+        hidden_size=cfg.d_model, num_hidden_layers=cfg.n_layers, num_attention_heads=cfg.n_heads,
+        intermediate_size=cfg.ff_dim, conv_kernel_size=cfg.conv_kernel,
+        subsampling_factor=cfg.sub_factor, subsampling_conv_channels=cfg.sub_channels,
+        num_mel_bins=cfg.n_mels, scale_input=cfg.xscaling, dropout=0.0, layerdrop=0.0,
+        activation_dropout=0.0, attention_dropout=0.0)
+    rc = ParakeetRNNTConfig(vocab_size=cfg.n_logits, decoder_hidden_size=cfg.pred_hidden,
+                            num_decoder_layers=cfg.pred_layers, max_symbols_per_step=cfg.max_symbols,
+                            encoder_config=enc, blank_token_id=cfg.blank_id, pad_token_id=cfg.blank_id)
+    model = ParakeetForRNNT(rc).eval()
+    missing, unexpected = model.load_state_dict(hf_state_dict(cfg, sd), strict=False)
+    missing = [m for m in missing if "inv_freq" not in m]
+    assert not missing and not unexpected, (missing, unexpected)
+    model.generation_config.decoder_start_token_id = cfg.blank_id
+    return model
+
+
+def main():
+    _install_librosa_stub()
+    from transformers.models.parakeet.feature_extraction_parakeet import ParakeetFeatureExtractor
+    cfg = TINY
+    sd = synthetic_state_dict(cfg, SEED, blank_bias=BLANK_BIAS)
+    rng = np.random.default_rng(SEED)
+    lens = [24000, 17717]                        # 1.5 s and ~1.1 s incl. padding
+    audio = np.zeros((2, max(lens)), dtype=np.float32)
+    for b, L in enumerate(lens):
+        t = np.arange(L) / 16000.0
+        audio[b, :L] = (0.05 * rng.standard_normal(L) +
+                        0.2 * np.sin(2 * np.pi * (220.0 * (b + 1)) * t) * np.sin(2 * np.pi * 3.0 * t)
+                        ).astype(np.float32)
+    fe = ParakeetFeatureExtractor()
+    feats = fe([audio[b, :L] for b, L in enumerate(lens)], sampling_rate=16000, return_tensors="pt")
+    model = build_hf_model(cfg, sd)
+    with torch.no_grad():
+        enc_out = model.get_audio_features(input_features=feats["input_features"],
+                                           attention_mask=feats["attention_mask"])
+        gen = model.generate(input_features=feats["input_features"],
+                             attention_mask=feats["attention_mask"])
+    seqs = gen.sequences.numpy()
+    durs = gen.durations.numpy()
+    ids, frames = [], []
+    enc_lens = enc_out.attention_mask.sum(-1).numpy()
+    for b in range(2):
+        fr = np.cumsum(durs[b])                  # frame index AFTER each step
+        i_b, f_b = [], []
+        for s in range(1, seqs.shape[1]):
+            frame_at_emit = fr[s] - durs[b, s]   # pointer value when the token was produced
+            if frame_at_emit >= enc_lens[b]:
+                break
+            if seqs[b, s] != cfg.blank_id:
+                i_b.append(int(seqs[b, s]))
+                f_b.append(int(frame_at_emit))
+        ids.append(i_b)
+        frames.append(f_b)
+    umax = max(len(x) for x in ids)
+    ids_arr = np.full((2, umax), -1, np.int32)
+    frm_arr = np.full((2, umax), -1, np.int32)
+    for b in range(2):
+        ids_arr[b, :len(ids[b])] = ids[b]
+        frm_arr[b, :len(frames[b])] = frames[b]
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "parakeet_tiny.npz")
+    np.savez_compressed(
+        out, seed=SEED, blank_bias=BLANK_BIAS, audio=audio, lengths=np.array(lens, np.int64),
+        hf_feats=feats["input_features"].numpy().astype(np.float32),
+        hf_n_frames=feats["attention_mask"].sum(-1).numpy().astype(np.int64),
+        hf_enc=enc_out.last_hidden_state.numpy().astype(np.float32),
+        hf_joint_enc=enc_out.pooler_output.numpy().astype(np.float32),
+        hf_enc_lens=enc_lens.astype(np.int64), hf_ids=ids_arr, hf_frames=frm_arr,
+        hf_n_ids=np.array([len(x) for x in ids], np.int32))
+    print("wrote", out, os.path.getsize(out), "bytes; tokens per utt:", [len(x) for x in ids],
+          "enc lens", enc_lens)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,180 @@
+"""-m gpu: per-operator parity of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Tolerances (bf16 operands, f32 accumulation):
+  GEMM            |err| <= 2e-3 * (|a|.|w| row/col norms)  (f32 reassociation only: operands are
+                  rounded to bf16 identically on both sides)
+  LayerNorm       1e-5 relative (f32), bf16 output within 1 bf16 ulp
+  attention ctx   2e-2 absolute on O(1) values (probabilities rounded to bf16 against a running
+                  instead of the final row maximum, fast exp)
+  front-end       2e-3 absolute on normalised log-mel (f32 FFT vs pocketfft)
+"""
+import numpy as np
+import pytest
+import torch
+
+from reazonspeech_amd.runtime import capi
+from reazonspeech_amd.runtime.config import TINY, FASTCONFORMER_619M
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_device):
+    c = capi.Context(TINY, 0)
+    yield c
+    c.close()
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_mfma_layout_asymmetric(ctx, gpu_device):
+    """A = I against an asymmetric W catches a transposed or permuted C-write (guide G9)."""
+    M = N = K = 128
+    A = torch.eye(M, K)
+    W = (torch.arange(N)[:, None] * 0.5 + torch.arange(K)[None, :] * 0.001953125)   # exact in bf16? keep small
+    W = rb(W)
+    out = torch.zeros((M, N), dtype=torch.float32, device=gpu_device)
+    ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out, flags=capi.GEMM_OUT_F32)
+    sync()
+    assert torch.equal(out.cpu(), W.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (130, 72, 192), (1, 640, 256),
+                                   (517, 3072, 256), (4416, 512, 256)])
+def test_gemm_shapes(ctx, gpu_device, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = rb(torch.randn((M, K), generator=g))
+    W = rb(torch.randn((N, K), generator=g) / K ** 0.5)
+    ref = A @ W.t()
+    out = torch.full((M, N), 7.0, dtype=torch.float32, device=gpu_device)
+    ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out, flags=capi.GEMM_OUT_F32)
+    sync()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 2e-3, err
+
+
+def test_gemm_epilogues(ctx, gpu_device):
+    g = torch.Generator().manual_seed(5)
+    B, T, Fq, K, N = 3, 11, 5, 128, 192
+    M = B * T * Fq
+    A = rb(torch.randn((M, K), generator=g))
+    W = rb(torch.randn((N, K), generator=g) / K ** 0.5)
+    bias = torch.randn((N,), generator=g)
+    res = torch.randn((M, N), generator=g)
+    lens = torch.tensor([11, 4, 0], dtype=torch.int32)
+    dA, dW, dbias = bf(A).to(gpu_device), bf(W).to(gpu_device), bias.to(gpu_device)
+    base = A @ W.t() + bias
+    # bias + SiLU -> bf16
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=gpu_device)
+    ctx.gemm(dA, dW, out, flags=capi.GEMM_BIAS | capi.GEMM_SILU, bias=dbias)
+    sync()
+    ref = torch.nn.functional.silu(base)
+    assert (out.cpu().float() - ref).abs().max() <= 2e-2
+    # bias, *0.5, + residual, in place on an f32 stream
+    stream = res.clone().to(gpu_device)
+    ctx.gemm(dA, dW, stream, flags=capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32, bias=dbias, alpha=0.5,
+             residual=stream)
+    sync()
+    assert (stream.cpu() - (res + 0.5 * base)).abs().max() <= 2e-3
+    # bias + ReLU + per-utterance row mask -> bf16
+    out = torch.ones((M, N), dtype=torch.bfloat16, device=gpu_device)
+    ctx.gemm(dA, dW, out, flags=capi.GEMM_BIAS | capi.GEMM_RELU | capi.GEMM_ROWMASK, bias=dbias,
+             mask_lens=lens.to(gpu_device), mask_rows=Fq, mask_steps=T)
+    sync()
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float()[:, :, None, None].expand(B, T, Fq, N).reshape(M, N)
+    ref = torch.relu(base) * mask
+    got = out.cpu().float()
+    assert (got - ref).abs().max() <= 2e-2
+    assert torch.all(got[mask == 0] == 0)
+
+
+def test_gemm_rejects_bad_k(ctx, gpu_device):
+    A = torch.zeros((4, 48), dtype=torch.bfloat16, device=gpu_device)
+    W = torch.zeros((8, 48), dtype=torch.bfloat16, device=gpu_device)
+    out = torch.zeros((4, 8), dtype=torch.float32, device=gpu_device)
+    with pytest.raises(capi.RsError):
+        ctx.gemm(A, W, out, flags=capi.GEMM_OUT_F32)
+
+
+@pytest.mark.parametrize("d", [256, 1024])
+def test_layernorm(ctx, gpu_device, d):
+    g = torch.Generator().manual_seed(d)
+    M = 77
+    x = torch.randn((M, d), generator=g) * 3 + 1.5
+    gamma = 1 + 0.1 * torch.randn((d,), generator=g)
+    beta = 0.1 * torch.randn((d,), generator=g)
+    ref = torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-5)
+    o32 = torch.zeros((M, d), dtype=torch.float32, device=gpu_device)
+    o16 = torch.zeros((M, d), dtype=torch.bfloat16, device=gpu_device)
+    dx = x.to(gpu_device)
+    ctx.layernorm(dx, gamma.to(gpu_device), beta.to(gpu_device), 1e-5, out_bf16=o16, out_f32=o32)
+    sync()
+    assert (o32.cpu() - ref).abs().max() <= 2e-5
+    assert (o16.cpu().float() - ref).abs().max() <= 2e-2
+    # in place (how the encoder applies norm_out to the residual stream)
+    ctx.layernorm(dx, gamma.to(gpu_device), beta.to(gpu_device), 1e-5, out_f32=dx)
+    sync()
+    assert (dx.cpu() - ref).abs().max() <= 2e-5
+
+
+@pytest.mark.parametrize("T,lens", [(19, [19, 14]), (70, [70, 33, 1]), (138, [138, 100])])
+def test_glu_dwconv_silu(ctx, gpu_device, T, lens):
+    g = torch.Generator().manual_seed(T)
+    B, d, k = len(lens), 256, 9
+    x = rb(torch.randn((B, T, 2 * d), generator=g))
+    w = torch.randn((d, k), generator=g) / 3
+    b = 0.1 * torch.randn((d,), generator=g)
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    a, gate = x[..., :d], x[..., d:]
+    u = a * torch.sigmoid(gate) * (torch.arange(T)[None, :] < lens_t[:, None])[:, :, None]
+    z = torch.nn.functional.conv1d(u.transpose(1, 2), w[:, None, :], b, padding=4, groups=d).transpose(1, 2)
+    ref = torch.nn.functional.silu(z)
+    out = torch.zeros((B * T, d), dtype=torch.bfloat16, device=gpu_device)
+    ctx.glu_dwconv(bf(x).reshape(B * T, 2 * d).to(gpu_device), w.t().contiguous().to(gpu_device), b.to(gpu_device),
+                   lens_t.to(gpu_device), B, T, d, k, out)
+    sync()
+    assert (out.cpu().float().view(B, T, d) - ref).abs().max() <= 2e-2
+
+
+@pytest.mark.parametrize("T,lens,window", [(19, [19, 14], None), (138, [138, 97, 5], None), (64, [64, 33], None),
+                                           (300, [300, 160], None), (138, [138, 60], (32, 16, 1))])
+def test_relpos_attention(gpu_device, T, lens, window):
+    cfg = TINY if window is None else TINY.with_(att_left=window[0], att_right=window[1], n_global=window[2])
+    c = capi.Context(cfg, 0)
+    g = torch.Generator().manual_seed(T + len(lens))
+    B, H, dh, d = len(lens), cfg.n_heads, cfg.head_dim, cfg.d_model
+    qkv = rb(torch.randn((B, T, 3 * d), generator=g))
+    p = rb(torch.randn((2 * T - 1, d), generator=g))
+    bu = 0.3 * torch.randn((H, dh), generator=g)
+    bv = 0.3 * torch.randn((H, dh), generator=g)
+    lens_t = torch.tensor(lens, dtype=torch.int64)
+    q, k, v = (qkv[..., i * d:(i + 1) * d].reshape(B, T, H, dh) for i in range(3))
+    ref = om.attention_core(cfg, q, k, v, p.view(2 * T - 1, H, dh), bu, bv, lens_t, "bf16")
+    out = torch.full((B * T, d), 3.0, dtype=torch.bfloat16, device=gpu_device)
+    c.attention(bf(qkv).reshape(B * T, 3 * d).to(gpu_device), bf(p).to(gpu_device), bu.reshape(-1).to(gpu_device),
+                bv.reshape(-1).to(gpu_device), lens_t.to(torch.int32).to(gpu_device), B, T, out)
+    sync()
+    got = out.cpu().float().view(B, T, d)
+    for b in range(B):
+        n = lens[b]
+        err = (got[b, :n] - ref[b, :n]).abs().max().item()
+        assert err <= 2e-2, (b, err)
+        assert torch.all(got[b, n:] == 0)      # padded queries: NeMo zero-fills
+    c.close()
+
+
+def test_rejects_wrong_head_dim(gpu_device):
+    with pytest.raises(capi.RsError):
+        capi.Context(TINY.with_(n_heads=4), 0)
