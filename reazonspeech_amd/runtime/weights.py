@@ -84,6 +84,13 @@ def rel_pos_table(cfg: ModelConfig, T: int) -> np.ndarray:
 # synthetic state dict (NeMo key names)
 # ------------------------------------------------------------------------------------
 
+# gain of the last linear of every residual branch.  Small on purpose: with O(1) branch gains a
+# deep random-weight conformer collapses every frame onto the same vector (rank collapse), the
+# joint logits stop depending on the frame and greedy decode emits either nothing or
+# max_symbols tokens on every frame.  0.25 keeps ~60 % of the temporal variance through 24 layers.
+BRANCH_GAIN = 0.25
+
+
 def _seed_for(name: str, seed: int) -> int:
     h = 1469598103934665603
     for ch in name.encode():
@@ -143,10 +150,11 @@ def synthetic_state_dict(cfg: ModelConfig, seed: int = 0, blank_bias: float = No
         for ff in ("feed_forward1", "feed_forward2"):
             norm(L + "norm_" + ff, d)
             lin(L + ff + ".linear1", f, d)
-            lin(L + ff + ".linear2", d, f, gain=1.4)
+            lin(L + ff + ".linear2", d, f, gain=BRANCH_GAIN)
         norm(L + "norm_self_att", d)
         for nm in ("linear_q", "linear_k", "linear_v", "linear_out"):
-            lin(L + "self_attn." + nm, d, d, gain=(2.0 if nm in ("linear_q", "linear_k") else 1.0))
+            lin(L + "self_attn." + nm, d, d,
+                gain=(2.0 if nm in ("linear_q", "linear_k") else BRANCH_GAIN if nm == "linear_out" else 1.0))
         lin(L + "self_attn.linear_pos", d, d, bias=False)
         sd[L + "self_attn.pos_bias_u"] = _randn(L + "pos_bias_u", seed, (cfg.n_heads, cfg.head_dim), 0.1)
         sd[L + "self_attn.pos_bias_v"] = _randn(L + "pos_bias_v", seed, (cfg.n_heads, cfg.head_dim), 0.1)
@@ -162,7 +170,7 @@ def synthetic_state_dict(cfg: ModelConfig, seed: int = 0, blank_bias: float = No
         sd[L + "conv.batch_norm.running_var"] = 1.0 + 0.1 * torch.rand(
             (d,), generator=torch.Generator().manual_seed(_seed_for(L + "bn.v", seed)))
         sd[L + "conv.batch_norm.num_batches_tracked"] = torch.tensor(1, dtype=torch.int64)
-        sd[L + "conv.pointwise_conv2.weight"] = _randn(L + "pw2.w", seed, (d, d, 1), 1.4 / math.sqrt(d))
+        sd[L + "conv.pointwise_conv2.weight"] = _randn(L + "pw2.w", seed, (d, d, 1), BRANCH_GAIN / math.sqrt(d))
         sd[L + "conv.pointwise_conv2.bias"] = _randn(L + "pw2.b", seed, (d,), 0.05)
         norm(L + "norm_out", d)
 
@@ -190,7 +198,7 @@ def default_blank_bias(cfg: ModelConfig) -> float:
     return _BLANK_BIAS.get((cfg.d_model, cfg.n_layers, cfg.vocab_size), 3.0)
 
 
-_BLANK_BIAS = {}
+_BLANK_BIAS = {(1024, 24, 3000): 6.2, (256, 2, 63): 3.4}
 
 
 # ------------------------------------------------------------------------------------

@@ -1,0 +1,69 @@
+"""CPU: the C-ABI shared library builds for gfx950, loads, and exports every symbol that
+include/rs_asr.h declares (no compute: there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from reazonspeech_amd import build as rs_build
+from reazonspeech_amd.runtime import capi
+from reazonspeech_amd.runtime.config import TINY, FASTCONFORMER_619M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rs_asr.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    lib_path = rs_build.build()
+    assert os.path.exists(lib_path)
+    lib = ctypes.CDLL(lib_path)
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in rs_asr.h but not exported"
+    assert sorted(capi.EXPORTS) == syms, "capi.EXPORTS must list exactly the header's functions"
+
+
+def test_header_cites_reference_and_is_plain_c():
+    src = open(HEADER).read()
+    assert "pkg/nemo-asr/src/transcribe.py" in src
+    assert "torch" not in re.sub(r"/\*.*?\*/", "", src, flags=re.S)      # no torch types in signatures
+    assert 'extern "C"' in src
+
+
+def test_dims_struct_matches_header_field_order():
+    src = open(HEADER).read()
+    body = src[src.index("typedef struct rs_dims {"):src.index("} rs_dims;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:int32_t|float)\s+([a-z_0-9]+)\s*;", body)
+    assert fields == [f[0] for f in capi.RsDims._fields_]
+    d = capi.RsDims.from_config(FASTCONFORMER_619M)
+    assert (d.d_model, d.n_layers, d.n_logits, d.blank_id, d.sub_stages) == (1024, 24, 3001, 3000, 3)
+
+
+def test_context_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.RsError):
+        capi.Context(TINY, 0)
+    from reazonspeech_amd.nemo.asr import load_model
+    with pytest.raises(RuntimeError):
+        load_model()            # no silent CPU fallback
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "reazonspeech_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "librs_oracle" not in text, f

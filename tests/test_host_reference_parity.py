@@ -1,0 +1,133 @@
+"""CPU: the host-side pieces of the path against golden vectors produced by importing the
+reference's own in-tree files (tests/golden/make_reference_golden.py): decode_hypothesis,
+find_end_of_segment, constants, writers, TranscribeConfig defaults, pad/norm audio."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from reazonspeech_amd.nemo.asr import decode as D
+from reazonspeech_amd.nemo.asr import audio as A
+from reazonspeech_amd.nemo.asr import writer as W
+from reazonspeech_amd.nemo.asr.interface import (Hypothesis, TranscribeConfig, TranscribeResult, Subword,
+                                                 Segment, AudioData)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_host.json")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(GOLD, encoding="utf-8") as fp:
+        return json.load(fp)
+
+
+class _Tok:
+    def __init__(self, pieces):
+        self.pieces = pieces
+
+    def ids_to_text(self, ids):
+        text = "".join(self.pieces[i] for i in ids).replace("▁", " ")
+        return text[1:] if text.startswith(" ") else text
+
+
+class _Model:
+    def __init__(self, pieces):
+        self.tokenizer = _Tok(pieces)
+
+
+def test_constants(gold):
+    c = gold["consts"]
+    assert (D.PAD_SECONDS, D.SECONDS_PER_STEP, D.SUBWORDS_PER_SEGMENTS, D.PHONEMIC_BREAK) == \
+        (c["PAD_SECONDS"], c["SECONDS_PER_STEP"], c["SUBWORDS_PER_SEGMENTS"], c["PHONEMIC_BREAK"])
+    assert sorted(D.TOKEN_EOS) == c["TOKEN_EOS"] and sorted(D.TOKEN_COMMA) == c["TOKEN_COMMA"]
+    cfg = TranscribeConfig()
+    assert {"verbose": cfg.verbose, "raw_hypothesis": cfg.raw_hypothesis} == gold["config_defaults"]
+
+
+def test_decode_hypothesis_matches_reference(gold):
+    model = _Model(gold["pieces"])
+    for case in gold["cases"]:
+        # the greedy adapter must reproduce the ALSD-shaped input the reference consumed
+        hyp = Hypothesis.from_greedy(case["ids"], case["frames"], case["blank"])
+        assert hyp.timestamp == case["steps"]
+        assert hyp.y_sequence.tolist() == [case["blank"]] + case["ids"]
+        res = D.decode_hypothesis(model, hyp)
+        assert isinstance(res, TranscribeResult) and res.hypothesis is None
+        assert res.text == case["text"]
+        assert [[s.seconds, s.token_id, s.token] for s in res.subwords] == case["subwords"]
+        assert [[s.start_seconds, s.end_seconds, s.text] for s in res.segments] == case["segments"]
+
+
+def test_greedy_adapter_time_formula():
+    hyp = Hypothesis.from_greedy([7, 8, 9], [0, 10, 10], blank_id=99)
+    model = _Model({7: "a", 8: "b", 9: "c"})
+    res = D.decode_hypothesis(model, hyp)
+    # seconds = max(0.08 * frame - 0.5, 0)  (decode.py:48 with the adapter's step = frame + idx + 1)
+    assert [s.seconds for s in res.subwords] == [0, max(0.08 * 10 - 0.5, 0), max(0.08 * 10 - 0.5, 0)]
+
+
+def test_writers_match_reference(gold):
+    model = _Model(gold["pieces"])
+    for case in gold["cases"]:
+        res = D.decode_hypothesis(model, Hypothesis.from_greedy(case["ids"], case["frames"], case["blank"]))
+        for ext, want in case["writers"].items():
+            fp = io.StringIO()
+            w = W.get_writer(fp, None if ext == "None" else ext)
+            w.write_header()
+            for seg in res.segments:
+                w.write(seg)
+            assert fp.getvalue() == want, ext
+
+
+def test_get_writer_extension_quirk(gold):
+    class Named(io.StringIO):
+        name = "x.vtt"
+    assert type(W.get_writer(Named())).__name__ == gold["writer_for_x_vtt"] == "TextWriter"
+    assert isinstance(W.get_writer(io.StringIO(), "vtt"), W.VTTWriter)
+
+
+def test_find_end_of_segment_rules():
+    sw = lambda tok, sec: Subword(seconds=sec, token_id=0, token=tok)   # noqa: E731
+    # closes after EOS unless punctuation follows
+    subs = [sw("a", 0), sw("。", 0.1), sw("b", 0.2)]
+    assert D.find_end_of_segment(subs, 0) == 1
+    subs = [sw("a", 0), sw("。", 0.1), sw("!", 0.2), sw("b", 0.3)]
+    assert D.find_end_of_segment(subs, 0) == 2
+    # long pause only breaks once the segment has >= 10 subwords
+    subs = [sw("x", 0.08 * i) for i in range(10)] + [sw("y", 5.0), sw("z", 9.0), sw("w", 9.1)]
+    assert D.find_end_of_segment(subs, 0) == 10
+    assert D.find_end_of_segment(subs, 11) == 12          # last subword always closes
+    assert D.find_end_of_segment([sw("a", 0)], 0) == 0
+
+
+def test_pad_and_norm_audio():
+    x = np.arange(10, dtype=np.float32)
+    padded = A.pad_audio(AudioData(x, 16000), 0.5)
+    assert padded.waveform.shape == (10 + 2 * 8000,) and padded.samplerate == 16000
+    assert np.all(padded.waveform[:8000] == 0) and np.all(padded.waveform[-8000:] == 0)
+    assert np.array_equal(padded.waveform[8000:8010], x)
+    # int(seconds * samplerate) like np.pad(pad_width=int(...)) — audio.py:80-82
+    assert A.pad_audio(AudioData(x, 22050), 0.33).waveform.shape == (10 + 2 * int(0.33 * 22050),)
+    # 16 kHz mono is passed through untouched
+    same = A.norm_audio(AudioData(x, 16000))
+    assert same.waveform is x
+    # resample BEFORE down-mix, stereo -> mono mean over channels (audio.py:64-67)
+    st = np.stack([np.ones(8000, np.float32), 3 * np.ones(8000, np.float32)])
+    out = A.norm_audio(AudioData(st, 8000))
+    assert out.samplerate == 16000 and out.waveform.shape == (16000,)
+    assert abs(float(out.waveform[4000:12000].mean()) - 2.0) < 1e-3
+
+
+def test_audio_constructors(tmp_path):
+    import torch
+    from scipy.io import wavfile
+    a = A.audio_from_numpy(np.zeros(4, np.float32), 8000)
+    assert a.samplerate == 8000
+    t = A.audio_from_tensor(torch.ones(5), 16000)
+    assert isinstance(t.waveform, np.ndarray) and t.waveform.shape == (5,)
+    path = str(tmp_path / "a.wav")
+    wavfile.write(path, 22050, (np.sin(np.arange(2205) / 10.0) * 20000).astype(np.int16))
+    f = A.audio_from_path(path)
+    assert f.samplerate == 22050 and f.waveform.dtype == np.float32 and abs(f.waveform).max() <= 1.0

@@ -1,0 +1,175 @@
+"""CPU: host logic of the runtime — model dims, synthetic weights, weight prep layouts, .nemo
+round trip, tokenizer, synthetic inputs, sharding helpers, world_size-2 gloo gather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from reazonspeech_amd.runtime import dist as rdist
+from reazonspeech_amd.runtime.config import FASTCONFORMER_619M, TINY, from_nemo_yaml
+from reazonspeech_amd.runtime.synth import synthetic_batch
+from reazonspeech_amd.runtime.tokenizer import SyntheticTokenizer
+from reazonspeech_amd.runtime import weights as W
+
+
+def test_config_geometry():
+    cfg = FASTCONFORMER_619M
+    assert round(cfg.n_params() / 1e6, 1) == 619.2            # README.rst:34-35 "619M"
+    assert cfg.mel_frames(176000) == 1100 and cfg.stft_frames(176000) == 1101
+    assert cfg.enc_frames(1100) == 138 and cfg.enc_frames(900) == 113
+    assert cfg.sub_freq == 10 and cfg.head_dim == 128 and cfg.blank_id == 3000
+    assert abs(cfg.hop_length * cfg.sub_factor / cfg.sample_rate - 0.08) < 1e-12   # decode.py:5
+
+
+def test_synthetic_state_dict_is_deterministic_and_shaped():
+    a = W.synthetic_state_dict(TINY, 3)
+    b = W.synthetic_state_dict(TINY, 3)
+    c = W.synthetic_state_dict(TINY, 4)
+    assert a.keys() == b.keys()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert not torch.equal(a["joint.enc.weight"], c["joint.enc.weight"])
+    n = sum(v.numel() for k, v in a.items()
+            if not k.startswith("preprocessor") and "running" not in k and "num_batches" not in k)
+    assert n == TINY.n_params()
+    assert torch.all(a["decoder.prediction.embed.weight"][TINY.blank_id] == 0)      # blank_as_pad
+    assert a["encoder.layers.1.self_attn.pos_bias_u"].shape == (TINY.n_heads, 128)
+
+
+def test_prepare_weights_layouts():
+    cfg = TINY
+    sd = W.synthetic_state_dict(cfg, 1)
+    p = W.prepare_weights(cfg, sd, pos_cap=40)
+    C, d, F = cfg.sub_channels, cfg.d_model, cfg.sub_freq
+    assert p["sub.conv0.w"].shape == (9, C) and p["sub.dw1.w"].dtype == torch.float32
+    assert torch.equal(p["sub.conv0.w"][4], sd["encoder.pre_encode.conv.0.weight"][:, 0, 1, 1])
+    assert p["sub.pw2.w"].dtype == torch.bfloat16 and p["sub.pw2.w"].shape == (C, C)
+    # output Linear: columns permuted from (c, f) to (f, c)
+    w = sd["encoder.pre_encode.out.weight"]
+    assert p["sub.out.w"].shape == (d, F * C)
+    assert p["sub.out.w"][5, 3 * C + 7] == w[5, 7 * F + 3].to(torch.bfloat16)
+    assert p["L0.att.qkv.w"].shape == (3 * d, d) and p["L0.att.qkv.b"].shape == (3 * d,)
+    assert torch.equal(p["L0.att.qkv.w"][d:2 * d], sd["encoder.layers.0.self_attn.linear_k.weight"].to(torch.bfloat16))
+    assert p["L1.conv.dw.w"].shape == (cfg.conv_kernel, d)
+    H = cfg.pred_hidden
+    assert p["pred.lstm0.w"].shape == (4 * H, 2 * H)
+    assert torch.equal(p["pred.lstm1.b"], sd["decoder.prediction.dec_rnn.lstm.bias_ih_l1"] +
+                       sd["decoder.prediction.dec_rnn.lstm.bias_hh_l1"])
+    assert p["pos.table"].shape == (79, d) and p["pos.table"].dtype == torch.bfloat16
+    # row (cap - T) + n of the capped table is row n of the table for T  (slice trick in rs_encoder_forward)
+    t13 = torch.from_numpy(W.rel_pos_table(cfg, 13)).to(torch.bfloat16)
+    assert torch.equal(p["pos.table"][40 - 13:40 - 13 + 25], t13)
+    idx, fw = p["fe.fb_idx"].numpy(), p["fe.fb_w"].numpy()
+    fb = sd["preprocessor.featurizer.fb"][0].numpy()
+    m = 37
+    dense = np.zeros(257, np.float32)
+    dense[idx[m, 0]:idx[m, 0] + idx[m, 1]] = fw[m, :idx[m, 1]]
+    assert np.array_equal(dense, fb[m])
+    tw = p["fe.twiddle"].numpy()
+    assert np.allclose(tw[128], [0.0, -1.0], atol=1e-7) and np.allclose(tw[0], [1.0, 0.0])
+
+
+def test_folded_batchnorm_equals_unfolded():
+    cfg = TINY
+    sd = W.synthetic_state_dict(cfg, 2)
+    p = W.prepare_weights(cfg, sd, pos_cap=8)
+    L = "encoder.layers.0.conv."
+    x = torch.randn(2, cfg.d_model, 30)
+    y = torch.nn.functional.conv1d(x, sd[L + "depthwise_conv.weight"], sd[L + "depthwise_conv.bias"], padding=4,
+                                   groups=cfg.d_model)
+    y = torch.nn.functional.batch_norm(y, sd[L + "batch_norm.running_mean"], sd[L + "batch_norm.running_var"],
+                                       sd[L + "batch_norm.weight"], sd[L + "batch_norm.bias"], False, 0.0, cfg.bn_eps)
+    z = torch.nn.functional.conv1d(x, p["L0.conv.dw.w"].t().unsqueeze(1).contiguous(), p["L0.conv.dw.b"], padding=4,
+                                   groups=cfg.d_model)
+    assert (y - z).abs().max() <= 1e-5
+
+
+def test_nemo_archive_round_trip(tmp_path):
+    cfg = TINY.with_(att_left=64, att_right=64, n_global=1, max_symbols=7)
+    sd = W.synthetic_state_dict(cfg, 9)
+    path = str(tmp_path / "m.nemo")
+    W.write_nemo(path, cfg, sd, tokenizer_model=b"not-a-real-spm")
+    cfg2, sd2, tok = W.read_nemo(path)
+    assert cfg2 == cfg
+    assert tok == b"not-a-real-spm"
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+    with pytest.raises(ValueError):
+        import tarfile
+        bad = str(tmp_path / "bad.nemo")
+        with tarfile.open(bad, "w"):
+            pass
+        W.read_nemo(bad)
+
+
+def test_from_nemo_yaml_defaults():
+    cfg = from_nemo_yaml({"encoder": {"d_model": 1024, "n_heads": 8, "n_layers": 24, "self_attention_model": "rel_pos"},
+                          "decoder": {"vocab_size": 3000}})
+    assert cfg == FASTCONFORMER_619M
+
+
+def test_synthetic_tokenizer_and_sentencepiece_rule():
+    tok = SyntheticTokenizer(3000, 0)
+    assert len(tok.pieces) == len(set(tok.pieces)) == 3000
+    assert tok.ids_to_text([0]) == ""                     # bare U+2581 -> dropped by decode.py:53
+    assert tok.ids_to_text([1]) == "。"
+    text = tok.ids_to_text([10, 0, 11])
+    assert " " in text and not text.startswith(" ")
+    assert SyntheticTokenizer(3000, 0).pieces == tok.pieces
+
+
+def test_synthetic_batch():
+    a, l = synthetic_batch(3, 1.0, seed=1)
+    b, _ = synthetic_batch(3, 1.0, seed=1)
+    assert a.shape == (3, 16000) and a.dtype == np.float32 and np.array_equal(a, b)
+    assert l.tolist() == [16000] * 3 and 0.001 < np.abs(a).max() <= 1.0
+    r, lr = synthetic_batch(6, 2.0, seed=2, ragged=True, min_seconds=0.5)
+    assert lr.min() >= 8000 and lr.max() <= 32000
+    for i in range(6):
+        assert np.all(r[i, lr[i]:] == 0)
+
+
+def test_shard_helpers():
+    assert [rdist.shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    lens = [50, 10, 40, 20, 30, 60, 5]
+    shards = rdist.shard_by_length(lens, 3)
+    assert sorted(sum(shards, [])) == list(range(7))
+    assert [len(s) for s in shards] == [3, 2, 2]
+    assert max(lens[i] for i in shards[0]) <= min(lens[i] for i in shards[1])
+    assert rdist.shard_by_length([], 2) == [[], []]
+    assert rdist.world_size() == 1 and rdist.rank() == 0 and rdist.max_over_ranks(1.5) == 1.5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    rdist.init("gloo")
+    B, U = 3, 5
+    ids = torch.full((B, U), rank * 100, dtype=torch.int32) + torch.arange(U, dtype=torch.int32)
+    frames = ids + 1000
+    n = torch.tensor([rank + 1, 0, U], dtype=torch.int32)
+    g_ids, g_frames, g_n = rdist.gather_hypotheses(ids, frames, n)
+    mx = rdist.max_over_ranks(float(rank + 1))
+    rdist.barrier()
+    torch.save((g_ids, g_frames, g_n, mx), os.path.join(out_dir, f"r{rank}.pt"))
+    rdist.shutdown()
+
+
+def test_gather_hypotheses_gloo_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_gather_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        g_ids, g_frames, g_n, mx = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
+        assert g_ids.shape == (6, 5) and mx == 2.0
+        assert g_ids[:, 0].tolist() == [0, 0, 0, 100, 100, 100]
+        assert torch.equal(g_frames, g_ids + 1000)
+        assert g_n.tolist() == [1, 0, 5, 2, 0, 5]

@@ -1,0 +1,108 @@
+"""CPU: the oracle against the committed golden fixture generated from the independent
+`transformers.models.parakeet` implementation (tests/golden/make_parakeet_golden.py), and the C
+greedy restatement against torch's own LSTM / greedy loop."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from reazonspeech_amd.runtime.config import TINY
+from reazonspeech_amd.runtime.weights import synthetic_state_dict
+from oracle import model as om, greedy as og
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parakeet_tiny.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def sd(gold):
+    return synthetic_state_dict(TINY, int(gold["seed"]), blank_bias=float(gold["blank_bias"]))
+
+
+def test_frontend_vs_hf(gold, sd):
+    feats, n = om.frontend(TINY, sd, torch.from_numpy(gold["audio"]), torch.from_numpy(gold["lengths"]))
+    assert n.tolist() == gold["hf_n_frames"].tolist()
+    hf = torch.from_numpy(gold["hf_feats"])[:, :feats.shape[1]]
+    assert (feats - hf).abs().max() <= 1e-4
+
+
+def test_encoder_and_joint_projection_vs_hf(gold, sd):
+    taps = {}
+    f, el = om.forward_to_joint(TINY, sd, torch.from_numpy(gold["audio"]), torch.from_numpy(gold["lengths"]),
+                                "fp32", taps)
+    assert el.tolist() == gold["hf_enc_lens"].tolist()
+    for b in range(2):
+        n = int(el[b])
+        assert (taps["enc"][b, :n] - torch.from_numpy(gold["hf_enc"])[b, :n]).abs().max() <= 1e-4
+        assert (f[b, :n] - torch.from_numpy(gold["hf_joint_enc"])[b, :n]).abs().max() <= 1e-4
+
+
+def test_greedy_c_vs_hf_and_torch(gold, sd):
+    f, el = om.forward_to_joint(TINY, sd, torch.from_numpy(gold["audio"]), torch.from_numpy(gold["lengths"]), "fp32")
+    c_out = og.rnnt_greedy(TINY, sd, f.numpy(), el.numpy())
+    t_out = om.greedy_torch(TINY, sd, f, el)
+    assert c_out == t_out
+    for b in range(2):
+        n = int(gold["hf_n_ids"][b])
+        assert c_out[b][0] == gold["hf_ids"][b, :n].tolist()
+        assert c_out[b][1] == gold["hf_frames"][b, :n].tolist()
+
+
+def test_greedy_c_vs_torch_random_inputs():
+    """diverse emissions: random joint-encoder tensors, ragged lengths, an empty utterance"""
+    sd = synthetic_state_dict(TINY, 11, blank_bias=3.2)
+    g = torch.Generator().manual_seed(2)
+    B, Tp = 9, 30
+    f = torch.randn((B, Tp, TINY.joint_hidden), generator=g) * 1.5
+    lens = torch.randint(1, Tp + 1, (B,), generator=g)
+    lens[2] = 0
+    c_out = og.rnnt_greedy(TINY, sd, f.numpy(), lens.numpy())
+    t_out = om.greedy_torch(TINY, sd, f, lens)
+    assert c_out == t_out
+    assert c_out[2] == ([], [])
+    assert sum(len(i) for i, _ in c_out) > 20
+    runs = max(sum(1 for x in fr if x == t) for _, fr in c_out for t in set(fr))
+    assert runs <= TINY.max_symbols
+
+
+def test_greedy_overflow_reported():
+    sd = synthetic_state_dict(TINY, 11, blank_bias=-5.0)     # emits max_symbols on every frame
+    f = torch.zeros((1, 4, TINY.joint_hidden))
+    with pytest.raises(RuntimeError):
+        og.rnnt_greedy(TINY, sd, f.numpy(), np.array([4]), u_max=7)
+    out = og.rnnt_greedy(TINY, sd, f.numpy(), np.array([4]))
+    assert len(out[0][0]) == 4 * TINY.max_symbols
+
+
+def test_exact_math_functions():
+    L = og.lib()
+    for x in np.linspace(-30, 30, 601):
+        x = float(np.float32(x))
+        assert abs(L.rs_oracle_expf(x) - math.exp(x)) <= 2e-7 * math.exp(x)
+        assert abs(L.rs_oracle_sigmoidf(x) - 1 / (1 + math.exp(-x))) <= 2e-7
+        assert abs(L.rs_oracle_tanhf(x) - math.tanh(x)) <= 3e-7
+    assert L.rs_oracle_expf(-1000.0) > 0 and math.isfinite(L.rs_oracle_expf(1000.0))
+
+
+def test_bf16_recipe_stays_close_to_fp32(gold, sd):
+    a, l = torch.from_numpy(gold["audio"]), torch.from_numpy(gold["lengths"])
+    f32, el = om.forward_to_joint(TINY, sd, a, l, "fp32")
+    f16, _ = om.forward_to_joint(TINY, sd, a, l, "bf16")
+    for b in range(2):
+        n = int(el[b])
+        assert (f32[b, :n] - f16[b, :n]).abs().max() <= 0.1
+
+
+def test_attention_window_predicate():
+    cfg = TINY.with_(att_left=2, att_right=1, n_global=1)
+    allowed = om.attention_allowed(cfg, 6, torch.tensor([6, 4]))
+    a = allowed[0]
+    assert a[3, 1] and a[3, 4] and not a[3, 5] and not a[4, 1]      # |i-j| window
+    assert a[5, 0] and a[0, 5]                                        # global token 0
+    assert not allowed[1][:, 4:].any() and not allowed[1][4:, :].any()  # padding
