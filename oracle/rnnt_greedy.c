@@ -12,7 +12,8 @@
  *
  * Float32 with a FIXED accumulation order — the same one the HIP kernels use
  * (reazonspeech_amd/csrc/k_rnnt.hip) so that token ids can be compared bit for bit:
- *   dot(a, w, K) = ((p0 + p1) + p2) + p3,  p_s = chain over slice s of K/4 contiguous k,
+ *   dot(a, w, K) = ((p0 + p1) + p2) + .. ,  p_s = chain over slice s of K/S contiguous k
+ *   (S = 8 for the LSTM gate products, 4 for the joint and prediction projections),
  *   chain order inside a slice: for u in 16-blocks: for e in 0..3: for kk in 0..3: k = base+16u+4kk+e,
  *   each step acc = fmaf(a[k], w[k], acc) starting from 0.
  * exp/sigmoid/tanh are the same polynomial (only + - * / and fmaf).
@@ -23,7 +24,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define SPLITK 4
+#define SPLITK_LSTM 8   /* K slices of the LSTM gate products */
+#define SPLITK_TILE 4   /* K slices of the joint / prediction projections */
+#define SPLITK_MAX 8
 
 static inline float rs_expf(float x) {
     x = fminf(fmaxf(x, -87.0f), 88.0f);
@@ -51,10 +54,10 @@ float rs_oracle_sigmoidf(float x) { return rs_sigmoidf(x); }
 float rs_oracle_tanhf(float x) { return rs_tanhf(x); }
 
 /* a may be the concatenation of two vectors: a0[0..K0) then a1[0..K-K0) */
-static inline float dot_ordered2(const float* a0, int K0, const float* a1, const float* w, int K) {
-    float part[SPLITK];
-    const int ks = K / SPLITK;
-    for (int s = 0; s < SPLITK; ++s) {
+static inline float dot_ordered2(const float* a0, int K0, const float* a1, const float* w, int K, int splitk) {
+    float part[SPLITK_MAX];
+    const int ks = K / splitk;
+    for (int s = 0; s < splitk; ++s) {
         float acc = 0.0f;
         const int base = s * ks;
         for (int u = 0; u < ks; u += 16)
@@ -66,10 +69,12 @@ static inline float dot_ordered2(const float* a0, int K0, const float* a1, const
                 }
         part[s] = acc;
     }
-    return ((part[0] + part[1]) + part[2]) + part[3];
+    float sum = part[0];
+    for (int s = 1; s < splitk; ++s) sum = sum + part[s];
+    return sum;
 }
 
-float rs_oracle_dot(const float* a, const float* w, int K) { return dot_ordered2(a, K, a, w, K); }
+float rs_oracle_dot(const float* a, const float* w, int K) { return dot_ordered2(a, K, a, w, K, SPLITK_TILE); }
 
 /* one LSTM layer step for one row: x[H], h[H], c[H] -> h_out[H], c_out[H]; W [4H][2H] = [W_ih | W_hh],
  * bias [4H] = b_ih + b_hh (summed in float32 on the host, same as the device weight prep) */
@@ -78,7 +83,7 @@ void rs_oracle_lstm_step(const float* x, const float* h, const float* c, const f
     const int K = 2 * H;
     for (int u = 0; u < H; ++u) {
         float z[4];
-        for (int g = 0; g < 4; ++g) z[g] = dot_ordered2(x, H, h, W + (size_t)(g * H + u) * K, K) + bias[g * H + u];
+        for (int g = 0; g < 4; ++g) z[g] = dot_ordered2(x, H, h, W + (size_t)(g * H + u) * K, K, SPLITK_LSTM) + bias[g * H + u];
         const float ig = rs_sigmoidf(z[0]), fg = rs_sigmoidf(z[1]), gg = rs_tanhf(z[2]), og = rs_sigmoidf(z[3]);
         const float cn = fmaf(fg, c[u], ig * gg);
         c_out[u] = cn;

@@ -2,27 +2,27 @@
 //
 //   out[M][N] = epilogue( A[M][K] . W[N][K]^T )        A, W row-major bf16 (K contiguous)
 //
-// This one kernel carries every dense contraction of the encoder (SURVEY.md §8a rows S2-S4,
-// L2, L3, L6 pw1/pw2, D1): 96.8 % of the path's FLOPs.  Structure:
-//   * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
-//     2x2 blocks of v_mfma_f32_32x32x16_bf16), BK = 64.
-//   * operands go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double
-//     buffered: the DMA of K-tile t+1 is in flight while tile t is multiplied.
-//   * LDS rows are 128 B (64 bf16); 16-B chunks are XOR-swizzled with ((row>>1)&7) so the
-//     ds_read_b128 fragment reads (32 rows x one chunk per half-wave) hit 16 distinct
-//     4-bank slots per 16-lane group: conflict free.  global_load_lds writes LDS linearly,
-//     so the swizzle is applied to the per-lane SOURCE address and again on the read.
-//   * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs (private L2) walks a
-//     contiguous run of tiles, n-fastest, so an XCD reads each A row-panel once.
-//   * epilogue fused in registers: +bias, ReLU/SiLU, *alpha, +residual (f32), per-utterance
-//     row mask, store bf16 or f32.
+// This one kernel family carries every dense contraction of the encoder (SURVEY.md §8a rows
+// S2-S4, L2, L3, L6 pw1/pw2, D1): 96.8 % of the path's FLOPs.  Structure (template parameters):
+//   * BM x BN output tile per workgroup, WM x WN waves, each wave (BM/WM) x (BN/WN) as blocks of
+//     v_mfma_f32_32x32x16_bf16; BK-deep K steps through an NST-stage LDS ring.
+//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip).  With NST > 2
+//     the loads of the next NST-2 stages stay in flight across the (raw) s_barrier: the wait is a
+//     COUNTED s_waitcnt vmcnt(n), never a drain (guide §5 T3+T4).
+//   * LDS rows are BK bf16; 16-byte chunks are XOR-swizzled by row so the ds_read_b128 fragment
+//     reads (32 rows x one chunk per half-wave) are bank-conflict free.  global_load_lds writes
+//     LDS linearly, so the swizzle is applied to the per-lane SOURCE address and again on the read.
+//   * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs (private L2) walks a contiguous
+//     run of tiles, n-fastest, so an XCD reads each A row-panel once.
+//   * epilogue in registers: the weight fragment is the MFMA A operand, so each lane ends up with
+//     4 consecutive output columns per register quad (row-per-lane layout): +bias, ReLU/SiLU,
+//     *alpha, +residual (f32, prefetched per 32x32 block), per-utterance row mask, 16-byte f32 /
+//     8-byte bf16 stores, no LDS round trip.
+#include <stdlib.h>
+
 #include "rs_common.h"
 
 namespace {
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int NTHREADS = 256;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 struct GemmParams {
     const uint16_t* A; const uint16_t* W; void* out;
@@ -31,38 +31,76 @@ struct GemmParams {
     float alpha;
     int mask_rows_per_step, mask_steps;
     int tiles_m, tiles_n;
+    int skew_cycles;   // one-off start delay of every second dispatch round (see launch_variant)
 };
 
-__device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ base, int ld, int row0, int max_row,
-                                           int k0, char* lds_tile, int wave, int lane) {
-    // 16 wave-instructions cover 128 rows x 128 B; wave w issues 4 of them (8 rows each).
-    const int r = lane >> 3, pc = lane & 7;
+template <int BK>
+struct Swz {
+    // 16-byte chunks per row and the row-dependent XOR that spreads a 16-lane read group over all
+    // 64 banks (BK=64: rows alternate bank halves -> use (row>>1)&7; BK=32: 4 rows per 256 B bank
+    // row -> use (row>>2)&3).
+    static constexpr int CHUNKS = BK / 8;
+    static constexpr int ROW_BYTES = BK * 2;
+    __device__ static __forceinline__ int x(int row) {
+        return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+    }
+};
+
+template <int BK, int ROWS, int NWAVES>
+__device__ __forceinline__ void stage_rows(const uint16_t* __restrict__ base, int ld, int row0, int max_row, int k0,
+                                           char* lds_tile, int wave, int lane) {
+    using S = Swz<BK>;
+    constexpr int ROWS_PER_INST = 1024 / S::ROW_BYTES;       // 8 (BK=64) or 16 (BK=32)
+    constexpr int INSTS = ROWS / ROWS_PER_INST;
+    constexpr int PER_WAVE = INSTS / NWAVES;
+    static_assert(INSTS % NWAVES == 0, "tile rows must split evenly over the waves");
+    const int r = lane / S::CHUNKS, pc = lane % S::CHUNKS;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wave * 32 + j * 8 + r;
-        const int c = pc ^ ((row >> 1) & 7);
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int rbase = (wave * PER_WAVE + j) * ROWS_PER_INST;
+        const int row = rbase + r;
+        const int c = pc ^ S::x(row);
         int grow = row0 + row;
         grow = grow < max_row ? grow : max_row - 1;
         const uint16_t* src = base + (size_t)grow * ld + k0 + c * 8;
-        char* dst = lds_tile + (wave * 32 + j * 8) * 128;  // wave-uniform; HW adds lane*16
+        char* dst = lds_tile + rbase * S::ROW_BYTES;  // wave-uniform; HW adds lane*16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
 }
 
+template <int BK>
 __device__ __forceinline__ bf16x8_t read_frag(const char* lds_tile, int row, int chunk) {
-    const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    using S = Swz<BK>;
+    const int off = row * S::ROW_BYTES + ((chunk ^ S::x(row)) << 4);
     return *reinterpret_cast<const bf16x8_t*>(lds_tile + off);
 }
 
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N < 0, "add the vmcnt literal");
+}
+
+template <int BM, int BN, int BK, int NST, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmParams p) {
+    constexpr int NWAVES = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int LOADS_PER_STAGE = STAGE_BYTES / 1024 / NWAVES;   // global_load_lds per wave per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                   // [2][TILE_BYTES]
-    char* Bs = smem + 2 * TILE_BYTES;  // [2][TILE_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware, bijective remap (blocks b, b+8, b+16.. share an XCD)
     const int nwg = p.tiles_m * p.tiles_n;
@@ -73,105 +111,209 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
     const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    // De-synchronise the workgroups that share a CU: all tiles cost the same, so without this every
+    // CU of the chip alternates in lockstep between "all MFMA" and "all stores".  Workgroups of the
+    // second dispatch round (the second resident workgroup of each CU) start half a tile late, once;
+    // from then on one workgroup's epilogue overlaps its neighbour's main loop.
+    if (p.skew_cycles > 0 && bid >= 256 && bid < 512) {
+        const long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < p.skew_cycles) __builtin_amdgcn_s_sleep(8);
+    }
+
     const int nk = p.K / BK;
-    stage_tile(p.A, p.lda, m0, p.M, 0, As, wave, lane);
-    stage_tile(p.W, p.ldw, n0, p.N, 0, Bs, wave, lane);
+    auto issue = [&](int t) {
+        char* st = smem + (t % NST) * STAGE_BYTES;
+        stage_rows<BK, BM, NWAVES>(p.A, p.lda, m0, p.M, t * BK, st, wave, lane);
+        stage_rows<BK, BN, NWAVES>(p.W, p.ldw, n0, p.N, t * BK, st + A_BYTES, wave, lane);
+    };
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) issue(t);
 
     const int frow = lane & 31, fhalf = lane >> 5;
+    constexpr int KS = BK / 16;
     for (int t = 0; t < nk; ++t) {
-        __syncthreads();  // tile t landed (vmcnt(0) inside) and buffer (t+1)&1 is free
-        const int cur = t & 1;
-        if (t + 1 < nk) {
-            stage_tile(p.A, p.lda, m0, p.M, (t + 1) * BK, As + (cur ^ 1) * TILE_BYTES, wave, lane);
-            stage_tile(p.W, p.ldw, n0, p.N, (t + 1) * BK, Bs + (cur ^ 1) * TILE_BYTES, wave, lane);
-        }
-        const char* at = As + cur * TILE_BYTES;
-        const char* bt = Bs + cur * TILE_BYTES;
+        // stage t must have landed: at most NST-2 younger stages may still be in flight
+        if (t + NST - 2 < nk) wait_vmcnt<LOADS_PER_STAGE * (NST - 2)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // everyone's part of stage t is in LDS; stage t-1's buffer is free
+        const char* at = smem + (t % NST) * STAGE_BYTES;
+        const char* bt = at + A_BYTES;
+        // software pipeline over the k sub-steps: the fragments of ks+1 are requested from LDS before
+        // the MFMAs of ks issue, and the next stage's DMA is issued under the first fragment reads
+        bf16x8_t af[2][MI], bfr[2][NI];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8_t af[2], bfr[2];
+        for (int i = 0; i < MI; ++i) af[0][i] = read_frag<BK>(at, wm * TM + i * 32 + frow, fhalf);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = read_frag(at, wm * 64 + i * 32 + frow, ks * 2 + fhalf);
+        for (int j = 0; j < NI; ++j) bfr[0][j] = read_frag<BK>(bt, wn * TN + j * 32 + frow, fhalf);
+        if (t + NST - 1 < nk) issue(t + NST - 1);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = read_frag(bt, wn * 64 + j * 32 + frow, ks * 2 + fhalf);
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < KS) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i) af[nxt][i] = read_frag<BK>(at, wm * TM + i * 32 + frow, (ks + 1) * 2 + fhalf);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) bfr[nxt][j] = read_frag<BK>(bt, wn * TN + j * 32 + frow, (ks + 1) * 2 + fhalf);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
 
-    // ---- epilogue: C layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue, straight from registers.  The MFMAs ran with the weight fragment as the A operand,
+    // so D = (A.W^T)^T: lane = (m = lane&31, half h), register r <-> n = (r&3) + 8*(r>>2) + 4*h.  Each
+    // lane therefore owns 4 consecutive n per register quad: one 16-byte f32 (8-byte bf16) access,
+    // two lanes (h = 0,1) cover a contiguous 32-byte (16-byte) run of one output row.
     const int flags = p.flags;
     const bool has_bias = flags & RS_GEMM_BIAS, relu = flags & RS_GEMM_RELU, silu = flags & RS_GEMM_SILU;
     const bool has_res = flags & RS_GEMM_RESIDUAL, out_f32 = flags & RS_GEMM_OUT_F32;
     const bool rowmask = flags & RS_GEMM_ROWMASK;
+    const float alpha = p.alpha;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-        const bool n_ok = n < p.N;
-        const float bv = (has_bias && n_ok) ? p.bias[n] : 0.0f;
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * TM + i * 32 + frow;
+        const bool m_ok = m < p.M;
+        bool keep = true;
+        if (rowmask && m_ok) {
+            const int step = m / p.mask_rows_per_step;
+            const int b = step / p.mask_steps;
+            keep = step - b * p.mask_steps < p.mask_lens[b];
+        }
+        const size_t rowoff = (size_t)m * p.ldc;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < NI; ++j) {
+            const int nb = n0 + wn * TN + j * 32 + 4 * fhalf;
+            float4 rv[4];
+            if (has_res) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                if (!n_ok || m >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (relu) v = fmaxf(v, 0.0f);
-                if (silu) v = silu_f(v);
-                v *= p.alpha;
-                const size_t o = (size_t)m * p.ldc + n;
-                if (has_res) v += p.residual[o];
-                if (rowmask) {
-                    const int step = m / p.mask_rows_per_step;
-                    const int b = step / p.mask_steps;
-                    if (step - b * p.mask_steps >= p.mask_lens[b]) v = 0.0f;
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nb + 8 * g;
+                    rv[g] = (m_ok && n < p.N) ? *reinterpret_cast<const float4*>(p.residual + rowoff + n)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                if (out_f32) reinterpret_cast<float*>(p.out)[o] = v;
-                else reinterpret_cast<uint16_t*>(p.out)[o] = f32_to_bf16(v);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nb + 8 * g;
+                if (!m_ok || n >= p.N) continue;     // N % 4 == 0 is enforced by the launcher
+                float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                if (has_bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+                if (has_res) { v.x += rv[g].x; v.y += rv[g].y; v.z += rv[g].z; v.w += rv[g].w; }
+                if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (out_f32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + rowoff + n) = v;
+                } else {
+                    *reinterpret_cast<u16x4_t*>(reinterpret_cast<uint16_t*>(p.out) + rowoff + n) =
+                        pack_bf16x4(v.x, v.y, v.z, v.w);
+                }
             }
         }
     }
 }
 
+extern int g_skew;
+
+template <int BM, int BN, int BK, int NST, int WM, int WN>
+int launch_variant(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    constexpr int LDS = NST * STAGE_BYTES;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    // half of one tile's main-loop time at ~1 PF/s, in shader cycles (2.4 GHz), only when two
+    // workgroups share a CU and there are enough tiles for the offset to matter
+    constexpr bool two_per_cu = NST * STAGE_BYTES <= 80 * 1024;
+    const double skew_frac = g_skew < 0 ? (two_per_cu ? 1.0 : 0.0) : g_skew / 100.0;   // in tile times
+    p.skew_cycles = (p.tiles_m * p.tiles_n >= 1024)
+                        ? (int)(skew_frac * (2.0 * BM * BN * (double)p.K / 1.0e15 * 256.0) * 2.4e9) : 0;
+    auto kern = gemm_bf16_kernel<BM, BN, BK, NST, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return rs_fail(ctx, RS_EHIP, "gemm: cannot reserve %d bytes of LDS", LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), LDS, s, p);
+    return RS_OK;
+}
+
+int g_variant = -1;
+int g_skew = -1;
+
 }  // namespace
+
+// tuning hook for A/B runs (scripts/gemm_bench.py); not part of the public header
+extern "C" void rs_debug_set_gemm_variant(int v) { g_variant = v; }
+extern "C" void rs_debug_set_gemm_skew(int v) { g_skew = v; }
 
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return rs_fail(ctx, RS_EINVAL, "gemm: empty shape %d %d %d", a.M, a.N, a.K);
-    if (a.K % BK) return rs_fail(ctx, RS_EINVAL, "gemm: K=%d must be a multiple of %d", a.K, BK);
-    if ((a.lda % 8) || (a.ldw % 8) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15))
+    if (a.K % 64) return rs_fail(ctx, RS_EINVAL, "gemm: K=%d must be a multiple of 64", a.K);
+    if (a.N % 4 || a.ldc % 4) return rs_fail(ctx, RS_EINVAL, "gemm: N=%d and ldc=%d must be multiples of 4", a.N, a.ldc);
+    if ((a.lda % 8) || (a.ldw % 8) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.out & 15))
         return rs_fail(ctx, RS_EINVAL, "gemm: operands must be 16-byte aligned (lda %d ldw %d)", a.lda, a.ldw);
     if ((a.flags & RS_GEMM_ROWMASK) && (!a.mask_lens || a.mask_rows_per_step <= 0 || a.mask_steps <= 0))
         return rs_fail(ctx, RS_EINVAL, "gemm: row mask requested without lens");
-    if ((a.flags & RS_GEMM_BIAS) && !a.bias) return rs_fail(ctx, RS_EINVAL, "gemm: bias flag without pointer");
-    if ((a.flags & RS_GEMM_RESIDUAL) && !a.residual) return rs_fail(ctx, RS_EINVAL, "gemm: residual flag without pointer");
+    if ((a.flags & RS_GEMM_BIAS) && (!a.bias || ((uintptr_t)a.bias & 15)))
+        return rs_fail(ctx, RS_EINVAL, "gemm: bias flag without a 16-byte aligned pointer");
+    if ((a.flags & RS_GEMM_RESIDUAL) && (!a.residual || ((uintptr_t)a.residual & 15)))
+        return rs_fail(ctx, RS_EINVAL, "gemm: residual flag without a 16-byte aligned pointer");
     GemmParams p;
     p.A = a.A; p.W = a.W; p.out = a.out; p.bias = a.bias; p.residual = a.residual; p.mask_lens = a.mask_lens;
     p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K; p.flags = a.flags;
     p.alpha = a.alpha; p.mask_rows_per_step = a.mask_rows_per_step; p.mask_steps = a.mask_steps;
-    p.tiles_m = (a.M + BM - 1) / BM; p.tiles_n = (a.N + BN - 1) / BN;
-    const int nwg = p.tiles_m * p.tiles_n;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-        attr_set = true;
+    p.tiles_m = p.tiles_n = 0;
+    if (g_variant < 0) {
+        const char* e = getenv("RS_GEMM_VARIANT");   // tuning knob for A/B runs; default chosen by shape
+        g_variant = e ? atoi(e) : 0;
     }
     const double flops = 2.0 * a.M * (double)a.N * a.K;
     const double bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                          (double)a.M * a.N * ((a.flags & RS_GEMM_OUT_F32) ? 4 : 2);
     rs_prof_begin(ctx, RS_PROF_GEMM, s, flops, bytes);
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(nwg), dim3(NTHREADS), 4 * TILE_BYTES, s, p);
+    int rc;
+    int v = g_variant;
+    if (v == 0) {
+        // measured on MI355X (profiles/r01_gemm_variants.txt): the 256x256 tile wins whenever there
+        // are enough tiles to fill the chip a few times; narrow-N / short-K problems prefer the
+        // 128x128 3-stage kernel (3 workgroups per CU hide its epilogue better)
+        const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+        if (a.M < 1024 || a.N < 256) v = 1;
+        else if (tiles256 < 1024 && a.K <= 1024) v = 7;
+        else v = 2;
+    }
+    switch (v) {
+        case 1: rc = launch_variant<128, 128, 64, 2, 2, 2>(ctx, p, s); break;   // small problems
+        case 2: rc = launch_variant<256, 256, 64, 2, 2, 4>(ctx, p, s); break;   // big tile, drain per K step
+        case 3: rc = launch_variant<256, 256, 32, 4, 2, 4>(ctx, p, s); break;   // big tile, 4-stage ring, counted vmcnt
+        case 4: rc = launch_variant<128, 128, 32, 4, 2, 2>(ctx, p, s); break;
+        case 5: rc = launch_variant<256, 128, 32, 4, 4, 2>(ctx, p, s); break;
+        case 6: rc = launch_variant<256, 128, 32, 3, 2, 2>(ctx, p, s); break;   // 2 independent WGs per CU
+        case 7: rc = launch_variant<128, 128, 32, 3, 2, 2>(ctx, p, s); break;   // 3 WGs per CU
+        case 8: rc = launch_variant<256, 128, 64, 2, 2, 2>(ctx, p, s); break;
+        default: rc = rs_fail(ctx, RS_EINVAL, "gemm: unknown RS_GEMM_VARIANT %d", v);
+    }
     rs_prof_end(ctx, RS_PROF_GEMM, s);
+    if (rc != RS_OK) return rc;
     RS_CHECK_LAUNCH(ctx, "gemm_bf16");
     return RS_OK;
 }

@@ -21,12 +21,15 @@ typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float bf16_to_f32(unsigned short v) {
     return __uint_as_float(((unsigned)v) << 16);
 }
-// round-to-nearest-even, NaN preserved as quiet NaN (same as torch .to(bfloat16))
+// round-to-nearest-even (same as torch .to(bfloat16)); lowers to v_cvt_pk_bf16_f32 on gfx950
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+__device__ __forceinline__ u16x4_t pack_bf16x4(float a, float b, float c, float d) {
+    const f32x4_t v = {a, b, c, d};
+    return __builtin_bit_cast(u16x4_t, __builtin_convertvector(v, bf16x4_t));
 }
 __device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 

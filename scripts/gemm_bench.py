@@ -1,0 +1,76 @@
+"""A/B the GEMM kernel variants on the shapes of the 619M encoder (run on the GPU box).
+
+    python scripts/gemm_bench.py [variants...]
+Prints per shape and variant: correctness vs a torch bf16 matmul, median microseconds, TFLOP/s.
+"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reazonspeech_amd.runtime import capi                     # noqa: E402
+from reazonspeech_amd.runtime.config import FASTCONFORMER_619M  # noqa: E402
+
+M = 35328
+SHAPES = [  # name, M, N, K, flags
+    ("ffn_up  silu->bf16", M, 4096, 1024, capi.GEMM_BIAS | capi.GEMM_SILU),
+    ("ffn_down res->f32 ", M, 1024, 4096, capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32),
+    ("qkv     bias->bf16", M, 3072, 1024, capi.GEMM_BIAS),
+    ("out/pw2 res->f32  ", M, 1024, 1024, capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32),
+    ("pw1     bias->bf16", M, 2048, 1024, capi.GEMM_BIAS),
+    ("sub_pw1 relu->bf16", 256 * 275 * 20, 256, 256, capi.GEMM_BIAS | capi.GEMM_RELU),
+    ("sub_out ->f32     ", M, 1024, 2560, capi.GEMM_BIAS | capi.GEMM_OUT_F32),
+]
+
+
+def main():
+    quick = "--quick" in sys.argv
+    variants = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [1, 2, 3, 4, 5]
+    dev = torch.device("cuda", 0)
+    ctx = capi.Context(FASTCONFORMER_619M, 0)
+    setv = ctx.lib.rs_debug_set_gemm_variant
+    setv.argtypes = [ctypes.c_int]
+    setv.restype = None
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for name, m, n, k, flags in SHAPES:
+        A = torch.randn((m, k), generator=g).to(torch.bfloat16).to(dev)
+        W = (torch.randn((n, k), generator=g) / k ** 0.5).to(torch.bfloat16).to(dev)
+        bias = torch.randn((n,), generator=g).to(dev)
+        res = torch.randn((m, n), generator=g).to(dev) if flags & capi.GEMM_RESIDUAL else None
+        out = torch.empty((m, n), dtype=torch.float32 if flags & capi.GEMM_OUT_F32 else torch.bfloat16, device=dev)
+        ref = A[:4096].float() @ W.float().t() + bias
+        if flags & capi.GEMM_SILU:
+            ref = torch.nn.functional.silu(ref)
+        if flags & capi.GEMM_RELU:
+            ref = torch.relu(ref)
+        if res is not None:
+            ref = ref + res[:4096]
+        for v in variants:
+            setv(v)
+            try:
+                ctx.gemm(A, W, out, flags=flags, bias=bias, residual=res)
+                torch.cuda.synchronize()
+            except capi.RsError as e:
+                print(f"{name} v{v}: {e}")
+                continue
+            err = (out[:4096].float() - ref).abs().max().item()
+            ts = []
+            for _ in range(1 if quick else 7):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(1 if quick else 4):
+                    ctx.gemm(A, W, out, flags=flags, bias=bias, residual=res)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / (1 if quick else 4))
+            ts.sort()
+            us = ts[len(ts) // 2] * 1e3
+            print(f"{name} M{m} N{n} K{k} v{v}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
+        del A, W, out, res
+    setv(0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,29 @@
+"""Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel table.
+
+    python scripts/rocprof_summary.py gpurun_out/prof_X/trace_results.db [steps] > profiles/<name>.txt
+"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sys.argv[1]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    rows = cur.execute(f"select {name_col}, count(*), sum(end - start), avg(end - start), min(end - start), "
+                       f"max(end - start) from kernels group by {name_col} order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows)
+    print(f"# rocprofv3 --kernel-trace summary of {db}")
+    print(f"# total kernel time {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches"
+          + (f"; {steps + 1} bench steps incl. 1 warm-up" if steps else ""))
+    print(f"{'kernel':<64} {'calls':>7} {'total_ms':>10} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'share':>6}")
+    for n, c, s, a, mn, mx in rows:
+        short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        print(f"{short[:64]:<64} {c:>7} {s / 1e6:>10.3f} {a / 1e3:>10.2f} {mn / 1e3:>9.2f} {mx / 1e3:>9.2f} {s / total:>6.1%}")
+
+
+if __name__ == "__main__":
+    main()
