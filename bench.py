@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="debug: 2-layer toy config (NOT a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run encoder and decode of each batch back to back on one stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,18 +105,35 @@ def main():
     t0 = time.time()
     sd = synthetic_state_dict(cfg, seed=0)
     model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device=f"cuda:{local_rank}")
-    audio, lens = synthetic_batch(args.batch, args.seconds, seed=1234 + rank)
-    buf = model.stage([audio[b, :lens[b]] for b in range(args.batch)])
-    torch.cuda.synchronize()
+    # two resident batches (different utterances): the pipelined path alternates between them
+    bufs, lens_all = [], []
+    for k in range(2):
+        audio, lens = synthetic_batch(args.batch, args.seconds, seed=1234 + 17 * rank + 1000 * k)
+        b = model.stage([audio[i, :lens[i]] for i in range(args.batch)],
+                        buf=model.new_buffers(args.batch, int(args.seconds * 16000)))
+        torch.cuda.synchronize()
+        bufs.append(b)
+        lens_all.append(lens)
+    buf = bufs[0]
+    audio0, lens0 = synthetic_batch(args.batch, args.seconds, seed=1234 + 17 * rank)
     setup_s = time.time() - t0
+    pipelined = not args.no_pipeline
 
-    def step():
-        model.run_device(buf)
+    def gather(bf):
         if world > 1:
-            rdist.gather_hypotheses(buf.ids, buf.frames, buf.n_ids)
+            rdist.gather_hypotheses(bf.ids, bf.frames, bf.n_ids)
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n):
+        if pipelined:
+            model.run_pipelined(bufs, n, after_decode=None)
+            for i in range(n):                      # one collective per step, as the path defines it
+                gather(bufs[i % 2])
+        else:
+            for i in range(n):
+                model.run_device(bufs[i % 2])
+                gather(bufs[i % 2])
+
+    run_steps(args.warmup)
     prof = not args.no_profile
     if prof:
         model.ctx.profile_reset()
@@ -122,8 +141,7 @@ def main():
     rdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     rdist.barrier()
     dt = time.perf_counter() - t0
@@ -131,9 +149,9 @@ def main():
     model.ctx.profile_enable(0)
     dt = rdist.max_over_ranks(dt)
 
-    n_ids = buf.n_ids.cpu().numpy()
+    n_ids = np.concatenate([b.n_ids.cpu().numpy() for b in bufs])
     mean_tokens = float(n_ids.mean())
-    audio_seconds = float(lens.sum()) / 16000.0 * world * args.steps
+    audio_seconds = sum(float(lens_all[i % 2].sum()) for i in range(args.steps)) / 16000.0 * world
     value = audio_seconds / dt
 
     if rank == 0:
@@ -146,7 +164,10 @@ def main():
                                    f"{args.seconds:g} s utterances per GPU (+0.5 s pad each side), greedy decode, "
                                    "random-init weights", "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "parallelism": f"dp{world}",
-                       "enc_frames": buf.tp_max, "mean_tokens_per_utt": round(mean_tokens, 1)},
+                       "enc_frames": buf.tp_max, "mean_tokens_per_utt": round(mean_tokens, 1),
+                       "max_tokens_per_utt": int(n_ids.max()),
+                       "schedule": "2-stage pipeline: encoder(i+1) || greedy decode(i) on two HIP streams"
+                                   if pipelined else "sequential"},
             "setup_s": round(setup_s, 1),
         }
         gf = algorithmic_gflop_per_utt(cfg, buf.tp_max, mean_tokens)
@@ -160,9 +181,9 @@ def main():
                                "launches": gemm["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
                                "share_of_step": round(gemm["ms"] / (dt * 1e3), 3)}
         if world == 1 and not args.no_cpu_baseline and not args.tiny:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, audio, lens)
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, audio0, lens0)
         elif world == 1 and args.tiny and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, audio, lens, seconds_budget=5.0, max_utt=2)
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, audio0, lens0, seconds_budget=5.0, max_utt=2)
         print(json.dumps(out), flush=True)
     rdist.shutdown()
 

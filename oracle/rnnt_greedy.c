@@ -13,7 +13,7 @@
  * Float32 with a FIXED accumulation order — the same one the HIP kernels use
  * (reazonspeech_amd/csrc/k_rnnt.hip) so that token ids can be compared bit for bit:
  *   dot(a, w, K) = ((p0 + p1) + p2) + .. ,  p_s = chain over slice s of K/S contiguous k
- *   (S = 8 for the LSTM gate products, 4 for the joint and prediction projections),
+ *   (S = 16 for the LSTM gate products, 8 for the joint and prediction projections),
  *   chain order inside a slice: for u in 16-blocks: for e in 0..3: for kk in 0..3: k = base+16u+4kk+e,
  *   each step acc = fmaf(a[k], w[k], acc) starting from 0.
  * exp/sigmoid/tanh are the same polynomial (only + - * / and fmaf).
@@ -24,9 +24,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define SPLITK_LSTM 8   /* K slices of the LSTM gate products */
-#define SPLITK_TILE 4   /* K slices of the joint / prediction projections */
-#define SPLITK_MAX 8
+#define SPLITK_LSTM 16  /* K slices of the LSTM gate products */
+#define SPLITK_TILE 8   /* K slices of the joint / prediction projections */
+#define SPLITK_MAX 16
 
 static inline float rs_expf(float x) {
     x = fminf(fmaxf(x, -87.0f), 88.0f);

@@ -5,7 +5,7 @@
 // Everything here is EXACT float32 with a fixed accumulation order, so that greedy token ids can
 // be compared bit-for-bit with oracle/rnnt_greedy.c:
 //   * dot products run on v_mfma_f32_16x16x4_f32 (exact f32 fma chain, guide §3); every output is
-//     S partial chains over contiguous K slices (S = 8 for the LSTM gates, 4 for the joint and the
+//     S partial chains over contiguous K slices (S = 16 for the LSTM gates, 8 for the joint and the
 //     prediction projection), slice s accumulating from 0 in the order
 //         for u in 16-blocks: for e in 0..3: for kk in 0..3:  k = base_s + 16u + 4kk + e
 //     (what a lane's float4 loads feed the MFMA), combined left to right ((p0 + p1) + p2) + ..,
@@ -22,8 +22,8 @@
 
 namespace {
 
-constexpr int SPLITK_LSTM = 8;   // K slices of the LSTM gate products
-constexpr int SPLITK_TILE = 4;   // K slices of the joint / prediction projections
+constexpr int SPLITK_LSTM = 16;  // K slices of the LSTM gate products
+constexpr int SPLITK_TILE = 8;   // K slices of the joint / prediction projections
 
 // ---- exact-order math (mirrored verbatim in oracle/rnnt_greedy.c) --------------------------------
 __device__ __forceinline__ float rs_expf(float x) {
@@ -44,6 +44,20 @@ __device__ __forceinline__ float rs_expf(float x) {
 }
 __device__ __forceinline__ float rs_sigmoidf(float x) { return 1.0f / (1.0f + rs_expf(-x)); }
 __device__ __forceinline__ float rs_tanhf(float x) { return 1.0f - 2.0f / (rs_expf(2.0f * x) + 1.0f); }
+
+// Activation rows are gathered by index, so a lane-per-row load (what the MFMA A operand wants:
+// lane = row + 16*kk) would be 64 separate 16-byte requests per instruction and the texture
+// addresser, not the MFMA pipe, would set the pace.  Instead lane l loads (row l>>2, 16-byte chunk
+// l&3) — four adjacent lanes cover one contiguous 64-byte run — and one ds_bpermute per dword moves
+// the data to the MFMA layout: lane m = (li, kk) takes it from lane 4*li + kk.
+__device__ __forceinline__ float4 to_mfma_a_layout(float4 v, int src_lane_bytes) {
+    float4 r;
+    r.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_bytes, __float_as_int(v.x)));
+    r.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_bytes, __float_as_int(v.y)));
+    r.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_bytes, __float_as_int(v.z)));
+    r.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_bytes, __float_as_int(v.w)));
+    return r;
+}
 
 struct DecodeState {
     // per-row state (B rows)
@@ -79,14 +93,18 @@ __global__ void rnnt_init_kernel(DecodeState st, const int32_t* __restrict__ enc
 }
 
 // ---- LSTM layer: gates = [x ; h_prev] . [W_ih | W_hh]^T + b, cell update ---------------------------
-// grid (H/16 unit tiles, ceil(B/32) row tiles); block 512 = 8 waves = the 8 K slices of one
-// [32 rows] x [16 units x 4 gates] output tile (rows come from the compacted `act` list).
-__global__ __launch_bounds__(512) void rnnt_lstm_kernel(DecodeState st, int layer, int B, int H,
+// grid (H/16 unit tiles, ceil(B/32) row tiles); block 1024 = 16 waves = the 16 K slices of one
+// [32 rows] x [16 units x 4 gates] output tile (rows come from the compacted `act` list).  Short
+// per-wave chains matter more than anything else here: a decode step is a dependency chain of
+// five small launches, so each kernel's latency is what the batch pays.
+__global__ __launch_bounds__(1024) void rnnt_lstm_kernel(DecodeState st, int layer, int B, int H,
                                                         const float* __restrict__ embed,
                                                         const float* __restrict__ W /* [4H][2H] */,
                                                         const float* __restrict__ bias /* [4H] = b_ih + b_hh */) {
-    __shared__ float part[SPLITK_LSTM][4][32][16];   // 64 KiB; 4 rows x 16 lanes = 64 consecutive floats per store: conflict free
-    __shared__ int rows_s[32];
+    extern __shared__ __attribute__((aligned(16))) char lstm_smem[];
+    // [SPLITK_LSTM][4][32][16] floats = 128 KiB; 4 rows x 16 lanes = 64 consecutive floats per store: conflict free
+    float (*part)[4][32][16] = reinterpret_cast<float (*)[4][32][16]>(lstm_smem);
+    int* rows_s = reinterpret_cast<int*>(lstm_smem + SPLITK_LSTM * 4 * 32 * 16 * 4);
     const int n_act = st.counters[0];
     const int rt = blockIdx.y, ut = blockIdx.x;
     if (rt * 32 >= n_act) return;
@@ -97,42 +115,66 @@ __global__ __launch_bounds__(512) void rnnt_lstm_kernel(DecodeState st, int laye
     }
     __syncthreads();
     const int li = lane & 15, kk = lane >> 4;
-    const int K = 2 * H, kslice = K / SPLITK_LSTM;
+    const int lr = lane >> 2, lc = lane & 3;             // load mapping: row, 16-byte chunk
+    const int perm = 4 * (4 * li + kk);                   // bpermute source lane (bytes)
+    const int K = 2 * H, kslice = K / SPLITK_LSTM, nkb = K / 16;
     const float* xsrc[2];
     const float* hsrc[2];
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri) {
-        const int row = rows_s[ri * 16 + li];
+        const int row = rows_s[ri * 16 + lr];
         xsrc[ri] = layer == 0 ? embed + (size_t)st.token[row] * H : st.h_tmp + ((size_t)(layer - 1) * B + row) * H;
         hsrc[ri] = st.h + ((size_t)layer * B + row) * H;
     }
-    const float* wrow[4];
+    // weights are stored fragment-major (weights.py: to_fragment_major): [n/16][k/16][lane][4]
+    const float* wfrag[4];
 #pragma unroll
-    for (int gt = 0; gt < 4; ++gt) wrow[gt] = W + (size_t)(gt * H + ut * 16 + li) * K;
+    for (int gt = 0; gt < 4; ++gt) wfrag[gt] = W + ((size_t)((gt * H) / 16 + ut) * nkb) * 256 + lane * 4;
     f32x4_t acc[2][4];
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt) acc[ri][gt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const int kbeg = wave * kslice;
-    for (int k0 = kbeg; k0 < kbeg + kslice; k0 += 16) {
-        const int k = k0 + 4 * kk;
-        float4 a[2], w[4];
+    // operands stream straight from L2 (row-strided 16-byte pieces): a 2-deep register prefetch keeps
+    // two k-blocks of loads in flight under the 32 MFMAs of the current one (one wave per SIMD here,
+    // so there is no other wave to hide the latency)
+    struct Frag { float4 a[2], w[4]; };
+    auto load = [&](int k0) {
+        Frag fr;
+        const int k = k0 + 4 * lc;
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri)
-            a[ri] = (k < H) ? *reinterpret_cast<const float4*>(xsrc[ri] + k)
-                            : *reinterpret_cast<const float4*>(hsrc[ri] + (k - H));
+            fr.a[ri] = (k < H) ? *reinterpret_cast<const float4*>(xsrc[ri] + k)
+                               : *reinterpret_cast<const float4*>(hsrc[ri] + (k - H));
 #pragma unroll
-        for (int gt = 0; gt < 4; ++gt) w[gt] = *reinterpret_cast<const float4*>(wrow[gt] + k);
+        for (int gt = 0; gt < 4; ++gt) fr.w[gt] = *reinterpret_cast<const float4*>(wfrag[gt] + (size_t)(k0 >> 4) * 256);
+        return fr;
+    };
+    auto compute = [&](const Frag& fin) {
+        Frag fr = fin;
 #pragma unroll
-        for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt) {
-                acc[ri][gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ri].x, w[gt].x, acc[ri][gt], 0, 0, 0);
-                acc[ri][gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ri].y, w[gt].y, acc[ri][gt], 0, 0, 0);
-                acc[ri][gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ri].z, w[gt].z, acc[ri][gt], 0, 0, 0);
-                acc[ri][gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ri].w, w[gt].w, acc[ri][gt], 0, 0, 0);
-            }
+        for (int ri = 0; ri < 2; ++ri) fr.a[ri] = to_mfma_a_layout(fin.a[ri], perm);
+        // e-major issue order: 8 independent accumulators between two MFMAs on the same one
+        // (the f32 16x16x4 MFMA has a 40-cycle dependent latency but a 32-cycle issue interval)
+#define RS_MFMA_E(c)                                                                                            \
+        _Pragma("unroll") for (int ri = 0; ri < 2; ++ri) _Pragma("unroll") for (int gt = 0; gt < 4; ++gt)      \
+            acc[ri][gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr.a[ri].c, fr.w[gt].c, acc[ri][gt], 0, 0, 0);
+        RS_MFMA_E(x) RS_MFMA_E(y) RS_MFMA_E(z) RS_MFMA_E(w)
+#undef RS_MFMA_E
+    };
+    const int kbeg = wave * kslice, nblk = kslice / 16;
+    {
+        Frag f0 = load(kbeg);
+        Frag f1 = nblk > 1 ? load(kbeg + 16) : f0;
+        int u = 0;
+        for (; u + 2 < nblk; ++u) {
+            const Frag f2 = load(kbeg + 16 * (u + 2));
+            compute(f0);
+            f0 = f1;
+            f1 = f2;
+        }
+        if (nblk >= 2) { compute(f0); f0 = f1; }
+        compute(f0);
     }
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri)
@@ -142,6 +184,7 @@ __global__ __launch_bounds__(512) void rnnt_lstm_kernel(DecodeState st, int laye
             for (int r = 0; r < 4; ++r) part[wave][gt][ri * 16 + 4 * kk + r][li] = acc[ri][gt][r];
     __syncthreads();
     // epilogue: thread = (row i, unit j)
+    if (tid >= 512) return;
     const int i = tid >> 4, j = tid & 15;
     if (rt * 32 + i >= n_act) return;
     const int brow = rows_s[i];
@@ -161,15 +204,16 @@ __global__ __launch_bounds__(512) void rnnt_lstm_kernel(DecodeState st, int laye
     st.h_tmp[o] = og * rs_tanhf(cn);
 }
 
-// ---- [32 rows] x [64 cols] tile of  out = W . a + bias  with the 4 K slices on the 4 waves --------------
+// ---- [32 rows] x [64 cols] tile of  out = W . a + bias  with the 8 K slices on the 8 waves --------------
 // MODE 0: prediction projection g = W_p . h_top + b_p over the `act` rows (+ LSTM state commit)
 // MODE 1: joint logits  W_o . relu(f[b][t_b] + g[b]) + b_o over the `alive` rows, per-tile argmax
 template <int MODE>
-__global__ __launch_bounds__(256) void rnnt_tile_kernel(DecodeState st, const float* __restrict__ f, int B, int Tp,
+__global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const float* __restrict__ f, int B, int Tp,
                                                         int L, int H, int K, int N, const float* __restrict__ W,
                                                         const float* __restrict__ bias, int n_ctiles, int step) {
-    __shared__ float part[SPLITK_TILE][32][65];
-    __shared__ int rows_s[32];
+    extern __shared__ __attribute__((aligned(16))) char tile_smem[];
+    float (*part)[32][65] = reinterpret_cast<float (*)[32][65]>(tile_smem);   // [SPLITK_TILE][32][65]
+    int* rows_s = reinterpret_cast<int*>(tile_smem + SPLITK_TILE * 32 * 65 * 4);
     const int rt = blockIdx.y, ct = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t* list = MODE == 0 ? st.act : st.alive + (size_t)(step & 1) * B;
@@ -185,11 +229,13 @@ __global__ __launch_bounds__(256) void rnnt_tile_kernel(DecodeState st, const fl
     }
     __syncthreads();
     const int li = lane & 15, kk = lane >> 4;
+    const int lr = lane >> 2, lc = lane & 3;             // load mapping: row, 16-byte chunk
+    const int perm = 4 * (4 * li + kk);                   // bpermute source lane (bytes)
     const float* asrc[2];
     const float* gsrc[2];
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri) {
-        const int row = rows_s[ri * 16 + li];
+        const int row = rows_s[ri * 16 + lr];
         if (MODE == 0) {
             asrc[ri] = st.h_tmp + ((size_t)(L - 1) * B + row) * H;
             gsrc[ri] = nullptr;
@@ -200,42 +246,63 @@ __global__ __launch_bounds__(256) void rnnt_tile_kernel(DecodeState st, const fl
             gsrc[ri] = st.g + (size_t)row * K;
         }
     }
-    const float* wr[4];
+    // fragment-major weights ([ceil(N/16)][K/16][lane][4], rows past N are zero)
+    const int nkb = K / 16, ntile = (N + 15) / 16;
+    const float* wfrag[4];
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj) {
-        int v = ct * 64 + cj * 16 + li;
-        v = v < N ? v : N - 1;
-        wr[cj] = W + (size_t)v * K;
+        int tn = ct * 4 + cj;
+        tn = tn < ntile ? tn : ntile - 1;
+        wfrag[cj] = W + ((size_t)tn * nkb) * 256 + lane * 4;
     }
     f32x4_t acc[2][4];
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) acc[ri][cj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const int kslice = K / SPLITK_TILE, kbeg = wave * kslice;
-    for (int k0 = kbeg; k0 < kbeg + kslice; k0 += 16) {
-        const int k = k0 + 4 * kk;
-        float4 a[2], w[4];
+    struct Frag { float4 a[2], g[2], w[4]; };
+    auto load = [&](int k0) {
+        Frag fr;
+        const int k = k0 + 4 * lc;
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri) {
-            a[ri] = *reinterpret_cast<const float4*>(asrc[ri] + k);
-            if (MODE == 1) {
-                const float4 gv = *reinterpret_cast<const float4*>(gsrc[ri] + k);
-                a[ri].x = fmaxf(a[ri].x + gv.x, 0.0f); a[ri].y = fmaxf(a[ri].y + gv.y, 0.0f);
-                a[ri].z = fmaxf(a[ri].z + gv.z, 0.0f); a[ri].w = fmaxf(a[ri].w + gv.w, 0.0f);
-            }
+            fr.a[ri] = *reinterpret_cast<const float4*>(asrc[ri] + k);
+            if (MODE == 1) fr.g[ri] = *reinterpret_cast<const float4*>(gsrc[ri] + k);
         }
 #pragma unroll
-        for (int cj = 0; cj < 4; ++cj) w[cj] = *reinterpret_cast<const float4*>(wr[cj] + k);
+        for (int cj = 0; cj < 4; ++cj) fr.w[cj] = *reinterpret_cast<const float4*>(wfrag[cj] + (size_t)(k0 >> 4) * 256);
+        return fr;
+    };
+    auto compute = [&](const Frag& fr) {
+        float4 a[2];
 #pragma unroll
-        for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-            for (int cj = 0; cj < 4; ++cj) {
-                acc[ri][cj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ri].x, w[cj].x, acc[ri][cj], 0, 0, 0);
-                acc[ri][cj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ri].y, w[cj].y, acc[ri][cj], 0, 0, 0);
-                acc[ri][cj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ri].z, w[cj].z, acc[ri][cj], 0, 0, 0);
-                acc[ri][cj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ri].w, w[cj].w, acc[ri][cj], 0, 0, 0);
+        for (int ri = 0; ri < 2; ++ri) {
+            a[ri] = fr.a[ri];
+            if (MODE == 1) {   // relu(f + g) is elementwise: apply it before the lane permutation
+                a[ri].x = fmaxf(a[ri].x + fr.g[ri].x, 0.0f); a[ri].y = fmaxf(a[ri].y + fr.g[ri].y, 0.0f);
+                a[ri].z = fmaxf(a[ri].z + fr.g[ri].z, 0.0f); a[ri].w = fmaxf(a[ri].w + fr.g[ri].w, 0.0f);
             }
+            a[ri] = to_mfma_a_layout(a[ri], perm);
+        }
+#define RS_MFMA_E(c)                                                                                            \
+        _Pragma("unroll") for (int ri = 0; ri < 2; ++ri) _Pragma("unroll") for (int cj = 0; cj < 4; ++cj)      \
+            acc[ri][cj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ri].c, fr.w[cj].c, acc[ri][cj], 0, 0, 0);
+        RS_MFMA_E(x) RS_MFMA_E(y) RS_MFMA_E(z) RS_MFMA_E(w)
+#undef RS_MFMA_E
+    };
+    const int kslice = K / SPLITK_TILE, kbeg = wave * kslice, nblk = kslice / 16;
+    {
+        Frag f0 = load(kbeg);
+        Frag f1 = nblk > 1 ? load(kbeg + 16) : f0;
+        int u = 0;
+        for (; u + 2 < nblk; ++u) {
+            const Frag f2 = load(kbeg + 16 * (u + 2));
+            compute(f0);
+            f0 = f1;
+            f1 = f2;
+        }
+        if (nblk >= 2) { compute(f0); f0 = f1; }
+        compute(f0);
     }
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri)
@@ -244,7 +311,8 @@ __global__ __launch_bounds__(256) void rnnt_tile_kernel(DecodeState st, const fl
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[wave][ri * 16 + 4 * kk + r][cj * 16 + li] = acc[ri][cj][r];
     __syncthreads();
-    // thread = (row i, 8 consecutive columns)
+    // thread = (row i, 8 consecutive columns); waves 4..7 are done
+    if (tid >= 256) return;
     const int i = tid >> 3, c0 = (tid & 7) * 8;
     const bool row_ok = rt * 32 + i < n_rows;
     const int brow = rows_s[i];
@@ -355,7 +423,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     const rs_dims& d = ctx->d;
     const int L = d.pred_layers, H = d.pred_hidden, J = d.joint_hidden, V = d.n_logits;
     if (B <= 0) return RS_OK;
-    if (H % 64 || J % 64) return rs_fail(ctx, RS_EINVAL, "rnnt: pred_hidden/joint_hidden must be multiples of 64");
+    if (H % 128 || J % 128) return rs_fail(ctx, RS_EINVAL, "rnnt: pred_hidden/joint_hidden must be multiples of 128");
     if (L < 1 || L > 4) return rs_fail(ctx, RS_EINVAL, "rnnt: 1..4 LSTM layers supported");
     if (workspace_bytes < rs_rnnt_workspace_bytes(ctx, B)) return rs_fail(ctx, RS_EWORKSPACE, "rnnt: workspace too small");
     const int nct = (V + 63) / 64;
@@ -373,11 +441,20 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     st.pmax = (float*)take((size_t)B * nct * 4); st.pidx = (int32_t*)take((size_t)B * nct * 4);
 
     const int rtiles = (B + 31) / 32;
+    constexpr int LSTM_LDS = SPLITK_LSTM * 4 * 32 * 16 * 4 + 32 * 4;
+    constexpr int TILE_LDS = SPLITK_TILE * 32 * 65 * 4 + 32 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RS_HIP(ctx, hipFuncSetAttribute((const void*)rnnt_lstm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LSTM_LDS));
+        RS_HIP(ctx, hipFuncSetAttribute((const void*)rnnt_tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS));
+        RS_HIP(ctx, hipFuncSetAttribute((const void*)rnnt_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS));
+        attr_set = true;
+    }
     auto lstm_and_pred = [&]() {
         for (int l = 0; l < L; ++l)
-            hipLaunchKernelGGL(rnnt_lstm_kernel, dim3(H / 16, rtiles), dim3(512), 0, s, st, l, B, H, ctx->embed,
+            hipLaunchKernelGGL(rnnt_lstm_kernel, dim3(H / 16, rtiles), dim3(1024), LSTM_LDS, s, st, l, B, H, ctx->embed,
                                ctx->lstm_w[l], ctx->lstm_b[l]);
-        hipLaunchKernelGGL(rnnt_tile_kernel<0>, dim3((J + 63) / 64, rtiles), dim3(256), 0, s, st, (const float*)nullptr, B,
+        hipLaunchKernelGGL(rnnt_tile_kernel<0>, dim3((J + 63) / 64, rtiles), dim3(512), TILE_LDS, s, st, (const float*)nullptr, B,
                            0, L, H, H, J, ctx->jpred_w, ctx->jpred_b, 0, 0);
     };
 
@@ -395,7 +472,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     bool finished = false;
     while (!finished && steps < max_steps) {
         for (int c = 0; c < CHUNK; ++c, ++steps) {
-            hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(nct, rtiles), dim3(256), 0, s, st, joint_enc, B, tp_max, L, H, J,
+            hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(nct, rtiles), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H, J,
                                V, ctx->jout_w, ctx->jout_b, nct, steps);
             hipLaunchKernelGGL(rnnt_finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, st, enc_lens, B, nct,
                                d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);

@@ -166,7 +166,7 @@ int rs_finalize(rs_ctx* ctx) {
         r.get(p + ".b", 4 * H, ctx->lstm_b[l]);
     }
     r.get("joint.pred.w", J * H, ctx->jpred_w); r.get("joint.pred.b", J, ctx->jpred_b);
-    r.get("joint.out.w", V * J, ctx->jout_w); r.get("joint.out.b", V, ctx->jout_b);
+    r.get("joint.out.w", ((V + 15) / 16 * 16) * J, ctx->jout_w); r.get("joint.out.b", V, ctx->jout_b);   // fragment-major, rows padded to 16
     if (r.rc != RS_OK) return r.rc;
     auto it = ctx->tensors.find("pos.table");
     if (it == ctx->tensors.end()) return rs_fail(ctx, RS_EMISSING, "weight tensor 'pos.table' was not registered");

@@ -117,6 +117,7 @@ class Context:
     def __init__(self, cfg, device_index=0):
         self.lib = load()
         self.cfg = cfg
+        self.device_index = int(device_index)
         self._h = c_void_p()
         self._keep = {}
         dims = RsDims.from_config(cfg)
@@ -127,6 +128,15 @@ class Context:
                 self.lib.rs_destroy(self._h)
                 self._h = c_void_p()
             raise RsError(rc, msg)
+
+    def clone(self):
+        """a second context over the SAME device weights (contexts are per stream: the pipelined
+        path runs the encoder and the decoder of consecutive batches on two streams)"""
+        other = Context(self.cfg, self.device_index)
+        for name, t in self._keep.items():
+            other.set_tensor(name, t)
+        other.finalize()
+        return other
 
     def close(self):
         if getattr(self, "_h", None):

@@ -110,7 +110,7 @@ class ModelConfig:
         assert self.head_dim == 128, "attention kernel is built for head_dim 128"
         assert self.d_model % 64 == 0 and self.ff_dim % 64 == 0
         assert self.sub_channels % 64 == 0
-        assert self.pred_hidden % 16 == 0 and self.joint_hidden % 16 == 0
+        assert self.pred_hidden % 128 == 0 and self.joint_hidden % 128 == 0   # K slices of k_rnnt.hip
         assert self.pred_hidden == self.joint_hidden or True
         assert self.conv_kernel % 2 == 1 and self.conv_kernel <= 31
         assert self.n_fft == 512 and self.win_length <= 512
@@ -122,7 +122,7 @@ FASTCONFORMER_619M = ModelConfig()
 
 # a shape small enough for CPU oracle runs and committed golden fixtures
 TINY = ModelConfig(d_model=256, n_heads=2, ff_dim=512, n_layers=2, sub_channels=64,
-                   vocab_size=63, pred_hidden=64, joint_hidden=64)
+                   vocab_size=63, pred_hidden=128, joint_hidden=128)
 
 
 def from_nemo_yaml(cfg: dict) -> ModelConfig:

@@ -6,6 +6,8 @@ three stage entry points of librs_asr.so on torch's current HIP stream.  It stan
 and exposes the one attribute the reference's post-processing touches: `.tokenizer`
 (pkg/nemo-asr/src/decode.py:41,47).
 """
+import queue
+import threading
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -46,6 +48,8 @@ class _Buffers:
         self.frames = torch.zeros((B, self.u_max), dtype=i32, device=dev)
         self.n_ids = torch.zeros((B,), dtype=i32, device=dev)
         self.ws = torch.empty((ctx.workspace_bytes(B, self.l_pad),), dtype=torch.uint8, device=dev)
+        # the decoder of batch i overlaps the encoder of batch i+1 in the pipelined path: own scratch
+        self.ws_dec = torch.empty((ctx.workspace_bytes(B, 16),), dtype=torch.uint8, device=dev)
         # pinned staging for the host boundary
         self.h_audio = torch.zeros((B, l_max), dtype=f32).pin_memory()
         self.h_lens = torch.zeros((B,), dtype=i32).pin_memory()
@@ -70,6 +74,8 @@ class AsrModel:
             self.ctx = capi.Context(cfg, index)
             self._upload(prepare_weights(cfg, state_dict, pos_cap))
         self._bufs = {}
+        self._ctx_dec = None
+        self._streams = None
 
     # ------------------------------------------------------------------------------------------
     def _upload(self, tensors):
@@ -103,13 +109,82 @@ class AsrModel:
             self.ctx.rnnt_greedy(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, buf.u_max, buf.ids, buf.frames,
                                  buf.n_ids, buf.ws, stream)
 
-    def stage(self, waveforms: Sequence[np.ndarray], l_max: Optional[int] = None) -> _Buffers:
+    # ------------------------------------------------------------------------------------------
+    def run_encoder(self, buf: _Buffers, stream):
+        """front-end + encoder of one batch on `stream` (asynchronous)"""
+        self.ctx.frontend(buf.audio, buf.lens, self.pad_left, self.pad_right, buf.t_max, buf.feats, buf.n_frames,
+                          buf.ws, stream)
+        self.ctx.encoder(buf.feats, buf.n_frames, buf.B, buf.t_max, None, buf.joint_enc, buf.enc_lens, buf.ws, stream)
+
+    def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None):
+        """Process `steps` batches (bufs[i % len(bufs)], inputs already in HBM) as a two-stage
+        pipeline: the throughput-bound front-end + encoder of batch i+1 runs on one HIP stream while
+        the latency-bound greedy decode of batch i (a dependency chain of small launches that leaves
+        most CUs idle) runs on a second stream, driven by a worker thread (ctypes releases the GIL;
+        rs_rnnt_greedy synchronises only its own stream).  Every batch is fully decoded when this
+        returns.  `after_decode(buf)` is called on the worker thread after each batch."""
+        assert len(bufs) >= 2, "the pipeline needs two buffer sets"
+        with torch.cuda.device(self.device):
+            if self._ctx_dec is None:
+                self._ctx_dec = self.ctx.clone()
+                self._streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            enc_stream, dec_stream = self._streams
+            enc_stream.wait_stream(torch.cuda.current_stream())
+            jobs: "queue.Queue" = queue.Queue()
+            done = [threading.Event() for _ in range(steps)]
+            errors = []
+
+            def worker():
+                with torch.cuda.device(self.device):
+                    while True:
+                        item = jobs.get()
+                        if item is None:
+                            return
+                        i, buf, ev = item
+                        try:
+                            dec_stream.wait_event(ev)
+                            # decode scratch lives past the encoder's scratch in buf.ws_dec
+                            self._ctx_dec.rnnt_greedy(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, buf.u_max, buf.ids,
+                                                      buf.frames, buf.n_ids, buf.ws_dec, dec_stream.cuda_stream)
+                            if after_decode is not None:
+                                after_decode(buf)
+                        except Exception as e:          # surfaced on the caller's thread below
+                            errors.append(e)
+                        finally:
+                            done[i].set()
+
+            th = threading.Thread(target=worker, daemon=True)
+            th.start()
+            nb = len(bufs)
+            for i in range(steps):
+                buf = bufs[i % nb]
+                if i >= nb:
+                    done[i - nb].wait()           # this buffer set's previous decode must be finished
+                self.run_encoder(buf, enc_stream.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(enc_stream)
+                jobs.put((i, buf, ev))
+            jobs.put(None)
+            th.join()
+            torch.cuda.current_stream().wait_stream(enc_stream)
+            torch.cuda.current_stream().wait_stream(dec_stream)
+            if errors:
+                raise errors[0]
+
+    def new_buffers(self, B, l_max) -> _Buffers:
+        """an un-cached buffer set (the pipelined path keeps two batches in flight)"""
+        with torch.cuda.device(self.device):
+            return _Buffers(self, B, (max(int(l_max), 1) + 63) // 64 * 64)
+
+    def stage(self, waveforms: Sequence[np.ndarray], l_max: Optional[int] = None, buf: Optional[_Buffers] = None) -> _Buffers:
         """copy host waveforms (16 kHz mono float32, un-padded) into a pinned buffer and on to HBM"""
         B = len(waveforms)
         longest = max((len(w) for w in waveforms), default=0)
         l_max = max(int(l_max or 0), longest, 1)
         l_max = (l_max + 63) // 64 * 64          # rows stay 256-B aligned
-        buf = self.buffers(B, l_max)
+        if buf is None:
+            buf = self.buffers(B, l_max)
+        assert buf.B == B and buf.l_max >= longest
         ha = buf.h_audio.numpy()
         hl = buf.h_lens.numpy()
         for b, w in enumerate(waveforms):

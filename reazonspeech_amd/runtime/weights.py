@@ -198,7 +198,7 @@ def default_blank_bias(cfg: ModelConfig) -> float:
     return _BLANK_BIAS.get((cfg.d_model, cfg.n_layers, cfg.vocab_size), 3.0)
 
 
-_BLANK_BIAS = {(1024, 24, 3000): 6.2, (256, 2, 63): 3.4}
+_BLANK_BIAS = {(1024, 24, 3000): 6.2, (256, 2, 63): 4.1}
 
 
 # ------------------------------------------------------------------------------------
@@ -295,6 +295,19 @@ def banded_filterbank(fb: np.ndarray):
     return idx, w
 
 
+def to_fragment_major(w: torch.Tensor) -> torch.Tensor:
+    """float32 [N][K] -> [ceil(N/16)][K/16][64 lanes][4]: the 16x16 block (n-tile, k-block) is
+    stored in the order the v_mfma_f32_16x16x4_f32 B-operand lanes consume it (lane = 16*kk + li
+    holds W[16*tn + li][16*kb + 4*kk + 0..3]), so a wave's operand load is one contiguous 1 KiB
+    run instead of 64 row-strided 16-byte pieces.  Rows past N are zero."""
+    n, k = w.shape
+    assert k % 16 == 0
+    nt = (n + 15) // 16
+    wp = torch.zeros((nt * 16, k), dtype=torch.float32)
+    wp[:n] = w.to(torch.float32)
+    return wp.view(nt, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(nt, k // 16, 64, 4)
+
+
 def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int = DEFAULT_POS_CAP):
     """-> dict name -> CPU torch tensor (float32 / bfloat16 / int32) exactly as registered with
     rs_set_tensor (DESIGN.md "Weights in HBM").  Host-side transforms, all one-off:
@@ -304,7 +317,9 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
         (c, f) to (f, c) order to match the channels-last activation layout
       * conv-module BatchNorm folded into the depthwise weights (float64 math, float32 store),
         stored tap-major [k][d]
-      * LSTM: W = [W_ih | W_hh] ([4H][2H]) float32, bias = b_ih + b_hh (float32 add)
+      * LSTM: W = [W_ih | W_hh] ([4H][2H]) float32, bias = b_ih + b_hh (float32 add); the three
+        float32 decode matrices (LSTM, joint.pred, joint output) are stored fragment-major
+        (to_fragment_major) for contiguous MFMA operand loads
       * relative position table for T' up to pos_cap, bf16 [2*cap-1][d]
     """
     out = {}
@@ -377,11 +392,11 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
     out["pred.embed"] = f32(sd["decoder.prediction.embed.weight"])
     P = "decoder.prediction.dec_rnn.lstm."
     for l in range(cfg.pred_layers):
-        out[f"pred.lstm{l}.w"] = f32(torch.cat([sd[P + f"weight_ih_l{l}"], sd[P + f"weight_hh_l{l}"]], dim=1))
+        out[f"pred.lstm{l}.w"] = to_fragment_major(torch.cat([sd[P + f"weight_ih_l{l}"], sd[P + f"weight_hh_l{l}"]], dim=1))
         out[f"pred.lstm{l}.b"] = f32(sd[P + f"bias_ih_l{l}"].float() + sd[P + f"bias_hh_l{l}"].float())
-    out["joint.pred.w"] = f32(sd["joint.pred.weight"])
+    out["joint.pred.w"] = to_fragment_major(sd["joint.pred.weight"])
     out["joint.pred.b"] = f32(sd["joint.pred.bias"])
-    out["joint.out.w"] = f32(sd["joint.joint_net.2.weight"])
+    out["joint.out.w"] = to_fragment_major(sd["joint.joint_net.2.weight"])
     out["joint.out.b"] = f32(sd["joint.joint_net.2.bias"])
     out["pos.table"] = torch.from_numpy(rel_pos_table(cfg, pos_cap)).to(torch.bfloat16).contiguous()
     return out

@@ -24,7 +24,7 @@ from reazonspeech_amd.runtime.config import TINY, ModelConfig          # noqa: E
 from reazonspeech_amd.runtime.weights import synthetic_state_dict, slaney_mel_filterbank  # noqa: E402
 
 SEED = 7
-BLANK_BIAS = 3.0
+BLANK_BIAS = 3.9
 
 
 def _fake(name, **attrs):

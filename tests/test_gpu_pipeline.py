@@ -115,7 +115,7 @@ def test_decode_bit_exact_many_utterances(gpu_device):
     """synthetic joint-encoder tensors straight into rs_rnnt_greedy: ragged lengths, an empty
     utterance, a batch that is not a multiple of the 16-row tile"""
     cfg = TINY
-    sd = synthetic_state_dict(cfg, 11, blank_bias=3.2)
+    sd = synthetic_state_dict(cfg, 11, blank_bias=4.0)
     model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device="cuda:0")
     g = torch.Generator().manual_seed(2)
     B, Tp = 37, 45
@@ -156,7 +156,7 @@ def test_end_to_end_ids_vs_oracle(tiny, gold):
 def test_batch_invariance(gpu_device):
     """an utterance decoded alone == the same utterance inside a ragged batch (reference
     semantics: batch_size=1, transcribe.py:48-50)"""
-    sd = synthetic_state_dict(TINY, 21, blank_bias=3.0)
+    sd = synthetic_state_dict(TINY, 21, blank_bias=4.0)
     model = AsrModel(TINY, sd, SyntheticTokenizer(TINY.vocab_size), device="cuda:0")
     audio, lens = synthetic_batch(5, 3.0, seed=9, ragged=True, min_seconds=0.5)
     waves = [audio[b, :lens[b]] for b in range(5)]
@@ -165,6 +165,31 @@ def test_batch_invariance(gpu_device):
         alone = model.transcribe_waveforms([waves[b]])
         assert alone.ids[0] == together.ids[b]
         assert alone.frames[0] == together.frames[b]
+
+
+def test_pipelined_schedule_equals_sequential(gpu_device):
+    """encoder(i+1) || decode(i) on two streams gives exactly what the one-stream path gives"""
+    sd = synthetic_state_dict(TINY, 31, blank_bias=4.0)
+    model = AsrModel(TINY, sd, SyntheticTokenizer(TINY.vocab_size), device="cuda:0")
+    bufs, want = [], []
+    for k in range(2):
+        audio, lens = synthetic_batch(6, 2.5, seed=40 + k, ragged=True, min_seconds=0.5)
+        waves = [audio[b, :lens[b]] for b in range(6)]
+        ref = model.transcribe_waveforms(waves)
+        want.append((ref.ids, ref.frames))
+        bufs.append(model.stage(waves, buf=model.new_buffers(6, 40000)))
+    got = {}
+
+    def grab(buf):
+        torch.cuda.current_stream().synchronize()
+        got.setdefault(id(buf), []).append(model.collect(buf))
+
+    model.run_pipelined(bufs, 5, after_decode=grab)
+    for k in range(2):
+        runs = got[id(bufs[k])]
+        assert len(runs) == (3 if k == 0 else 2)
+        for r in runs:
+            assert (r.ids, r.frames) == want[k]
 
 
 def test_python_boundary(tiny):

@@ -55,7 +55,16 @@ def test_prepare_weights_layouts():
     assert torch.equal(p["L0.att.qkv.w"][d:2 * d], sd["encoder.layers.0.self_attn.linear_k.weight"].to(torch.bfloat16))
     assert p["L1.conv.dw.w"].shape == (cfg.conv_kernel, d)
     H = cfg.pred_hidden
-    assert p["pred.lstm0.w"].shape == (4 * H, 2 * H)
+    # decode matrices are fragment-major: [n/16][k/16][lane = 16*kk + li][4]
+    wl = torch.cat([sd["decoder.prediction.dec_rnn.lstm.weight_ih_l0"],
+                    sd["decoder.prediction.dec_rnn.lstm.weight_hh_l0"]], dim=1)
+    assert p["pred.lstm0.w"].shape == (4 * H // 16, 2 * H // 16, 64, 4)
+    tn, kb, li, kk, e = 5, 3, 7, 2, 1
+    assert p["pred.lstm0.w"][tn, kb, 16 * kk + li, e] == wl[16 * tn + li, 16 * kb + 4 * kk + e]
+    jo = p["joint.out.w"]
+    assert jo.shape == ((cfg.n_logits + 15) // 16, cfg.joint_hidden // 16, 64, 4)
+    assert jo[3, 1, 16 * 3 + 15, 2] == sd["joint.joint_net.2.weight"][63, 16 + 12 + 2]     # last real row
+    assert torch.all(jo.view(-1, cfg.joint_hidden // 16, 4, 16, 4)[3, :, :, 15 + 1 - 16:, :][:, :, :0] == 0)
     assert torch.equal(p["pred.lstm1.b"], sd["decoder.prediction.dec_rnn.lstm.bias_ih_l1"] +
                        sd["decoder.prediction.dec_rnn.lstm.bias_hh_l1"])
     assert p["pos.table"].shape == (79, d) and p["pos.table"].dtype == torch.bfloat16

@@ -56,7 +56,7 @@ def test_greedy_c_vs_hf_and_torch(gold, sd):
 
 def test_greedy_c_vs_torch_random_inputs():
     """diverse emissions: random joint-encoder tensors, ragged lengths, an empty utterance"""
-    sd = synthetic_state_dict(TINY, 11, blank_bias=3.2)
+    sd = synthetic_state_dict(TINY, 11, blank_bias=4.0)
     g = torch.Generator().manual_seed(2)
     B, Tp = 9, 30
     f = torch.randn((B, Tp, TINY.joint_hidden), generator=g) * 1.5
