@@ -175,9 +175,17 @@ def main():
         if gemm and gemm["launches"]:
             per_launch_ms = gemm["ms"] / gemm["launches"]
             achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+            traffic = None
+            try:   # HBM bytes per launch from the committed PMC passes (cannot be collected in-process)
+                with open(os.path.join(ROOT, "profiles", "gemm_traffic.json")) as fp:
+                    traffic = json.load(fp)["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all encoder linears)",
                                "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (PMC, profiles/gemm_traffic.json)",
+                               "algorithmic_bytes_per_launch": round(gemm["bytes"] / gemm["launches"]),
                                "launches": gemm["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
                                "share_of_step": round(gemm["ms"] / (dt * 1e3), 3)}
         if world == 1 and not args.no_cpu_baseline and not args.tiny:
