@@ -90,185 +90,253 @@ __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
-template <int BM, int BN, int BK, int NST, int WM, int WN>
+template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NWAVES = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int LOADS_PER_STAGE = STAGE_BYTES / 1024 / NWAVES;   // global_load_lds per wave per stage
+    constexpr int KS = BK / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 31, fhalf = lane >> 5;
 
-    // XCD-aware, bijective remap (blocks b, b+8, b+16.. share an XCD)
+    // XCD-aware, bijective tile order: workgroups b, b+8, b+16 .. run on one XCD (private L2); that
+    // XCD owns a contiguous run of tiles, n-fastest, so it reads each A row panel once.
     const int nwg = p.tiles_m * p.tiles_n;
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, loc = bid >> 3;
+    const int xcd = bid & 7, slot = bid >> 3;
     const int q = nwg >> 3, rr = nwg & 7;
-    const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-    const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int xbase = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    const int xcount = xcd < rr ? q + 1 : q;
+    // PERSIST: the grid is one workgroup per CU and each walks its XCD's run with stride = the number
+    // of workgroups on that XCD; otherwise one tile per workgroup.
+    const int nslots = PERSIST ? (((int)gridDim.x - xcd + 7) >> 3) : xcount;
+    if (slot >= xcount) return;
 
-    f32x16_t acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    // De-synchronise the workgroups that share a CU: all tiles cost the same, so without this every
-    // CU of the chip alternates in lockstep between "all MFMA" and "all stores".  Workgroups of the
-    // second dispatch round (the second resident workgroup of each CU) start half a tile late, once;
-    // from then on one workgroup's epilogue overlaps its neighbour's main loop.
-    if (p.skew_cycles > 0 && bid >= 256 && bid < 512) {
+    if (PERSIST && p.skew_cycles > 0) {
+        // All tiles cost the same, so without this every CU alternates in lockstep between "all MFMA"
+        // and "all stores" and the output bursts are paid at full HBM-write latency.  Four start
+        // phases a quarter tile apart spread the store traffic of the chip over time.
+        const long long wait = (long long)p.skew_cycles * (slot & 3);
         const long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < p.skew_cycles) __builtin_amdgcn_s_sleep(8);
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
     }
 
     const int nk = p.K / BK;
-    auto issue = [&](int t) {
-        char* st = smem + (t % NST) * STAGE_BYTES;
-        stage_rows<BK, BM, NWAVES>(p.A, p.lda, m0, p.M, t * BK, st, wave, lane);
-        stage_rows<BK, BN, NWAVES>(p.W, p.ldw, n0, p.N, t * BK, st + A_BYTES, wave, lane);
-    };
-#pragma unroll
-    for (int t = 0; t < NST - 1; ++t)
-        if (t < nk) issue(t);
-
-    const int frow = lane & 31, fhalf = lane >> 5;
-    constexpr int KS = BK / 16;
-    for (int t = 0; t < nk; ++t) {
-        // stage t must have landed: at most NST-2 younger stages may still be in flight
-        if (t + NST - 2 < nk) wait_vmcnt<LOADS_PER_STAGE * (NST - 2)>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // everyone's part of stage t is in LDS; stage t-1's buffer is free
-        const char* at = smem + (t % NST) * STAGE_BYTES;
-        const char* bt = at + A_BYTES;
-        // software pipeline over the k sub-steps: the fragments of ks+1 are requested from LDS before
-        // the MFMAs of ks issue, and the next stage's DMA is issued under the first fragment reads
-        bf16x8_t af[2][MI], bfr[2][NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[0][i] = read_frag<BK>(at, wm * TM + i * 32 + frow, fhalf);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[0][j] = read_frag<BK>(bt, wn * TN + j * 32 + frow, fhalf);
-        if (t + NST - 1 < nk) issue(t + NST - 1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < KS) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[nxt][i] = read_frag<BK>(at, wm * TM + i * 32 + frow, (ks + 1) * 2 + fhalf);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bfr[nxt][j] = read_frag<BK>(bt, wn * TN + j * 32 + frow, (ks + 1) * 2 + fhalf);
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-    }
-
-    // ---- epilogue, straight from registers.  The MFMAs ran with the weight fragment as the A operand,
-    // so D = (A.W^T)^T: lane = (m = lane&31, half h), register r <-> n = (r&3) + 8*(r>>2) + 4*h.  Each
-    // lane therefore owns 4 consecutive n per register quad: one 16-byte f32 (8-byte bf16) access,
-    // two lanes (h = 0,1) cover a contiguous 32-byte (16-byte) run of one output row.
     const int flags = p.flags;
     const bool has_bias = flags & RS_GEMM_BIAS, relu = flags & RS_GEMM_RELU, silu = flags & RS_GEMM_SILU;
     const bool has_res = flags & RS_GEMM_RESIDUAL, out_f32 = flags & RS_GEMM_OUT_F32;
     const bool rowmask = flags & RS_GEMM_ROWMASK;
     const float alpha = p.alpha;
+
+    auto issue = [&](int m0, int n0, int t) {
+        char* st = smem + (t % NST) * STAGE_BYTES;
+        stage_rows<BK, BM, NWAVES>(p.A, p.lda, m0, p.M, t * BK, st, wave, lane);
+        stage_rows<BK, BN, NWAVES>(p.W, p.ldw, n0, p.N, t * BK, st + A_BYTES, wave, lane);
+    };
+    auto tile_origin = [&](int j, int& m0, int& n0) {
+        const int wg = xbase + j;
+        const int tile_m = wg / p.tiles_n;
+        m0 = tile_m * BM;
+        n0 = (wg - tile_m * p.tiles_n) * BN;
+    };
+
+    int m0, n0;
+    tile_origin(slot, m0, n0);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * TM + i * 32 + frow;
-        const bool m_ok = m < p.M;
-        bool keep = true;
-        if (rowmask && m_ok) {
-            const int step = m / p.mask_rows_per_step;
-            const int b = step / p.mask_steps;
-            keep = step - b * p.mask_steps < p.mask_lens[b];
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) issue(m0, n0, t);
+
+    for (int j = slot; j < xcount; j += nslots) {
+        f32x16_t acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.0f;
+
+        for (int t = 0; t < nk; ++t) {
+            // stage t must have landed: at most NST-2 younger stages may still be in flight.
+            // In the persistent loop the previous tile's stores share the counter and loads/stores may
+            // retire out of order with respect to each other, so the first wait of a tile is a drain.
+            if (t + NST - 2 < nk && !(PERSIST && t == 0)) wait_vmcnt<LOADS_PER_STAGE * (NST - 2)>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // everyone's part of stage t is in LDS; stage t-1's buffer is free
+            const char* at = smem + (t % NST) * STAGE_BYTES;
+            const char* bt = at + A_BYTES;
+            // software pipeline over the k sub-steps: the fragments of ks+1 are requested from LDS before
+            // the MFMAs of ks issue, and the next stage's DMA is issued under the first fragment reads
+            bf16x8_t af[2][MI], bfr[2][NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[0][i] = read_frag<BK>(at, wm * TM + i * 32 + frow, fhalf);
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj) bfr[0][jj] = read_frag<BK>(bt, wn * TN + jj * 32 + frow, fhalf);
+            if (t + NST - 1 < nk) issue(m0, n0, t + NST - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        af[nxt][i] = read_frag<BK>(at, wm * TM + i * 32 + frow, (ks + 1) * 2 + fhalf);
+#pragma unroll
+                    for (int jj = 0; jj < NI; ++jj)
+                        bfr[nxt][jj] = read_frag<BK>(bt, wn * TN + jj * 32 + frow, (ks + 1) * 2 + fhalf);
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < NI; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][jj], af[cur][i], acc[i][jj], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
         }
-        const size_t rowoff = (size_t)m * p.ldc;
+
+        // ---- next tile's first stages go in flight before this tile's epilogue, so their HBM/L2
+        // latency (and the workgroup launch a non-persistent grid would pay) hides under the stores
+        int cm0 = m0, cn0 = n0;
+        // make the epilogue's addresses un-hoistable: computed at kernel entry they would be kept alive
+        // across the main loop and spilled (~90 VGPRs of scratch traffic around every tile)
+        asm volatile("" : "+s"(cm0), "+s"(cn0));
+        if (PERSIST && j + nslots < xcount) {
+            __builtin_amdgcn_s_barrier();   // all fragment reads of the last stage are done
+            tile_origin(j + nslots, m0, n0);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int nb = n0 + wn * TN + j * 32 + 4 * fhalf;
-            float4 rv[4];
-            if (has_res) {
+            for (int t = 0; t < NST - 1; ++t)
+                if (t < nk) issue(m0, n0, t);
+        }
+
+        // ---- epilogue, straight from registers.  The MFMAs ran with the weight fragment as the A
+        // operand, so D = (A.W^T)^T: lane = (m = lane&31, half h), register r <-> n = (r&3) + 8*(r>>2) + 4*h.
+        // Each lane owns 4 consecutive n per register quad: one 16-byte f32 (8-byte bf16) access; the
+        // two half-waves cover a contiguous 32-byte (16-byte) run of one output row.
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = cm0 + wm * TM + i * 32 + frow;
+            const bool m_ok = m < p.M;
+            bool keep = true;
+            if (rowmask && m_ok) {
+                const int step = m / p.mask_rows_per_step;
+                const int b = step / p.mask_steps;
+                keep = step - b * p.mask_steps < p.mask_lens[b];
+            }
+            const size_t rowoff = (size_t)m * p.ldc;
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj) {
+                const int nb = cn0 + wn * TN + jj * 32 + 4 * fhalf;
+                float4 rv[4];
+                if (has_res) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = nb + 8 * g;
+                        rv[g] = (m_ok && n < p.N) ? *reinterpret_cast<const float4*>(p.residual + rowoff + n)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                float4 v[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = nb + 8 * g;
-                    rv[g] = (m_ok && n < p.N) ? *reinterpret_cast<const float4*>(p.residual + rowoff + n)
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[g] = make_float4(acc[i][jj][4 * g], acc[i][jj][4 * g + 1], acc[i][jj][4 * g + 2], acc[i][jj][4 * g + 3]);
+                    if (has_bias && n < p.N) {
+                        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                        v[g].x += bv.x; v[g].y += bv.y; v[g].z += bv.z; v[g].w += bv.w;
+                    }
+                    if (relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
+                    if (silu) { v[g].x = silu_f(v[g].x); v[g].y = silu_f(v[g].y); v[g].z = silu_f(v[g].z); v[g].w = silu_f(v[g].w); }
+                    v[g].x *= alpha; v[g].y *= alpha; v[g].z *= alpha; v[g].w *= alpha;
+                    if (has_res) { v[g].x += rv[g].x; v[g].y += rv[g].y; v[g].z += rv[g].z; v[g].w += rv[g].w; }
+                    if (!keep) v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nb + 8 * g;
-                if (!m_ok || n >= p.N) continue;     // N % 4 == 0 is enforced by the launcher
-                float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                if (has_bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                }
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
-                if (has_res) { v.x += rv[g].x; v.y += rv[g].y; v.z += rv[g].z; v.w += rv[g].w; }
-                if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (out_f32) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + rowoff + n) = v;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = nb + 8 * g;
+                        if (m_ok && n < p.N) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + rowoff + n) = v[g];
+                    }
                 } else {
-                    *reinterpret_cast<u16x4_t*>(reinterpret_cast<uint16_t*>(p.out) + rowoff + n) =
-                        pack_bf16x4(v.x, v.y, v.z, v.w);
+                    // bf16: pair the register quads (g, g+1) across the two half-waves with
+                    // v_permlane32_swap so every lane stores 8 consecutive columns (16 bytes) and the
+                    // two half-waves together a contiguous 32-byte run of the row (guide T21)
+#pragma unroll
+                    for (int g = 0; g < 4; g += 2) {
+                        const u16x4_t pa = pack_bf16x4(v[g].x, v[g].y, v[g].z, v[g].w);
+                        const u16x4_t pb = pack_bf16x4(v[g + 1].x, v[g + 1].y, v[g + 1].z, v[g + 1].w);
+                        unsigned a0 = __builtin_bit_cast(uint2, pa).x, a1 = __builtin_bit_cast(uint2, pa).y;
+                        unsigned b0 = __builtin_bit_cast(uint2, pb).x, b1 = __builtin_bit_cast(uint2, pb).y;
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                        // h = 0: [own g | partner's g] -> columns 8g .. 8g+7 ; h = 1: [partner's g+1 | own g+1]
+                        const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        const int n = cn0 + wn * TN + jj * 32 + 8 * (g + fhalf);
+                        if (m_ok && n < p.N) {
+                            uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + rowoff + n;
+                            if (n + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = o;
+                            else *reinterpret_cast<uint2*>(dst) = make_uint2(o.x, o.y);   // N % 8 == 4 tail
+                        }
+                    }
                 }
+                // one 32x32 block at a time: without this fence the scheduler hoists the residual
+                // loads of all MI*NI blocks above the first store and spills ~100 VGPRs
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 }
 
 extern int g_skew;
+extern int g_persistent;
 
-template <int BM, int BN, int BK, int NST, int WM, int WN>
+template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST = false>
 int launch_variant(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int LDS = NST * STAGE_BYTES;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    // half of one tile's main-loop time at ~1 PF/s, in shader cycles (2.4 GHz), only when two
-    // workgroups share a CU and there are enough tiles for the offset to matter
-    constexpr bool two_per_cu = NST * STAGE_BYTES <= 80 * 1024;
-    const double skew_frac = g_skew < 0 ? (two_per_cu ? 1.0 : 0.0) : g_skew / 100.0;   // in tile times
-    p.skew_cycles = (p.tiles_m * p.tiles_n >= 1024)
-                        ? (int)(skew_frac * (2.0 * BM * BN * (double)p.K / 1.0e15 * 256.0) * 2.4e9) : 0;
-    auto kern = gemm_bf16_kernel<BM, BN, BK, NST, WM, WN>;
+    const int nwg = p.tiles_m * p.tiles_n;
+    constexpr int CUS = 256;
+    const bool persist = PERSIST && nwg > CUS;
+    // quarter of one tile's main-loop time at ~1 PF/s in shader cycles (2.4 GHz)
+    const double skew_frac = g_skew < 0 ? 0.0 : g_skew / 100.0;   // measured: any start skew loses (profiles/r01_gemm_persistent.txt)
+    p.skew_cycles = persist ? (int)(skew_frac * (2.0 * BM * BN * (double)p.K / 1.0e15 * 256.0) * 2.4e9) : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, PERSIST>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return rs_fail(ctx, RS_EHIP, "gemm: cannot reserve %d bytes of LDS", LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), LDS, s, p);
+    if (persist)
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, PERSIST>), dim3(CUS), dim3(64 * WM * WN), LDS, s, p);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false>), dim3(nwg), dim3(64 * WM * WN), LDS, s, p);
     return RS_OK;
 }
 
 int g_variant = -1;
 int g_skew = -1;
+int g_persistent = -1;
 
 }  // namespace
 
 // tuning hook for A/B runs (scripts/gemm_bench.py); not part of the public header
 extern "C" void rs_debug_set_gemm_variant(int v) { g_variant = v; }
 extern "C" void rs_debug_set_gemm_skew(int v) { g_skew = v; }
+extern "C" void rs_debug_set_gemm_persistent(int v) { g_persistent = v; }
 
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return rs_fail(ctx, RS_EINVAL, "gemm: empty shape %d %d %d", a.M, a.N, a.K);
     if (a.K % 64) return rs_fail(ctx, RS_EINVAL, "gemm: K=%d must be a multiple of 64", a.K);
     if (a.N % 4 || a.ldc % 4) return rs_fail(ctx, RS_EINVAL, "gemm: N=%d and ldc=%d must be multiples of 4", a.N, a.ldc);
+    if (!(a.flags & RS_GEMM_OUT_F32) && (a.ldc % 8)) return rs_fail(ctx, RS_EINVAL, "gemm: bf16 output needs ldc %% 8 == 0 (got %d)", a.ldc);
     if ((a.lda % 8) || (a.ldw % 8) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.out & 15))
         return rs_fail(ctx, RS_EINVAL, "gemm: operands must be 16-byte aligned (lda %d ldw %d)", a.lda, a.ldw);
     if ((a.flags & RS_GEMM_ROWMASK) && (!a.mask_lens || a.mask_rows_per_step <= 0 || a.mask_steps <= 0))
@@ -286,6 +354,10 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         const char* e = getenv("RS_GEMM_VARIANT");   // tuning knob for A/B runs; default chosen by shape
         g_variant = e ? atoi(e) : 0;
     }
+    if (g_persistent < 0) {
+        const char* e = getenv("RS_GEMM_PERSISTENT");
+        g_persistent = e ? atoi(e) : 0;
+    }
     const double flops = 2.0 * a.M * (double)a.N * a.K;
     const double bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                          (double)a.M * a.N * ((a.flags & RS_GEMM_OUT_F32) ? 4 : 2);
@@ -299,7 +371,11 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
         if (a.M < 1024 || a.N < 256) v = 1;
         else if (tiles256 < 1024 && a.K <= 1024) v = 7;
-        else v = 2;
+        else v = g_persistent ? 9 : 2;
+        // (variant 9, the persistent tile loop, is ~20 % faster in isolation — profiles/r01_gemm_persistent.txt —
+        // but one 128 KiB-LDS workgroup per CU for the whole launch starves the decode stream of the
+        // two-stage pipeline; it is selected with rs_debug_set_gemm_persistent(1) / RS_GEMM_PERSISTENT=1
+        // for single-stream use)
     }
     switch (v) {
         case 1: rc = launch_variant<128, 128, 64, 2, 2, 2>(ctx, p, s); break;   // small problems
@@ -310,6 +386,8 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         case 6: rc = launch_variant<256, 128, 32, 3, 2, 2>(ctx, p, s); break;   // 2 independent WGs per CU
         case 7: rc = launch_variant<128, 128, 32, 3, 2, 2>(ctx, p, s); break;   // 3 WGs per CU
         case 8: rc = launch_variant<256, 128, 64, 2, 2, 2>(ctx, p, s); break;
+        case 9: rc = launch_variant<256, 256, 64, 2, 2, 4, true>(ctx, p, s); break;    // persistent, one WG per CU
+        case 10: rc = launch_variant<256, 256, 32, 4, 2, 4, true>(ctx, p, s); break;
         default: rc = rs_fail(ctx, RS_EINVAL, "gemm: unknown RS_GEMM_VARIANT %d", v);
     }
     rs_prof_end(ctx, RS_PROF_GEMM, s);

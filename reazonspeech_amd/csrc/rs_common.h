@@ -43,8 +43,10 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// fast forms for the bf16 encoder path (v_exp_f32 + v_rcp_f32, ~1 ulp each; outputs are rounded to
+// bf16 right after).  The exact-f32 decode path has its own polynomial versions in k_rnnt.hip.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
 // ----------------------------------------------------------------------------------------
 // host side: context

@@ -6,6 +6,7 @@ three stage entry points of librs_asr.so on torch's current HIP stream.  It stan
 and exposes the one attribute the reference's post-processing touches: `.tokenizer`
 (pkg/nemo-asr/src/decode.py:41,47).
 """
+import os
 import queue
 import threading
 from dataclasses import dataclass
@@ -127,7 +128,10 @@ class AsrModel:
         with torch.cuda.device(self.device):
             if self._ctx_dec is None:
                 self._ctx_dec = self.ctx.clone()
-                self._streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+                # the decode chain is latency-critical: its workgroups should take the first free slots
+                self._streams = (torch.cuda.Stream(device=self.device),
+                                 torch.cuda.Stream(device=self.device,
+                                                   priority=int(os.environ.get("RS_DECODE_PRIORITY", "-1"))))
             enc_stream, dec_stream = self._streams
             enc_stream.wait_stream(torch.cuda.current_stream())
             jobs: "queue.Queue" = queue.Queue()

@@ -12,8 +12,8 @@ sets = ctx.lib.rs_debug_set_gemm_skew; sets.argtypes = [ctypes.c_int]; sets.rest
 for spec in sys.argv[1:] or ["2"]:
     v, sk = (spec.split(":") + ["-1"])[:2]
     v = int(v); setv(v); sets(int(sk)); v = spec
-    for name, n, flags in [("plain->bf16", 4096, 0), ("bias->bf16", 4096, capi.GEMM_BIAS), ("silu->bf16", 4096, capi.GEMM_BIAS | capi.GEMM_SILU),
-                           ("plain->f32", 1024, capi.GEMM_OUT_F32), ("res->f32", 1024, capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32)]:
+    for name, n, flags in [("plain->bf16", 4096, 0), ("silu->bf16", 4096, capi.GEMM_BIAS | capi.GEMM_SILU),
+                           ("res->f32", 1024, capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32)]:
         for k in (64, 1024, 4096):
             A = torch.randn((M, k), device=dev).to(torch.bfloat16)
             W = torch.randn((n, k), device=dev).to(torch.bfloat16)
