@@ -16,19 +16,21 @@
 // key axis permuted the same way, so the contraction pairs up.
 //
 // The position term needs, for the (query block, key block) pair, the 63 relative positions
-// n0 .. n0+62 with n0 = j0 - i0 - 31 + T - 1:  BD^T[64][32] = P[n0..n0+63] . (Q+v)^T by 16 MFMAs,
-// then the per-row skew  bd[key][query] = BD^T[key - query + 31][query]  goes through an 8 KiB
-// per-wave LDS scratch (conflict-free both ways: the query is the fastest index).
+// n0 .. n0+62 with n0 = j0 - i0 - 31 + T - 1:  BD^T[64][32] = P[n0..n0+63] . (Q+v)^T.  Moving to the
+// next key block shifts n0 by 32, so only the upper 32 rows are new: 8 MFMAs per block, the lower
+// half is the previous block's upper half.  The per-row skew  bd[key][query] = BD^T[key - query + 31][query]
+// goes through a per-wave LDS scratch (conflict-free both ways: the query is the fastest index);
+// the same scratch first stages the 32 position rows (coalesced 256-byte reads from L2).
 #include "rs_common.h"
 
 namespace {
 
 constexpr int HD = 128;             // head dim (fixed)
-constexpr int KROW = 272;           // bytes per K row in LDS (256 + 16 pad: conflict-free b128 reads)
+constexpr int KROW = 272;           // bytes per K / P row in LDS (256 + 16 pad: conflict-free b128 reads)
 constexpr int VROW = 80;            // bytes per V^T row in LDS (64 + 16 pad)
 constexpr int K_BYTES = 32 * KROW;  // 8704
 constexpr int VT_BYTES = HD * VROW; // 10240
-constexpr int SCR_BYTES = 64 * 32 * 4;
+constexpr int SCR_BYTES = 32 * KROW;   // per-wave scratch: 32 staged P rows, later the [64][32] f32 skew tile
 constexpr float NEG = -1.0e30f;
 
 struct AttnParams {
@@ -40,6 +42,15 @@ struct AttnParams {
 
 __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// position of key `key` (0..31) inside a V^T row: the order in which the S^T accumulator registers
+// of a lane enumerate the keys, so P^T can feed the PV MFMA straight from registers
+__device__ __forceinline__ int vt_pos(int key) {
+    const int kh = (key >> 2) & 1, kr = (key & 3) + 4 * (key >> 3);
+    return (kr >> 3) * 16 + kh * 8 + (kr & 7);
+}
+
+// One workgroup = (batch b, head h, up to 8 query blocks of 32); one wave = one query block.
+// K/V of key block jb+1 are fetched into registers while block jb is being multiplied (guide T14).
 __global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -47,7 +58,8 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
     const int nw = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* scr = reinterpret_cast<float*>(smem + K_BYTES + VT_BYTES + wave * SCR_BYTES);
+    char* scr = smem + K_BYTES + VT_BYTES + wave * SCR_BYTES;
+    float* scr_f = reinterpret_cast<float*>(scr);
 
     const int b = blockIdx.z, h = blockIdx.y;
     const int T = p.T, d = p.d_model, ld = 3 * d;
@@ -90,24 +102,83 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
     const uint16_t* pos_h = p.pos + h * HD;
     const int n_pos = 2 * T - 1;
 
+    // ---- K / V staging: thread -> (key, 16-byte chunk); two (K,V) chunk pairs per thread (blockDim >= 256)
+    u16x8_t kreg[2], vreg[2];
+    auto fetch_kv = [&](int j0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * blockDim.x;
+            if (idx < 32 * 16) {
+                const int key = idx >> 4, ch = idx & 15;
+                int krow = j0 + key;
+                krow = krow < T ? krow : T - 1;
+                const uint16_t* kp = base + (size_t)krow * ld + d + h * HD + ch * 8;
+                kreg[it] = *reinterpret_cast<const u16x8_t*>(kp);
+                vreg[it] = *reinterpret_cast<const u16x8_t*>(kp + d);
+            }
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * blockDim.x;
+            if (idx < 32 * 16) {
+                const int key = idx >> 4, ch = idx & 15;
+                *reinterpret_cast<u16x8_t*>(Ks + key * KROW + ch * 16) = kreg[it];
+                const int posk = vt_pos(key);
+                // 16-byte chunk of the key axis XOR-ed with (d>>3)&3 = ch&3: the 16 threads that share a
+                // key hit 4 bank groups instead of one
+                const int col = (((posk >> 3) ^ (ch & 3)) << 4) + (posk & 7) * 2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *reinterpret_cast<unsigned short*>(Vts + (ch * 8 + e) * VROW + col) = vreg[it][e];
+            }
+        }
+    };
+
+    // ---- BD^T block: 32 relative-position rows starting at nrow0, through the wave's scratch
+    //      (coalesced 256-byte row reads from L2 -> LDS rows of 272 B -> conflict-free fragment reads)
+    auto bd_block = [&](int nrow0) -> f32x16_t {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {   // two passes of 4 rows-of-4: 16 staging VGPRs, not 32
+            uint4 pr4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int n = nrow0 + 4 * (4 * half + q) + (lane >> 4);
+                n = n < 0 ? 0 : (n >= n_pos ? n_pos - 1 : n);
+                pr4[q] = *reinterpret_cast<const uint4*>(pos_h + (size_t)n * d + (lane & 15) * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4*>(scr + (4 * (4 * half + q) + (lane >> 4)) * KROW + (lane & 15) * 16) = pr4[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x16_t acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(scr + il * KROW + (2 * ks + hh) * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qv[ks], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // fragment reads done before the scratch is reused
+        return acc;
+    };
+
+    if (n_kblocks > 0) {
+        fetch_kv(0);
+        store_kv();
+    }
+    // rows n0 .. n0+31 of the first key block; every later block reuses the previous block's upper half
+    f32x16_t bd_lo = bd_block(0 - i0 - 31 + T - 1);
+    __syncthreads();
+
     for (int jb = 0; jb < n_kblocks; ++jb) {
         const int j0 = jb * 32;
-        __syncthreads();  // everyone is done with the previous K / V^T tiles
-        // ---- stage K [32][128] and V^T [128][32 permuted] for this key block
-        for (int idx = tid; idx < 32 * 16; idx += blockDim.x) {
-            const int key = idx >> 4, ch = idx & 15;
-            int krow = j0 + key;
-            krow = krow < T ? krow : T - 1;
-            const uint16_t* kp = base + (size_t)krow * ld + d + h * HD + ch * 8;
-            *reinterpret_cast<u16x8_t*>(Ks + key * KROW + ch * 16) = *reinterpret_cast<const u16x8_t*>(kp);
-            const u16x8_t vv = *reinterpret_cast<const u16x8_t*>(kp + d);
-            const int kh = (key >> 2) & 1, kr = (key & 3) + 4 * (key >> 3);
-            const int posk = (kr >> 3) * 16 + kh * 8 + (kr & 7);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<unsigned short*>(Vts + (ch * 8 + e) * VROW + posk * 2) = vv[e];
-        }
-        __syncthreads();
+        const bool more = jb + 1 < n_kblocks;
+        if (more) fetch_kv(j0 + 32);          // in flight under this block's MFMAs
 
         // ---- S^T = K . (Q+u)^T   (8 MFMAs)
         f32x16_t s;
@@ -118,27 +189,16 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
             const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + il * KROW + (2 * ks + hh) * 16);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[ks], s, 0, 0, 0);
         }
-        // ---- BD^T[64][32] = P[n0 .. n0+63] . (Q+v)^T   (16 MFMAs), rows straight from L2
+        // ---- upper half of BD^T for this key block: relative positions n0+32 .. n0+63   (8 MFMAs)
         const int n0 = j0 - i0 - 31 + T - 1;
-        f32x16_t bd[2];
+        const f32x16_t bd_hi = bd_block(n0 + 32);
+
+        // ---- skew through the per-wave scratch: scr_f[n_local][query]
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) bd[nb][e] = 0.0f;
-            int n = n0 + nb * 32 + il;
-            n = n < 0 ? 0 : (n >= n_pos ? n_pos - 1 : n);
-            const uint16_t* pp = pos_h + (size_t)n * d;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(pp + 8 * (2 * ks + hh));
-                bd[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qv[ks], bd[nb], 0, 0, 0);
-            }
+        for (int r = 0; r < 16; ++r) {
+            scr_f[rowmap(r, hh) * 32 + il] = bd_lo[r];
+            scr_f[(32 + rowmap(r, hh)) * 32 + il] = bd_hi[r];
         }
-        // ---- skew through the per-wave scratch: scr[n_local][query]
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) scr[(nb * 32 + rowmap(r, hh)) * 32 + il] = bd[nb][r];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -148,7 +208,7 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) {
             const int jl = rowmap(r, hh);
             const int j = j0 + jl;
-            const float bdv = scr[(jl - il + 31) * 32 + il];
+            const float bdv = scr_f[(jl - il + 31) * 32 + il];
             bool ok = q_valid && j < len;
             if (p.att_left >= 0 || p.att_right >= 0) {
                 bool win = (p.att_left < 0 || qi - j <= p.att_left) && (p.att_right < 0 || j - qi <= p.att_right);
@@ -159,7 +219,9 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
             pr[r] = sc;
             mblk = fmaxf(mblk, sc);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();  // scratch reads done before the next block overwrites it
+        bd_lo = bd_hi;
         mblk = fmaxf(mblk, __shfl_xor(mblk, 32, 64));
         const float m_new = fmaxf(m_run, mblk);
         const float alpha = __expf(m_run - m_new);
@@ -181,19 +243,28 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
         bf16x8_t pf[2];
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
+            const u16x4_t lo = pack_bf16x4(pr[8 * sidx], pr[8 * sidx + 1], pr[8 * sidx + 2], pr[8 * sidx + 3]);
+            const u16x4_t hi = pack_bf16x4(pr[8 * sidx + 4], pr[8 * sidx + 5], pr[8 * sidx + 6], pr[8 * sidx + 7]);
             u16x8_t t;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = f32_to_bf16(pr[8 * sidx + e]);
+            for (int e = 0; e < 4; ++e) { t[e] = lo[e]; t[4 + e] = hi[e]; }
             pf[sidx] = __builtin_bit_cast(bf16x8_t, t);
         }
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+        for (int db = 0; db < 4; ++db) {
+            const int drow = db * 32 + il;
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
-                const bf16x8_t vf =
-                    *reinterpret_cast<const bf16x8_t*>(Vts + (db * 32 + il) * VROW + (2 * sidx + hh) * 16);
+                const int chunk = (2 * sidx + hh) ^ ((drow >> 3) & 3);
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vts + drow * VROW + chunk * 16);
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sidx], o[db], 0, 0, 0);
             }
+        }
+        __syncthreads();                 // everyone is done with this block's K / V^T tiles
+        if (more) {
+            store_kv();
+            __syncthreads();
+        }
     }
 
     // ---- write ctx: lane = (query il, half hh); reg r of block db -> d = db*32 + rowmap(r, hh)
@@ -203,12 +274,9 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u16x4_t v4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v4[e] = f32_to_bf16(o[db][4 * g + e] * inv);
-                *reinterpret_cast<u16x4_t*>(op + db * 32 + 8 * g + 4 * hh) = v4;
-            }
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<u16x4_t*>(op + db * 32 + 8 * g + 4 * hh) =
+                    pack_bf16x4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
     }
 }
 
@@ -224,16 +292,18 @@ int rs_launch_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, c
     p.T = T; p.d_model = dm.d_model; p.att_left = dm.att_left; p.att_right = dm.att_right; p.n_global = dm.n_global;
     p.scale = 1.0f / sqrtf((float)HD);
     const int qblocks = (T + 31) / 32;
-    const int nw = qblocks < 8 ? qblocks : 8;
+    int nw = qblocks < 8 ? qblocks : 8;
+    if (nw < 4) nw = 4;                  // K/V staging assumes >= 256 threads (2 chunk pairs per thread)
     const dim3 grid((qblocks + nw - 1) / nw, dm.n_heads, B), block(64 * nw);
     const size_t lds = K_BYTES + VT_BYTES + (size_t)nw * SCR_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)relpos_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            K_BYTES + VT_BYTES + 8 * SCR_BYTES);
+        if (hipFuncSetAttribute((const void*)relpos_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                K_BYTES + VT_BYTES + 8 * SCR_BYTES) != hipSuccess)
+            return rs_fail(ctx, RS_EHIP, "attention: cannot reserve LDS");
         attr_set = true;
     }
-    // algorithmic: ac + bd + pv = 3 * 2*T*T*128 per (b,h), + skew-free bd counted once
+    // algorithmic: ac + bd + pv = 3 * 2*T*T*128 per (b,h)
     const double flops = (double)B * dm.n_heads * 3.0 * 2.0 * T * (double)T * HD;
     const double bytes = (double)B * T * dm.d_model * 2.0 * 4.0;
     rs_prof_begin(ctx, RS_PROF_ATTN, s, flops, bytes);

@@ -91,7 +91,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 1 : 2) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NWAVES = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -387,6 +387,8 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         case 7: rc = launch_variant<128, 128, 32, 3, 2, 2>(ctx, p, s); break;   // 3 WGs per CU
         case 8: rc = launch_variant<256, 128, 64, 2, 2, 2>(ctx, p, s); break;
         case 9: rc = launch_variant<256, 256, 64, 2, 2, 4, true>(ctx, p, s); break;    // persistent, one WG per CU
+        case 11: rc = launch_variant<256, 256, 64, 2, 2, 2>(ctx, p, s); break;         // 4 waves x (128x128): one wave per SIMD, 512-VGPR budget
+        case 12: rc = launch_variant<256, 256, 64, 2, 2, 2, true>(ctx, p, s); break;
         case 10: rc = launch_variant<256, 256, 32, 4, 2, 4, true>(ctx, p, s); break;
         default: rc = rs_fail(ctx, RS_EINVAL, "gemm: unknown RS_GEMM_VARIANT %d", v);
     }

@@ -51,6 +51,8 @@ class _Buffers:
         self.ws = torch.empty((ctx.workspace_bytes(B, self.l_pad),), dtype=torch.uint8, device=dev)
         # the decoder of batch i overlaps the encoder of batch i+1 in the pipelined path: own scratch
         self.ws_dec = torch.empty((ctx.workspace_bytes(B, 16),), dtype=torch.uint8, device=dev)
+        # second encoder scratch: the pipelined path runs the two halves of a batch on two streams
+        self.ws2 = None
         # pinned staging for the host boundary
         self.h_audio = torch.zeros((B, l_max), dtype=f32).pin_memory()
         self.h_lens = torch.zeros((B,), dtype=i32).pin_memory()
@@ -76,6 +78,8 @@ class AsrModel:
             self._upload(prepare_weights(cfg, state_dict, pos_cap))
         self._bufs = {}
         self._ctx_dec = None
+        self._ctx_enc2 = None
+        self._enc2_stream = None
         self._streams = None
 
     # ------------------------------------------------------------------------------------------
@@ -117,7 +121,27 @@ class AsrModel:
                           buf.ws, stream)
         self.ctx.encoder(buf.feats, buf.n_frames, buf.B, buf.t_max, None, buf.joint_enc, buf.enc_lens, buf.ws, stream)
 
-    def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None):
+    def run_encoder_split(self, buf: _Buffers, streams):
+        """front-end + encoder of one batch as two independent half-batches on two streams: the
+        memory-bound kernels of one half (LayerNorm, attention, conv, GEMM epilogues) overlap the
+        MFMA-bound main loops of the other, and each GEMM's partial last round of tiles is filled
+        by the other stream's work."""
+        B = buf.B
+        h0 = (B + 1) // 2
+        if buf.ws2 is None:
+            buf.ws2 = torch.empty((self.ctx.workspace_bytes(B - h0 if B > h0 else 1, buf.l_pad),), dtype=torch.uint8,
+                                  device=self.device)
+        parts = ((0, h0, self.ctx, buf.ws, streams[0]), (h0, B, self._ctx_enc2, buf.ws2, streams[1]))
+        for lo, hi, ctx, ws, st in parts:
+            if hi <= lo:
+                continue
+            s = st.cuda_stream
+            ctx.frontend(buf.audio[lo:hi], buf.lens[lo:hi], self.pad_left, self.pad_right, buf.t_max, buf.feats[lo:hi],
+                         buf.n_frames[lo:hi], ws, s)
+            ctx.encoder(buf.feats[lo:hi], buf.n_frames[lo:hi], hi - lo, buf.t_max, None, buf.joint_enc[lo:hi],
+                        buf.enc_lens[lo:hi], ws, s)
+
+    def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None, split_encoder: bool = None):
         """Process `steps` batches (bufs[i % len(bufs)], inputs already in HBM) as a two-stage
         pipeline: the throughput-bound front-end + encoder of batch i+1 runs on one HIP stream while
         the latency-bound greedy decode of batch i (a dependency chain of small launches that leaves
@@ -126,8 +150,15 @@ class AsrModel:
         returns.  `after_decode(buf)` is called on the worker thread after each batch."""
         assert len(bufs) >= 2, "the pipeline needs two buffer sets"
         with torch.cuda.device(self.device):
+            if split_encoder is None:
+                # measured on MI355X: splitting the encoder batch over two streams LOSES ~5 % (83.8 vs
+                # 79.8 ms/step, profiles/r01h_bench_matrix_split.txt) — the GEMM grids halve and the
+                # tile rounds quantise worse than the overlap wins; kept as an opt-in experiment
+                split_encoder = os.environ.get("RS_SPLIT_ENCODER", "0") != "0"
             if self._ctx_dec is None:
                 self._ctx_dec = self.ctx.clone()
+                self._ctx_enc2 = self.ctx.clone()
+                self._enc2_stream = torch.cuda.Stream(device=self.device)
                 # the decode chain is latency-critical: its workgroups should take the first free slots
                 self._streams = (torch.cuda.Stream(device=self.device),
                                  torch.cuda.Stream(device=self.device,
@@ -164,7 +195,12 @@ class AsrModel:
                 buf = bufs[i % nb]
                 if i >= nb:
                     done[i - nb].wait()           # this buffer set's previous decode must be finished
-                self.run_encoder(buf, enc_stream.cuda_stream)
+                if split_encoder and buf.B >= 2:
+                    self._enc2_stream.wait_stream(enc_stream)       # keep batch order across both halves
+                    self.run_encoder_split(buf, (enc_stream, self._enc2_stream))
+                    enc_stream.wait_stream(self._enc2_stream)
+                else:
+                    self.run_encoder(buf, enc_stream.cuda_stream)
                 ev = torch.cuda.Event()
                 ev.record(enc_stream)
                 jobs.put((i, buf, ev))

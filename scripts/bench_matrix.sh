@@ -5,9 +5,6 @@ run() { echo "== $1"; shift; env "$@" timeout 300 python bench.py --steps 8 --wa
 import sys, json
 d = json.loads(sys.stdin.readline()); r = d.get('roofline', {})
 print('   ms/step %.2f  RTFx %.0f  gemm %.0f TF/s (share %.2f)' % (d['ms_per_step'], d['value'], r.get('achieved', 0), r.get('share_of_step', 0)))"; }
-run "default (non-persistent, prio -1)" A=1
-run "prio 0" RS_DECODE_PRIORITY=0
-run "persistent pipelined" RS_GEMM_PERSISTENT=1
-EXTRA=--no-pipeline run "sequential" A=1
-EXTRA=--no-pipeline run "sequential persistent" RS_GEMM_PERSISTENT=1
+run "default (split encoder)" A=1
+run "no split" RS_SPLIT_ENCODER=0
 run "default again" A=1
