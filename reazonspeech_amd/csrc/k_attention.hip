@@ -31,6 +31,7 @@ constexpr int VROW = 80;            // bytes per V^T row in LDS (64 + 16 pad)
 constexpr int K_BYTES = 32 * KROW;  // 8704
 constexpr int VT_BYTES = HD * VROW; // 10240
 constexpr int SCR_BYTES = 32 * KROW;   // per-wave scratch: 32 staged P rows, later the [64][32] f32 skew tile
+constexpr int KB_CHUNK = 5;            // key blocks staged per workgroup barrier (160 keys: all of T' = 138)
 constexpr float NEG = -1.0e30f;
 
 struct AttnParams {
@@ -49,16 +50,15 @@ __device__ __forceinline__ int vt_pos(int key) {
     return (kr >> 3) * 16 + kh * 8 + (kr & 7);
 }
 
-// One workgroup = (batch b, head h, up to 8 query blocks of 32); one wave = one query block.
-// K/V of key block jb+1 are fetched into registers while block jb is being multiplied (guide T14).
-__global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
+// One workgroup = (batch b, head h, up to 6 query blocks of 32); one wave = one query block.
+__global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;
-    char* Vts = smem + K_BYTES;
+    char* Ks = smem;                              // [KB_CHUNK][32 keys][272 B]
+    char* Vts = smem + KB_CHUNK * K_BYTES;        // [KB_CHUNK][128 d][80 B]
     const int nw = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char* scr = smem + K_BYTES + VT_BYTES + wave * SCR_BYTES;
+    char* scr = smem + KB_CHUNK * (K_BYTES + VT_BYTES) + wave * SCR_BYTES;
     float* scr_f = reinterpret_cast<float*>(scr);
 
     const int b = blockIdx.z, h = blockIdx.y;
@@ -102,37 +102,25 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
     const uint16_t* pos_h = p.pos + h * HD;
     const int n_pos = 2 * T - 1;
 
-    // ---- K / V staging: thread -> (key, 16-byte chunk); two (K,V) chunk pairs per thread (blockDim >= 256)
-    u16x8_t kreg[2], vreg[2];
-    auto fetch_kv = [&](int j0) {
+    // ---- K / V staging of one key block into slot `slot`: thread -> (key, 16-byte chunk)
+    auto stage_kv = [&](int j0, int slot) {
+        char* ks = Ks + slot * K_BYTES;
+        char* vts = Vts + slot * VT_BYTES;
+        for (int idx = tid; idx < 32 * 16; idx += blockDim.x) {
+            const int key = idx >> 4, ch = idx & 15;
+            int krow = j0 + key;
+            krow = krow < T ? krow : T - 1;
+            const uint16_t* kp = base + (size_t)krow * ld + d + h * HD + ch * 8;
+            const u16x8_t kv = *reinterpret_cast<const u16x8_t*>(kp);
+            const u16x8_t vv = *reinterpret_cast<const u16x8_t*>(kp + d);
+            *reinterpret_cast<u16x8_t*>(ks + key * KROW + ch * 16) = kv;
+            const int posk = vt_pos(key);
+            // 16-byte chunk of the key axis XOR-ed with (d>>3)&3 = ch&3: the 16 threads that share a
+            // key hit 4 bank groups instead of one
+            const int col = (((posk >> 3) ^ (ch & 3)) << 4) + (posk & 7) * 2;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * blockDim.x;
-            if (idx < 32 * 16) {
-                const int key = idx >> 4, ch = idx & 15;
-                int krow = j0 + key;
-                krow = krow < T ? krow : T - 1;
-                const uint16_t* kp = base + (size_t)krow * ld + d + h * HD + ch * 8;
-                kreg[it] = *reinterpret_cast<const u16x8_t*>(kp);
-                vreg[it] = *reinterpret_cast<const u16x8_t*>(kp + d);
-            }
-        }
-    };
-    auto store_kv = [&]() {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * blockDim.x;
-            if (idx < 32 * 16) {
-                const int key = idx >> 4, ch = idx & 15;
-                *reinterpret_cast<u16x8_t*>(Ks + key * KROW + ch * 16) = kreg[it];
-                const int posk = vt_pos(key);
-                // 16-byte chunk of the key axis XOR-ed with (d>>3)&3 = ch&3: the 16 threads that share a
-                // key hit 4 bank groups instead of one
-                const int col = (((posk >> 3) ^ (ch & 3)) << 4) + (posk & 7) * 2;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    *reinterpret_cast<unsigned short*>(Vts + (ch * 8 + e) * VROW + col) = vreg[it][e];
-            }
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<unsigned short*>(vts + (ch * 8 + e) * VROW + col) = vv[e];
         }
     };
 
@@ -167,103 +155,103 @@ __global__ __launch_bounds__(512) void relpos_attention_kernel(AttnParams p) {
         return acc;
     };
 
-    if (n_kblocks > 0) {
-        fetch_kv(0);
-        store_kv();
-    }
     // rows n0 .. n0+31 of the first key block; every later block reuses the previous block's upper half
     f32x16_t bd_lo = bd_block(0 - i0 - 31 + T - 1);
-    __syncthreads();
 
-    for (int jb = 0; jb < n_kblocks; ++jb) {
-        const int j0 = jb * 32;
-        const bool more = jb + 1 < n_kblocks;
-        if (more) fetch_kv(j0 + 32);          // in flight under this block's MFMAs
+    // Keys are staged KB_CHUNK blocks at a time (all of them for T' <= 160): between two workgroup
+    // barriers every wave walks its key blocks on its own, so the waves drift apart and hide each
+    // other's L2 / LDS latencies instead of marching in lockstep.
+    for (int jc = 0; jc < n_kblocks; jc += KB_CHUNK) {
+        const int nb = n_kblocks - jc < KB_CHUNK ? n_kblocks - jc : KB_CHUNK;
+        if (jc > 0) __syncthreads();          // previous chunk fully consumed
+        for (int sl = 0; sl < nb; ++sl) stage_kv((jc + sl) * 32, sl);
+        __syncthreads();
 
-        // ---- S^T = K . (Q+u)^T   (8 MFMAs)
-        f32x16_t s;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + il * KROW + (2 * ks + hh) * 16);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[ks], s, 0, 0, 0);
-        }
-        // ---- upper half of BD^T for this key block: relative positions n0+32 .. n0+63   (8 MFMAs)
-        const int n0 = j0 - i0 - 31 + T - 1;
-        const f32x16_t bd_hi = bd_block(n0 + 32);
+        for (int sl = 0; sl < nb; ++sl) {
+            const int j0 = (jc + sl) * 32;
+            const char* ks_t = Ks + sl * K_BYTES;
+            const char* vts_t = Vts + sl * VT_BYTES;
 
-        // ---- skew through the per-wave scratch: scr_f[n_local][query]
+            // ---- S^T = K . (Q+u)^T   (8 MFMAs)
+            f32x16_t s;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            scr_f[rowmap(r, hh) * 32 + il] = bd_lo[r];
-            scr_f[(32 + rowmap(r, hh)) * 32 + il] = bd_hi[r];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        float pr[16];
-        float mblk = NEG;
+            for (int e = 0; e < 16; ++e) s[e] = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int jl = rowmap(r, hh);
-            const int j = j0 + jl;
-            const float bdv = scr_f[(jl - il + 31) * 32 + il];
-            bool ok = q_valid && j < len;
-            if (p.att_left >= 0 || p.att_right >= 0) {
-                bool win = (p.att_left < 0 || qi - j <= p.att_left) && (p.att_right < 0 || j - qi <= p.att_right);
-                if (p.n_global > 0) win = win || qi < p.n_global || j < p.n_global;
-                ok = ok && win;
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks_t + il * KROW + (2 * ks + hh) * 16);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[ks], s, 0, 0, 0);
             }
-            const float sc = ok ? (s[r] + bdv) * p.scale : NEG;
-            pr[r] = sc;
-            mblk = fmaxf(mblk, sc);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // scratch reads done before the next block overwrites it
-        bd_lo = bd_hi;
-        mblk = fmaxf(mblk, __shfl_xor(mblk, 32, 64));
-        const float m_new = fmaxf(m_run, mblk);
-        const float alpha = __expf(m_run - m_new);
-        float psum = 0.0f;
+            // ---- upper half of BD^T for this key block: relative positions n0+32 .. n0+63   (8 MFMAs)
+            const int n0 = j0 - i0 - 31 + T - 1;
+            const f32x16_t bd_hi = bd_block(n0 + 32);
+
+            // ---- skew through the per-wave scratch: scr_f[n_local][query]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = pr[r] > 0.5f * NEG ? __expf(pr[r] - m_new) : 0.0f;
-            pr[r] = e;
-            psum += e;
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+            for (int r = 0; r < 16; ++r) {
+                scr_f[rowmap(r, hh) * 32 + il] = bd_lo[r];
+                scr_f[(32 + rowmap(r, hh)) * 32 + il] = bd_hi[r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            float pr[16];
+            float mblk = NEG;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int r = 0; r < 16; ++r) {
+                const int jl = rowmap(r, hh);
+                const int j = j0 + jl;
+                const float bdv = scr_f[(jl - il + 31) * 32 + il];
+                bool ok = q_valid && j < len;
+                if (p.att_left >= 0 || p.att_right >= 0) {
+                    bool win = (p.att_left < 0 || qi - j <= p.att_left) && (p.att_right < 0 || j - qi <= p.att_right);
+                    if (p.n_global > 0) win = win || qi < p.n_global || j < p.n_global;
+                    ok = ok && win;
+                }
+                const float sc = ok ? (s[r] + bdv) * p.scale : NEG;
+                pr[r] = sc;
+                mblk = fmaxf(mblk, sc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // scratch reads done before the next block overwrites it
+            bd_lo = bd_hi;
+            mblk = fmaxf(mblk, __shfl_xor(mblk, 32, 64));
+            const float m_new = fmaxf(m_run, mblk);
+            const float alpha = __expf(m_run - m_new);
+            float psum = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
-        // ---- P^T fragments (bf16) and  O^T += V^T . P^T   (8 MFMAs)
-        bf16x8_t pf[2];
+            for (int r = 0; r < 16; ++r) {
+                const float e = pr[r] > 0.5f * NEG ? __expf(pr[r] - m_new) : 0.0f;
+                pr[r] = e;
+                psum += e;
+            }
+            psum += __shfl_xor(psum, 32, 64);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
 #pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
-            const u16x4_t lo = pack_bf16x4(pr[8 * sidx], pr[8 * sidx + 1], pr[8 * sidx + 2], pr[8 * sidx + 3]);
-            const u16x4_t hi = pack_bf16x4(pr[8 * sidx + 4], pr[8 * sidx + 5], pr[8 * sidx + 6], pr[8 * sidx + 7]);
-            u16x8_t t;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { t[e] = lo[e]; t[4 + e] = hi[e]; }
-            pf[sidx] = __builtin_bit_cast(bf16x8_t, t);
-        }
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            const int drow = db * 32 + il;
+                for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+            // ---- P^T fragments (bf16) and  O^T += V^T . P^T   (8 MFMAs)
+            bf16x8_t pf[2];
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
-                const int chunk = (2 * sidx + hh) ^ ((drow >> 3) & 3);
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vts + drow * VROW + chunk * 16);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sidx], o[db], 0, 0, 0);
+                const u16x4_t lo = pack_bf16x4(pr[8 * sidx], pr[8 * sidx + 1], pr[8 * sidx + 2], pr[8 * sidx + 3]);
+                const u16x4_t hi = pack_bf16x4(pr[8 * sidx + 4], pr[8 * sidx + 5], pr[8 * sidx + 6], pr[8 * sidx + 7]);
+                u16x8_t t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { t[e] = lo[e]; t[4 + e] = hi[e]; }
+                pf[sidx] = __builtin_bit_cast(bf16x8_t, t);
             }
-        }
-        __syncthreads();                 // everyone is done with this block's K / V^T tiles
-        if (more) {
-            store_kv();
-            __syncthreads();
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const int drow = db * 32 + il;
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    const int chunk = (2 * sidx + hh) ^ ((drow >> 3) & 3);
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vts_t + drow * VROW + chunk * 16);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sidx], o[db], 0, 0, 0);
+                }
+            }
         }
     }
 
@@ -292,14 +280,14 @@ int rs_launch_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, c
     p.T = T; p.d_model = dm.d_model; p.att_left = dm.att_left; p.att_right = dm.att_right; p.n_global = dm.n_global;
     p.scale = 1.0f / sqrtf((float)HD);
     const int qblocks = (T + 31) / 32;
-    int nw = qblocks < 8 ? qblocks : 8;
-    if (nw < 4) nw = 4;                  // K/V staging assumes >= 256 threads (2 chunk pairs per thread)
+    // at most 6 query blocks per workgroup: 5 * (8704 + 10240) + 6 * 8704 = 147 KB of the 160 KB LDS
+    const int nw = qblocks < 6 ? qblocks : 6;
     const dim3 grid((qblocks + nw - 1) / nw, dm.n_heads, B), block(64 * nw);
-    const size_t lds = K_BYTES + VT_BYTES + (size_t)nw * SCR_BYTES;
+    const size_t lds = (size_t)KB_CHUNK * (K_BYTES + VT_BYTES) + (size_t)nw * SCR_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)relpos_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                K_BYTES + VT_BYTES + 8 * SCR_BYTES) != hipSuccess)
+                                KB_CHUNK * (K_BYTES + VT_BYTES) + 6 * SCR_BYTES) != hipSuccess)
             return rs_fail(ctx, RS_EHIP, "attention: cannot reserve LDS");
         attr_set = true;
     }
