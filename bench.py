@@ -149,6 +149,17 @@ def main():
     model.ctx.profile_enable(0)
     dt = rdist.max_over_ranks(dt)
 
+    # PCIe-inclusive rate (never `value`): same steps, but every batch is copied from pinned host
+    # memory first and its hypotheses are copied back after decode
+    dt_host = None
+    if pipelined and world == 1:
+        model.run_pipelined(bufs, 2, from_host=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model.run_pipelined(bufs, args.steps, from_host=True)
+        torch.cuda.synchronize()
+        dt_host = time.perf_counter() - t1
+
     n_ids = np.concatenate([b.n_ids.cpu().numpy() for b in bufs])
     mean_tokens = float(n_ids.mean())
     audio_seconds = sum(float(lens_all[i % 2].sum()) for i in range(args.steps)) / 16000.0 * world
@@ -170,6 +181,8 @@ def main():
                                    if pipelined else "sequential"},
             "setup_s": round(setup_s, 1),
         }
+        if dt_host:
+            out["value_pcie_inclusive"] = round(audio_seconds / dt_host, 1)
         gf = algorithmic_gflop_per_utt(cfg, buf.tp_max, mean_tokens)
         out["algorithmic_tflops_whole_path"] = round(gf * args.batch * world * args.steps / dt / 1e3, 1)
         if gemm and gemm["launches"]:

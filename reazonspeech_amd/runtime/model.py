@@ -141,13 +141,17 @@ class AsrModel:
             ctx.encoder(buf.feats[lo:hi], buf.n_frames[lo:hi], hi - lo, buf.t_max, None, buf.joint_enc[lo:hi],
                         buf.enc_lens[lo:hi], ws, s)
 
-    def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None, split_encoder: bool = None):
+    def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None, split_encoder: bool = None,
+                      from_host: bool = False):
         """Process `steps` batches (bufs[i % len(bufs)], inputs already in HBM) as a two-stage
         pipeline: the throughput-bound front-end + encoder of batch i+1 runs on one HIP stream while
         the latency-bound greedy decode of batch i (a dependency chain of small launches that leaves
         most CUs idle) runs on a second stream, driven by a worker thread (ctypes releases the GIL;
         rs_rnnt_greedy synchronises only its own stream).  Every batch is fully decoded when this
-        returns.  `after_decode(buf)` is called on the worker thread after each batch."""
+        returns.  `after_decode(buf)` is called on the worker thread after each batch.  With
+        `from_host` every batch is first copied from its pinned host buffer (H2D on the encoder
+        stream) and its hypotheses are copied back to the host after decode (the PCIe-inclusive
+        boundary)."""
         assert len(bufs) >= 2, "the pipeline needs two buffer sets"
         with torch.cuda.device(self.device):
             if split_encoder is None:
@@ -181,6 +185,9 @@ class AsrModel:
                             # decode scratch lives past the encoder's scratch in buf.ws_dec
                             self._ctx_dec.rnnt_greedy(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, buf.u_max, buf.ids,
                                                       buf.frames, buf.n_ids, buf.ws_dec, dec_stream.cuda_stream)
+                            if from_host:
+                                with torch.cuda.stream(dec_stream):
+                                    buf.h_out = (buf.n_ids.cpu(), buf.ids.cpu(), buf.frames.cpu())
                             if after_decode is not None:
                                 after_decode(buf)
                         except Exception as e:          # surfaced on the caller's thread below
@@ -195,6 +202,10 @@ class AsrModel:
                 buf = bufs[i % nb]
                 if i >= nb:
                     done[i - nb].wait()           # this buffer set's previous decode must be finished
+                if from_host:
+                    with torch.cuda.stream(enc_stream):
+                        buf.audio.copy_(buf.h_audio, non_blocking=True)
+                        buf.lens.copy_(buf.h_lens, non_blocking=True)
                 if split_encoder and buf.B >= 2:
                     self._enc2_stream.wait_stream(enc_stream)       # keep batch order across both halves
                     self.run_encoder_split(buf, (enc_stream, self._enc2_stream))
@@ -245,10 +256,53 @@ class AsrModel:
         return DecodedBatch([ids[b, :n[b]].tolist() for b in range(buf.B)],
                             [frames[b, :n[b]].tolist() for b in range(buf.B)], el.tolist())
 
-    def transcribe_waveforms(self, waveforms: Sequence[np.ndarray]) -> DecodedBatch:
-        """host float32 waveforms -> token ids / frames (the batched boundary)"""
-        if len(waveforms) == 0:
+    def transcribe_waveforms(self, waveforms: Sequence[np.ndarray], max_batch: int = 256) -> DecodedBatch:
+        """host float32 waveforms -> token ids / frames (the batched boundary).
+
+        Up to `max_batch` utterances run as one batch.  Longer lists are sorted by length, cut into
+        batches of `max_batch` (tight padding per batch) and pushed through the two-stage pipeline
+        (encoder of batch i+1 || decode of batch i); results come back in the caller's order."""
+        n = len(waveforms)
+        if n == 0:
             return DecodedBatch([], [], [])
-        buf = self.stage(waveforms)
-        self.run_device(buf)
-        return self.collect(buf)
+        if n <= max_batch:
+            buf = self.stage(waveforms)
+            self.run_device(buf)
+            return self.collect(buf)
+        order = sorted(range(n), key=lambda i: (len(waveforms[i]), i))
+        ids, frames, enc_lens = [None] * n, [None] * n, [None] * n
+        groups = [order[i:i + max_batch] for i in range(0, n, max_batch)]
+        l_max = max(len(w) for w in waveforms)
+        pool = [self.new_buffers(max_batch, l_max), self.new_buffers(max_batch, l_max)]
+
+        def fill(buf, group):
+            # short last group: pad with empty utterances (length 0 decodes to nothing)
+            waves = [waveforms[i] for i in group] + [np.zeros(0, np.float32)] * (max_batch - len(group))
+            self.stage(waves, buf=buf)
+
+        def harvest(buf, group):
+            torch.cuda.current_stream().synchronize()
+            res = self.collect(buf)
+            for k, i in enumerate(group):
+                ids[i], frames[i], enc_lens[i] = res.ids[k], res.frames[k], res.enc_lens[k]
+
+        # the pipeline needs inputs resident before a step starts: stage two groups ahead of use
+        pending = {}
+
+        def after(buf):
+            harvest(buf, pending.pop(id(buf)))
+
+        # process pairs of groups through run_pipelined so staging of the next pair never races the
+        # encoder of the current one
+        for g0 in range(0, len(groups), 2):
+            pair = groups[g0:g0 + 2]
+            for k, group in enumerate(pair):
+                fill(pool[k], group)
+                pending[id(pool[k])] = group
+            torch.cuda.current_stream().synchronize()
+            if len(pair) == 2:
+                self.run_pipelined(pool, 2, after_decode=after)
+            else:
+                self.run_device(pool[0])
+                after(pool[0])
+        return DecodedBatch(ids, frames, enc_lens)
