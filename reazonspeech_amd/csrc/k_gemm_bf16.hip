@@ -32,6 +32,7 @@ struct GemmParams {
     int mask_rows_per_step, mask_steps;
     int tiles_m, tiles_n;
     int skew_cycles;   // one-off start delay of every second dispatch round (see launch_variant)
+    long long* trace;  // debug: per-tile timestamps (scripts/gemm_trace.py); nullptr in production
 };
 
 template <int BK>
@@ -90,7 +91,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
-template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST>
+template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST, bool RES, bool TRACE = false>
 __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 1 : 2) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NWAVES = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
     const int nk = p.K / BK;
     const int flags = p.flags;
     const bool has_bias = flags & RS_GEMM_BIAS, relu = flags & RS_GEMM_RELU, silu = flags & RS_GEMM_SILU;
-    const bool has_res = flags & RS_GEMM_RESIDUAL, out_f32 = flags & RS_GEMM_OUT_F32;
+    constexpr bool has_res = RES;   // residual epilogue is its own instantiation: no dead residual registers elsewhere
+    const bool out_f32 = RES || (flags & RS_GEMM_OUT_F32);
     const bool rowmask = flags & RS_GEMM_ROWMASK;
     const float alpha = p.alpha;
 
@@ -152,6 +154,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
         if (t < nk) issue(m0, n0, t);
 
     for (int j = slot; j < xcount; j += nslots) {
+        long long ts0 = 0, ts1 = 0, ts2 = 0, wall0 = 0;
+        if constexpr (TRACE) { ts0 = __builtin_readcyclecounter(); wall0 = (long long)wall_clock64(); }
         f32x16_t acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
             if (t + NST - 2 < nk && !(PERSIST && t == 0)) wait_vmcnt<LOADS_PER_STAGE * (NST - 2)>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();   // everyone's part of stage t is in LDS; stage t-1's buffer is free
+            if constexpr (TRACE) { if (t == 0) ts1 = __builtin_readcyclecounter(); }
             const char* at = smem + (t % NST) * STAGE_BYTES;
             const char* bt = at + A_BYTES;
             // software pipeline over the k sub-steps: the fragments of ks+1 are requested from LDS before
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
 
         // ---- next tile's first stages go in flight before this tile's epilogue, so their HBM/L2
         // latency (and the workgroup launch a non-persistent grid would pay) hides under the stores
+        if constexpr (TRACE) ts2 = __builtin_readcyclecounter();
         int cm0 = m0, cn0 = n0;
         // make the epilogue's addresses un-hoistable: computed at kernel entry they would be kept alive
         // across the main loop and spilled (~90 VGPRs of scratch traffic around every tile)
@@ -216,8 +222,36 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
         // operand, so D = (A.W^T)^T: lane = (m = lane&31, half h), register r <-> n = (r&3) + 8*(r>>2) + 4*h.
         // Each lane owns 4 consecutive n per register quad: one 16-byte f32 (8-byte bf16) access; the
         // two half-waves cover a contiguous 32-byte (16-byte) run of one output row.
+        // Loads first, math later: the bias of the whole wave tile is fetched up front and the
+        // residual of block k+1 is requested before block k is processed, so no store waits on a
+        // load that was issued right before it (per-block exposed L2/HBM latency was 27 % of a
+        // K=1024 tile and 21 % of a K=4096 residual tile — profiles/r01k_gemm_tile_timeline.txt).
+        float4 bias_r[NI][4];
+        if (has_bias) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+            for (int jj = 0; jj < NI; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = cn0 + wn * TN + jj * 32 + 4 * fhalf + 8 * g;
+                    bias_r[jj][g] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
+        auto load_res = [&](int blk, float4 (&rv)[4]) {
+            const int i = blk / NI, jj = blk % NI;
+            const int m = cm0 + wm * TM + i * 32 + frow;
+            const int nb = cn0 + wn * TN + jj * 32 + 4 * fhalf;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nb + 8 * g;
+                rv[g] = (m < p.M && n < p.N) ? *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldc + n)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        float4 rv_next[4];
+        if constexpr (has_res) load_res(0, rv_next);
+#pragma unroll
+        for (int blk = 0; blk < MI * NI; ++blk) {
+            const int i = blk / NI, jj = blk % NI;
             const int m = cm0 + wm * TM + i * 32 + frow;
             const bool m_ok = m < p.M;
             bool keep = true;
@@ -227,64 +261,64 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
                 keep = step - b * p.mask_steps < p.mask_lens[b];
             }
             const size_t rowoff = (size_t)m * p.ldc;
+            const int nb = cn0 + wn * TN + jj * 32 + 4 * fhalf;
+            float4 rv[4];
+            if constexpr (has_res) {
 #pragma unroll
-            for (int jj = 0; jj < NI; ++jj) {
-                const int nb = cn0 + wn * TN + jj * 32 + 4 * fhalf;
-                float4 rv[4];
-                if (has_res) {
+                for (int g = 0; g < 4; ++g) rv[g] = rv_next[g];
+                if (blk + 1 < MI * NI) load_res(blk + 1, rv_next);
+            }
+            float4 v[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = nb + 8 * g;
-                        rv[g] = (m_ok && n < p.N) ? *reinterpret_cast<const float4*>(p.residual + rowoff + n)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                }
-                float4 v[4];
+            for (int g = 0; g < 4; ++g) {
+                v[g] = make_float4(acc[i][jj][4 * g], acc[i][jj][4 * g + 1], acc[i][jj][4 * g + 2], acc[i][jj][4 * g + 3]);
+                if (has_bias) { v[g].x += bias_r[jj][g].x; v[g].y += bias_r[jj][g].y; v[g].z += bias_r[jj][g].z; v[g].w += bias_r[jj][g].w; }
+                if (relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
+                if (silu) { v[g].x = silu_f(v[g].x); v[g].y = silu_f(v[g].y); v[g].z = silu_f(v[g].z); v[g].w = silu_f(v[g].w); }
+                v[g].x *= alpha; v[g].y *= alpha; v[g].z *= alpha; v[g].w *= alpha;
+                if constexpr (has_res) { v[g].x += rv[g].x; v[g].y += rv[g].y; v[g].z += rv[g].z; v[g].w += rv[g].w; }
+                if (!keep) v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (out_f32) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = nb + 8 * g;
-                    v[g] = make_float4(acc[i][jj][4 * g], acc[i][jj][4 * g + 1], acc[i][jj][4 * g + 2], acc[i][jj][4 * g + 3]);
-                    if (has_bias && n < p.N) {
-                        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                        v[g].x += bv.x; v[g].y += bv.y; v[g].z += bv.z; v[g].w += bv.w;
-                    }
-                    if (relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
-                    if (silu) { v[g].x = silu_f(v[g].x); v[g].y = silu_f(v[g].y); v[g].z = silu_f(v[g].z); v[g].w = silu_f(v[g].w); }
-                    v[g].x *= alpha; v[g].y *= alpha; v[g].z *= alpha; v[g].w *= alpha;
-                    if (has_res) { v[g].x += rv[g].x; v[g].y += rv[g].y; v[g].z += rv[g].z; v[g].w += rv[g].w; }
-                    if (!keep) v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m_ok && n < p.N) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + rowoff + n) = v[g];
                 }
-                if (out_f32) {
+            } else {
+                // bf16: pair the register quads (g, g+1) across the two half-waves with
+                // v_permlane32_swap so every lane stores 8 consecutive columns (16 bytes) and the
+                // two half-waves together a contiguous 32-byte run of the row (guide T21)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = nb + 8 * g;
-                        if (m_ok && n < p.N) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + rowoff + n) = v[g];
-                    }
-                } else {
-                    // bf16: pair the register quads (g, g+1) across the two half-waves with
-                    // v_permlane32_swap so every lane stores 8 consecutive columns (16 bytes) and the
-                    // two half-waves together a contiguous 32-byte run of the row (guide T21)
-#pragma unroll
-                    for (int g = 0; g < 4; g += 2) {
-                        const u16x4_t pa = pack_bf16x4(v[g].x, v[g].y, v[g].z, v[g].w);
-                        const u16x4_t pb = pack_bf16x4(v[g + 1].x, v[g + 1].y, v[g + 1].z, v[g + 1].w);
-                        unsigned a0 = __builtin_bit_cast(uint2, pa).x, a1 = __builtin_bit_cast(uint2, pa).y;
-                        unsigned b0 = __builtin_bit_cast(uint2, pb).x, b1 = __builtin_bit_cast(uint2, pb).y;
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                        // h = 0: [own g | partner's g] -> columns 8g .. 8g+7 ; h = 1: [partner's g+1 | own g+1]
-                        const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                        const int n = cn0 + wn * TN + jj * 32 + 8 * (g + fhalf);
-                        if (m_ok && n < p.N) {
-                            uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + rowoff + n;
-                            if (n + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = o;
-                            else *reinterpret_cast<uint2*>(dst) = make_uint2(o.x, o.y);   // N % 8 == 4 tail
-                        }
+                for (int g = 0; g < 4; g += 2) {
+                    const u16x4_t pa = pack_bf16x4(v[g].x, v[g].y, v[g].z, v[g].w);
+                    const u16x4_t pb = pack_bf16x4(v[g + 1].x, v[g + 1].y, v[g + 1].z, v[g + 1].w);
+                    unsigned a0 = __builtin_bit_cast(uint2, pa).x, a1 = __builtin_bit_cast(uint2, pa).y;
+                    unsigned b0 = __builtin_bit_cast(uint2, pb).x, b1 = __builtin_bit_cast(uint2, pb).y;
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    // h = 0: [own g | partner's g] -> columns 8g .. 8g+7 ; h = 1: [partner's g+1 | own g+1]
+                    const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    const int n = cn0 + wn * TN + jj * 32 + 8 * (g + fhalf);
+                    if (m_ok && n < p.N) {
+                        uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + rowoff + n;
+                        if (n + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = o;
+                        else *reinterpret_cast<uint2*>(dst) = make_uint2(o.x, o.y);   // N % 8 == 4 tail
                     }
                 }
-                // one 32x32 block at a time: without this fence the scheduler hoists the residual
-                // loads of all MI*NI blocks above the first store and spills ~100 VGPRs
-                __builtin_amdgcn_sched_barrier(0);
+            }
+            // one 32x32 block at a time (the next block's residual is already in flight): without
+            // this fence the scheduler hoists every block's loads above the first store and spills
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (TRACE) {
+            const long long ts3 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long ts4 = __builtin_readcyclecounter();
+            if (tid == 0) {
+                long long* tr = p.trace + (size_t)(xbase + j) * 8;
+                tr[0] = 0; tr[1] = ts1 - ts0; tr[2] = ts2 - ts0; tr[3] = ts3 - ts0; tr[4] = ts4 - ts0; tr[5] = bid;
+                tr[6] = wall0; tr[7] = (long long)wall_clock64();   // 100 MHz, chip-wide
             }
         }
     }
@@ -292,9 +326,10 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
 
 extern int g_skew;
 extern int g_persistent;
+extern long long* g_trace;
 
-template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST = false>
-int launch_variant(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
+template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST, bool RES>
+int launch_variant2(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int LDS = NST * STAGE_BYTES;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -307,20 +342,31 @@ int launch_variant(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     p.skew_cycles = persist ? (int)(skew_frac * (2.0 * BM * BN * (double)p.K / 1.0e15 * 256.0) * 2.4e9) : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, PERSIST>,
+        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, PERSIST, RES>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false>,
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return rs_fail(ctx, RS_EHIP, "gemm: cannot reserve %d bytes of LDS", LDS);
         attr_set = true;
     }
-    if (persist)
-        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, PERSIST>), dim3(CUS), dim3(64 * WM * WN), LDS, s, p);
+    if (p.trace)     // debug build of the same kernel that records per-tile timestamps
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, true>), dim3(nwg), dim3(64 * WM * WN), LDS, s, p);
+    else if (persist)
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, PERSIST, RES>), dim3(CUS), dim3(64 * WM * WN), LDS, s, p);
     else
-        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false>), dim3(nwg), dim3(64 * WM * WN), LDS, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES>), dim3(nwg), dim3(64 * WM * WN), LDS, s, p);
     return RS_OK;
 }
 
+template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST = false>
+int launch_variant(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
+    if (p.flags & RS_GEMM_RESIDUAL) return launch_variant2<BM, BN, BK, NST, WM, WN, PERSIST, true>(ctx, p, s);
+    return launch_variant2<BM, BN, BK, NST, WM, WN, PERSIST, false>(ctx, p, s);
+}
+
+long long* g_trace = nullptr;
 int g_variant = -1;
 int g_skew = -1;
 int g_persistent = -1;
@@ -330,6 +376,7 @@ int g_persistent = -1;
 // tuning hook for A/B runs (scripts/gemm_bench.py); not part of the public header
 extern "C" void rs_debug_set_gemm_variant(int v) { g_variant = v; }
 extern "C" void rs_debug_set_gemm_skew(int v) { g_skew = v; }
+extern "C" void rs_debug_set_gemm_trace(long long* buf) { g_trace = buf; }
 extern "C" void rs_debug_set_gemm_persistent(int v) { g_persistent = v; }
 
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
@@ -350,6 +397,7 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K; p.flags = a.flags;
     p.alpha = a.alpha; p.mask_rows_per_step = a.mask_rows_per_step; p.mask_steps = a.mask_steps;
     p.tiles_m = p.tiles_n = 0;
+    p.trace = g_trace;
     if (g_variant < 0) {
         const char* e = getenv("RS_GEMM_VARIANT");   // tuning knob for A/B runs; default chosen by shape
         g_variant = e ? atoi(e) : 0;
@@ -381,15 +429,8 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         case 1: rc = launch_variant<128, 128, 64, 2, 2, 2>(ctx, p, s); break;   // small problems
         case 2: rc = launch_variant<256, 256, 64, 2, 2, 4>(ctx, p, s); break;   // big tile, drain per K step
         case 3: rc = launch_variant<256, 256, 32, 4, 2, 4>(ctx, p, s); break;   // big tile, 4-stage ring, counted vmcnt
-        case 4: rc = launch_variant<128, 128, 32, 4, 2, 2>(ctx, p, s); break;
-        case 5: rc = launch_variant<256, 128, 32, 4, 4, 2>(ctx, p, s); break;
-        case 6: rc = launch_variant<256, 128, 32, 3, 2, 2>(ctx, p, s); break;   // 2 independent WGs per CU
         case 7: rc = launch_variant<128, 128, 32, 3, 2, 2>(ctx, p, s); break;   // 3 WGs per CU
-        case 8: rc = launch_variant<256, 128, 64, 2, 2, 2>(ctx, p, s); break;
         case 9: rc = launch_variant<256, 256, 64, 2, 2, 4, true>(ctx, p, s); break;    // persistent, one WG per CU
-        case 11: rc = launch_variant<256, 256, 64, 2, 2, 2>(ctx, p, s); break;         // 4 waves x (128x128): one wave per SIMD, 512-VGPR budget
-        case 12: rc = launch_variant<256, 256, 64, 2, 2, 2, true>(ctx, p, s); break;
-        case 10: rc = launch_variant<256, 256, 32, 4, 2, 4, true>(ctx, p, s); break;
         default: rc = rs_fail(ctx, RS_EINVAL, "gemm: unknown RS_GEMM_VARIANT %d", v);
     }
     rs_prof_end(ctx, RS_PROF_GEMM, s);
