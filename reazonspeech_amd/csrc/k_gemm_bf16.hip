@@ -47,7 +47,8 @@ struct Swz {
     }
 };
 
-template <int BK, int ROWS, int NWAVES>
+// issues the wave's global_load_lds number J0 .. J1-1 (of PER_WAVE) for one operand tile
+template <int BK, int ROWS, int NWAVES, int J0 = 0, int J1 = -1>
 __device__ __forceinline__ void stage_rows(const uint16_t* __restrict__ base, int ld, int row0, int max_row, int k0,
                                            char* lds_tile, int wave, int lane) {
     using S = Swz<BK>;
@@ -55,9 +56,10 @@ __device__ __forceinline__ void stage_rows(const uint16_t* __restrict__ base, in
     constexpr int INSTS = ROWS / ROWS_PER_INST;
     constexpr int PER_WAVE = INSTS / NWAVES;
     static_assert(INSTS % NWAVES == 0, "tile rows must split evenly over the waves");
+    constexpr int JE = J1 < 0 ? PER_WAVE : (J1 < PER_WAVE ? J1 : PER_WAVE);
     const int r = lane / S::CHUNKS, pc = lane % S::CHUNKS;
 #pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
+    for (int j = J0; j < JE; ++j) {
         const int rbase = (wave * PER_WAVE + j) * ROWS_PER_INST;
         const int row = rbase + r;
         const int c = pc ^ S::x(row);
@@ -181,10 +183,28 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
             for (int i = 0; i < MI; ++i) af[0][i] = read_frag<BK>(at, wm * TM + i * 32 + frow, fhalf);
 #pragma unroll
             for (int jj = 0; jj < NI; ++jj) bfr[0][jj] = read_frag<BK>(bt, wn * TN + jj * 32 + frow, fhalf);
-            if (t + NST - 1 < nk) issue(m0, n0, t + NST - 1);
+            const bool more = t + NST - 1 < nk;
+            char* nst = smem + ((t + NST - 1) % NST) * STAGE_BYTES;
+            const int nk0 = (t + NST - 1) * BK;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int cur = ks & 1, nxt = cur ^ 1;
+                // the next stage's DMA is spread over the k sub-steps (a global_load_lds costs ~100 issue
+                // cycles: eight of them in one burst after the barrier left the MFMA pipe idle for a
+                // third of every K step)
+                if (more) {
+                    constexpr int PW_A = (BM / (1024 / (BK * 2))) / NWAVES, PW_B = (BN / (1024 / (BK * 2))) / NWAVES;
+                    constexpr int HALF = KS / 2 > 0 ? KS / 2 : 1;
+                    if (KS >= 2) {
+                        if (ks < HALF) {
+                            if (ks == 0) stage_rows<BK, BM, NWAVES, 0, (PW_A + HALF - 1) / HALF>(p.A, p.lda, m0, p.M, nk0, nst, wave, lane);
+                            if (ks == 1 && HALF > 1) stage_rows<BK, BM, NWAVES, (PW_A + HALF - 1) / HALF, PW_A>(p.A, p.lda, m0, p.M, nk0, nst, wave, lane);
+                        } else {
+                            if (ks == HALF) stage_rows<BK, BN, NWAVES, 0, (PW_B + HALF - 1) / HALF>(p.W, p.ldw, n0, p.N, nk0, nst + A_BYTES, wave, lane);
+                            if (ks == HALF + 1 && HALF > 1) stage_rows<BK, BN, NWAVES, (PW_B + HALF - 1) / HALF, PW_B>(p.W, p.ldw, n0, p.N, nk0, nst + A_BYTES, wave, lane);
+                        }
+                    }
+                }
                 if (ks + 1 < KS) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
