@@ -242,35 +242,43 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
         // operand, so D = (A.W^T)^T: lane = (m = lane&31, half h), register r <-> n = (r&3) + 8*(r>>2) + 4*h.
         // Each lane owns 4 consecutive n per register quad: one 16-byte f32 (8-byte bf16) access; the
         // two half-waves cover a contiguous 32-byte (16-byte) run of one output row.
-        // Loads first, math later: the bias of the whole wave tile is fetched up front and the
-        // residual of block k+1 is requested before block k is processed, so no store waits on a
-        // load that was issued right before it (per-block exposed L2/HBM latency was 27 % of a
-        // K=1024 tile and 21 % of a K=4096 residual tile — profiles/r01k_gemm_tile_timeline.txt).
-        float4 bias_r[NI][4];
-        if (has_bias) {
+        // Loads first, math later.  The unit of work is half a 32x32 block (two register quads = the
+        // pair that the bf16 store widens with v_permlane32_swap).  Without a residual the bias of the
+        // whole wave tile is fetched up front; with one, the (bias, residual) of unit k+1 is requested
+        // before unit k is processed, so no store waits on a load issued right before it (per-block
+        // exposed L2/HBM latency was 27 % of a K=1024 tile — profiles/r01k_gemm_tile_timeline.txt)
+        // and only 32 VGPRs are in flight (the 128x128 kernel keeps 3 workgroups per CU).
+        constexpr int UNITS = MI * NI * 2;
+        float4 bias_all[has_res ? 1 : NI][has_res ? 1 : 4];
+        if constexpr (!has_res) {
+            if (has_bias) {
 #pragma unroll
-            for (int jj = 0; jj < NI; ++jj)
+                for (int jj = 0; jj < NI; ++jj)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = cn0 + wn * TN + jj * 32 + 4 * fhalf + 8 * g;
-                    bias_r[jj][g] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = cn0 + wn * TN + jj * 32 + 4 * fhalf + 8 * g;
+                        bias_all[jj][g] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
         }
-        auto load_res = [&](int blk, float4 (&rv)[4]) {
+        auto load_unit = [&](int u, float4 (&rv)[2], float4 (&bv)[2]) {   // RES kernels only
+            const int blk = u >> 1, gp = u & 1;
             const int i = blk / NI, jj = blk % NI;
             const int m = cm0 + wm * TM + i * 32 + frow;
             const int nb = cn0 + wn * TN + jj * 32 + 4 * fhalf;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nb + 8 * g;
-                rv[g] = (m < p.M && n < p.N) ? *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldc + n)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < 2; ++q) {
+                const int n = nb + 8 * (2 * gp + q);
+                const bool ok = m < p.M && n < p.N;
+                rv[q] = ok ? *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldc + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[q] = (has_bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        float4 rv_next[4];
-        if constexpr (has_res) load_res(0, rv_next);
+        float4 rv_next[2], bv_next[2];
+        if constexpr (has_res) load_unit(0, rv_next, bv_next);
 #pragma unroll
-        for (int blk = 0; blk < MI * NI; ++blk) {
+        for (int u = 0; u < UNITS; ++u) {
+            const int blk = u >> 1, gp = u & 1;
             const int i = blk / NI, jj = blk % NI;
             const int m = cm0 + wm * TM + i * 32 + frow;
             const bool m_ok = m < p.M;
@@ -282,53 +290,54 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
             }
             const size_t rowoff = (size_t)m * p.ldc;
             const int nb = cn0 + wn * TN + jj * 32 + 4 * fhalf;
-            float4 rv[4];
+            float4 rv[2], bv[2];
             if constexpr (has_res) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) rv[g] = rv_next[g];
-                if (blk + 1 < MI * NI) load_res(blk + 1, rv_next);
-            }
-            float4 v[4];
+                for (int q = 0; q < 2; ++q) { rv[q] = rv_next[q]; bv[q] = bv_next[q]; }
+                if (u + 1 < UNITS) load_unit(u + 1, rv_next, bv_next);
+            } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                v[g] = make_float4(acc[i][jj][4 * g], acc[i][jj][4 * g + 1], acc[i][jj][4 * g + 2], acc[i][jj][4 * g + 3]);
-                if (has_bias) { v[g].x += bias_r[jj][g].x; v[g].y += bias_r[jj][g].y; v[g].z += bias_r[jj][g].z; v[g].w += bias_r[jj][g].w; }
-                if (relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
-                if (silu) { v[g].x = silu_f(v[g].x); v[g].y = silu_f(v[g].y); v[g].z = silu_f(v[g].z); v[g].w = silu_f(v[g].w); }
-                v[g].x *= alpha; v[g].y *= alpha; v[g].z *= alpha; v[g].w *= alpha;
-                if constexpr (has_res) { v[g].x += rv[g].x; v[g].y += rv[g].y; v[g].z += rv[g].z; v[g].w += rv[g].w; }
-                if (!keep) v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < 2; ++q) bv[q] = has_bias ? bias_all[jj][2 * gp + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4 v[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int g = 2 * gp + q;
+                v[q] = make_float4(acc[i][jj][4 * g], acc[i][jj][4 * g + 1], acc[i][jj][4 * g + 2], acc[i][jj][4 * g + 3]);
+                v[q].x += bv[q].x; v[q].y += bv[q].y; v[q].z += bv[q].z; v[q].w += bv[q].w;
+                if (relu) { v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f); }
+                if (silu) { v[q].x = silu_f(v[q].x); v[q].y = silu_f(v[q].y); v[q].z = silu_f(v[q].z); v[q].w = silu_f(v[q].w); }
+                v[q].x *= alpha; v[q].y *= alpha; v[q].z *= alpha; v[q].w *= alpha;
+                if constexpr (has_res) { v[q].x += rv[q].x; v[q].y += rv[q].y; v[q].z += rv[q].z; v[q].w += rv[q].w; }
+                if (!keep) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (out_f32) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = nb + 8 * g;
-                    if (m_ok && n < p.N) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + rowoff + n) = v[g];
+                for (int q = 0; q < 2; ++q) {
+                    const int n = nb + 8 * (2 * gp + q);
+                    if (m_ok && n < p.N) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + rowoff + n) = v[q];
                 }
             } else {
-                // bf16: pair the register quads (g, g+1) across the two half-waves with
-                // v_permlane32_swap so every lane stores 8 consecutive columns (16 bytes) and the
-                // two half-waves together a contiguous 32-byte run of the row (guide T21)
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    const u16x4_t pa = pack_bf16x4(v[g].x, v[g].y, v[g].z, v[g].w);
-                    const u16x4_t pb = pack_bf16x4(v[g + 1].x, v[g + 1].y, v[g + 1].z, v[g + 1].w);
-                    unsigned a0 = __builtin_bit_cast(uint2, pa).x, a1 = __builtin_bit_cast(uint2, pa).y;
-                    unsigned b0 = __builtin_bit_cast(uint2, pb).x, b1 = __builtin_bit_cast(uint2, pb).y;
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                    // h = 0: [own g | partner's g] -> columns 8g .. 8g+7 ; h = 1: [partner's g+1 | own g+1]
-                    const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    const int n = cn0 + wn * TN + jj * 32 + 8 * (g + fhalf);
-                    if (m_ok && n < p.N) {
-                        uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + rowoff + n;
-                        if (n + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = o;
-                        else *reinterpret_cast<uint2*>(dst) = make_uint2(o.x, o.y);   // N % 8 == 4 tail
-                    }
+                // bf16: pair the two register quads across the half-waves with v_permlane32_swap so
+                // every lane stores 8 consecutive columns (16 bytes) and the two half-waves together a
+                // contiguous 32-byte run of the row (guide T21)
+                const u16x4_t pa = pack_bf16x4(v[0].x, v[0].y, v[0].z, v[0].w);
+                const u16x4_t pb = pack_bf16x4(v[1].x, v[1].y, v[1].z, v[1].w);
+                unsigned a0 = __builtin_bit_cast(uint2, pa).x, a1 = __builtin_bit_cast(uint2, pa).y;
+                unsigned b0 = __builtin_bit_cast(uint2, pb).x, b1 = __builtin_bit_cast(uint2, pb).y;
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                // h = 0: [own g | partner's g] -> columns 8g .. 8g+7 ; h = 1: [partner's g+1 | own g+1]
+                const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                const int n = cn0 + wn * TN + jj * 32 + 8 * (2 * gp + fhalf);
+                if (m_ok && n < p.N) {
+                    uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + rowoff + n;
+                    if (n + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = o;
+                    else *reinterpret_cast<uint2*>(dst) = make_uint2(o.x, o.y);   // N % 8 == 4 tail
                 }
             }
-            // one 32x32 block at a time (the next block's residual is already in flight): without
-            // this fence the scheduler hoists every block's loads above the first store and spills
+            // one unit at a time (the next unit's loads are already in flight): without this fence the
+            // scheduler hoists every unit's loads above the first store and spills
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (TRACE) {
