@@ -248,6 +248,19 @@ def test_python_boundary(tiny):
     assert isinstance(r8.text, str)
 
 
+def test_evaluation_batch_hook(tiny):
+    """SURVEY.md §8f next #1: the batched evaluation hook == per-example transcribe()"""
+    from reazonspeech_amd.evaluation import RSAmdEvaluator
+    model, _ = tiny
+    audio, lens = synthetic_batch(5, 1.5, seed=3, ragged=True, min_seconds=0.4)
+    rows = [{"audio": {"array": audio[b, :lens[b]], "sampling_rate": 16000}, "text": "あ"} for b in range(5)]
+    ev = RSAmdEvaluator(model=model, batch_size=3)
+    out = ev.evaluate(rows)
+    assert [r["prediction"] for r in out] == [transcribe(model, audio_from_numpy(audio[b, :lens[b]], 16000)).text
+                                              for b in range(5)]
+    assert all(r["length"] == 1 for r in out)
+
+
 def test_load_model_rejects_cpu():
     with pytest.raises(RuntimeError):
         load_model(device="cpu")
