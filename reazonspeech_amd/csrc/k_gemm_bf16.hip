@@ -442,13 +442,19 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     int rc;
     int v = g_variant;
     if (v == 0) {
-        // measured on MI355X (profiles/r01_gemm_variants.txt): the 256x256 tile wins whenever there
-        // are enough tiles to fill the chip a few times; narrow-N / short-K problems prefer the
-        // 128x128 3-stage kernel (3 workgroups per CU hide its epilogue better)
-        const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+        // measured on MI355X (profiles/r01_gemm_variants.txt, r01n_gemm_tile_height.txt): big tiles win
+        // whenever they fill the chip at least twice; below that the 128x128 kernels (2-3 workgroups
+        // per CU) hide their epilogue better.  All tiles of a launch cost the same and the 256 CUs run
+        // them in lockstep rounds, so the tile HEIGHT is picked to minimise rounds x height: at
+        // M=35328, N=1024 a 256-row tile needs 3 rounds with the last one 16 % full, a 192-row tile
+        // fills 2.9 rounds (ffn_down 413 -> 351 us).
+        constexpr long CUS = 256;
+        const long tn = (a.N + 255) / 256;
+        const long t256 = (long)((a.M + 255) / 256) * tn, t192 = (long)((a.M + 191) / 192) * tn;
         if (a.M < 1024 || a.N < 256) v = 1;
-        else if (tiles256 < 1024 && a.K <= 1024) v = 7;
-        else v = g_persistent ? 9 : 2;
+        else if (t256 < 2 * CUS) v = a.K <= 1024 ? 7 : 1;
+        else if (g_persistent) v = 9;
+        else v = ((t192 + CUS - 1) / CUS) * 192 < ((t256 + CUS - 1) / CUS) * 256 ? 10 : 2;
         // (variant 9, the persistent tile loop, is ~20 % faster in isolation — profiles/r01_gemm_persistent.txt —
         // but one 128 KiB-LDS workgroup per CU for the whole launch starves the decode stream of the
         // two-stage pipeline; it is selected with rs_debug_set_gemm_persistent(1) / RS_GEMM_PERSISTENT=1
@@ -460,6 +466,7 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         case 3: rc = launch_variant<256, 256, 32, 4, 2, 4>(ctx, p, s); break;   // big tile, 4-stage ring, counted vmcnt
         case 7: rc = launch_variant<128, 128, 32, 3, 2, 2>(ctx, p, s); break;   // 3 WGs per CU
         case 9: rc = launch_variant<256, 256, 64, 2, 2, 4, true>(ctx, p, s); break;    // persistent, one WG per CU
+        case 10: rc = launch_variant<192, 256, 64, 2, 2, 4>(ctx, p, s); break;  // 3/4 tile: fewer idle CUs in the last round
         default: rc = rs_fail(ctx, RS_EINVAL, "gemm: unknown RS_GEMM_VARIANT %d", v);
     }
     rs_prof_end(ctx, RS_PROF_GEMM, s);
