@@ -31,6 +31,7 @@ struct GemmParams {
     float alpha;
     int mask_rows_per_step, mask_steps;
     int tiles_m, tiles_n;
+    int group_m;       // row panels per tile group (see tile_origin)
     int skew_cycles;   // one-off start delay of every second dispatch round (see launch_variant)
     long long* trace;  // debug: per-tile timestamps (scripts/gemm_trace.py); nullptr in production
 };
@@ -142,11 +143,19 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
         stage_rows<BK, BM, NWAVES>(p.A, p.lda, m0, p.M, t * BK, st, wave, lane);
         stage_rows<BK, BN, NWAVES>(p.W, p.ldw, n0, p.N, t * BK, st + A_BYTES, wave, lane);
     };
+    // Linear tile index -> (tile_m, tile_n), grouped: group_m row panels form a group that is walked
+    // m-fastest, then across n.  The ~32 tiles an XCD runs at the same time are then group_m A panels x
+    // 32/group_m weight tiles instead of 2 x 16: fewer distinct bytes per round, and the weight matrix
+    // is re-streamed through that XCD's L2 once per group_m panels instead of once per two.
     auto tile_origin = [&](int j, int& m0, int& n0) {
         const int wg = xbase + j;
-        const int tile_m = wg / p.tiles_n;
-        m0 = tile_m * BM;
-        n0 = (wg - tile_m * p.tiles_n) * BN;
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = wg / per_group, r = wg - g * per_group;
+        const int left = p.tiles_m - g * p.group_m;
+        const int gm = left < p.group_m ? left : p.group_m;
+        const int tile_n = r / gm;
+        m0 = (g * p.group_m + (r - tile_n * gm)) * BM;
+        n0 = tile_n * BN;
     };
 
     int m0, n0;
@@ -355,6 +364,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
 
 extern int g_skew;
 extern int g_persistent;
+extern int g_group_m;
 extern long long* g_trace;
 
 template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST, bool RES>
@@ -364,6 +374,11 @@ int launch_variant2(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const int nwg = p.tiles_m * p.tiles_n;
+    // measured (profiles/r01o_gemm_group_m.txt): with operands hot in the 256 MiB infinity cache, 8
+    // panels x 4 weight tiles per XCD round beats the plain n-fastest order by 15-19 % (ffn_up 392 ->
+    // 318 us); inside the encoder, where A comes from HBM, the gain is 1.7 % (776 vs 784 TF/s).
+    // Narrow, short-K problems like 16 panels; K = 4096 (2 MiB per A panel) likes 4.
+    p.group_m = g_group_m > 0 ? g_group_m : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8));
     constexpr int CUS = 256;
     const bool persist = PERSIST && nwg > CUS;
     // quarter of one tile's main-loop time at ~1 PF/s in shader cycles (2.4 GHz)
@@ -399,6 +414,7 @@ long long* g_trace = nullptr;
 int g_variant = -1;
 int g_skew = -1;
 int g_persistent = -1;
+int g_group_m = 0;   // 0 = by shape
 
 }  // namespace
 
@@ -407,6 +423,7 @@ extern "C" void rs_debug_set_gemm_variant(int v) { g_variant = v; }
 extern "C" void rs_debug_set_gemm_skew(int v) { g_skew = v; }
 extern "C" void rs_debug_set_gemm_trace(long long* buf) { g_trace = buf; }
 extern "C" void rs_debug_set_gemm_persistent(int v) { g_persistent = v; }
+extern "C" void rs_debug_set_gemm_group_m(int v) { g_group_m = v; }
 
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return rs_fail(ctx, RS_EINVAL, "gemm: empty shape %d %d %d", a.M, a.N, a.K);
@@ -430,6 +447,12 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     if (g_variant < 0) {
         const char* e = getenv("RS_GEMM_VARIANT");   // tuning knob for A/B runs; default chosen by shape
         g_variant = e ? atoi(e) : 0;
+    }
+    static bool group_env = false;
+    if (!group_env) {
+        const char* e = getenv("RS_GEMM_GROUP_M");   // A/B knob; 0 / unset = by shape
+        if (e) g_group_m = atoi(e);
+        group_env = true;
     }
     if (g_persistent < 0) {
         const char* e = getenv("RS_GEMM_PERSISTENT");

@@ -28,11 +28,15 @@ SHAPES = [  # name, M, N, K, flags
 def main():
     quick = "--quick" in sys.argv
     variants = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [1, 2, 3, 4, 5]
+    groups = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--group-m=")] or [None]
     dev = torch.device("cuda", 0)
     ctx = capi.Context(FASTCONFORMER_619M, 0)
     setv = ctx.lib.rs_debug_set_gemm_variant
     setv.argtypes = [ctypes.c_int]
     setv.restype = None
+    setg = ctx.lib.rs_debug_set_gemm_group_m
+    setg.argtypes = [ctypes.c_int]
+    setg.restype = None
     g = torch.Generator(device="cpu").manual_seed(0)
     for name, m, n, k, flags in SHAPES:
         A = torch.randn((m, k), generator=g).to(torch.bfloat16).to(dev)
@@ -47,8 +51,10 @@ def main():
             ref = torch.relu(ref)
         if res is not None:
             ref = ref + res[:4096]
-        for v in variants:
+        for v, gm in [(v, gm) for v in variants for gm in groups]:
             setv(v)
+            if gm is not None:
+                setg(gm)
             try:
                 ctx.gemm(A, W, out, flags=flags, bias=bias, residual=res)
                 torch.cuda.synchronize()
@@ -67,7 +73,7 @@ def main():
                 ts.append(e0.elapsed_time(e1) / (1 if quick else 4))
             ts.sort()
             us = ts[len(ts) // 2] * 1e3
-            print(f"{name} M{m} N{n} K{k} v{v}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
+            print(f"{name} M{m} N{n} K{k} v{v}{'' if gm is None else f' gm{gm}'}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
         del A, W, out, res
     setv(0)
 
