@@ -30,7 +30,8 @@ constexpr int KROW = 272;           // bytes per K / P row in LDS (256 + 16 pad:
 constexpr int VROW = 80;            // bytes per V^T row in LDS (64 + 16 pad)
 constexpr int K_BYTES = 32 * KROW;  // 8704
 constexpr int VT_BYTES = HD * VROW; // 10240
-constexpr int SCR_BYTES = 32 * KROW;   // per-wave scratch: 32 staged P rows, later the [64][32] f32 skew tile
+constexpr int SCR_BYTES = 32 * KROW;   // per-wave scratch: 32 staged P rows, later the [32 queries][68] f32 skew tile
+constexpr int SKEW_LD = 68;            // floats per query row of the skew tile (64 used): 32 * 68 * 4 = SCR_BYTES
 constexpr int KB_CHUNK = 5;            // key blocks staged per workgroup barrier (160 keys: all of T' = 138)
 constexpr float NEG = -1.0e30f;
 
@@ -39,6 +40,7 @@ struct AttnParams {
     const int32_t* lens; uint16_t* out;
     int T, d_model, att_left, att_right, n_global;
     float scale;
+    long long* trace;   // debug: per-workgroup phase timestamps of wave 1 (scripts/attn_trace.py); nullptr in production
 };
 
 __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -51,7 +53,21 @@ __device__ __forceinline__ int vt_pos(int key) {
 }
 
 // One workgroup = (batch b, head h, up to 6 query blocks of 32); one wave = one query block.
+// WINDOW: limited-context / global-token masks compiled in (full attention otherwise: no per-score branches)
+template <bool TRACE, bool WINDOW>
 __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
+    long long ts[40];
+    int nts = 0;
+    // TRACE: drain the memory counters, make the newest MFMA result architecturally visible, then stamp
+    auto stamp = [&](float dep) {
+        if constexpr (TRACE) {
+            float tmp;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tv_mov_b32 %0, %1" : "=v"(tmp) : "v"(dep) : "memory");
+            if (nts < 40) ts[nts++] = __builtin_readcyclecounter();
+            asm volatile("" :: "v"(tmp));
+        }
+    };
+    stamp(0.0f);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                              // [KB_CHUNK][32 keys][272 B]
     char* Vts = smem + KB_CHUNK * K_BYTES;        // [KB_CHUNK][128 d][80 B]
@@ -59,6 +75,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* scr = smem + KB_CHUNK * (K_BYTES + VT_BYTES) + wave * SCR_BYTES;
+    float* bias_s = reinterpret_cast<float*>(smem + KB_CHUNK * (K_BYTES + VT_BYTES) + nw * SCR_BYTES);   // [u(128) | v(128)]
     float* scr_f = reinterpret_cast<float*>(scr);
 
     const int b = blockIdx.z, h = blockIdx.y;
@@ -70,25 +87,113 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     const bool q_valid = qi < len && qi < T;
     const uint16_t* base = p.qkv + (size_t)b * T * ld;
 
+    const int n_kblocks = ((len < T ? len : T) + 31) >> 5;  // key blocks at/after len are fully masked
+    // ---- K / V staging of `nb` key blocks starting at block jc, first chunk only (nothing else is live
+    //      in registers yet, so every global load of the chunk is in flight before the first LDS store).
+    //      K: thread -> (slot, key, 16-byte chunk), rows copied as they are.
+    //      V: thread -> (slot, 4 consecutive keys, 8 d columns): the 4 x 8 block is transposed in
+    //      registers (v_perm_b32) and stored as 8-byte runs of V^T.  The element-wise scatter this
+    //      replaces (64 two-byte stores per thread, 16 lanes per bank) was 7.6 of a workgroup's 24 us
+    //      (profiles/r01o_attention_phase_timeline.txt).
+    auto stage_kv = [&](int jc, int nb) {
+        // nb * 512 K items <= 8 * blockDim for every launch shape.  Named scalars, unconditional (clamped)
+        // loads: an indexed array or a predicated definition is demoted to scratch memory by the compiler.
+        const int items = nb * 512;
+        auto k_src = [&](int it) -> const uint4* {
+            int idx = tid + it * (int)blockDim.x;
+            idx = idx < items ? idx : items - 1;
+            const int slot = idx >> 9, key = (idx >> 4) & 31, ch = idx & 15;
+            int krow = (jc + slot) * 32 + key;
+            krow = krow < T ? krow : T - 1;
+            return reinterpret_cast<const uint4*>(base + (size_t)krow * ld + d + h * HD + ch * 8);
+        };
+        const uint4 kr0 = *k_src(0), kr1 = *k_src(1), kr2 = *k_src(2), kr3 = *k_src(3);
+        const uint4 kr4 = *k_src(4), kr5 = *k_src(5), kr6 = *k_src(6), kr7 = *k_src(7);
+        // V work items are wave-wide: (slot, half of the 16 chunks); lane = (key group g, chunk c_lo);
+        // a 16-lane store group is 8 key groups x 2 chunks (2-way bank conflict at worst)
+        constexpr int MAXV = 2;               // 2 * nb wave items over nw waves
+        const int g = lane & 7, c_lo = (lane >> 3) & 7;
+        uint4 vreg[MAXV][4];
+#pragma unroll
+        for (int it = 0; it < MAXV; ++it) {
+            int wi = wave + it * nw;
+            wi = wi < 2 * nb ? wi : 2 * nb - 1;
+            const int slot = wi >> 1, ch = (wi & 1) * 8 + c_lo;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                int krow = (jc + slot) * 32 + 4 * g + a;
+                krow = krow < T ? krow : T - 1;
+                vreg[it][a] = *reinterpret_cast<const uint4*>(base + (size_t)krow * ld + 2 * d + h * HD + ch * 8);
+            }
+        }
+        auto k_put = [&](int it, const uint4& v) {
+            const int idx = tid + it * (int)blockDim.x;
+            if (idx < items) {
+                const int slot = idx >> 9, key = (idx >> 4) & 31, ch = idx & 15;
+                *reinterpret_cast<uint4*>(Ks + slot * K_BYTES + key * KROW + ch * 16) = v;
+            }
+        };
+        k_put(0, kr0); k_put(1, kr1); k_put(2, kr2); k_put(3, kr3);
+        k_put(4, kr4); k_put(5, kr5); k_put(6, kr6); k_put(7, kr7);
+#pragma unroll
+        for (int it = 0; it < MAXV; ++it) {
+            const int wi = wave + it * nw;
+            if (wi < 2 * nb) {
+                const int slot = wi >> 1, ch = (wi & 1) * 8 + c_lo;
+                const int pos0 = vt_pos(4 * g);           // keys 4g .. 4g+3 sit at positions pos0 .. pos0+3
+                char* dst = Vts + slot * VT_BYTES + (ch * 8) * VROW + ((((pos0 >> 3) ^ (ch & 3)) << 4) + (pos0 & 7) * 2);
+                const unsigned k0[4] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w};
+                const unsigned k1[4] = {vreg[it][1].x, vreg[it][1].y, vreg[it][1].z, vreg[it][1].w};
+                const unsigned k2[4] = {vreg[it][2].x, vreg[it][2].y, vreg[it][2].z, vreg[it][2].w};
+                const unsigned k3[4] = {vreg[it][3].x, vreg[it][3].y, vreg[it][3].z, vreg[it][3].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    // v_perm_b32 D, S0, S1: bytes 0-3 = S1, 4-7 = S0; pick the low (even d) or high halves
+                    const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                    const unsigned lo = __builtin_amdgcn_perm(k1[e >> 1], k0[e >> 1], sel);
+                    const unsigned hi = __builtin_amdgcn_perm(k3[e >> 1], k2[e >> 1], sel);
+                    *reinterpret_cast<uint2*>(dst + e * VROW) = make_uint2(lo, hi);
+                }
+            }
+        }
+    };
+
+    // ---- prologue.  Everything the workgroup needs from HBM is requested up front: the raw Q rows
+    // first, then the first K/V chunk (staged while nothing else is live in registers).  The two bias
+    // vectors of this head go through LDS: read per lane from global memory they were 32 x 16 bytes
+    // per lane, identical across the wave, and held the prologue for ~3 us.
+    const int qrow = qi < T ? qi : T - 1;
+    const uint16_t* qp = base + (size_t)qrow * ld + h * HD;
+    u16x8_t raw[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) raw[ks] = *reinterpret_cast<const u16x8_t*>(qp + 8 * (2 * ks + hh));
+    if (wave == 0)
+        *reinterpret_cast<float4*>(bias_s + 4 * lane) =
+            *reinterpret_cast<const float4*>((lane < 32 ? p.bias_u : p.bias_v - HD) + h * HD + 4 * lane);
+    stage_kv(0, n_kblocks < KB_CHUNK ? n_kblocks : KB_CHUNK);
+    stamp(0.0f);                                   // [1] own K/V stores issued and landed
+    __syncthreads();
+    stamp(0.0f);                                   // [2] workgroup barrier passed
+
     // ---- Q fragments (+u, +v), rounded to bf16: B operand, lane = (query il, k-chunk hh)
     bf16x8_t qu[8], qv[8];
-    {
-        const int qrow = qi < T ? qi : T - 1;
-        const uint16_t* qp = base + (size_t)qrow * ld + h * HD;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int c = 8 * (2 * ks + hh);
-            const u16x8_t raw = *reinterpret_cast<const u16x8_t*>(qp + c);
-            u16x8_t a, bq;
+    for (int ks = 0; ks < 8; ++ks) {
+        const int c = 8 * (2 * ks + hh);
+        float bu[8], bvv[8];
+        *reinterpret_cast<float4*>(&bu[0]) = *reinterpret_cast<const float4*>(bias_s + c);
+        *reinterpret_cast<float4*>(&bu[4]) = *reinterpret_cast<const float4*>(bias_s + c + 4);
+        *reinterpret_cast<float4*>(&bvv[0]) = *reinterpret_cast<const float4*>(bias_s + HD + c);
+        *reinterpret_cast<float4*>(&bvv[4]) = *reinterpret_cast<const float4*>(bias_s + HD + c + 4);
+        u16x8_t a, bq;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = bf16_to_f32(raw[e]);
-                a[e] = f32_to_bf16(f + p.bias_u[h * HD + c + e]);
-                bq[e] = f32_to_bf16(f + p.bias_v[h * HD + c + e]);
-            }
-            qu[ks] = __builtin_bit_cast(bf16x8_t, a);
-            qv[ks] = __builtin_bit_cast(bf16x8_t, bq);
+        for (int e = 0; e < 8; ++e) {
+            const float f = bf16_to_f32(raw[ks][e]);
+            a[e] = f32_to_bf16(f + bu[e]);
+            bq[e] = f32_to_bf16(f + bvv[e]);
         }
+        qu[ks] = __builtin_bit_cast(bf16x8_t, a);
+        qv[ks] = __builtin_bit_cast(bf16x8_t, bq);
     }
 
     f32x16_t o[4];
@@ -97,48 +202,28 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[i][e] = 0.0f;
     float m_run = NEG, l_run = 0.0f;
+    stamp(0.0f);                                   // [3] Q fragments built
 
-    const int n_kblocks = ((len < T ? len : T) + 31) >> 5;  // key blocks at/after len are fully masked
     const uint16_t* pos_h = p.pos + h * HD;
     const int n_pos = 2 * T - 1;
-
-    // ---- K / V staging of one key block into slot `slot`: thread -> (key, 16-byte chunk)
-    auto stage_kv = [&](int j0, int slot) {
-        char* ks = Ks + slot * K_BYTES;
-        char* vts = Vts + slot * VT_BYTES;
-        for (int idx = tid; idx < 32 * 16; idx += blockDim.x) {
-            const int key = idx >> 4, ch = idx & 15;
-            int krow = j0 + key;
-            krow = krow < T ? krow : T - 1;
-            const uint16_t* kp = base + (size_t)krow * ld + d + h * HD + ch * 8;
-            const u16x8_t kv = *reinterpret_cast<const u16x8_t*>(kp);
-            const u16x8_t vv = *reinterpret_cast<const u16x8_t*>(kp + d);
-            *reinterpret_cast<u16x8_t*>(ks + key * KROW + ch * 16) = kv;
-            const int posk = vt_pos(key);
-            // 16-byte chunk of the key axis XOR-ed with (d>>3)&3 = ch&3: the 16 threads that share a
-            // key hit 4 bank groups instead of one
-            const int col = (((posk >> 3) ^ (ch & 3)) << 4) + (posk & 7) * 2;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<unsigned short*>(vts + (ch * 8 + e) * VROW + col) = vv[e];
-        }
-    };
 
     // ---- BD^T block: 32 relative-position rows starting at nrow0, through the wave's scratch
     //      (coalesced 256-byte row reads from L2 -> LDS rows of 272 B -> conflict-free fragment reads)
     auto bd_block = [&](int nrow0) -> f32x16_t {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {   // two passes of 4 rows-of-4: 16 staging VGPRs, not 32
-            uint4 pr4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            // (named scalars: a uint4 array here is demoted to scratch memory, with dead stores in the loop)
+            auto p_src = [&](int q) -> const uint4* {
                 int n = nrow0 + 4 * (4 * half + q) + (lane >> 4);
                 n = n < 0 ? 0 : (n >= n_pos ? n_pos - 1 : n);
-                pr4[q] = *reinterpret_cast<const uint4*>(pos_h + (size_t)n * d + (lane & 15) * 8);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<uint4*>(scr + (4 * (4 * half + q) + (lane >> 4)) * KROW + (lane & 15) * 16) = pr4[q];
+                return reinterpret_cast<const uint4*>(pos_h + (size_t)n * d + (lane & 15) * 8);
+            };
+            const uint4 p0 = *p_src(0), p1 = *p_src(1), p2 = *p_src(2), p3 = *p_src(3);
+            char* dst = scr + (16 * half + (lane >> 4)) * KROW + (lane & 15) * 16;
+            *reinterpret_cast<uint4*>(dst) = p0;
+            *reinterpret_cast<uint4*>(dst + 4 * KROW) = p1;
+            *reinterpret_cast<uint4*>(dst + 8 * KROW) = p2;
+            *reinterpret_cast<uint4*>(dst + 12 * KROW) = p3;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -157,15 +242,33 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
 
     // rows n0 .. n0+31 of the first key block; every later block reuses the previous block's upper half
     f32x16_t bd_lo = bd_block(0 - i0 - 31 + T - 1);
+    stamp(bd_lo[0]);                               // [4] first position block
 
     // Keys are staged KB_CHUNK blocks at a time (all of them for T' <= 160): between two workgroup
     // barriers every wave walks its key blocks on its own, so the waves drift apart and hide each
     // other's L2 / LDS latencies instead of marching in lockstep.
     for (int jc = 0; jc < n_kblocks; jc += KB_CHUNK) {
         const int nb = n_kblocks - jc < KB_CHUNK ? n_kblocks - jc : KB_CHUNK;
-        if (jc > 0) __syncthreads();          // previous chunk fully consumed
-        for (int sl = 0; sl < nb; ++sl) stage_kv((jc + sl) * 32, sl);
-        __syncthreads();
+        if (jc > 0) {
+            __syncthreads();                  // previous chunk fully consumed
+            // later chunks (T' > 160 only) restage with everything live: one item at a time, 8 staging VGPRs
+#pragma unroll 1
+            for (int idx = tid; idx < nb * 512; idx += blockDim.x) {
+                const int slot = idx >> 9, key = (idx >> 4) & 31, ch = idx & 15;
+                int krow = (jc + slot) * 32 + key;
+                krow = krow < T ? krow : T - 1;
+                const uint16_t* kp = base + (size_t)krow * ld + d + h * HD + ch * 8;
+                const uint4 kv = *reinterpret_cast<const uint4*>(kp);
+                const u16x8_t vv = *reinterpret_cast<const u16x8_t*>(kp + d);
+                *reinterpret_cast<uint4*>(Ks + slot * K_BYTES + key * KROW + ch * 16) = kv;
+                const int posk = vt_pos(key);
+                const int col = (((posk >> 3) ^ (ch & 3)) << 4) + (posk & 7) * 2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *reinterpret_cast<unsigned short*>(Vts + slot * VT_BYTES + (ch * 8 + e) * VROW + col) = vv[e];
+            }
+            __syncthreads();
+        }
 
         for (int sl = 0; sl < nb; ++sl) {
             const int j0 = (jc + sl) * 32;
@@ -181,28 +284,42 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks_t + il * KROW + (2 * ks + hh) * 16);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[ks], s, 0, 0, 0);
             }
+            stamp(s[0]);                           // [5+5k] S^T
             // ---- upper half of BD^T for this key block: relative positions n0+32 .. n0+63   (8 MFMAs)
             const int n0 = j0 - i0 - 31 + T - 1;
             const f32x16_t bd_hi = bd_block(n0 + 32);
+            stamp(bd_hi[0]);                       // [6+5k] position rows fetched, BD^T
 
-            // ---- skew through the per-wave scratch: scr_f[n_local][query]
+            // ---- skew through the per-wave scratch, query-major: scr_f[query][n_local], row stride 68 floats.
+            //      A lane's register quad (r & 3 = 0..3) is 4 consecutive n_local: 8 x 16-byte stores
+            //      (slots 17*il mod 16: conflict-free) instead of 32 x 4-byte; the skewed reads
+            //      scr_f[il][jl - il + 31] land in bank (3*il + const) mod 32: conflict-free too.
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                scr_f[rowmap(r, hh) * 32 + il] = bd_lo[r];
-                scr_f[(32 + rowmap(r, hh)) * 32 + il] = bd_hi[r];
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(scr_f + il * SKEW_LD + 8 * g + 4 * hh) =
+                    make_float4(bd_lo[4 * g], bd_lo[4 * g + 1], bd_lo[4 * g + 2], bd_lo[4 * g + 3]);
+                *reinterpret_cast<float4*>(scr_f + il * SKEW_LD + 32 + 8 * g + 4 * hh) =
+                    make_float4(bd_hi[4 * g], bd_hi[4 * g + 1], bd_hi[4 * g + 2], bd_hi[4 * g + 3]);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
+            // all 16 skewed reads are issued together and pinned: left to itself the compiler sinks each
+            // read under its own `ok` branch (16 x exec-mask branch + a full LDS round trip each)
+            float bdw[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bdw[r] = scr_f[il * SKEW_LD + (rowmap(r, hh) - il + 31)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bdw[r]));
             float pr[16];
             float mblk = NEG;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jl = rowmap(r, hh);
                 const int j = j0 + jl;
-                const float bdv = scr_f[(jl - il + 31) * 32 + il];
+                const float bdv = bdw[r];
                 bool ok = q_valid && j < len;
-                if (p.att_left >= 0 || p.att_right >= 0) {
+                if constexpr (WINDOW) {
                     bool win = (p.att_left < 0 || qi - j <= p.att_left) && (p.att_right < 0 || j - qi <= p.att_right);
                     if (p.n_global > 0) win = win || qi < p.n_global || j < p.n_global;
                     ok = ok && win;
@@ -213,6 +330,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();  // scratch reads done before the next block overwrites it
+            stamp(pr[0]);                          // [7+5k] skew + masked scores
             bd_lo = bd_hi;
             mblk = fmaxf(mblk, __shfl_xor(mblk, 32, 64));
             const float m_new = fmaxf(m_run, mblk);
@@ -231,6 +349,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+            stamp(o[0][0]);                        // [8+5k] softmax update
             // ---- P^T fragments (bf16) and  O^T += V^T . P^T   (8 MFMAs)
             bf16x8_t pf[2];
 #pragma unroll
@@ -255,20 +374,43 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
         }
     }
 
-    // ---- write ctx: lane = (query il, half hh); reg r of block db -> d = db*32 + rowmap(r, hh)
-    if (qi < T) {
+    stamp(o[0][0]);                                // after the last block's PV ([9+5k] inside the loop is implied by the next S stamp)
+    // ---- write ctx.  lane = (query il, half hh); reg r of block db -> d = db*32 + rowmap(r, hh): a lane owns
+    //      8-byte pieces of its query's row.  They are gathered through the wave's scratch (rows of 272 B)
+    //      so that the global stores are whole 256-byte rows, 16 bytes per lane.
+    {
         const float inv = (q_valid && l_run > 0.0f) ? 1.0f / l_run : 0.0f;
-        uint16_t* op = p.out + ((size_t)b * T + qi) * d + h * HD;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<u16x4_t*>(op + db * 32 + 8 * g + 4 * hh) =
+                *reinterpret_cast<u16x4_t*>(scr + il * KROW + (db * 32 + 8 * g + 4 * hh) * 2) =
                     pack_bf16x4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = 4 * q + (lane >> 4);
+            const uint4 v = *reinterpret_cast<const uint4*>(scr + row * KROW + (lane & 15) * 16);
+            if (i0 + row < T)
+                *reinterpret_cast<uint4*>(p.out + ((size_t)b * T + i0 + row) * d + h * HD + (lane & 15) * 8) = v;
+        }
+    }
+    if constexpr (TRACE) {
+        stamp(0.0f);
+        if (wave == 1 && lane == 0) {
+            long long* tr = p.trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 40;
+            for (int i = 0; i < 40; ++i) tr[i] = i < nts ? ts[i] - ts[0] : -1;
+        }
     }
 }
 
+long long* g_attn_trace = nullptr;
+
 }  // namespace
+
+// debug hook (scripts/attn_trace.py): buffer of 40 int64 per workgroup, or nullptr to switch tracing off
+extern "C" void rs_debug_set_attn_trace(long long* buf) { g_attn_trace = buf; }
 
 int rs_launch_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, const float* bias_u,
                         const float* bias_v, const int32_t* lens, int B, int T, uint16_t* out, hipStream_t s) {
@@ -283,11 +425,13 @@ int rs_launch_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, c
     // at most 6 query blocks per workgroup: 5 * (8704 + 10240) + 6 * 8704 = 147 KB of the 160 KB LDS
     const int nw = qblocks < 6 ? qblocks : 6;
     const dim3 grid((qblocks + nw - 1) / nw, dm.n_heads, B), block(64 * nw);
-    const size_t lds = (size_t)KB_CHUNK * (K_BYTES + VT_BYTES) + (size_t)nw * SCR_BYTES;
+    const size_t lds = (size_t)KB_CHUNK * (K_BYTES + VT_BYTES) + (size_t)nw * SCR_BYTES + 2 * HD * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)relpos_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                KB_CHUNK * (K_BYTES + VT_BYTES) + 6 * SCR_BYTES) != hipSuccess)
+        constexpr int MAX_LDS = KB_CHUNK * (K_BYTES + VT_BYTES) + 6 * SCR_BYTES + 2 * HD * (int)sizeof(float);
+        if (hipFuncSetAttribute((const void*)relpos_attention_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)relpos_attention_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)relpos_attention_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS) != hipSuccess)
             return rs_fail(ctx, RS_EHIP, "attention: cannot reserve LDS");
         attr_set = true;
     }
@@ -295,7 +439,11 @@ int rs_launch_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, c
     const double flops = (double)B * dm.n_heads * 3.0 * 2.0 * T * (double)T * HD;
     const double bytes = (double)B * T * dm.d_model * 2.0 * 4.0;
     rs_prof_begin(ctx, RS_PROF_ATTN, s, flops, bytes);
-    hipLaunchKernelGGL(relpos_attention_kernel, grid, block, lds, s, p);
+    p.trace = g_attn_trace;
+    const bool window = p.att_left >= 0 || p.att_right >= 0;
+    if (window) hipLaunchKernelGGL((relpos_attention_kernel<false, true>), grid, block, lds, s, p);
+    else if (p.trace) hipLaunchKernelGGL((relpos_attention_kernel<true, false>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((relpos_attention_kernel<false, false>), grid, block, lds, s, p);
     rs_prof_end(ctx, RS_PROF_ATTN, s);
     RS_CHECK_LAUNCH(ctx, "relpos_attention");
     return RS_OK;
