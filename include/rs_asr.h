@@ -85,7 +85,10 @@ int rs_abi_version(void);
 
 /* Register one prepared weight tensor by name (device pointer, caller-owned, must outlive the
  * context).  Names and layouts: DESIGN.md §"Weights in HBM".  Replaces: load_state_dict inside
- * from_pretrained (transcribe.py:26-28). */
+ * from_pretrained (transcribe.py:26-28).
+ * Optional derived tensors "L{i}.att.pos_proj" (bf16, same shape as "pos.table"): the position
+ * table already multiplied by layer i's linear_pos weight (one rs_gemm_bf16 call per layer at load
+ * time); when registered, rs_encoder_forward skips that projection in every call. */
 int rs_set_tensor(rs_ctx* ctx, const char* name, const void* dev_ptr, size_t nbytes);
 /* Check that every tensor the dims require is present; must precede any forward call. */
 int rs_finalize(rs_ctx* ctx);

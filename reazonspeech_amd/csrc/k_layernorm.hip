@@ -50,6 +50,68 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Two LayerNorms back to back on one read of the row: y = LN(x; g1, b1) is stored as f32 (the residual
+// stream after a layer's output norm), z = LN(y; g2, b2) as bf16 (the next layer's first FFN input).
+// Same arithmetic as two layernorm_kernel launches (y is normalised from registers instead of being
+// re-read), 362 MB instead of 507 MB of traffic per layer boundary at B=256.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, const float* __restrict__ g1,
+                                                         const float* __restrict__ b1, const float* __restrict__ g2,
+                                                         const float* __restrict__ b2, int M, float eps,
+                                                         float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    float4 v[NV];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = xr[i * 64 + lane];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, dd = v[i].w - mean;
+        q += (a * a + bb * bb) + (c * c + dd * dd);
+    }
+    float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+    s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 gg = reinterpret_cast<const float4*>(g1)[i * 64 + lane], bb = reinterpret_cast<const float4*>(b1)[i * 64 + lane];
+        float4 y;
+        y.x = (v[i].x - mean) * rstd * gg.x + bb.x;
+        y.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+        y.z = (v[i].z - mean) * rstd * gg.z + bb.z;
+        y.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+        reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[i * 64 + lane] = y;
+        v[i] = y;
+        s += (y.x + y.y) + (y.z + y.w);
+    }
+    mean = wave_sum(s) * (1.0f / D);
+    q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, dd = v[i].w - mean;
+        q += (a * a + bb * bb) + (c * c + dd * dd);
+    }
+    rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 gg = reinterpret_cast<const float4*>(g2)[i * 64 + lane], bb = reinterpret_cast<const float4*>(b2)[i * 64 + lane];
+        u16x4_t o;
+        o[0] = f32_to_bf16((v[i].x - mean) * rstd * gg.x + bb.x);
+        o[1] = f32_to_bf16((v[i].y - mean) * rstd * gg.y + bb.y);
+        o[2] = f32_to_bf16((v[i].z - mean) * rstd * gg.z + bb.z);
+        o[3] = f32_to_bf16((v[i].w - mean) * rstd * gg.w + bb.w);
+        reinterpret_cast<u16x4_t*>(out_bf16 + (size_t)row * D)[i * 64 + lane] = o;
+    }
+}
+
 // GLU + mask + depthwise conv (BatchNorm folded) + SiLU.
 //   x  bf16 [B*T][2d]  (a | gate),  w f32 [k][d] tap-major, bias f32 [d]  ->  out bf16 [B*T][d]
 // Workgroup = 256 threads = 32 channel groups (8 channels, one 16-B load) x 8 time lanes; it
@@ -116,7 +178,100 @@ __global__ __launch_bounds__(256) void glu_dwconv_silu_kernel(const uint16_t* __
     }
 }
 
+// Fast path of the same operator for a compile-time kernel size K: a thread owns 8 channels x R
+// CONSECUTIVE frames.  The K taps of its channels live in registers (loaded once), the R + K - 1
+// input frames it needs are read from LDS once each (a sliding window: 2 x 16 B per frame instead
+// of 2 x 16 B per frame AND tap), and every HBM load of the tile is in flight before the first GLU.
+// Workgroup tile = 8 * R frames x 256 channels (R = 6: 48 frames, three tiles cover T' = 138 + 6).
+template <int K, int R>
+__global__ __launch_bounds__(256) void glu_dwconv_silu_fast_kernel(const uint16_t* __restrict__ x,
+                                                                   const float* __restrict__ w,
+                                                                   const float* __restrict__ bias,
+                                                                   const int32_t* __restrict__ lens, int T, int d,
+                                                                   uint16_t* __restrict__ out) {
+    constexpr int TTF = 8 * R, ROWS = TTF + K - 1, HALF = (K - 1) / 2;
+    constexpr int NLD = (ROWS + 7) / 8;          // rows staged per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);  // [ROWS][CT]
+    const int b = blockIdx.z, c0 = blockIdx.y * CT, t0 = blockIdx.x * TTF;
+    const int cg = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int len = lens[b];
+    const int c = c0 + cg * 8;
+    // ---- stage: all loads first (rows outside [0, min(T, len)) are zero: "same" padding + frame mask)
+    uint4 av[NLD], gv[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int r = tl + 8 * i;
+        int t = t0 + r - HALF;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);     // clamped address, masked below
+        const uint16_t* px = x + ((size_t)b * T + t) * (2 * d) + c;
+        av[i] = *reinterpret_cast<const uint4*>(px);
+        gv[i] = *reinterpret_cast<const uint4*>(px + d);
+    }
+    float wt[K][8];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        *reinterpret_cast<float4*>(&wt[j][0]) = *reinterpret_cast<const float4*>(w + (size_t)j * d + c);
+        *reinterpret_cast<float4*>(&wt[j][4]) = *reinterpret_cast<const float4*>(w + (size_t)j * d + c + 4);
+    }
+    float bb[8];
+    *reinterpret_cast<float4*>(&bb[0]) = *reinterpret_cast<const float4*>(bias + c);
+    *reinterpret_cast<float4*>(&bb[4]) = *reinterpret_cast<const float4*>(bias + c + 4);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int r = tl + 8 * i;
+        const int t = t0 + r - HALF;
+        const bool ok = t >= 0 && t < T && t < len;
+        const u16x8_t a = __builtin_bit_cast(u16x8_t, av[i]);
+        const u16x8_t gt = __builtin_bit_cast(u16x8_t, gv[i]);
+        float u[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = ok ? bf16_to_f32(a[e]) * sigmoid_f(bf16_to_f32(gt[e])) : 0.0f;
+        if (r < ROWS) {
+            float4* dst = reinterpret_cast<float4*>(tile + r * CT + cg * 8);
+            dst[0] = make_float4(u[0], u[1], u[2], u[3]);
+            dst[1] = make_float4(u[4], u[5], u[6], u[7]);
+        }
+    }
+    __syncthreads();
+    // ---- sliding window over this thread's R consecutive frames
+    float acc[R][8];
+#pragma unroll
+    for (int o = 0; o < R; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o][e] = bb[e];
+#pragma unroll
+    for (int row = 0; row < R + K - 1; ++row) {
+        const float4* src = reinterpret_cast<const float4*>(tile + (tl * R + row) * CT + cg * 8);
+        const float4 x0 = src[0], x1 = src[1];
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            const int j = row - o;               // tap index, compile-time after unrolling
+            if (j >= 0 && j < K) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(xv[e], wt[j][e], acc[o][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+        const int t = t0 + tl * R + o;
+        if (t < T) {
+            u16x8_t ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16(silu_f(acc[o][e]));
+            *reinterpret_cast<u16x8_t*>(out + ((size_t)b * T + t) * d + c) = ov;
+        }
+    }
+}
+
+int g_glu_generic = 0;
+
 }  // namespace
+
+// A/B hook (scripts/glu_bench.py): force the generic any-kernel-size path
+extern "C" void rs_debug_set_glu_generic(int v) { g_glu_generic = v; }
 
 int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float* b, int M, int d, float eps,
                         uint16_t* out_bf16, float* out_f32, hipStream_t s) {
@@ -135,16 +290,47 @@ int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float
     return RS_OK;
 }
 
+int rs_launch_layernorm2(rs_ctx* ctx, const float* x, const float* g1, const float* b1, const float* g2, const float* b2,
+                         int M, int d, float eps, float* out_f32, uint16_t* out_bf16, hipStream_t s) {
+    if (M <= 0) return RS_OK;
+    if (d % 256 || d > 2048) return rs_fail(ctx, RS_EINVAL, "layernorm: d=%d must be a multiple of 256, <= 2048", d);
+    const dim3 grid((M + 3) / 4), block(256);
+    rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, 16.0 * M * d, (double)M * d * 10.0);
+    switch (d / 256) {
+#define LN_CASE(NV) case NV: hipLaunchKernelGGL(layernorm2_kernel<NV>, grid, block, 0, s, x, g1, b1, g2, b2, M, eps, out_f32, out_bf16); break;
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+#undef LN_CASE
+    }
+    rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
+    RS_CHECK_LAUNCH(ctx, "layernorm2");
+    return RS_OK;
+}
+
 int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, const float* w, const float* b, const int32_t* lens,
                          int B, int T, int d, int k, uint16_t* out, hipStream_t s) {
     if (B <= 0 || T <= 0) return RS_OK;
     if (d % CT) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: d=%d must be a multiple of %d", d, CT);
     if (k < 1 || k > KMAX || !(k & 1)) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: kernel size %d unsupported", k);
-    const dim3 grid((T + TT - 1) / TT, d / CT, B), block(256);
-    const size_t lds = (size_t)(TT + k - 1) * CT * sizeof(float);
     const double bytes = (double)B * T * d * (4.0 + 2.0);
     rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, (double)B * T * d * (2.0 * k + 12.0), bytes);
-    hipLaunchKernelGGL(glu_dwconv_silu_kernel, grid, block, lds, s, x, w, b, lens, T, d, k, out);
+    if (k == 9 && !g_glu_generic) {
+        // register-window fast path (the FastConformer kernel size); 48-frame tiles
+        constexpr int R = 6, TTF = 8 * R;
+        const dim3 grid((T + TTF - 1) / TTF, d / CT, B), block(256);
+        const size_t lds = (size_t)(TTF + 9 - 1) * CT * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)glu_dwconv_silu_fast_kernel<9, R>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return rs_fail(ctx, RS_EHIP, "glu_dwconv: cannot reserve %zu bytes of LDS", lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((glu_dwconv_silu_fast_kernel<9, R>), grid, block, lds, s, x, w, b, lens, T, d, out);
+    } else {
+        const dim3 grid((T + TT - 1) / TT, d / CT, B), block(256);
+        const size_t lds = (size_t)(TT + k - 1) * CT * sizeof(float);
+        hipLaunchKernelGGL(glu_dwconv_silu_kernel, grid, block, lds, s, x, w, b, lens, T, d, k, out);
+    }
     rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
     RS_CHECK_LAUNCH(ctx, "glu_dwconv_silu");
     return RS_OK;

@@ -173,6 +173,15 @@ int rs_finalize(rs_ctx* ctx) {
     const size_t rowb = dm * sizeof(uint16_t);
     if (it->second.second % rowb || !((it->second.second / rowb) & 1))
         return rs_fail(ctx, RS_EINVAL, "pos.table must be bf16 [2*Tcap-1][d_model]");
+    // optional derived weights: the position table already projected by each layer's linear_pos
+    // (it depends on nothing but the weights, so a caller can compute it once with rs_gemm_bf16)
+    for (int i = 0; i < d.n_layers; ++i) {
+        auto pp = ctx->tensors.find("L" + std::to_string(i) + ".att.pos_proj");
+        if (pp == ctx->tensors.end()) { ctx->layers[i].pos_proj = nullptr; continue; }
+        if (pp->second.second != it->second.second || ((uintptr_t)pp->second.first & 15))
+            return rs_fail(ctx, RS_EINVAL, "L%d.att.pos_proj must be 16-byte aligned and as large as pos.table", i);
+        ctx->layers[i].pos_proj = reinterpret_cast<const uint16_t*>(pp->second.first);
+    }
     ctx->finalized = true;
     return RS_OK;
 }
@@ -312,15 +321,17 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
     for (int i = 0; i < d.n_layers; ++i) {
         const rs_layer_w& L = ctx->layers[i];
         const bool last = i == d.n_layers - 1;
-        // 1/2 FFN
-        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_ff1_g, L.ln_ff1_b, M, dm, d.ln_eps, hn, nullptr, s));
+        // 1/2 FFN  (layers > 0: hn was produced by the previous layer's fused output-norm kernel)
+        if (i == 0) RS_TRY(rs_launch_layernorm(ctx, x, L.ln_ff1_g, L.ln_ff1_b, M, dm, d.ln_eps, hn, nullptr, s));
         RS_TRY(gemm(hn, dm, L.ff1_w1, dm, big, ff, M, ff, RS_GEMM_BIAS | RS_GEMM_SILU, L.ff1_b1, 1.0f, nullptr));
         RS_TRY(gemm(big, ff, L.ff1_w2, ff, x, dm, M, dm, RES, L.ff1_b2, 0.5f, x));
         // rel-pos MHSA
         RS_TRY(rs_launch_layernorm(ctx, x, L.ln_att_g, L.ln_att_b, M, dm, d.ln_eps, hn, nullptr, s));
         RS_TRY(gemm(hn, dm, L.qkv_w, dm, big, 3 * dm, M, 3 * dm, RS_GEMM_BIAS, L.qkv_b, 1.0f, nullptr));
-        RS_TRY(gemm(pos_slice, dm, L.pos_w, dm, posp, dm, npos, dm, 0, nullptr, 1.0f, nullptr));
-        RS_TRY(rs_launch_attention(ctx, big, posp, L.bias_u, L.bias_v, lens, B, Tp, ctxb, s));
+        const uint16_t* pproj = posp;
+        if (L.pos_proj) pproj = L.pos_proj + (size_t)(tcap - Tp) * dm;      // rows of the pre-projected table
+        else RS_TRY(gemm(pos_slice, dm, L.pos_w, dm, posp, dm, npos, dm, 0, nullptr, 1.0f, nullptr));
+        RS_TRY(rs_launch_attention(ctx, big, pproj, L.bias_u, L.bias_v, lens, B, Tp, ctxb, s));
         RS_TRY(gemm(ctxb, dm, L.out_w, dm, x, dm, M, dm, RES, L.out_b, 1.0f, x));
         // conv module
         RS_TRY(rs_launch_layernorm(ctx, x, L.ln_conv_g, L.ln_conv_b, M, dm, d.ln_eps, hn, nullptr, s));
@@ -333,7 +344,13 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         RS_TRY(gemm(big, ff, L.ff2_w2, ff, x, dm, M, dm, RES, L.ff2_b2, 0.5f, x));
         // output norm (in place on the residual stream; the last layer also emits the bf16 copy
         // that feeds the joint's encoder projection)
-        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_out_g, L.ln_out_b, M, dm, d.ln_eps, last ? hn : nullptr, x, s));
+        if (last) {
+            RS_TRY(rs_launch_layernorm(ctx, x, L.ln_out_g, L.ln_out_b, M, dm, d.ln_eps, hn, x, s));
+        } else {
+            // output norm + the next layer's first norm on one read of the row
+            const rs_layer_w& Ln = ctx->layers[i + 1];
+            RS_TRY(rs_launch_layernorm2(ctx, x, L.ln_out_g, L.ln_out_b, Ln.ln_ff1_g, Ln.ln_ff1_b, M, dm, d.ln_eps, x, hn, s));
+        }
     }
     if (enc_out) RS_HIP(ctx, hipMemcpyAsync(enc_out, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
     RS_TRY(gemm(hn, dm, ctx->jenc_w, dm, joint_enc, d.joint_hidden, M, d.joint_hidden, RS_GEMM_BIAS | RS_GEMM_OUT_F32,

@@ -65,6 +65,7 @@ struct rs_layer_w {
     const uint16_t *ff1_w1, *ff1_w2, *ff2_w1, *ff2_w2, *qkv_w, *out_w, *pos_w, *pw1_w, *pw2_w;
     const float *ff1_b1, *ff1_b2, *ff2_b1, *ff2_b2, *qkv_b, *out_b, *bias_u, *bias_v, *pw1_b, *pw2_b;
     const float *dw_w, *dw_b;
+    const uint16_t* pos_proj;   // optional "L{i}.att.pos_proj": pos.table @ pos_w^T, bf16 [2*Tcap-1][d]; nullptr = project per call
 };
 
 struct rs_ctx {
@@ -133,6 +134,8 @@ struct rs_gemm_args {
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s);
 int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float* b, int M, int d, float eps,
                         uint16_t* out_bf16, float* out_f32, hipStream_t s);
+int rs_launch_layernorm2(rs_ctx* ctx, const float* x, const float* g1, const float* b1, const float* g2, const float* b2,
+                         int M, int d, float eps, float* out_f32, uint16_t* out_bf16, hipStream_t s);
 int rs_launch_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, const float* bias_u,
                         const float* bias_v, const int32_t* lens, int B, int T, uint16_t* out, hipStream_t s);
 int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, const float* w, const float* b, const int32_t* lens,

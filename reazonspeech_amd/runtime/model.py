@@ -84,8 +84,19 @@ class AsrModel:
 
     # ------------------------------------------------------------------------------------------
     def _upload(self, tensors):
+        dev = {}
         for name, t in tensors.items():
-            self.ctx.set_tensor(name, t.to(self.device, non_blocking=False).contiguous())
+            dev[name] = t.to(self.device, non_blocking=False).contiguous()
+            self.ctx.set_tensor(name, dev[name])
+        # derived weights: the relative-position table projected by every layer's linear_pos, computed
+        # once with the library's own GEMM (same kernel and row arithmetic as the per-call projection
+        # it replaces, so results are bit-identical) — 24 x [2*cap-1][d] bf16 = 100 MB at cap 1024
+        table = dev["pos.table"]
+        for i in range(self.cfg.n_layers):
+            proj = torch.empty_like(table)
+            self.ctx.gemm(table, dev[f"L{i}.att.pos.w"], proj, flags=0)
+            self.ctx.set_tensor(f"L{i}.att.pos_proj", proj)
+        torch.cuda.synchronize(self.device)
         self.ctx.finalize()
 
     def buffers(self, B, l_max) -> _Buffers:
