@@ -114,36 +114,79 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
     }
 }
 
-// per utterance: mean / unbiased std over the valid frames, normalise, zero the padding
-__global__ __launch_bounds__(256) void feat_normalize_kernel(const float* __restrict__ raw,
-                                                             const int32_t* __restrict__ n_frames, int t_max,
-                                                             int n_mels, float eps, float* __restrict__ out) {
-    __shared__ float red[8][128];
-    __shared__ float mean_s[128], rstd_s[128];
+// per utterance: mean / unbiased std over the valid frames, normalise, zero the padding.
+// One workgroup of 1000 (+24 idle) threads per utterance; the [t][n_mels] block is walked as float4
+// columns: thread i owns mel quad i % Q and rows i / Q + k * (1000 / Q), so its partial sums stay in
+// registers and every pass is ~22 independent 16-byte loads per thread instead of 550 dependent
+// 4-byte ones (the previous 256-thread version: 480 us, latency-bound).  Statistics are two-pass
+// (mean, then sum of squared deviations) like torch's; passes 2 and 3 re-read the block from L2.
+__global__ __launch_bounds__(1024) void feat_normalize_kernel(const float* __restrict__ raw,
+                                                              const int32_t* __restrict__ n_frames, int t_max,
+                                                              int n_mels, float eps, float* __restrict__ out) {
+    __shared__ float4 red[1024];
+    __shared__ float4 mean_s[32], rstd_s[32];
     const int b = blockIdx.x;
     const int n = min(n_frames[b], t_max);
-    const int m = threadIdx.x & 127 , tl = threadIdx.x >> 7;  // 2 time lanes x 128 feature slots
-    const bool mv = m < n_mels;
-    const float* r = raw + (size_t)b * t_max * n_mels;
-    float s = 0.0f;
-    if (mv) for (int t = tl; t < n; t += 2) s += r[(size_t)t * n_mels + m];
-    red[tl][m] = s;
-    __syncthreads();
-    if (tl == 0) mean_s[m] = (red[0][m] + red[1][m]) / (float)n;
-    __syncthreads();
-    const float mean = mean_s[m];
-    float q = 0.0f;
-    if (mv) for (int t = tl; t < n; t += 2) { const float dlt = r[(size_t)t * n_mels + m] - mean; q += dlt * dlt; }
-    red[tl][m] = q;
-    __syncthreads();
-    if (tl == 0) rstd_s[m] = 1.0f / (sqrtf((red[0][m] + red[1][m]) / (float)(n - 1)) + eps);
-    __syncthreads();
-    float* o = out + (size_t)b * t_max * n_mels;
-    const int total = t_max * n_mels;
-    for (int idx = threadIdx.x; idx < total; idx += 256) {
-        const int t = idx / n_mels, mm = idx - t * n_mels;
-        o[idx] = (t < n) ? (r[idx] - mean_s[mm]) * rstd_s[mm] : 0.0f;
+    const int Q = n_mels >> 2;                       // float4 per row (n_mels % 4 == 0, Q <= 32)
+    const int RG = 1000 / Q;                         // row groups walked in parallel
+    const int tid = threadIdx.x;
+    const int q = tid % Q, rg = tid / Q;
+    const bool act = rg < RG;
+    const float4* r4 = reinterpret_cast<const float4*>(raw + (size_t)b * t_max * n_mels);
+    auto reduce_rows = [&](float4 v) -> float4 {     // sum over row groups; result valid in threads rg == 0
+        red[tid] = act ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < Q) {
+            for (int g = 0; g < RG; ++g) {
+                const float4 x = red[g * Q + tid];
+                acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+            }
+        }
+        return acc;
+    };
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act)
+#pragma unroll 8
+        for (int t = rg; t < n; t += RG) {
+            const float4 x = r4[(size_t)t * Q + q];
+            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
+    s = reduce_rows(s);
+    if (tid < Q) {
+        const float inv = 1.0f / (float)n;
+        mean_s[tid] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
     }
+    __syncthreads();
+    const float4 mean = mean_s[q];
+    float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act)
+#pragma unroll 8
+        for (int t = rg; t < n; t += RG) {
+            const float4 x = r4[(size_t)t * Q + q];
+            const float a = x.x - mean.x, bb = x.y - mean.y, c = x.z - mean.z, d = x.w - mean.w;
+            m2.x += a * a; m2.y += bb * bb; m2.z += c * c; m2.w += d * d;
+        }
+    m2 = reduce_rows(m2);
+    if (tid < Q) {
+        const float dn = (float)(n - 1);
+        rstd_s[tid] = make_float4(1.0f / (sqrtf(m2.x / dn) + eps), 1.0f / (sqrtf(m2.y / dn) + eps),
+                                  1.0f / (sqrtf(m2.z / dn) + eps), 1.0f / (sqrtf(m2.w / dn) + eps));
+    }
+    __syncthreads();
+    const float4 rstd = rstd_s[q];
+    float4* o4 = reinterpret_cast<float4*>(out + (size_t)b * t_max * n_mels);
+    if (act)
+#pragma unroll 8
+        for (int t = rg; t < t_max; t += RG) {
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < n) {
+                const float4 x = r4[(size_t)t * Q + q];
+                y = make_float4((x.x - mean.x) * rstd.x, (x.y - mean.y) * rstd.y, (x.z - mean.z) * rstd.z,
+                                (x.w - mean.w) * rstd.w);
+            }
+            o4[(size_t)t * Q + q] = y;
+        }
 }
 
 }  // namespace
@@ -154,7 +197,8 @@ int rs_launch_frontend(rs_ctx* ctx, const float* audio, const int32_t* lens, int
     const rs_dims& d = ctx->d;
     if (B <= 0 || t_max <= 0) return RS_OK;
     if (d.n_fft != NFFT) return rs_fail(ctx, RS_EINVAL, "frontend: only n_fft=512 is built");
-    if (d.n_mels > 128 || d.win_length > NFFT) return rs_fail(ctx, RS_EINVAL, "frontend: n_mels<=128, win<=512");
+    if (d.n_mels > 128 || d.n_mels % 4 || d.win_length > NFFT)
+        return rs_fail(ctx, RS_EINVAL, "frontend: n_mels must be a multiple of 4 up to 128, win<=512");
     FrontParams p;
     p.audio = audio; p.lens = lens; p.raw = raw; p.n_frames = n_frames;
     p.window = ctx->fe_window; p.twiddle = ctx->fe_twiddle; p.fb_idx = ctx->fe_fb_idx; p.fb_w = ctx->fe_fb_w;
@@ -166,7 +210,7 @@ int rs_launch_frontend(rs_ctx* ctx, const float* audio, const int32_t* lens, int
     const double bytes = (double)B * ((double)t_max * d.hop_length * 4.0 + (double)t_max * d.n_mels * 4.0 * 3.0);
     rs_prof_begin(ctx, RS_PROF_FRONTEND, s, (double)B * t_max * (5.0 * 512 * 9 + 3 * 257 + 2 * 600), bytes);
     hipLaunchKernelGGL(logmel_kernel, grid, block, 0, s, p);
-    hipLaunchKernelGGL(feat_normalize_kernel, dim3(B), dim3(256), 0, s, raw, n_frames, t_max, d.n_mels, d.norm_eps,
+    hipLaunchKernelGGL(feat_normalize_kernel, dim3(B), dim3(1024), 0, s, raw, n_frames, t_max, d.n_mels, d.norm_eps,
                        feats);
     rs_prof_end(ctx, RS_PROF_FRONTEND, s);
     RS_CHECK_LAUNCH(ctx, "frontend");

@@ -477,7 +477,14 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         if (a.M < 1024 || a.N < 256) v = 1;
         else if (t256 < 2 * CUS) v = a.K <= 1024 ? 7 : 1;
         else if (g_persistent) v = 9;
-        else v = ((t192 + CUS - 1) / CUS) * 192 < ((t256 + CUS - 1) / CUS) * 256 ? 10 : 2;
+        else {
+            // the 192-row tile is a little less efficient per flop; inside the two-stream pipeline (decode
+            // workgroups borrow CUs, so rounds are not exact) it only pays where the round count drops by
+            // a quarter (N = 1024: 3 rounds of 256 rows -> 3 of 192), not for 7 -> 6.75 or 5 -> 4.5
+            // (profiles/r01q_kernel_stats.txt: qkv 245 -> 273 us, pw1 177 -> 187 us with it)
+            const long c192 = ((t192 + CUS - 1) / CUS) * 192, c256 = ((t256 + CUS - 1) / CUS) * 256;
+            v = c192 * 100 < c256 * 88 ? 10 : 2;
+        }
         // (variant 9, the persistent tile loop, is ~20 % faster in isolation — profiles/r01_gemm_persistent.txt —
         // but one 128 KiB-LDS workgroup per CU for the whole launch starves the decode stream of the
         // two-stage pipeline; it is selected with rs_debug_set_gemm_persistent(1) / RS_GEMM_PERSISTENT=1

@@ -32,51 +32,76 @@ __global__ __launch_bounds__(256) void sub_conv0_dw1_kernel(
     int n_mels, int T2, int F1, int F2, int C, const float* __restrict__ w0 /* [9][C] */,
     const float* __restrict__ b0, const float* __restrict__ wd /* [9][C] */, const float* __restrict__ bd,
     uint16_t* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* mel = reinterpret_cast<float*>(smem);  // [7][n_mels + 2], column 0 = mel bin -1
     const int b = blockIdx.y, t2 = blockIdx.x, c = threadIdx.x;
     const int L1 = lens_stage[0 * B + b], L2 = lens_stage[1 * B + b];
-    const int W = n_mels + 2;
     uint16_t* orow = out + (((size_t)b * T2 + t2) * F2) * C + c;
     if (t2 >= L2) {  // masked output row
         for (int f2 = 0; f2 < F2; ++f2) orow[(size_t)f2 * C] = 0;
         return;
     }
-    // mel rows 4*t2-3 .. 4*t2+3
-    for (int idx = threadIdx.x; idx < 7 * W; idx += blockDim.x) {
-        const int r = idx / W, col = idx - r * W - 1;
-        const int tm = 4 * t2 - 3 + r;
-        float v = 0.0f;
-        if (tm >= 0 && tm < t_max && col >= 0 && col < n_mels) v = feats[((size_t)b * t_max + tm) * n_mels + col];
-        mel[idx] = v;
-    }
-    __syncthreads();
     float k0[9], kd[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) { k0[j] = w0[j * C + c]; kd[j] = wd[j * C + c]; }
     const float bias0 = b0[c], biasd = bd[c];
+    const float* fb = feats + (size_t)b * t_max * n_mels;
 
-    // conv0 output at (row index a in 0..2 <-> t1 = 2*t2-1+a, column f1); 0 outside the valid region
-    auto conv0 = [&](int a, int f1) -> float {
+    // The mel operand of every conv0 tap is the same for all 256 channels of the workgroup: its
+    // address depends on (block, loop counter) only, so the row loads below are SCALAR loads
+    // (s_load_dwordx4, 4 new mel bins of each of the 7 rows per output column) and the taps are v_fma
+    // with an SGPR operand — no LDS staging and no LDS read per FMA (the LDS-broadcast version was
+    // LDS-issue-bound at a quarter of the f32 VALU rate).  Zero padding costs nothing per tap: the
+    // left mel bin -1 is the initial value of the carried column, out-of-range mel rows are read from
+    // a clamped row with their taps' weights zeroed (kz), invalid conv0 rows are skipped (uniform).
+    const float* rowp[7];
+    bool rowok[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const int tm = 4 * t2 - 3 + r;
+        rowok[r] = tm >= 0 && tm < t_max;
+        rowp[r] = fb + (size_t)(tm < 0 ? 0 : (tm >= t_max ? t_max - 1 : tm)) * n_mels;
+    }
+    float kz[3][9];
+    bool a_ok[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
         const int t1 = 2 * t2 - 1 + a;
-        if (t1 < 0 || t1 >= L1 || f1 < 0 || f1 >= F1) return 0.0f;
-        // mel rows 2*t1-1 .. 2*t1+1  -> local rows 2a .. 2a+2 ; mel cols 2*f1-1 .. 2*f1+1 -> +1 offset
-        const float* m0 = mel + (2 * a) * W + 2 * f1;
-        float acc = bias0;
+        a_ok[a] = t1 >= 0 && t1 < L1;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc = fmaf(k0[i * 3 + j], m0[i * W + j], acc);
-        return fmaxf(acc, 0.0f);
-    };
-
+            for (int j = 0; j < 3; ++j) kz[a][i * 3 + j] = rowok[2 * a + i] ? k0[i * 3 + j] : 0.0f;
+    }
+    float carry[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) carry[r] = 0.0f;     // mel bin -1
     float left[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) left[a] = 0.0f;  // f1 = -1 is padding
+    for (int a = 0; a < 3; ++a) left[a] = 0.0f;      // f1 = -1 is padding
     for (int f2 = 0; f2 < F2; ++f2) {
+        float m[7][5];                               // mel bins 4*f2-1 .. 4*f2+3 of the 7 rows
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const float4 q = *reinterpret_cast<const float4*>(rowp[r] + 4 * f2);
+            m[r][0] = carry[r]; m[r][1] = q.x; m[r][2] = q.y; m[r][3] = q.z; m[r][4] = q.w;
+            carry[r] = q.w;
+        }
         float mid[3], right[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { mid[a] = conv0(a, 2 * f2); right[a] = conv0(a, 2 * f2 + 1); }
+        for (int a = 0; a < 3; ++a) {
+            float am = 0.0f, ar = 0.0f;
+            if (a_ok[a]) {
+                am = bias0; ar = bias0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        am = fmaf(kz[a][i * 3 + j], m[2 * a + i][j], am);          // f1 = 2*f2   : bins 4*f2-1 .. 4*f2+1
+                        ar = fmaf(kz[a][i * 3 + j], m[2 * a + i][2 + j], ar);      // f1 = 2*f2+1 : bins 4*f2+1 .. 4*f2+3
+                    }
+                am = fmaxf(am, 0.0f); ar = fmaxf(ar, 0.0f);
+            }
+            mid[a] = am; right[a] = ar;
+        }
         float acc = biasd;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -149,7 +174,9 @@ int rs_launch_sub_conv0_dw1(rs_ctx* ctx, const float* feats, const int32_t* lens
     const int C = d.sub_channels;
     if (C > 256 || (C % 64)) return rs_fail(ctx, RS_EINVAL, "subsampling: channels %d unsupported (<=256, %%64)", C);
     const int F1 = (d.n_mels + 2 - 3) / 2 + 1;
-    const size_t lds = (size_t)7 * (d.n_mels + 2) * sizeof(float);
+    if (d.n_mels % 4 || 4 * F2 > d.n_mels || 2 * F2 < F1)
+        return rs_fail(ctx, RS_EINVAL, "subsampling: n_mels=%d must be a multiple of 4 with 4*F2 <= n_mels", d.n_mels);
+    const size_t lds = 0;
     const double flops = (double)B * T2 * F2 * C * 2.0 * (6 * 9 + 9);
     const double bytes = (double)B * t_max * d.n_mels * 4.0 + (double)B * T2 * F2 * C * 2.0;
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, flops, bytes);
