@@ -39,9 +39,14 @@ __device__ __forceinline__ float fetch_sample(const float* __restrict__ a, int i
 
 __device__ __forceinline__ int bitrev9(int v) { return (int)(__brev((unsigned)v) >> 23); }
 
+// One wave transforms TWO frames per 512-point complex FFT (frame t in the real part, t+1 in the
+// imaginary part; the two real spectra are separated afterwards: X_a[k] = (Z[k] + conj Z[N-k]) / 2,
+// X_b[k] = (Z[k] - conj Z[N-k]) / 2i).  Everything a wave touches in LDS is its own, so the stages are
+// separated by wave-level fences, not workgroup barriers; the twiddles are staged once per workgroup.
 __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
     __shared__ float2 buf[WAVES][NFFT];
-    __shared__ float pw[WAVES][NBIN + 3];
+    __shared__ float pw[WAVES][2][NBIN + 3];
+    __shared__ float2 tw[NFFT / 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int len = p.lens[b];
@@ -50,67 +55,82 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
     if (blockIdx.x == 0 && threadIdx.x == 0) p.n_frames[b] = n_valid;
     const float* a = p.audio + (size_t)b * p.audio_stride;
     if ((int)blockIdx.x * WAVES * FRAMES_PER_WAVE >= min(n_valid, p.t_max)) return;  // block-uniform
+    tw[threadIdx.x] = reinterpret_cast<const float2*>(p.twiddle)[threadIdx.x];      // 256 threads, 256 twiddles
+    __syncthreads();
     const int frame_base = (blockIdx.x * WAVES + wave) * FRAMES_PER_WAVE;
     const int centre_off = (NFFT - p.win_length) / 2;     // 56: window centred in the 512 frame
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // windowed, pre-emphasised sample n of frame t (0 outside the frame / the padded signal)
+    auto sample = [&](int t, int n) -> float {
+        if (t >= n_valid || t >= p.t_max || n >= p.win_length) return 0.0f;
+        const int i = t * p.hop - NFFT / 2 + centre_off + n;  // index in the padded signal
+        if (i < 0 || i >= Lp) return 0.0f;
+        const float x0 = fetch_sample(a, i, p.pad_left, len);
+        const float x1 = (i >= 1) ? fetch_sample(a, i - 1, p.pad_left, len) : 0.0f;
+        const float y = (i >= 1) ? x0 - p.preemph * x1 : x0;
+        return y * p.window[n];
+    };
 
-    for (int fi = 0; fi < FRAMES_PER_WAVE; ++fi) {
+    for (int fi = 0; fi < FRAMES_PER_WAVE; fi += 2) {
         const int t = frame_base + fi;
-        const bool active = t < n_valid && t < p.t_max;
-        // ---- windowed, pre-emphasised samples -> bit-reversed LDS order.  A circular shift of the
-        // FFT input only changes the phase, so the 400 samples go to slots 0..399 directly.
+        if (t >= n_valid || t >= p.t_max) break;          // wave-uniform
+        // ---- two frames -> bit-reversed LDS order.  A circular shift of the FFT input only changes the
+        // phase, so the 400 samples go to slots 0..399 directly.
         float2* z = buf[wave];
 #pragma unroll
         for (int q = 0; q < NFFT / 64; ++q) {
             const int n = q * 64 + lane;
-            float v = 0.0f;
-            if (active && n < p.win_length) {
-                const int i = t * p.hop - NFFT / 2 + centre_off + n;  // index in the padded signal
-                if (i >= 0 && i < Lp) {
-                    const float x0 = fetch_sample(a, i, p.pad_left, len);
-                    const float x1 = (i >= 1) ? fetch_sample(a, i - 1, p.pad_left, len) : 0.0f;
-                    const float y = (i >= 1) ? x0 - p.preemph * x1 : x0;
-                    v = y * p.window[n];
-                }
-            }
-            z[bitrev9(n)] = make_float2(v, 0.0f);
+            z[bitrev9(n)] = make_float2(sample(t, n), sample(t + 1, n));
         }
-        __syncthreads();
+        wave_sync();
         // ---- 9 radix-2 DIT stages, 256 butterflies each (4 per lane)
-#pragma unroll 1
+#pragma unroll
         for (int s = 0; s < 9; ++s) {
             const int half = 1 << s;
+            float2 u[4], v[4], w[4];
+            int i0[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int tb = q * 64 + lane;
                 const int pos = tb & (half - 1);
-                const int i0 = ((tb >> s) << (s + 1)) + pos;
-                const int i1 = i0 + half;
-                const float2 w = reinterpret_cast<const float2*>(p.twiddle)[pos << (8 - s)];
-                const float2 u = z[i0], v = z[i1];
-                const float tr = v.x * w.x - v.y * w.y;
-                const float ti = v.x * w.y + v.y * w.x;
-                z[i0] = make_float2(u.x + tr, u.y + ti);
-                z[i1] = make_float2(u.x - tr, u.y - ti);
+                i0[q] = ((tb >> s) << (s + 1)) + pos;
+                w[q] = tw[pos << (8 - s)];
+                u[q] = z[i0[q]];
+                v[q] = z[i0[q] + half];
             }
-            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float tr = v[q].x * w[q].x - v[q].y * w[q].y;
+                const float ti = v[q].x * w[q].y + v[q].y * w[q].x;
+                z[i0[q]] = make_float2(u[q].x + tr, u[q].y + ti);
+                z[i0[q] + half] = make_float2(u[q].x - tr, u[q].y - ti);
+            }
+            wave_sync();
         }
-        // ---- power spectrum bins 0..256
+        // ---- split the two spectra, power of bins 0..256
         for (int k = lane; k < NBIN; k += 64) {
-            const float2 c = z[k];
-            pw[wave][k] = c.x * c.x + c.y * c.y;
+            const float2 zk = z[k], zn = z[(NFFT - k) & (NFFT - 1)];
+            const float ar = 0.5f * (zk.x + zn.x), ai = 0.5f * (zk.y - zn.y);
+            const float br = 0.5f * (zk.y + zn.y), bi = 0.5f * (zn.x - zk.x);
+            pw[wave][0][k] = ar * ar + ai * ai;
+            pw[wave][1][k] = br * br + bi * bi;
         }
-        __syncthreads();
-        // ---- banded mel filterbank + log
-        if (active) {
-            for (int m = lane; m < p.n_mels; m += 64) {
+        wave_sync();
+        // ---- banded mel filterbank + log: lane -> (frame of the pair, mel bin)
+        for (int idx = lane; idx < 2 * p.n_mels; idx += 64) {
+            const int f = idx >= p.n_mels, m = idx - f * p.n_mels;
+            if (t + f < n_valid && t + f < p.t_max) {
                 const int k0 = p.fb_idx[2 * m], cnt = p.fb_idx[2 * m + 1];
                 const float* w = p.fb_w + m * FB_MAXW;
                 float acc = 0.0f;
-                for (int j = 0; j < cnt; ++j) acc = fmaf(w[j], pw[wave][k0 + j], acc);
-                p.raw[((size_t)b * p.t_max + t) * p.n_mels + m] = logf(acc + p.log_guard);
+                for (int j = 0; j < cnt; ++j) acc = fmaf(w[j], pw[wave][f][k0 + j], acc);
+                p.raw[((size_t)b * p.t_max + t + f) * p.n_mels + m] = logf(acc + p.log_guard);
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
