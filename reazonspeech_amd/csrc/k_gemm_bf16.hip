@@ -258,8 +258,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
         // exposed L2/HBM latency was 27 % of a K=1024 tile — profiles/r01k_gemm_tile_timeline.txt)
         // and only 32 VGPRs are in flight (the 128x128 kernel keeps 3 workgroups per CU).
         constexpr int UNITS = MI * NI * 2;
-        float4 bias_all[has_res ? 1 : NI][has_res ? 1 : 4];
-        if constexpr (!has_res) {
+        constexpr bool BIAS_PRELOAD = !has_res && NI <= 2;   // wide wave tiles fetch the bias per unit (registers)
+        float4 bias_all[BIAS_PRELOAD ? NI : 1][BIAS_PRELOAD ? 4 : 1];
+        if constexpr (BIAS_PRELOAD) {
             if (has_bias) {
 #pragma unroll
                 for (int jj = 0; jj < NI; ++jj)
@@ -304,9 +305,15 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
 #pragma unroll
                 for (int q = 0; q < 2; ++q) { rv[q] = rv_next[q]; bv[q] = bv_next[q]; }
                 if (u + 1 < UNITS) load_unit(u + 1, rv_next, bv_next);
-            } else {
+            } else if constexpr (BIAS_PRELOAD) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) bv[q] = has_bias ? bias_all[jj][2 * gp + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int n = nb + 8 * (2 * gp + q);
+                    bv[q] = (has_bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             float4 v[2];
 #pragma unroll
@@ -485,6 +492,9 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
             const long c192 = ((t192 + CUS - 1) / CUS) * 192, c256 = ((t256 + CUS - 1) / CUS) * 256;
             v = c192 * 100 < c256 * 88 ? 10 : 2;
         }
+        static int big = -1;      // A/B knob for whole-pipeline runs: remap the 256x256 choice
+        if (big < 0) { const char* e = getenv("RS_GEMM_BIG"); big = e ? atoi(e) : 0; }
+        if (v == 2 && big > 0) v = big;
         // (variant 9, the persistent tile loop, is ~20 % faster in isolation — profiles/r01_gemm_persistent.txt —
         // but one 128 KiB-LDS workgroup per CU for the whole launch starves the decode stream of the
         // two-stage pipeline; it is selected with rs_debug_set_gemm_persistent(1) / RS_GEMM_PERSISTENT=1
