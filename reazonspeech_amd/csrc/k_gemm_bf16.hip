@@ -94,7 +94,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
-template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST, bool RES, bool TRACE = false>
+template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST, bool RES, bool TRACE = false, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 1 : 2) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NWAVES = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -175,6 +175,63 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.0f;
 
+        if constexpr (PP) {
+            // ---- ping-pong main loop (BK = 32 granules in a 4-deep ring).  The two wave rows (wm = 0 / 1:
+            // one wave of each per SIMD) run half a phase apart: while one group issues its 8 MFMAs of a
+            // 16-deep k slice, the other fetches its next fragments from LDS and issues its share of the
+            // DMA for the granule three ahead; two barriers per phase keep the alternation exact.
+            //   group 0:      mem(p) | B | mfma(p) | B | mem(p+1) | B | ...
+            //   group 1:  B | mem(p) | B | mfma(p) | B | ...                       (one barrier late)
+            // RAW: granule g+1 is waited for (counted vmcnt) in the memory part of g's LAST phase and first
+            // read one phase later, i.e. after a barrier that both groups' waits precede.  WAR: the DMA
+            // into granule g-1's buffer starts in g's first phase, a full phase after both groups drained
+            // (lgkmcnt(0) before the barrier) their last reads of it.
+            static_assert(!PP || (BK == 32 && NST == 4 && WM == 2 && !PERSIST), "ping-pong loop: 32-deep granules, ring of 4");
+            if (nk >= 3) wait_vmcnt<2 * LOADS_PER_STAGE>();
+            else if (nk == 2) wait_vmcnt<LOADS_PER_STAGE>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (wm == 1) __builtin_amdgcn_s_barrier();
+            for (int g = 0; g < nk; ++g) {
+                const char* at = smem + (g & 3) * STAGE_BYTES;
+                const char* bt = at + A_BYTES;
+                char* nst = smem + ((g + 3) & 3) * STAGE_BYTES;
+                const bool more = g + 3 < nk;
+                const int nk0 = (g + 3) * BK;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8_t af[MI], bfr[NI];
+#pragma unroll
+                    for (int jj = 0; jj < NI; ++jj) bfr[jj] = read_frag<BK>(bt, wn * TN + jj * 32 + frow, ks * 2 + fhalf);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[i] = read_frag<BK>(at, wm * TM + i * 32 + frow, ks * 2 + fhalf);
+                    if (ks == 1 && g + 1 < nk) {
+                        if (g + 3 < nk) wait_vmcnt<LOADS_PER_STAGE + LOADS_PER_STAGE / 2>();
+                        else if (g + 2 < nk) wait_vmcnt<LOADS_PER_STAGE>();
+                        else wait_vmcnt<0>();
+                    }
+                    if (more) {
+                        if (ks == 0) stage_rows<BK, BM, NWAVES>(p.A, p.lda, m0, p.M, nk0, nst, wave, lane);
+                        else stage_rows<BK, BN, NWAVES>(p.W, p.ldw, n0, p.N, nk0, nst + A_BYTES, wave, lane);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < NI; ++jj)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (wm == 0) __builtin_amdgcn_s_barrier();
+        } else
         for (int t = 0; t < nk; ++t) {
             // stage t must have landed: at most NST-2 younger stages may still be in flight.
             // In the persistent loop the previous tile's stores share the counter and loads/stores may
@@ -374,7 +431,7 @@ extern int g_persistent;
 extern int g_group_m;
 extern long long* g_trace;
 
-template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST, bool RES>
+template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST, bool RES, bool PP = false>
 int launch_variant2(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int LDS = NST * STAGE_BYTES;
@@ -406,15 +463,24 @@ int launch_variant2(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, true>), dim3(nwg), dim3(64 * WM * WN), LDS, s, p);
     else if (persist)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, PERSIST, RES>), dim3(CUS), dim3(64 * WM * WN), LDS, s, p);
-    else
+    else if (PP) {
+        static bool pp_attr = false;
+        if (!pp_attr) {
+            if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, false, PP>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+                return rs_fail(ctx, RS_EHIP, "gemm: cannot reserve %d bytes of LDS", LDS);
+            pp_attr = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, false, PP>), dim3(nwg), dim3(64 * WM * WN), LDS, s, p);
+    } else
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES>), dim3(nwg), dim3(64 * WM * WN), LDS, s, p);
     return RS_OK;
 }
 
-template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST = false>
+template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST = false, bool PP = false>
 int launch_variant(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
-    if (p.flags & RS_GEMM_RESIDUAL) return launch_variant2<BM, BN, BK, NST, WM, WN, PERSIST, true>(ctx, p, s);
-    return launch_variant2<BM, BN, BK, NST, WM, WN, PERSIST, false>(ctx, p, s);
+    if (p.flags & RS_GEMM_RESIDUAL) return launch_variant2<BM, BN, BK, NST, WM, WN, PERSIST, true, PP>(ctx, p, s);
+    return launch_variant2<BM, BN, BK, NST, WM, WN, PERSIST, false, PP>(ctx, p, s);
 }
 
 long long* g_trace = nullptr;
@@ -507,6 +573,10 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         case 7: rc = launch_variant<128, 128, 32, 3, 2, 2>(ctx, p, s); break;   // 3 WGs per CU
         case 9: rc = launch_variant<256, 256, 64, 2, 2, 4, true>(ctx, p, s); break;    // persistent, one WG per CU
         case 10: rc = launch_variant<192, 256, 64, 2, 2, 4>(ctx, p, s); break;  // 3/4 tile: fewer idle CUs in the last round
+        // ping-pong wave groups: +14-17 % over case 2 in ~10 ms bursts, identical in the sustained regime (the
+        // package sits at its ~1.4 kW cap and the clock drops from 2.04 to 1.94 GHz instead:
+        // profiles/r01t_gemm_sustained_power.txt); opt-in with RS_GEMM_BIG=20
+        case 20: rc = launch_variant<256, 256, 32, 4, 2, 4, false, true>(ctx, p, s); break;
         default: rc = rs_fail(ctx, RS_EINVAL, "gemm: unknown RS_GEMM_VARIANT %d", v);
     }
     rs_prof_end(ctx, RS_PROF_GEMM, s);
