@@ -533,7 +533,8 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     }
     const double flops = 2.0 * a.M * (double)a.N * a.K;
     const double bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
-                         (double)a.M * a.N * ((a.flags & RS_GEMM_OUT_F32) ? 4 : 2);
+                         (double)a.M * a.N * ((a.flags & RS_GEMM_OUT_F32) ? 4 : 2) +
+                         ((a.flags & RS_GEMM_RESIDUAL) ? (double)a.M * a.N * 4 : 0.0);   // residual is read once
     rs_prof_begin(ctx, RS_PROF_GEMM, s, flops, bytes);
     int rc;
     int v = g_variant;
