@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="debug: 2-layer toy config (NOT a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--enc-streams", type=int, default=int(os.environ.get("RS_ENC_STREAMS", "1")),
+                    help="experimental: encoders of consecutive batches on two streams (four resident batches)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decode of each batch back to back on one stream")
     args = ap.parse_args()
@@ -107,7 +109,8 @@ def main():
     model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device=f"cuda:{local_rank}")
     # two resident batches (different utterances): the pipelined path alternates between them
     bufs, lens_all = [], []
-    for k in range(2):
+    n_sets = 4 if args.enc_streams == 2 else 2
+    for k in range(n_sets):
         audio, lens = synthetic_batch(args.batch, args.seconds, seed=1234 + 17 * rank + 1000 * k)
         b = model.stage([audio[i, :lens[i]] for i in range(args.batch)],
                         buf=model.new_buffers(args.batch, int(args.seconds * 16000)))
@@ -125,13 +128,13 @@ def main():
 
     def run_steps(n):
         if pipelined:
-            model.run_pipelined(bufs, n, after_decode=None)
+            model.run_pipelined(bufs, n, after_decode=None, enc_streams=args.enc_streams)
             for i in range(n):                      # one collective per step, as the path defines it
-                gather(bufs[i % 2])
+                gather(bufs[i % n_sets])
         else:
             for i in range(n):
-                model.run_device(bufs[i % 2])
-                gather(bufs[i % 2])
+                model.run_device(bufs[i % n_sets])
+                gather(bufs[i % n_sets])
 
     run_steps(args.warmup)
     prof = not args.no_profile
@@ -153,16 +156,16 @@ def main():
     # memory first and its hypotheses are copied back after decode
     dt_host = None
     if pipelined and world == 1:
-        model.run_pipelined(bufs, 2, from_host=True)
+        model.run_pipelined(bufs, 2, from_host=True, enc_streams=args.enc_streams)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        model.run_pipelined(bufs, args.steps, from_host=True)
+        model.run_pipelined(bufs, args.steps, from_host=True, enc_streams=args.enc_streams)
         torch.cuda.synchronize()
         dt_host = time.perf_counter() - t1
 
     n_ids = np.concatenate([b.n_ids.cpu().numpy() for b in bufs])
     mean_tokens = float(n_ids.mean())
-    audio_seconds = sum(float(lens_all[i % 2].sum()) for i in range(args.steps)) / 16000.0 * world
+    audio_seconds = sum(float(lens_all[i % n_sets].sum()) for i in range(args.steps)) / 16000.0 * world
     value = audio_seconds / dt
 
     if rank == 0:
@@ -177,7 +180,8 @@ def main():
                        "utterance_seconds": args.seconds, "parallelism": f"dp{world}",
                        "enc_frames": buf.tp_max, "mean_tokens_per_utt": round(mean_tokens, 1),
                        "max_tokens_per_utt": int(n_ids.max()),
-                       "schedule": "2-stage pipeline: encoder(i+1) || greedy decode(i) on two HIP streams"
+                       "schedule": ("2-stage pipeline: encoder(i+1) || greedy decode(i) on two HIP streams"
+                                    + (" (encoders of consecutive batches on two streams)" if args.enc_streams == 2 else ""))
                                    if pipelined else "sequential"},
             "setup_s": round(setup_s, 1),
         }

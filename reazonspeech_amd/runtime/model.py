@@ -126,11 +126,12 @@ class AsrModel:
                                  buf.n_ids, buf.ws, stream)
 
     # ------------------------------------------------------------------------------------------
-    def run_encoder(self, buf: _Buffers, stream):
+    def run_encoder(self, buf: _Buffers, stream, ctx=None):
         """front-end + encoder of one batch on `stream` (asynchronous)"""
-        self.ctx.frontend(buf.audio, buf.lens, self.pad_left, self.pad_right, buf.t_max, buf.feats, buf.n_frames,
-                          buf.ws, stream)
-        self.ctx.encoder(buf.feats, buf.n_frames, buf.B, buf.t_max, None, buf.joint_enc, buf.enc_lens, buf.ws, stream)
+        ctx = ctx or self.ctx
+        ctx.frontend(buf.audio, buf.lens, self.pad_left, self.pad_right, buf.t_max, buf.feats, buf.n_frames,
+                     buf.ws, stream)
+        ctx.encoder(buf.feats, buf.n_frames, buf.B, buf.t_max, None, buf.joint_enc, buf.enc_lens, buf.ws, stream)
 
     def run_encoder_split(self, buf: _Buffers, streams):
         """front-end + encoder of one batch as two independent half-batches on two streams: the
@@ -153,7 +154,7 @@ class AsrModel:
                         buf.enc_lens[lo:hi], ws, s)
 
     def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None, split_encoder: bool = None,
-                      from_host: bool = False):
+                      from_host: bool = False, enc_streams: int = 1):
         """Process `steps` batches (bufs[i % len(bufs)], inputs already in HBM) as a two-stage
         pipeline: the throughput-bound front-end + encoder of batch i+1 runs on one HIP stream while
         the latency-bound greedy decode of batch i (a dependency chain of small launches that leaves
@@ -162,8 +163,11 @@ class AsrModel:
         returns.  `after_decode(buf)` is called on the worker thread after each batch.  With
         `from_host` every batch is first copied from its pinned host buffer (H2D on the encoder
         stream) and its hypotheses are copied back to the host after decode (the PCIe-inclusive
-        boundary)."""
+        boundary).  `enc_streams=2` (experimental) runs the encoders of consecutive batches on two
+        streams (each with its full-size launches) so that one batch's HBM-bound kernels can overlap the
+        other's GEMMs; it needs four buffer sets."""
         assert len(bufs) >= 2, "the pipeline needs two buffer sets"
+        assert enc_streams in (1, 2) and (enc_streams == 1 or len(bufs) >= 4), "two encoder streams need four buffer sets"
         with torch.cuda.device(self.device):
             if split_encoder is None:
                 # measured on MI355X: splitting the encoder batch over two streams LOSES ~5 % (83.8 vs
@@ -214,9 +218,19 @@ class AsrModel:
                 if i >= nb:
                     done[i - nb].wait()           # this buffer set's previous decode must be finished
                 if from_host:
-                    with torch.cuda.stream(enc_stream):
+                    with torch.cuda.stream(self._enc2_stream if (enc_streams == 2 and (i & 1)) else enc_stream):
                         buf.audio.copy_(buf.h_audio, non_blocking=True)
                         buf.lens.copy_(buf.h_lens, non_blocking=True)
+                if enc_streams == 2 and (i & 1):
+                    # odd batches: second context (a context is bound to one stream) on the second stream
+                    es = self._enc2_stream
+                    if i < 2:
+                        es.wait_stream(torch.cuda.current_stream())
+                    self.run_encoder(buf, es.cuda_stream, ctx=self._ctx_enc2)
+                    ev = torch.cuda.Event()
+                    ev.record(es)
+                    jobs.put((i, buf, ev))
+                    continue
                 if split_encoder and buf.B >= 2:
                     self._enc2_stream.wait_stream(enc_stream)       # keep batch order across both halves
                     self.run_encoder_split(buf, (enc_stream, self._enc2_stream))
@@ -229,6 +243,7 @@ class AsrModel:
             jobs.put(None)
             th.join()
             torch.cuda.current_stream().wait_stream(enc_stream)
+            torch.cuda.current_stream().wait_stream(self._enc2_stream)
             torch.cuda.current_stream().wait_stream(dec_stream)
             if errors:
                 raise errors[0]
