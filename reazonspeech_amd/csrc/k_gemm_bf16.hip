@@ -426,6 +426,226 @@ __global__ __launch_bounds__(64 * WM * WN, (BM / WM) * (BN / WN) >= 128 * 128 ? 
     }
 }
 
+
+// =====================================================================================================
+// 16x16x32 variant.  Same tile (256 x 256, 8 waves of 128 x 64), ping-pong wave groups over a ring of four
+// 32-deep granules, but the products run on v_mfma_f32_16x16x32_bf16.  Reason: the chip is package-power
+// limited in the sustained regime and, registers only, the 16x16x32 shape sustains 2.45 PF/s
+// where 32x32x16 is throttled to 1.9-2.06 PF/s (scripts/mfma_power.hip, profiles/r01w_mfma_shape_power.txt):
+// fewer joules per FLOP is the lever that is left.
+//   fragments: lane = (row = lane & 15, k chunk = lane >> 4), 8 bf16 (16 B) per lane, one ds_read_b128 per
+//   16 x 32 block.  LDS rows are 64 B (4 chunks); chunk c of row r sits at c ^ f[(r >> 2) & 3] with
+//   f = {0, 2, 3, 1}: the four 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27}, ...) then hit 16 distinct
+//   16-byte slots.
+//   D^T trick as above: weights are the A operand, so a lane ends up with m = lane & 15 and the 4 consecutive
+//   n = 4 * (lane >> 4) + reg of every 16 x 16 block: 16-byte f32 / 8-byte bf16 accesses, 64 / 32 contiguous
+//   bytes per row and instruction.
+__device__ __forceinline__ int swz16(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+template <int ROWS, int NWAVES>
+__device__ __forceinline__ void stage_rows16(const uint16_t* __restrict__ base, int ld, int row0, int max_row, int k0,
+                                             char* lds_tile, int wave, int lane) {
+    constexpr int INSTS = ROWS / 16, PER_WAVE = INSTS / NWAVES;
+    static_assert(INSTS % NWAVES == 0, "tile rows must split evenly over the waves");
+    const int r = lane >> 2, pc = lane & 3;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int rbase = (wave * PER_WAVE + j) * 16;
+        const int row = rbase + r;
+        const int c = pc ^ swz16(row);
+        int grow = row0 + row;
+        grow = grow < max_row ? grow : max_row - 1;
+        const uint16_t* src = base + (size_t)grow * ld + k0 + c * 8;
+        char* dst = lds_tile + rbase * 64;   // wave-uniform; HW adds lane*16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8_t read_frag16(const char* lds_tile, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8_t*>(lds_tile + row * 64 + ((chunk ^ swz16(row)) << 4));
+}
+
+// runtime (wave-uniform) counted wait for the literals this kernel needs
+__device__ __forceinline__ void wait_vmcnt_rt(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+}
+
+template <int BM, int BN, bool RES>
+__global__ __launch_bounds__(512, 2) void gemm_mf16_kernel(GemmParams p) {
+    constexpr int BK = 32, NST = 4, WM = 2, WN = 4, NWAVES = 8;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16, MH = MI / 2;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_INSTS = BM / 16, LB = BN / 16 / NWAVES;
+    static_assert(BN == 256 && (A_INSTS == 16 || A_INSTS == 12) && (MI % 2) == 0, "tile shapes: 256 x 256 or 192 x 256");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fch = lane >> 4;
+    // A-tile DMA instructions (16 rows each) of this wave per granule: ids wave, wave + 8 (< A_INSTS).
+    // 192-row tiles have 12: the waves of group 0 issue two, those of group 1 one.
+    const int LAw = (A_INSTS - wave + NWAVES - 1) / NWAVES;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int xbase = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    const int xcount = xcd < rr ? q + 1 : q;
+    if (slot >= xcount) return;
+    int m0, n0;
+    {
+        const int wg = xbase + slot;
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = wg / per_group, r = wg - g * per_group;
+        const int left = p.tiles_m - g * p.group_m;
+        const int gm = left < p.group_m ? left : p.group_m;
+        const int tile_n = r / gm;
+        m0 = (g * p.group_m + (r - tile_n * gm)) * BM;
+        n0 = tile_n * BN;
+    }
+    const int nk = p.K / BK;
+    const int flags = p.flags;
+    const bool has_bias = flags & RS_GEMM_BIAS, relu = flags & RS_GEMM_RELU, silu = flags & RS_GEMM_SILU;
+    const bool out_f32 = RES || (flags & RS_GEMM_OUT_F32);
+    const bool rowmask = flags & RS_GEMM_ROWMASK;
+    const float alpha = p.alpha;
+
+    auto issue_a = [&](int t) {
+        char* tile = smem + (t & 3) * STAGE_BYTES;
+        const int r = lane >> 2, pc = lane & 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int id = wave + NWAVES * j;
+            if (id < A_INSTS) {                                   // wave-uniform
+                const int row = id * 16 + r;
+                int grow = m0 + row;
+                grow = grow < p.M ? grow : p.M - 1;
+                const uint16_t* src = p.A + (size_t)grow * p.lda + t * BK + (pc ^ swz16(row)) * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(tile + id * 16 * 64), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_b = [&](int t) { stage_rows16<BN, NWAVES>(p.W, p.ldw, n0, p.N, t * BK, smem + (t & 3) * STAGE_BYTES + A_BYTES, wave, lane); };
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) { issue_a(t); issue_b(t); }
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
+
+    // ping-pong main loop: see the PP branch of gemm_bf16_kernel for the barrier / RAW / WAR argument
+    wait_vmcnt_rt(nk >= 3 ? 2 * (LAw + LB) : (nk == 2 ? LAw + LB : 0));
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    for (int g = 0; g < nk; ++g) {
+        const char* at = smem + (g & 3) * STAGE_BYTES;
+        const char* bt = at + A_BYTES;
+        const bool more = g + 3 < nk;
+        bf16x8_t bfr[NI];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {       // ks = which half of the wave's 128 activation rows
+            bf16x8_t af[MH];
+            if (ks == 0) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bfr[j] = read_frag16(bt, wn * TN + j * 16 + frow, fch);
+            }
+#pragma unroll
+            for (int i = 0; i < MH; ++i) af[i] = read_frag16(at, wm * TM + (ks * MH + i) * 16 + frow, fch);
+            if (ks == 1 && g + 1 < nk)     // younger than granule g+1: all of g+2, the A part of g+3
+                wait_vmcnt_rt(g + 3 < nk ? 2 * LAw + LB : (g + 2 < nk ? LAw + LB : 0));
+            if (more) {
+                if (ks == 0) issue_a(g + 3);
+                else issue_b(g + 3);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MH; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[ks * MH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[ks * MH + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue from registers: block (i, j) -> m = .. + i*16 + (lane & 15), n = .. + j*16 + 4*(lane >> 4) + 0..3
+    int cm0 = m0, cn0 = n0;
+    asm volatile("" : "+s"(cm0), "+s"(cn0));   // keep the addresses out of the main loop's live ranges
+    float4 bias_r[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = cn0 + wn * TN + j * 16 + 4 * fch;
+        bias_r[j] = (has_bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto load_res = [&](int i, float4 (&rv)[NI]) {
+        const int m = cm0 + wm * TM + i * 16 + frow;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = cn0 + wn * TN + j * 16 + 4 * fch;
+            rv[j] = (m < p.M && n < p.N) ? *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldc + n)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 rv_next[NI];
+    if constexpr (RES) load_res(0, rv_next);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = cm0 + wm * TM + i * 16 + frow;
+        const bool m_ok = m < p.M;
+        bool keep = true;
+        if (rowmask && m_ok) {
+            const int step = m / p.mask_rows_per_step;
+            const int b = step / p.mask_steps;
+            keep = step - b * p.mask_steps < p.mask_lens[b];
+        }
+        float4 rv[NI];
+        if constexpr (RES) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) rv[j] = rv_next[j];
+            if (i + 1 < MI) load_res(i + 1, rv_next);
+        }
+        const size_t rowoff = (size_t)m * p.ldc;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = cn0 + wn * TN + j * 16 + 4 * fch;
+            float4 v = make_float4(acc[i][j][0] + bias_r[j].x, acc[i][j][1] + bias_r[j].y, acc[i][j][2] + bias_r[j].z,
+                                   acc[i][j][3] + bias_r[j].w);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+            if constexpr (RES) { v.x += rv[j].x; v.y += rv[j].y; v.z += rv[j].z; v.w += rv[j].w; }
+            if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m_ok && n < p.N) {
+                if (out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + rowoff + n) = v;
+                else *reinterpret_cast<u16x4_t*>(reinterpret_cast<uint16_t*>(p.out) + rowoff + n) = pack_bf16x4(v.x, v.y, v.z, v.w);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 extern int g_skew;
 extern int g_persistent;
 extern int g_group_m;
@@ -481,6 +701,26 @@ template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST = false,
 int launch_variant(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     if (p.flags & RS_GEMM_RESIDUAL) return launch_variant2<BM, BN, BK, NST, WM, WN, PERSIST, true, PP>(ctx, p, s);
     return launch_variant2<BM, BN, BK, NST, WM, WN, PERSIST, false, PP>(ctx, p, s);
+}
+
+template <int BM, int BN>
+int launch_mf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
+    constexpr int LDS = 4 * (BM + BN) * 32 * 2;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    p.group_m = g_group_m > 0 ? g_group_m : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8));
+    p.skew_cycles = 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_mf16_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_mf16_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return rs_fail(ctx, RS_EHIP, "gemm: cannot reserve %d bytes of LDS", LDS);
+        attr_set = true;
+    }
+    if (p.flags & RS_GEMM_RESIDUAL) hipLaunchKernelGGL((gemm_mf16_kernel<BM, BN, true>), dim3(nwg), dim3(512), LDS, s, p);
+    else hipLaunchKernelGGL((gemm_mf16_kernel<BM, BN, false>), dim3(nwg), dim3(512), LDS, s, p);
+    return RS_OK;
 }
 
 long long* g_trace = nullptr;
@@ -561,7 +801,11 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         }
         static int big = -1;      // A/B knob for whole-pipeline runs: remap the 256x256 choice
         if (big < 0) { const char* e = getenv("RS_GEMM_BIG"); big = e ? atoi(e) : 0; }
-        if (v == 2 && big > 0) v = big;
+        // big == 0: the 16x16x32 kernels (whole path 71.7 -> 69.5 ms/step with them: profiles/r01w_*);
+        // 1 = the 32x32x16 kernels they replaced; 20 = 32x32x16 ping-pong; 31 = 16x16x32 with 256-row tiles only
+        if (big == 0) { if (v == 2) v = 30; else if (v == 10) v = 32; }
+        else if (big == 31) { if (v == 2 || v == 10) v = 30; }
+        else if (v == 2 && big > 1) v = big;
         // (variant 9, the persistent tile loop, is ~20 % faster in isolation — profiles/r01_gemm_persistent.txt —
         // but one 128 KiB-LDS workgroup per CU for the whole launch starves the decode stream of the
         // two-stage pipeline; it is selected with rs_debug_set_gemm_persistent(1) / RS_GEMM_PERSISTENT=1
@@ -578,6 +822,8 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         // package sits at its ~1.4 kW cap and the clock drops from 2.04 to 1.94 GHz instead:
         // profiles/r01t_gemm_sustained_power.txt); opt-in with RS_GEMM_BIG=20
         case 20: rc = launch_variant<256, 256, 32, 4, 2, 4, false, true>(ctx, p, s); break;
+        case 30: rc = launch_mf16<256, 256>(ctx, p, s); break;   // 16x16x32 MFMA, ping-pong wave groups
+        case 32: rc = launch_mf16<192, 256>(ctx, p, s); break;   // the same with the 3/4-height tile
         default: rc = rs_fail(ctx, RS_EINVAL, "gemm: unknown RS_GEMM_VARIANT %d", v);
     }
     rs_prof_end(ctx, RS_PROF_GEMM, s);

@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 var=$1; shift
 vals=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do vals+=("$1"); shift; done
 [ "$1" == "--" ] && shift
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for v in "${vals[@]}"; do
   echo "== $var=$v (rep $rep) $*"
   env $var=$v timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "
