@@ -198,7 +198,7 @@ def main():
                     traffic = json.load(fp)["hbm_bytes_per_launch"]
             except Exception:
                 pass
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all encoder linears)",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_mf16_kernel / gemm_bf16_kernel (all encoder linears)",
                                "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (PMC, profiles/gemm_traffic.json)",
