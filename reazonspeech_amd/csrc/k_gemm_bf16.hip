@@ -804,6 +804,7 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         // big == 0: the 16x16x32 kernels (whole path 71.7 -> 69.5 ms/step with them: profiles/r01w_*);
         // 1 = the 32x32x16 kernels they replaced; 20 = 32x32x16 ping-pong; 31 = 16x16x32 with 256-row tiles only
         if (big == 0) { if (v == 2) v = 30; else if (v == 10) v = 32; }
+        else if (big == 33) { if (v == 10) v = 32; }          // hybrid for A/B: 32x32x16 plain epilogue, 16x16x32 residual
         else if (big == 31) { if (v == 2 || v == 10) v = 30; }
         else if (v == 2 && big > 1) v = big;
         // (variant 9, the persistent tile loop, is ~20 % faster in isolation — profiles/r01_gemm_persistent.txt —
