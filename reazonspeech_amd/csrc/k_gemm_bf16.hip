@@ -2,22 +2,28 @@
 //
 //   out[M][N] = epilogue( A[M][K] . W[N][K]^T )        A, W row-major bf16 (K contiguous)
 //
-// This one kernel family carries every dense contraction of the encoder (SURVEY.md §8a rows
-// S2-S4, L2, L3, L6 pw1/pw2, D1): 96.8 % of the path's FLOPs.  Structure (template parameters):
-//   * BM x BN output tile per workgroup, WM x WN waves, each wave (BM/WM) x (BN/WN) as blocks of
-//     v_mfma_f32_32x32x16_bf16; BK-deep K steps through an NST-stage LDS ring.
-//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip).  With NST > 2
-//     the loads of the next NST-2 stages stay in flight across the (raw) s_barrier: the wait is a
-//     COUNTED s_waitcnt vmcnt(n), never a drain (guide §5 T3+T4).
-//   * LDS rows are BK bf16; 16-byte chunks are XOR-swizzled by row so the ds_read_b128 fragment
-//     reads (32 rows x one chunk per half-wave) are bank-conflict free.  global_load_lds writes
-//     LDS linearly, so the swizzle is applied to the per-lane SOURCE address and again on the read.
-//   * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs (private L2) walks a contiguous
-//     run of tiles, n-fastest, so an XCD reads each A row-panel once.
-//   * epilogue in registers: the weight fragment is the MFMA A operand, so each lane ends up with
-//     4 consecutive output columns per register quad (row-per-lane layout): +bias, ReLU/SiLU,
-//     *alpha, +residual (f32, prefetched per 32x32 block), per-utterance row mask, 16-byte f32 /
-//     8-byte bf16 stores, no LDS round trip.
+// These kernels carry every dense contraction of the encoder (SURVEY.md §8a rows S2-S4, L2, L3, L6
+// pw1/pw2, D1): 96.8 % of the path's FLOPs.  Two families share the staging, tile-order and epilogue ideas:
+//
+//   gemm_mf16_kernel  (default for the big shapes)  v_mfma_f32_16x16x32_bf16, 256x256 / 192x256 tiles, ring of
+//       four 32-deep granules, ping-pong wave groups.  It exists because the chip is package-power limited in
+//       the sustained regime and this MFMA shape costs fewer joules per FLOP.
+//   gemm_bf16_kernel  v_mfma_f32_32x32x16_bf16; template parameters BM x BN tile, WM x WN waves, BK-deep K steps
+//       through an NST-stage LDS ring; serves the small / narrow problems (128x128 tiles) and stays selectable
+//       for the big ones (RS_GEMM_BIG=1).
+//
+// Common structure:
+//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip); loads of later stages stay
+//     in flight across the (raw) s_barrier: the wait is a COUNTED s_waitcnt vmcnt(n), never a drain
+//     (guide §5 T3+T4).
+//   * 16-byte chunks of an LDS row are XOR-swizzled by row so the ds_read_b128 fragment reads are bank-conflict
+//     free.  global_load_lds writes LDS linearly, so the swizzle is applied to the per-lane SOURCE address and
+//     again on the read.
+//   * blockIdx -> tile mapping is XCD-aware (each of the 8 XCDs, private L2, walks a contiguous run of tiles)
+//     and grouped (group_m A row panels x a few weight tiles run together on an XCD).
+//   * epilogue in registers: the weight fragment is the MFMA A operand, so each lane ends up with consecutive
+//     output columns of one row: +bias, ReLU/SiLU, *alpha, +residual (f32, prefetched), per-utterance row
+//     mask, 16-byte f32 / 8-16-byte bf16 stores, no LDS round trip.
 #include <stdlib.h>
 
 #include "rs_common.h"
