@@ -65,6 +65,48 @@ def test_gemm_shapes(ctx, gpu_device, M, N, K):
     assert err <= 2e-3, err
 
 
+@pytest.mark.parametrize("family", ["mfma16x16x32", "mfma32x32x16"])
+@pytest.mark.parametrize("N,K,residual", [(4096, 1024, False), (1024, 4096, True), (1024, 256, True)])
+def test_gemm_big_tiles(ctx, gpu_device, N, K, residual, family):
+    """The benchmark-geometry launches (M = 35 328 - 37 rows: ragged last tile) go to the 256x256 / 192x256
+    kernels, which the small shapes above never select.  Both MFMA families are checked on three row
+    bands (first, middle, ragged tail) against a float32 reference of the bf16-rounded operands, and the
+    rows past M must stay untouched."""
+    import ctypes
+    M = 35328 - 37
+    g = torch.Generator().manual_seed(N + K)
+    A = rb(torch.randn((M, K), generator=g))
+    W = rb(torch.randn((N, K), generator=g) / K ** 0.5)
+    bias = torch.randn((N,), generator=g)
+    res = torch.randn((M, N), generator=g) if residual else None
+    rows = torch.cat([torch.arange(0, 256), torch.arange(17000, 17256), torch.arange(M - 300, M)])
+    ref = A[rows] @ W.t() + bias
+    if residual:
+        ref = 0.5 * ref + res[rows]
+        flags, alpha = capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32, 0.5
+        out_full = torch.full((M + 64, N), 7.0, dtype=torch.float32, device=gpu_device)
+    else:
+        ref = torch.nn.functional.silu(ref)
+        flags, alpha = capi.GEMM_BIAS | capi.GEMM_SILU, 1.0
+        out_full = torch.full((M + 64, N), 7.0, dtype=torch.bfloat16, device=gpu_device)
+    setv = ctx.lib.rs_debug_set_gemm_variant
+    setv.argtypes = [ctypes.c_int]
+    setv.restype = None
+    try:
+        if family == "mfma32x32x16":
+            setv(10 if residual else 2)        # the kernels the default replaced (192x256 residual, 256x256 plain)
+        ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out_full[:M], flags=flags, bias=bias.to(gpu_device),
+                 alpha=alpha, residual=res.to(gpu_device) if residual else None)
+        sync()
+    finally:
+        setv(0)
+    got = out_full[rows.to(gpu_device)].float().cpu()
+    tol = 2e-3 + (0.0 if residual else 2.0 ** -8) * ref.abs()      # bf16 output: one rounding of the result
+    bad = ((got - ref).abs() > tol)
+    assert not bad.any(), (int(bad.sum()), float((got - ref).abs().max()))
+    assert (out_full[M:].float() == 7.0).all(), "rows past M were written"
+
+
 def test_gemm_epilogues(ctx, gpu_device):
     g = torch.Generator().manual_seed(5)
     B, T, Fq, K, N = 3, 11, 5, 128, 192
