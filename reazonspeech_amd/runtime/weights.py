@@ -194,7 +194,7 @@ def synthetic_state_dict(cfg: ModelConfig, seed: int = 0, blank_bias: float = No
 
 def default_blank_bias(cfg: ModelConfig) -> float:
     """Blank-logit offset of the synthetic joint so that greedy emits on the order of
-    5 tokens per audio-second (tuned with the CPU oracle, scripts/tune_blank_bias.py)."""
+    5 tokens per audio-second (tuned with the CPU oracle, tests/golden/tune_blank_bias.py)."""
     return _BLANK_BIAS.get((cfg.d_model, cfg.n_layers, cfg.vocab_size), 3.0)
 
 

@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reazonspeech_amd.runtime.config import TINY, FASTCONFORMER_619M   # noqa: E402
 from reazonspeech_amd.runtime.weights import synthetic_state_dict      # noqa: E402
 from reazonspeech_amd.runtime.synth import synthetic_batch             # noqa: E402
