@@ -264,3 +264,33 @@ def test_evaluation_batch_hook(tiny):
 def test_load_model_rejects_cpu():
     with pytest.raises(RuntimeError):
         load_model(device="cpu")
+
+
+def test_full_size_model_properties(gpu_device):
+    """The 619M configuration (d = 1024, 24 layers, 8 heads) through the whole path: kernel instantiations that
+    TINY never selects (LayerNorm<4>, the fused norm pair, 8-head attention, 4096-wide FFN GEMMs).  Asserted are
+    size-independent properties only — run-to-run determinism, alone == inside a ragged batch, pipelined ==
+    sequential; the CPU oracle of this size is timed by bench.py, not compared here."""
+    from reazonspeech_amd.runtime.config import FASTCONFORMER_619M as CFG
+    sd = synthetic_state_dict(CFG, 0)
+    model = AsrModel(CFG, sd, SyntheticTokenizer(CFG.vocab_size), device="cuda:0")
+    audio, lens = synthetic_batch(6, 3.0, seed=77, ragged=True, min_seconds=1.0)
+    waves = [audio[b, :lens[b]] for b in range(6)]
+    first = model.transcribe_waveforms(waves)
+    again = model.transcribe_waveforms(waves)
+    assert first.ids == again.ids and first.frames == again.frames
+    assert sum(len(x) for x in first.ids) > 0, "degenerate fixture: nothing was emitted"
+    for b in (0, 3):
+        alone = model.transcribe_waveforms([waves[b]])
+        assert alone.ids[0] == first.ids[b] and alone.frames[0] == first.frames[b]
+    bufs = [model.stage(waves, buf=model.new_buffers(6, 48000)) for _ in range(2)]
+    got = []
+
+    def grab(buf):
+        torch.cuda.current_stream().synchronize()
+        got.append(model.collect(buf))
+
+    model.run_pipelined(bufs, 3, after_decode=grab)
+    assert len(got) == 3
+    for r in got:
+        assert (r.ids, r.frames) == (first.ids, first.frames)
