@@ -132,6 +132,13 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
                        float* enc_out, float* joint_enc, int32_t* enc_lens,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Parity taps (tests only; no reference counterpart — NeMo exposes intermediate activations through
+ * forward hooks): when set, the next rs_encoder_forward calls also copy the f32 residual stream
+ * [B*tp_max][d_model] after the subsampling block (sub_out) and after each listed
+ * conformer layer (layer_out[k] for layer_ids[k]; rows L1-L7).  NULL / 0 disables.  layer_ids is a host array. */
+int rs_encoder_set_taps(rs_ctx* ctx, float* sub_out, float* layer_out, const int32_t* layer_ids,
+                        int n_layer_ids);
+
 /* ---- stage 3: RNN-T greedy decode -------------------------------------------------------
  * Replaces: decoding.rnnt_decoder_predictions_tensor inside model.transcribe
  * (transcribe.py:48-53) — prediction network (Embedding + LSTM), joint (ReLU + Linear),

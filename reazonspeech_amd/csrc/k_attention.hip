@@ -426,14 +426,12 @@ int rs_launch_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, c
     const int nw = qblocks < 6 ? qblocks : 6;
     const dim3 grid((qblocks + nw - 1) / nw, dm.n_heads, B), block(64 * nw);
     const size_t lds = (size_t)KB_CHUNK * (K_BYTES + VT_BYTES) + (size_t)nw * SCR_BYTES + 2 * HD * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         constexpr int MAX_LDS = KB_CHUNK * (K_BYTES + VT_BYTES) + 6 * SCR_BYTES + 2 * HD * (int)sizeof(float);
-        if (hipFuncSetAttribute((const void*)relpos_attention_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)relpos_attention_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)relpos_attention_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS) != hipSuccess)
-            return rs_fail(ctx, RS_EHIP, "attention: cannot reserve LDS");
-        attr_set = true;
+        int rc = rs_ensure_dynamic_lds(ctx, (const void*)relpos_attention_kernel<false, false>, MAX_LDS);
+        if (rc == RS_OK) rc = rs_ensure_dynamic_lds(ctx, (const void*)relpos_attention_kernel<false, true>, MAX_LDS);
+        if (rc == RS_OK) rc = rs_ensure_dynamic_lds(ctx, (const void*)relpos_attention_kernel<true, false>, MAX_LDS);
+        if (rc != RS_OK) return rc;
     }
     // algorithmic: ac + bd + pv = 3 * 2*T*T*128 per (b,h)
     const double flops = (double)B * dm.n_heads * 3.0 * 2.0 * T * (double)T * HD;

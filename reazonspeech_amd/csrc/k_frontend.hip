@@ -189,9 +189,12 @@ __global__ __launch_bounds__(1024) void feat_normalize_kernel(const float* __res
         }
     m2 = reduce_rows(m2);
     if (tid < Q) {
+        // n == 1: the unbiased variance is 0/0 (NaN in the reference stack too); emit zeros instead of
+        // poisoning the encoder and the argmax
         const float dn = (float)(n - 1);
-        rstd_s[tid] = make_float4(1.0f / (sqrtf(m2.x / dn) + eps), 1.0f / (sqrtf(m2.y / dn) + eps),
-                                  1.0f / (sqrtf(m2.z / dn) + eps), 1.0f / (sqrtf(m2.w / dn) + eps));
+        rstd_s[tid] = n > 1 ? make_float4(1.0f / (sqrtf(m2.x / dn) + eps), 1.0f / (sqrtf(m2.y / dn) + eps),
+                                          1.0f / (sqrtf(m2.z / dn) + eps), 1.0f / (sqrtf(m2.w / dn) + eps))
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     const float4 rstd = rstd_s[q];

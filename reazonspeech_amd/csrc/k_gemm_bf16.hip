@@ -26,6 +26,9 @@
 //     mask, 16-byte f32 / 8-16-byte bf16 stores, no LDS round trip.
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "rs_common.h"
 
 namespace {
@@ -652,10 +655,12 @@ __global__ __launch_bounds__(512, 2) void gemm_mf16_kernel(GemmParams p) {
     }
 }
 
-extern int g_skew;
-extern int g_persistent;
-extern int g_group_m;
-extern long long* g_trace;
+// Process-wide A/B knobs (debug / tuning only; the defaults are the measured winners and nothing in the product
+// path writes them).  Atomics initialised once from the environment, so concurrent first launches from the encoder
+// thread and the decode worker are safe; they are deliberately not per-context: they select code paths, not state.
+extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big;
+extern std::atomic<long long*> g_trace;
+void gemm_knobs_from_env();
 
 template <int BM, int BN, int BK, int NST, int WM, int WN, bool PERSIST, bool RES, bool PP = false>
 int launch_variant2(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
@@ -668,35 +673,21 @@ int launch_variant2(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     // panels x 4 weight tiles per XCD round beats the plain n-fastest order by 15-19 % (ffn_up 392 ->
     // 318 us); inside the encoder, where A comes from HBM, the gain is 1.7 % (776 vs 784 TF/s).
     // Narrow, short-K problems like 16 panels; K = 4096 (2 MiB per A panel) likes 4.
-    p.group_m = g_group_m > 0 ? g_group_m : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8));
+    p.group_m = g_group_m.load() > 0 ? g_group_m.load() : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8));
     constexpr int CUS = 256;
     const bool persist = PERSIST && nwg > CUS;
     // quarter of one tile's main-loop time at ~1 PF/s in shader cycles (2.4 GHz)
     const double skew_frac = g_skew < 0 ? 0.0 : g_skew / 100.0;   // measured: any start skew loses (profiles/r01_gemm_persistent.txt)
     p.skew_cycles = persist ? (int)(skew_frac * (2.0 * BM * BN * (double)p.K / 1.0e15 * 256.0) * 2.4e9) : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, PERSIST, RES>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return rs_fail(ctx, RS_EHIP, "gemm: cannot reserve %d bytes of LDS", LDS);
-        attr_set = true;
-    }
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, PERSIST, RES>, LDS); rc != RS_OK) return rc;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES>, LDS); rc != RS_OK) return rc;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, true>, LDS); rc != RS_OK) return rc;
     if (p.trace)     // debug build of the same kernel that records per-tile timestamps
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, true>), dim3(nwg), dim3(64 * WM * WN), LDS, s, p);
     else if (persist)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, PERSIST, RES>), dim3(CUS), dim3(64 * WM * WN), LDS, s, p);
     else if (PP) {
-        static bool pp_attr = false;
-        if (!pp_attr) {
-            if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, false, PP>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-                return rs_fail(ctx, RS_EHIP, "gemm: cannot reserve %d bytes of LDS", LDS);
-            pp_attr = true;
-        }
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, false, PP>, LDS); rc != RS_OK) return rc;
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES, false, PP>), dim3(nwg), dim3(64 * WM * WN), LDS, s, p);
     } else
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NST, WM, WN, false, RES>), dim3(nwg), dim3(64 * WM * WN), LDS, s, p);
@@ -715,34 +706,36 @@ int launch_mf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const int nwg = p.tiles_m * p.tiles_n;
-    p.group_m = g_group_m > 0 ? g_group_m : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8));
+    p.group_m = g_group_m.load() > 0 ? g_group_m.load() : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8));
     p.skew_cycles = 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_mf16_kernel<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_mf16_kernel<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return rs_fail(ctx, RS_EHIP, "gemm: cannot reserve %d bytes of LDS", LDS);
-        attr_set = true;
-    }
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_mf16_kernel<BM, BN, false>, LDS); rc != RS_OK) return rc;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_mf16_kernel<BM, BN, true>, LDS); rc != RS_OK) return rc;
     if (p.flags & RS_GEMM_RESIDUAL) hipLaunchKernelGGL((gemm_mf16_kernel<BM, BN, true>), dim3(nwg), dim3(512), LDS, s, p);
     else hipLaunchKernelGGL((gemm_mf16_kernel<BM, BN, false>), dim3(nwg), dim3(512), LDS, s, p);
     return RS_OK;
 }
 
-long long* g_trace = nullptr;
-int g_variant = -1;
-int g_skew = -1;
-int g_persistent = -1;
-int g_group_m = 0;   // 0 = by shape
+std::atomic<long long*> g_trace{nullptr};
+std::atomic<int> g_variant{0}, g_skew{-1}, g_persistent{0}, g_group_m{0} /* 0 = by shape */, g_big{0};
+void gemm_knobs_from_env() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        auto env = [](const char* name, std::atomic<int>& v) { if (const char* e = getenv(name)) v = atoi(e); };
+        env("RS_GEMM_VARIANT", g_variant);        // force one kernel variant (microbenchmarks); 0 = by shape
+        env("RS_GEMM_GROUP_M", g_group_m);        // row panels per XCD tile group; 0 = by shape
+        env("RS_GEMM_PERSISTENT", g_persistent);  // persistent tile loop
+        env("RS_GEMM_BIG", g_big);                // big-tile kernel family (DESIGN.md A/B knob table)
+    });
+}
 
 }  // namespace
 
 // tuning hook for A/B runs (scripts/gemm_bench.py); not part of the public header
-extern "C" void rs_debug_set_gemm_variant(int v) { g_variant = v; }
+extern "C" void rs_debug_set_gemm_variant(int v) { gemm_knobs_from_env(); g_variant = v; }
 extern "C" void rs_debug_set_gemm_skew(int v) { g_skew = v; }
 extern "C" void rs_debug_set_gemm_trace(long long* buf) { g_trace = buf; }
-extern "C" void rs_debug_set_gemm_persistent(int v) { g_persistent = v; }
-extern "C" void rs_debug_set_gemm_group_m(int v) { g_group_m = v; }
+extern "C" void rs_debug_set_gemm_persistent(int v) { gemm_knobs_from_env(); g_persistent = v; }
+extern "C" void rs_debug_set_gemm_group_m(int v) { gemm_knobs_from_env(); g_group_m = v; }
 
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return rs_fail(ctx, RS_EINVAL, "gemm: empty shape %d %d %d", a.M, a.N, a.K);
@@ -762,21 +755,8 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K; p.flags = a.flags;
     p.alpha = a.alpha; p.mask_rows_per_step = a.mask_rows_per_step; p.mask_steps = a.mask_steps;
     p.tiles_m = p.tiles_n = 0;
-    p.trace = g_trace;
-    if (g_variant < 0) {
-        const char* e = getenv("RS_GEMM_VARIANT");   // tuning knob for A/B runs; default chosen by shape
-        g_variant = e ? atoi(e) : 0;
-    }
-    static bool group_env = false;
-    if (!group_env) {
-        const char* e = getenv("RS_GEMM_GROUP_M");   // A/B knob; 0 / unset = by shape
-        if (e) g_group_m = atoi(e);
-        group_env = true;
-    }
-    if (g_persistent < 0) {
-        const char* e = getenv("RS_GEMM_PERSISTENT");
-        g_persistent = e ? atoi(e) : 0;
-    }
+    p.trace = g_trace.load();
+    gemm_knobs_from_env();
     const double flops = 2.0 * a.M * (double)a.N * a.K;
     const double bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                          (double)a.M * a.N * ((a.flags & RS_GEMM_OUT_F32) ? 4 : 2) +
@@ -805,8 +785,7 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
             const long c192 = ((t192 + CUS - 1) / CUS) * 192, c256 = ((t256 + CUS - 1) / CUS) * 256;
             v = c192 * 100 < c256 * 88 ? 10 : 2;
         }
-        static int big = -1;      // A/B knob for whole-pipeline runs: remap the 256x256 choice
-        if (big < 0) { const char* e = getenv("RS_GEMM_BIG"); big = e ? atoi(e) : 0; }
+        const int big = g_big;    // A/B knob for whole-pipeline runs: remap the 256x256 choice
         // big == 0: the 16x16x32 kernels (whole path 71.7 -> 69.5 ms/step with them: profiles/r01w_*);
         // 1 = the 32x32x16 kernels they replaced; 20 = 32x32x16 ping-pong; 31 = 16x16x32 with 256-row tiles only
         if (big == 0) { if (v == 2) v = 30; else if (v == 10) v = 32; }

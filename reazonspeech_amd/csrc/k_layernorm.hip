@@ -318,13 +318,7 @@ int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, const float* w, const f
         constexpr int R = 6, TTF = 8 * R;
         const dim3 grid((T + TTF - 1) / TTF, d / CT, B), block(256);
         const size_t lds = (size_t)(TTF + 9 - 1) * CT * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)glu_dwconv_silu_fast_kernel<9, R>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return rs_fail(ctx, RS_EHIP, "glu_dwconv: cannot reserve %zu bytes of LDS", lds);
-            attr_set = true;
-        }
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)glu_dwconv_silu_fast_kernel<9, R>, (int)lds); rc != RS_OK) return rc;
         hipLaunchKernelGGL((glu_dwconv_silu_fast_kernel<9, R>), grid, block, lds, s, x, w, b, lens, T, d, out);
     } else {
         const dim3 grid((T + TT - 1) / TT, d / CT, B), block(256);

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void rnnt_finalize_kernel(DecodeState st, cons
     if (lane != 0) return;
     int t = st.tcur[b], sy = st.sym[b];
     bool emitted = false;
-    if (idx == blank) {
+    if (idx == blank || idx == 0x7fffffff) {   // sentinel: every logit was NaN (cannot outrank -inf) -> treat as blank
         t += 1; sy = 0;
     } else {
         const int n = n_ids[b];
@@ -443,13 +443,9 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     const int rtiles = (B + 31) / 32;
     constexpr int LSTM_LDS = SPLITK_LSTM * 4 * 32 * 16 * 4 + 32 * 4;
     constexpr int TILE_LDS = SPLITK_TILE * 32 * 65 * 4 + 32 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RS_HIP(ctx, hipFuncSetAttribute((const void*)rnnt_lstm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LSTM_LDS));
-        RS_HIP(ctx, hipFuncSetAttribute((const void*)rnnt_tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS));
-        RS_HIP(ctx, hipFuncSetAttribute((const void*)rnnt_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS));
-        attr_set = true;
-    }
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_lstm_kernel, LSTM_LDS); rc != RS_OK) return rc;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<0>, TILE_LDS); rc != RS_OK) return rc;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<1>, TILE_LDS); rc != RS_OK) return rc;
     auto lstm_and_pred = [&]() {
         for (int l = 0; l < L; ++l)
             hipLaunchKernelGGL(rnnt_lstm_kernel, dim3(H / 16, rtiles), dim3(1024), LSTM_LDS, s, st, l, B, H, ctx->embed,

@@ -3,6 +3,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "rs_common.h"
 
 size_t rs_rnnt_workspace_bytes(const rs_ctx* ctx, int B);
@@ -18,6 +22,18 @@ int rs_fail(rs_ctx* ctx, int code, const char* fmt, ...) {
     va_end(ap);
     if (ctx) ctx->err = buf;
     return code;
+}
+
+int rs_ensure_dynamic_lds(rs_ctx* ctx, const void* func, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(ctx->device, func);
+    if (done.count(key)) return RS_OK;
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return rs_fail(ctx, RS_EHIP, "cannot reserve %d bytes of dynamic LDS on device %d", bytes, ctx->device);
+    done.insert(key);
+    return RS_OK;
 }
 
 // ---- profiling ---------------------------------------------------------------------------------
@@ -186,6 +202,17 @@ int rs_finalize(rs_ctx* ctx) {
     return RS_OK;
 }
 
+int rs_encoder_set_taps(rs_ctx* ctx, float* sub_out, float* layer_out, const int32_t* layer_ids, int n_layer_ids) {
+    if (!ctx) return RS_EINVAL;
+    if (n_layer_ids < 0 || (n_layer_ids > 0 && (!layer_out || !layer_ids))) return rs_fail(ctx, RS_EINVAL, "taps: null pointer");
+    for (int i = 0; i < n_layer_ids; ++i)
+        if (layer_ids[i] < 0 || layer_ids[i] >= ctx->d.n_layers) return rs_fail(ctx, RS_EINVAL, "taps: layer %d out of range", layer_ids[i]);
+    ctx->tap_sub = sub_out;
+    ctx->tap_layers = n_layer_ids > 0 ? layer_out : nullptr;
+    ctx->tap_ids.assign(layer_ids, layer_ids + n_layer_ids);
+    return RS_OK;
+}
+
 int rs_mel_frames(const rs_ctx* ctx, int n_samples) { return n_samples / ctx->d.hop_length; }
 
 int rs_enc_frames(const rs_ctx* ctx, int n) {
@@ -301,6 +328,7 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
     }
     const int32_t* lens = lens_stage + (S - 1) * B;
     RS_HIP(ctx, hipMemcpyAsync(enc_lens, lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    if (ctx->tap_sub) RS_HIP(ctx, hipMemcpyAsync(ctx->tap_sub, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
 
     // ---- position table slice for this T ---------------------------------------------------------
     const auto& pt = ctx->tensors.at("pos.table");
@@ -351,6 +379,9 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
             const rs_layer_w& Ln = ctx->layers[i + 1];
             RS_TRY(rs_launch_layernorm2(ctx, x, L.ln_out_g, L.ln_out_b, Ln.ln_ff1_g, Ln.ln_ff1_b, M, dm, d.ln_eps, x, hn, s));
         }
+        for (size_t k = 0; k < ctx->tap_ids.size(); ++k)     // parity taps: x now holds this layer's output
+            if (ctx->tap_ids[k] == i)
+                RS_HIP(ctx, hipMemcpyAsync(ctx->tap_layers + k * (size_t)M * dm, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
     }
     if (enc_out) RS_HIP(ctx, hipMemcpyAsync(enc_out, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
     RS_TRY(gemm(hn, dm, ctx->jenc_w, dm, joint_enc, d.joint_hidden, M, d.joint_hidden, RS_GEMM_BIAS | RS_GEMM_OUT_F32,

@@ -90,10 +90,19 @@ struct rs_ctx {
     const float *embed = nullptr, *lstm_w[8] = {}, *lstm_b[8] = {}, *jpred_w = nullptr, *jpred_b = nullptr,
                 *jout_w = nullptr, *jout_b = nullptr;
     // position table cache: the caller registers "pos_table.<T>" tensors (bf16 [2T-1][d])
+    // parity taps (rs_encoder_set_taps): copies of the residual stream taken inside rs_encoder_forward
+    float* tap_sub = nullptr;
+    float* tap_layers = nullptr;
+    std::vector<int> tap_ids;
     // profiling
     int prof_mask = 0;
     rs_prof_slot prof[8];
 };
+
+// Opt-in for more than 64 KiB of dynamic LDS, once per (device, kernel): the attribute is per device and the
+// first launch of a kernel can come from any thread (the decode worker and the encoder thread both start
+// kernels), so the bookkeeping is a mutex-guarded set keyed by the context's device — not a function-local flag.
+int rs_ensure_dynamic_lds(rs_ctx* ctx, const void* func, int bytes);
 
 int rs_fail(rs_ctx* ctx, int code, const char* fmt, ...);
 

@@ -125,6 +125,12 @@ TINY = ModelConfig(d_model=256, n_heads=2, ff_dim=512, n_layers=2, sub_channels=
                    vocab_size=63, pred_hidden=128, joint_hidden=128)
 
 
+# the 619M geometry (d = 1024, 8 heads, C = 256, FFN 4096, V + 1 = 3001, 640-wide LSTM / joint) with two
+# layers: every kernel instantiation and tile path of the benchmark configuration at a size the CPU oracle
+# and the HF golden generator finish in seconds (tests/golden/parakeet_wide.npz)
+WIDE2 = ModelConfig(n_layers=2)
+
+
 def from_nemo_yaml(cfg: dict) -> ModelConfig:
     """Map a NeMo `model_config.yaml` (already parsed to a dict) onto ModelConfig.
     [UPSTREAM] key names follow NeMo >= 2.6 `EncDecRNNTBPEModel` configs."""

@@ -1,0 +1,225 @@
+"""-m gpu: parity at the BENCHMARK geometry (d = 1024, 8 heads, C = 256, FFN 4096, V + 1 = 3001, 640-wide LSTM and
+joint) — the kernel paths the 2-layer toy configuration never reaches:
+
+  decode   rs_rnnt_greedy vs oracle/rnnt_greedy.c, token ids AND emission frames BIT-EXACT: K slices of five
+           16-blocks (the register-prefetch loops), 47 column tiles with the cross-tile argmax merge, the
+           ragged last tile (3001 = 46 * 64 + 57, blank id 3000 lives in it), a forced exact tie between two
+           column tiles (lowest index must win), a batch that is not a multiple of the 32-row tile
+  encoder  619M (24 layers) vs the bf16-recipe oracle with per-stage taps (subsampling output = rows S1-S5 at
+           C = 256; layers 0 / 11 / 23 = LayerNorm<4>, the fused norm pair, 8-head attention, the big-tile GEMMs)
+           and the WIDE2 (2-layer) HF golden, three seeds
+
+Stated tolerances (LayerNorm-ed O(1) activations, bf16 GEMM operands / stored activations, f32 accumulation):
+  subsampling output (x sqrt(d) scaled, |x| ~ 30)   max |err| <= 0.5,  mean <= 0.03
+  layer outputs, 24-layer encoder output            max |err| <= TOL_MAX, mean <= TOL_MEAN (below)
+  joint encoder projection                          same class
+The measured values of every run are written to gpurun_out/parity_fullsize.json.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from reazonspeech_amd.runtime.config import FASTCONFORMER_619M, WIDE2
+from reazonspeech_amd.runtime.model import AsrModel
+from reazonspeech_amd.runtime.synth import synthetic_batch
+from reazonspeech_amd.runtime.tokenizer import SyntheticTokenizer
+from reazonspeech_amd.runtime.weights import synthetic_state_dict
+from oracle import model as om, greedy as og
+from test_oracle_pinned import WIDE_GOLD, wide_case
+
+pytestmark = pytest.mark.gpu
+
+# 24 layers of bf16-operand GEMMs against the oracle that rounds at the same points: the two sides differ
+# by f32 accumulation order and fast exp / rcp, which the next bf16 rounding amplifies to one bf16 ulp
+# (2^-8 relative) per flipped rounding; LayerNorm after every layer keeps the error from compounding.
+TOL_MAX, TOL_MEAN = 0.25, 0.02
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_fullsize.json")
+
+
+def report(key, value):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    data = {}
+    if os.path.exists(REPORT):
+        try:
+            data = json.load(open(REPORT))
+        except Exception:
+            data = {}
+    data[key] = value
+    json.dump(data, open(REPORT, "w"), indent=1, sort_keys=True)
+
+
+def run_greedy(model, f, lens, u_max=None):
+    B, Tp, _ = f.shape
+    u_max = u_max or Tp * model.cfg.max_symbols
+    dev = model.device
+    ids = torch.zeros((B, u_max), dtype=torch.int32, device=dev)
+    frames = torch.zeros_like(ids)
+    n_ids = torch.zeros((B,), dtype=torch.int32, device=dev)
+    ws = torch.empty((model.ctx.workspace_bytes(B, 16000),), dtype=torch.uint8, device=dev)
+    model.ctx.rnnt_greedy(f.to(dev), lens.to(dev), B, Tp, u_max, ids, frames, n_ids, ws,
+                          torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    n = n_ids.cpu().numpy()
+    return [(ids[b, :n[b]].cpu().tolist(), frames[b, :n[b]].cpu().tolist()) for b in range(B)]
+
+
+@pytest.fixture(scope="module")
+def wide(gpu_device):
+    """the 619M decoder / joint (same tensor names and seeds -> the same weights as the 24-layer model) behind a
+    2-layer encoder, so the fixture builds in seconds"""
+    sd = synthetic_state_dict(WIDE2, 0, blank_bias=7.5)
+    return AsrModel(WIDE2, sd, SyntheticTokenizer(WIDE2.vocab_size), device="cuda:0"), sd
+
+
+def test_decode_bit_exact_at_619m_geometry(wide):
+    model, sd = wide
+    cfg = model.cfg
+    assert (cfg.pred_hidden, cfg.joint_hidden, cfg.n_logits) == (640, 640, 3001)
+    g = torch.Generator().manual_seed(2)
+    B, Tp = 37, 45
+    f = torch.randn((B, Tp, cfg.joint_hidden), generator=g) * (0.8 + 0.4 * torch.rand((B, 1, 1), generator=g))
+    lens = torch.randint(1, Tp + 1, (B,), generator=g, dtype=torch.int32)
+    lens[3] = 0
+    lens[5] = Tp
+    got = run_greedy(model, f, lens)
+    ref = og.rnnt_greedy(cfg, sd, f.numpy(), lens.numpy())
+    n_tok = sum(len(r[0]) for r in ref)
+    report("decode_619m", {"tokens": n_tok, "distinct": len({t for r in ref for t in r[0]}),
+                           "max_per_utt": max(len(r[0]) for r in ref)})
+    assert n_tok > 300 and len({t for r in ref for t in r[0]}) > 40, "fixture should emit a varied token stream"
+    for b in range(B):
+        assert got[b][0] == ref[b][0], f"ids differ for utterance {b}"
+        assert got[b][1] == ref[b][1], f"frames differ for utterance {b}"
+
+
+def test_decode_tie_across_column_tiles_picks_lowest_index(gpu_device):
+    """two identical joint rows in DIFFERENT 64-column tiles (ids 100 and 2900: tiles 1 and 45) produce bit-identical
+    logits; whenever they are the maximum the merge across tiles must return the lower id, as torch.argmax and the
+    oracle do.  A third copy inside the ragged last tile (id 2999) ties as well."""
+    cfg = WIDE2
+    sd = synthetic_state_dict(cfg, 0, blank_bias=7.5)
+    W, b = sd["joint.joint_net.2.weight"], sd["joint.joint_net.2.bias"]
+    for dup in (2900, 2999):
+        W[dup] = W[100]
+        b[dup] = b[100]
+    b[[100, 2900, 2999]] += 3.5                                     # make the tied triple win often
+    model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device="cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, Tp = 9, 30
+    f = torch.randn((B, Tp, cfg.joint_hidden), generator=g)
+    lens = torch.randint(8, Tp + 1, (B,), generator=g, dtype=torch.int32)
+    got = run_greedy(model, f, lens)
+    ref = og.rnnt_greedy(cfg, sd, f.numpy(), lens.numpy())
+    toks = [t for r in ref for t in r[0]]
+    assert toks.count(100) >= 5, "the tie must actually decide emissions in this fixture"
+    assert 2900 not in toks and 2999 not in toks
+    assert got == ref
+
+
+def test_decode_overflow_and_small_umax(wide):
+    """u_max smaller than the emission count -> RS_EOVERFLOW, like the oracle's -5"""
+    from reazonspeech_amd.runtime import capi
+    model, sd = wide
+    g = torch.Generator().manual_seed(9)
+    f = torch.randn((2, 20, model.cfg.joint_hidden), generator=g) * 1.5     # emits max_symbols on most frames
+    lens = torch.tensor([20, 20], dtype=torch.int32)
+    with pytest.raises(capi.RsError) as e:
+        run_greedy(model, f, lens, u_max=8)
+    assert e.value.code == capi.RS_EOVERFLOW
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_wide_geometry_vs_hf_golden(gpu_device, seed):
+    """d = 1024 / 8 heads / C = 256 / V + 1 = 3001 through the whole HIP path against the HF outputs of
+    tests/golden/parakeet_wide.npz: encoder output within 0.15 of the fp32 HF encoder, decode bit-exact against
+    the C oracle on the HIP joint projection; agreement with the HF token ids is recorded."""
+    gold = np.load(WIDE_GOLD)
+    cfg, sd, audio, lens = wide_case(gold, seed)
+    model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device="cuda:0", pad_seconds=0.0)
+    buf = model.stage([audio[b, :int(lens[b])] for b in range(2)])
+    enc = torch.zeros((2, buf.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
+    model.run_device(buf, want_enc=enc)
+    torch.cuda.synchronize()
+    k = f"s{seed}_"
+    assert buf.n_frames.cpu().tolist() == gold[k + "hf_n_frames"].tolist()
+    el = buf.enc_lens.cpu().tolist()
+    assert el == gold[k + "hf_enc_lens"].tolist()
+    worst = 0.0
+    for b in range(2):
+        d = (enc.cpu()[b, :el[b]] - torch.from_numpy(gold[k + "hf_enc"])[b, :el[b]]).abs()
+        dj = (buf.joint_enc.cpu()[b, :el[b]] - torch.from_numpy(gold[k + "hf_joint_enc"])[b, :el[b]]).abs()
+        worst = max(worst, d.max().item(), dj.max().item())
+        assert d.max() <= 0.15 and dj.max() <= 0.15, (b, d.max().item(), dj.max().item())
+    got = model.collect(buf)
+    ref = og.rnnt_greedy(cfg, sd, buf.joint_enc.cpu().numpy(), buf.enc_lens.cpu().numpy())
+    assert got.ids == [r[0] for r in ref] and got.frames == [r[1] for r in ref]
+    hf_ids = [gold[k + "hf_ids"][b, :gold[k + "hf_n_ids"][b]].tolist() for b in range(2)]
+    report(f"wide_hf_seed{seed}", {"enc_max_err_vs_hf_fp32": worst, "ids_equal_hf": got.ids == hf_ids,
+                                   "n_ids": [len(x) for x in got.ids], "n_ids_hf": [len(x) for x in hf_ids]})
+
+
+@pytest.fixture(scope="module")
+def full(gpu_device):
+    sd = synthetic_state_dict(FASTCONFORMER_619M, 0)
+    return AsrModel(FASTCONFORMER_619M, sd, SyntheticTokenizer(FASTCONFORMER_619M.vocab_size), device="cuda:0"), sd
+
+
+def test_encoder_619m_vs_bf16_oracle_with_taps(full):
+    """the 24-layer model on 3 ragged utterances (1.2 - 3 s + 0.5 s pad each side) against the bf16-recipe oracle:
+    subsampling output, layers 0 / 11 / 23, encoder output, joint projection; then decode bit-exact on the HIP joint
+    projection and the id agreement with the oracle's own end-to-end greedy"""
+    model, sd = full
+    cfg = model.cfg
+    audio, lens = synthetic_batch(3, 3.0, seed=123, ragged=True, min_seconds=1.2)
+    waves = [audio[b, :lens[b]] for b in range(3)]
+    buf = model.stage(waves)
+    M = buf.B * buf.tp_max
+    dev = model.device
+    tap_ids = (0, 11, 23)
+    sub = torch.zeros((M, cfg.d_model), dtype=torch.float32, device=dev)
+    lay = torch.zeros((len(tap_ids), M, cfg.d_model), dtype=torch.float32, device=dev)
+    enc = torch.zeros((buf.B, buf.tp_max, cfg.d_model), dtype=torch.float32, device=dev)
+    model.ctx.set_taps(sub, lay, tap_ids)
+    try:
+        model.run_device(buf, want_enc=enc)
+        torch.cuda.synchronize()
+    finally:
+        model.ctx.set_taps()
+    padded = np.zeros((3, audio.shape[1] + 16000), np.float32)
+    for b in range(3):
+        padded[b, 8000:8000 + lens[b]] = waves[b]
+    taps = {}
+    f_ref, el = om.forward_to_joint(cfg, sd, torch.from_numpy(padded), torch.from_numpy(lens + 16000), "bf16", taps)
+    assert buf.enc_lens.cpu().tolist() == el.tolist()
+    Tp = buf.tp_max
+    sub = sub.cpu().view(3, Tp, -1)
+    lay = lay.cpu().view(len(tap_ids), 3, Tp, -1)
+    enc = enc.cpu()
+    stats = {}
+
+    def cmp(name, got, want, tol_max, tol_mean):
+        mx, sm, cnt = 0.0, 0.0, 0
+        for b in range(3):
+            n = int(el[b])
+            d = (got[b, :n] - want[b, :n]).abs()
+            mx, sm, cnt = max(mx, d.max().item()), sm + d.sum().item(), cnt + d.numel()
+        stats[name] = {"max": mx, "mean": sm / cnt}
+        return mx <= tol_max and sm / cnt <= tol_mean
+
+    ok = cmp("sub_out", sub, taps["sub_out"], 0.5, 0.03)
+    for k, i in enumerate(tap_ids):
+        ok &= cmp(f"layer{i}", lay[k], taps[f"layer{i}"], TOL_MAX, TOL_MEAN)
+    ok &= cmp("enc", enc, taps["enc"], TOL_MAX, TOL_MEAN)
+    ok &= cmp("joint_enc", buf.joint_enc.cpu(), f_ref, TOL_MAX, TOL_MEAN)
+    assert torch.equal(lay[len(tap_ids) - 1], enc), "the last layer's tap is the encoder output"
+    got = model.collect(buf)
+    ref_same = og.rnnt_greedy(cfg, sd, buf.joint_enc.cpu().numpy(), buf.enc_lens.cpu().numpy())
+    ref_e2e = og.rnnt_greedy(cfg, sd, f_ref.numpy(), el.numpy())
+    stats["ids_equal_oracle_e2e"] = [got.ids[b] == ref_e2e[b][0] for b in range(3)]
+    stats["n_ids"] = [len(x) for x in got.ids]
+    report("encoder_619m", stats)
+    assert ok, stats
+    assert got.ids == [r[0] for r in ref_same] and got.frames == [r[1] for r in ref_same]

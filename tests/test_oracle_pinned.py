@@ -106,3 +106,43 @@ def test_attention_window_predicate():
     assert a[3, 1] and a[3, 4] and not a[3, 5] and not a[4, 1]      # |i-j| window
     assert a[5, 0] and a[0, 5]                                        # global token 0
     assert not allowed[1][:, 4:].any() and not allowed[1][4:, :].any()  # padding
+
+
+# ---- the 619M geometry (d = 1024, 8 heads, C = 256, V + 1 = 3001, 640-wide LSTM / joint) with two layers ----
+WIDE_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parakeet_wide.npz")
+
+
+def wide_case(gold, seed):
+    """inputs of one seed of tests/golden/parakeet_wide.npz, regenerated and checksum-verified"""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_parakeet_golden import wide_audio
+    from reazonspeech_amd.runtime.config import WIDE2
+    audio, lens = wide_audio(seed)
+    want = bytes(gold[f"s{seed}_audio_sha256"].tolist())
+    assert hashlib.sha256(audio.tobytes()).digest() == want, "fixture inputs drifted from the generator"
+    bias = float(gold["blank_bias"][list(gold["seeds"]).index(seed)])
+    return WIDE2, synthetic_state_dict(WIDE2, seed, blank_bias=bias), audio, lens
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_wide_geometry_vs_hf(seed):
+    """oracle (fp32) == transformers.models.parakeet at the benchmark model's widths, three seeds:
+    encoder output and joint projection within 2e-4, greedy ids and emission frames identical"""
+    gold = np.load(WIDE_GOLD)
+    cfg, sd, audio, lens = wide_case(gold, seed)
+    taps = {}
+    f, el = om.forward_to_joint(cfg, sd, torch.from_numpy(audio), torch.from_numpy(lens), "fp32", taps)
+    k = f"s{seed}_"
+    assert taps["n_frames"].tolist() == gold[k + "hf_n_frames"].tolist()
+    assert el.tolist() == gold[k + "hf_enc_lens"].tolist()
+    for b in range(2):
+        n = int(el[b])
+        assert (taps["enc"][b, :n] - torch.from_numpy(gold[k + "hf_enc"])[b, :n]).abs().max() <= 2e-4
+        assert (f[b, :n] - torch.from_numpy(gold[k + "hf_joint_enc"])[b, :n]).abs().max() <= 2e-4
+    out = og.rnnt_greedy(cfg, sd, f.numpy(), el.numpy())
+    for b in range(2):
+        n = int(gold[k + "hf_n_ids"][b])
+        assert out[b][0] == gold[k + "hf_ids"][b, :n].tolist()
+        assert out[b][1] == gold[k + "hf_frames"][b, :n].tolist()
