@@ -7,10 +7,14 @@
 
 One "step" = one pass of the whole hot path (log-mel front-end -> 24-layer FastConformer encoder
 -> joint projection -> batched greedy RNN-T decode) over one batch of 256 synthetic 10 s
-utterances per GPU, inputs already resident in HBM when the timed region starts.  Weak scaling:
-every rank processes its own 256 utterances (BASELINE.json configs[2]: 2048 = 8 x 256); with
-N > 1 each step ends with the one collective of the path, an RCCL all_gather of the hypotheses.
-Rank 0 prints ONE JSON line.
+utterances per GPU, inputs already resident in HBM when the timed region starts (the bench contract's
+definition of `value`; the host-to-host rate — pinned float32 in, token ids out, H2D and D2H inside the
+timed region, SURVEY.md §8d — is reported next to it as `value_pcie_inclusive`).  Weak scaling: every rank
+processes its own 256 utterances (BASELINE.json configs[2]: 2048 = 8 x 256); with N > 1 every step ends
+with the one collective of the path, an RCCL all_gather of that step's hypotheses, issued from the decode
+worker as soon as the batch is decoded.  Rank 0 prints ONE JSON line, which also carries `roofline`
+(dominant kernel class, HIP events on the launch stream), `cpu_baseline` (the CPU oracle on a bounded
+sample) and `parity` (the HIP path against that CPU leg's outputs on the same utterances).
 """
 import argparse
 import json
@@ -59,23 +63,72 @@ def cpu_baseline(cfg, sd, audio, lens, seconds_budget=20.0, max_utt=8):
     try:
         from oracle import model as om, greedy as og
     except Exception as e:                      # oracle is optional infrastructure for this leg
-        return {"value": None, "unit": "x real-time", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+        return {"value": None, "unit": "x real-time", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}, []
     threads = torch.get_num_threads()
     done, audio_s = 0, 0.0
+    outputs = []                                 # (joint_enc f32 [T', J], enc f32 [T', d], ids, frames) per utterance
     t0 = time.perf_counter()
     for b in range(min(max_utt, audio.shape[0])):
         n = int(lens[b])
         wav = np.pad(audio[b, :n], 8000)
-        f, el = om.forward_to_joint(cfg, sd, torch.from_numpy(wav)[None], torch.tensor([len(wav)]), "fp32")
-        og.rnnt_greedy(cfg, sd, f.numpy(), el.numpy())
+        taps = {}
+        f, el = om.forward_to_joint(cfg, sd, torch.from_numpy(wav)[None], torch.tensor([len(wav)]), "fp32", taps)
+        hyp = og.rnnt_greedy(cfg, sd, f.numpy(), el.numpy())[0]
+        outputs.append((f[0, :int(el[0])], taps["enc"][0, :int(el[0])], hyp[0], hyp[1]))
         done += 1
         audio_s += n / 16000.0
         if time.perf_counter() - t0 > seconds_budget:
             break
     dt = time.perf_counter() - t0
     return {"value": round(audio_s / dt, 3), "unit": "x real-time", "cores": threads, "kind": "port",
-            "sample": f"{done} utterance(s) x 10 s, one per call (batch_size=1), fp32 torch CPU oracle + C greedy, "
-                      f"{dt:.1f} s wall"}
+            "sample": f"{done} utterance(s) x {audio_s / max(done, 1):g} s, one per call (batch_size=1), fp32 torch CPU "
+                      f"oracle + C greedy, {dt:.1f} s wall"}, outputs
+
+
+def edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+def parity_vs_cpu_leg(model, cfg, sd, audio, lens, outputs):
+    """The CPU leg's outputs are the checker of the same utterances through the HIP path (one batch, padding folded
+    into the kernel): encoder output and joint projection error against the fp32 oracle, greedy ids against the
+    oracle's end-to-end ids (bf16 encoder noise can flip near-ties, so this is an agreement rate), and the decode
+    kernels alone — C greedy on the HIP joint projection — which must agree bit for bit."""
+    from oracle import greedy as og
+    k = len(outputs)
+    if k == 0:
+        return None
+    buf = model.stage([audio[b, :int(lens[b])] for b in range(k)])
+    enc = torch.zeros((k, buf.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
+    model.run_device(buf, want_enc=enc)
+    torch.cuda.synchronize()
+    got = model.collect(buf)
+    enc, f = enc.cpu(), buf.joint_enc.cpu()
+    e_max = e_sum = j_max = j_sum = cnt_e = cnt_j = 0.0
+    exact = dist = ref_tokens = 0
+    for b, (f_ref, enc_ref, ids_ref, frames_ref) in enumerate(outputs):
+        n = f_ref.shape[0]
+        assert got.enc_lens[b] == n, (got.enc_lens[b], n)
+        de, dj = (enc[b, :n] - enc_ref).abs(), (f[b, :n] - f_ref).abs()
+        e_max, j_max = max(e_max, de.max().item()), max(j_max, dj.max().item())
+        e_sum, j_sum, cnt_e, cnt_j = e_sum + de.sum().item(), j_sum + dj.sum().item(), cnt_e + de.numel(), cnt_j + dj.numel()
+        exact += int(got.ids[b] == ids_ref)
+        dist += edit_distance(got.ids[b], ids_ref)
+        ref_tokens += len(ids_ref)
+    same = og.rnnt_greedy(cfg, sd, f.numpy(), buf.enc_lens.cpu().numpy())
+    bit_exact = all(got.ids[b] == same[b][0] and got.frames[b] == same[b][1] for b in range(k))
+    return {"utterances": k, "checker": "fp32 CPU oracle (cpu_baseline leg), same audio",
+            "encoder_max_err": round(e_max, 4), "encoder_mean_err": round(e_sum / cnt_e, 5),
+            "joint_enc_max_err": round(j_max, 4), "joint_enc_mean_err": round(j_sum / cnt_j, 5),
+            "greedy_ids_exact_match": f"{exact}/{k}",
+            "token_agreement": round(1.0 - dist / max(ref_tokens, 1), 4), "reference_tokens": ref_tokens,
+            "decode_bit_exact_given_same_joint_enc": bool(bit_exact)}
 
 
 def main():
@@ -122,19 +175,22 @@ def main():
     setup_s = time.time() - t0
     pipelined = not args.no_pipeline
 
-    def gather(bf):
+    step_done = []                  # host time at which each step's hypotheses were complete (and gathered)
+
+    def after_decode(bf):
+        # called on the decode worker right after batch i is decoded: this step's one collective
         if world > 1:
             rdist.gather_hypotheses(bf.ids, bf.frames, bf.n_ids)
+            torch.cuda.current_stream().synchronize()
+        step_done.append(time.perf_counter())
 
     def run_steps(n):
         if pipelined:
-            model.run_pipelined(bufs, n, after_decode=None, enc_streams=args.enc_streams)
-            for i in range(n):                      # one collective per step, as the path defines it
-                gather(bufs[i % n_sets])
+            model.run_pipelined(bufs, n, after_decode=after_decode, enc_streams=args.enc_streams)
         else:
             for i in range(n):
                 model.run_device(bufs[i % n_sets])
-                gather(bufs[i % n_sets])
+                after_decode(bufs[i % n_sets])
 
     run_steps(args.warmup)
     prof = not args.no_profile
@@ -143,6 +199,7 @@ def main():
         model.ctx.profile_enable(capi.PROF_GEMM)
     rdist.barrier()
     torch.cuda.synchronize()
+    step_done.clear()
     t0 = time.perf_counter()
     run_steps(args.steps)
     torch.cuda.synchronize()
@@ -151,6 +208,10 @@ def main():
     gemm = model.ctx.profile_read(capi.PROF_GEMM) if prof else None
     model.ctx.profile_enable(0)
     dt = rdist.max_over_ranks(dt)
+    # per-step completion intervals (steady state of the pipeline): median next to the mean
+    marks = [t0] + list(step_done)
+    intervals = sorted(b - a for a, b in zip(marks[1:-1], marks[2:])) if len(marks) > 3 else []
+    median_ms = intervals[len(intervals) // 2] * 1e3 if intervals else None
 
     # PCIe-inclusive rate (never `value`): same steps, but every batch is copied from pinned host
     # memory first and its hypotheses are copied back after decode
@@ -170,9 +231,10 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "RTFx (audio-sec/wall-sec), FastConformer-RNNT 619M batch=256",
+            "metric": f"RTFx (audio-sec/wall-sec), FastConformer-RNNT 619M batch={args.batch}",
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step_median": round(median_ms, 3) if median_ms else None, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"FastConformer-RNNT {cfg.n_params() / 1e6:.0f}M, {args.batch} x "
                                    f"{args.seconds:g} s utterances per GPU (+0.5 s pad each side), greedy decode, "
@@ -186,7 +248,9 @@ def main():
             "setup_s": round(setup_s, 1),
         }
         if dt_host:
+            # SURVEY.md §8d's wall clock: pinned host float32 -> H2D -> path -> D2H of the hypotheses
             out["value_pcie_inclusive"] = round(audio_seconds / dt_host, 1)
+            out["ms_per_step_pcie_inclusive"] = round(dt_host / args.steps * 1e3, 3)
         gf = algorithmic_gflop_per_utt(cfg, buf.tp_max, mean_tokens)
         out["algorithmic_tflops_whole_path"] = round(gf * args.batch * world * args.steps / dt / 1e3, 1)
         if gemm and gemm["launches"]:
@@ -205,10 +269,13 @@ def main():
                                "algorithmic_bytes_per_launch": round(gemm["bytes"] / gemm["launches"]),
                                "launches": gemm["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
                                "share_of_step": round(gemm["ms"] / (dt * 1e3), 3)}
-        if world == 1 and not args.no_cpu_baseline and not args.tiny:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, audio0, lens0)
-        elif world == 1 and args.tiny and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, audio0, lens0, seconds_budget=5.0, max_utt=2)
+        if world == 1 and not args.no_cpu_baseline:
+            budget, k = (5.0, 2) if args.tiny else (20.0, 8)
+            out["cpu_baseline"], cpu_outputs = cpu_baseline(cfg, sd, audio0, lens0, seconds_budget=budget, max_utt=k)
+            try:
+                out["parity"] = parity_vs_cpu_leg(model, cfg, sd, audio0, lens0, cpu_outputs)
+            except Exception as e:               # the bench line must still be printed
+                out["parity"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     rdist.shutdown()
 

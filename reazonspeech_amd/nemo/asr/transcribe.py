@@ -7,6 +7,7 @@ folded into the front-end kernel instead of `np.pad`; decoding is batched greedy
 the ALSD-shaped `Hypothesis` the reference post-processor expects (interface.Hypothesis).
 """
 import os
+import sys
 
 import torch
 
@@ -63,11 +64,16 @@ def _prepare(audio):
     return np.ascontiguousarray(norm_audio(audio).waveform, dtype=np.float32)
 
 
-def transcribe_batch(model, audios, config=None):
+def transcribe_batch(model, audios, config=None, distributed=False):
     """Transcribe a list of AudioData in one batched pass.
 
     Each utterance is processed exactly as `transcribe()` would process it alone
     (per-utterance padding, masking and normalisation inside the kernels).
+
+    With `distributed=True` and `torch.distributed` initialised (one process per GPU; the reference's
+    multi-GPU mechanism, pkg/evaluation/src/base.py:194-212) every rank passes the same list, decodes a
+    length-balanced shard on its own GPU and gets every result back, in the caller's order, through the
+    path's one collective (an RCCL all_gather of the hypotheses).
 
     Returns:
       list[TranscribeResult]
@@ -75,7 +81,11 @@ def transcribe_batch(model, audios, config=None):
     if config is None:
         config = TranscribeConfig()
     waves = [_prepare(a) for a in audios]
-    decoded = model.transcribe_waveforms(waves)
+    if config.verbose:
+        # the reference forwards `verbose` to NeMo (transcribe.py:52), which draws a tqdm bar on stderr
+        print(f"[reazonspeech_amd] transcribing {len(waves)} utterance(s), "
+              f"{sum(len(w) for w in waves) / 16000.0:.1f} s of audio on {model.device}", file=sys.stderr, flush=True)
+    decoded = model.transcribe_waveforms_sharded(waves) if distributed else model.transcribe_waveforms(waves)
     results = []
     for ids, frames in zip(decoded.ids, decoded.frames):
         hyp = Hypothesis.from_greedy(ids, frames, model.cfg.blank_id)

@@ -80,3 +80,61 @@ def gather_hypotheses(ids: torch.Tensor, frames: torch.Tensor, n_ids: torch.Tens
     g_frames = out[:, B * U:2 * B * U].reshape(W * B, U)
     g_n = out[:, 2 * B * U:].reshape(W * B)
     return g_ids, g_frames, g_n
+
+
+def _collective_device() -> torch.device:
+    """RCCL moves device tensors, gloo host tensors"""
+    if is_on() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def sharded_decode(lengths: Sequence[int], run_local, counters=None):
+    """The multi-GPU entry point of the path (BASELINE.json configs[2]: 2048 utterances over 8 GPUs; reference
+    mechanism: one process per GPU, pkg/evaluation/src/base.py:194-212, examples/rs-nemo/eval.py:24-28).
+
+    Every rank calls this with the SAME `lengths` (samples per utterance, caller order).  The utterances are dealt
+    to ranks by `shard_by_length`, rank r decodes its shard with `run_local(indices) -> (ids, frames, enc_lens)`
+    (lists in shard order), and ONE all_gather of the padded hypotheses (ids | frames | counts | encoder lengths
+    fused into one int32 payload per rank) returns every utterance's result to every rank, restored to caller order.
+    There is no other collective besides a MAX all_reduce that agrees on the payload width.
+
+    -> (ids, frames, enc_lens): lists of length len(lengths) in caller order."""
+    n = len(lengths)
+    W, r = world_size(), rank()
+    shards = shard_by_length(lengths, W)
+    ids, frames, enc_lens = run_local(list(shards[r]))
+    assert len(ids) == len(frames) == len(enc_lens) == len(shards[r]), "run_local must answer for every index it was given"
+    if W == 1:
+        out = ([None] * n, [None] * n, [None] * n)
+        for k, i in enumerate(shards[0]):
+            out[0][i], out[1][i], out[2][i] = list(ids[k]), list(frames[k]), int(enc_lens[k])
+        return out
+    dev = _collective_device()
+    u_local = max((len(x) for x in ids), default=0)
+    um = torch.tensor([u_local], dtype=torch.int32, device=dev)
+    dist.all_reduce(um, op=dist.ReduceOp.MAX)
+    U = int(um.item())
+    bmax = max(len(s) for s in shards)
+    pay = torch.zeros((bmax, 2 + 2 * U), dtype=torch.int32)
+    for k in range(len(ids)):
+        u = len(ids[k])
+        pay[k, 0], pay[k, 1] = u, int(enc_lens[k])
+        if u:
+            pay[k, 2:2 + u] = torch.as_tensor(ids[k], dtype=torch.int32)
+            pay[k, 2 + U:2 + U + u] = torch.as_tensor(frames[k], dtype=torch.int32)
+    pay = pay.to(dev).contiguous()
+    got = torch.empty((W,) + tuple(pay.shape), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(got.view(-1), pay.view(-1))
+    if counters is not None:
+        counters["collectives"] = counters.get("collectives", 0) + 1
+        counters["bytes"] = counters.get("bytes", 0) + got.numel() * 4
+    got = got.cpu()
+    out = ([None] * n, [None] * n, [None] * n)
+    for rr in range(W):
+        for k, i in enumerate(shards[rr]):
+            u = int(got[rr, k, 0])
+            out[0][i] = got[rr, k, 2:2 + u].tolist()
+            out[1][i] = got[rr, k, 2 + U:2 + U + u].tolist()
+            out[2][i] = int(got[rr, k, 1])
+    return out

@@ -282,6 +282,20 @@ class AsrModel:
         return DecodedBatch([ids[b, :n[b]].tolist() for b in range(buf.B)],
                             [frames[b, :n[b]].tolist() for b in range(buf.B)], el.tolist())
 
+    def transcribe_waveforms_sharded(self, waveforms: Sequence[np.ndarray], max_batch: int = 256) -> DecodedBatch:
+        """SPMD form of `transcribe_waveforms` for one process per GPU (`torch.distributed` initialised, RCCL):
+        every rank passes the same list, decodes its length-balanced shard on its own GPU and receives all
+        hypotheses in the caller's order after the path's one collective (runtime/dist.py: sharded_decode).
+        With a single process it is `transcribe_waveforms`."""
+        from . import dist as rdist
+
+        def run_local(indices):
+            res = self.transcribe_waveforms([waveforms[i] for i in indices], max_batch=max_batch)
+            return res.ids, res.frames, res.enc_lens
+
+        ids, frames, enc_lens = rdist.sharded_decode([len(w) for w in waveforms], run_local)
+        return DecodedBatch(ids, frames, enc_lens)
+
     def transcribe_waveforms(self, waveforms: Sequence[np.ndarray], max_batch: int = 256) -> DecodedBatch:
         """host float32 waveforms -> token ids / frames (the batched boundary).
 

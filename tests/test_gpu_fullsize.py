@@ -10,7 +10,7 @@ joint) — the kernel paths the 2-layer toy configuration never reaches (VERDICT
            and the WIDE2 (2-layer) HF golden, three seeds
 
 Stated tolerances (LayerNorm-ed O(1) activations, bf16 GEMM operands / stored activations, f32 accumulation):
-  subsampling output (x sqrt(d) scaled, |x| ~ 30)   max |err| <= 0.5,  mean <= 0.03
+  subsampling output (x sqrt(d) scaled, |x| ~ 30)   max |err| <= 0.2,  mean <= 0.015   (measured 0.061 / 0.0042)
   layer outputs, 24-layer encoder output            max |err| <= TOL_MAX, mean <= TOL_MEAN (below)
   joint encoder projection                          same class
 The measured values of every run are written to gpurun_out/parity_fullsize.json.
@@ -35,7 +35,7 @@ pytestmark = pytest.mark.gpu
 # 24 layers of bf16-operand GEMMs against the oracle that rounds at the same points: the two sides differ
 # by f32 accumulation order and fast exp / rcp, which the next bf16 rounding amplifies to one bf16 ulp
 # (2^-8 relative) per flipped rounding; LayerNorm after every layer keeps the error from compounding.
-TOL_MAX, TOL_MEAN = 0.25, 0.02
+TOL_MAX, TOL_MEAN = 0.06, 0.008      # measured on MI355X: max 0.020, mean 0.0029 (profiles/r02a_parity_fullsize.json)
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_fullsize.json")
 
 
@@ -134,7 +134,7 @@ def test_decode_overflow_and_small_umax(wide):
 @pytest.mark.parametrize("seed", [7, 8, 9])
 def test_wide_geometry_vs_hf_golden(gpu_device, seed):
     """d = 1024 / 8 heads / C = 256 / V + 1 = 3001 through the whole HIP path against the HF outputs of
-    tests/golden/parakeet_wide.npz: encoder output within 0.15 of the fp32 HF encoder, decode bit-exact against
+    tests/golden/parakeet_wide.npz: encoder output within 0.08 of the fp32 HF encoder (measured 0.019 - 0.024), decode bit-exact against
     the C oracle on the HIP joint projection; agreement with the HF token ids is recorded."""
     gold = np.load(WIDE_GOLD)
     cfg, sd, audio, lens = wide_case(gold, seed)
@@ -152,7 +152,7 @@ def test_wide_geometry_vs_hf_golden(gpu_device, seed):
         d = (enc.cpu()[b, :el[b]] - torch.from_numpy(gold[k + "hf_enc"])[b, :el[b]]).abs()
         dj = (buf.joint_enc.cpu()[b, :el[b]] - torch.from_numpy(gold[k + "hf_joint_enc"])[b, :el[b]]).abs()
         worst = max(worst, d.max().item(), dj.max().item())
-        assert d.max() <= 0.15 and dj.max() <= 0.15, (b, d.max().item(), dj.max().item())
+        assert d.max() <= 0.08 and dj.max() <= 0.08, (b, d.max().item(), dj.max().item())
     got = model.collect(buf)
     ref = og.rnnt_greedy(cfg, sd, buf.joint_enc.cpu().numpy(), buf.enc_lens.cpu().numpy())
     assert got.ids == [r[0] for r in ref] and got.frames == [r[1] for r in ref]
@@ -209,7 +209,7 @@ def test_encoder_619m_vs_bf16_oracle_with_taps(full):
         stats[name] = {"max": mx, "mean": sm / cnt}
         return mx <= tol_max and sm / cnt <= tol_mean
 
-    ok = cmp("sub_out", sub, taps["sub_out"], 0.5, 0.03)
+    ok = cmp("sub_out", sub, taps["sub_out"], 0.2, 0.015)
     for k, i in enumerate(tap_ids):
         ok &= cmp(f"layer{i}", lay[k], taps[f"layer{i}"], TOL_MAX, TOL_MEAN)
     ok &= cmp("enc", enc, taps["enc"], TOL_MAX, TOL_MEAN)

@@ -182,3 +182,49 @@ def test_gather_hypotheses_gloo_world2(tmp_path):
         assert g_ids[:, 0].tolist() == [0, 0, 0, 100, 100, 100]
         assert torch.equal(g_frames, g_ids + 1000)
         assert g_n.tolist() == [1, 0, 5, 2, 0, 5]
+
+
+def _fake_decode(lengths):
+    """a stand-in for the GPU path: the 'hypothesis' of an utterance is a function of its length only"""
+    def run_local(indices):
+        ids = [[(lengths[i] * 7 + k) % 3000 for k in range(lengths[i] % 11)] for i in indices]
+        frames = [[k // 2 for k in range(len(x))] for x in ids]
+        return ids, frames, [lengths[i] // 1280 for i in indices]
+    return run_local
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    rdist.init("gloo")
+    lengths = [16000 * 3 + 977 * i for i in (5, 0, 9, 3, 3, 12, 1)]        # 7 utterances: shards of 4 and 3
+    calls = []
+
+    def run_local(indices):
+        calls.append(list(indices))
+        return _fake_decode(lengths)(indices)
+
+    counters = {}
+    out = rdist.sharded_decode(lengths, run_local, counters)
+    empty = rdist.sharded_decode([], lambda idx: ([], [], []))
+    torch.save((out, calls, counters, empty), os.path.join(out_dir, f"s{rank}.pt"))
+    rdist.shutdown()
+
+
+def test_sharded_decode_gloo_world2(tmp_path):
+    """config #3's mechanism on 2 CPU ranks: shard by length -> decode locally -> ONE gather -> caller order,
+    identical on every rank and identical to the single-process answer (ragged shards, an utterance with
+    no tokens, uneven shard sizes)"""
+    world, port = 2, _free_port()
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    lengths = [16000 * 3 + 977 * i for i in (5, 0, 9, 3, 3, 12, 1)]
+    want = rdist.sharded_decode(lengths, _fake_decode(lengths))              # world = 1 path
+    assert [len(x) for x in want[0]].count(0) >= 0 and all(x is not None for x in want[0])
+    seen = []
+    for r in range(world):
+        out, calls, counters, empty = torch.load(os.path.join(str(tmp_path), f"s{r}.pt"))
+        assert out == want
+        assert len(calls) == 1 and counters["collectives"] == 1
+        assert empty == ([], [], [])
+        seen.append(calls[0])
+    assert sorted(seen[0] + seen[1]) == list(range(7)) and len(seen[0]) == 4 and len(seen[1]) == 3
+    assert max(lengths[i] for i in seen[0]) <= min(lengths[i] for i in seen[1])   # contiguous in sorted order
