@@ -132,6 +132,13 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
                        float* enc_out, float* joint_enc, int32_t* enc_lens,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Scheduling options of a context (no reference counterpart).
+ *   "gemm_reserved_cus"  compute units the persistent GEMM grid leaves free for work on OTHER streams (the
+ *                        two-stage pipeline runs batch i's greedy decode next to batch i+1's encoder; a GEMM
+ *                        workgroup owns every register of its CU for the whole launch).  -1 = process default
+ *                        ($RS_GEMM_RESERVE_CUS, 0). */
+int rs_set_option(rs_ctx* ctx, const char* key, int value);
+
 /* Parity taps (tests only; no reference counterpart — NeMo exposes intermediate activations through
  * forward hooks): when set, the next rs_encoder_forward calls also copy the f32 residual stream
  * [B*tp_max][d_model] after the subsampling block (sub_out) and after each listed

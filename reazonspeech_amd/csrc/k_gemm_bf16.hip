@@ -655,10 +655,318 @@ __global__ __launch_bounds__(512, 2) void gemm_mf16_kernel(GemmParams p) {
     }
 }
 
+// =====================================================================================================
+// Persistent 16x16x32 kernel: the default for the big shapes.
+//
+// Why: with one 128 KiB-LDS workgroup per CU, a tile's epilogue (bias / activation / stores) and the next
+// tile's prologue (first HBM/L2 round trip) overlap with nothing, and all 256 CUs hit their store bursts at
+// the same moment (profiles/r01k_gemm_tile_timeline.txt: 6-11 us of a 41 us K = 1024 tile).  Here a grid of
+// (CUs - reserved) workgroups each walks a run of tiles and
+//   * the LDS ring never drains: the last three granules of a tile's main loop already DMA the first three
+//     granules of the NEXT tile, so the epilogue runs with those loads in flight and the next main loop starts
+//     on data that has landed;
+//   * the epilogue goes through a 4 KiB per-wave LDS scratch (the 32 KiB the ring leaves free) that turns the
+//     MFMA accumulator layout (16 rows x 8 bytes per instruction) into whole 128 / 256-byte row segments:
+//     half the store instructions, every one a full cache line;
+//   * stores are fire-and-forget: nothing waits for them except the counted waits of the next tile, which
+//     account for them (vmcnt retires in order and counts stores too);
+//   * `reserved` CUs are left to the decode stream of the two-stage pipeline (a workgroup of this kernel owns
+//     all registers of its CU for the whole launch, so decode kernels could not co-reside).
+// The DMAs are issued from inline asm (global_load_lds_dwordx4 with a scalar base and a 32-bit lane offset):
+// hipcc then counts only the epilogue's own loads / stores, which are all younger than the DMAs in flight, so
+// its counted waits stay correct and it never drains the ring (guide §5 "three .s-level traps" (b)).
+// Epilogue memory operations are raw buffer loads / stores with out-of-range offsets for masked rows: they
+// always issue, so the number of operations in flight is a compile-time constant the next tile's waits can use.
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {   // make wave-uniformity provable ("s" operands)
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate is the only form gfx950 has)
+__device__ __forceinline__ void wait_vmcnt_any(int n) {
+    n = n > 63 ? 63 : n;
+#define RS_W1(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define RS_W8(a, b, c, d, e, f, g, h) RS_W1(a) RS_W1(b) RS_W1(c) RS_W1(d) RS_W1(e) RS_W1(f) RS_W1(g) RS_W1(h)
+    switch (n) {
+        RS_W8(0, 1, 2, 3, 4, 5, 6, 7) RS_W8(8, 9, 10, 11, 12, 13, 14, 15) RS_W8(16, 17, 18, 19, 20, 21, 22, 23)
+        RS_W8(24, 25, 26, 27, 28, 29, 30, 31) RS_W8(32, 33, 34, 35, 36, 37, 38, 39) RS_W8(40, 41, 42, 43, 44, 45, 46, 47)
+        RS_W8(48, 49, 50, 51, 52, 53, 54, 55) RS_W8(56, 57, 58, 59, 60, 61, 62, 63)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef RS_W8
+#undef RS_W1
+}
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// OUT: 0 = bf16, 1 = f32, 2 = f32 with a residual read-modify-write; MASK: per-utterance row mask (subsampling GEMMs)
+template <int BM, int OUT, bool MASK>
+__global__ __launch_bounds__(512, 2) void gemm_pmf16_kernel(GemmParams p) {
+    constexpr bool RES = OUT == 2, out_f32 = OUT >= 1, rowmask = MASK;
+    constexpr int BN = 256, BK = 32, WN = 4, NWAVES = 8;
+    constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16, MH = MI / 2;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_INSTS = BM / 16, LB = BN / 16 / NWAVES;
+    constexpr int RING_BYTES = 4 * STAGE_BYTES, SCR_BYTES = 4096;
+    static_assert((A_INSTS == 16 || A_INSTS == 12) && (MI % 2) == 0 && LB == 2, "tile shapes: 256 x 256 or 192 x 256");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fch = lane >> 4;
+    const int LAw = (A_INSTS - wave + NWAVES - 1) / NWAVES;      // A-tile DMA instructions of this wave per granule
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    char* scr = smem + RING_BYTES + wave * SCR_BYTES;            // this wave's epilogue scratch
+
+    // ---- tile schedule: XCD x owns a contiguous run of the (grouped) tile order; its workgroups take
+    // the run's tiles round-robin
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int xbase = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    const int xcount = xcd < rr ? q + 1 : q;
+    const int nslots = ((int)gridDim.x - xcd + 7) >> 3;
+    if (slot >= xcount) return;
+    auto tile_origin = [&](int j, int& m0, int& n0) {
+        const int wg = xbase + j;
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = wg / per_group, r = wg - g * per_group;
+        const int left = p.tiles_m - g * p.group_m;
+        const int gm = left < p.group_m ? left : p.group_m;
+        const int tile_n = r / gm;
+        m0 = (g * p.group_m + (r - tile_n * gm)) * BM;
+        n0 = tile_n * BN;
+    };
+    // per-lane byte offsets of this wave's DMA pieces for a tile (row clamp folded in)
+    const int dr = lane >> 2, dpc = lane & 3;
+    auto lane_offsets = [&](int m0, int n0, unsigned (&oa)[2], unsigned (&ob)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ida = wave + NWAVES * j;                   // valid iff < A_INSTS (wave-uniform)
+            const int rowa = ida * 16 + dr;
+            int ga = m0 + rowa;
+            ga = ga < p.M ? ga : p.M - 1;
+            oa[j] = (unsigned)ga * (unsigned)(p.lda * 2) + (unsigned)((dpc ^ swz16(rowa)) * 16);
+            const int rowb = (wave * LB + j) * 16 + dr;
+            int gb = n0 + rowb;
+            gb = gb < p.N ? gb : p.N - 1;
+            ob[j] = (unsigned)gb * (unsigned)(p.ldw * 2) + (unsigned)((dpc ^ swz16(rowb)) * 16);
+        }
+    };
+    auto issue_a = [&](const unsigned (&oa)[2], int t, int ring_slot) {
+        const void* sb = uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)t * (BK * 2));
+        const unsigned dst = lds0 + ring_slot * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int id = wave + NWAVES * j;
+            if (id < A_INSTS) glds16(oa[j], sb, __builtin_amdgcn_readfirstlane(dst + id * 1024));
+        }
+    };
+    auto issue_b = [&](const unsigned (&ob)[2], int t, int ring_slot) {
+        const void* sb = uniform_ptr(reinterpret_cast<const char*>(p.W) + (size_t)t * (BK * 2));
+        const unsigned dst = lds0 + ring_slot * STAGE_BYTES + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(ob[j], sb, __builtin_amdgcn_readfirstlane(dst + (wave * LB + j) * 1024));
+    };
+
+    const int nk = p.K / BK;                                      // >= 4 (launcher)
+    const int flags = p.flags;
+    const bool has_bias = flags & RS_GEMM_BIAS, relu = flags & RS_GEMM_RELU, silu = flags & RS_GEMM_SILU;
+    const float alpha = p.alpha;
+    // VMEM operations a wave leaves in flight at the end of an epilogue (a lower bound is what the waits need)
+    constexpr int E_ops = out_f32 ? MI * 4 : (MI / 2) * 4;
+    const size_t out_bytes = (size_t)p.M * p.ldc * (out_f32 ? 4 : 2);
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.residual : (const float*)p.out), 0,
+                                                            (int)out_bytes, 0x00020000);
+    const auto bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_bias ? p.bias : (const float*)p.out), 0,
+                                                             has_bias ? p.N * 4 : 0, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;                         // beyond every buffer: loads return 0, stores are dropped
+
+    int m0, n0, mn, nn;
+    unsigned oa[2], ob[2], oan[2], obn[2];
+    tile_origin(slot, m0, n0);
+    lane_offsets(m0, n0, oa, ob);
+    int gc = 0;                                                   // granules consumed so far (ring position)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { issue_a(oa, t, t); issue_b(ob, t, t); }
+    wait_vmcnt_any(2 * (LAw + LB));
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind from here on
+
+    for (int j = slot, tile_no = 0; j < xcount; j += nslots, ++tile_no) {
+        const bool has_next = j + nslots < xcount;
+        if (has_next) { tile_origin(j + nslots, mn, nn); lane_offsets(mn, nn, oan, obn); }
+        f32x4_t acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.0f;
+
+        // ---- main loop: ping-pong wave groups over the granule ring (see gemm_mf16_kernel / gemm_bf16_kernel<PP>
+        // for the barrier, RAW and WAR argument; the ring position simply keeps counting across tiles)
+        for (int g = 0; g < nk; ++g) {
+            const char* at = smem + ((gc + g) & 3) * STAGE_BYTES;
+            const char* bt = at + A_BYTES;
+            const bool own = g + 3 < nk;                          // granule g+3 belongs to this tile
+            const bool more = own || has_next;
+            const int tn = own ? g + 3 : g + 3 - nk;
+            bf16x8_t bfr[NI];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t af[MH];
+                if (ks == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < NI; ++jj) bfr[jj] = read_frag16(bt, wn * TN + jj * 16 + frow, fch);
+                }
+#pragma unroll
+                for (int i = 0; i < MH; ++i) af[i] = read_frag16(at, wm * TM + (ks * MH + i) * 16 + frow, fch);
+                if (ks == 1 && (g + 1 < nk || has_next)) {
+                    // granule g+1 must have landed; issued after it: granule g+2, the A part of g+3, and — for
+                    // the first two granules of a later tile — the previous epilogue's stores
+                    int younger = 0;
+                    if (g + 2 < nk || has_next) younger += LAw + LB;
+                    if (more) younger += LAw;
+                    if (tile_no > 0 && g < 2) younger += E_ops;
+                    wait_vmcnt_any(younger);
+                }
+                if (more) {
+                    if (ks == 0) { if (own) issue_a(oa, tn, (gc + g + 3) & 3); else issue_a(oan, tn, (gc + g + 3) & 3); }
+                    else { if (own) issue_b(ob, tn, (gc + g + 3) & 3); else issue_b(obn, tn, (gc + g + 3) & 3); }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MH; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < NI; ++jj)
+                        acc[ks * MH + i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[ks * MH + i][jj], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        gc += nk;
+
+        // ---- epilogue (no workgroup barrier: the scratch is per wave, LDS operations of one wave execute in order)
+        int cm0 = __builtin_amdgcn_readfirstlane(m0), cn0 = __builtin_amdgcn_readfirstlane(n0);
+        asm volatile("" : "+s"(cm0), "+s"(cn0));                 // keep the addresses out of the main loop's live ranges
+        const int wrow0 = cm0 + wm * TM, wcol0 = cn0 + wn * TN;
+        float4 bias_r[NI];
+#pragma unroll
+        for (int jj = 0; jj < NI; ++jj) {
+            const int n = wcol0 + jj * 16 + 4 * fch;
+            const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(bias_rsrc, (unsigned)n * 4u, 0, 0);   // no bias / n >= N: zeros
+            bias_r[jj] = __builtin_bit_cast(float4, b);
+        }
+        auto finish = [&](int i, int jj) -> float4 {
+            float4 v = make_float4(acc[i][jj][0] + bias_r[jj].x, acc[i][jj][1] + bias_r[jj].y, acc[i][jj][2] + bias_r[jj].z,
+                                   acc[i][jj][3] + bias_r[jj].w);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+            return v;
+        };
+        auto row_keep = [&](int m) -> bool {
+            if (!rowmask || m >= p.M) return true;      // rowmask is a template constant
+            const int step = m / p.mask_rows_per_step;
+            const int b = step / p.mask_steps;
+            return step - b * p.mask_steps < p.mask_lens[b];
+        };
+        if constexpr (!out_f32) {
+            // bf16: chunks of 32 rows x 64 columns (4 KiB, 128-byte rows, 16-byte pieces XOR-swizzled by row)
+            const int rr8 = lane >> 3, cc = lane & 7;
+#pragma unroll
+            for (int c = 0; c < MI / 2; ++c) {
+#pragma unroll
+                for (int il = 0; il < 2; ++il)
+#pragma unroll
+                    for (int jj = 0; jj < NI; ++jj) {
+                        const float4 v = finish(2 * c + il, jj);
+                        const int row = il * 16 + frow;
+                        const int piece = (jj * 2 + (fch >> 1)) ^ (row & 7);
+                        *reinterpret_cast<u16x4_t*>(scr + row * 128 + piece * 16 + (fch & 1) * 8) = pack_bf16x4(v.x, v.y, v.z, v.w);
+                    }
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+                    const int row = sgm * 8 + rr8;
+                    u32x4_t d = *reinterpret_cast<const u32x4_t*>(scr + row * 128 + ((cc ^ (row & 7)) * 16));
+                    const int m = wrow0 + c * 32 + row, n = wcol0 + cc * 8;
+                    if (!row_keep(m)) d = (u32x4_t){0u, 0u, 0u, 0u};
+                    const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 2u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(d, out_rsrc, off, 0, 0);
+                }
+            }
+        } else {
+            // f32: chunks of 16 rows x 64 columns (4 KiB, 256-byte rows, 16-byte pieces XOR-swizzled by row);
+            // the residual of chunk i+1 is requested (row-major, whole 256-byte segments) before chunk i is stored
+            const int rr4 = lane >> 4, cc = lane & 15;
+            u32x4_t rv_next[4];
+            auto load_res = [&](int i, u32x4_t (&rv)[4]) {
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+                    const int m = wrow0 + i * 16 + sgm * 4 + rr4, n = wcol0 + cc * 4;
+                    const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : OOB;
+                    rv[sgm] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, off, 0, 0);
+                }
+            };
+            if constexpr (RES) load_res(0, rv_next);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                u32x4_t rv[4];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int sgm = 0; sgm < 4; ++sgm) rv[sgm] = rv_next[sgm];
+                    if (i + 1 < MI) load_res(i + 1, rv_next);
+                }
+#pragma unroll
+                for (int jj = 0; jj < NI; ++jj) {
+                    const float4 v = finish(i, jj);
+                    const int piece = (jj * 4 + fch) ^ frow;
+                    *reinterpret_cast<float4*>(scr + frow * 256 + piece * 16) = v;
+                }
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+                    const int row = sgm * 4 + rr4;
+                    float4 v = *reinterpret_cast<const float4*>(scr + row * 256 + ((cc ^ row) * 16));
+                    if constexpr (RES) {
+                        const float4 r = __builtin_bit_cast(float4, rv[sgm]);
+                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    }
+                    const int m = wrow0 + i * 16 + row, n = wcol0 + cc * 4;
+                    if (!row_keep(m)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), out_rsrc, off, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (has_next) {
+            m0 = mn; n0 = nn;
+#pragma unroll
+            for (int jx = 0; jx < 2; ++jx) { oa[jx] = oan[jx]; ob[jx] = obn[jx]; }
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier at the start
+}
+
 // Process-wide A/B knobs (debug / tuning only; the defaults are the measured winners and nothing in the product
 // path writes them).  Atomics initialised once from the environment, so concurrent first launches from the encoder
 // thread and the decode worker are safe; they are deliberately not per-context: they select code paths, not state.
-extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big;
+extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve;
 extern std::atomic<long long*> g_trace;
 void gemm_knobs_from_env();
 
@@ -715,15 +1023,43 @@ int launch_mf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     return RS_OK;
 }
 
+template <int BM>
+int launch_pmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
+    constexpr int BN = 256;
+    constexpr int LDS = 4 * (BM + BN) * 32 * 2 + 8 * 4096;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    p.group_m = g_group_m.load() > 0 ? g_group_m.load() : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8));
+    p.skew_cycles = 0;
+    const int grid = nwg < grid_cap ? nwg : grid_cap;
+    const int out = (p.flags & RS_GEMM_RESIDUAL) ? 2 : ((p.flags & RS_GEMM_OUT_F32) ? 1 : 0);
+    const bool mask = p.flags & RS_GEMM_ROWMASK;
+#define RS_PMF(O, MK)                                                                                         \
+    do {                                                                                                      \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_pmf16_kernel<BM, O, MK>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_pmf16_kernel<BM, O, MK>), dim3(grid), dim3(512), LDS, s, p);                 \
+    } while (0)
+    if (out == 2 && !mask) RS_PMF(2, false);
+    else if (out == 1 && !mask) RS_PMF(1, false);
+    else if (out == 0 && !mask) RS_PMF(0, false);
+    else if (out == 0 && mask) RS_PMF(0, true);
+    else return rs_fail(ctx, RS_EINVAL, "gemm: row mask with f32 output has no persistent kernel");
+#undef RS_PMF
+    return RS_OK;
+}
+
 std::atomic<long long*> g_trace{nullptr};
-std::atomic<int> g_variant{0}, g_skew{-1}, g_persistent{0}, g_group_m{0} /* 0 = by shape */, g_big{0};
+std::atomic<int> g_variant{0}, g_skew{-1}, g_persistent{1}, g_group_m{0} /* 0 = by shape */, g_big{0};
+std::atomic<int> g_reserve{0};   // CUs the persistent kernel leaves free when a context does not say (rs_set_option)
 void gemm_knobs_from_env() {
     static std::once_flag once;
     std::call_once(once, [] {
         auto env = [](const char* name, std::atomic<int>& v) { if (const char* e = getenv(name)) v = atoi(e); };
         env("RS_GEMM_VARIANT", g_variant);        // force one kernel variant (microbenchmarks); 0 = by shape
         env("RS_GEMM_GROUP_M", g_group_m);        // row panels per XCD tile group; 0 = by shape
-        env("RS_GEMM_PERSISTENT", g_persistent);  // persistent tile loop
+        env("RS_GEMM_PERSISTENT", g_persistent);  // 1 (default) = persistent 16x16x32 kernel for the big shapes, 0 = one tile per workgroup
+        env("RS_GEMM_RESERVE_CUS", g_reserve);    // CUs the persistent grid leaves to other streams (contexts may override)
         env("RS_GEMM_BIG", g_big);                // big-tile kernel family (DESIGN.md A/B knob table)
     });
 }
@@ -776,7 +1112,7 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         const long t256 = (long)((a.M + 255) / 256) * tn, t192 = (long)((a.M + 191) / 192) * tn;
         if (a.M < 1024 || a.N < 256) v = 1;
         else if (t256 < 2 * CUS) v = a.K <= 1024 ? 7 : 1;
-        else if (g_persistent) v = 9;
+        else if (g_persistent.load() == 9) v = 9;          // the 32x32x16 persistent experiment of round 1
         else {
             // the 192-row tile is a little less efficient per flop; inside the two-stream pipeline (decode
             // workgroups borrow CUs, so rounds are not exact) it only pays where the round count drops by
@@ -797,7 +1133,21 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         // two-stage pipeline; it is selected with rs_debug_set_gemm_persistent(1) / RS_GEMM_PERSISTENT=1
         // for single-stream use)
     }
+    if ((v == 30 || v == 32) && g_variant == 0 && g_persistent.load() == 1 && a.K >= 128 && (a.N % 8) == 0 &&
+        (size_t)a.M * a.ldc * ((a.flags & (RS_GEMM_OUT_F32 | RS_GEMM_RESIDUAL)) ? 4 : 2) < (1ull << 31) &&
+        (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32) &&
+        !((a.flags & RS_GEMM_ROWMASK) && (a.flags & (RS_GEMM_OUT_F32 | RS_GEMM_RESIDUAL))))
+        v += 10;                                  // 40 / 42: the persistent form of 30 / 32
+    if (ctx->n_cus <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
+        ctx->n_cus = n;
+    }
+    const int reserve = ctx->gemm_reserved_cus >= 0 ? ctx->gemm_reserved_cus : g_reserve.load();
+    const int grid_cap = ctx->n_cus - reserve > 8 ? ctx->n_cus - reserve : 8;
     switch (v) {
+        case 40: rc = launch_pmf16<256>(ctx, p, s, grid_cap); break;            // persistent 16x16x32, 256-row tiles
+        case 42: rc = launch_pmf16<192>(ctx, p, s, grid_cap); break;            // persistent, 3/4-height tiles
         case 1: rc = launch_variant<128, 128, 64, 2, 2, 2>(ctx, p, s); break;   // small problems
         case 2: rc = launch_variant<256, 256, 64, 2, 2, 4>(ctx, p, s); break;   // big tile, drain per K step
         case 3: rc = launch_variant<256, 256, 32, 4, 2, 4>(ctx, p, s); break;   // big tile, 4-stage ring, counted vmcnt

@@ -202,6 +202,16 @@ int rs_finalize(rs_ctx* ctx) {
     return RS_OK;
 }
 
+int rs_set_option(rs_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return RS_EINVAL;
+    if (!strcmp(key, "gemm_reserved_cus")) {
+        if (value < -1 || value > 248) return rs_fail(ctx, RS_EINVAL, "gemm_reserved_cus must be -1 .. 248");
+        ctx->gemm_reserved_cus = value;
+        return RS_OK;
+    }
+    return rs_fail(ctx, RS_EINVAL, "unknown option '%s'", key);
+}
+
 int rs_encoder_set_taps(rs_ctx* ctx, float* sub_out, float* layer_out, const int32_t* layer_ids, int n_layer_ids) {
     if (!ctx) return RS_EINVAL;
     if (n_layer_ids < 0 || (n_layer_ids > 0 && (!layer_out || !layer_ids))) return rs_fail(ctx, RS_EINVAL, "taps: null pointer");

@@ -90,6 +90,9 @@ struct rs_ctx {
     const float *embed = nullptr, *lstm_w[8] = {}, *lstm_b[8] = {}, *jpred_w = nullptr, *jpred_b = nullptr,
                 *jout_w = nullptr, *jout_b = nullptr;
     // position table cache: the caller registers "pos_table.<T>" tensors (bf16 [2T-1][d])
+    // options (rs_set_option)
+    int n_cus = 0;                  // compute units of the device (queried on first use)
+    int gemm_reserved_cus = -1;     // CUs the persistent GEMM grid leaves to other streams; -1 = process default
     // parity taps (rs_encoder_set_taps): copies of the residual stream taken inside rs_encoder_forward
     float* tap_sub = nullptr;
     float* tap_layers = nullptr;

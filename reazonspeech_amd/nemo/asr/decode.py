@@ -1,7 +1,7 @@
 """Hypothesis -> text / subword timestamps / segments.
 
 Restates pkg/nemo-asr/src/decode.py:4-66.  It is the one part of the hot path whose
-behaviour is fully pinned by in-tree reference code, so `tests/test_decode_host.py`
+behaviour is fully pinned by in-tree reference code, so `tests/test_host_reference_parity.py`
 checks it against golden vectors produced by importing the reference file itself
 (`tests/golden/make_reference_golden.py`).
 """

@@ -21,7 +21,7 @@ from .audio import norm_audio
 CHECKPOINT_ENV = "REAZONSPEECH_NEMO_CHECKPOINT"
 
 
-def load_model(device=None, checkpoint=None, config=None, seed=0):
+def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None):
     """Load the ReazonSpeech FastConformer-RNNT model onto a ROCm GPU.
 
     Args:
@@ -33,6 +33,8 @@ def load_model(device=None, checkpoint=None, config=None, seed=0):
         (benchmarks / tests; transcripts are then meaningless).
       config (ModelConfig): override the architecture for synthetic weights.
       seed (int): seed of the synthetic weights.
+      pos_cap (int): encoder frames (80 ms each) the resident relative-position tables cover at load time
+        (default 1024, about 82 s); longer utterances grow the tables on first use.
 
     Returns:
       reazonspeech_amd.runtime.model.AsrModel
@@ -55,7 +57,8 @@ def load_model(device=None, checkpoint=None, config=None, seed=0):
         cfg = config or FASTCONFORMER_619M
         sd = W.synthetic_state_dict(cfg, seed)
         tokenizer = SyntheticTokenizer(cfg.vocab_size, seed)
-    return AsrModel(cfg, sd, tokenizer, device=device, pad_seconds=PAD_SECONDS)
+    kw = {} if pos_cap is None else {"pos_cap": int(pos_cap)}
+    return AsrModel(cfg, sd, tokenizer, device=device, pad_seconds=PAD_SECONDS, **kw)
 
 
 def _prepare(audio):

@@ -24,7 +24,7 @@ EXPORTS = [
     "rs_abi_version", "rs_create", "rs_destroy", "rs_last_error", "rs_set_tensor", "rs_finalize",
     "rs_workspace_bytes", "rs_mel_frames", "rs_enc_frames", "rs_frontend_logmel", "rs_encoder_forward",
     "rs_rnnt_greedy", "rs_profile_enable", "rs_profile_read", "rs_profile_reset", "rs_gemm_bf16",
-    "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_encoder_set_taps",
+    "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_encoder_set_taps", "rs_set_option",
 ]
 
 
@@ -88,6 +88,7 @@ def load():
     lib.rs_enc_frames.argtypes = [vp, c_int]
     lib.rs_frontend_logmel.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_size_t, vp]
     lib.rs_encoder_forward.argtypes = [vp, vp, vp, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
+    lib.rs_set_option.argtypes = [vp, c_char_p, c_int]
     lib.rs_encoder_set_taps.argtypes = [vp, vp, vp, POINTER(c_int32), c_int]
     lib.rs_rnnt_greedy.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
     lib.rs_profile_enable.argtypes = [vp, c_int]
@@ -182,6 +183,9 @@ class Context:
         self.check(self.lib.rs_encoder_forward(self._h, _ptr(feats), _ptr(n_frames), B, t_max, _ptr(enc_out),
                                                _ptr(joint_enc), _ptr(enc_lens), _ptr(ws),
                                                ws.numel() * ws.element_size(), c_void_p(stream)))
+
+    def set_option(self, key, value):
+        self.check(self.lib.rs_set_option(self._h, key.encode(), int(value)))
 
     def set_taps(self, sub_out=None, layer_out=None, layer_ids=()):
         """parity taps of rs_encoder_forward (tests): f32 [B*tp_max][d] after subsampling, and

@@ -31,6 +31,7 @@ class ModelConfig:
     sub_channels: int = 256
     sub_factor: int = 8
     xscaling: bool = True
+    use_bias: bool = True   # encoder Linear / Conv1d biases ([UPSTREAM] ConformerEncoder(use_bias=...)); False -> zeros
     ln_eps: float = 1e-5
     bn_eps: float = 1e-5
     att_left: int = -1      # -1 = unlimited (full attention); SURVEY.md §8a row L5
@@ -131,29 +132,122 @@ TINY = ModelConfig(d_model=256, n_heads=2, ff_dim=512, n_layers=2, sub_channels=
 WIDE2 = ModelConfig(n_layers=2)
 
 
-def from_nemo_yaml(cfg: dict) -> ModelConfig:
+class UnsupportedCheckpoint(ValueError):
+    """the checkpoint asks for an architecture variant the HIP kernels do not implement"""
+
+
+def resolve_interpolations(cfg: dict) -> dict:
+    """Resolve OmegaConf-style `${a.b.c}` references (NeMo configs use them freely:
+    `feat_in: ${model.preprocessor.features}`, `pred_hidden: ${model.model_defaults.pred_hidden}`) against the
+    document itself, with or without the leading `model.`; `???` (OmegaConf's "missing") becomes None."""
+    import re
+    pat = re.compile(r"^\$\{([^}]+)\}$")
+
+    def lookup(path):
+        for keys in (path.split("."), path.split(".")[1:] if path.startswith("model.") else None):
+            if keys is None:
+                continue
+            node = cfg
+            try:
+                for k in keys:
+                    node = node[int(k)] if isinstance(node, list) else node[k]
+                return node
+            except (KeyError, IndexError, TypeError, ValueError):
+                continue
+        raise UnsupportedCheckpoint(f"model_config.yaml: cannot resolve ${{{path}}}")
+
+    def walk(node, depth=0):
+        if depth > 32:
+            raise UnsupportedCheckpoint("model_config.yaml: interpolation cycle")
+        if isinstance(node, dict):
+            return {k: walk(v, depth) for k, v in node.items()}
+        if isinstance(node, list):
+            return [walk(v, depth) for v in node]
+        if isinstance(node, str):
+            if node == "???":
+                return None
+            m = pat.match(node.strip())
+            if m:
+                return walk(lookup(m.group(1)), depth + 1)
+        return node
+
+    return walk(cfg)
+
+
+def from_nemo_yaml(cfg: dict, strict: bool = True) -> ModelConfig:
     """Map a NeMo `model_config.yaml` (already parsed to a dict) onto ModelConfig.
-    [UPSTREAM] key names follow NeMo >= 2.6 `EncDecRNNTBPEModel` configs."""
-    pre = cfg.get("preprocessor", {})
-    enc = cfg.get("encoder", {})
-    dec = cfg.get("decoder", {})
-    joint = cfg.get("joint", {})
-    sr = int(pre.get("sample_rate", 16000))
-    prednet = dec.get("prednet", {})
-    jn = joint.get("jointnet", {})
+    [UPSTREAM] key names follow NeMo >= 2.6 `EncDecRNNTBPEModel` configs
+    (examples/asr/conf/fastconformer/fast-conformer_transducer_bpe.yaml).
+
+    With `strict` (the default) every setting that would make the kernels compute something else than the
+    checkpoint's architecture raises `UnsupportedCheckpoint` instead of loading silently: other
+    subsampling types, LayerNorm in the conv module, Longformer global attention with separate projections,
+    a non-per-feature front-end normalisation, frame splicing, a non-ReLU joint, and so on.  A decoding
+    strategy other than greedy only warns: the path decodes greedily by design."""
+    import warnings
+    if "model" in cfg and isinstance(cfg["model"], dict) and "encoder" in cfg["model"]:
+        cfg = {**cfg["model"], "model": cfg["model"]}        # training-style file: the model subtree is the config
+    cfg = resolve_interpolations(cfg)
+    pre = cfg.get("preprocessor", {}) or {}
+    enc = cfg.get("encoder", {}) or {}
+    dec = cfg.get("decoder", {}) or {}
+    joint = cfg.get("joint", {}) or {}
+    sr = int(pre.get("sample_rate", cfg.get("sample_rate", 16000)) or 16000)
+    prednet = dec.get("prednet", {}) or {}
+    jn = joint.get("jointnet", {}) or {}
     ctx = enc.get("att_context_size", [-1, -1]) or [-1, -1]
     if ctx and isinstance(ctx[0], (list, tuple)):
         ctx = ctx[0]
-    local = str(enc.get("self_attention_model", "rel_pos")) == "rel_pos_local_attn"
-    greedy = (cfg.get("decoding", {}) or {}).get("greedy", {}) or {}
-    vocab = int(dec.get("vocab_size", joint.get("num_classes", 3000)))
+    att_model = str(enc.get("self_attention_model", "rel_pos"))
+    local = att_model == "rel_pos_local_attn"
+    decoding = cfg.get("decoding", {}) or {}
+    greedy = decoding.get("greedy", {}) or {}
+    vocab = dec.get("vocab_size", None)
+    if vocab is None:
+        vocab = joint.get("num_classes", None)
+    if vocab is None and isinstance(joint.get("vocabulary"), (list, tuple)):
+        vocab = len(joint["vocabulary"])
+    if vocab is None:
+        vocab = 3000
+    if strict:
+        def need(cond, what):
+            if not cond:
+                raise UnsupportedCheckpoint(f"model_config.yaml: {what} is not implemented by the gfx950 kernels")
+        need(str(enc.get("subsampling", "dw_striding")) == "dw_striding", f"encoder.subsampling={enc.get('subsampling')!r}")
+        need(not enc.get("causal_downsampling", False), "encoder.causal_downsampling")
+        need(att_model in ("rel_pos", "rel_pos_local_attn"), f"encoder.self_attention_model={att_model!r}")
+        need(str(enc.get("conv_norm_type", "batch_norm")) == "batch_norm", f"encoder.conv_norm_type={enc.get('conv_norm_type')!r}")
+        need(enc.get("conv_context_size") in (None, "null") or list(enc.get("conv_context_size")) == [
+            (int(enc.get("conv_kernel_size", 9)) - 1) // 2] * 2, "a causal / asymmetric encoder.conv_context_size")
+        need(str(enc.get("att_context_style", "regular")) == "regular", f"encoder.att_context_style={enc.get('att_context_style')!r}")
+        need(int(enc.get("reduction_factor", 1) or 1) == 1 and enc.get("reduction") in (None, "null"), "encoder.reduction")
+        need(not (local and enc.get("global_attn_separate", False)), "encoder.global_attn_separate (separate global q/k/v)")
+        need(int(enc.get("feat_in", pre.get("features", 80)) or 80) == int(pre.get("features", 80)), "encoder.feat_in != preprocessor.features")
+        need(str(pre.get("normalize", "per_feature")) == "per_feature", f"preprocessor.normalize={pre.get('normalize')!r}")
+        need(str(pre.get("window", "hann")) == "hann", f"preprocessor.window={pre.get('window')!r}")
+        need(int(pre.get("frame_splicing", 1) or 1) == 1, "preprocessor.frame_splicing")
+        need(bool(pre.get("log", True)), "preprocessor.log=false")
+        need(str(pre.get("log_zero_guard_type", "add")) == "add", "preprocessor.log_zero_guard_type")
+        need(float(pre.get("mag_power", 2.0) or 2.0) == 2.0, "preprocessor.mag_power != 2")
+        need(str(jn.get("activation", "relu")).lower() == "relu", f"joint.jointnet.activation={jn.get('activation')!r}")
+        need(dec.get("blank_as_pad", True) in (True, None), "decoder.blank_as_pad=false")
+        need(str(prednet.get("rnn_type", "lstm") or "lstm").lower() == "lstm" if "rnn_type" in prednet else True, "a non-LSTM prediction network")
+    strategy = str(decoding.get("strategy", "greedy_batch"))
+    if strategy not in ("greedy", "greedy_batch"):
+        warnings.warn(f"checkpoint decoding.strategy={strategy!r}: this path always decodes greedily (batched greedy RNN-T); "
+                      "transcripts can differ from the reference's beam search", RuntimeWarning, stacklevel=2)
+    guard = pre.get("log_zero_guard_value", 2.0 ** -24)
+    if isinstance(guard, str):            # NeMo also accepts the names of torch.finfo fields
+        import torch
+        guard = {"tiny": torch.finfo(torch.float32).tiny, "eps": torch.finfo(torch.float32).eps}.get(guard, 2.0 ** -24)
     return ModelConfig(
         sample_rate=sr,
-        n_fft=int(pre.get("n_fft", 512)),
+        n_fft=int(pre.get("n_fft", 512) or 512),
         win_length=int(round(float(pre.get("window_size", 0.025)) * sr)),
         hop_length=int(round(float(pre.get("window_stride", 0.01)) * sr)),
         n_mels=int(pre.get("features", 80)),
         preemph=float(pre.get("preemph", 0.97) or 0.0),
+        log_guard=float(guard),
         d_model=int(enc.get("d_model", 1024)),
         n_heads=int(enc.get("n_heads", 8)),
         ff_dim=int(enc.get("d_model", 1024)) * int(enc.get("ff_expansion_factor", 4)),
@@ -162,12 +256,13 @@ def from_nemo_yaml(cfg: dict) -> ModelConfig:
         sub_channels=int(enc.get("subsampling_conv_channels", 256)),
         sub_factor=int(enc.get("subsampling_factor", 8)),
         xscaling=bool(enc.get("xscaling", True)),
+        use_bias=bool(enc.get("use_bias", True)),
         att_left=int(ctx[0]) if local else -1,
         att_right=int(ctx[1]) if local else -1,
-        n_global=int(enc.get("global_tokens", 0)) if local else 0,
-        vocab_size=vocab,
+        n_global=int(enc.get("global_tokens", 0) or 0) if local else 0,
+        vocab_size=int(vocab),
         pred_hidden=int(prednet.get("pred_hidden", 640)),
         pred_layers=int(prednet.get("pred_rnn_layers", 2)),
         joint_hidden=int(jn.get("joint_hidden", 640)),
-        max_symbols=int(greedy.get("max_symbols", 10) or 10),
+        max_symbols=int(greedy.get("max_symbols", greedy.get("max_symbols_per_step", 10)) or 10),
     ).validate()

@@ -37,6 +37,7 @@ class _Buffers:
         self.l_pad = l_max + model.pad_left + model.pad_right
         self.t_max = max(ctx.mel_frames(self.l_pad), 1)
         self.tp_max = max(ctx.enc_frames(self.t_max), 1)
+        model.ensure_pos_cap(self.tp_max)
         self.u_max = self.tp_max * cfg.max_symbols
         i32, f32 = torch.int32, torch.float32
         self.audio = torch.zeros((B, l_max), dtype=f32, device=dev)
@@ -73,14 +74,15 @@ class AsrModel:
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", index)
         self.pad_left = self.pad_right = int(pad_seconds * cfg.sample_rate)   # audio.py:80-82 via decode.py:4
-        with torch.cuda.device(self.device):
-            self.ctx = capi.Context(cfg, index)
-            self._upload(prepare_weights(cfg, state_dict, pos_cap))
         self._bufs = {}
         self._ctx_dec = None
         self._ctx_enc2 = None
         self._enc2_stream = None
         self._streams = None
+        self.pos_cap = 0
+        with torch.cuda.device(self.device):
+            self.ctx = capi.Context(cfg, index)
+            self._upload(prepare_weights(cfg, state_dict, pos_cap))
 
     # ------------------------------------------------------------------------------------------
     def _upload(self, tensors):
@@ -88,24 +90,61 @@ class AsrModel:
         for name, t in tensors.items():
             dev[name] = t.to(self.device, non_blocking=False).contiguous()
             self.ctx.set_tensor(name, dev[name])
-        # derived weights: the relative-position table projected by every layer's linear_pos, computed
-        # once with the library's own GEMM (same kernel and row arithmetic as the per-call projection
-        # it replaces, so results are bit-identical) — 24 x [2*cap-1][d] bf16 = 100 MB at cap 1024
-        table = dev["pos.table"]
+        self._pos_w = [dev[f"L{i}.att.pos.w"] for i in range(self.cfg.n_layers)]
+        self._set_pos_tables(dev["pos.table"])
+
+    def _contexts(self):
+        return [c for c in (self.ctx, self._ctx_dec, self._ctx_enc2) if c is not None]
+
+    def _set_pos_tables(self, table):
+        """register the relative-position table (bf16 [2*cap-1][d]) and the derived per-layer tensors: the table
+        projected by every layer's linear_pos, computed once with the library's own GEMM (same kernel and row
+        arithmetic as the per-call projection it replaces, so results are bit-identical) — 24 x [2*cap-1][d] bf16
+        = 100 MB at cap 1024"""
+        projs = []
         for i in range(self.cfg.n_layers):
             proj = torch.empty_like(table)
-            self.ctx.gemm(table, dev[f"L{i}.att.pos.w"], proj, flags=0)
-            self.ctx.set_tensor(f"L{i}.att.pos_proj", proj)
+            self.ctx.gemm(table, self._pos_w[i], proj, flags=0)
+            projs.append(proj)
         torch.cuda.synchronize(self.device)
-        self.ctx.finalize()
+        for c in self._contexts():
+            c.set_tensor("pos.table", table)
+            for i, proj in enumerate(projs):
+                c.set_tensor(f"L{i}.att.pos_proj", proj)
+            c.finalize()
+        self.pos_cap = (table.shape[0] + 1) // 2
+
+    def ensure_pos_cap(self, tp: int):
+        """Long-form audio: the reference hands a whole file to the model as ONE utterance
+        (pkg/nemo-asr/src/transcribe.py:44-53), so T' is unbounded.  The resident position tables cover T' up to
+        `pos_cap`; a longer utterance grows them (next power of two) instead of failing."""
+        if tp <= self.pos_cap:
+            return
+        from .weights import rel_pos_table
+        cap = 1 << (int(tp) - 1).bit_length()
+        torch.cuda.synchronize(self.device)          # nothing may still read the tables being replaced
+        with torch.cuda.device(self.device):
+            table = torch.from_numpy(rel_pos_table(self.cfg, cap)).to(torch.bfloat16).to(self.device).contiguous()
+            self._set_pos_tables(table)
+
+    BUCKET = 16000      # cached buffer sets are sized in whole seconds of audio
 
     def buffers(self, B, l_max) -> _Buffers:
+        """a cached buffer set for B utterances of up to l_max samples.  Lengths are bucketed to whole seconds and a
+        larger cached set of the same B is reused: the kernels mask by per-utterance length, so the result does not
+        depend on the padded extent (tests: batch invariance), and consecutive transcribe() calls on clips of
+        different lengths stop re-allocating pinned staging + workspace every time."""
+        l_max = (max(int(l_max), 1) + self.BUCKET - 1) // self.BUCKET * self.BUCKET
+        fits = [k for k in self._bufs if k[0] == B and l_max <= k[1] <= 2 * l_max]
+        if fits:
+            key = min(fits, key=lambda k: k[1])
+            self._bufs[key] = self._bufs.pop(key)          # most recently used last
+            return self._bufs[key]
         key = (B, l_max)
-        if key not in self._bufs:
-            if len(self._bufs) >= 4:       # keep HBM bounded: drop the oldest geometry
-                self._bufs.pop(next(iter(self._bufs)))
-            with torch.cuda.device(self.device):
-                self._bufs[key] = _Buffers(self, B, l_max)
+        if len(self._bufs) >= 4:           # keep HBM bounded: drop the least recently used geometry
+            self._bufs.pop(next(iter(self._bufs)))
+        with torch.cuda.device(self.device):
+            self._bufs[key] = _Buffers(self, B, l_max)
         return self._bufs[key]
 
     @property
@@ -262,6 +301,7 @@ class AsrModel:
         if buf is None:
             buf = self.buffers(B, l_max)
         assert buf.B == B and buf.l_max >= longest
+        # rows past each utterance's length are masked by the kernels, but keep the tail deterministic
         ha = buf.h_audio.numpy()
         hl = buf.h_lens.numpy()
         for b, w in enumerate(waveforms):

@@ -7,7 +7,7 @@ The reference obtains its weights with
 `model_weights.ckpt` and a SentencePiece `tokenizer.model`.  No checkpoint can be
 fetched here, so `synthetic_state_dict` builds a state dict with NeMo's key names and
 shapes from a seed (SURVEY.md §8d "Synthetic weights"); `read_nemo` reads a real one
-when it is mounted.  Both feed `prepare_device_weights`.
+when it is mounted.  Both feed `prepare_weights`.
 """
 import io
 import math
@@ -17,7 +17,7 @@ from typing import Dict
 import numpy as np
 import torch
 
-from .config import ModelConfig, from_nemo_yaml
+from .config import ModelConfig, UnsupportedCheckpoint, from_nemo_yaml
 
 # ------------------------------------------------------------------------------------
 # front-end constants
@@ -222,10 +222,15 @@ def read_nemo(path: str):
             elif name == "model_weights.ckpt":
                 buf = io.BytesIO(tar.extractfile(member).read())
                 sd = torch.load(buf, map_location="cpu", weights_only=True)
-            elif name.endswith("tokenizer.model"):
+                if isinstance(sd, dict) and "state_dict" in sd and all(isinstance(k, str) for k in sd["state_dict"]):
+                    sd = sd["state_dict"]                 # a Lightning-style checkpoint wrapped around the weights
+            elif name.endswith("tokenizer.model"):        # NeMo prefixes artefacts with a content hash
                 tok = tar.extractfile(member).read()
     if cfg_dict is None or sd is None:
         raise ValueError(f"{path}: not a .nemo archive (model_config.yaml / model_weights.ckpt missing)")
+    target = str(cfg_dict.get("target", "") or "")
+    if target and "RNNT" not in target and "Transducer" not in target and "Hybrid" not in target:
+        raise UnsupportedCheckpoint(f"{path}: model class {target!r} is not an RNN-T model")
     return from_nemo_yaml(cfg_dict), sd, tok
 
 
@@ -326,6 +331,26 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
     bf = lambda t: t.detach().to(torch.float32).to(torch.bfloat16).contiguous()   # noqa: E731
     f32 = lambda t: t.detach().to(torch.float32).contiguous()                      # noqa: E731
     C, d = cfg.sub_channels, cfg.d_model
+    raw_sd, used = sd, set()
+
+    class _Tracked:
+        """records which checkpoint tensors the prep consumed; a bias the checkpoint does not have is zeros when
+        the encoder was built with use_bias=False ([UPSTREAM] ConformerEncoder(use_bias=...)), an error otherwise"""
+
+        def __getitem__(self, key):
+            if key not in raw_sd:
+                if key.endswith(".bias") and key.startswith("encoder.layers.") and not cfg.use_bias:
+                    wkey = key[:-5] + ".weight"
+                    used.add(key)
+                    return torch.zeros((raw_sd[wkey].shape[0],), dtype=torch.float32)
+                raise UnsupportedCheckpoint(f"checkpoint has no tensor {key!r} (architecture differs from model_config.yaml?)")
+            used.add(key)
+            return raw_sd[key]
+
+        def __contains__(self, key):
+            return key in raw_sd
+
+    sd = _Tracked()
 
     fb = sd["preprocessor.featurizer.fb"].to(torch.float32).reshape(cfg.n_mels, -1).numpy()
     idx, w = banded_filterbank(fb)
@@ -396,7 +421,25 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
         out[f"pred.lstm{l}.b"] = f32(sd[P + f"bias_ih_l{l}"].float() + sd[P + f"bias_hh_l{l}"].float())
     out["joint.pred.w"] = to_fragment_major(sd["joint.pred.weight"])
     out["joint.pred.b"] = f32(sd["joint.pred.bias"])
-    out["joint.out.w"] = to_fragment_major(sd["joint.joint_net.2.weight"])
-    out["joint.out.b"] = f32(sd["joint.joint_net.2.bias"])
+    # joint_net = [activation, (Dropout if dropout > 0), Linear]: the Linear's index is 1 or 2 — find it
+    jkeys = sorted(k for k in raw_sd if k.startswith("joint.joint_net.") and k.endswith(".weight"))
+    if len(jkeys) != 1:
+        raise UnsupportedCheckpoint(f"expected exactly one joint.joint_net.N.weight, found {jkeys}")
+    jout = jkeys[0][:-len(".weight")]
+    if tuple(raw_sd[jkeys[0]].shape) != (cfg.n_logits, cfg.joint_hidden):
+        raise UnsupportedCheckpoint(f"{jkeys[0]} has shape {tuple(raw_sd[jkeys[0]].shape)}, expected "
+                                    f"({cfg.n_logits}, {cfg.joint_hidden}) (vocab_size + blank, joint_hidden)")
+    out["joint.out.w"] = to_fragment_major(sd[jout + ".weight"])
+    out["joint.out.b"] = f32(sd[jout + ".bias"])
     out["pos.table"] = torch.from_numpy(rel_pos_table(cfg, pos_cap)).to(torch.bfloat16).contiguous()
+    # anything under the model's own prefixes that was NOT consumed means the checkpoint holds parameters of a
+    # variant this path does not compute (e.g. self_attn.global_q/k/v, conv.layer_norm, a second joint layer):
+    # refuse instead of silently ignoring them.  Other top-level modules (ctc_decoder.*, spec_augmentation.*) and
+    # non-parameter buffers are not part of the RNN-T inference path.
+    core = ("encoder.", "decoder.", "joint.")
+    benign = ("num_batches_tracked", "encoder.pos_enc.pe", "encoder.pos_emb_max_len")
+    left = [k for k in raw_sd if k.startswith(core) and k not in used and not k.endswith(benign)]
+    if left:
+        raise UnsupportedCheckpoint(f"{len(left)} checkpoint tensor(s) have no counterpart in this implementation: "
+                                    + ", ".join(left[:8]) + (" ..." if len(left) > 8 else ""))
     return out

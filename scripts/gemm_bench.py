@@ -21,6 +21,7 @@ SHAPES = [  # name, M, N, K, flags
     ("out/pw2 res->f32  ", M, 1024, 1024, capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32),
     ("pw1     bias->bf16", M, 2048, 1024, capi.GEMM_BIAS),
     ("sub_pw1 relu->bf16", 256 * 275 * 20, 256, 256, capi.GEMM_BIAS | capi.GEMM_RELU),
+    ("sub_pw2 relu->bf16", 256 * 138 * 10, 256, 256, capi.GEMM_BIAS | capi.GEMM_RELU),
     ("sub_out ->f32     ", M, 1024, 2560, capi.GEMM_BIAS | capi.GEMM_OUT_F32),
 ]
 

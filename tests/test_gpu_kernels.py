@@ -107,6 +107,30 @@ def test_gemm_big_tiles(ctx, gpu_device, N, K, residual, family):
     assert (out_full[M:].float() == 7.0).all(), "rows past M were written"
 
 
+def test_gemm_big_rowmask(ctx, gpu_device):
+    """the subsampling pointwise GEMM at a size that selects the big-tile (persistent) kernel: bias + ReLU + the
+    per-utterance row mask (rows of frames at or past an utterance's length are zeroed), ragged last tile"""
+    g = torch.Generator().manual_seed(17)
+    B, T, Fq, K, N = 37, 275, 20, 256, 256
+    M = B * T * Fq
+    A = rb(torch.randn((M, K), generator=g))
+    W = rb(torch.randn((N, K), generator=g) / K ** 0.5)
+    bias = torch.randn((N,), generator=g)
+    lens = torch.randint(0, T + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0], lens[1] = T, 0
+    out = torch.full((M + 64, N), 7.0, dtype=torch.bfloat16, device=gpu_device)
+    ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out[:M], flags=capi.GEMM_BIAS | capi.GEMM_RELU | capi.GEMM_ROWMASK,
+             bias=bias.to(gpu_device), mask_lens=lens.to(gpu_device), mask_rows=Fq, mask_steps=T)
+    sync()
+    for b in (0, 1, 5, 36):
+        rows = slice(b * T * Fq, (b + 1) * T * Fq)
+        ref = torch.relu(A[rows] @ W.t() + bias).view(T, Fq, N)
+        ref[int(lens[b]):] = 0
+        got = out[rows].float().cpu().view(T, Fq, N)
+        assert ((got - ref).abs() <= 2e-3 + 2.0 ** -8 * ref.abs()).all(), b
+    assert (out[M:].float() == 7.0).all(), "rows past M were written"
+
+
 def test_gemm_epilogues(ctx, gpu_device):
     g = torch.Generator().manual_seed(5)
     B, T, Fq, K, N = 3, 11, 5, 128, 192

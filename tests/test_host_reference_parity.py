@@ -131,3 +131,31 @@ def test_audio_constructors(tmp_path):
     wavfile.write(path, 22050, (np.sin(np.arange(2205) / 10.0) * 20000).astype(np.int16))
     f = A.audio_from_path(path)
     assert f.samplerate == 22050 and f.waveform.dtype == np.float32 and abs(f.waveform).max() <= 1.0
+
+
+def test_reference_import_path_and_console_script():
+    """`reazonspeech.nemo.asr` is importable with the reference's exports (pkg/nemo-asr/src/__init__.py:1-3) and the
+    console script declared in pyproject.toml resolves (pkg/nemo-asr/pyproject.toml:19-20)"""
+    import importlib
+    import re
+    import reazonspeech.nemo.asr as ref_path
+    import reazonspeech_amd.nemo.asr as impl
+    ref_init = open("/root/reference/pkg/nemo-asr/src/__init__.py").read() if os.path.exists(
+        "/root/reference/pkg/nemo-asr/src/__init__.py") else (
+        "from .interface import TranscribeConfig\nfrom .transcribe import transcribe, load_model\n"
+        "from .audio import audio_from_numpy, audio_from_tensor, audio_from_path\n")
+    names = [n.strip() for line in ref_init.splitlines() if " import " in line
+             for n in line.split(" import ")[1].split(",")]
+    assert sorted(names) == sorted(["TranscribeConfig", "transcribe", "load_model", "audio_from_numpy",
+                                    "audio_from_tensor", "audio_from_path"])
+    for n in names + ["transcribe_batch"]:
+        assert getattr(ref_path, n) is getattr(impl, n)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    toml = open(os.path.join(root, "pyproject.toml")).read()
+    m = re.search(r'reazonspeech-nemo-asr\s*=\s*"([\w.]+):(\w+)"', toml)
+    assert m and m.group(1) == "reazonspeech.nemo.asr.cli"
+    assert callable(getattr(importlib.import_module(m.group(1)), m.group(2)))
+    from reazonspeech.nemo.asr.interface import TranscribeConfig
+    assert TranscribeConfig is impl.TranscribeConfig
+    assert not os.path.exists(os.path.join(root, "reazonspeech", "__init__.py"))          # namespace package
+    assert not os.path.exists(os.path.join(root, "reazonspeech", "nemo", "__init__.py"))

@@ -228,3 +228,160 @@ def test_sharded_decode_gloo_world2(tmp_path):
         seen.append(calls[0])
     assert sorted(seen[0] + seen[1]) == list(range(7)) and len(seen[0]) == 4 and len(seen[1]) == 3
     assert max(lengths[i] for i in seen[0]) <= min(lengths[i] for i in seen[1])   # contiguous in sorted order
+
+
+# ---- .nemo archives shaped like NeMo writes them (not produced by this repo's write_nemo) -------------------------
+NEMO_YAML = """
+sample_rate: 16000
+compute_eval_loss: false
+log_prediction: true
+model_defaults:
+  enc_hidden: ${model.encoder.d_model}
+  pred_hidden: 128
+  joint_hidden: 128
+tokenizer:
+  dir: ???
+  type: bpe
+  model_path: nemo:0a1b2c_tokenizer.model
+preprocessor:
+  _target_: nemo.collections.asr.modules.AudioToMelSpectrogramPreprocessor
+  sample_rate: ${model.sample_rate}
+  normalize: per_feature
+  window_size: 0.025
+  window_stride: 0.01
+  window: hann
+  features: 80
+  n_fft: 512
+  frame_splicing: 1
+  dither: 1.0e-05
+  pad_to: 0
+encoder:
+  _target_: nemo.collections.asr.modules.ConformerEncoder
+  feat_in: ${model.preprocessor.features}
+  feat_out: -1
+  n_layers: 2
+  d_model: 256
+  use_bias: %(use_bias)s
+  subsampling: %(subsampling)s
+  subsampling_factor: 8
+  subsampling_conv_channels: 64
+  causal_downsampling: false
+  ff_expansion_factor: 2
+  self_attention_model: rel_pos
+  n_heads: 2
+  att_context_size: [-1, -1]
+  att_context_style: regular
+  xscaling: true
+  untie_biases: true
+  pos_emb_max_len: 5000
+  conv_kernel_size: 9
+  conv_norm_type: %(conv_norm)s
+  conv_context_size: null
+  dropout: 0.1
+decoder:
+  _target_: nemo.collections.asr.modules.RNNTDecoder
+  normalization_mode: null
+  random_state_sampling: false
+  blank_as_pad: true
+  prednet:
+    pred_hidden: ${model.model_defaults.pred_hidden}
+    pred_rnn_layers: 2
+    t_max: null
+    dropout: 0.2
+  vocab_size: 63
+joint:
+  _target_: nemo.collections.asr.modules.RNNTJoint
+  log_softmax: null
+  fuse_loss_wer: true
+  jointnet:
+    joint_hidden: ${model.model_defaults.joint_hidden}
+    activation: relu
+    dropout: %(joint_dropout)s
+  num_classes: 63
+decoding:
+  strategy: %(strategy)s
+  greedy:
+    max_symbols: 10
+  beam:
+    beam_size: 4
+target: nemo.collections.asr.models.rnnt_bpe_models.EncDecRNNTBPEModel
+nemo_version: 2.6.1
+"""
+
+
+def _nemo_like_archive(path, sd, yaml_text, tokenizer_model=None, gz=True, wrap_state_dict=False):
+    import io
+    import tarfile
+    with tarfile.open(path, "w:gz" if gz else "w") as tar:
+        def add(name, data):
+            info = tarfile.TarInfo(name)
+            info.size = len(data)
+            tar.addfile(info, io.BytesIO(data))
+        add("./model_config.yaml", yaml_text.encode())
+        buf = io.BytesIO()
+        torch.save({"state_dict": dict(sd)} if wrap_state_dict else dict(sd), buf)
+        add("./model_weights.ckpt", buf.getvalue())
+        if tokenizer_model is not None:
+            add("./0a1b2c_tokenizer.model", tokenizer_model)
+            add("./0a1b2c_vocab.txt", b"x\n")
+            add("./0a1b2c_tokenizer.vocab", b"x\t0\n")
+
+
+def _tiny_sentencepiece(tmp_path):
+    import sentencepiece as spm
+    corpus = tmp_path / "corpus.txt"
+    words = ["こんにちは", "世界", "音声", "認識", "です", "ます", "。", "、", "東京", "大阪", "天気", "今日", "明日"]
+    rng = np.random.default_rng(0)
+    corpus.write_text("\n".join("".join(rng.choice(words, size=6)) for _ in range(400)), encoding="utf-8")
+    prefix = str(tmp_path / "spm")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=prefix, vocab_size=63, model_type="unigram",
+                                   character_coverage=1.0, minloglevel=2)
+    return open(prefix + ".model", "rb").read()
+
+
+def test_read_nemo_like_archive(tmp_path):
+    """OmegaConf interpolations / `???`, hash-prefixed artefacts, gzip, use_bias=false (bias-less encoder linears),
+    joint dropout = 0 (the output Linear sits at joint_net.1), extra non-RNNT modules, a real SentencePiece model"""
+    from reazonspeech_amd.runtime.config import UnsupportedCheckpoint
+    from reazonspeech_amd.runtime.tokenizer import SentencePieceTokenizer
+    cfg0 = TINY.with_(use_bias=False)
+    sd = W.synthetic_state_dict(TINY, 3)
+    sd = {k: v for k, v in sd.items() if not (k.startswith("encoder.layers.") and k.endswith(".bias") and
+                                              ("linear" in k or "pointwise" in k or "depthwise" in k))}
+    sd["joint.joint_net.1.weight"] = sd.pop("joint.joint_net.2.weight")
+    sd["joint.joint_net.1.bias"] = sd.pop("joint.joint_net.2.bias")
+    sd["ctc_decoder.decoder_layers.0.weight"] = torch.zeros(4, 4)            # hybrid models carry a CTC head
+    sd["encoder.pos_enc.pe"] = torch.zeros(1, 9, 256)
+    spm_model = _tiny_sentencepiece(tmp_path)
+    fill = dict(use_bias="false", subsampling="dw_striding", conv_norm="batch_norm", joint_dropout="0.0",
+                strategy="greedy_batch")
+    path = str(tmp_path / "like.nemo")
+    _nemo_like_archive(path, sd, NEMO_YAML % fill, spm_model, wrap_state_dict=True)
+    cfg, sd2, tok = W.read_nemo(path)
+    assert cfg == cfg0 and tok == spm_model
+    prepared = W.prepare_weights(cfg, sd2, pos_cap=16)
+    assert torch.count_nonzero(prepared["L0.ff1.b1"]) == 0 and prepared["L0.ff1.b1"].shape == (TINY.ff_dim,)
+    assert torch.count_nonzero(prepared["L1.ln_ff1.b"]) > 0                    # LayerNorm biases are real
+    full = W.prepare_weights(TINY, W.synthetic_state_dict(TINY, 3), pos_cap=16)
+    assert torch.equal(prepared["joint.out.w"], full["joint.out.w"])
+    t = SentencePieceTokenizer(tok)
+    assert t.vocab_size == 63 and isinstance(t.ids_to_text([5, 9, 12]), str)
+    assert t.ids_to_text([]) == ""
+
+    # settings the kernels do not implement are refused, not silently mis-computed
+    for bad in (dict(fill, subsampling="striding"), dict(fill, conv_norm="layer_norm")):
+        _nemo_like_archive(path, sd, NEMO_YAML % bad, spm_model)
+        with pytest.raises(UnsupportedCheckpoint):
+            W.read_nemo(path)
+    # parameters without a counterpart (Longformer separate global projections) are refused at weight prep
+    extra = dict(sd)
+    extra["encoder.layers.0.self_attn.global_q.weight"] = torch.zeros(256, 256)
+    with pytest.raises(UnsupportedCheckpoint, match="global_q"):
+        W.prepare_weights(cfg, extra, pos_cap=16)
+    missing = {k: v for k, v in sd.items() if k != "encoder.layers.1.conv.batch_norm.running_var"}
+    with pytest.raises(UnsupportedCheckpoint, match="running_var"):
+        W.prepare_weights(cfg, missing, pos_cap=16)
+    # a beam-search checkpoint loads, with a warning that this path decodes greedily
+    _nemo_like_archive(path, sd, NEMO_YAML % dict(fill, strategy="alsd"), spm_model, gz=False)
+    with pytest.warns(RuntimeWarning, match="greedily"):
+        W.read_nemo(path)
