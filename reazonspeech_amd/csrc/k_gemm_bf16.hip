@@ -92,6 +92,7 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* lds_tile, int row, int
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -682,10 +683,10 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {   // make wa
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     return (const void*)(((unsigned long long)hi << 32) | lo);
 }
+// M0 (the DMA's LDS base) is written and consumed inside one asm statement.  Nothing else in these kernels
+// uses M0 (gfx950 DS instructions do not), so it is not saved / restored around the statement.
 __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate is the only form gfx950 has)
@@ -705,8 +706,129 @@ __device__ __forceinline__ void wait_vmcnt_any(int n) {
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+// ---- epilogue shared by the cross-tile kernels (no workgroup barrier: the scratch is per wave, LDS operations of
+// one wave execute in order).  bf16 output: chunks of 32 rows x 64 columns; f32: 16 rows x 64 columns; both 4 KiB,
+// 16-byte pieces XOR-swizzled by row.  All global accesses are raw buffer operations (masked rows / columns get an
+// out-of-range offset), so the number of VMEM operations a wave issues here is a compile-time constant.
+template <int MI, int NI, int OUT, bool MASK>
+__device__ __forceinline__ void pmf16_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][NI], char* scr, int cm0, int cn0,
+                                               int wm, int wn, int lane) {
+    constexpr bool RES = OUT == 2, out_f32 = OUT >= 1, rowmask = MASK;
+    constexpr int TM = MI * 16, TN = NI * 16;
+    constexpr unsigned OOB = 0xfffffff0u;                         // beyond every buffer: loads return 0, stores are dropped
+    const int frow = lane & 15, fch = lane >> 4;
+    const int flags = p.flags;
+    const bool has_bias = flags & RS_GEMM_BIAS, relu = flags & RS_GEMM_RELU, silu = flags & RS_GEMM_SILU;
+    const float alpha = p.alpha;
+    const size_t out_bytes = (size_t)p.M * p.ldc * (out_f32 ? 4 : 2);
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.residual : (const float*)p.out), 0,
+                                                            (int)out_bytes, 0x00020000);
+    const auto bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_bias ? p.bias : (const float*)p.out), 0,
+                                                             has_bias ? p.N * 4 : 0, 0x00020000);
+    const int wrow0 = cm0 + wm * TM, wcol0 = cn0 + wn * TN;
+    float4 bias_r[NI];
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+        const int n = wcol0 + jj * 16 + 4 * fch;
+        const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(bias_rsrc, (unsigned)n * 4u, 0, 0);   // no bias / n >= N: zeros
+        bias_r[jj] = __builtin_bit_cast(float4, b);
+    }
+    auto finish = [&](int i, int jj) -> float4 {
+        float4 v = make_float4(acc[i][jj][0] + bias_r[jj].x, acc[i][jj][1] + bias_r[jj].y, acc[i][jj][2] + bias_r[jj].z,
+                               acc[i][jj][3] + bias_r[jj].w);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+        return v;
+    };
+    auto row_keep = [&](int m) -> bool {
+        if (!rowmask || m >= p.M) return true;      // rowmask is a template constant
+        const int step = m / p.mask_rows_per_step;
+        const int b = step / p.mask_steps;
+        return step - b * p.mask_steps < p.mask_lens[b];
+    };
+    if constexpr (!out_f32) {
+        // bf16: chunks of 32 rows x 64 columns (4 KiB, 128-byte rows, 16-byte pieces XOR-swizzled by row)
+        const int rr8 = lane >> 3, cc = lane & 7;
+#pragma unroll
+        for (int c = 0; c < MI / 2; ++c) {
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int jj = 0; jj < NI; ++jj) {
+                    const float4 v = finish(2 * c + il, jj);
+                    const int row = il * 16 + frow;
+                    const int piece = (jj * 2 + (fch >> 1)) ^ (row & 7);
+                    *reinterpret_cast<u16x4_t*>(scr + row * 128 + piece * 16 + (fch & 1) * 8) = pack_bf16x4(v.x, v.y, v.z, v.w);
+                }
+#pragma unroll
+            for (int sgm = 0; sgm < 4; ++sgm) {
+                const int row = sgm * 8 + rr8;
+                u32x4_t d = *reinterpret_cast<const u32x4_t*>(scr + row * 128 + ((cc ^ (row & 7)) * 16));
+                const int m = wrow0 + c * 32 + row, n = wcol0 + cc * 8;
+                if (!row_keep(m)) d = (u32x4_t){0u, 0u, 0u, 0u};
+                const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 2u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(d, out_rsrc, off, 0, 0);
+            }
+        }
+    } else {
+        // f32: chunks of 16 rows x 64 columns (4 KiB, 256-byte rows, 16-byte pieces XOR-swizzled by row);
+        // the residual of chunk i+1 is requested (row-major, whole 256-byte segments) before chunk i is stored
+        const int rr4 = lane >> 4, cc = lane & 15;
+        u32x4_t rv_next[4];
+        auto load_res = [&](int i, u32x4_t (&rv)[4]) {
+#pragma unroll
+            for (int sgm = 0; sgm < 4; ++sgm) {
+                const int m = wrow0 + i * 16 + sgm * 4 + rr4, n = wcol0 + cc * 4;
+                const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : OOB;
+                rv[sgm] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, off, 0, 0);
+            }
+        };
+        if constexpr (RES) load_res(0, rv_next);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            u32x4_t rv[4];
+            if constexpr (RES) {
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) rv[sgm] = rv_next[sgm];
+                if (i + 1 < MI) load_res(i + 1, rv_next);
+            }
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj) {
+                const float4 v = finish(i, jj);
+                const int piece = (jj * 4 + fch) ^ frow;
+                *reinterpret_cast<float4*>(scr + frow * 256 + piece * 16) = v;
+            }
+#pragma unroll
+            for (int sgm = 0; sgm < 4; ++sgm) {
+                const int row = sgm * 4 + rr4;
+                float4 v = *reinterpret_cast<const float4*>(scr + row * 256 + ((cc ^ row) * 16));
+                if constexpr (RES) {
+                    const float4 r = __builtin_bit_cast(float4, rv[sgm]);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                const int m = wrow0 + i * 16 + row, n = wcol0 + cc * 4;
+                if (!row_keep(m)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), out_rsrc, off, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // OUT: 0 = bf16, 1 = f32, 2 = f32 with a residual read-modify-write; MASK: per-utterance row mask (subsampling GEMMs)
-template <int BM, int OUT, bool MASK>
+// SCHED: where a granule's four DMA instructions are issued
+//   0  in the memory halves of the two phases (with the fragment reads), as gemm_mf16_kernel does
+//   1  between the MFMAs of the two phases: the memory half is then fragment reads only
+//   2  one phase per granule: 12 fragment reads | 32 MFMAs with the four DMAs spread between them
+//   3  one phase per granule, all four DMAs in the memory half (before the fragment reads)
+//   4  one phase per granule, three DMAs in the memory half, one between the MFMAs;  5: two and two
+// ABL (ablation builds for profiling only; results are wrong): 1 = no MFMAs, 2 = no DMAs inside the main loop,
+// 3 = no fragment reads inside the main loop, 4 = reads after the DMAs instead of before,
+// 5 = every DMA fetches 8 rows x 128 B (whole cache lines; half the rows, twice the k extent) instead of 16 rows x 64 B
+template <int BM, int OUT, bool MASK, int SCHED, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pmf16_kernel(GemmParams p) {
     constexpr bool RES = OUT == 2, out_f32 = OUT >= 1, rowmask = MASK;
     constexpr int BN = 256, BK = 32, WN = 4, NWAVES = 8;
@@ -758,45 +880,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pmf16_kernel(GemmParams p) {
             int gb = n0 + rowb;
             gb = gb < p.N ? gb : p.N - 1;
             ob[j] = (unsigned)gb * (unsigned)(p.ldw * 2) + (unsigned)((dpc ^ swz16(rowb)) * 16);
+            if constexpr (ABL == 5) {                             // timing experiment: whole 128-byte lines
+                int ra = m0 + ida * 8 + (lane >> 3), rb = n0 + (wave * LB + j) * 8 + (lane >> 3);
+                ra = ra < p.M - 4 ? ra : p.M - 5;
+                rb = rb < p.N - 4 ? rb : p.N - 5;
+                oa[j] = (unsigned)ra * (unsigned)(p.lda * 2) + (unsigned)((lane & 7) * 16);
+                ob[j] = (unsigned)rb * (unsigned)(p.ldw * 2) + (unsigned)((lane & 7) * 16);
+            }
         }
     };
-    auto issue_a = [&](const unsigned (&oa)[2], int t, int ring_slot) {
-        const void* sb = uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)t * (BK * 2));
-        const unsigned dst = lds0 + ring_slot * STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int id = wave + NWAVES * j;
-            if (id < A_INSTS) glds16(oa[j], sb, __builtin_amdgcn_readfirstlane(dst + id * 1024));
-        }
+    // piece q of a granule: q = 0, 1 the wave's A pieces (16 rows x 64 B each), q = 2, 3 its W pieces
+    auto dma = [&](int q, unsigned voff, int t, int ring_slot) {
+        if constexpr (A_INSTS != 16) { if (q == 1 && wave + NWAVES >= A_INSTS) return; }    // 192-row tiles: 12 A pieces
+        const char* base = (q < 2 ? reinterpret_cast<const char*>(p.A) : reinterpret_cast<const char*>(p.W)) + (size_t)t * (ABL == 5 ? BK * 4 : BK * 2);
+        const unsigned dst = lds0 + ring_slot * STAGE_BYTES + (q < 2 ? (wave + NWAVES * q) * 1024 : A_BYTES + (wave * LB + (q - 2)) * 1024);
+        glds16(voff, base, dst);
     };
-    auto issue_b = [&](const unsigned (&ob)[2], int t, int ring_slot) {
-        const void* sb = uniform_ptr(reinterpret_cast<const char*>(p.W) + (size_t)t * (BK * 2));
-        const unsigned dst = lds0 + ring_slot * STAGE_BYTES + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(ob[j], sb, __builtin_amdgcn_readfirstlane(dst + (wave * LB + j) * 1024));
-    };
-
     const int nk = p.K / BK;                                      // >= 4 (launcher)
-    const int flags = p.flags;
-    const bool has_bias = flags & RS_GEMM_BIAS, relu = flags & RS_GEMM_RELU, silu = flags & RS_GEMM_SILU;
-    const float alpha = p.alpha;
     // VMEM operations a wave leaves in flight at the end of an epilogue (a lower bound is what the waits need)
     constexpr int E_ops = out_f32 ? MI * 4 : (MI / 2) * 4;
-    const size_t out_bytes = (size_t)p.M * p.ldc * (out_f32 ? 4 : 2);
-    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
-    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.residual : (const float*)p.out), 0,
-                                                            (int)out_bytes, 0x00020000);
-    const auto bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_bias ? p.bias : (const float*)p.out), 0,
-                                                             has_bias ? p.N * 4 : 0, 0x00020000);
-    constexpr unsigned OOB = 0xfffffff0u;                         // beyond every buffer: loads return 0, stores are dropped
-
     int m0, n0, mn, nn;
     unsigned oa[2], ob[2], oan[2], obn[2];
     tile_origin(slot, m0, n0);
     lane_offsets(m0, n0, oa, ob);
     int gc = 0;                                                   // granules consumed so far (ring position)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) { issue_a(oa, t, t); issue_b(ob, t, t); }
+    for (int t = 0; t < 3; ++t) { dma(0, oa[0], t, t); dma(1, oa[1], t, t); dma(2, ob[0], t, t); dma(3, ob[1], t, t); }
     wait_vmcnt_any(2 * (LAw + LB));
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind from here on
@@ -820,7 +929,80 @@ __global__ __launch_bounds__(512, 2) void gemm_pmf16_kernel(GemmParams p) {
             const bool own = g + 3 < nk;                          // granule g+3 belongs to this tile
             const bool more = own || has_next;
             const int tn = own ? g + 3 : g + 3 - nk;
+            const int nslot = (gc + g + 3) & 3;
+            // piece q (0, 1 = the A pieces; 2, 3 = the W pieces) of granule g+3, of this tile or of the next one
+            auto dma_piece = [&](int q) {
+                if (!more) return;
+                const unsigned voff = q < 2 ? (own ? oa[q] : oan[q]) : (own ? ob[q - 2] : obn[q - 2]);
+                dma(q, voff, tn, nslot);
+            };
             bf16x8_t bfr[NI];
+            if constexpr (SCHED >= 2) {
+                constexpr int IN_MEM = SCHED == 2 ? 0 : (SCHED == 3 ? 4 : (SCHED == 4 ? 3 : 2));   // DMAs issued with the reads
+                bf16x8_t af[MI];
+                if (g + 1 < nk || has_next) {
+                    // granule g+1 must have landed; issued after it: granule g+2 (g+3 is issued below) and, for
+                    // the first two granules of a later tile, the previous epilogue's stores
+                    if ((g + 2 < nk || has_next) && !(tile_no > 0 && g < 2)) {        // steady state: one literal wait
+                        if (LAw == 2) wait_vmcnt<2 + LB>(); else wait_vmcnt<1 + LB>();
+                    } else {
+                        int younger = 0;
+                        if (g + 2 < nk || has_next) younger += LAw + LB;
+                        if (tile_no > 0 && g < 2) younger += E_ops;
+                        wait_vmcnt_any(younger);
+                    }
+                }
+                if constexpr (ABL == 4) {
+#pragma unroll
+                    for (int q = 0; q < IN_MEM; ++q) dma_piece(q);
+                }
+                if (ABL != 3 || g == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < NI; ++jj) bfr[jj] = read_frag16(bt, wn * TN + jj * 16 + frow, fch);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[i] = read_frag16(at, wm * TM + i * 16 + frow, fch);
+                }
+                if constexpr (ABL != 4 && ABL != 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < IN_MEM; ++q) dma_piece(q);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (ABL == 1) {
+#pragma unroll
+                        for (int i = q * (MI / 4); i < (q + 1) * (MI / 4); ++i)
+                            asm volatile("" :: "v"(af[i]), "v"(bfr[i & 3]));
+                    } else {
+#pragma unroll
+                    for (int i = q * (MI / 4); i < (q + 1) * (MI / 4); ++i)
+#pragma unroll
+                        for (int jj = 0; jj < NI; ++jj)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
+                    }
+                    if (q >= IN_MEM) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma_piece(q);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if constexpr (MI % 4 != 0) {                      // 192-row tiles: 6 row blocks = 4 x 1 + 2
+#pragma unroll
+                    for (int i = 4 * (MI / 4); i < MI; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < NI; ++jj)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8_t af[MH];
@@ -839,120 +1021,39 @@ __global__ __launch_bounds__(512, 2) void gemm_pmf16_kernel(GemmParams p) {
                     if (tile_no > 0 && g < 2) younger += E_ops;
                     wait_vmcnt_any(younger);
                 }
-                if (more) {
-                    if (ks == 0) { if (own) issue_a(oa, tn, (gc + g + 3) & 3); else issue_a(oan, tn, (gc + g + 3) & 3); }
-                    else { if (own) issue_b(ob, tn, (gc + g + 3) & 3); else issue_b(obn, tn, (gc + g + 3) & 3); }
-                }
+                if constexpr (SCHED == 0) { dma_piece(2 * ks); dma_piece(2 * ks + 1); }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < MH; ++i)
+                for (int i = 0; i < MH; ++i) {
 #pragma unroll
                     for (int jj = 0; jj < NI; ++jj)
                         acc[ks * MH + i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[ks * MH + i][jj], 0, 0, 0);
+                    if constexpr (SCHED == 1) {
+                        if (i == 0 || i == MH / 2) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            dma_piece(2 * ks + (i == 0 ? 0 : 1));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
         }
         gc += nk;
 
-        // ---- epilogue (no workgroup barrier: the scratch is per wave, LDS operations of one wave execute in order)
-        int cm0 = __builtin_amdgcn_readfirstlane(m0), cn0 = __builtin_amdgcn_readfirstlane(n0);
-        asm volatile("" : "+s"(cm0), "+s"(cn0));                 // keep the addresses out of the main loop's live ranges
-        const int wrow0 = cm0 + wm * TM, wcol0 = cn0 + wn * TN;
-        float4 bias_r[NI];
-#pragma unroll
-        for (int jj = 0; jj < NI; ++jj) {
-            const int n = wcol0 + jj * 16 + 4 * fch;
-            const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(bias_rsrc, (unsigned)n * 4u, 0, 0);   // no bias / n >= N: zeros
-            bias_r[jj] = __builtin_bit_cast(float4, b);
-        }
-        auto finish = [&](int i, int jj) -> float4 {
-            float4 v = make_float4(acc[i][jj][0] + bias_r[jj].x, acc[i][jj][1] + bias_r[jj].y, acc[i][jj][2] + bias_r[jj].z,
-                                   acc[i][jj][3] + bias_r[jj].w);
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
-            return v;
-        };
-        auto row_keep = [&](int m) -> bool {
-            if (!rowmask || m >= p.M) return true;      // rowmask is a template constant
-            const int step = m / p.mask_rows_per_step;
-            const int b = step / p.mask_steps;
-            return step - b * p.mask_steps < p.mask_lens[b];
-        };
-        if constexpr (!out_f32) {
-            // bf16: chunks of 32 rows x 64 columns (4 KiB, 128-byte rows, 16-byte pieces XOR-swizzled by row)
-            const int rr8 = lane >> 3, cc = lane & 7;
-#pragma unroll
-            for (int c = 0; c < MI / 2; ++c) {
-#pragma unroll
-                for (int il = 0; il < 2; ++il)
-#pragma unroll
-                    for (int jj = 0; jj < NI; ++jj) {
-                        const float4 v = finish(2 * c + il, jj);
-                        const int row = il * 16 + frow;
-                        const int piece = (jj * 2 + (fch >> 1)) ^ (row & 7);
-                        *reinterpret_cast<u16x4_t*>(scr + row * 128 + piece * 16 + (fch & 1) * 8) = pack_bf16x4(v.x, v.y, v.z, v.w);
-                    }
-#pragma unroll
-                for (int sgm = 0; sgm < 4; ++sgm) {
-                    const int row = sgm * 8 + rr8;
-                    u32x4_t d = *reinterpret_cast<const u32x4_t*>(scr + row * 128 + ((cc ^ (row & 7)) * 16));
-                    const int m = wrow0 + c * 32 + row, n = wcol0 + cc * 8;
-                    if (!row_keep(m)) d = (u32x4_t){0u, 0u, 0u, 0u};
-                    const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 2u : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(d, out_rsrc, off, 0, 0);
-                }
-            }
-        } else {
-            // f32: chunks of 16 rows x 64 columns (4 KiB, 256-byte rows, 16-byte pieces XOR-swizzled by row);
-            // the residual of chunk i+1 is requested (row-major, whole 256-byte segments) before chunk i is stored
-            const int rr4 = lane >> 4, cc = lane & 15;
-            u32x4_t rv_next[4];
-            auto load_res = [&](int i, u32x4_t (&rv)[4]) {
-#pragma unroll
-                for (int sgm = 0; sgm < 4; ++sgm) {
-                    const int m = wrow0 + i * 16 + sgm * 4 + rr4, n = wcol0 + cc * 4;
-                    const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : OOB;
-                    rv[sgm] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, off, 0, 0);
-                }
-            };
-            if constexpr (RES) load_res(0, rv_next);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                u32x4_t rv[4];
-                if constexpr (RES) {
-#pragma unroll
-                    for (int sgm = 0; sgm < 4; ++sgm) rv[sgm] = rv_next[sgm];
-                    if (i + 1 < MI) load_res(i + 1, rv_next);
-                }
-#pragma unroll
-                for (int jj = 0; jj < NI; ++jj) {
-                    const float4 v = finish(i, jj);
-                    const int piece = (jj * 4 + fch) ^ frow;
-                    *reinterpret_cast<float4*>(scr + frow * 256 + piece * 16) = v;
-                }
-#pragma unroll
-                for (int sgm = 0; sgm < 4; ++sgm) {
-                    const int row = sgm * 4 + rr4;
-                    float4 v = *reinterpret_cast<const float4*>(scr + row * 256 + ((cc ^ row) * 16));
-                    if constexpr (RES) {
-                        const float4 r = __builtin_bit_cast(float4, rv[sgm]);
-                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                    }
-                    const int m = wrow0 + i * 16 + row, n = wcol0 + cc * 4;
-                    if (!row_keep(m)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), out_rsrc, off, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        // ---- epilogue
+        {
+            int cm0 = __builtin_amdgcn_readfirstlane(m0), cn0 = __builtin_amdgcn_readfirstlane(n0);
+            asm volatile("" : "+s"(cm0), "+s"(cn0));             // keep the addresses out of the main loop's live ranges
+            pmf16_epilogue<MI, NI, OUT, MASK>(p, acc, scr, cm0, cn0, wm, wn, lane);
         }
         if (has_next) {
             m0 = mn; n0 = nn;
@@ -961,6 +1062,196 @@ __global__ __launch_bounds__(512, 2) void gemm_pmf16_kernel(GemmParams p) {
         }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier at the start
+}
+
+// =====================================================================================================
+// Cross-tile kernel with WHOLE-LINE operand fetches (the default for the big shapes).
+//
+// gemm_pmf16_kernel stages 32-deep granules: every DMA instruction fetches 16 rows x 64 B, i.e. HALF of each 128-byte
+// cache line; the other half is fetched again one granule later, after 32 KiB of other lines went through the 32 KiB
+// L1, so the L2 -> L1 path moves every operand byte twice.  Measured (profiles/r02e_*: ablation 349): fetching 8 rows
+// x 128 B per instruction instead is worth +17 %.  This kernel therefore keeps 64-deep K tiles in LDS:
+//   * LDS: ring of two K tiles, each [BM + 256 rows][128 B] (64 KiB at BM = 256), 16-byte chunks XOR-swizzled by
+//     (row >> 1) & 7 (conflict-free for the 16 x 4-chunk fragment reads of v_mfma_f32_16x16x32_bf16), plus the
+//     4 KiB-per-wave epilogue scratch;
+//   * a K tile is consumed in two phases (k-steps of 32), each [12 fragment reads | 32 MFMAs], ping-pong wave
+//     groups as before;
+//   * K tile t+1 (8 DMA instructions per wave) is issued during phase (t, 0) — NM0 of them with the fragment reads,
+//     the rest between the MFMAs — into the buffer whose last reads finished in phase (t-1, 1);
+//   * it is waited for with vmcnt(0) one interval before its first read: group 0 at the END of its MFMA half of phase
+//     (t, 1), group 1 (one barrier behind) in its memory half of (t, 1).  Nothing younger than those DMAs exists at
+//     that point (the previous epilogue's stores are older, vmcnt retires in order), so no counting is needed;
+//   * the ring keeps running across the tiles of a persistent workgroup exactly as in gemm_pmf16_kernel.
+__device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
+
+template <int BM, int OUT, bool MASK, int NM0>
+__global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
+    constexpr int BN = 256, WN = 4, NWAVES = 8;
+    constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int LA = BM / 8 / NWAVES, LB = BN / 8 / NWAVES, NP = LA + LB;   // DMA pieces (8 rows x 128 B) per wave and K tile
+    constexpr int RING_BYTES = 2 * STAGE_BYTES, SCR_BYTES = 4096;
+    static_assert((BM == 256 || BM == 192) && LB == 4 && (MI % 2) == 0, "tile shapes: 256 x 256 or 192 x 256");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fch = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    char* scr = smem + RING_BYTES + wave * SCR_BYTES;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int xbase = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    const int xcount = xcd < rr ? q + 1 : q;
+    const int nslots = ((int)gridDim.x - xcd + 7) >> 3;
+    if (slot >= xcount) return;
+    auto tile_origin = [&](int j, int& m0, int& n0) {
+        const int wg = xbase + j;
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = wg / per_group, r = wg - g * per_group;
+        const int left = p.tiles_m - g * p.group_m;
+        const int gm = left < p.group_m ? left : p.group_m;
+        const int tile_n = r / gm;
+        m0 = (g * p.group_m + (r - tile_n * gm)) * BM;
+        n0 = tile_n * BN;
+    };
+    // per-lane byte offsets of this wave's DMA pieces: lane = (row l >> 3 of the piece, physical chunk l & 7)
+    const int dr = lane >> 3, dpc = lane & 7;
+    unsigned off[NP];
+    auto lane_offsets = [&](int m0, int n0) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int row = (wave + NWAVES * j) * 8 + dr;
+            int gr = m0 + row;
+            gr = gr < p.M ? gr : p.M - 1;
+            off[j] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const int row = (wave * LB + j) * 8 + dr;
+            int gr = n0 + row;
+            gr = gr < p.N ? gr : p.N - 1;
+            off[LA + j] = (unsigned)gr * (unsigned)(p.ldw * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
+        }
+    };
+    // piece q of K tile t into ring buffer `buf`
+    auto dma = [&](int q, int t, int buf) {
+        const char* base = (q < LA ? reinterpret_cast<const char*>(p.A) : reinterpret_cast<const char*>(p.W)) + (size_t)t * 128;
+        const unsigned dst = lds0 + buf * STAGE_BYTES + (q < LA ? (wave + NWAVES * q) * 1024 : A_BYTES + (wave * LB + (q - LA)) * 1024);
+        glds16(off[q], base, dst);
+    };
+    auto frag = [&](const char* tile, int row, int chunk) -> bf16x8_t {
+        return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + ((chunk ^ swz64(row)) << 4));
+    };
+
+    const int nk = p.K / 64;                                      // K tiles per output tile, >= 2 (launcher)
+    int m0, n0;
+    tile_origin(slot, m0, n0);
+    lane_offsets(m0, n0);
+    int gc = 0;                                                   // K tiles consumed so far (ring position)
+#pragma unroll
+    for (int qq = 0; qq < NP; ++qq) dma(qq, 0, 0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind from here on
+
+    for (int j = slot; j < xcount; j += nslots) {
+        const bool has_next = j + nslots < xcount;
+        const int cm0 = m0, cn0 = n0;
+        f32x4_t acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.0f;
+
+        for (int t = 0; t < nk; ++t) {
+            const char* at = smem + ((gc + t) & 1) * STAGE_BYTES;
+            const char* bt = at + A_BYTES;
+            const bool own = t + 1 < nk;                          // K tile t+1 belongs to this output tile
+            const bool more = own || has_next;
+            const int tn = own ? t + 1 : 0;
+            const int nbuf = (gc + t + 1) & 1;
+            if (!own && has_next) {                               // all DMAs of this tile are issued: switch to the next tile
+                tile_origin(j + nslots, m0, n0);
+                lane_offsets(m0, n0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t bfr[NI], af[MI];
+#pragma unroll
+                for (int jj = 0; jj < NI; ++jj) bfr[jj] = frag(bt, wn * TN + jj * 16 + frow, ks * 4 + fch);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = frag(at, wm * TM + i * 16 + frow, ks * 4 + fch);
+                if (ks == 0 && more) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int qq = 0; qq < (NM0 < NP ? NM0 : NP); ++qq) dma(qq, tn, nbuf);
+                }
+                if (ks == 1 && more && wm == 1) wait_vmcnt<0>();            // group 1: K tile t+1 landed (see header)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                constexpr int REST = NP - (NM0 < NP ? NM0 : NP);            // pieces issued between the MFMAs of phase (t, 0)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int jj = 0; jj < NI; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
+                    if (REST > 0 && ks == 0 && i < REST && more) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma(NP - REST + i, tn, nbuf);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (ks == 1 && more && wm == 0) wait_vmcnt<0>();            // group 0: before the barrier its reads follow
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        gc += nk;
+        {
+            int em0 = __builtin_amdgcn_readfirstlane(cm0), en0 = __builtin_amdgcn_readfirstlane(cn0);
+            asm volatile("" : "+s"(em0), "+s"(en0));
+            pmf16_epilogue<MI, NI, OUT, MASK>(p, acc, scr, em0, en0, wm, wn, lane);
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier at the start
+}
+
+template <int BM, int NM0>
+int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
+    constexpr int BN = 256;
+    constexpr int LDS = 2 * (BM + BN) * 128 + 8 * 4096;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    extern std::atomic<int> g_group_m;
+    p.group_m = g_group_m.load() > 0 ? g_group_m.load() : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8));
+    p.skew_cycles = 0;
+    const int grid = nwg < grid_cap ? nwg : grid_cap;
+    const int out = (p.flags & RS_GEMM_RESIDUAL) ? 2 : ((p.flags & RS_GEMM_OUT_F32) ? 1 : 0);
+    const bool mask = p.flags & RS_GEMM_ROWMASK;
+#define RS_LMF(O, MK)                                                                                         \
+    do {                                                                                                      \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, O, MK, NM0>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_lmf16_kernel<BM, O, MK, NM0>), dim3(grid), dim3(512), LDS, s, p);            \
+    } while (0)
+    if (out == 2 && !mask) RS_LMF(2, false);
+    else if (out == 1 && !mask) RS_LMF(1, false);
+    else if (out == 0 && !mask) RS_LMF(0, false);
+    else if (out == 0 && mask) RS_LMF(0, true);
+    else return rs_fail(ctx, RS_EINVAL, "gemm: row mask with f32 output has no persistent kernel");
+#undef RS_LMF
+    return RS_OK;
 }
 
 // Process-wide A/B knobs (debug / tuning only; the defaults are the measured winners and nothing in the product
@@ -1023,7 +1314,7 @@ int launch_mf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     return RS_OK;
 }
 
-template <int BM>
+template <int BM, int SCHED, int ABL = 0>
 int launch_pmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
     constexpr int BN = 256;
     constexpr int LDS = 4 * (BM + BN) * 32 * 2 + 8 * 4096;
@@ -1037,9 +1328,14 @@ int launch_pmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
     const bool mask = p.flags & RS_GEMM_ROWMASK;
 #define RS_PMF(O, MK)                                                                                         \
     do {                                                                                                      \
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_pmf16_kernel<BM, O, MK>, LDS); rc != RS_OK) return rc; \
-        hipLaunchKernelGGL((gemm_pmf16_kernel<BM, O, MK>), dim3(grid), dim3(512), LDS, s, p);                 \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_pmf16_kernel<BM, O, MK, SCHED>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_pmf16_kernel<BM, O, MK, SCHED>), dim3(grid), dim3(512), LDS, s, p);          \
     } while (0)
+    if constexpr (ABL != 0) {
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_pmf16_kernel<BM, 0, false, SCHED, ABL>, LDS); rc != RS_OK) return rc;
+        hipLaunchKernelGGL((gemm_pmf16_kernel<BM, 0, false, SCHED, ABL>), dim3(grid), dim3(512), LDS, s, p);
+        return RS_OK;
+    }
     if (out == 2 && !mask) RS_PMF(2, false);
     else if (out == 1 && !mask) RS_PMF(1, false);
     else if (out == 0 && !mask) RS_PMF(0, false);
@@ -1050,7 +1346,7 @@ int launch_pmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
 }
 
 std::atomic<long long*> g_trace{nullptr};
-std::atomic<int> g_variant{0}, g_skew{-1}, g_persistent{1}, g_group_m{0} /* 0 = by shape */, g_big{0};
+std::atomic<int> g_variant{0}, g_skew{-1}, g_persistent{2}, g_group_m{0} /* 0 = by shape */, g_big{0};
 std::atomic<int> g_reserve{0};   // CUs the persistent kernel leaves free when a context does not say (rs_set_option)
 void gemm_knobs_from_env() {
     static std::once_flag once;
@@ -1058,7 +1354,7 @@ void gemm_knobs_from_env() {
         auto env = [](const char* name, std::atomic<int>& v) { if (const char* e = getenv(name)) v = atoi(e); };
         env("RS_GEMM_VARIANT", g_variant);        // force one kernel variant (microbenchmarks); 0 = by shape
         env("RS_GEMM_GROUP_M", g_group_m);        // row panels per XCD tile group; 0 = by shape
-        env("RS_GEMM_PERSISTENT", g_persistent);  // 1 (default) = persistent 16x16x32 kernel for the big shapes, 0 = one tile per workgroup
+        env("RS_GEMM_PERSISTENT", g_persistent);  // 2 (default) = whole-line kernel, one tile per workgroup; 1 = persistent grid; 0 = round-1 kernels
         env("RS_GEMM_RESERVE_CUS", g_reserve);    // CUs the persistent grid leaves to other streams (contexts may override)
         env("RS_GEMM_BIG", g_big);                // big-tile kernel family (DESIGN.md A/B knob table)
     });
@@ -1133,11 +1429,13 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         // two-stage pipeline; it is selected with rs_debug_set_gemm_persistent(1) / RS_GEMM_PERSISTENT=1
         // for single-stream use)
     }
-    if ((v == 30 || v == 32) && g_variant == 0 && g_persistent.load() == 1 && a.K >= 128 && (a.N % 8) == 0 &&
+    // the big-tile choice (30 / 32) is served by the whole-line cross-tile kernel (60 / 62): RS_GEMM_PERSISTENT = 2
+    // (default) one tile per workgroup, 1 = persistent grid of (CUs - reserved) workgroups, 0 = the round-1 kernels
+    if ((v == 30 || v == 32) && g_variant == 0 && g_persistent.load() != 0 && a.K >= 128 && (a.N % 8) == 0 &&
         (size_t)a.M * a.ldc * ((a.flags & (RS_GEMM_OUT_F32 | RS_GEMM_RESIDUAL)) ? 4 : 2) < (1ull << 31) &&
         (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32) &&
         !((a.flags & RS_GEMM_ROWMASK) && (a.flags & (RS_GEMM_OUT_F32 | RS_GEMM_RESIDUAL))))
-        v += 10;                                  // 40 / 42: the persistent form of 30 / 32
+        v += 30 + (g_persistent.load() == 2 ? 1000 : 0);
     if (ctx->n_cus <= 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
@@ -1145,9 +1443,33 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     }
     const int reserve = ctx->gemm_reserved_cus >= 0 ? ctx->gemm_reserved_cus : g_reserve.load();
     const int grid_cap = ctx->n_cus - reserve > 8 ? ctx->n_cus - reserve : 8;
-    switch (v) {
-        case 40: rc = launch_pmf16<256>(ctx, p, s, grid_cap); break;            // persistent 16x16x32, 256-row tiles
-        case 42: rc = launch_pmf16<192>(ctx, p, s, grid_cap); break;            // persistent, 3/4-height tiles
+    // 40 / 42 (+100 * SCHED): the cross-tile kernel, persistent grid; +1000: the same kernel, one tile per workgroup
+    const int pgrid = v >= 1000 ? (1 << 30) : grid_cap;
+    switch (v % 1000) {
+        case 40: rc = launch_pmf16<256, 0>(ctx, p, s, pgrid); break;            // 256-row tiles
+        case 42: rc = launch_pmf16<192, 0>(ctx, p, s, pgrid); break;            // 3/4-height tiles
+        case 140: rc = launch_pmf16<256, 1>(ctx, p, s, pgrid); break;
+        case 142: rc = launch_pmf16<192, 1>(ctx, p, s, pgrid); break;
+        case 240: rc = launch_pmf16<256, 2>(ctx, p, s, pgrid); break;
+        case 242: rc = launch_pmf16<192, 2>(ctx, p, s, pgrid); break;
+        case 340: rc = launch_pmf16<256, 3>(ctx, p, s, pgrid); break;
+        case 342: rc = launch_pmf16<192, 3>(ctx, p, s, pgrid); break;
+        case 341: rc = launch_pmf16<256, 3, 1>(ctx, p, s, pgrid); break;         // ablations of 340 (wrong results)
+        case 343: rc = launch_pmf16<256, 3, 2>(ctx, p, s, pgrid); break;
+        case 345: rc = launch_pmf16<256, 3, 3>(ctx, p, s, pgrid); break;
+        case 347: rc = launch_pmf16<256, 3, 4>(ctx, p, s, pgrid); break;
+        case 349: rc = launch_pmf16<256, 3, 5>(ctx, p, s, pgrid); break;
+        case 440: rc = launch_pmf16<256, 4>(ctx, p, s, pgrid); break;
+        // 5x / 6x / 7x: the whole-line kernel with 8 / 5 / 3 of a K tile's DMAs issued beside the fragment reads
+        case 50: rc = launch_lmf16<256, 8>(ctx, p, s, pgrid); break;
+        case 52: rc = launch_lmf16<192, 8>(ctx, p, s, pgrid); break;
+        case 60: rc = launch_lmf16<256, 5>(ctx, p, s, pgrid); break;
+        case 62: rc = launch_lmf16<192, 5>(ctx, p, s, pgrid); break;
+        case 70: rc = launch_lmf16<256, 3>(ctx, p, s, pgrid); break;
+        case 72: rc = launch_lmf16<192, 3>(ctx, p, s, pgrid); break;
+        case 442: rc = launch_pmf16<192, 4>(ctx, p, s, pgrid); break;
+        case 540: rc = launch_pmf16<256, 5>(ctx, p, s, pgrid); break;
+        case 542: rc = launch_pmf16<192, 5>(ctx, p, s, pgrid); break;
         case 1: rc = launch_variant<128, 128, 64, 2, 2, 2>(ctx, p, s); break;   // small problems
         case 2: rc = launch_variant<256, 256, 64, 2, 2, 4>(ctx, p, s); break;   // big tile, drain per K step
         case 3: rc = launch_variant<256, 256, 32, 4, 2, 4>(ctx, p, s); break;   // big tile, 4-stage ring, counted vmcnt
