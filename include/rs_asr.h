@@ -136,7 +136,10 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
  *   "gemm_reserved_cus"  compute units the persistent GEMM grid leaves free for work on OTHER streams (the
  *                        two-stage pipeline runs batch i's greedy decode next to batch i+1's encoder; a GEMM
  *                        workgroup owns every register of its CU for the whole launch).  -1 = process default
- *                        ($RS_GEMM_RESERVE_CUS, 0). */
+ *                        ($RS_GEMM_RESERVE_CUS, 0).
+ *   "decode_screen"      1 (default when the tensors joint.out.w16 / .wrm / .bpad / .wmax are registered): the joint's
+ *                        output layer runs as a bf16 screening GEMM followed by an exact float32 evaluation of every
+ *                        column that can still be the argmax (bit-identical result); 0 = every column in exact float32. */
 int rs_set_option(rs_ctx* ctx, const char* key, int value);
 
 /* Parity taps (tests only; no reference counterpart — NeMo exposes intermediate activations through

@@ -74,6 +74,10 @@ struct DecodeState {
     int32_t* counters;  // [0]=n_act [1]=overflow flag [2],[3]=n_alive of list 0 / 1
     float* pmax;     // [B][n_ctiles] partial max
     int32_t* pidx;   // [B][n_ctiles] partial argmax
+    // screened joint (see rnnt_prep_kernel / rnnt_verify_kernel)
+    uint16_t* a16;   // [B][J] bf16 relu(f + g) of alive slot i
+    float* anorm;    // [B]    ||relu(f + g)||_2 of alive slot i (rounded up)
+    float* zapprox;  // [B][Vpad] approximate logits of alive slot i (bf16 MFMA GEMM, f32 accumulate, + bias)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -401,6 +405,371 @@ __global__ __launch_bounds__(256) void rnnt_finalize_kernel(DecodeState st, cons
     }
 }
 
+
+
+// ---- narrow-tile variants (the default) -----------------------------------------------------------------------
+// A decode step's LSTM / projection work is tiny (~0.2 GFLOP per layer at 32 emitting rows); what a batch pays is
+// the LATENCY of each launch.  The wide tiles above put a whole [32 x 64] tile's 2560 f32 MFMAs on ONE CU (16 us per
+// launch in profiles/r02i_*): 40 workgroups busy, 216 CUs idle.  These variants keep the K slices on the waves of a
+// workgroup (same accumulation order) but give every workgroup a single 16-column tile, so four times as many CUs
+// share the step and each workgroup's chain is a quarter as long.
+//   LSTM: the 16 columns of a workgroup are 4 units x 4 gates — weights are stored fragment-major in that permuted
+//   row order ("pred.lstm{l}.w4": row ug*16 + gate*4 + u  <-  row gate*H + 4*ug + u), so the cell update still finds
+//   its four gates in one workgroup.
+__global__ __launch_bounds__(1024) void rnnt_lstm4_kernel(DecodeState st, int layer, int B, int H,
+                                                         const float* __restrict__ embed,
+                                                         const float* __restrict__ W4 /* fragment-major, permuted rows */,
+                                                         const float* __restrict__ bias /* [4H] = b_ih + b_hh */) {
+    __shared__ float part[SPLITK_LSTM][32][17];
+    __shared__ int rows_s[32];
+    const int n_act = st.counters[0];
+    const int rt = blockIdx.y, ug = blockIdx.x;
+    if (rt * 32 >= n_act) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 32) {
+        const int i = rt * 32 + tid;
+        rows_s[tid] = st.act[i < n_act ? i : n_act - 1];
+    }
+    __syncthreads();
+    const int li = lane & 15, kk = lane >> 4;
+    const int lr = lane >> 2, lc = lane & 3;
+    const int perm = 4 * (4 * li + kk);
+    const int K = 2 * H, kslice = K / SPLITK_LSTM, nkb = K / 16;
+    const float* xsrc[2];
+    const float* hsrc[2];
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri) {
+        const int row = rows_s[ri * 16 + lr];
+        xsrc[ri] = layer == 0 ? embed + (size_t)st.token[row] * H : st.h_tmp + ((size_t)(layer - 1) * B + row) * H;
+        hsrc[ri] = st.h + ((size_t)layer * B + row) * H;
+    }
+    const float* wfrag = W4 + ((size_t)ug * nkb) * 256 + lane * 4;
+    f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+    const int kbeg = wave * kslice, nblk = kslice / 16;
+    // every operand of the slice is requested up front (nblk <= 8: at most 24 float4 in flight per lane)
+    float4 av[2][8], wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nblk) {
+            const int k = kbeg + 16 * u + 4 * lc;
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri)
+                av[ri][u] = (k < H) ? *reinterpret_cast<const float4*>(xsrc[ri] + k) : *reinterpret_cast<const float4*>(hsrc[ri] + (k - H));
+            wv[u] = *reinterpret_cast<const float4*>(wfrag + (size_t)((kbeg >> 4) + u) * 256);
+        }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nblk) {
+            const float4 a0 = to_mfma_a_layout(av[0][u], perm), a1 = to_mfma_a_layout(av[1][u], perm);
+#define RS_MFMA_E(c)                                                                         \
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.c, wv[u].c, acc[0], 0, 0, 0);   \
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.c, wv[u].c, acc[1], 0, 0, 0);
+            RS_MFMA_E(x) RS_MFMA_E(y) RS_MFMA_E(z) RS_MFMA_E(w)
+#undef RS_MFMA_E
+        }
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][ri * 16 + 4 * kk + r][li] = acc[ri][r];
+    __syncthreads();
+    if (tid >= 128) return;                               // thread = (row i, unit u4)
+    const int i = tid >> 2, u4 = tid & 3;
+    if (rt * 32 + i >= n_act) return;
+    const int brow = rows_s[i];
+    const int unit = ug * 4 + u4;
+    float z[4];
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) {
+        float sm = part[0][i][gt * 4 + u4];
+#pragma unroll
+        for (int sl = 1; sl < SPLITK_LSTM; ++sl) sm = sm + part[sl][i][gt * 4 + u4];
+        z[gt] = sm + bias[gt * H + unit];
+    }
+    const float ig = rs_sigmoidf(z[0]), fg = rs_sigmoidf(z[1]), gg = rs_tanhf(z[2]), og = rs_sigmoidf(z[3]);
+    const size_t o = ((size_t)layer * B + brow) * H + unit;
+    const float cn = fmaf(fg, st.c[o], ig * gg);
+    st.c_tmp[o] = cn;
+    st.h_tmp[o] = og * rs_tanhf(cn);
+}
+
+// prediction projection g = W_p . h_top + b_p over the `act` rows, one 16-column tile per workgroup, the 8 K slices
+// on its 8 waves; the workgroups of column tile 0 also commit the new LSTM state of their rows
+__global__ __launch_bounds__(512) void rnnt_pred16_kernel(DecodeState st, int B, int L, int H, int N /* = J */,
+                                                         const float* __restrict__ W, const float* __restrict__ bias) {
+    __shared__ float part[SPLITK_TILE][32][17];
+    __shared__ int rows_s[32];
+    const int rt = blockIdx.y, ct = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_rows = st.counters[0];
+    if (rt * 32 >= n_rows) return;
+    if (tid < 32) {
+        const int i = rt * 32 + tid;
+        rows_s[tid] = st.act[i < n_rows ? i : n_rows - 1];
+    }
+    __syncthreads();
+    const int li = lane & 15, kk = lane >> 4;
+    const int lr = lane >> 2, lc = lane & 3;
+    const int perm = 4 * (4 * li + kk);
+    const int K = H, nkb = K / 16;
+    const float* asrc[2];
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri) asrc[ri] = st.h_tmp + ((size_t)(L - 1) * B + rows_s[ri * 16 + lr]) * H;
+    const float* wfrag = W + ((size_t)ct * nkb) * 256 + lane * 4;
+    f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+    const int kslice = K / SPLITK_TILE, kbeg = wave * kslice, nblk = kslice / 16;
+    float4 av[2][8], wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nblk) {
+            const int k = kbeg + 16 * u + 4 * lc;
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri) av[ri][u] = *reinterpret_cast<const float4*>(asrc[ri] + k);
+            wv[u] = *reinterpret_cast<const float4*>(wfrag + (size_t)((kbeg >> 4) + u) * 256);
+        }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nblk) {
+            const float4 a0 = to_mfma_a_layout(av[0][u], perm), a1 = to_mfma_a_layout(av[1][u], perm);
+#define RS_MFMA_E(c)                                                                         \
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.c, wv[u].c, acc[0], 0, 0, 0);   \
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.c, wv[u].c, acc[1], 0, 0, 0);
+            RS_MFMA_E(x) RS_MFMA_E(y) RS_MFMA_E(z) RS_MFMA_E(w)
+#undef RS_MFMA_E
+        }
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][ri * 16 + 4 * kk + r][li] = acc[ri][r];
+    __syncthreads();
+    const int i = tid >> 4, c = tid & 15;                 // thread = (row i, column c)
+    const bool row_ok = rt * 32 + i < n_rows;
+    const int brow = rows_s[i];
+    const int v = ct * 16 + c;
+    if (row_ok && v < N) {
+        float sm = part[0][i][c];
+#pragma unroll
+        for (int sl = 1; sl < SPLITK_TILE; ++sl) sm = sm + part[sl][i][c];
+        st.g[(size_t)brow * N + v] = sm + bias[v];
+    }
+    if (row_ok) {
+        // commit this row's new LSTM state: the column tiles share the H units of every layer
+        const int nct = gridDim.x;
+        for (int l = 0; l < L; ++l)
+            for (int u = ct * 16 + c; u < H; u += nct * 16) {
+                const size_t o = ((size_t)l * B + brow) * H + u;
+                st.h[o] = st.h_tmp[o];
+                st.c[o] = st.c_tmp[o];
+            }
+    }
+}
+
+// a = relu(f[b][t_b] + g[b]) of every alive slot, once per step: bf16 copy for the screening GEMM and ||a||_2
+__global__ __launch_bounds__(256) void rnnt_prep_kernel(DecodeState st, const float* __restrict__ f, int B, int Tp, int J,
+                                                        int step) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // the lists this step's verify kernel will build
+        st.counters[0] = 0;
+        st.counters[2 + ((step + 1) & 1)] = 0;
+    }
+    if (slot >= st.counters[2 + (step & 1)]) return;
+    const int b = st.alive[(size_t)(step & 1) * B + slot];
+    int t = st.tcur[b];
+    t = t < Tp ? t : Tp - 1;
+    const float* fr = f + ((size_t)b * Tp + t) * J;
+    const float* gr = st.g + (size_t)b * J;
+    float ss = 0.0f;
+    for (int k = 4 * lane; k < J; k += 256) {
+        const float4 fv = *reinterpret_cast<const float4*>(fr + k), gv = *reinterpret_cast<const float4*>(gr + k);
+        const float a0 = fmaxf(fv.x + gv.x, 0.0f), a1 = fmaxf(fv.y + gv.y, 0.0f), a2 = fmaxf(fv.z + gv.z, 0.0f),
+                    a3 = fmaxf(fv.w + gv.w, 0.0f);
+        ss = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, fmaf(a3, a3, ss))));
+        *reinterpret_cast<u16x4_t*>(st.a16 + (size_t)slot * J + k) = pack_bf16x4(a0, a1, a2, a3);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) st.anorm[slot] = sqrtf(ss) * 1.0001f;        // any summation order is fine: the bound has slack
+}
+
+// screening GEMM of the joint (see "screened joint" below):
+//   workgroup (column group of 64, 32 alive slots): the slots' bf16 operand rows -> LDS, then
+//   z~[slot][v] = a . W16[v] + b_pad[v] on v_mfma_f32_16x16x32_bf16, one 16-column tile per wave.
+__global__ __launch_bounds__(256) void rnnt_screen_kernel(DecodeState st, const float* __restrict__ f, int B, int Tp, int J,
+                                                          int Vpad, const uint16_t* __restrict__ W16,
+                                                          const float* __restrict__ bpad, int step) {
+    extern __shared__ __attribute__((aligned(16))) char scr_smem[];
+    const int ldrow = J * 2 + 16;                         // bytes per row: +16 keeps the 16-row fragment reads conflict free
+    const int ct = blockIdx.x, rt = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_alive = st.counters[2 + (step & 1)];
+    if (rt * 32 >= n_alive) return;
+    // the wave's weight fragments do not depend on the rows: request them first (J / 32 <= 20 k-steps of 16 bytes)
+    const int col0 = (ct * 4 + wave) * 16;
+    const bool has_cols = col0 < Vpad;
+    const int li = lane & 15, kc = lane >> 4;
+    const int nks = J / 32;
+    const uint16_t* wrow = W16 + (size_t)((has_cols ? col0 : 0) + li) * J + kc * 8;
+    bf16x8_t wf[20];
+#pragma unroll
+    for (int q = 0; q < 20; ++q)
+        if (q < nks) wf[q] = *reinterpret_cast<const bf16x8_t*>(wrow + q * 32);
+    const float bv = bpad[(has_cols ? col0 : 0) + li];
+    // the bf16 operand rows of this row tile (built once per step by rnnt_prep_kernel): 16-byte pieces into LDS
+    {
+        const int per_row = J / 8;                        // 16-byte pieces per row
+        for (int idx = tid; idx < 32 * per_row; idx += 256) {
+            const int r = idx / per_row, c = idx - r * per_row;
+            const int i = rt * 32 + r;
+            const uint4 v = *reinterpret_cast<const uint4*>(st.a16 + (size_t)(i < n_alive ? i : n_alive - 1) * J + c * 8);
+            *reinterpret_cast<uint4*>(scr_smem + r * ldrow + c * 16) = v;
+        }
+    }
+    __syncthreads();
+    if (!has_cols) return;
+    f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int q = 0; q < 20; ++q)
+        if (q < nks) {
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri) {
+                const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(scr_smem + (ri * 16 + li) * ldrow + (q * 32 + kc * 8) * 2);
+                acc[ri] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[q], acc[ri], 0, 0, 0);
+            }
+        }
+    // D: lane = (column li, rows 4*kc + r)
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int slot = rt * 32 + ri * 16 + 4 * kc + r;
+            if (slot < n_alive) st.zapprox[(size_t)slot * Vpad + col0 + li] = acc[ri][r] + bv;
+        }
+}
+
+// ---- screened joint ---------------------------------------------------------------------------------------
+// The joint's output layer (640 -> 3001 per row and step, 0.98 GFLOP at 256 rows) is two thirds of the decode
+// loop's work when it runs in exact float32.  Greedy decoding only needs its ARGMAX, so the exact evaluation is
+// restricted to the columns that can possibly win:
+//   1. rnnt_screen_kernel a = relu(f[b][t_b] + g[b]) per alive row (bf16 tile in LDS, ||a||_2), then
+//                         z~ = bf16(a) . bf16(W_o)^T + b_o   (bf16 MFMA, f32 accumulate: 1/16 of the f32 MFMA cost)
+//   2. rnnt_verify_kernel per row: m = max z~; every column with z~_v >= m - 2 eps is a candidate, where
+//        |z~_v - z_v| <= eps = 2^-7 * 1.25 * ||a|| * max_v ||w_v||
+//      (bf16 rounding of both operands is <= 2^-8 relative each, the products are exact in f32, Cauchy-Schwarz bounds
+//      sum |a_k w_vk|, the factor 1.25 covers the f32 accumulation error of both sums).  The true argmax of the exact
+//      logits is therefore always a candidate; each candidate's logit is then recomputed in EXACT float32 with the
+//      accumulation order documented at the top of this file, and the argmax (lowest index on ties) of those exact
+//      values is taken.  The result is bit-identical to evaluating all 3001 columns exactly (oracle/rnnt_greedy.c);
+//      the number of candidates only changes the cost (typically 1-3; every column in the worst case).
+//   The same kernel then runs the greedy state machine for the row (emit / advance / work lists).
+template <int NCH>   // NCH * 64 >= V: the row's approximate logits live in registers
+__global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const float* __restrict__ f,
+                                                          const int32_t* __restrict__ enc_lens, int B, int Tp, int J, int V,
+                                                          int Vpad, const float* __restrict__ Wrm /* [V][J] */,
+                                                          const float* __restrict__ bo, const float* __restrict__ wmax, int blank,
+                                                          int max_symbols, int u_max, int step, int32_t* __restrict__ ids,
+                                                          int32_t* __restrict__ frames, int32_t* __restrict__ n_ids) {
+    extern __shared__ __attribute__((aligned(16))) char ver_smem[];          // [4 waves][J] float: the exact a = relu(f + g)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
+    const int n_alive = st.counters[2 + (step & 1)];
+    if (slot >= n_alive) return;
+    const int b = st.alive[(size_t)(step & 1) * B + slot];
+    const float* z = st.zapprox + (size_t)slot * Vpad;
+    float zr[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) zr[c] = (c * 64 + lane < V) ? z[c * 64 + lane] : -INFINITY;
+    int t = st.tcur[b];
+    const int tc = t < Tp ? t : Tp - 1;
+    const float* fr = f + ((size_t)b * Tp + tc) * J;
+    const float* gr = st.g + (size_t)b * J;
+    float* a_s = reinterpret_cast<float*>(ver_smem) + wave * J;
+    for (int k = 4 * lane; k < J; k += 256) {
+        const float4 fv = *reinterpret_cast<const float4*>(fr + k), gv = *reinterpret_cast<const float4*>(gr + k);
+        *reinterpret_cast<float4*>(a_s + k) = make_float4(fmaxf(fv.x + gv.x, 0.0f), fmaxf(fv.y + gv.y, 0.0f),
+                                                          fmaxf(fv.z + gv.z, 0.0f), fmaxf(fv.w + gv.w, 0.0f));
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) m = fmaxf(m, zr[c]);
+    m = wave_max(m);
+    // 2 eps = 2 * 2^-7 * 1.25 * ||a|| * max_v ||w_v||  (wmax[0] holds the largest row norm of W_o, rounded up)
+    const float thr = m - 0.01953125f * wmax[0] * st.anorm[slot];
+    const int cgrp = lane >> 3, sl = lane & 7;                    // 8 candidates per pass x 8 K slices
+    const int kslice = J / SPLITK_TILE, nblk = kslice / 16;       // nblk <= 8 (launcher)
+    // candidate columns, ascending, compacted into LDS (the unrolled part stays tiny: the exact evaluation
+    // below exists once in the instruction stream)
+    int* cand_s = reinterpret_cast<int*>(ver_smem + 4 * J * 4) + wave * (NCH * 64);
+    int n_cand = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool is = zr[c] >= thr;                             // -inf padding never passes (thr is finite)
+        const unsigned long long mask = __ballot(is);
+        if (is) cand_s[n_cand + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = c * 64 + lane;
+        n_cand += __builtin_popcountll(mask);
+    }
+    float best = -INFINITY;
+    int best_idx = 0x7fffffff;
+    for (int c0 = 0; c0 < n_cand; c0 += 8) {                      // wave-uniform trip count
+        const bool valid = c0 + cgrp < n_cand;
+        const int cand = valid ? cand_s[c0 + cgrp] : 0;
+        const float* w = Wrm + (size_t)cand * J + sl * kslice;
+        const float* as = a_s + sl * kslice;
+        float4 wv[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < nblk) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) wv[u][kk] = *reinterpret_cast<const float4*>(w + 16 * u + 4 * kk);
+            }
+        float acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < nblk) {
+                // a 16-block: float4 loads give (e = 0..3) of each kk; the chain runs e-major, kk-minor
+                float4 av[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) av[kk] = *reinterpret_cast<const float4*>(as + 16 * u + 4 * kk);
+#define RS_CHAIN_E(cc) _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) acc = fmaf(av[kk].cc, wv[u][kk].cc, acc);
+                RS_CHAIN_E(x) RS_CHAIN_E(y) RS_CHAIN_E(z) RS_CHAIN_E(w)
+#undef RS_CHAIN_E
+            }
+        // partial chains combined left to right by the group's first lane, then + bias
+        float sum = __shfl(acc, lane & ~7, 64);
+#pragma unroll
+        for (int q = 1; q < SPLITK_TILE; ++q) sum = sum + __shfl(acc, (lane & ~7) + q, 64);
+        float val = valid ? sum + bo[cand] : -INFINITY;
+        int idx = valid ? cand : 0x7fffffff;
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {                  // argmax over the 8 groups (exact values, lowest index on ties)
+            const float ov = __shfl_xor(val, off, 64);
+            const int oi = __shfl_xor(idx, off, 64);
+            if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+        }
+        if (val > best || (val == best && idx < best_idx)) { best = val; best_idx = idx; }
+    }
+    if (lane != 0) return;
+    // greedy state machine (identical to rnnt_finalize_kernel)
+    const int idx = best_idx;
+    int sy = st.sym[b];
+    bool emitted = false;
+    if (idx == blank || idx == 0x7fffffff) {
+        t += 1; sy = 0;
+    } else {
+        const int n = n_ids[b];
+        if (n < u_max) { ids[(size_t)b * u_max + n] = idx; frames[(size_t)b * u_max + n] = t; n_ids[b] = n + 1; }
+        else st.counters[1] = 1;
+        st.token[b] = idx;
+        emitted = true;
+        sy += 1;
+        if (sy >= max_symbols) { t += 1; sy = 0; }
+    }
+    st.tcur[b] = t; st.sym[b] = sy;
+    if (t < enc_lens[b]) {
+        const int pos = atomicAdd(&st.counters[2 + ((step + 1) & 1)], 1);
+        st.alive[(size_t)((step + 1) & 1) * B + pos] = b;
+        if (emitted) { const int pa = atomicAdd(&st.counters[0], 1); st.act[pa] = b; }
+    }
+}
+
 }  // namespace
 
 // --------------------------------------------------------------------------------------------------
@@ -414,6 +783,8 @@ size_t rs_rnnt_workspace_bytes(const rs_ctx* ctx, int B) {
     n += 6 * rs_align((size_t)B * 4);
     n += rs_align(64);
     n += 2 * rs_align((size_t)B * nct * 4);
+    const size_t vpad = (size_t)(d.n_logits + 15) / 16 * 16;
+    n += rs_align((size_t)B * J * 2) + rs_align((size_t)B * 4) + rs_align((size_t)B * vpad * 4);   // screened joint
     return n + 1024;
 }
 
@@ -439,6 +810,12 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     st.alive = (int32_t*)take((size_t)2 * B * 4);
     st.counters = (int32_t*)take(64);
     st.pmax = (float*)take((size_t)B * nct * 4); st.pidx = (int32_t*)take((size_t)B * nct * 4);
+    const int Vpad = (V + 15) / 16 * 16;
+    st.a16 = (uint16_t*)take((size_t)B * J * 2); st.anorm = (float*)take((size_t)B * 4);
+    st.zapprox = (float*)take((size_t)B * Vpad * 4);
+    // the screened joint keeps a row's logits (<= 48 x 64) and a K slice (<= 8 blocks of 16) in registers, J / 32 <= 20 weight fragments
+    const bool screen = ctx->decode_screen && ctx->jout_w16 && ctx->jout_wrm && ctx->jout_bpad && ctx->jout_wmax && V <= 48 * 64 &&
+                        J / SPLITK_TILE / 16 <= 8 && J / 32 <= 20;
 
     const int rtiles = (B + 31) / 32;
     constexpr int LSTM_LDS = SPLITK_LSTM * 4 * 32 * 16 * 4 + 32 * 4;
@@ -446,11 +823,27 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_lstm_kernel, LSTM_LDS); rc != RS_OK) return rc;
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<0>, TILE_LDS); rc != RS_OK) return rc;
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<1>, TILE_LDS); rc != RS_OK) return rc;
-    auto lstm_and_pred = [&]() {
+    bool narrow = true;                                   // narrow-tile LSTM / projection kernels (need the permuted weights)
+    for (int l = 0; l < L; ++l) narrow = narrow && ctx->lstm_w4[l] != nullptr;
+    narrow = narrow && 2 * H / SPLITK_LSTM / 16 <= 8 && H / SPLITK_TILE / 16 <= 8;   // the kernels keep a whole K slice in registers
+    {
+        const char* e = getenv("RS_DECODE_NARROW");       // A/B knob: 0 = the wide-tile kernels of round 1
+        if (e && atoi(e) == 0) narrow = false;
+    }
+    auto lstm_and_pred = [&](int rows_bound) {
+        const int rts = (rows_bound + 31) / 32 > 0 ? (rows_bound + 31) / 32 : 1;
+        if (narrow) {
+            for (int l = 0; l < L; ++l)
+                hipLaunchKernelGGL(rnnt_lstm4_kernel, dim3(H / 4, rts), dim3(1024), 0, s, st, l, B, H, ctx->embed, ctx->lstm_w4[l],
+                                   ctx->lstm_b[l]);
+            hipLaunchKernelGGL(rnnt_pred16_kernel, dim3((J + 15) / 16, rts), dim3(512), 0, s, st, B, L, H, J, ctx->jpred_w,
+                               ctx->jpred_b);
+            return;
+        }
         for (int l = 0; l < L; ++l)
-            hipLaunchKernelGGL(rnnt_lstm_kernel, dim3(H / 16, rtiles), dim3(1024), LSTM_LDS, s, st, l, B, H, ctx->embed,
+            hipLaunchKernelGGL(rnnt_lstm_kernel, dim3(H / 16, rts), dim3(1024), LSTM_LDS, s, st, l, B, H, ctx->embed,
                                ctx->lstm_w[l], ctx->lstm_b[l]);
-        hipLaunchKernelGGL(rnnt_tile_kernel<0>, dim3((J + 63) / 64, rtiles), dim3(512), TILE_LDS, s, st, (const float*)nullptr, B,
+        hipLaunchKernelGGL(rnnt_tile_kernel<0>, dim3((J + 63) / 64, rts), dim3(512), TILE_LDS, s, st, (const float*)nullptr, B,
                            0, L, H, H, J, ctx->jpred_w, ctx->jpred_b, 0, 0);
     };
 
@@ -458,26 +851,44 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     RS_HIP(ctx, hipMemsetAsync(st.h, 0, 2 * rs_align(state_bytes), s));   // h and c are adjacent
     RS_HIP(ctx, hipMemsetAsync(st.g, 0, (size_t)B * J * 4, s));
     hipLaunchKernelGGL(rnnt_init_kernel, dim3(1), dim3(256), 0, s, st, enc_lens, B, d.blank_id, n_ids);
-    lstm_and_pred();  // SOS: blank token, zero state, all rows
+    lstm_and_pred(B);  // SOS: blank token, zero state, all rows
     RS_CHECK_LAUNCH(ctx, "rnnt init");
 
     const int max_steps = tp_max + (u_max < tp_max * d.max_symbols ? u_max : tp_max * d.max_symbols) + 1;
     const int CHUNK = 16;
     int32_t host_counters[4] = {0, 0, 0, 0};
-    int steps = 0;
+    int steps = 0, alive_bound = B;
     bool finished = false;
     while (!finished && steps < max_steps) {
         for (int c = 0; c < CHUNK; ++c, ++steps) {
-            hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(nct, rtiles), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H, J,
-                               V, ctx->jout_w, ctx->jout_b, nct, steps);
-            hipLaunchKernelGGL(rnnt_finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, st, enc_lens, B, nct,
-                               d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
-            lstm_and_pred();
+            // rows still decoding never increase: the count read back after the previous chunk bounds this one
+            const int rows = alive_bound < B ? alive_bound : B;
+            if (screen) {
+                const int rts = (rows + 31) / 32 > 0 ? (rows + 31) / 32 : 1;
+                hipLaunchKernelGGL(rnnt_prep_kernel, dim3((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1), dim3(256), 0, s, st, joint_enc, B,
+                                   tp_max, J, steps);
+                hipLaunchKernelGGL(rnnt_screen_kernel, dim3((Vpad + 63) / 64, rts), dim3(256), 32 * (J * 2 + 16), s, st, joint_enc, B,
+                                   tp_max, J, Vpad, ctx->jout_w16, ctx->jout_bpad, steps);
+                const dim3 vg((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1);
+                if (V <= 64 * 8)
+                    hipLaunchKernelGGL(rnnt_verify_kernel<8>, vg, dim3(256), 4 * J * 4 + 4 * 8 * 64 * 4, s, st, joint_enc, enc_lens, B, tp_max, J, V, Vpad,
+                                       ctx->jout_wrm, ctx->jout_b, ctx->jout_wmax, d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
+                else
+                    hipLaunchKernelGGL(rnnt_verify_kernel<48>, vg, dim3(256), 4 * J * 4 + 4 * 48 * 64 * 4, s, st, joint_enc, enc_lens, B, tp_max, J, V, Vpad,
+                                       ctx->jout_wrm, ctx->jout_b, ctx->jout_wmax, d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
+            } else {
+                hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(nct, rtiles), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H, J,
+                                   V, ctx->jout_w, ctx->jout_b, nct, steps);
+                hipLaunchKernelGGL(rnnt_finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, st, enc_lens, B, nct,
+                                   d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
+            }
+            lstm_and_pred(rows);
         }
         RS_CHECK_LAUNCH(ctx, "rnnt step");
         RS_HIP(ctx, hipMemcpyAsync(host_counters, st.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         RS_HIP(ctx, hipStreamSynchronize(s));
         finished = host_counters[2 + (steps & 1)] == 0;
+        alive_bound = host_counters[2 + (steps & 1)];
     }
     rs_prof_end(ctx, RS_PROF_DECODE, s);
     if (host_counters[1]) return rs_fail(ctx, RS_EOVERFLOW, "rnnt: an utterance emitted more than u_max=%d tokens", u_max);

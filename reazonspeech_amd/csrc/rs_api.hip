@@ -1,6 +1,7 @@
 // rs_api.hip — the C ABI of librs_asr.so (include/rs_asr.h): context, weight registry, workspace
 // carving and the stage orchestrators that enqueue the kernels of k_*.hip on the caller's stream.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -184,6 +185,28 @@ int rs_finalize(rs_ctx* ctx) {
     r.get("joint.pred.w", J * H, ctx->jpred_w); r.get("joint.pred.b", J, ctx->jpred_b);
     r.get("joint.out.w", ((V + 15) / 16 * 16) * J, ctx->jout_w); r.get("joint.out.b", V, ctx->jout_b);   // fragment-major, rows padded to 16
     if (r.rc != RS_OK) return r.rc;
+    // optional: the screened joint's operands (bf16 [Vpad][J] row-major, f32 [V][J] row-major, bias padded with -3e38,
+    // the largest row norm).  All four or none; without them the decode loop evaluates every column in exact f32.
+    {
+        const size_t Vpad = (V + 15) / 16 * 16;
+        const bool any = ctx->tensors.count("joint.out.w16") || ctx->tensors.count("joint.out.wrm") ||
+                         ctx->tensors.count("joint.out.bpad") || ctx->tensors.count("joint.out.wmax");
+        ctx->jout_w16 = nullptr; ctx->jout_wrm = ctx->jout_bpad = ctx->jout_wmax = nullptr;
+        if (any) {
+            r.get("joint.out.w16", Vpad * J, ctx->jout_w16);
+            r.get("joint.out.wrm", V * J, ctx->jout_wrm);
+            r.get("joint.out.bpad", Vpad, ctx->jout_bpad);
+            r.get("joint.out.wmax", (size_t)4, ctx->jout_wmax);
+            if (r.rc != RS_OK) return r.rc;
+        }
+        for (int l = 0; l < d.pred_layers; ++l) {
+            const std::string nm = "pred.lstm" + std::to_string(l) + ".w4";
+            ctx->lstm_w4[l] = nullptr;
+            if (ctx->tensors.count(nm)) { r.get(nm, 4 * H * 2 * H, ctx->lstm_w4[l]); if (r.rc != RS_OK) return r.rc; }
+        }
+        const char* e = getenv("RS_DECODE_SCREEN");       // A/B knob: 0 = exact evaluation of every column
+        ctx->decode_screen = !(e && atoi(e) == 0);
+    }
     auto it = ctx->tensors.find("pos.table");
     if (it == ctx->tensors.end()) return rs_fail(ctx, RS_EMISSING, "weight tensor 'pos.table' was not registered");
     const size_t rowb = dm * sizeof(uint16_t);
@@ -204,6 +227,7 @@ int rs_finalize(rs_ctx* ctx) {
 
 int rs_set_option(rs_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return RS_EINVAL;
+    if (!strcmp(key, "decode_screen")) { ctx->decode_screen = value != 0; return RS_OK; }
     if (!strcmp(key, "gemm_reserved_cus")) {
         if (value < -1 || value > 248) return rs_fail(ctx, RS_EINVAL, "gemm_reserved_cus must be -1 .. 248");
         ctx->gemm_reserved_cus = value;

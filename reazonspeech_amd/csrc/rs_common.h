@@ -87,8 +87,13 @@ struct rs_ctx {
     std::vector<rs_layer_w> layers;
     const uint16_t* jenc_w = nullptr;
     const float* jenc_b = nullptr;
+    const float* lstm_w4[8] = {};   // optional "pred.lstm{l}.w4": fragment-major with rows permuted to (unit group, gate, unit)
     const float *embed = nullptr, *lstm_w[8] = {}, *lstm_b[8] = {}, *jpred_w = nullptr, *jpred_b = nullptr,
                 *jout_w = nullptr, *jout_b = nullptr;
+    // screened joint (optional tensors joint.out.w16 / .wrm / .bpad / .wmax; k_rnnt.hip)
+    const uint16_t* jout_w16 = nullptr;
+    const float *jout_wrm = nullptr, *jout_bpad = nullptr, *jout_wmax = nullptr;
+    bool decode_screen = true;
     // position table cache: the caller registers "pos_table.<T>" tensors (bf16 [2T-1][d])
     // options (rs_set_option)
     int n_cus = 0;                  // compute units of the device (queried on first use)

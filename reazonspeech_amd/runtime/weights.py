@@ -417,7 +417,13 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
     out["pred.embed"] = f32(sd["decoder.prediction.embed.weight"])
     P = "decoder.prediction.dec_rnn.lstm."
     for l in range(cfg.pred_layers):
-        out[f"pred.lstm{l}.w"] = to_fragment_major(torch.cat([sd[P + f"weight_ih_l{l}"], sd[P + f"weight_hh_l{l}"]], dim=1))
+        wl = torch.cat([sd[P + f"weight_ih_l{l}"], sd[P + f"weight_hh_l{l}"]], dim=1)
+        out[f"pred.lstm{l}.w"] = to_fragment_major(wl)
+        # narrow-tile LSTM kernel: rows regrouped so that a 16-row tile holds the 4 gates of 4 consecutive units
+        # (row ug*16 + gate*4 + u  <-  row gate*H + 4*ug + u)
+        Hh = cfg.pred_hidden
+        perm = torch.arange(4 * Hh).view(4, Hh // 4, 4).permute(1, 0, 2).reshape(-1)
+        out[f"pred.lstm{l}.w4"] = to_fragment_major(wl.to(torch.float32)[perm])
         out[f"pred.lstm{l}.b"] = f32(sd[P + f"bias_ih_l{l}"].float() + sd[P + f"bias_hh_l{l}"].float())
     out["joint.pred.w"] = to_fragment_major(sd["joint.pred.weight"])
     out["joint.pred.b"] = f32(sd["joint.pred.bias"])
@@ -431,6 +437,20 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
                                     f"({cfg.n_logits}, {cfg.joint_hidden}) (vocab_size + blank, joint_hidden)")
     out["joint.out.w"] = to_fragment_major(sd[jout + ".weight"])
     out["joint.out.b"] = f32(sd[jout + ".bias"])
+    # screened joint (k_rnnt.hip): bf16 copy for the screening GEMM (rows padded to a multiple of 16 with zeros, bias
+    # pad -3e38 so a padded column can never be a candidate), the float32 row-major copy the exact re-evaluation reads,
+    # and the largest row norm (rounded up: it scales an error BOUND)
+    wo = sd[jout + ".weight"].detach().to(torch.float32)
+    vpad = (cfg.n_logits + 15) // 16 * 16
+    w16 = torch.zeros((vpad, cfg.joint_hidden), dtype=torch.bfloat16)
+    w16[:cfg.n_logits] = wo.to(torch.bfloat16)
+    bpad = torch.full((vpad,), -3.0e38, dtype=torch.float32)
+    bpad[:cfg.n_logits] = sd[jout + ".bias"].detach().to(torch.float32)
+    out["joint.out.w16"] = w16.contiguous()
+    out["joint.out.wrm"] = wo.contiguous()
+    out["joint.out.bpad"] = bpad
+    wmax = float(wo.double().norm(dim=1).max()) * (1.0 + 2.0 ** -10)
+    out["joint.out.wmax"] = torch.tensor([wmax, 0.0, 0.0, 0.0], dtype=torch.float32)
     out["pos.table"] = torch.from_numpy(rel_pos_table(cfg, pos_cap)).to(torch.bfloat16).contiguous()
     # anything under the model's own prefixes that was NOT consumed means the checkpoint holds parameters of a
     # variant this path does not compute (e.g. self_attn.global_q/k/v, conv.layer_norm, a second joint layer):
