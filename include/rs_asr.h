@@ -132,6 +132,13 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
                        float* enc_out, float* joint_enc, int32_t* enc_lens,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* A HIP stream restricted to a set of compute units (bit i of cu_mask = CU i may run this stream's workgroups;
+ * hipExtStreamCreateWithCUMask), or, with cu_mask == NULL, a plain non-blocking stream of the given priority.
+ * The two-stage pipeline can confine the latency-bound decode loop to a slice of the chip so that its many small
+ * launches stop delaying the encoder GEMMs' tile rounds on the other CUs.  No reference counterpart. */
+int rs_stream_create(void** stream_out, int device, const uint32_t* cu_mask, int n_words, int priority);
+int rs_stream_destroy(void* stream);
+
 /* Scheduling options of a context (no reference counterpart).
  *   "gemm_reserved_cus"  compute units the persistent GEMM grid leaves free for work on OTHER streams (the
  *                        two-stage pipeline runs batch i's greedy decode next to batch i+1's encoder; a GEMM

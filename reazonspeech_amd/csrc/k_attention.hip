@@ -240,8 +240,33 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
         return acc;
     };
 
+    // ---- limited context (WINDOW): only the key blocks a query block can see are visited, so the cost is
+    // O(T * (left + right)) instead of O(T^2) — what makes hour-long single utterances (the reference hands a whole
+    // file to the model: pkg/nemo-asr/src/transcribe.py:44-53) affordable.  A workgroup skips the staging of key
+    // chunks none of its query blocks needs; a wave skips the blocks outside its own window.  Blocks holding
+    // global keys (j < n_global) are always visited, and query blocks holding global queries visit everything.
+    int wg_lo = 0, wg_hi = n_kblocks - 1, w_lo = 0, w_hi = n_kblocks - 1, gb_hi = -1;
+    if constexpr (WINDOW) {
+        const int wq_lo = blockIdx.x * nw * 32;
+        int wq_hi = wq_lo + nw * 32 - 1;
+        wq_hi = wq_hi < T - 1 ? wq_hi : T - 1;
+        gb_hi = p.n_global > 0 ? (p.n_global - 1) >> 5 : -1;
+        if (!(p.n_global > 0 && wq_lo < p.n_global)) {
+            if (p.att_left >= 0) { const int lo = wq_lo - p.att_left; wg_lo = lo > 0 ? lo >> 5 : 0; }
+            if (p.att_right >= 0) { const int hi = (wq_hi + p.att_right) >> 5; wg_hi = hi < wg_hi ? hi : wg_hi; }
+        }
+        if (!(p.n_global > 0 && i0 < p.n_global)) {
+            if (p.att_left >= 0) { const int lo = i0 - p.att_left; w_lo = lo > 0 ? lo >> 5 : 0; }
+            if (p.att_right >= 0) { const int hi = (i0 + 31 + p.att_right) >> 5; w_hi = hi < w_hi ? hi : w_hi; }
+        }
+    }
+    auto chunk_needed = [&](int jc, int nb) { return !WINDOW || (jc <= wg_hi && jc + nb - 1 >= wg_lo) || jc <= gb_hi; };
+    auto block_needed = [&](int blk) { return !WINDOW || (blk >= w_lo && blk <= w_hi) || blk <= gb_hi; };
+
     // rows n0 .. n0+31 of the first key block; every later block reuses the previous block's upper half
+    // (bd_for = the key block whose lower half bd_lo currently holds)
     f32x16_t bd_lo = bd_block(0 - i0 - 31 + T - 1);
+    int bd_for = 0;
     stamp(bd_lo[0]);                               // [4] first position block
 
     // Keys are staged KB_CHUNK blocks at a time (all of them for T' <= 160): between two workgroup
@@ -249,6 +274,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     // other's L2 / LDS latencies instead of marching in lockstep.
     for (int jc = 0; jc < n_kblocks; jc += KB_CHUNK) {
         const int nb = n_kblocks - jc < KB_CHUNK ? n_kblocks - jc : KB_CHUNK;
+        if (!chunk_needed(jc, nb)) continue;      // workgroup-uniform
         if (jc > 0) {
             __syncthreads();                  // previous chunk fully consumed
             // later chunks (T' > 160 only) restage with everything live: one item at a time, 8 staging VGPRs
@@ -271,7 +297,9 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
         }
 
         for (int sl = 0; sl < nb; ++sl) {
+            if (!block_needed(jc + sl)) continue; // wave-uniform
             const int j0 = (jc + sl) * 32;
+            if (WINDOW && bd_for != jc + sl) bd_lo = bd_block(j0 - i0 - 31 + T - 1);   // blocks were skipped: rebuild the lower half
             const char* ks_t = Ks + sl * K_BYTES;
             const char* vts_t = Vts + sl * VT_BYTES;
 
@@ -332,6 +360,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
             __builtin_amdgcn_wave_barrier();  // scratch reads done before the next block overwrites it
             stamp(pr[0]);                          // [7+5k] skew + masked scores
             bd_lo = bd_hi;
+            bd_for = jc + sl + 1;
             mblk = fmaxf(mblk, __shfl_xor(mblk, 32, 64));
             const float m_new = fmaxf(m_run, mblk);
             const float alpha = __expf(m_run - m_new);

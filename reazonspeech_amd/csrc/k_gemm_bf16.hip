@@ -1084,7 +1084,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pmf16_kernel(GemmParams p) {
 //   * the ring keeps running across the tiles of a persistent workgroup exactly as in gemm_pmf16_kernel.
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 
-template <int BM, int OUT, bool MASK, int NM0>
+// ABL (profiling builds, wrong results): 1 = no MFMAs, 2 = no DMAs in the main loop, 3 = no fragment reads
+template <int BM, int OUT, bool MASK, int NM0, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
     constexpr int BN = 256, WN = 4, NWAVES = 8;
     constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -1183,11 +1184,13 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8_t bfr[NI], af[MI];
+                if (ABL != 3 || (t == 0 && ks == 0)) {
 #pragma unroll
-                for (int jj = 0; jj < NI; ++jj) bfr[jj] = frag(bt, wn * TN + jj * 16 + frow, ks * 4 + fch);
+                    for (int jj = 0; jj < NI; ++jj) bfr[jj] = frag(bt, wn * TN + jj * 16 + frow, ks * 4 + fch);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = frag(at, wm * TM + i * 16 + frow, ks * 4 + fch);
-                if (ks == 0 && more) {
+                    for (int i = 0; i < MI; ++i) af[i] = frag(at, wm * TM + i * 16 + frow, ks * 4 + fch);
+                }
+                if (ks == 0 && more && ABL != 2) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int qq = 0; qq < (NM0 < NP ? NM0 : NP); ++qq) dma(qq, tn, nbuf);
@@ -1201,10 +1204,13 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
                 constexpr int REST = NP - (NM0 < NP ? NM0 : NP);            // pieces issued between the MFMAs of phase (t, 0)
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
+                    if constexpr (ABL == 1) asm volatile("" :: "v"(af[i]), "v"(bfr[i & 3]));
+                    else {
 #pragma unroll
                     for (int jj = 0; jj < NI; ++jj)
                         acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
-                    if (REST > 0 && ks == 0 && i < REST && more) {
+                    }
+                    if (REST > 0 && ks == 0 && i < REST && more && ABL != 2) {
                         __builtin_amdgcn_sched_barrier(0);
                         dma(NP - REST + i, tn, nbuf);
                         __builtin_amdgcn_sched_barrier(0);
@@ -1227,7 +1233,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier at the start
 }
 
-template <int BM, int NM0>
+template <int BM, int NM0, int ABL = 0>
 int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
     constexpr int BN = 256;
     constexpr int LDS = 2 * (BM + BN) * 128 + 8 * 4096;
@@ -1240,6 +1246,11 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
     const int grid = nwg < grid_cap ? nwg : grid_cap;
     const int out = (p.flags & RS_GEMM_RESIDUAL) ? 2 : ((p.flags & RS_GEMM_OUT_F32) ? 1 : 0);
     const bool mask = p.flags & RS_GEMM_ROWMASK;
+    if constexpr (ABL != 0) {
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 0, false, NM0, ABL>, LDS); rc != RS_OK) return rc;
+        hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 0, false, NM0, ABL>), dim3(grid), dim3(512), LDS, s, p);
+        return RS_OK;
+    }
 #define RS_LMF(O, MK)                                                                                         \
     do {                                                                                                      \
         if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, O, MK, NM0>, LDS); rc != RS_OK) return rc; \
@@ -1464,6 +1475,9 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         case 50: rc = launch_lmf16<256, 8>(ctx, p, s, pgrid); break;
         case 52: rc = launch_lmf16<192, 8>(ctx, p, s, pgrid); break;
         case 60: rc = launch_lmf16<256, 5>(ctx, p, s, pgrid); break;
+        case 61: rc = launch_lmf16<256, 5, 1>(ctx, p, s, pgrid); break;          // ablations of 60 (wrong results)
+        case 63: rc = launch_lmf16<256, 5, 2>(ctx, p, s, pgrid); break;
+        case 65: rc = launch_lmf16<256, 5, 3>(ctx, p, s, pgrid); break;
         case 62: rc = launch_lmf16<192, 5>(ctx, p, s, pgrid); break;
         case 70: rc = launch_lmf16<256, 3>(ctx, p, s, pgrid); break;
         case 72: rc = launch_lmf16<192, 3>(ctx, p, s, pgrid); break;

@@ -225,6 +225,24 @@ int rs_finalize(rs_ctx* ctx) {
     return RS_OK;
 }
 
+int rs_stream_create(void** out, int device, const uint32_t* cu_mask, int n_words, int priority) {
+    if (!out) return RS_EINVAL;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return RS_EHIP;
+    hipStream_t s = nullptr;
+    hipError_t e;
+    if (cu_mask && n_words > 0) e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask);
+    else e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
+    if (e != hipSuccess) return RS_EHIP;
+    *out = (void*)s;
+    return RS_OK;
+}
+
+int rs_stream_destroy(void* stream) {
+    if (!stream) return RS_OK;
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? RS_OK : RS_EHIP;
+}
+
 int rs_set_option(rs_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return RS_EINVAL;
     if (!strcmp(key, "decode_screen")) { ctx->decode_screen = value != 0; return RS_OK; }

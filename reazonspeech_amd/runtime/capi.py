@@ -24,7 +24,7 @@ EXPORTS = [
     "rs_abi_version", "rs_create", "rs_destroy", "rs_last_error", "rs_set_tensor", "rs_finalize",
     "rs_workspace_bytes", "rs_mel_frames", "rs_enc_frames", "rs_frontend_logmel", "rs_encoder_forward",
     "rs_rnnt_greedy", "rs_profile_enable", "rs_profile_read", "rs_profile_reset", "rs_gemm_bf16",
-    "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_encoder_set_taps", "rs_set_option",
+    "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
 ]
 
 
@@ -89,6 +89,8 @@ def load():
     lib.rs_frontend_logmel.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_size_t, vp]
     lib.rs_encoder_forward.argtypes = [vp, vp, vp, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
     lib.rs_set_option.argtypes = [vp, c_char_p, c_int]
+    lib.rs_stream_create.argtypes = [POINTER(c_void_p), c_int, POINTER(ctypes.c_uint32), c_int, c_int]
+    lib.rs_stream_destroy.argtypes = [vp]
     lib.rs_encoder_set_taps.argtypes = [vp, vp, vp, POINTER(c_int32), c_int]
     lib.rs_rnnt_greedy.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
     lib.rs_profile_enable.argtypes = [vp, c_int]
@@ -111,6 +113,30 @@ def _ptr(t):
     if t is None:
         return None
     return c_void_p(t.data_ptr())
+
+
+def create_stream(device_index, n_cus=0, total_cus=256, priority=0):
+    """raw HIP stream handle (int) restricted to `n_cus` compute units spread evenly over the XCDs (0 = all CUs,
+    plain stream of the given priority).  The bit pattern keeps whole groups of 8 consecutive bits together and
+    spaces the groups, so both a round-robin and a blocked bit -> XCD numbering give every XCD the same share."""
+    lib = load()
+    out = c_void_p()
+    if n_cus and n_cus < total_cus:
+        words = (total_cus + 31) // 32
+        groups, want = total_cus // 8, max(1, n_cus // 8)
+        chosen = {int(round(k * groups / want)) for k in range(want)}
+        mask = [0] * words
+        for g in chosen:
+            for b in range(8):
+                i = g * 8 + b
+                mask[i // 32] |= 1 << (i % 32)
+        arr = (ctypes.c_uint32 * words)(*mask)
+        rc = lib.rs_stream_create(byref(out), int(device_index), arr, words, int(priority))
+    else:
+        rc = lib.rs_stream_create(byref(out), int(device_index), None, 0, int(priority))
+    if rc != RS_OK:
+        raise RsError(rc, "rs_stream_create failed")
+    return out.value
 
 
 class Context:
@@ -183,6 +209,10 @@ class Context:
         self.check(self.lib.rs_encoder_forward(self._h, _ptr(feats), _ptr(n_frames), B, t_max, _ptr(enc_out),
                                                _ptr(joint_enc), _ptr(enc_lens), _ptr(ws),
                                                ws.numel() * ws.element_size(), c_void_p(stream)))
+
+    def n_cus(self):
+        import torch
+        return int(torch.cuda.get_device_properties(self.device_index).multi_processor_count)
 
     def set_option(self, key, value):
         self.check(self.lib.rs_set_option(self._h, key.encode(), int(value)))

@@ -218,9 +218,15 @@ class AsrModel:
                 self._ctx_enc2 = self.ctx.clone()
                 self._enc2_stream = torch.cuda.Stream(device=self.device)
                 # the decode chain is latency-critical: its workgroups should take the first free slots
-                self._streams = (torch.cuda.Stream(device=self.device),
-                                 torch.cuda.Stream(device=self.device,
-                                                   priority=int(os.environ.get("RS_DECODE_PRIORITY", "-1"))))
+                dec_cus = int(os.environ.get("RS_DECODE_CUS", "0"))
+                dec_prio = int(os.environ.get("RS_DECODE_PRIORITY", "-1"))
+                if dec_cus > 0:
+                    # decode confined to a slice of the chip (A/B knob): raw HIP stream with a CU mask
+                    self._dec_raw = capi.create_stream(self.device.index, dec_cus, self.ctx.n_cus(), dec_prio)
+                    dec = torch.cuda.ExternalStream(self._dec_raw, device=self.device)
+                else:
+                    dec = torch.cuda.Stream(device=self.device, priority=dec_prio)
+                self._streams = (torch.cuda.Stream(device=self.device), dec)
             enc_stream, dec_stream = self._streams
             enc_stream.wait_stream(torch.cuda.current_stream())
             jobs: "queue.Queue" = queue.Queue()

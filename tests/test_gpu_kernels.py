@@ -215,7 +215,11 @@ def test_glu_dwconv_silu(ctx, gpu_device, T, lens):
 
 
 @pytest.mark.parametrize("T,lens,window", [(19, [19, 14], None), (138, [138, 97, 5], None), (64, [64, 33], None),
-                                           (300, [300, 160], None), (138, [138, 60], (32, 16, 1))])
+                                           (300, [300, 160], None), (138, [138, 60], (32, 16, 1)),
+                                           # limited context over many key chunks: block / chunk skipping (O(T * W)), with
+                                           # and without global tokens, asymmetric windows, a window wider than a chunk
+                                           (1400, [1400, 777], (128, 128, 1)), (1000, [1000, 333], (40, 200, 0)),
+                                           (900, [900, 650], (0, 0, 3)), (700, [700, 512], (300, 17, 0))])
 def test_relpos_attention(gpu_device, T, lens, window):
     cfg = TINY if window is None else TINY.with_(att_left=window[0], att_right=window[1], n_global=window[2])
     c = capi.Context(cfg, 0)

@@ -232,6 +232,39 @@ def test_long_form_audio_crosses_key_chunks(gpu_device):
     assert got.ids == [r[0] for r in ref] and got.frames == [r[1] for r in ref]
 
 
+def test_long_form_ten_minutes_limited_context(gpu_device):
+    """One 10-minute utterance through the whole path (the reference passes a whole file as one utterance,
+    pkg/nemo-asr/src/transcribe.py:44-53): T' = 7 507 frames — far past the 1024 rows the position tables start
+    with, so they grow on first use — with the limited-context attention variant ([128, 128] + one global token:
+    only ~9 of 235 key blocks are visited per query block).  Checked against the bf16-recipe oracle (which
+    materialises the full T' x T' score matrix with the same mask) and decoded bit-exactly."""
+    cfg = TINY.with_(att_left=128, att_right=128, n_global=1)
+    sd = synthetic_state_dict(cfg, 41, blank_bias=3.5)
+    model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device="cuda:0")
+    audio, lens = synthetic_batch(1, 600.0, seed=11)
+    assert model.pos_cap == 1024
+    buf = model.stage([audio[0]])
+    assert model.pos_cap >= buf.tp_max > 7000
+    enc = torch.zeros((1, buf.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
+    model.run_device(buf, want_enc=enc)
+    torch.cuda.synchronize()
+    padded = np.zeros((1, audio.shape[1] + 16000), np.float32)
+    padded[0, 8000:8000 + lens[0]] = audio[0]
+    taps = {}
+    f_ref, el = om.forward_to_joint(cfg, sd, torch.from_numpy(padded), torch.from_numpy(lens + 16000), "bf16", taps)
+    assert buf.enc_lens.cpu().tolist() == el.tolist()
+    n = int(el[0])
+    dlt = (enc.cpu()[0, :n] - taps["enc"][0, :n]).abs()
+    assert dlt.max() <= 8e-2 and dlt.mean() <= 8e-3, (dlt.max().item(), dlt.mean().item())
+    got = model.collect(buf)
+    ref = og.rnnt_greedy(cfg, sd, buf.joint_enc.cpu().numpy(), buf.enc_lens.cpu().numpy())
+    assert len(got.ids[0]) > 100
+    assert got.ids == [r[0] for r in ref] and got.frames == [r[1] for r in ref]
+    # a short clip afterwards still works on the grown tables
+    short = model.transcribe_waveforms([audio[0][:32000]])
+    assert short.ids[0] == model.transcribe_waveforms([audio[0][:32000]]).ids[0]
+
+
 def test_python_boundary(tiny):
     model, _ = tiny
     audio, lens = synthetic_batch(2, 1.0, seed=1)
