@@ -18,67 +18,9 @@
 // Work lists keep the step cost proportional to the rows that still need it: the joint runs over
 // the rows still decoding (`alive`), the LSTM over the rows that just emitted a non-blank (`act`).
 // Tiles are [32 rows] x [64 columns] so that operands fetched from L2 are reused 2-4x in registers.
-#include "rs_common.h"
+#include "k_rnnt_common.h"
 
 namespace {
-
-constexpr int SPLITK_LSTM = 16;  // K slices of the LSTM gate products
-constexpr int SPLITK_TILE = 8;   // K slices of the joint / prediction projections
-
-// ---- exact-order math (mirrored verbatim in oracle/rnnt_greedy.c) --------------------------------
-__device__ __forceinline__ float rs_expf(float x) {
-    x = fminf(fmaxf(x, -87.0f), 88.0f);
-    const float n = rintf(x * 1.44269504088896341f);
-    float r = fmaf(n, -0.693359375f, x);
-    r = fmaf(n, 2.12194440e-4f, r);
-    float p = 1.9875691500e-4f;
-    p = fmaf(p, r, 1.3981999507e-3f);
-    p = fmaf(p, r, 8.3334519073e-3f);
-    p = fmaf(p, r, 4.1665795894e-2f);
-    p = fmaf(p, r, 1.6666665459e-1f);
-    p = fmaf(p, r, 5.0000001201e-1f);
-    const float r2 = r * r;
-    const float y = fmaf(p, r2, r) + 1.0f;
-    const int ni = (int)n;
-    return y * __uint_as_float((unsigned)(ni + 127) << 23);
-}
-__device__ __forceinline__ float rs_sigmoidf(float x) { return 1.0f / (1.0f + rs_expf(-x)); }
-__device__ __forceinline__ float rs_tanhf(float x) { return 1.0f - 2.0f / (rs_expf(2.0f * x) + 1.0f); }
-
-// Activation rows are gathered by index, so a lane-per-row load (what the MFMA A operand wants:
-// lane = row + 16*kk) would be 64 separate 16-byte requests per instruction and the texture
-// addresser, not the MFMA pipe, would set the pace.  Instead lane l loads (row l>>2, 16-byte chunk
-// l&3) — four adjacent lanes cover one contiguous 64-byte run — and one ds_bpermute per dword moves
-// the data to the MFMA layout: lane m = (li, kk) takes it from lane 4*li + kk.
-__device__ __forceinline__ float4 to_mfma_a_layout(float4 v, int src_lane_bytes) {
-    float4 r;
-    r.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_bytes, __float_as_int(v.x)));
-    r.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_bytes, __float_as_int(v.y)));
-    r.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_bytes, __float_as_int(v.z)));
-    r.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_bytes, __float_as_int(v.w)));
-    return r;
-}
-
-struct DecodeState {
-    // per-row state (B rows)
-    float* h;        // [L][B][H] committed hidden
-    float* c;        // [L][B][H] committed cell
-    float* h_tmp;    // [L][B][H] this step's new hidden (rows that emitted only)
-    float* c_tmp;    // [L][B][H]
-    float* g;        // [B][J]   prediction-net output after joint.pred
-    int32_t* tcur;   // [B] encoder frame pointer
-    int32_t* sym;    // [B] symbols emitted at the current frame
-    int32_t* token;  // [B] last emitted token (LSTM input)
-    int32_t* act;    // [B] rows that emitted a non-blank this step (LSTM work list)
-    int32_t* alive;  // [2][B] rows still decoding; list (s&1) is read by step s, (s+1)&1 is built by it
-    int32_t* counters;  // [0]=n_act [1]=overflow flag [2],[3]=n_alive of list 0 / 1
-    float* pmax;     // [B][n_ctiles] partial max
-    int32_t* pidx;   // [B][n_ctiles] partial argmax
-    // screened joint (see rnnt_prep_kernel / rnnt_verify_kernel)
-    uint16_t* a16;   // [B][J] bf16 relu(f + g) of alive slot i
-    float* anorm;    // [B]    ||relu(f + g)||_2 of alive slot i (rounded up)
-    float* zapprox;  // [B][Vpad] approximate logits of alive slot i (bf16 MFMA GEMM, f32 accumulate, + bias)
-};
 
 // ------------------------------------------------------------------------------------------------
 __global__ void rnnt_init_kernel(DecodeState st, const int32_t* __restrict__ enc_lens, int B, int blank,
@@ -773,6 +715,11 @@ __global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const 
 }  // namespace
 
 // --------------------------------------------------------------------------------------------------
+size_t rs_rnnt_persist_lds_bytes(int J);
+int rs_rnnt_persist_launch(rs_ctx* ctx, const void* st_ptr, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max,
+                           int u_max, int max_steps, int32_t* ids, int32_t* frames, int32_t* n_ids, unsigned* sync, int n_wgs,
+                           hipStream_t s);
+
 size_t rs_rnnt_workspace_bytes(const rs_ctx* ctx, int B) {
     const rs_dims& d = ctx->d;
     const int L = d.pred_layers, H = d.pred_hidden, J = d.joint_hidden;
@@ -826,10 +773,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     bool narrow = true;                                   // narrow-tile LSTM / projection kernels (need the permuted weights)
     for (int l = 0; l < L; ++l) narrow = narrow && ctx->lstm_w4[l] != nullptr;
     narrow = narrow && 2 * H / SPLITK_LSTM / 16 <= 8 && H / SPLITK_TILE / 16 <= 8;   // the kernels keep a whole K slice in registers
-    {
-        const char* e = getenv("RS_DECODE_NARROW");       // A/B knob: 0 = the wide-tile kernels of round 1
-        if (e && atoi(e) == 0) narrow = false;
-    }
+    narrow = narrow && ctx->decode_narrow;
     auto lstm_and_pred = [&](int rows_bound) {
         const int rts = (rows_bound + 31) / 32 > 0 ? (rows_bound + 31) / 32 : 1;
         if (narrow) {
@@ -851,10 +795,28 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     RS_HIP(ctx, hipMemsetAsync(st.h, 0, 2 * rs_align(state_bytes), s));   // h and c are adjacent
     RS_HIP(ctx, hipMemsetAsync(st.g, 0, (size_t)B * J * 4, s));
     hipLaunchKernelGGL(rnnt_init_kernel, dim3(1), dim3(256), 0, s, st, enc_lens, B, d.blank_id, n_ids);
-    lstm_and_pred(B);  // SOS: blank token, zero state, all rows
+    if (!(ctx->decode_persist_wgs > 0 && screen && narrow)) lstm_and_pred(B);  // SOS: blank token, zero state, all rows (the persistent kernel does its own)
     RS_CHECK_LAUNCH(ctx, "rnnt init");
 
     const int max_steps = tp_max + (u_max < tp_max * d.max_symbols ? u_max : tp_max * d.max_symbols) + 1;
+    // ---- one persistent launch per batch (k_rnnt_persist.hip): needs the screened joint and the narrow-tile weights
+    int persist_wgs = ctx->decode_persist_wgs;
+    if (persist_wgs > 0 && screen && narrow) {
+        unsigned* sync = reinterpret_cast<unsigned*>(st.counters + 8);      // words 8..10 of the 16-word counter block
+        RS_HIP(ctx, hipMemsetAsync(sync, 0, 8 * sizeof(unsigned), s));
+        if (int rc = rs_rnnt_persist_launch(ctx, &st, joint_enc, enc_lens, B, tp_max, u_max, max_steps, ids, frames, n_ids, sync,
+                                            persist_wgs, s); rc != RS_OK) return rc;
+        RS_CHECK_LAUNCH(ctx, "rnnt persistent decode");
+        int32_t hc[16] = {0};
+        RS_HIP(ctx, hipMemcpyAsync(hc, st.counters, sizeof hc, hipMemcpyDeviceToHost, s));
+        RS_HIP(ctx, hipStreamSynchronize(s));
+        rs_prof_end(ctx, RS_PROF_DECODE, s);
+        if (hc[9] != 0) return rs_fail(ctx, RS_ESTATE, "rnnt: grid barrier of the persistent decode kernel timed out");
+        if (hc[1]) return rs_fail(ctx, RS_EOVERFLOW, "rnnt: an utterance emitted more than u_max=%d tokens", u_max);
+        if (hc[2] != 0 && hc[3] != 0) return rs_fail(ctx, RS_ESTATE, "rnnt: decode did not finish in %d steps", max_steps);
+        if (hc[2 + (hc[10] & 1)] != 0) return rs_fail(ctx, RS_ESTATE, "rnnt: decode did not finish in %d steps", max_steps);
+        return RS_OK;
+    }
     const int CHUNK = 16;
     int32_t host_counters[4] = {0, 0, 0, 0};
     int steps = 0, alive_bound = B;

@@ -206,6 +206,8 @@ int rs_finalize(rs_ctx* ctx) {
         }
         const char* e = getenv("RS_DECODE_SCREEN");       // A/B knob: 0 = exact evaluation of every column
         ctx->decode_screen = !(e && atoi(e) == 0);
+        if (const char* nw = getenv("RS_DECODE_NARROW")) ctx->decode_narrow = atoi(nw) != 0;         // A/B knob: 0 = the wide-tile kernels of round 1
+        if (const char* pw = getenv("RS_DECODE_PERSIST_WGS")) ctx->decode_persist_wgs = atoi(pw);   // A/B knob: > 0 = one persistent launch per batch
     }
     auto it = ctx->tensors.find("pos.table");
     if (it == ctx->tensors.end()) return rs_fail(ctx, RS_EMISSING, "weight tensor 'pos.table' was not registered");
@@ -246,6 +248,12 @@ int rs_stream_destroy(void* stream) {
 int rs_set_option(rs_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return RS_EINVAL;
     if (!strcmp(key, "decode_screen")) { ctx->decode_screen = value != 0; return RS_OK; }
+    if (!strcmp(key, "decode_narrow")) { ctx->decode_narrow = value != 0; return RS_OK; }
+    if (!strcmp(key, "decode_persist_wgs")) {
+        if (value < 0 || value > 256) return rs_fail(ctx, RS_EINVAL, "decode_persist_wgs must be 0 .. 256");
+        ctx->decode_persist_wgs = value;
+        return RS_OK;
+    }
     if (!strcmp(key, "gemm_reserved_cus")) {
         if (value < -1 || value > 248) return rs_fail(ctx, RS_EINVAL, "gemm_reserved_cus must be -1 .. 248");
         ctx->gemm_reserved_cus = value;

@@ -129,6 +129,21 @@ class AsrModel:
 
     BUCKET = 16000      # cached buffer sets are sized in whole seconds of audio
 
+    def _decode_policy(self, ctx, B, pipelined):
+        """Pick the decode kernel family for a call (all are bit-identical; tests/test_gpu_fullsize.py).  Measured on
+        MI355X (profiles/r02o_pipeline_decode_variants_ab.txt, r02q_small_batch_decode_ab.txt):
+          * what a step costs next to the encoder GEMMs of the pipeline is the number of launches and of workgroups that
+            must find free CUs, not the length of each kernel on an idle chip: at B = 256 the wide-tile kernels with
+            the exact joint (5 launches, 40-workgroup LSTM) give 65.5 ms per step, screened / narrow 66.5-68.5;
+          * small batches are decode-bound: narrow tiles + exact joint win (B = 32: 19.6 ms vs 25.8 wide, 22.6 screened);
+          * big batches on an otherwise idle chip (sequential schedule): screened joint + narrow tiles (79.9 vs 84.7 ms).
+        $RS_DECODE_SCREEN / $RS_DECODE_NARROW override (A/B runs)."""
+        if "RS_DECODE_SCREEN" in os.environ or "RS_DECODE_NARROW" in os.environ:
+            return
+        big = B >= 128
+        ctx.set_option("decode_narrow", 0 if (pipelined and big) else 1)
+        ctx.set_option("decode_screen", 1 if (big and not pipelined) else 0)
+
     def buffers(self, B, l_max) -> _Buffers:
         """a cached buffer set for B utterances of up to l_max samples.  Lengths are bucketed to whole seconds and a
         larger cached set of the same B is reused: the kernels mask by per-utterance length, so the result does not
@@ -157,6 +172,7 @@ class AsrModel:
         Outputs land in buf.ids / buf.frames / buf.n_ids.  rs_rnnt_greedy synchronises the stream."""
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
+            self._decode_policy(self.ctx, buf.B, pipelined=False)
             self.ctx.frontend(buf.audio, buf.lens, self.pad_left, self.pad_right, buf.t_max, buf.feats,
                               buf.n_frames, buf.ws, stream)
             self.ctx.encoder(buf.feats, buf.n_frames, buf.B, buf.t_max, want_enc, buf.joint_enc, buf.enc_lens,
@@ -228,6 +244,7 @@ class AsrModel:
                     dec = torch.cuda.Stream(device=self.device, priority=dec_prio)
                 self._streams = (torch.cuda.Stream(device=self.device), dec)
             enc_stream, dec_stream = self._streams
+            self._decode_policy(self._ctx_dec, bufs[0].B, pipelined=True)
             enc_stream.wait_stream(torch.cuda.current_stream())
             jobs: "queue.Queue" = queue.Queue()
             done = [threading.Event() for _ in range(steps)]

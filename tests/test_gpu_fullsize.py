@@ -223,3 +223,31 @@ def test_encoder_619m_vs_bf16_oracle_with_taps(full):
     report("encoder_619m", stats)
     assert ok, stats
     assert got.ids == [r[0] for r in ref_same] and got.frames == [r[1] for r in ref_same]
+
+
+@pytest.mark.parametrize("options", [dict(decode_screen=0, decode_narrow=0), dict(decode_screen=0, decode_narrow=1),
+                                     dict(decode_screen=1, decode_narrow=0), dict(decode_persist_wgs=12)])
+def test_every_decode_kernel_family_is_bit_exact(wide, options):
+    """the four ways the library can run the greedy loop — wide / narrow LSTM tiles, exact / screened joint, one
+    launch per phase / one persistent launch with grid barriers — emit identical ids and frames (the oracle's)"""
+    model, sd = wide
+    cfg = model.cfg
+    g = torch.Generator().manual_seed(4)
+    B, Tp = 21, 33
+    f = torch.randn((B, Tp, cfg.joint_hidden), generator=g) * (0.8 + 0.4 * torch.rand((B, 1, 1), generator=g))
+    lens = torch.randint(1, Tp + 1, (B,), generator=g, dtype=torch.int32)
+    lens[2] = 0
+    ref = og.rnnt_greedy(cfg, sd, f.numpy(), lens.numpy())
+    ctx = model.ctx.clone()
+    try:
+        for k, v in options.items():
+            ctx.set_option(k, v)
+        saved, model.ctx = model.ctx, ctx
+        try:
+            got = run_greedy(model, f, lens)
+        finally:
+            model.ctx = saved
+    finally:
+        ctx.close()
+    assert sum(len(r[0]) for r in ref) > 100
+    assert got == ref
