@@ -657,51 +657,29 @@ __global__ __launch_bounds__(512, 2) void gemm_mf16_kernel(GemmParams p) {
 }
 
 // =====================================================================================================
-// Persistent 16x16x32 kernel: the default for the big shapes.
+// Cross-tile 16x16x32 kernels — shared pieces (DMA helper, LDS-staged epilogue).  The kernel itself is
+// gemm_lmf16_kernel below; its first version (gemm_pmf16_kernel: 32-deep granules, six DMA schedules, ablation
+// builds) was removed once the whole-line kernel superseded it — the measurements that led there are kept in
+// profiles/r02b .. r02e_*.txt and the code in the git history of this file.
 //
-// Why: with one 128 KiB-LDS workgroup per CU, a tile's epilogue (bias / activation / stores) and the next
-// tile's prologue (first HBM/L2 round trip) overlap with nothing, and all 256 CUs hit their store bursts at
-// the same moment (profiles/r01k_gemm_tile_timeline.txt: 6-11 us of a 41 us K = 1024 tile).  Here a grid of
-// (CUs - reserved) workgroups each walks a run of tiles and
-//   * the LDS ring never drains: the last three granules of a tile's main loop already DMA the first three
-//     granules of the NEXT tile, so the epilogue runs with those loads in flight and the next main loop starts
-//     on data that has landed;
-//   * the epilogue goes through a 4 KiB per-wave LDS scratch (the 32 KiB the ring leaves free) that turns the
-//     MFMA accumulator layout (16 rows x 8 bytes per instruction) into whole 128 / 256-byte row segments:
-//     half the store instructions, every one a full cache line;
-//   * stores are fire-and-forget: nothing waits for them except the counted waits of the next tile, which
-//     account for them (vmcnt retires in order and counts stores too);
-//   * `reserved` CUs are left to the decode stream of the two-stage pipeline (a workgroup of this kernel owns
-//     all registers of its CU for the whole launch, so decode kernels could not co-reside).
-// The DMAs are issued from inline asm (global_load_lds_dwordx4 with a scalar base and a 32-bit lane offset):
-// hipcc then counts only the epilogue's own loads / stores, which are all younger than the DMAs in flight, so
-// its counted waits stay correct and it never drains the ring (guide §5 "three .s-level traps" (b)).
-// Epilogue memory operations are raw buffer loads / stores with out-of-range offsets for masked rows: they
-// always issue, so the number of operations in flight is a compile-time constant the next tile's waits can use.
-__device__ __forceinline__ const void* uniform_ptr(const void* p) {   // make wave-uniformity provable ("s" operands)
-    const unsigned long long a = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return (const void*)(((unsigned long long)hi << 32) | lo);
-}
+// Why a workgroup walks several tiles / keeps its LDS ring running across tile boundaries: with one big-LDS
+// workgroup per CU, a tile's epilogue and the next tile's prologue (first HBM / L2 round trip) overlap with
+// nothing (profiles/r01k_gemm_tile_timeline.txt: 6-11 us of a 41 us K = 1024 tile).  So
+//   * the last K tile of an output tile already DMAs the first K tile of the NEXT one: the epilogue runs with those
+//     loads in flight and the next main loop starts on data that has landed (grid = CUs - reserved workgroups in
+//     persistent mode; with one tile per workgroup the same code simply has no next tile);
+//   * the epilogue goes through a 4 KiB per-wave LDS scratch (the 32 KiB the ring leaves free) that turns the MFMA
+//     accumulator layout (16 rows x 8 bytes per instruction) into whole 128 / 256-byte row segments: half the store
+//     instructions, every one a full cache line;
+//   * stores are fire-and-forget (vmcnt retires in order and counts stores: the next tile's waits cover them).
+// The DMAs are issued from inline asm (global_load_lds_dwordx4, scalar base + 32-bit lane offset): hipcc then counts
+// only the epilogue's own loads / stores, which are all younger than the DMAs in flight, so its counted waits stay
+// correct and it never drains the ring (guide §5 "three .s-level traps" (b)).  Epilogue memory operations are raw
+// buffer loads / stores with an out-of-range offset for masked rows: they always issue, whatever the row mask.
 // M0 (the DMA's LDS base) is written and consumed inside one asm statement.  Nothing else in these kernels
 // uses M0 (gfx950 DS instructions do not), so it is not saved / restored around the statement.
 __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate is the only form gfx950 has)
-__device__ __forceinline__ void wait_vmcnt_any(int n) {
-    n = n > 63 ? 63 : n;
-#define RS_W1(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-#define RS_W8(a, b, c, d, e, f, g, h) RS_W1(a) RS_W1(b) RS_W1(c) RS_W1(d) RS_W1(e) RS_W1(f) RS_W1(g) RS_W1(h)
-    switch (n) {
-        RS_W8(0, 1, 2, 3, 4, 5, 6, 7) RS_W8(8, 9, 10, 11, 12, 13, 14, 15) RS_W8(16, 17, 18, 19, 20, 21, 22, 23)
-        RS_W8(24, 25, 26, 27, 28, 29, 30, 31) RS_W8(32, 33, 34, 35, 36, 37, 38, 39) RS_W8(40, 41, 42, 43, 44, 45, 46, 47)
-        RS_W8(48, 49, 50, 51, 52, 53, 54, 55) RS_W8(56, 57, 58, 59, 60, 61, 62, 63)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef RS_W8
-#undef RS_W1
 }
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -816,252 +794,6 @@ __device__ __forceinline__ void pmf16_epilogue(const GemmParams& p, f32x4_t (&ac
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-}
-
-// OUT: 0 = bf16, 1 = f32, 2 = f32 with a residual read-modify-write; MASK: per-utterance row mask (subsampling GEMMs)
-// SCHED: where a granule's four DMA instructions are issued
-//   0  in the memory halves of the two phases (with the fragment reads), as gemm_mf16_kernel does
-//   1  between the MFMAs of the two phases: the memory half is then fragment reads only
-//   2  one phase per granule: 12 fragment reads | 32 MFMAs with the four DMAs spread between them
-//   3  one phase per granule, all four DMAs in the memory half (before the fragment reads)
-//   4  one phase per granule, three DMAs in the memory half, one between the MFMAs;  5: two and two
-// ABL (ablation builds for profiling only; results are wrong): 1 = no MFMAs, 2 = no DMAs inside the main loop,
-// 3 = no fragment reads inside the main loop, 4 = reads after the DMAs instead of before,
-// 5 = every DMA fetches 8 rows x 128 B (whole cache lines; half the rows, twice the k extent) instead of 16 rows x 64 B
-template <int BM, int OUT, bool MASK, int SCHED, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm_pmf16_kernel(GemmParams p) {
-    constexpr bool RES = OUT == 2, out_f32 = OUT >= 1, rowmask = MASK;
-    constexpr int BN = 256, BK = 32, WN = 4, NWAVES = 8;
-    constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16, MH = MI / 2;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_INSTS = BM / 16, LB = BN / 16 / NWAVES;
-    constexpr int RING_BYTES = 4 * STAGE_BYTES, SCR_BYTES = 4096;
-    static_assert((A_INSTS == 16 || A_INSTS == 12) && (MI % 2) == 0 && LB == 2, "tile shapes: 256 x 256 or 192 x 256");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int frow = lane & 15, fch = lane >> 4;
-    const int LAw = (A_INSTS - wave + NWAVES - 1) / NWAVES;      // A-tile DMA instructions of this wave per granule
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    char* scr = smem + RING_BYTES + wave * SCR_BYTES;            // this wave's epilogue scratch
-
-    // ---- tile schedule: XCD x owns a contiguous run of the (grouped) tile order; its workgroups take
-    // the run's tiles round-robin
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int q = nwg >> 3, rr = nwg & 7;
-    const int xbase = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
-    const int xcount = xcd < rr ? q + 1 : q;
-    const int nslots = ((int)gridDim.x - xcd + 7) >> 3;
-    if (slot >= xcount) return;
-    auto tile_origin = [&](int j, int& m0, int& n0) {
-        const int wg = xbase + j;
-        const int per_group = p.group_m * p.tiles_n;
-        const int g = wg / per_group, r = wg - g * per_group;
-        const int left = p.tiles_m - g * p.group_m;
-        const int gm = left < p.group_m ? left : p.group_m;
-        const int tile_n = r / gm;
-        m0 = (g * p.group_m + (r - tile_n * gm)) * BM;
-        n0 = tile_n * BN;
-    };
-    // per-lane byte offsets of this wave's DMA pieces for a tile (row clamp folded in)
-    const int dr = lane >> 2, dpc = lane & 3;
-    auto lane_offsets = [&](int m0, int n0, unsigned (&oa)[2], unsigned (&ob)[2]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ida = wave + NWAVES * j;                   // valid iff < A_INSTS (wave-uniform)
-            const int rowa = ida * 16 + dr;
-            int ga = m0 + rowa;
-            ga = ga < p.M ? ga : p.M - 1;
-            oa[j] = (unsigned)ga * (unsigned)(p.lda * 2) + (unsigned)((dpc ^ swz16(rowa)) * 16);
-            const int rowb = (wave * LB + j) * 16 + dr;
-            int gb = n0 + rowb;
-            gb = gb < p.N ? gb : p.N - 1;
-            ob[j] = (unsigned)gb * (unsigned)(p.ldw * 2) + (unsigned)((dpc ^ swz16(rowb)) * 16);
-            if constexpr (ABL == 5) {                             // timing experiment: whole 128-byte lines
-                int ra = m0 + ida * 8 + (lane >> 3), rb = n0 + (wave * LB + j) * 8 + (lane >> 3);
-                ra = ra < p.M - 4 ? ra : p.M - 5;
-                rb = rb < p.N - 4 ? rb : p.N - 5;
-                oa[j] = (unsigned)ra * (unsigned)(p.lda * 2) + (unsigned)((lane & 7) * 16);
-                ob[j] = (unsigned)rb * (unsigned)(p.ldw * 2) + (unsigned)((lane & 7) * 16);
-            }
-        }
-    };
-    // piece q of a granule: q = 0, 1 the wave's A pieces (16 rows x 64 B each), q = 2, 3 its W pieces
-    auto dma = [&](int q, unsigned voff, int t, int ring_slot) {
-        if constexpr (A_INSTS != 16) { if (q == 1 && wave + NWAVES >= A_INSTS) return; }    // 192-row tiles: 12 A pieces
-        const char* base = (q < 2 ? reinterpret_cast<const char*>(p.A) : reinterpret_cast<const char*>(p.W)) + (size_t)t * (ABL == 5 ? BK * 4 : BK * 2);
-        const unsigned dst = lds0 + ring_slot * STAGE_BYTES + (q < 2 ? (wave + NWAVES * q) * 1024 : A_BYTES + (wave * LB + (q - 2)) * 1024);
-        glds16(voff, base, dst);
-    };
-    const int nk = p.K / BK;                                      // >= 4 (launcher)
-    // VMEM operations a wave leaves in flight at the end of an epilogue (a lower bound is what the waits need)
-    constexpr int E_ops = out_f32 ? MI * 4 : (MI / 2) * 4;
-    int m0, n0, mn, nn;
-    unsigned oa[2], ob[2], oan[2], obn[2];
-    tile_origin(slot, m0, n0);
-    lane_offsets(m0, n0, oa, ob);
-    int gc = 0;                                                   // granules consumed so far (ring position)
-#pragma unroll
-    for (int t = 0; t < 3; ++t) { dma(0, oa[0], t, t); dma(1, oa[1], t, t); dma(2, ob[0], t, t); dma(3, ob[1], t, t); }
-    wait_vmcnt_any(2 * (LAw + LB));
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind from here on
-
-    for (int j = slot, tile_no = 0; j < xcount; j += nslots, ++tile_no) {
-        const bool has_next = j + nslots < xcount;
-        if (has_next) { tile_origin(j + nslots, mn, nn); lane_offsets(mn, nn, oan, obn); }
-        f32x4_t acc[MI][NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int jj = 0; jj < NI; ++jj)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.0f;
-
-        // ---- main loop: ping-pong wave groups over the granule ring (see gemm_mf16_kernel / gemm_bf16_kernel<PP>
-        // for the barrier, RAW and WAR argument; the ring position simply keeps counting across tiles)
-        for (int g = 0; g < nk; ++g) {
-            const char* at = smem + ((gc + g) & 3) * STAGE_BYTES;
-            const char* bt = at + A_BYTES;
-            const bool own = g + 3 < nk;                          // granule g+3 belongs to this tile
-            const bool more = own || has_next;
-            const int tn = own ? g + 3 : g + 3 - nk;
-            const int nslot = (gc + g + 3) & 3;
-            // piece q (0, 1 = the A pieces; 2, 3 = the W pieces) of granule g+3, of this tile or of the next one
-            auto dma_piece = [&](int q) {
-                if (!more) return;
-                const unsigned voff = q < 2 ? (own ? oa[q] : oan[q]) : (own ? ob[q - 2] : obn[q - 2]);
-                dma(q, voff, tn, nslot);
-            };
-            bf16x8_t bfr[NI];
-            if constexpr (SCHED >= 2) {
-                constexpr int IN_MEM = SCHED == 2 ? 0 : (SCHED == 3 ? 4 : (SCHED == 4 ? 3 : 2));   // DMAs issued with the reads
-                bf16x8_t af[MI];
-                if (g + 1 < nk || has_next) {
-                    // granule g+1 must have landed; issued after it: granule g+2 (g+3 is issued below) and, for
-                    // the first two granules of a later tile, the previous epilogue's stores
-                    if ((g + 2 < nk || has_next) && !(tile_no > 0 && g < 2)) {        // steady state: one literal wait
-                        if (LAw == 2) wait_vmcnt<2 + LB>(); else wait_vmcnt<1 + LB>();
-                    } else {
-                        int younger = 0;
-                        if (g + 2 < nk || has_next) younger += LAw + LB;
-                        if (tile_no > 0 && g < 2) younger += E_ops;
-                        wait_vmcnt_any(younger);
-                    }
-                }
-                if constexpr (ABL == 4) {
-#pragma unroll
-                    for (int q = 0; q < IN_MEM; ++q) dma_piece(q);
-                }
-                if (ABL != 3 || g == 0) {
-#pragma unroll
-                    for (int jj = 0; jj < NI; ++jj) bfr[jj] = read_frag16(bt, wn * TN + jj * 16 + frow, fch);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) af[i] = read_frag16(at, wm * TM + i * 16 + frow, fch);
-                }
-                if constexpr (ABL != 4 && ABL != 2) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < IN_MEM; ++q) dma_piece(q);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if constexpr (ABL == 1) {
-#pragma unroll
-                        for (int i = q * (MI / 4); i < (q + 1) * (MI / 4); ++i)
-                            asm volatile("" :: "v"(af[i]), "v"(bfr[i & 3]));
-                    } else {
-#pragma unroll
-                    for (int i = q * (MI / 4); i < (q + 1) * (MI / 4); ++i)
-#pragma unroll
-                        for (int jj = 0; jj < NI; ++jj)
-                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
-                    }
-                    if (q >= IN_MEM) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        dma_piece(q);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                if constexpr (MI % 4 != 0) {                      // 192-row tiles: 6 row blocks = 4 x 1 + 2
-#pragma unroll
-                    for (int i = 4 * (MI / 4); i < MI; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < NI; ++jj)
-                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
-                }
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t af[MH];
-                if (ks == 0) {
-#pragma unroll
-                    for (int jj = 0; jj < NI; ++jj) bfr[jj] = read_frag16(bt, wn * TN + jj * 16 + frow, fch);
-                }
-#pragma unroll
-                for (int i = 0; i < MH; ++i) af[i] = read_frag16(at, wm * TM + (ks * MH + i) * 16 + frow, fch);
-                if (ks == 1 && (g + 1 < nk || has_next)) {
-                    // granule g+1 must have landed; issued after it: granule g+2, the A part of g+3, and — for
-                    // the first two granules of a later tile — the previous epilogue's stores
-                    int younger = 0;
-                    if (g + 2 < nk || has_next) younger += LAw + LB;
-                    if (more) younger += LAw;
-                    if (tile_no > 0 && g < 2) younger += E_ops;
-                    wait_vmcnt_any(younger);
-                }
-                if constexpr (SCHED == 0) { dma_piece(2 * ks); dma_piece(2 * ks + 1); }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < MH; ++i) {
-#pragma unroll
-                    for (int jj = 0; jj < NI; ++jj)
-                        acc[ks * MH + i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[ks * MH + i][jj], 0, 0, 0);
-                    if constexpr (SCHED == 1) {
-                        if (i == 0 || i == MH / 2) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            dma_piece(2 * ks + (i == 0 ? 0 : 1));
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            }
-        }
-        gc += nk;
-
-        // ---- epilogue
-        {
-            int cm0 = __builtin_amdgcn_readfirstlane(m0), cn0 = __builtin_amdgcn_readfirstlane(n0);
-            asm volatile("" : "+s"(cm0), "+s"(cn0));             // keep the addresses out of the main loop's live ranges
-            pmf16_epilogue<MI, NI, OUT, MASK>(p, acc, scr, cm0, cn0, wm, wn, lane);
-        }
-        if (has_next) {
-            m0 = mn; n0 = nn;
-#pragma unroll
-            for (int jx = 0; jx < 2; ++jx) { oa[jx] = oan[jx]; ob[jx] = obn[jx]; }
-        }
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier at the start
 }
 
 // =====================================================================================================
@@ -1241,7 +973,10 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
     p.tiles_n = (p.N + BN - 1) / BN;
     const int nwg = p.tiles_m * p.tiles_n;
     extern std::atomic<int> g_group_m;
-    p.group_m = g_group_m.load() > 0 ? g_group_m.load() : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8));
+    // row panels per XCD tile group (profiles/r02r_gemm_group_m_sweep.txt): N = 1024 (4 weight tiles) likes 2 panels at
+    // K = 4096 and 6 below; one-tile-wide problems (the subsampling GEMMs) 16; everything else is flat from 6 up
+    p.group_m = g_group_m.load() > 0 ? g_group_m.load()
+              : (p.tiles_n == 4 ? (p.K >= 4096 ? 2 : 6) : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8)));
     p.skew_cycles = 0;
     const int grid = nwg < grid_cap ? nwg : grid_cap;
     const int out = (p.flags & RS_GEMM_RESIDUAL) ? 2 : ((p.flags & RS_GEMM_OUT_F32) ? 1 : 0);
@@ -1322,37 +1057,6 @@ int launch_mf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_mf16_kernel<BM, BN, true>, LDS); rc != RS_OK) return rc;
     if (p.flags & RS_GEMM_RESIDUAL) hipLaunchKernelGGL((gemm_mf16_kernel<BM, BN, true>), dim3(nwg), dim3(512), LDS, s, p);
     else hipLaunchKernelGGL((gemm_mf16_kernel<BM, BN, false>), dim3(nwg), dim3(512), LDS, s, p);
-    return RS_OK;
-}
-
-template <int BM, int SCHED, int ABL = 0>
-int launch_pmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
-    constexpr int BN = 256;
-    constexpr int LDS = 4 * (BM + BN) * 32 * 2 + 8 * 4096;
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = p.tiles_m * p.tiles_n;
-    p.group_m = g_group_m.load() > 0 ? g_group_m.load() : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8));
-    p.skew_cycles = 0;
-    const int grid = nwg < grid_cap ? nwg : grid_cap;
-    const int out = (p.flags & RS_GEMM_RESIDUAL) ? 2 : ((p.flags & RS_GEMM_OUT_F32) ? 1 : 0);
-    const bool mask = p.flags & RS_GEMM_ROWMASK;
-#define RS_PMF(O, MK)                                                                                         \
-    do {                                                                                                      \
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_pmf16_kernel<BM, O, MK, SCHED>, LDS); rc != RS_OK) return rc; \
-        hipLaunchKernelGGL((gemm_pmf16_kernel<BM, O, MK, SCHED>), dim3(grid), dim3(512), LDS, s, p);          \
-    } while (0)
-    if constexpr (ABL != 0) {
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_pmf16_kernel<BM, 0, false, SCHED, ABL>, LDS); rc != RS_OK) return rc;
-        hipLaunchKernelGGL((gemm_pmf16_kernel<BM, 0, false, SCHED, ABL>), dim3(grid), dim3(512), LDS, s, p);
-        return RS_OK;
-    }
-    if (out == 2 && !mask) RS_PMF(2, false);
-    else if (out == 1 && !mask) RS_PMF(1, false);
-    else if (out == 0 && !mask) RS_PMF(0, false);
-    else if (out == 0 && mask) RS_PMF(0, true);
-    else return rs_fail(ctx, RS_EINVAL, "gemm: row mask with f32 output has no persistent kernel");
-#undef RS_PMF
     return RS_OK;
 }
 
@@ -1454,23 +1158,9 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     }
     const int reserve = ctx->gemm_reserved_cus >= 0 ? ctx->gemm_reserved_cus : g_reserve.load();
     const int grid_cap = ctx->n_cus - reserve > 8 ? ctx->n_cus - reserve : 8;
-    // 40 / 42 (+100 * SCHED): the cross-tile kernel, persistent grid; +1000: the same kernel, one tile per workgroup
+    // 50-72: the whole-line cross-tile kernel, persistent grid; +1000: the same kernel, one tile per workgroup
     const int pgrid = v >= 1000 ? (1 << 30) : grid_cap;
     switch (v % 1000) {
-        case 40: rc = launch_pmf16<256, 0>(ctx, p, s, pgrid); break;            // 256-row tiles
-        case 42: rc = launch_pmf16<192, 0>(ctx, p, s, pgrid); break;            // 3/4-height tiles
-        case 140: rc = launch_pmf16<256, 1>(ctx, p, s, pgrid); break;
-        case 142: rc = launch_pmf16<192, 1>(ctx, p, s, pgrid); break;
-        case 240: rc = launch_pmf16<256, 2>(ctx, p, s, pgrid); break;
-        case 242: rc = launch_pmf16<192, 2>(ctx, p, s, pgrid); break;
-        case 340: rc = launch_pmf16<256, 3>(ctx, p, s, pgrid); break;
-        case 342: rc = launch_pmf16<192, 3>(ctx, p, s, pgrid); break;
-        case 341: rc = launch_pmf16<256, 3, 1>(ctx, p, s, pgrid); break;         // ablations of 340 (wrong results)
-        case 343: rc = launch_pmf16<256, 3, 2>(ctx, p, s, pgrid); break;
-        case 345: rc = launch_pmf16<256, 3, 3>(ctx, p, s, pgrid); break;
-        case 347: rc = launch_pmf16<256, 3, 4>(ctx, p, s, pgrid); break;
-        case 349: rc = launch_pmf16<256, 3, 5>(ctx, p, s, pgrid); break;
-        case 440: rc = launch_pmf16<256, 4>(ctx, p, s, pgrid); break;
         // 5x / 6x / 7x: the whole-line kernel with 8 / 5 / 3 of a K tile's DMAs issued beside the fragment reads
         case 50: rc = launch_lmf16<256, 8>(ctx, p, s, pgrid); break;
         case 52: rc = launch_lmf16<192, 8>(ctx, p, s, pgrid); break;
@@ -1481,9 +1171,6 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         case 62: rc = launch_lmf16<192, 5>(ctx, p, s, pgrid); break;
         case 70: rc = launch_lmf16<256, 3>(ctx, p, s, pgrid); break;
         case 72: rc = launch_lmf16<192, 3>(ctx, p, s, pgrid); break;
-        case 442: rc = launch_pmf16<192, 4>(ctx, p, s, pgrid); break;
-        case 540: rc = launch_pmf16<256, 5>(ctx, p, s, pgrid); break;
-        case 542: rc = launch_pmf16<192, 5>(ctx, p, s, pgrid); break;
         case 1: rc = launch_variant<128, 128, 64, 2, 2, 2>(ctx, p, s); break;   // small problems
         case 2: rc = launch_variant<256, 256, 64, 2, 2, 4>(ctx, p, s); break;   // big tile, drain per K step
         case 3: rc = launch_variant<256, 256, 32, 4, 2, 4>(ctx, p, s); break;   // big tile, 4-stage ring, counted vmcnt
