@@ -1,0 +1,31 @@
+"""profiles/<tag>_pmc_per_kernel.txt (scripts/pmc_summary.py output) -> profiles/gemm_traffic.json, the `traffic` field
+of the bench line: mean HBM-side bytes per GEMM launch (all encoder linears), PMC FETCH_SIZE x 2 + WRITE_SIZE.
+
+    python scripts/pmc_to_traffic.py profiles/r02n_pmc_per_kernel.txt
+"""
+import json
+import re
+import sys
+
+src = sys.argv[1]
+tot_n = tot_b = 0
+per = {}
+for line in open(src):
+    m = re.match(r"(gemm_\w+<[^>]*>)\s+n=(\d+).*hbm_rd\s+([\d.]+) MB wr\s+([\d.]+) MB", line)
+    if not m:
+        continue
+    name, n, rd, wr = m.group(1), int(m.group(2)), float(m.group(3)) * 1e6, float(m.group(4)) * 1e6
+    per[name] = {"launches": n, "read_bytes": rd, "write_bytes": wr}
+    tot_n += n
+    tot_b += n * (rd + wr)
+out = {
+    "kernel": "all GEMM launches of the encoder (gemm_lmf16_kernel: whole-line cross-tile kernel; gemm_bf16_kernel: small shapes)",
+    "hbm_bytes_per_launch": round(tot_b / tot_n),
+    "per_kernel": per,
+    "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-pipeline`; "
+              "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, guides/MI355X_MICROARCH.md §HBM); launch-weighted "
+              "mean.  These are L2-miss bytes at the TCC/EA boundary: re-reads served by the 256 MiB infinity cache count too.",
+    "source": src,
+}
+json.dump(out, open("profiles/gemm_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
