@@ -8,15 +8,20 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "rnnt_greedy.c")
+SOURCES = [os.path.join(HERE, n) for n in ("rnnt_greedy.c", "rnnt_alsd.c")]
+DEPENDS = SOURCES + [os.path.join(HERE, "rnnt_math.h")]
 OUT = os.path.join(HERE, "librs_oracle.so")
 
 
+def stale():
+    return not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(p) for p in DEPENDS)
+
+
 def build(force=False):
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= os.path.getmtime(SRC):
+    if not force and not stale():
         return OUT
     cmd = ["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC",
-           "-o", OUT, SRC, "-lm"]
+           "-o", OUT] + SOURCES + ["-lm"]
     subprocess.check_call(cmd)
     return OUT
 

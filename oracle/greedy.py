@@ -1,4 +1,4 @@
-"""ctypes wrapper of oracle/rnnt_greedy.c.  TEST INFRASTRUCTURE (oracle/__init__.py)."""
+"""ctypes wrapper of oracle/rnnt_greedy.c and oracle/rnnt_alsd.c.  TEST INFRASTRUCTURE (oracle/__init__.py)."""
 import ctypes
 import os
 
@@ -12,9 +12,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = _build.OUT
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(_build.SRC):
-            path = _build.build(force=True)
+        path = _build.build(force=True) if _build.stale() else _build.OUT
         _lib = ctypes.CDLL(path)
         _lib.rs_oracle_expf.restype = ctypes.c_float
         _lib.rs_oracle_expf.argtypes = [ctypes.c_float]
@@ -24,6 +22,12 @@ def lib():
         _lib.rs_oracle_tanhf.argtypes = [ctypes.c_float]
         _lib.rs_oracle_dot.restype = ctypes.c_float
         _lib.rs_oracle_rnnt_greedy.restype = ctypes.c_int
+        _lib.rs_oracle_rnnt_alsd.restype = ctypes.c_int
+        _lib.rs_oracle_logf.restype = ctypes.c_float
+        _lib.rs_oracle_logf.argtypes = [ctypes.c_float]
+        _lib.rs_oracle_logaddexpf.restype = ctypes.c_float
+        _lib.rs_oracle_logaddexpf.argtypes = [ctypes.c_float, ctypes.c_float]
+        _lib.rs_oracle_lse.restype = ctypes.c_float
     return _lib
 
 
@@ -73,3 +77,37 @@ def rnnt_greedy(cfg, sd, f, enc_lens, u_max=None):
     if rc != 0:
         raise RuntimeError(f"oracle greedy overflowed u_max={u_max}")
     return [(ids[b, :n_ids[b]].tolist(), frames[b, :n_ids[b]].tolist()) for b in range(B)]
+
+
+def alsd_budget(enc_lens, max_target_len):
+    """label budget per utterance (oracle/alsd.py: a float is a multiple of the frame count, an int is absolute)"""
+    if isinstance(max_target_len, float):
+        return np.asarray([int(max_target_len * int(t)) for t in enc_lens], np.int32)
+    return np.full((len(enc_lens),), int(max_target_len), np.int32)
+
+
+def rnnt_alsd(cfg, sd, f, enc_lens, beam=4, max_target_len=2.0, score_norm=True, recombine="upstream", out_cap=None):
+    """f float32 [B, Tp, J] (numpy), enc_lens int[B] -> list of (ids, alignment steps, score) of the best
+    hypothesis per utterance, in the fixed float32 evaluation order of rnnt_alsd.c."""
+    L = lib()
+    arr = decoder_arrays(cfg, sd)
+    f = np.ascontiguousarray(f, dtype=np.float32)
+    B, Tp, J = f.shape
+    enc_lens = np.ascontiguousarray(enc_lens, dtype=np.int32)
+    u_max = alsd_budget(enc_lens, max_target_len)
+    if out_cap is None:
+        out_cap = max(1, int((enc_lens + u_max).max())) if B else 1
+    ids = np.zeros((B, out_cap), np.int32)
+    steps = np.zeros((B, out_cap), np.int32)
+    n_ids = np.zeros((B,), np.int32)
+    scores = np.zeros((B,), np.float32)
+    PF = ctypes.POINTER(ctypes.c_float)
+    wl = (PF * cfg.pred_layers)(*[_fp(w) for w in arr["lstm_w"]])
+    bl = (PF * cfg.pred_layers)(*[_fp(b) for b in arr["lstm_b"]])
+    rc = L.rs_oracle_rnnt_alsd(_fp(f), _ip(enc_lens), B, Tp, J, cfg.pred_hidden, cfg.pred_layers, cfg.n_logits,
+                               cfg.blank_id, _fp(arr["embed"]), wl, bl, _fp(arr["Wp"]), _fp(arr["bp"]),
+                               _fp(arr["Wo"]), _fp(arr["bo"]), int(beam), _ip(u_max), int(bool(score_norm)),
+                               int(recombine == "merge"), out_cap, _ip(ids), _ip(steps), _ip(n_ids), _fp(scores))
+    if rc != 0:
+        raise RuntimeError(f"oracle alsd overflowed out_cap={out_cap}")
+    return [(ids[b, :n_ids[b]].tolist(), steps[b, :n_ids[b]].tolist(), float(scores[b])) for b in range(B)]

@@ -19,35 +19,10 @@
  * exp/sigmoid/tanh are the same polynomial (only + - * / and fmaf).
  * Build: gcc -O2 -mfma -ffp-contract=off -shared -fPIC (oracle/build.py).
  */
-#include <math.h>
-#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
-#define SPLITK_LSTM 16  /* K slices of the LSTM gate products */
-#define SPLITK_TILE 8   /* K slices of the joint / prediction projections */
-#define SPLITK_MAX 16
-
-static inline float rs_expf(float x) {
-    x = fminf(fmaxf(x, -87.0f), 88.0f);
-    const float n = rintf(x * 1.44269504088896341f);
-    float r = fmaf(n, -0.693359375f, x);
-    r = fmaf(n, 2.12194440e-4f, r);
-    float p = 1.9875691500e-4f;
-    p = fmaf(p, r, 1.3981999507e-3f);
-    p = fmaf(p, r, 8.3334519073e-3f);
-    p = fmaf(p, r, 4.1665795894e-2f);
-    p = fmaf(p, r, 1.6666665459e-1f);
-    p = fmaf(p, r, 5.0000001201e-1f);
-    const float r2 = r * r;
-    const float y = fmaf(p, r2, r) + 1.0f;
-    const int ni = (int)n;
-    union { uint32_t u; float f; } s;
-    s.u = (uint32_t)(ni + 127) << 23;
-    return y * s.f;
-}
-static inline float rs_sigmoidf(float x) { return 1.0f / (1.0f + rs_expf(-x)); }
-static inline float rs_tanhf(float x) { return 1.0f - 2.0f / (rs_expf(2.0f * x) + 1.0f); }
+#include "rnnt_math.h"
 
 float rs_oracle_expf(float x) { return rs_expf(x); }
 float rs_oracle_sigmoidf(float x) { return rs_sigmoidf(x); }
