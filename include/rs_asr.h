@@ -181,6 +181,33 @@ int rs_rnnt_greedy(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens,
                    int u_max, int32_t* ids, int32_t* frames, int32_t* n_ids,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- stage 3b: RNN-T alignment-length synchronous beam search (ALSD) ----------------------
+ * Replaces: the same call as rs_rnnt_greedy (transcribe.py:48-53) when the checkpoint's decoding
+ * strategy is "alsd" — what the reference's post-processing was written for (decode.py:29,38-41:
+ * "NeMo prepends a blank token to y_sequence with ALSD"; decode.py:48 converts alignment steps to
+ * frames).  [UPSTREAM] BeamRNNTInfer.align_length_sync_decoding; the evaluation order of every float
+ * is documented in oracle/rnnt_alsd.c and the results are bit-identical to it.
+ *
+ *   beam              hypotheses kept per utterance (1..8)
+ *   max_target_ratio / max_target_abs
+ *                     label budget per utterance: max_target_abs when >= 0, else
+ *                     (int)(max_target_ratio * enc_lens[b]); the search runs enc_lens[b] + budget steps
+ *   flags             RS_ALSD_SCORE_NORM: rank finished hypotheses by score / (labels + 1)
+ *                     RS_ALSD_MERGE: drop recombined duplicates from the beam (default keeps them)
+ *   ids    i32[B][out_cap]  labels of the best hypothesis (no leading blank)
+ *   steps  i32[B][out_cap]  alignment index i = frame + labels-before of each label
+ *   n_ids  i32[B],  scores f32[B] (log-probability of the best hypothesis)
+ * The workspace is separate from rs_workspace_bytes (it grows with beam and the alignment length):
+ * rs_rnnt_alsd_workspace_bytes(ctx, B, beam, tp_max, max_target_ratio, max_target_abs).
+ * Synchronises the stream internally.  RS_EOVERFLOW if a result has more than out_cap labels. */
+enum { RS_ALSD_SCORE_NORM = 1, RS_ALSD_MERGE = 2 };
+size_t rs_rnnt_alsd_workspace_bytes(const rs_ctx* ctx, int B, int beam, int tp_max, double max_target_ratio,
+                                    int max_target_abs);
+int rs_rnnt_alsd(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int beam,
+                 double max_target_ratio, int max_target_abs, int flags, int out_cap, int32_t* ids,
+                 int32_t* steps, int32_t* n_ids, float* scores, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
 /* ---- profiling hooks for bench.py (roofline.achieved) ------------------------------------
  * When enabled, the launcher brackets every launch of the selected kernel class with HIP
  * events on the launch stream.  rs_profile_read synchronises those events and returns the

@@ -153,10 +153,13 @@ __global__ __launch_bounds__(1024) void rnnt_lstm_kernel(DecodeState st, int lay
 // ---- [32 rows] x [64 cols] tile of  out = W . a + bias  with the 8 K slices on the 8 waves --------------
 // MODE 0: prediction projection g = W_p . h_top + b_p over the `act` rows (+ LSTM state commit)
 // MODE 1: joint logits  W_o . relu(f[b][t_b] + g[b]) + b_o over the `alive` rows, per-tile argmax
+// MODE 2: the same logits written out in full (beam search, k_rnnt_alsd.hip): rows are hypotheses, `rows_per_utt`
+//         consecutive rows share an utterance's encoder frames; logits go to st.zapprox with row stride 64 * n_ctiles
 template <int MODE>
 __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const float* __restrict__ f, int B, int Tp,
                                                         int L, int H, int K, int N, const float* __restrict__ W,
-                                                        const float* __restrict__ bias, int n_ctiles, int step) {
+                                                        const float* __restrict__ bias, int n_ctiles, int step,
+                                                        int rows_per_utt) {
     extern __shared__ __attribute__((aligned(16))) char tile_smem[];
     float (*part)[32][65] = reinterpret_cast<float (*)[32][65]>(tile_smem);   // [SPLITK_TILE][32][65]
     int* rows_s = reinterpret_cast<int*>(tile_smem + SPLITK_TILE * 32 * 65 * 4);
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t* list = MODE == 0 ? st.act : st.alive + (size_t)(step & 1) * B;
     const int n_rows = MODE == 0 ? st.counters[0] : st.counters[2 + (step & 1)];
-    if (MODE == 1 && rt == 0 && ct == 0 && tid == 0) {   // lists that this step's finalize will build
+    if (MODE >= 1 && rt == 0 && ct == 0 && tid == 0) {   // lists that this step's finalize will build
         st.counters[0] = 0;
         st.counters[2 + ((step + 1) & 1)] = 0;
     }
@@ -188,7 +191,8 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
         } else {
             int t = st.tcur[row];
             t = t < Tp ? t : Tp - 1;
-            asrc[ri] = f + ((size_t)row * Tp + t) * K;
+            const int utt = MODE == 2 ? row / rows_per_utt : row;
+            asrc[ri] = f + ((size_t)utt * Tp + t) * K;
             gsrc[ri] = st.g + (size_t)row * K;
         }
     }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri) {
             fr.a[ri] = *reinterpret_cast<const float4*>(asrc[ri] + k);
-            if (MODE == 1) fr.g[ri] = *reinterpret_cast<const float4*>(gsrc[ri] + k);
+            if (MODE >= 1) fr.g[ri] = *reinterpret_cast<const float4*>(gsrc[ri] + k);
         }
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) fr.w[cj] = *reinterpret_cast<const float4*>(wfrag[cj] + (size_t)(k0 >> 4) * 256);
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri) {
             a[ri] = fr.a[ri];
-            if (MODE == 1) {   // relu(f + g) is elementwise: apply it before the lane permutation
+            if (MODE >= 1) {   // relu(f + g) is elementwise: apply it before the lane permutation
                 a[ri].x = fmaxf(a[ri].x + fr.g[ri].x, 0.0f); a[ri].y = fmaxf(a[ri].y + fr.g[ri].y, 0.0f);
                 a[ri].z = fmaxf(a[ri].z + fr.g[ri].z, 0.0f); a[ri].w = fmaxf(a[ri].w + fr.g[ri].w, 0.0f);
             }
@@ -273,6 +277,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
         if (v < N) {
             s = s + bias[v];
             if (MODE == 0) { if (row_ok) st.g[(size_t)brow * N + v] = s; }
+            else if (MODE == 2) { if (row_ok) st.zapprox[(size_t)brow * (64 * n_ctiles) + v] = s; }
             else if (s > best) { best = s; best_idx = v; }
         }
     }
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
             st.pmax[(size_t)brow * n_ctiles + ct] = best;
             st.pidx[(size_t)brow * n_ctiles + ct] = best_idx;
         }
-    } else if (row_ok) {
+    } else if (MODE == 0 && row_ok) {
         // commit this row's new LSTM state (each column tile copies its share of the H units)
         const int stride = gridDim.x * 64;
         for (int l = 0; l < L; ++l)
@@ -714,6 +719,67 @@ __global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const 
 
 }  // namespace
 
+
+namespace {
+
+constexpr int LSTM_LDS = SPLITK_LSTM * 4 * 32 * 16 * 4 + 32 * 4;
+constexpr int TILE_LDS = SPLITK_TILE * 32 * 65 * 4 + 32 * 4;
+
+// narrow-tile LSTM / projection kernels: need the permuted weights and keep a whole K slice in registers
+bool narrow_kernels_usable(const rs_ctx* ctx) {
+    const int L = ctx->d.pred_layers, H = ctx->d.pred_hidden;
+    bool narrow = ctx->decode_narrow;
+    for (int l = 0; l < L; ++l) narrow = narrow && ctx->lstm_w4[l] != nullptr;
+    return narrow && 2 * H / SPLITK_LSTM / 16 <= 8 && H / SPLITK_TILE / 16 <= 8;
+}
+
+// prediction network over the `act` rows: LSTM layers, joint.pred projection, state commit
+void launch_lstm_pred(rs_ctx* ctx, const DecodeState& st, int B, int rows_bound, bool narrow, hipStream_t s) {
+    const int L = ctx->d.pred_layers, H = ctx->d.pred_hidden, J = ctx->d.joint_hidden;
+    const int rts = (rows_bound + 31) / 32 > 0 ? (rows_bound + 31) / 32 : 1;
+    if (narrow) {
+        for (int l = 0; l < L; ++l)
+            hipLaunchKernelGGL(rnnt_lstm4_kernel, dim3(H / 4, rts), dim3(1024), 0, s, st, l, B, H, ctx->embed, ctx->lstm_w4[l],
+                               ctx->lstm_b[l]);
+        hipLaunchKernelGGL(rnnt_pred16_kernel, dim3((J + 15) / 16, rts), dim3(512), 0, s, st, B, L, H, J, ctx->jpred_w,
+                           ctx->jpred_b);
+        return;
+    }
+    for (int l = 0; l < L; ++l)
+        hipLaunchKernelGGL(rnnt_lstm_kernel, dim3(H / 16, rts), dim3(1024), LSTM_LDS, s, st, l, B, H, ctx->embed,
+                           ctx->lstm_w[l], ctx->lstm_b[l]);
+    hipLaunchKernelGGL(rnnt_tile_kernel<0>, dim3((J + 63) / 64, rts), dim3(512), TILE_LDS, s, st, (const float*)nullptr, B,
+                       0, L, H, H, J, ctx->jpred_w, ctx->jpred_b, 0, 0, 1);
+}
+
+int ensure_decode_lds(rs_ctx* ctx) {
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_lstm_kernel, LSTM_LDS); rc != RS_OK) return rc;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<0>, TILE_LDS); rc != RS_OK) return rc;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<1>, TILE_LDS); rc != RS_OK) return rc;
+    return rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<2>, TILE_LDS);
+}
+
+}  // namespace
+
+// ---- launch helpers for the beam search (k_rnnt_alsd.hip); `st_ptr` points at a DecodeState over hypothesis rows ----
+int rs_rnnt_launch_lstm_pred(rs_ctx* ctx, const void* st_ptr, int rows, hipStream_t s) {
+    if (int rc = ensure_decode_lds(ctx); rc != RS_OK) return rc;
+    launch_lstm_pred(ctx, *reinterpret_cast<const DecodeState*>(st_ptr), rows, rows, narrow_kernels_usable(ctx), s);
+    return RS_OK;
+}
+
+// exact f32 joint logits of the rows on alive list (step & 1) -> st.zapprox [rows][64 * ceil(V / 64)]
+int rs_rnnt_launch_joint_logits(rs_ctx* ctx, const void* st_ptr, const float* joint_enc, int rows, int tp_max, int rows_per_utt,
+                                int step, hipStream_t s) {
+    if (int rc = ensure_decode_lds(ctx); rc != RS_OK) return rc;
+    const rs_dims& d = ctx->d;
+    const int nct = (d.n_logits + 63) / 64;
+    hipLaunchKernelGGL(rnnt_tile_kernel<2>, dim3(nct, (rows + 31) / 32), dim3(512), TILE_LDS, s,
+                       *reinterpret_cast<const DecodeState*>(st_ptr), joint_enc, rows, tp_max, d.pred_layers, d.pred_hidden,
+                       d.joint_hidden, d.n_logits, ctx->jout_w, ctx->jout_b, nct, step, rows_per_utt);
+    return RS_OK;
+}
+
 // --------------------------------------------------------------------------------------------------
 size_t rs_rnnt_persist_lds_bytes(int J);
 int rs_rnnt_persist_launch(rs_ctx* ctx, const void* st_ptr, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max,
@@ -765,31 +831,9 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
                         J / SPLITK_TILE / 16 <= 8 && J / 32 <= 20;
 
     const int rtiles = (B + 31) / 32;
-    constexpr int LSTM_LDS = SPLITK_LSTM * 4 * 32 * 16 * 4 + 32 * 4;
-    constexpr int TILE_LDS = SPLITK_TILE * 32 * 65 * 4 + 32 * 4;
-    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_lstm_kernel, LSTM_LDS); rc != RS_OK) return rc;
-    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<0>, TILE_LDS); rc != RS_OK) return rc;
-    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<1>, TILE_LDS); rc != RS_OK) return rc;
-    bool narrow = true;                                   // narrow-tile LSTM / projection kernels (need the permuted weights)
-    for (int l = 0; l < L; ++l) narrow = narrow && ctx->lstm_w4[l] != nullptr;
-    narrow = narrow && 2 * H / SPLITK_LSTM / 16 <= 8 && H / SPLITK_TILE / 16 <= 8;   // the kernels keep a whole K slice in registers
-    narrow = narrow && ctx->decode_narrow;
-    auto lstm_and_pred = [&](int rows_bound) {
-        const int rts = (rows_bound + 31) / 32 > 0 ? (rows_bound + 31) / 32 : 1;
-        if (narrow) {
-            for (int l = 0; l < L; ++l)
-                hipLaunchKernelGGL(rnnt_lstm4_kernel, dim3(H / 4, rts), dim3(1024), 0, s, st, l, B, H, ctx->embed, ctx->lstm_w4[l],
-                                   ctx->lstm_b[l]);
-            hipLaunchKernelGGL(rnnt_pred16_kernel, dim3((J + 15) / 16, rts), dim3(512), 0, s, st, B, L, H, J, ctx->jpred_w,
-                               ctx->jpred_b);
-            return;
-        }
-        for (int l = 0; l < L; ++l)
-            hipLaunchKernelGGL(rnnt_lstm_kernel, dim3(H / 16, rts), dim3(1024), LSTM_LDS, s, st, l, B, H, ctx->embed,
-                               ctx->lstm_w[l], ctx->lstm_b[l]);
-        hipLaunchKernelGGL(rnnt_tile_kernel<0>, dim3((J + 63) / 64, rts), dim3(512), TILE_LDS, s, st, (const float*)nullptr, B,
-                           0, L, H, H, J, ctx->jpred_w, ctx->jpred_b, 0, 0);
-    };
+    if (int rc = ensure_decode_lds(ctx); rc != RS_OK) return rc;
+    const bool narrow = narrow_kernels_usable(ctx);
+    auto lstm_and_pred = [&](int rows_bound) { launch_lstm_pred(ctx, st, B, rows_bound, narrow, s); };
 
     rs_prof_begin(ctx, RS_PROF_DECODE, s, 0.0, 0.0);
     RS_HIP(ctx, hipMemsetAsync(st.h, 0, 2 * rs_align(state_bytes), s));   // h and c are adjacent
@@ -840,7 +884,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
                                        ctx->jout_wrm, ctx->jout_b, ctx->jout_wmax, d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
             } else {
                 hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(nct, rtiles), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H, J,
-                                   V, ctx->jout_w, ctx->jout_b, nct, steps);
+                                   V, ctx->jout_w, ctx->jout_b, nct, steps, 1);
                 hipLaunchKernelGGL(rnnt_finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, st, enc_lens, B, nct,
                                    d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
             }

@@ -11,6 +11,10 @@
 #include "rs_common.h"
 
 size_t rs_rnnt_workspace_bytes(const rs_ctx* ctx, int B);
+size_t rs_rnnt_alsd_workspace_bytes_impl(const rs_ctx* ctx, int B, int beam, int cap);
+int rs_rnnt_alsd_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int beam, double ratio,
+                      int abs_len, int score_norm, int merge, int out_cap, int32_t* ids, int32_t* steps, int32_t* n_ids,
+                      float* scores, void* workspace, size_t workspace_bytes, hipStream_t s);
 int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int u_max,
                         int32_t* ids, int32_t* frames, int32_t* n_ids, void* workspace, size_t workspace_bytes,
                         hipStream_t s);
@@ -461,6 +465,37 @@ int rs_rnnt_greedy(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens,
     if (tp_max == 0) { RS_HIP(ctx, hipMemsetAsync(n_ids, 0, (size_t)B * 4, (hipStream_t)stream)); return RS_OK; }
     return rs_rnnt_greedy_impl(ctx, joint_enc, enc_lens, B, tp_max, u_max, ids, frames, n_ids, workspace,
                                workspace_bytes, (hipStream_t)stream);
+}
+
+static int alsd_steps(int tp_max, double ratio, int abs_len) {
+    const int budget = abs_len >= 0 ? abs_len : (int)(ratio * (double)tp_max);
+    return tp_max + budget > 0 ? tp_max + budget : 1;
+}
+
+size_t rs_rnnt_alsd_workspace_bytes(const rs_ctx* ctx, int B, int beam, int tp_max, double max_target_ratio, int max_target_abs) {
+    if (!ctx || B <= 0 || beam <= 0 || tp_max < 0 || (max_target_abs < 0 && !(max_target_ratio >= 0.0))) return 0;
+    const int W = beam < ctx->d.n_logits - 1 ? beam : ctx->d.n_logits - 1;
+    return rs_rnnt_alsd_workspace_bytes_impl(ctx, B, W, alsd_steps(tp_max, max_target_ratio, max_target_abs));
+}
+
+int rs_rnnt_alsd(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int beam,
+                 double max_target_ratio, int max_target_abs, int flags, int out_cap, int32_t* ids, int32_t* steps,
+                 int32_t* n_ids, float* scores, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_rnnt_alsd");
+    if (B < 0 || tp_max < 0 || out_cap < 0) return rs_fail(ctx, RS_EINVAL, "alsd: negative size");
+    if (max_target_abs < 0 && !(max_target_ratio >= 0.0 && max_target_ratio <= 64.0))
+        return rs_fail(ctx, RS_EINVAL, "alsd: max_target_ratio must be in [0, 64]");
+    if (B == 0) return RS_OK;
+    if (!joint_enc || !enc_lens || !ids || !steps || !n_ids || !scores || !workspace) return rs_fail(ctx, RS_EINVAL, "alsd: null pointer");
+    if (tp_max == 0) {
+        RS_HIP(ctx, hipMemsetAsync(n_ids, 0, (size_t)B * 4, (hipStream_t)stream));
+        RS_HIP(ctx, hipMemsetAsync(scores, 0, (size_t)B * 4, (hipStream_t)stream));
+        return RS_OK;
+    }
+    return rs_rnnt_alsd_impl(ctx, joint_enc, enc_lens, B, tp_max, beam, max_target_ratio, max_target_abs,
+                             (flags & RS_ALSD_SCORE_NORM) != 0, (flags & RS_ALSD_MERGE) != 0, out_cap, ids, steps, n_ids, scores,
+                             workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // ---- profiling -------------------------------------------------------------------------------------

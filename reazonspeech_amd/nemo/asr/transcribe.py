@@ -3,8 +3,9 @@ plus the additive batched entry point `transcribe_batch()` the RTFx metric is qu
 
 What changes underneath: NeMo's `EncDecRNNTBPEModel` is replaced by
 `reazonspeech_amd.runtime.model.AsrModel` (HIP kernels behind include/rs_asr.h); padding is
-folded into the front-end kernel instead of `np.pad`; decoding is batched greedy, adapted to
-the ALSD-shaped `Hypothesis` the reference post-processor expects (interface.Hypothesis).
+folded into the front-end kernel instead of `np.pad`; decoding is the checkpoint's strategy — batched
+greedy or ALSD beam search on the device — adapted to the ALSD-shaped `Hypothesis` the reference
+post-processor expects (interface.Hypothesis).
 """
 import os
 import sys
@@ -21,7 +22,7 @@ from .audio import norm_audio
 CHECKPOINT_ENV = "REAZONSPEECH_NEMO_CHECKPOINT"
 
 
-def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None):
+def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, decoding=None, beam_size=None):
     """Load the ReazonSpeech FastConformer-RNNT model onto a ROCm GPU.
 
     Args:
@@ -33,6 +34,9 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None):
         (benchmarks / tests; transcripts are then meaningless).
       config (ModelConfig): override the architecture for synthetic weights.
       seed (int): seed of the synthetic weights.
+      decoding (str): override the checkpoint's decoding strategy: "greedy_batch" or "alsd" (alignment-length
+        synchronous beam search, what the reference checkpoint ships with: decode.py:29,38-41).
+      beam_size (int): override the beam size of "alsd" (1..8).
       pos_cap (int): encoder frames (80 ms each) the resident relative-position tables cover at load time
         (default 1024, about 82 s); longer utterances grow the tables on first use.
 
@@ -57,6 +61,10 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None):
         cfg = config or FASTCONFORMER_619M
         sd = W.synthetic_state_dict(cfg, seed)
         tokenizer = SyntheticTokenizer(cfg.vocab_size, seed)
+    if decoding is not None:
+        cfg = cfg.with_(decoding=str(decoding))
+    if beam_size is not None:
+        cfg = cfg.with_(beam_size=int(beam_size))
     kw = {} if pos_cap is None else {"pos_cap": int(pos_cap)}
     return AsrModel(cfg, sd, tokenizer, device=device, pad_seconds=PAD_SECONDS, **kw)
 
@@ -90,8 +98,11 @@ def transcribe_batch(model, audios, config=None, distributed=False):
               f"{sum(len(w) for w in waves) / 16000.0:.1f} s of audio on {model.device}", file=sys.stderr, flush=True)
     decoded = model.transcribe_waveforms_sharded(waves) if distributed else model.transcribe_waveforms(waves)
     results = []
-    for ids, frames in zip(decoded.ids, decoded.frames):
+    for k, (ids, frames) in enumerate(zip(decoded.ids, decoded.frames)):
+        # greedy and ALSD results share one adapter: labels + the encoder frame each was emitted at
         hyp = Hypothesis.from_greedy(ids, frames, model.cfg.blank_id)
+        if decoded.scores is not None:
+            hyp.score = decoded.scores[k]
         ret = decode_hypothesis(model, hyp)
         if config.raw_hypothesis:
             ret.hypothesis = hyp

@@ -12,11 +12,13 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_in
 _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "librs_asr.so")
 
 RS_OK = 0
+RS_EINVAL = -1
 RS_EOVERFLOW = -5
 ERRORS = {-1: "RS_EINVAL", -2: "RS_EMISSING", -3: "RS_EWORKSPACE", -4: "RS_EHIP", -5: "RS_EOVERFLOW",
           -6: "RS_ESTATE"}
 
 GEMM_BIAS, GEMM_RELU, GEMM_SILU, GEMM_RESIDUAL, GEMM_OUT_F32, GEMM_ROWMASK = 1, 2, 4, 8, 16, 32
+ALSD_SCORE_NORM, ALSD_MERGE = 1, 2
 PROF_GEMM, PROF_ATTN, PROF_FRONTEND, PROF_DECODE, PROF_ELEMENTWISE, PROF_SUBSAMPLE = 1, 2, 4, 8, 16, 32
 
 # every symbol include/rs_asr.h declares (tests/test_capi_exports.py checks the .so exports them)
@@ -25,6 +27,7 @@ EXPORTS = [
     "rs_workspace_bytes", "rs_mel_frames", "rs_enc_frames", "rs_frontend_logmel", "rs_encoder_forward",
     "rs_rnnt_greedy", "rs_profile_enable", "rs_profile_read", "rs_profile_reset", "rs_gemm_bf16",
     "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
+    "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes",
 ]
 
 
@@ -93,6 +96,10 @@ def load():
     lib.rs_stream_destroy.argtypes = [vp]
     lib.rs_encoder_set_taps.argtypes = [vp, vp, vp, POINTER(c_int32), c_int]
     lib.rs_rnnt_greedy.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
+    lib.rs_rnnt_alsd_workspace_bytes.argtypes = [vp, c_int, c_int, c_int, c_double, c_int]
+    lib.rs_rnnt_alsd_workspace_bytes.restype = c_size_t
+    lib.rs_rnnt_alsd.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_double, c_int, c_int, c_int, vp, vp, vp, vp, vp,
+                                 c_size_t, vp]
     lib.rs_profile_enable.argtypes = [vp, c_int]
     lib.rs_profile_reset.argtypes = [vp]
     lib.rs_profile_read.argtypes = [vp, c_int, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
@@ -228,6 +235,29 @@ class Context:
         self.check(self.lib.rs_rnnt_greedy(self._h, _ptr(joint_enc), _ptr(enc_lens), B, tp_max, u_max, _ptr(ids),
                                            _ptr(frames), _ptr(n_ids), _ptr(ws), ws.numel() * ws.element_size(),
                                            c_void_p(stream)))
+
+    @staticmethod
+    def _alsd_budget(max_target_len):
+        """(ratio, abs) of the C ABI: a float is a multiple of the frame count, an int an absolute label budget"""
+        if isinstance(max_target_len, float):
+            return float(max_target_len), -1
+        return 0.0, int(max_target_len)
+
+    def alsd_workspace_bytes(self, B, beam, tp_max, max_target_len):
+        ratio, abs_len = self._alsd_budget(max_target_len)
+        n = self.lib.rs_rnnt_alsd_workspace_bytes(self._h, B, beam, tp_max, ratio, abs_len)
+        if n == 0:
+            raise RuntimeError("rs_rnnt_alsd_workspace_bytes: invalid arguments")
+        return n
+
+    def rnnt_alsd(self, joint_enc, enc_lens, B, tp_max, beam, max_target_len, score_norm, merge, ids, steps, n_ids,
+                  scores, ws, stream):
+        """ids / steps int32 [B][out_cap], n_ids int32 [B], scores float32 [B]"""
+        ratio, abs_len = self._alsd_budget(max_target_len)
+        flags = (ALSD_SCORE_NORM if score_norm else 0) | (ALSD_MERGE if merge else 0)
+        self.check(self.lib.rs_rnnt_alsd(self._h, _ptr(joint_enc), _ptr(enc_lens), B, tp_max, beam, ratio, abs_len, flags,
+                                         ids.shape[1], _ptr(ids), _ptr(steps), _ptr(n_ids), _ptr(scores), _ptr(ws),
+                                         ws.numel() * ws.element_size(), c_void_p(stream)))
 
     # ---- profiling ----
     def profile_enable(self, mask):

@@ -43,6 +43,11 @@ class ModelConfig:
     pred_layers: int = 2
     joint_hidden: int = 640
     max_symbols: int = 10
+    # --- decoding strategy (checkpoint cfg `decoding.*`; [UPSTREAM] RNNTDecodingConfig / BeamRNNTInferConfig) ---
+    decoding: str = "greedy_batch"       # "greedy" / "greedy_batch": batched greedy; "alsd": alignment-length synchronous beam search
+    beam_size: int = 4                   # decoding.beam.beam_size (1..8 on the device)
+    alsd_max_target_len: float = 2.0     # decoding.beam.alsd_max_target_len: float = multiple of T', int = absolute label budget
+    beam_score_norm: bool = True         # decoding.beam.score_norm: rank finished hypotheses by score / len(y_sequence)
 
     # ---- derived ----
     @property
@@ -115,6 +120,9 @@ class ModelConfig:
         assert self.pred_hidden == self.joint_hidden or True
         assert self.conv_kernel % 2 == 1 and self.conv_kernel <= 31
         assert self.n_fft == 512 and self.win_length <= 512
+        assert self.decoding in ("greedy", "greedy_batch", "alsd"), f"decoding strategy {self.decoding!r}"
+        assert 1 <= self.beam_size <= 8, "beam_size 1..8"
+        assert self.alsd_max_target_len >= 0
         return self
 
 
@@ -182,8 +190,8 @@ def from_nemo_yaml(cfg: dict, strict: bool = True) -> ModelConfig:
     With `strict` (the default) every setting that would make the kernels compute something else than the
     checkpoint's architecture raises `UnsupportedCheckpoint` instead of loading silently: other
     subsampling types, LayerNorm in the conv module, Longformer global attention with separate projections,
-    a non-per-feature front-end normalisation, frame splicing, a non-ReLU joint, and so on.  A decoding
-    strategy other than greedy only warns: the path decodes greedily by design."""
+    a non-per-feature front-end normalisation, frame splicing, a non-ReLU joint, and so on.  `decoding.strategy`
+    greedy / greedy_batch / alsd select the device search; anything else warns and decodes greedily."""
     import warnings
     if "model" in cfg and isinstance(cfg["model"], dict) and "encoder" in cfg["model"]:
         cfg = {**cfg["model"], "model": cfg["model"]}        # training-style file: the model subtree is the config
@@ -233,9 +241,17 @@ def from_nemo_yaml(cfg: dict, strict: bool = True) -> ModelConfig:
         need(dec.get("blank_as_pad", True) in (True, None), "decoder.blank_as_pad=false")
         need(str(prednet.get("rnn_type", "lstm") or "lstm").lower() == "lstm" if "rnn_type" in prednet else True, "a non-LSTM prediction network")
     strategy = str(decoding.get("strategy", "greedy_batch"))
-    if strategy not in ("greedy", "greedy_batch"):
-        warnings.warn(f"checkpoint decoding.strategy={strategy!r}: this path always decodes greedily (batched greedy RNN-T); "
-                      "transcripts can differ from the reference's beam search", RuntimeWarning, stacklevel=2)
+    beam = decoding.get("beam", {}) or {}
+    if strategy not in ("greedy", "greedy_batch", "alsd"):
+        warnings.warn(f"checkpoint decoding.strategy={strategy!r}: only greedy and alsd are implemented; decoding greedily "
+                      "(batched greedy RNN-T), transcripts can differ from the reference's beam search", RuntimeWarning,
+                      stacklevel=2)
+        strategy = "greedy_batch"
+    beam_size = int(beam.get("beam_size", 4) or 4)
+    if strategy == "alsd" and not 1 <= beam_size <= 8:
+        raise UnsupportedCheckpoint(f"decoding.beam.beam_size={beam_size}: the device beam search keeps 1..8 hypotheses")
+    max_target = beam.get("alsd_max_target_len", 2.0)
+    max_target = 2.0 if max_target is None else (int(max_target) if isinstance(max_target, int) else float(max_target))
     guard = pre.get("log_zero_guard_value", 2.0 ** -24)
     if isinstance(guard, str):            # NeMo also accepts the names of torch.finfo fields
         import torch
@@ -265,4 +281,8 @@ def from_nemo_yaml(cfg: dict, strict: bool = True) -> ModelConfig:
         pred_layers=int(prednet.get("pred_rnn_layers", 2)),
         joint_hidden=int(jn.get("joint_hidden", 640)),
         max_symbols=int(greedy.get("max_symbols", greedy.get("max_symbols_per_step", 10)) or 10),
+        decoding=strategy,
+        beam_size=min(max(beam_size, 1), 8),
+        alsd_max_target_len=max_target,
+        beam_score_norm=bool(beam.get("score_norm", True)),
     ).validate()

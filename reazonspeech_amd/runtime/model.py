@@ -22,10 +22,17 @@ from .weights import prepare_weights, DEFAULT_POS_CAP
 
 @dataclass
 class DecodedBatch:
-    """host-side result of one batch: token ids and emission frames per utterance"""
+    """host-side result of one batch: token ids and emission frames per utterance (+ the log-probability of the
+    hypothesis when it came from the beam search)"""
     ids: List[List[int]]
     frames: List[List[int]]
     enc_lens: List[int]
+    scores: Optional[List[float]] = None
+
+
+def alsd_label_budget(t_frames: int, max_target_len) -> int:
+    """labels a hypothesis may emit beyond the frames (oracle/alsd.py: float = multiple of T', int = absolute)"""
+    return int(max_target_len * t_frames) if isinstance(max_target_len, float) else int(max_target_len)
 
 
 class _Buffers:
@@ -39,6 +46,8 @@ class _Buffers:
         self.tp_max = max(ctx.enc_frames(self.t_max), 1)
         model.ensure_pos_cap(self.tp_max)
         self.u_max = self.tp_max * cfg.max_symbols
+        if cfg.decoding == "alsd":       # a hypothesis has at most one label per alignment step
+            self.u_max = max(1, self.tp_max + alsd_label_budget(self.tp_max, cfg.alsd_max_target_len))
         i32, f32 = torch.int32, torch.float32
         self.audio = torch.zeros((B, l_max), dtype=f32, device=dev)
         self.lens = torch.zeros((B,), dtype=i32, device=dev)
@@ -49,6 +58,8 @@ class _Buffers:
         self.ids = torch.zeros((B, self.u_max), dtype=i32, device=dev)
         self.frames = torch.zeros((B, self.u_max), dtype=i32, device=dev)
         self.n_ids = torch.zeros((B,), dtype=i32, device=dev)
+        self.scores = torch.zeros((B,), dtype=f32, device=dev)
+        self.ws_alsd = None              # beam-search scratch (grows with beam and alignment length): on first use
         self.ws = torch.empty((ctx.workspace_bytes(B, self.l_pad),), dtype=torch.uint8, device=dev)
         # the decoder of batch i overlaps the encoder of batch i+1 in the pipelined path: own scratch
         self.ws_dec = torch.empty((ctx.workspace_bytes(B, 16),), dtype=torch.uint8, device=dev)
@@ -177,8 +188,22 @@ class AsrModel:
                               buf.n_frames, buf.ws, stream)
             self.ctx.encoder(buf.feats, buf.n_frames, buf.B, buf.t_max, want_enc, buf.joint_enc, buf.enc_lens,
                              buf.ws, stream)
-            self.ctx.rnnt_greedy(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, buf.u_max, buf.ids, buf.frames,
-                                 buf.n_ids, buf.ws, stream)
+            self.decode(self.ctx, buf, buf.ws, stream)
+
+    def decode(self, ctx, buf: _Buffers, ws, stream):
+        """stage 3 on `stream`: the checkpoint's decoding strategy (cfg.decoding).  Greedy fills buf.ids / buf.frames
+        (emission frames); ALSD fills buf.ids / buf.frames (alignment steps i = frame + labels before) / buf.scores.
+        Both synchronise the stream."""
+        cfg = self.cfg
+        if cfg.decoding != "alsd":
+            ctx.rnnt_greedy(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, buf.u_max, buf.ids, buf.frames, buf.n_ids,
+                            ws, stream)
+            return
+        if buf.ws_alsd is None:
+            n = ctx.alsd_workspace_bytes(buf.B, cfg.beam_size, buf.tp_max, cfg.alsd_max_target_len)
+            buf.ws_alsd = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        ctx.rnnt_alsd(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, cfg.beam_size, cfg.alsd_max_target_len,
+                      cfg.beam_score_norm, False, buf.ids, buf.frames, buf.n_ids, buf.scores, buf.ws_alsd, stream)
 
     # ------------------------------------------------------------------------------------------
     def run_encoder(self, buf: _Buffers, stream, ctx=None):
@@ -260,8 +285,7 @@ class AsrModel:
                         try:
                             dec_stream.wait_event(ev)
                             # decode scratch lives past the encoder's scratch in buf.ws_dec
-                            self._ctx_dec.rnnt_greedy(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, buf.u_max, buf.ids,
-                                                      buf.frames, buf.n_ids, buf.ws_dec, dec_stream.cuda_stream)
+                            self.decode(self._ctx_dec, buf, buf.ws_dec, dec_stream.cuda_stream)
                             if from_host:
                                 with torch.cuda.stream(dec_stream):
                                     buf.h_out = (buf.n_ids.cpu(), buf.ids.cpu(), buf.frames.cpu())
@@ -342,8 +366,13 @@ class AsrModel:
         ids = buf.ids.cpu().numpy()
         frames = buf.frames.cpu().numpy()
         el = buf.enc_lens.cpu().numpy()
+        if self.cfg.decoding == "alsd":      # alignment step i = frame + labels emitted before
+            frames = frames - np.arange(frames.shape[1], dtype=frames.dtype)[None, :]
+            scores = buf.scores.cpu().numpy().tolist()
+        else:
+            scores = None
         return DecodedBatch([ids[b, :n[b]].tolist() for b in range(buf.B)],
-                            [frames[b, :n[b]].tolist() for b in range(buf.B)], el.tolist())
+                            [frames[b, :n[b]].tolist() for b in range(buf.B)], el.tolist(), scores)
 
     def transcribe_waveforms_sharded(self, waveforms: Sequence[np.ndarray], max_batch: int = 256) -> DecodedBatch:
         """SPMD form of `transcribe_waveforms` for one process per GPU (`torch.distributed` initialised, RCCL):
@@ -373,7 +402,7 @@ class AsrModel:
             self.run_device(buf)
             return self.collect(buf)
         order = sorted(range(n), key=lambda i: (len(waveforms[i]), i))
-        ids, frames, enc_lens = [None] * n, [None] * n, [None] * n
+        ids, frames, enc_lens, scores = [None] * n, [None] * n, [None] * n, [None] * n
         groups = [order[i:i + max_batch] for i in range(0, n, max_batch)]
         l_max = max(len(w) for w in waveforms)
         pool = [self.new_buffers(max_batch, l_max), self.new_buffers(max_batch, l_max)]
@@ -388,6 +417,7 @@ class AsrModel:
             res = self.collect(buf)
             for k, i in enumerate(group):
                 ids[i], frames[i], enc_lens[i] = res.ids[k], res.frames[k], res.enc_lens[k]
+                scores[i] = res.scores[k] if res.scores is not None else None
 
         # the pipeline needs inputs resident before a step starts: stage two groups ahead of use
         pending = {}
@@ -408,4 +438,4 @@ class AsrModel:
             else:
                 self.run_device(pool[0])
                 after(pool[0])
-        return DecodedBatch(ids, frames, enc_lens)
+        return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.decoding == "alsd" else None)

@@ -381,7 +381,12 @@ def test_read_nemo_like_archive(tmp_path):
     missing = {k: v for k, v in sd.items() if k != "encoder.layers.1.conv.batch_norm.running_var"}
     with pytest.raises(UnsupportedCheckpoint, match="running_var"):
         W.prepare_weights(cfg, missing, pos_cap=16)
-    # a beam-search checkpoint loads, with a warning that this path decodes greedily
+    # the shipped checkpoint's strategy (ALSD beam search, decode.py:29,38) selects the device beam search ...
     _nemo_like_archive(path, sd, NEMO_YAML % dict(fill, strategy="alsd"), spm_model, gz=False)
+    cfg_alsd, _, _ = W.read_nemo(path)
+    assert (cfg_alsd.decoding, cfg_alsd.beam_size, cfg_alsd.alsd_max_target_len, cfg_alsd.beam_score_norm) == ("alsd", 4, 2.0, True)
+    assert cfg.decoding == "greedy_batch"
+    # ... and a search that is not implemented loads with a warning that this path decodes greedily instead
+    _nemo_like_archive(path, sd, NEMO_YAML % dict(fill, strategy="maes"), spm_model, gz=False)
     with pytest.warns(RuntimeWarning, match="greedily"):
-        W.read_nemo(path)
+        assert W.read_nemo(path)[0].decoding == "greedy_batch"
