@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--enc-streams", type=int, default=int(os.environ.get("RS_ENC_STREAMS", "1")),
                     help="experimental: encoders of consecutive batches on two streams (four resident batches)")
+    ap.add_argument("--decoding", default="greedy_batch", choices=["greedy_batch", "alsd"],
+                    help="decode strategy: the headline metric is greedy; alsd = the device beam search (extra line for profiles/)")
+    ap.add_argument("--beam", type=int, default=4, help="beam size of --decoding alsd")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decode of each batch back to back on one stream")
     args = ap.parse_args()
@@ -157,6 +160,9 @@ def main():
         rdist.init("nccl")
 
     cfg = TINY if args.tiny else FASTCONFORMER_619M
+    alsd = args.decoding == "alsd"
+    if alsd:
+        cfg = cfg.with_(decoding="alsd", beam_size=args.beam)
     t0 = time.time()
     sd = synthetic_state_dict(cfg, seed=0)
     model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device=f"cuda:{local_rank}")
@@ -231,18 +237,20 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": f"RTFx (audio-sec/wall-sec), FastConformer-RNNT 619M batch={args.batch}",
+            "metric": f"RTFx (audio-sec/wall-sec), FastConformer-RNNT 619M batch={args.batch}"
+                      + (f", ALSD beam {args.beam} decode" if alsd else ""),
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "ms_per_step_median": round(median_ms, 3) if median_ms else None, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"FastConformer-RNNT {cfg.n_params() / 1e6:.0f}M, {args.batch} x "
-                                   f"{args.seconds:g} s utterances per GPU (+0.5 s pad each side), greedy decode, "
+                                   f"{args.seconds:g} s utterances per GPU (+0.5 s pad each side), "
+                                   + (f"ALSD beam-{args.beam} decode (max_target_len {cfg.alsd_max_target_len:g})" if alsd else "greedy decode") + ", "
                                    "random-init weights", "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "parallelism": f"dp{world}",
                        "enc_frames": buf.tp_max, "mean_tokens_per_utt": round(mean_tokens, 1),
                        "max_tokens_per_utt": int(n_ids.max()),
-                       "schedule": ("2-stage pipeline: encoder(i+1) || greedy decode(i) on two HIP streams"
+                       "schedule": ("2-stage pipeline: encoder(i+1) || decode(i) on two HIP streams"
                                     + (" (encoders of consecutive batches on two streams)" if args.enc_streams == 2 else ""))
                                    if pipelined else "sequential"},
             "setup_s": round(setup_s, 1),
@@ -262,14 +270,14 @@ def main():
                     traffic = json.load(fp)["hbm_bytes_per_launch"]
             except Exception:
                 pass
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_mf16_kernel / gemm_bf16_kernel (all encoder linears)",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_lmf16_kernel (all encoder linears; gemm_bf16_kernel for the small shapes)",
                                "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (PMC, profiles/gemm_traffic.json)",
                                "algorithmic_bytes_per_launch": round(gemm["bytes"] / gemm["launches"]),
                                "launches": gemm["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
                                "share_of_step": round(gemm["ms"] / (dt * 1e3), 3)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not alsd:     # the CPU leg and its parity check are the greedy path's
             budget, k = (5.0, 2) if args.tiny else (20.0, 8)
             out["cpu_baseline"], cpu_outputs = cpu_baseline(cfg, sd, audio0, lens0, seconds_budget=budget, max_utt=k)
             try:
