@@ -230,6 +230,18 @@ def main():
         torch.cuda.synchronize()
         dt_host = time.perf_counter() - t1
 
+    # the same GEMM launches without the decode stream next to them (sequential schedule, 2 steps): how much of the
+    # in-pipeline figure is CU sharing with the decode kernels rather than the kernel itself
+    gemm_seq = None
+    if prof and pipelined and world == 1:
+        model.ctx.profile_reset()
+        model.ctx.profile_enable(capi.PROF_GEMM)
+        for i in range(2):
+            model.run_device(bufs[i % n_sets])
+        torch.cuda.synchronize()
+        gemm_seq = model.ctx.profile_read(capi.PROF_GEMM)
+        model.ctx.profile_enable(0)
+
     n_ids = np.concatenate([b.n_ids.cpu().numpy() for b in bufs])
     mean_tokens = float(n_ids.mean())
     audio_seconds = sum(float(lens_all[i % n_sets].sum()) for i in range(args.steps)) / 16000.0 * world
@@ -277,6 +289,10 @@ def main():
                                "algorithmic_bytes_per_launch": round(gemm["bytes"] / gemm["launches"]),
                                "launches": gemm["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
                                "share_of_step": round(gemm["ms"] / (dt * 1e3), 3)}
+            if gemm_seq and gemm_seq["launches"]:
+                seq = gemm_seq["flops"] / (gemm_seq["ms"] * 1e-3) / 1e12
+                out["roofline"]["achieved_sequential_schedule"] = round(seq, 1)
+                out["roofline"]["frac_sequential_schedule"] = round(seq / MFMA_BF16_PEAK_TFLOPS, 4)
         if world == 1 and not args.no_cpu_baseline and not alsd:     # the CPU leg and its parity check are the greedy path's
             budget, k = (5.0, 2) if args.tiny else (20.0, 8)
             out["cpu_baseline"], cpu_outputs = cpu_baseline(cfg, sd, audio0, lens0, seconds_budget=budget, max_utt=k)
