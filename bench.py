@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--decoding", default="greedy_batch", choices=["greedy_batch", "alsd"],
                     help="decode strategy: the headline metric is greedy; alsd = the device beam search (extra line for profiles/)")
     ap.add_argument("--beam", type=int, default=4, help="beam size of --decoding alsd")
+    ap.add_argument("--buffer-sets", type=int, default=int(os.environ.get("RS_BUFFER_SETS", "2")),
+                    help="resident batches the pipeline rotates through (2 = encoder i+1 waits for decode i-1)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decode of each batch back to back on one stream")
     args = ap.parse_args()
@@ -168,7 +170,7 @@ def main():
     model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device=f"cuda:{local_rank}")
     # two resident batches (different utterances): the pipelined path alternates between them
     bufs, lens_all = [], []
-    n_sets = 4 if args.enc_streams == 2 else 2
+    n_sets = 4 if args.enc_streams == 2 else max(2, args.buffer_sets)
     for k in range(n_sets):
         audio, lens = synthetic_batch(args.batch, args.seconds, seed=1234 + 17 * rank + 1000 * k)
         b = model.stage([audio[i, :lens[i]] for i in range(args.batch)],
@@ -253,14 +255,16 @@ def main():
                       + (f", ALSD beam {args.beam} decode" if alsd else ""),
             "value": round(value, 1), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "ms_per_step_median": round(median_ms, 3) if median_ms else None, "higher_is_better": True,
+            "ms_per_step_median": round(median_ms, 3) if median_ms else None,
+            "step_intervals_ms": [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])],
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"FastConformer-RNNT {cfg.n_params() / 1e6:.0f}M, {args.batch} x "
                                    f"{args.seconds:g} s utterances per GPU (+0.5 s pad each side), "
                                    + (f"ALSD beam-{args.beam} decode (max_target_len {cfg.alsd_max_target_len:g})" if alsd else "greedy decode") + ", "
                                    "random-init weights", "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "parallelism": f"dp{world}",
-                       "enc_frames": buf.tp_max, "mean_tokens_per_utt": round(mean_tokens, 1),
+                       "enc_frames": buf.tp_max, "resident_batches": n_sets, "mean_tokens_per_utt": round(mean_tokens, 1),
                        "max_tokens_per_utt": int(n_ids.max()),
                        "schedule": ("2-stage pipeline: encoder(i+1) || decode(i) on two HIP streams"
                                     + (" (encoders of consecutive batches on two streams)" if args.enc_streams == 2 else ""))

@@ -688,7 +688,7 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // one wave execute in order).  bf16 output: chunks of 32 rows x 64 columns; f32: 16 rows x 64 columns; both 4 KiB,
 // 16-byte pieces XOR-swizzled by row.  All global accesses are raw buffer operations (masked rows / columns get an
 // out-of-range offset), so the number of VMEM operations a wave issues here is a compile-time constant.
-template <int MI, int NI, int OUT, bool MASK>
+template <int MI, int NI, int OUT, bool MASK, int PF = 1>
 __device__ __forceinline__ void pmf16_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][NI], char* scr, int cm0, int cn0,
                                                int wm, int wn, int lane) {
     constexpr bool RES = OUT == 2, out_f32 = OUT >= 1, rowmask = MASK;
@@ -751,10 +751,14 @@ __device__ __forceinline__ void pmf16_epilogue(const GemmParams& p, f32x4_t (&ac
             }
         }
     } else {
-        // f32: chunks of 16 rows x 64 columns (4 KiB, 256-byte rows, 16-byte pieces XOR-swizzled by row);
-        // the residual of chunk i+1 is requested (row-major, whole 256-byte segments) before chunk i is stored
+        // f32: chunks of 16 rows x 64 columns (4 KiB, 256-byte rows, 16-byte pieces XOR-swizzled by row).
+        // The residual rows (row-major, whole 256-byte segments) are requested PF chunks ahead: with one chunk of
+        // lookahead every chunk paid a full HBM round trip (a dependent chain of MI latencies per wave, ~14 us of a
+        // 36 us K = 1024 tile); with PF = MI every residual load of the tile is in flight before the first chunk
+        // is touched and the epilogue costs one latency.
         const int rr4 = lane >> 4, cc = lane & 15;
-        u32x4_t rv_next[4];
+        constexpr int NPF = RES ? (PF < 1 ? 1 : (PF > MI ? MI : PF)) : 1;
+        u32x4_t rvq[NPF][4];
         auto load_res = [&](int i, u32x4_t (&rv)[4]) {
 #pragma unroll
             for (int sgm = 0; sgm < 4; ++sgm) {
@@ -763,14 +767,17 @@ __device__ __forceinline__ void pmf16_epilogue(const GemmParams& p, f32x4_t (&ac
                 rv[sgm] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, off, 0, 0);
             }
         };
-        if constexpr (RES) load_res(0, rv_next);
+        if constexpr (RES) {
+#pragma unroll
+            for (int d = 0; d < NPF; ++d) load_res(d, rvq[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             u32x4_t rv[4];
             if constexpr (RES) {
 #pragma unroll
-                for (int sgm = 0; sgm < 4; ++sgm) rv[sgm] = rv_next[sgm];
-                if (i + 1 < MI) load_res(i + 1, rv_next);
+                for (int sgm = 0; sgm < 4; ++sgm) rv[sgm] = rvq[i % NPF][sgm];
             }
 #pragma unroll
             for (int jj = 0; jj < NI; ++jj) {
@@ -790,6 +797,9 @@ __device__ __forceinline__ void pmf16_epilogue(const GemmParams& p, f32x4_t (&ac
                 if (!row_keep(m)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), out_rsrc, off, 0, 0);
+            }
+            if constexpr (RES) {
+                if (i + NPF < MI) load_res(i + NPF, rvq[i % NPF]);       // refill the slot this chunk just consumed
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -816,9 +826,14 @@ __device__ __forceinline__ void pmf16_epilogue(const GemmParams& p, f32x4_t (&ac
 //   * the ring keeps running across the tiles of a persistent workgroup exactly as in gemm_pmf16_kernel.
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 
-// ABL (profiling builds, wrong results): 1 = no MFMAs, 2 = no DMAs in the main loop, 3 = no fragment reads
-template <int BM, int OUT, bool MASK, int NM0, int ABL = 0>
+// ABL (profiling builds): 1 = no MFMAs, 2 = no DMAs in the main loop, 3 = no fragment reads (wrong results);
+// 4 = correct results plus a per-tile timeline in p.trace (scripts/gemm_trace.py).
+// EPF: residual prefetch depth of the f32 epilogue in 16-row chunks (pmf16_epilogue).
+template <int BM, int OUT, bool MASK, int NM0, int ABL = 0, int EPF = 1>
 __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
+    constexpr bool TRACE = ABL == 4;
+    long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_w0 = 0, tr_stall = 0;
+    if constexpr (TRACE) { tr_t0 = __builtin_readcyclecounter(); tr_w0 = (long long)wall_clock64(); }
     constexpr int BN = 256, WN = 4, NWAVES = 8;
     constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -890,6 +905,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind from here on
+    if constexpr (TRACE) tr_t1 = __builtin_readcyclecounter();
 
     for (int j = slot; j < xcount; j += nslots) {
         const bool has_next = j + nslots < xcount;
@@ -927,7 +943,10 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
 #pragma unroll
                     for (int qq = 0; qq < (NM0 < NP ? NM0 : NP); ++qq) dma(qq, tn, nbuf);
                 }
-                if (ks == 1 && more && wm == 1) wait_vmcnt<0>();            // group 1: K tile t+1 landed (see header)
+                if (ks == 1 && more && wm == 1) {                           // group 1: K tile t+1 landed (see header)
+                    if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_vmcnt<0>(); tr_stall += __builtin_readcyclecounter() - a; }
+                    else wait_vmcnt<0>();
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -948,7 +967,10 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (ks == 1 && more && wm == 0) wait_vmcnt<0>();            // group 0: before the barrier its reads follow
+                if (ks == 1 && more && wm == 0) {                           // group 0: before the barrier its reads follow
+                    if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_vmcnt<0>(); tr_stall += __builtin_readcyclecounter() - a; }
+                    else wait_vmcnt<0>();
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -959,13 +981,26 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
         {
             int em0 = __builtin_amdgcn_readfirstlane(cm0), en0 = __builtin_amdgcn_readfirstlane(cn0);
             asm volatile("" : "+s"(em0), "+s"(en0));
-            pmf16_epilogue<MI, NI, OUT, MASK>(p, acc, scr, em0, en0, wm, wn, lane);
+            if constexpr (TRACE) tr_t2 = __builtin_readcyclecounter();
+            pmf16_epilogue<MI, NI, OUT, MASK, EPF>(p, acc, scr, em0, en0, wm, wn, lane);
+            if constexpr (TRACE) {
+                // wave 0 (group 0) and wave 4 (group 1) each write a record: [0] prologue, [1] main loop, [2] epilogue
+                // issue, [3] store drain, [4] cycles stalled in the K-tile waits, [5] block, [6] / [7] wall clock
+                const long long t3 = __builtin_readcyclecounter();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const long long t4 = __builtin_readcyclecounter();
+                if (lane == 0 && wn == 0) {
+                    long long* tr = p.trace + ((size_t)(xbase + j) * 2 + wm) * 8;
+                    tr[0] = tr_t1 - tr_t0; tr[1] = tr_t2 - tr_t1; tr[2] = t3 - tr_t2; tr[3] = t4 - t3; tr[4] = tr_stall;
+                    tr[5] = bid; tr[6] = tr_w0; tr[7] = (long long)wall_clock64();
+                }
+            }
         }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier at the start
 }
 
-template <int BM, int NM0, int ABL = 0>
+template <int BM, int NM0, int ABL = 0, int EPF = 1>
 int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
     constexpr int BN = 256;
     constexpr int LDS = 2 * (BM + BN) * 128 + 8 * 4096;
@@ -986,10 +1021,21 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
         hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 0, false, NM0, ABL>), dim3(grid), dim3(512), LDS, s, p);
         return RS_OK;
     }
+    if (p.trace) {      // debug build of the same kernel that records a per-tile timeline (one tile per workgroup only)
+        if (mask || out == 1 || grid != nwg) return rs_fail(ctx, RS_EINVAL, "gemm trace: plain bf16 or residual output, one tile per workgroup");
+        if (out == 2) {
+            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 2, false, NM0, 4, EPF>, LDS); rc != RS_OK) return rc;
+            hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 2, false, NM0, 4, EPF>), dim3(grid), dim3(512), LDS, s, p);
+        } else {
+            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 0, false, NM0, 4, EPF>, LDS); rc != RS_OK) return rc;
+            hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 0, false, NM0, 4, EPF>), dim3(grid), dim3(512), LDS, s, p);
+        }
+        return RS_OK;
+    }
 #define RS_LMF(O, MK)                                                                                         \
     do {                                                                                                      \
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, O, MK, NM0>, LDS); rc != RS_OK) return rc; \
-        hipLaunchKernelGGL((gemm_lmf16_kernel<BM, O, MK, NM0>), dim3(grid), dim3(512), LDS, s, p);            \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, O, MK, NM0, 0, EPF>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_lmf16_kernel<BM, O, MK, NM0, 0, EPF>), dim3(grid), dim3(512), LDS, s, p);            \
     } while (0)
     if (out == 2 && !mask) RS_LMF(2, false);
     else if (out == 1 && !mask) RS_LMF(1, false);
@@ -1003,7 +1049,7 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
 // Process-wide A/B knobs (debug / tuning only; the defaults are the measured winners and nothing in the product
 // path writes them).  Atomics initialised once from the environment, so concurrent first launches from the encoder
 // thread and the decode worker are safe; they are deliberately not per-context: they select code paths, not state.
-extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve;
+extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve, g_res_prefetch;
 extern std::atomic<long long*> g_trace;
 void gemm_knobs_from_env();
 
@@ -1063,6 +1109,7 @@ int launch_mf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
 std::atomic<long long*> g_trace{nullptr};
 std::atomic<int> g_variant{0}, g_skew{-1}, g_persistent{2}, g_group_m{0} /* 0 = by shape */, g_big{0};
 std::atomic<int> g_reserve{0};   // CUs the persistent kernel leaves free when a context does not say (rs_set_option)
+std::atomic<int> g_res_prefetch{6};   // residual chunks requested ahead by the f32 epilogue: 6 = all, 3, 1 = the round-2 kernel
 void gemm_knobs_from_env() {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1072,6 +1119,7 @@ void gemm_knobs_from_env() {
         env("RS_GEMM_PERSISTENT", g_persistent);  // 2 (default) = whole-line kernel, one tile per workgroup; 1 = persistent grid; 0 = round-1 kernels
         env("RS_GEMM_RESERVE_CUS", g_reserve);    // CUs the persistent grid leaves to other streams (contexts may override)
         env("RS_GEMM_BIG", g_big);                // big-tile kernel family (DESIGN.md A/B knob table)
+        env("RS_GEMM_RES_PREFETCH", g_res_prefetch);   // 6 (default) / 3 / 1 residual chunks in flight in the f32 epilogue
     });
 }
 
@@ -1151,6 +1199,8 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32) &&
         !((a.flags & RS_GEMM_ROWMASK) && (a.flags & (RS_GEMM_OUT_F32 | RS_GEMM_RESIDUAL))))
         v += 30 + (g_persistent.load() == 2 ? 1000 : 0);
+    // residual / f32 epilogue of the 192-row tile: deep residual prefetch (RS_GEMM_RES_PREFETCH=1 restores one chunk ahead)
+    if (g_variant == 0 && v % 1000 == 62 && g_res_prefetch.load() != 1) v += g_res_prefetch.load() == 3 ? 30 : 20;
     if (ctx->n_cus <= 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
@@ -1169,6 +1219,9 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         case 63: rc = launch_lmf16<256, 5, 2>(ctx, p, s, pgrid); break;
         case 65: rc = launch_lmf16<256, 5, 3>(ctx, p, s, pgrid); break;
         case 62: rc = launch_lmf16<192, 5>(ctx, p, s, pgrid); break;
+        // 82 / 92: 62 with every / three of the six residual chunks of the f32 epilogue requested up front
+        case 82: rc = launch_lmf16<192, 5, 0, 6>(ctx, p, s, pgrid); break;
+        case 92: rc = launch_lmf16<192, 5, 0, 3>(ctx, p, s, pgrid); break;
         case 70: rc = launch_lmf16<256, 3>(ctx, p, s, pgrid); break;
         case 72: rc = launch_lmf16<192, 3>(ctx, p, s, pgrid); break;
         case 1: rc = launch_variant<128, 128, 64, 2, 2, 2>(ctx, p, s); break;   // small problems
