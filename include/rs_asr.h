@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 1
+#define RS_ABI_VERSION 2
 
 enum {
     RS_OK = 0,
@@ -88,7 +88,11 @@ int rs_abi_version(void);
  * from_pretrained (transcribe.py:26-28).
  * Optional derived tensors "L{i}.att.pos_proj" (bf16, same shape as "pos.table"): the position
  * table already multiplied by layer i's linear_pos weight (one rs_gemm_bf16 call per layer at load
- * time); when registered, rs_encoder_forward skips that projection in every call. */
+ * time); when registered, rs_encoder_forward skips that projection in every call.
+ * "L{i}.conv.pw1.w" / ".b" (the conv module's first pointwise convolution, 2*d_model output rows) are registered
+ * with their rows interleaved in blocks of 32: rows 64j .. 64j+31 are the value rows 32j .. 32j+31 of NeMo's
+ * pointwise_conv1, rows 64j+32 .. 64j+63 the matching gate rows d_model + 32j ..: a GLU pair then sits in one
+ * MFMA lane of the GEMM and is applied in its epilogue (RS_GEMM_GLU). */
 int rs_set_tensor(rs_ctx* ctx, const char* name, const void* dev_ptr, size_t nbytes);
 /* Check that every tensor the dims require is present; must precede any forward call. */
 int rs_finalize(rs_ctx* ctx);
@@ -224,7 +228,11 @@ int rs_profile_reset(rs_ctx* ctx);
 /* C[M][N] = epilogue(A[M][K] . W[N][K]^T); A, W bf16 row-major, K % 64 == 0.
  * flags: see RS_GEMM_* ; bias f32[N]; residual f32[M][ldc] (may alias out when out is f32). */
 enum { RS_GEMM_BIAS = 1, RS_GEMM_RELU = 2, RS_GEMM_SILU = 4, RS_GEMM_RESIDUAL = 8,
-       RS_GEMM_OUT_F32 = 16, RS_GEMM_ROWMASK = 32 };
+       RS_GEMM_OUT_F32 = 16, RS_GEMM_ROWMASK = 32,
+       /* out bf16[M][N/2] = (a + bias_a) * sigmoid(g + bias_g): columns 64j .. 64j+31 of the product are values,
+        * 64j+32 .. 64j+63 their gates (weight rows interleaved in blocks of 32, see rs_set_tensor); bias only,
+        * N % 64 == 0, K >= 128; always served by the big-tile kernel */
+       RS_GEMM_GLU = 64 };
 int rs_gemm_bf16(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                  void* out, int ldc, int M, int N, int K, int flags, const float* bias, float alpha,
                  const float* residual, const int32_t* mask_lens, int mask_rows_per_step,
@@ -245,6 +253,12 @@ int rs_relpos_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, c
  *   x bf16[B*T][2*d], dw_w f32[k][d] (tap-major), dw_b f32[d]; out bf16[B*T][d]. */
 int rs_glu_dwconv_silu(rs_ctx* ctx, const uint16_t* x, const float* dw_w, const float* dw_b,
                        const int32_t* lens, int B, int T, int d, int k, uint16_t* out, void* stream);
+/* The same operator for the other layouts of its input: RS_GLU_HALVES = the layout above (values | gates);
+ * RS_GLU_BLOCK32 = x bf16[B*T][2*d] with values / gates interleaved in blocks of 32 columns (the plain product of
+ * the interleaved pw1 weight); RS_GLU_APPLIED = x bf16[B*T][d], GLU already applied by RS_GEMM_GLU. */
+enum { RS_GLU_HALVES = 0, RS_GLU_BLOCK32 = 1, RS_GLU_APPLIED = 2 };
+int rs_glu_dwconv_silu_layout(rs_ctx* ctx, const uint16_t* x, int layout, const float* dw_w, const float* dw_b,
+                              const int32_t* lens, int B, int T, int d, int k, uint16_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,10 @@ against (HF = transformers/models/parakeet/...).
   "bf16"  same math, but tensors are rounded to bfloat16 exactly where the HIP path
           stores / feeds bf16 (GEMM operands, stored activations); accumulation,
           LayerNorm statistics, softmax, residual stream stay float32.
+  "bf16-fused-glu"  the bf16 recipe of the batches the big-tile GEMM serves (M >= 1024 rows and at least two
+          chip-fulls of tiles): the conv module's GLU is applied to the float32 accumulators in the pw1 GEMM
+          epilogue and ITS output is what gets stored as bf16 (the plain "bf16" recipe rounds the pw1 output and
+          applies the GLU in float32 inside the depthwise kernel).
 """
 import math
 from typing import Dict, Optional
@@ -20,7 +24,7 @@ import torch.nn.functional as F
 
 def _rb(x: torch.Tensor, recipe: str) -> torch.Tensor:
     """round to bf16 and back (identity in the fp32 recipe)"""
-    if recipe == "bf16":
+    if recipe in ("bf16", "bf16-fused-glu"):
         return x.to(torch.bfloat16).to(torch.float32)
     return x
 
@@ -208,9 +212,13 @@ def conv_module(cfg, sd, prefix, h, lens, recipe):
     depthwise weights exactly like the device weight prep does."""
     B, T, d = h.shape
     w1 = _rb(sd[prefix + ".pointwise_conv1.weight"].squeeze(-1), recipe)
-    y = _rb(h @ w1.t() + sd[prefix + ".pointwise_conv1.bias"], recipe)  # [B,T,2d]
+    y = h @ w1.t() + sd[prefix + ".pointwise_conv1.bias"]  # [B,T,2d]
+    if recipe != "bf16-fused-glu":
+        y = _rb(y, recipe)                   # pw1 output stored bf16, GLU inside the conv kernel (f32, not rounded)
     a, g = y[..., :d], y[..., d:]
     u = a * torch.sigmoid(g)
+    if recipe == "bf16-fused-glu":
+        u = _rb(u, recipe)                   # GLU in the pw1 GEMM epilogue (f32 accumulators), its output stored bf16
     u = u * _len_mask(lens, T)[:, :, None]
     wdw, bdw = fold_batchnorm(cfg, sd, prefix)
     z = F.conv1d(u.transpose(1, 2), wdw[:, None, :], bdw, padding=(cfg.conv_kernel - 1) // 2,

@@ -691,13 +691,14 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int MI, int NI, int OUT, bool MASK, int PF = 1>
 __device__ __forceinline__ void pmf16_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][NI], char* scr, int cm0, int cn0,
                                                int wm, int wn, int lane) {
-    constexpr bool RES = OUT == 2, out_f32 = OUT >= 1, rowmask = MASK;
+    constexpr bool RES = OUT == 2, out_f32 = OUT == 1 || OUT == 2, GLU = OUT == 3, rowmask = MASK;
     constexpr int TM = MI * 16, TN = NI * 16;
     constexpr unsigned OOB = 0xfffffff0u;                         // beyond every buffer: loads return 0, stores are dropped
     const int frow = lane & 15, fch = lane >> 4;
     const int flags = p.flags;
     const bool has_bias = flags & RS_GEMM_BIAS, relu = flags & RS_GEMM_RELU, silu = flags & RS_GEMM_SILU;
     const float alpha = p.alpha;
+    // GLU: the output has N / 2 columns (ldc is the caller's row pitch of that narrower matrix)
     const size_t out_bytes = (size_t)p.M * p.ldc * (out_f32 ? 4 : 2);
     const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
     const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.residual : (const float*)p.out), 0,
@@ -726,7 +727,37 @@ __device__ __forceinline__ void pmf16_epilogue(const GemmParams& p, f32x4_t (&ac
         const int b = step / p.mask_steps;
         return step - b * p.mask_steps < p.mask_lens[b];
     };
-    if constexpr (!out_f32) {
+    if constexpr (GLU) {
+        // GLU pairs inside the wave (weight rows interleaved in blocks of 32 by the loader: columns [0, 32) of a
+        // wave's 64 are the values, [32, 64) their gates, i.e. accumulator blocks jj and jj + NI / 2 of the SAME lane):
+        // out[m][n / 2 ...] = bf16( (a + bias_a) * sigmoid(g + bias_g) ).  Chunks of 32 rows x 32 output columns
+        // (2 KiB, 64-byte rows, 16-byte pieces XOR-swizzled by row); two 16-row x 64-byte stores per chunk.
+        static_assert(NI == 4, "GLU epilogue: 64-column wave tiles");
+        const int rr4 = lane >> 2, cc = lane & 3;
+        const int ocol0 = wcol0 >> 1;
+#pragma unroll
+        for (int c = 0; c < MI / 2; ++c) {
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float4 a = finish(2 * c + il, jj), g = finish(2 * c + il, jj + 2);
+                    const int row = il * 16 + frow;
+                    const int piece = (jj * 2 + (fch >> 1)) ^ ((row >> 1) & 3);
+                    *reinterpret_cast<u16x4_t*>(scr + row * 64 + piece * 16 + (fch & 1) * 8) =
+                        pack_bf16x4(a.x * sigmoid_f(g.x), a.y * sigmoid_f(g.y), a.z * sigmoid_f(g.z), a.w * sigmoid_f(g.w));
+                }
+#pragma unroll
+            for (int sgm = 0; sgm < 2; ++sgm) {
+                const int row = sgm * 16 + rr4;
+                u32x4_t d = *reinterpret_cast<const u32x4_t*>(scr + row * 64 + ((cc ^ ((row >> 1) & 3)) * 16));
+                const int m = wrow0 + c * 32 + row, n = ocol0 + cc * 8;
+                if (!row_keep(m)) d = (u32x4_t){0u, 0u, 0u, 0u};
+                const unsigned off = (m < p.M && 2 * n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 2u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(d, out_rsrc, off, 0, 0);
+            }
+        }
+    } else if constexpr (!out_f32) {
         // bf16: chunks of 32 rows x 64 columns (4 KiB, 128-byte rows, 16-byte pieces XOR-swizzled by row)
         const int rr8 = lane >> 3, cc = lane & 7;
 #pragma unroll
@@ -829,7 +860,11 @@ __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 // ABL (profiling builds): 1 = no MFMAs, 2 = no DMAs in the main loop, 3 = no fragment reads (wrong results);
 // 4 = correct results plus a per-tile timeline in p.trace (scripts/gemm_trace.py).
 // EPF: residual prefetch depth of the f32 epilogue in 16-row chunks (pmf16_epilogue).
-template <int BM, int OUT, bool MASK, int NM0, int ABL = 0, int EPF = 1>
+// L2PF: every wave touches 64 operand lines (128 B each) of K tile t + L2PF with one discarded dword load per K tile,
+// issued right after the DMAs of K tile t + 1 (0 = off).  The ring looks ahead ONE K tile (~1.5 us): enough for
+// operands that sit in L2 / the infinity cache, not for an A matrix streamed from HBM (ffn_down: 289 MB, rows 8 KiB
+// apart) — there wave group 1 sat 22 of 100 us per tile in the K-tile wait (profiles/r02u_gemm_tile_timeline.txt).
+template <int BM, int OUT, bool MASK, int NM0, int ABL = 0, int EPF = 1, int L2PF = 0>
 __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
     constexpr bool TRACE = ABL == 4;
     long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_w0 = 0, tr_stall = 0;
@@ -899,6 +934,31 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
     int m0, n0;
     tile_origin(slot, m0, n0);
     lane_offsets(m0, n0);
+    // L2 prefetch: waves 0 .. BM/64-1 cover the A rows of the tile (lane = row), the next four the weight rows
+    constexpr int PFA = BM / 64;
+    const bool pf_is_a = wave < PFA;
+    unsigned pf_off = 0;
+    unsigned pf_sink = 0;                                         // destination of the discarded loads (kept live to the end)
+    auto pf_offsets = [&](int m0_, int n0_) {
+        if constexpr (L2PF > 0) {
+            int w = pf_is_a ? wave : wave - PFA;
+            w = w < 4 ? w : 3;
+            int gr = (pf_is_a ? m0_ : n0_) + w * 64 + lane;
+            const int lim = pf_is_a ? p.M : p.N;
+            gr = gr < lim ? gr : lim - 1;
+            pf_off = (unsigned)gr * (unsigned)((pf_is_a ? p.lda : p.ldw) * 2);
+        }
+    };
+    pf_offsets(m0, n0);
+    auto l2_prefetch = [&](int t) {
+        if constexpr (L2PF > 0) {
+            t = t < nk ? t : nk - 1;
+            const char* base = (pf_is_a ? reinterpret_cast<const char*>(p.A) : reinterpret_cast<const char*>(p.W)) + (size_t)t * 128;
+            asm volatile("global_load_dword %0, %1, %2 nt" : "+v"(pf_sink) : "v"(pf_off), "s"(base) : "memory");
+        }
+    };
+    // K-tile waits: the one prefetch load issued after the DMAs may still be in flight
+    auto wait_ktile = [&]() { if constexpr (L2PF > 0) wait_vmcnt<1>(); else wait_vmcnt<0>(); };
     int gc = 0;                                                   // K tiles consumed so far (ring position)
 #pragma unroll
     for (int qq = 0; qq < NP; ++qq) dma(qq, 0, 0);
@@ -928,6 +988,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
             if (!own && has_next) {                               // all DMAs of this tile are issued: switch to the next tile
                 tile_origin(j + nslots, m0, n0);
                 lane_offsets(m0, n0);
+                pf_offsets(m0, n0);
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -944,8 +1005,8 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
                     for (int qq = 0; qq < (NM0 < NP ? NM0 : NP); ++qq) dma(qq, tn, nbuf);
                 }
                 if (ks == 1 && more && wm == 1) {                           // group 1: K tile t+1 landed (see header)
-                    if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_vmcnt<0>(); tr_stall += __builtin_readcyclecounter() - a; }
-                    else wait_vmcnt<0>();
+                    if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_ktile(); tr_stall += __builtin_readcyclecounter() - a; }
+                    else wait_ktile();
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -966,10 +1027,15 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
                         dma(NP - REST + i, tn, nbuf);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (L2PF > 0 && ks == 0 && i == (REST > 0 ? REST : 0) && more) {   // after the last DMA of K tile t + 1
+                        __builtin_amdgcn_sched_barrier(0);
+                        l2_prefetch(own ? t + L2PF : L2PF - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 if (ks == 1 && more && wm == 0) {                           // group 0: before the barrier its reads follow
-                    if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_vmcnt<0>(); tr_stall += __builtin_readcyclecounter() - a; }
-                    else wait_vmcnt<0>();
+                    if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_ktile(); tr_stall += __builtin_readcyclecounter() - a; }
+                    else wait_ktile();
                 }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -981,6 +1047,11 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
         {
             int em0 = __builtin_amdgcn_readfirstlane(cm0), en0 = __builtin_amdgcn_readfirstlane(cn0);
             asm volatile("" : "+s"(em0), "+s"(en0));
+            if constexpr (L2PF > 0) {
+                // the compiler does not know about the discarded loads: retire them before their register can be reused
+                // (with a next tile in flight this also waits for its first K tile, which the loop would do anyway)
+                if (!has_next) { wait_vmcnt<0>(); asm volatile("" :: "v"(pf_sink)); }
+            }
             if constexpr (TRACE) tr_t2 = __builtin_readcyclecounter();
             pmf16_epilogue<MI, NI, OUT, MASK, EPF>(p, acc, scr, em0, en0, wm, wn, lane);
             if constexpr (TRACE) {
@@ -1000,7 +1071,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier at the start
 }
 
-template <int BM, int NM0, int ABL = 0, int EPF = 1>
+template <int BM, int NM0, int ABL = 0, int EPF = 1, int L2PF = 0>
 int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
     constexpr int BN = 256;
     constexpr int LDS = 2 * (BM + BN) * 128 + 8 * 4096;
@@ -1014,7 +1085,7 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
               : (p.tiles_n == 4 ? (p.K >= 4096 ? 2 : 6) : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8)));
     p.skew_cycles = 0;
     const int grid = nwg < grid_cap ? nwg : grid_cap;
-    const int out = (p.flags & RS_GEMM_RESIDUAL) ? 2 : ((p.flags & RS_GEMM_OUT_F32) ? 1 : 0);
+    const int out = (p.flags & RS_GEMM_RESIDUAL) ? 2 : ((p.flags & RS_GEMM_OUT_F32) ? 1 : ((p.flags & RS_GEMM_GLU) ? 3 : 0));
     const bool mask = p.flags & RS_GEMM_ROWMASK;
     if constexpr (ABL != 0) {
         if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 0, false, NM0, ABL>, LDS); rc != RS_OK) return rc;
@@ -1022,25 +1093,26 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
         return RS_OK;
     }
     if (p.trace) {      // debug build of the same kernel that records a per-tile timeline (one tile per workgroup only)
-        if (mask || out == 1 || grid != nwg) return rs_fail(ctx, RS_EINVAL, "gemm trace: plain bf16 or residual output, one tile per workgroup");
+        if (mask || out == 1 || out == 3 || grid != nwg) return rs_fail(ctx, RS_EINVAL, "gemm trace: plain bf16 or residual output, one tile per workgroup");
         if (out == 2) {
-            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 2, false, NM0, 4, EPF>, LDS); rc != RS_OK) return rc;
-            hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 2, false, NM0, 4, EPF>), dim3(grid), dim3(512), LDS, s, p);
+            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 2, false, NM0, 4, EPF, L2PF>, LDS); rc != RS_OK) return rc;
+            hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 2, false, NM0, 4, EPF, L2PF>), dim3(grid), dim3(512), LDS, s, p);
         } else {
-            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 0, false, NM0, 4, EPF>, LDS); rc != RS_OK) return rc;
-            hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 0, false, NM0, 4, EPF>), dim3(grid), dim3(512), LDS, s, p);
+            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 0, false, NM0, 4, EPF, L2PF>, LDS); rc != RS_OK) return rc;
+            hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 0, false, NM0, 4, EPF, L2PF>), dim3(grid), dim3(512), LDS, s, p);
         }
         return RS_OK;
     }
 #define RS_LMF(O, MK)                                                                                         \
     do {                                                                                                      \
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, O, MK, NM0, 0, EPF>, LDS); rc != RS_OK) return rc; \
-        hipLaunchKernelGGL((gemm_lmf16_kernel<BM, O, MK, NM0, 0, EPF>), dim3(grid), dim3(512), LDS, s, p);            \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, O, MK, NM0, 0, EPF, L2PF>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_lmf16_kernel<BM, O, MK, NM0, 0, EPF, L2PF>), dim3(grid), dim3(512), LDS, s, p);      \
     } while (0)
     if (out == 2 && !mask) RS_LMF(2, false);
     else if (out == 1 && !mask) RS_LMF(1, false);
     else if (out == 0 && !mask) RS_LMF(0, false);
     else if (out == 0 && mask) RS_LMF(0, true);
+    else if (out == 3 && !mask) RS_LMF(3, false);
     else return rs_fail(ctx, RS_EINVAL, "gemm: row mask with f32 output has no persistent kernel");
 #undef RS_LMF
     return RS_OK;
@@ -1049,7 +1121,7 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
 // Process-wide A/B knobs (debug / tuning only; the defaults are the measured winners and nothing in the product
 // path writes them).  Atomics initialised once from the environment, so concurrent first launches from the encoder
 // thread and the decode worker are safe; they are deliberately not per-context: they select code paths, not state.
-extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve, g_res_prefetch;
+extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve, g_res_prefetch, g_l2pf, g_l2pf_min_k;
 extern std::atomic<long long*> g_trace;
 void gemm_knobs_from_env();
 
@@ -1109,7 +1181,10 @@ int launch_mf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
 std::atomic<long long*> g_trace{nullptr};
 std::atomic<int> g_variant{0}, g_skew{-1}, g_persistent{2}, g_group_m{0} /* 0 = by shape */, g_big{0};
 std::atomic<int> g_reserve{0};   // CUs the persistent kernel leaves free when a context does not say (rs_set_option)
-std::atomic<int> g_res_prefetch{6};   // residual chunks requested ahead by the f32 epilogue: 6 = all, 3, 1 = the round-2 kernel
+// residual chunks requested ahead by the f32 epilogue: 3 (whole path 64.2 vs 64.5 ms/step with 1 and 65.0 with all 6:
+// profiles/r02u_bench_ab.txt; in isolation 6 is the fastest, in the pipeline its 24-load burst per wave is not)
+std::atomic<int> g_res_prefetch{3};
+std::atomic<int> g_l2pf{0}, g_l2pf_min_k{2048};   // L2 prefetch distance in K tiles (0 = off) for problems with K >= min_k
 void gemm_knobs_from_env() {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1119,7 +1194,9 @@ void gemm_knobs_from_env() {
         env("RS_GEMM_PERSISTENT", g_persistent);  // 2 (default) = whole-line kernel, one tile per workgroup; 1 = persistent grid; 0 = round-1 kernels
         env("RS_GEMM_RESERVE_CUS", g_reserve);    // CUs the persistent grid leaves to other streams (contexts may override)
         env("RS_GEMM_BIG", g_big);                // big-tile kernel family (DESIGN.md A/B knob table)
-        env("RS_GEMM_RES_PREFETCH", g_res_prefetch);   // 6 (default) / 3 / 1 residual chunks in flight in the f32 epilogue
+        env("RS_GEMM_RES_PREFETCH", g_res_prefetch);   // 3 (default) / 6 / 1 residual chunks in flight in the f32 epilogue
+        env("RS_GEMM_L2PF", g_l2pf);              // 0 / 2 / 3: operand lines touched that many K tiles ahead
+        env("RS_GEMM_L2PF_MIN_K", g_l2pf_min_k);  // ... for problems at least this deep
     });
 }
 
@@ -1132,32 +1209,9 @@ extern "C" void rs_debug_set_gemm_trace(long long* buf) { g_trace = buf; }
 extern "C" void rs_debug_set_gemm_persistent(int v) { gemm_knobs_from_env(); g_persistent = v; }
 extern "C" void rs_debug_set_gemm_group_m(int v) { gemm_knobs_from_env(); g_group_m = v; }
 
-int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return rs_fail(ctx, RS_EINVAL, "gemm: empty shape %d %d %d", a.M, a.N, a.K);
-    if (a.K % 64) return rs_fail(ctx, RS_EINVAL, "gemm: K=%d must be a multiple of 64", a.K);
-    if (a.N % 4 || a.ldc % 4) return rs_fail(ctx, RS_EINVAL, "gemm: N=%d and ldc=%d must be multiples of 4", a.N, a.ldc);
-    if (!(a.flags & RS_GEMM_OUT_F32) && (a.ldc % 8)) return rs_fail(ctx, RS_EINVAL, "gemm: bf16 output needs ldc %% 8 == 0 (got %d)", a.ldc);
-    if ((a.lda % 8) || (a.ldw % 8) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.out & 15))
-        return rs_fail(ctx, RS_EINVAL, "gemm: operands must be 16-byte aligned (lda %d ldw %d)", a.lda, a.ldw);
-    if ((a.flags & RS_GEMM_ROWMASK) && (!a.mask_lens || a.mask_rows_per_step <= 0 || a.mask_steps <= 0))
-        return rs_fail(ctx, RS_EINVAL, "gemm: row mask requested without lens");
-    if ((a.flags & RS_GEMM_BIAS) && (!a.bias || ((uintptr_t)a.bias & 15)))
-        return rs_fail(ctx, RS_EINVAL, "gemm: bias flag without a 16-byte aligned pointer");
-    if ((a.flags & RS_GEMM_RESIDUAL) && (!a.residual || ((uintptr_t)a.residual & 15)))
-        return rs_fail(ctx, RS_EINVAL, "gemm: residual flag without a 16-byte aligned pointer");
-    GemmParams p;
-    p.A = a.A; p.W = a.W; p.out = a.out; p.bias = a.bias; p.residual = a.residual; p.mask_lens = a.mask_lens;
-    p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K; p.flags = a.flags;
-    p.alpha = a.alpha; p.mask_rows_per_step = a.mask_rows_per_step; p.mask_steps = a.mask_steps;
-    p.tiles_m = p.tiles_n = 0;
-    p.trace = g_trace.load();
+// kernel variant for a problem (the numbers are the cases of rs_launch_gemm's switch; RS_GEMM_VARIANT forces one)
+static int gemm_pick_variant(const rs_gemm_args& a) {
     gemm_knobs_from_env();
-    const double flops = 2.0 * a.M * (double)a.N * a.K;
-    const double bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
-                         (double)a.M * a.N * ((a.flags & RS_GEMM_OUT_F32) ? 4 : 2) +
-                         ((a.flags & RS_GEMM_RESIDUAL) ? (double)a.M * a.N * 4 : 0.0);   // residual is read once
-    rs_prof_begin(ctx, RS_PROF_GEMM, s, flops, bytes);
-    int rc;
     int v = g_variant;
     if (v == 0) {
         // measured on MI355X (profiles/r01_gemm_variants.txt, r01n_gemm_tile_height.txt): big tiles win
@@ -1201,6 +1255,61 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         v += 30 + (g_persistent.load() == 2 ? 1000 : 0);
     // residual / f32 epilogue of the 192-row tile: deep residual prefetch (RS_GEMM_RES_PREFETCH=1 restores one chunk ahead)
     if (g_variant == 0 && v % 1000 == 62 && g_res_prefetch.load() != 1) v += g_res_prefetch.load() == 3 ? 30 : 20;
+    // long-K problems stream their A operand from HBM: L2 prefetch two (RS_GEMM_L2PF=3: three) K tiles ahead
+    if (g_variant == 0 && g_l2pf.load() > 0 && a.K >= g_l2pf_min_k.load()) {
+        if (v % 1000 == 92) v += g_l2pf.load() == 3 ? 20 : 10;
+        else if (v % 1000 == 60) v += g_l2pf.load() == 3 ? 50 : 40;
+    }
+    return v;
+}
+
+// the GLU epilogue (RS_GEMM_GLU) exists in the whole-line kernel only: 256- / 192-row tiles of 64-column wave tiles
+static bool gemm_variant_has_glu(int v) { const int k = v % 1000; return k == 50 || k == 52 || k == 60 || k == 62 || k == 70 || k == 72 || k == 82 || k == 92 || k == 100 || k == 110 || k == 102 || k == 112; }
+
+bool rs_gemm_has_glu(int M, int N, int K) {
+    rs_gemm_args a{};
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N / 2; a.flags = RS_GEMM_BIAS | RS_GEMM_GLU;
+    return gemm_variant_has_glu(gemm_pick_variant(a));
+}
+
+int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return rs_fail(ctx, RS_EINVAL, "gemm: empty shape %d %d %d", a.M, a.N, a.K);
+    if (a.K % 64) return rs_fail(ctx, RS_EINVAL, "gemm: K=%d must be a multiple of 64", a.K);
+    if (a.N % 4 || a.ldc % 4) return rs_fail(ctx, RS_EINVAL, "gemm: N=%d and ldc=%d must be multiples of 4", a.N, a.ldc);
+    if (!(a.flags & RS_GEMM_OUT_F32) && (a.ldc % 8)) return rs_fail(ctx, RS_EINVAL, "gemm: bf16 output needs ldc %% 8 == 0 (got %d)", a.ldc);
+    if ((a.lda % 8) || (a.ldw % 8) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.out & 15))
+        return rs_fail(ctx, RS_EINVAL, "gemm: operands must be 16-byte aligned (lda %d ldw %d)", a.lda, a.ldw);
+    if ((a.flags & RS_GEMM_ROWMASK) && (!a.mask_lens || a.mask_rows_per_step <= 0 || a.mask_steps <= 0))
+        return rs_fail(ctx, RS_EINVAL, "gemm: row mask requested without lens");
+    if ((a.flags & RS_GEMM_BIAS) && (!a.bias || ((uintptr_t)a.bias & 15)))
+        return rs_fail(ctx, RS_EINVAL, "gemm: bias flag without a 16-byte aligned pointer");
+    if ((a.flags & RS_GEMM_RESIDUAL) && (!a.residual || ((uintptr_t)a.residual & 15)))
+        return rs_fail(ctx, RS_EINVAL, "gemm: residual flag without a 16-byte aligned pointer");
+    if (a.flags & RS_GEMM_GLU) {
+        if (a.flags & (RS_GEMM_RELU | RS_GEMM_SILU | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32 | RS_GEMM_ROWMASK))
+            return rs_fail(ctx, RS_EINVAL, "gemm: GLU combines with a bias only");
+        if ((a.N % 64) || a.alpha != 1.0f) return rs_fail(ctx, RS_EINVAL, "gemm: GLU needs N %% 64 == 0 and alpha == 1 (N=%d)", a.N);
+    }
+    GemmParams p;
+    p.A = a.A; p.W = a.W; p.out = a.out; p.bias = a.bias; p.residual = a.residual; p.mask_lens = a.mask_lens;
+    p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K; p.flags = a.flags;
+    p.alpha = a.alpha; p.mask_rows_per_step = a.mask_rows_per_step; p.mask_steps = a.mask_steps;
+    p.tiles_m = p.tiles_n = 0;
+    p.trace = g_trace.load();
+    gemm_knobs_from_env();
+    const double flops = 2.0 * a.M * (double)a.N * a.K;
+    const double bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
+                         (double)a.M * a.N * ((a.flags & RS_GEMM_OUT_F32) ? 4 : ((a.flags & RS_GEMM_GLU) ? 1 : 2)) +
+                         ((a.flags & RS_GEMM_RESIDUAL) ? (double)a.M * a.N * 4 : 0.0);   // residual is read once
+    rs_prof_begin(ctx, RS_PROF_GEMM, s, flops, bytes);
+    int rc;
+    int v = gemm_pick_variant(a);
+    // the GLU epilogue lives in the whole-line kernel: problems the heuristics give to the small-tile kernels run
+    // on its 256-row tile instead (correct for every M; the encoder only asks for it where it is the natural choice)
+    if ((a.flags & RS_GEMM_GLU) && !gemm_variant_has_glu(v)) {
+        if (a.K < 128) return rs_fail(ctx, RS_EINVAL, "gemm: the GLU epilogue needs K >= 128 (K=%d)", a.K);
+        v = 1060;
+    }
     if (ctx->n_cus <= 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
@@ -1222,6 +1331,11 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         // 82 / 92: 62 with every / three of the six residual chunks of the f32 epilogue requested up front
         case 82: rc = launch_lmf16<192, 5, 0, 6>(ctx, p, s, pgrid); break;
         case 92: rc = launch_lmf16<192, 5, 0, 3>(ctx, p, s, pgrid); break;
+        // 1x0 / 1x2: L2 prefetch of the operand lines two / three K tiles ahead (see the kernel's L2PF)
+        case 100: rc = launch_lmf16<256, 5, 0, 1, 2>(ctx, p, s, pgrid); break;
+        case 110: rc = launch_lmf16<256, 5, 0, 1, 3>(ctx, p, s, pgrid); break;
+        case 102: rc = launch_lmf16<192, 5, 0, 3, 2>(ctx, p, s, pgrid); break;
+        case 112: rc = launch_lmf16<192, 5, 0, 3, 3>(ctx, p, s, pgrid); break;
         case 70: rc = launch_lmf16<256, 3>(ctx, p, s, pgrid); break;
         case 72: rc = launch_lmf16<192, 3>(ctx, p, s, pgrid); break;
         case 1: rc = launch_variant<128, 128, 64, 2, 2, 2>(ctx, p, s); break;   // small problems

@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
 
 // GLU + mask + depthwise conv (BatchNorm folded) + SiLU.
 //   x  bf16 [B*T][2d]  (a | gate),  w f32 [k][d] tap-major, bias f32 [d]  ->  out bf16 [B*T][d]
+// Input layouts (rs_asr.h RS_GLU_*): 0 = halves (values in columns [0, d), gates in [d, 2d)); 1 = blocks of 32
+// (columns 64j .. 64j+31 are the values of channels 32j .. 32j+31, the next 32 their gates: what the pw1 GEMM
+// produces from the loader's interleaved weight rows); 2 = GLU already applied by the GEMM epilogue, x is [B*T][d].
 // Workgroup = 256 threads = 32 channel groups (8 channels, one 16-B load) x 8 time lanes; it
 // produces a tile of TT frames x 256 channels.  The GLU'd, masked input tile (TT + k - 1 frames)
 // is staged once in LDS as f32, so every pw1 output element is read from HBM exactly once.
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_silu_kernel(const uint16_t* __
                                                               const float* __restrict__ w,
                                                               const float* __restrict__ bias,
                                                               const int32_t* __restrict__ lens, int T, int d, int k,
-                                                              uint16_t* __restrict__ out) {
+                                                              int layout, uint16_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);  // [(TT + k - 1)][CT]
     const int b = blockIdx.z, c0 = blockIdx.y * CT, t0 = blockIdx.x * TT;
@@ -138,11 +141,18 @@ __global__ __launch_bounds__(256) void glu_dwconv_silu_kernel(const uint16_t* __
         const int t = t0 + r - half;
         float u[8];
         if (t >= 0 && t < T && t < len) {
-            const uint16_t* px = x + ((size_t)b * T + t) * (2 * d) + c;
+            const int ld = layout == 2 ? d : 2 * d;
+            const int ca = layout == 1 ? 64 * (c >> 5) + (c & 31) : c, goff = layout == 1 ? 32 : d;
+            const uint16_t* px = x + ((size_t)b * T + t) * ld + ca;
             const u16x8_t a = *reinterpret_cast<const u16x8_t*>(px);
-            const u16x8_t gt = *reinterpret_cast<const u16x8_t*>(px + d);
+            if (layout == 2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) u[e] = bf16_to_f32(a[e]) * sigmoid_f(bf16_to_f32(gt[e]));
+                for (int e = 0; e < 8; ++e) u[e] = bf16_to_f32(a[e]);
+            } else {
+                const u16x8_t gt = *reinterpret_cast<const u16x8_t*>(px + goff);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u[e] = bf16_to_f32(a[e]) * sigmoid_f(bf16_to_f32(gt[e]));
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) u[e] = 0.0f;
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_silu_kernel(const uint16_t* __
 // input frames it needs are read from LDS once each (a sliding window: 2 x 16 B per frame instead
 // of 2 x 16 B per frame AND tap), and every HBM load of the tile is in flight before the first GLU.
 // Workgroup tile = 8 * R frames x 256 channels (R = 6: 48 frames, three tiles cover T' = 138 + 6).
-template <int K, int R>
+template <int K, int R, int LAYOUT>
 __global__ __launch_bounds__(256) void glu_dwconv_silu_fast_kernel(const uint16_t* __restrict__ x,
                                                                    const float* __restrict__ w,
                                                                    const float* __restrict__ bias,
@@ -204,9 +214,11 @@ __global__ __launch_bounds__(256) void glu_dwconv_silu_fast_kernel(const uint16_
         const int r = tl + 8 * i;
         int t = t0 + r - HALF;
         t = t < 0 ? 0 : (t >= T ? T - 1 : t);     // clamped address, masked below
-        const uint16_t* px = x + ((size_t)b * T + t) * (2 * d) + c;
+        const int ld = LAYOUT == 2 ? d : 2 * d;
+        const int ca = LAYOUT == 1 ? 64 * (c >> 5) + (c & 31) : c;
+        const uint16_t* px = x + ((size_t)b * T + t) * ld + ca;
         av[i] = *reinterpret_cast<const uint4*>(px);
-        gv[i] = *reinterpret_cast<const uint4*>(px + d);
+        if constexpr (LAYOUT != 2) gv[i] = *reinterpret_cast<const uint4*>(px + (LAYOUT == 1 ? 32 : d));
     }
     float wt[K][8];
 #pragma unroll
@@ -223,10 +235,15 @@ __global__ __launch_bounds__(256) void glu_dwconv_silu_fast_kernel(const uint16_
         const int t = t0 + r - HALF;
         const bool ok = t >= 0 && t < T && t < len;
         const u16x8_t a = __builtin_bit_cast(u16x8_t, av[i]);
-        const u16x8_t gt = __builtin_bit_cast(u16x8_t, gv[i]);
         float u[8];
+        if constexpr (LAYOUT == 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) u[e] = ok ? bf16_to_f32(a[e]) * sigmoid_f(bf16_to_f32(gt[e])) : 0.0f;
+            for (int e = 0; e < 8; ++e) u[e] = ok ? bf16_to_f32(a[e]) : 0.0f;
+        } else {
+            const u16x8_t gt = __builtin_bit_cast(u16x8_t, gv[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = ok ? bf16_to_f32(a[e]) * sigmoid_f(bf16_to_f32(gt[e])) : 0.0f;
+        }
         if (r < ROWS) {
             float4* dst = reinterpret_cast<float4*>(tile + r * CT + cg * 8);
             dst[0] = make_float4(u[0], u[1], u[2], u[3]);
@@ -306,24 +323,32 @@ int rs_launch_layernorm2(rs_ctx* ctx, const float* x, const float* g1, const flo
     return RS_OK;
 }
 
-int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, const float* w, const float* b, const int32_t* lens,
+int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, int layout, const float* w, const float* b, const int32_t* lens,
                          int B, int T, int d, int k, uint16_t* out, hipStream_t s) {
     if (B <= 0 || T <= 0) return RS_OK;
     if (d % CT) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: d=%d must be a multiple of %d", d, CT);
     if (k < 1 || k > KMAX || !(k & 1)) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: kernel size %d unsupported", k);
-    const double bytes = (double)B * T * d * (4.0 + 2.0);
+    if (layout < 0 || layout > 2) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: unknown input layout %d", layout);
+    const double bytes = (double)B * T * d * ((layout == 2 ? 2.0 : 4.0) + 2.0);
     rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, (double)B * T * d * (2.0 * k + 12.0), bytes);
     if (k == 9 && !g_glu_generic) {
         // register-window fast path (the FastConformer kernel size); 48-frame tiles
         constexpr int R = 6, TTF = 8 * R;
         const dim3 grid((T + TTF - 1) / TTF, d / CT, B), block(256);
         const size_t lds = (size_t)(TTF + 9 - 1) * CT * sizeof(float);
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)glu_dwconv_silu_fast_kernel<9, R>, (int)lds); rc != RS_OK) return rc;
-        hipLaunchKernelGGL((glu_dwconv_silu_fast_kernel<9, R>), grid, block, lds, s, x, w, b, lens, T, d, out);
+#define RS_GLU_FAST(LY)                                                                                                   \
+        do {                                                                                                              \
+            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)glu_dwconv_silu_fast_kernel<9, R, LY>, (int)lds); rc != RS_OK) return rc; \
+            hipLaunchKernelGGL((glu_dwconv_silu_fast_kernel<9, R, LY>), grid, block, lds, s, x, w, b, lens, T, d, out);   \
+        } while (0)
+        if (layout == 0) RS_GLU_FAST(0);
+        else if (layout == 1) RS_GLU_FAST(1);
+        else RS_GLU_FAST(2);
+#undef RS_GLU_FAST
     } else {
         const dim3 grid((T + TT - 1) / TT, d / CT, B), block(256);
         const size_t lds = (size_t)(TT + k - 1) * CT * sizeof(float);
-        hipLaunchKernelGGL(glu_dwconv_silu_kernel, grid, block, lds, s, x, w, b, lens, T, d, k, out);
+        hipLaunchKernelGGL(glu_dwconv_silu_kernel, grid, block, lds, s, x, w, b, lens, T, d, k, layout, out);
     }
     rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
     RS_CHECK_LAUNCH(ctx, "glu_dwconv_silu");

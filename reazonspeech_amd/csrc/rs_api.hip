@@ -211,6 +211,7 @@ int rs_finalize(rs_ctx* ctx) {
         const char* e = getenv("RS_DECODE_SCREEN");       // A/B knob: 0 = exact evaluation of every column
         ctx->decode_screen = !(e && atoi(e) == 0);
         if (const char* nw = getenv("RS_DECODE_NARROW")) ctx->decode_narrow = atoi(nw) != 0;         // A/B knob: 0 = the wide-tile kernels of round 1
+        if (const char* fg = getenv("RS_FUSE_GLU")) ctx->fuse_glu = atoi(fg);                  // A/B knob: 0 = GLU in the conv kernel
         if (const char* pw = getenv("RS_DECODE_PERSIST_WGS")) ctx->decode_persist_wgs = atoi(pw);   // A/B knob: > 0 = one persistent launch per batch
     }
     auto it = ctx->tensors.find("pos.table");
@@ -256,6 +257,11 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
     if (!strcmp(key, "decode_persist_wgs")) {
         if (value < 0 || value > 256) return rs_fail(ctx, RS_EINVAL, "decode_persist_wgs must be 0 .. 256");
         ctx->decode_persist_wgs = value;
+        return RS_OK;
+    }
+    if (!strcmp(key, "fuse_glu")) {
+        if (value < 0 || value > 2) return rs_fail(ctx, RS_EINVAL, "fuse_glu must be 0, 1 or 2");
+        ctx->fuse_glu = value;
         return RS_OK;
     }
     if (!strcmp(key, "gemm_reserved_cus")) {
@@ -409,6 +415,8 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         return rs_launch_gemm(ctx, g, s);
     };
     const int RES = RS_GEMM_BIAS | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32;
+    // fuse_glu: 1 = where the big-tile GEMM kernel is the natural choice for pw1, 2 = always (tests), 0 = never
+    const bool glu_fused = (dm % 32) == 0 && dm >= 128 && (ctx->fuse_glu == 2 || (ctx->fuse_glu == 1 && rs_gemm_has_glu(M, 2 * dm, dm)));
 
     for (int i = 0; i < d.n_layers; ++i) {
         const rs_layer_w& L = ctx->layers[i];
@@ -427,8 +435,16 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         RS_TRY(gemm(ctxb, dm, L.out_w, dm, x, dm, M, dm, RES, L.out_b, 1.0f, x));
         // conv module
         RS_TRY(rs_launch_layernorm(ctx, x, L.ln_conv_g, L.ln_conv_b, M, dm, d.ln_eps, hn, nullptr, s));
-        RS_TRY(gemm(hn, dm, L.pw1_w, dm, big, 2 * dm, M, 2 * dm, RS_GEMM_BIAS, L.pw1_b, 1.0f, nullptr));
-        RS_TRY(rs_launch_glu_dwconv(ctx, big, L.dw_w, L.dw_b, lens, B, Tp, dm, d.conv_kernel, ctxb, s));
+        // pw1's weight rows are interleaved (values / gates in blocks of 32): with the big-tile kernel the GLU is
+        // applied in the GEMM epilogue ([M][d] out, half the bytes written and read back); small problems keep
+        // the plain product and the conv kernel pairs the columns up itself
+        if (glu_fused) {
+            RS_TRY(gemm(hn, dm, L.pw1_w, dm, big, dm, M, 2 * dm, RS_GEMM_BIAS | RS_GEMM_GLU, L.pw1_b, 1.0f, nullptr));
+            RS_TRY(rs_launch_glu_dwconv(ctx, big, RS_GLU_APPLIED, L.dw_w, L.dw_b, lens, B, Tp, dm, d.conv_kernel, ctxb, s));
+        } else {
+            RS_TRY(gemm(hn, dm, L.pw1_w, dm, big, 2 * dm, M, 2 * dm, RS_GEMM_BIAS, L.pw1_b, 1.0f, nullptr));
+            RS_TRY(rs_launch_glu_dwconv(ctx, big, RS_GLU_BLOCK32, L.dw_w, L.dw_b, lens, B, Tp, dm, d.conv_kernel, ctxb, s));
+        }
         RS_TRY(gemm(ctxb, dm, L.pw2_w, dm, x, dm, M, dm, RES, L.pw2_b, 1.0f, x));
         // 1/2 FFN
         RS_TRY(rs_launch_layernorm(ctx, x, L.ln_ff2_g, L.ln_ff2_b, M, dm, d.ln_eps, hn, nullptr, s));
@@ -557,7 +573,15 @@ int rs_glu_dwconv_silu(rs_ctx* ctx, const uint16_t* x, const float* dw_w, const 
                        int T, int d, int k, uint16_t* out, void* stream) {
     if (!ctx) return RS_EINVAL;
     if (!x || !dw_w || !dw_b || !lens || !out) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: null pointer");
-    return rs_launch_glu_dwconv(ctx, x, dw_w, dw_b, lens, B, T, d, k, out, (hipStream_t)stream);
+    return rs_launch_glu_dwconv(ctx, x, RS_GLU_HALVES, dw_w, dw_b, lens, B, T, d, k, out, (hipStream_t)stream);
 }
+
+int rs_glu_dwconv_silu_layout(rs_ctx* ctx, const uint16_t* x, int layout, const float* dw_w, const float* dw_b,
+                              const int32_t* lens, int B, int T, int d, int k, uint16_t* out, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (!x || !dw_w || !dw_b || !lens || !out) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: null pointer");
+    return rs_launch_glu_dwconv(ctx, x, layout, dw_w, dw_b, lens, B, T, d, k, out, (hipStream_t)stream);
+}
+
 
 }  // extern "C"

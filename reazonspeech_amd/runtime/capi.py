@@ -17,7 +17,8 @@ RS_EOVERFLOW = -5
 ERRORS = {-1: "RS_EINVAL", -2: "RS_EMISSING", -3: "RS_EWORKSPACE", -4: "RS_EHIP", -5: "RS_EOVERFLOW",
           -6: "RS_ESTATE"}
 
-GEMM_BIAS, GEMM_RELU, GEMM_SILU, GEMM_RESIDUAL, GEMM_OUT_F32, GEMM_ROWMASK = 1, 2, 4, 8, 16, 32
+GEMM_BIAS, GEMM_RELU, GEMM_SILU, GEMM_RESIDUAL, GEMM_OUT_F32, GEMM_ROWMASK, GEMM_GLU = 1, 2, 4, 8, 16, 32, 64
+GLU_HALVES, GLU_BLOCK32, GLU_APPLIED = 0, 1, 2
 ALSD_SCORE_NORM, ALSD_MERGE = 1, 2
 PROF_GEMM, PROF_ATTN, PROF_FRONTEND, PROF_DECODE, PROF_ELEMENTWISE, PROF_SUBSAMPLE = 1, 2, 4, 8, 16, 32
 
@@ -26,7 +27,7 @@ EXPORTS = [
     "rs_abi_version", "rs_create", "rs_destroy", "rs_last_error", "rs_set_tensor", "rs_finalize",
     "rs_workspace_bytes", "rs_mel_frames", "rs_enc_frames", "rs_frontend_logmel", "rs_encoder_forward",
     "rs_rnnt_greedy", "rs_profile_enable", "rs_profile_read", "rs_profile_reset", "rs_gemm_bf16",
-    "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
+    "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_glu_dwconv_silu_layout", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
     "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes",
 ]
 
@@ -109,7 +110,8 @@ def load():
     lib.rs_layernorm.argtypes = [vp, vp, vp, vp, c_int, c_int, c_float, vp, vp, vp]
     lib.rs_relpos_attention.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp]
     lib.rs_glu_dwconv_silu.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
-    if lib.rs_abi_version() != 1:
+    lib.rs_glu_dwconv_silu_layout.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
+    if lib.rs_abi_version() != 2:
         raise ImportError("librs_asr.so ABI version mismatch")
     _lib = lib
     return lib
@@ -289,6 +291,11 @@ class Context:
         self.check(self.lib.rs_relpos_attention(self._h, _ptr(qkv), _ptr(pos), _ptr(bias_u), _ptr(bias_v),
                                                 _ptr(lens), B, T, _ptr(out), c_void_p(stream)))
 
-    def glu_dwconv(self, x, w, b, lens, B, T, d, k, out, stream=0):
-        self.check(self.lib.rs_glu_dwconv_silu(self._h, _ptr(x), _ptr(w), _ptr(b), _ptr(lens), B, T, d, k,
-                                               _ptr(out), c_void_p(stream)))
+    def glu_dwconv(self, x, w, b, lens, B, T, d, k, out, stream=0, layout=None):
+        if layout is None:
+            self.check(self.lib.rs_glu_dwconv_silu(self._h, _ptr(x), _ptr(w), _ptr(b), _ptr(lens), B, T, d, k,
+                                                   _ptr(out), c_void_p(stream)))
+        else:
+            self.check(self.lib.rs_glu_dwconv_silu_layout(self._h, _ptr(x), int(layout), _ptr(w), _ptr(b), _ptr(lens),
+                                                          B, T, d, k, _ptr(out), c_void_p(stream)))
+

@@ -313,6 +313,15 @@ def to_fragment_major(w: torch.Tensor) -> torch.Tensor:
     return wp.view(nt, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(nt, k // 16, 64, 4)
 
 
+def glu_interleave_index(d: int) -> torch.Tensor:
+    """row order of the registered pointwise_conv1 weight: blocks of 64 rows = 32 value rows (32j ..) followed
+    by their 32 gate rows (d + 32j ..)"""
+    assert d % 32 == 0, "GLU interleave needs d_model % 32 == 0"
+    j = torch.arange(d // 32)[:, None]
+    r = torch.arange(32)[None, :]
+    return torch.cat([32 * j + r, d + 32 * j + r], dim=1).reshape(-1)
+
+
 def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int = DEFAULT_POS_CAP):
     """-> dict name -> CPU torch tensor (float32 / bfloat16 / int32) exactly as registered with
     rs_set_tensor (DESIGN.md "Weights in HBM").  Host-side transforms, all one-off:
@@ -398,8 +407,11 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
         out[p + "att.bias_u"] = f32(sd[A + "pos_bias_u"].reshape(-1))
         out[p + "att.bias_v"] = f32(sd[A + "pos_bias_v"].reshape(-1))
         Cm = L + "conv."
-        out[p + "conv.pw1.w"] = bf(sd[Cm + "pointwise_conv1.weight"].squeeze(-1))
-        out[p + "conv.pw1.b"] = f32(sd[Cm + "pointwise_conv1.bias"])
+        # rows interleaved in blocks of 32 (values 32j.., then their gates d + 32j..): a GLU pair lands in one
+        # MFMA lane of the pw1 GEMM and is applied in its epilogue (include/rs_asr.h: RS_GEMM_GLU)
+        glu_rows = glu_interleave_index(cfg.d_model)
+        out[p + "conv.pw1.w"] = bf(sd[Cm + "pointwise_conv1.weight"].squeeze(-1)[glu_rows])
+        out[p + "conv.pw1.b"] = f32(sd[Cm + "pointwise_conv1.bias"][glu_rows])
         g = sd[Cm + "batch_norm.weight"].double()
         b = sd[Cm + "batch_norm.bias"].double()
         mu = sd[Cm + "batch_norm.running_mean"].double()

@@ -20,6 +20,7 @@ SHAPES = [  # name, M, N, K, flags
     ("qkv     bias->bf16", M, 3072, 1024, capi.GEMM_BIAS),
     ("out/pw2 res->f32  ", M, 1024, 1024, capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32),
     ("pw1     bias->bf16", M, 2048, 1024, capi.GEMM_BIAS),
+    ("pw1     glu ->bf16", M, 2048, 1024, capi.GEMM_BIAS | capi.GEMM_GLU),
     ("sub_pw1 relu->bf16", 256 * 275 * 20, 256, 256, capi.GEMM_BIAS | capi.GEMM_RELU),
     ("sub_pw2 relu->bf16", 256 * 138 * 10, 256, 256, capi.GEMM_BIAS | capi.GEMM_RELU),
     ("sub_out ->f32     ", M, 1024, 2560, capi.GEMM_BIAS | capi.GEMM_OUT_F32),
@@ -44,8 +45,12 @@ def main():
         W = (torch.randn((n, k), generator=g) / k ** 0.5).to(torch.bfloat16).to(dev)
         bias = torch.randn((n,), generator=g).to(dev)
         res = torch.randn((m, n), generator=g).to(dev) if flags & capi.GEMM_RESIDUAL else None
-        out = torch.empty((m, n), dtype=torch.float32 if flags & capi.GEMM_OUT_F32 else torch.bfloat16, device=dev)
+        glu = bool(flags & capi.GEMM_GLU)
+        out = torch.empty((m, n // 2 if glu else n), dtype=torch.float32 if flags & capi.GEMM_OUT_F32 else torch.bfloat16, device=dev)
         ref = A[:4096].float() @ W.float().t() + bias
+        if glu:      # value / gate columns interleaved in blocks of 32
+            r3 = ref.view(4096, n // 64, 2, 32)
+            ref = (r3[:, :, 0] * torch.sigmoid(r3[:, :, 1])).reshape(4096, n // 2)
         if flags & capi.GEMM_SILU:
             ref = torch.nn.functional.silu(ref)
         if flags & capi.GEMM_RELU:

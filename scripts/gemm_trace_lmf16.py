@@ -28,13 +28,16 @@ SHAPES = [
 
 
 def main():
-    forced = [int(v) for v in sys.argv[1:]]
+    forced = [int(v) for v in sys.argv[1:] if not v.startswith("--")]
+    only = [a.split("=")[1] for a in sys.argv[1:] if a.startswith("--shape=")]
     ctx = capi.Context(FASTCONFORMER_619M, 0)
     lib = ctx.lib
     lib.rs_debug_set_gemm_variant.argtypes = [ctypes.c_int]
     lib.rs_debug_set_gemm_trace.argtypes = [ctypes.c_void_p]
     dev = torch.device("cuda", 0)
     for name, n, k, flags, bm in SHAPES:
+        if only and not any(o in name for o in only):
+            continue
         variants = forced or ([1060] if bm == 256 else [1062, 1082])
         for v in variants:
             if (v % 1000) % 10 == 2 and bm != 192 or (v % 1000) % 10 == 0 and bm != 256:

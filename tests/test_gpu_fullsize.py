@@ -167,7 +167,8 @@ def full(gpu_device):
     return AsrModel(FASTCONFORMER_619M, sd, SyntheticTokenizer(FASTCONFORMER_619M.vocab_size), device="cuda:0"), sd
 
 
-def test_encoder_619m_vs_bf16_oracle_with_taps(full):
+@pytest.mark.parametrize("fuse_glu", [1, 2])
+def test_encoder_619m_vs_bf16_oracle_with_taps(full, fuse_glu):
     """the 24-layer model on 3 ragged utterances (1.2 - 3 s + 0.5 s pad each side) against the bf16-recipe oracle:
     subsampling output, layers 0 / 11 / 23, encoder output, joint projection; then decode bit-exact on the HIP joint
     projection and the id agreement with the oracle's own end-to-end greedy"""
@@ -183,16 +184,19 @@ def test_encoder_619m_vs_bf16_oracle_with_taps(full):
     lay = torch.zeros((len(tap_ids), M, cfg.d_model), dtype=torch.float32, device=dev)
     enc = torch.zeros((buf.B, buf.tp_max, cfg.d_model), dtype=torch.float32, device=dev)
     model.ctx.set_taps(sub, lay, tap_ids)
+    model.ctx.set_option("fuse_glu", fuse_glu)     # 2: GLU in the pw1 GEMM epilogue, as the benchmark batches run it
     try:
         model.run_device(buf, want_enc=enc)
         torch.cuda.synchronize()
     finally:
         model.ctx.set_taps()
+        model.ctx.set_option("fuse_glu", 1)
     padded = np.zeros((3, audio.shape[1] + 16000), np.float32)
     for b in range(3):
         padded[b, 8000:8000 + lens[b]] = waves[b]
     taps = {}
-    f_ref, el = om.forward_to_joint(cfg, sd, torch.from_numpy(padded), torch.from_numpy(lens + 16000), "bf16", taps)
+    f_ref, el = om.forward_to_joint(cfg, sd, torch.from_numpy(padded), torch.from_numpy(lens + 16000),
+                                    "bf16-fused-glu" if fuse_glu == 2 else "bf16", taps)
     assert buf.enc_lens.cpu().tolist() == el.tolist()
     Tp = buf.tp_max
     sub = sub.cpu().view(3, Tp, -1)
@@ -220,7 +224,7 @@ def test_encoder_619m_vs_bf16_oracle_with_taps(full):
     ref_e2e = og.rnnt_greedy(cfg, sd, f_ref.numpy(), el.numpy())
     stats["ids_equal_oracle_e2e"] = [got.ids[b] == ref_e2e[b][0] for b in range(3)]
     stats["n_ids"] = [len(x) for x in got.ids]
-    report("encoder_619m", stats)
+    report(f"encoder_619m_fuse_glu{fuse_glu}", stats)
     assert ok, stats
     assert got.ids == [r[0] for r in ref_same] and got.frames == [r[1] for r in ref_same]
 

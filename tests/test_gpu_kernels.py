@@ -107,6 +107,73 @@ def test_gemm_big_tiles(ctx, gpu_device, N, K, residual, family):
     assert (out_full[M:].float() == 7.0).all(), "rows past M were written"
 
 
+@pytest.mark.parametrize("variant", [1062, 1082, 1092, 1102, 1112, 1100, 1110])
+def test_gemm_prefetch_variants(ctx, gpu_device, variant):
+    """the whole-line kernel's latency options — residual chunks requested 1 / 3 / 6 ahead in the f32 epilogue, operand
+    lines touched in L2 two / three K tiles ahead — compute the same thing: residual update IN PLACE (out aliases the
+    residual, as in the encoder) for the 192-row variants, SiLU -> bf16 for the 256-row ones, ragged last tile"""
+    import ctypes
+    M, N, K = 35328 - 37, 1024, 4096
+    residual = variant % 10 == 2
+    g = torch.Generator().manual_seed(variant)
+    A = rb(torch.randn((M, K), generator=g))
+    W = rb(torch.randn((N, K), generator=g) / K ** 0.5)
+    bias = torch.randn((N,), generator=g)
+    rows = torch.cat([torch.arange(0, 200), torch.arange(17000, 17200), torch.arange(M - 300, M)])
+    ref = A[rows] @ W.t() + bias
+    if residual:
+        x = torch.randn((M, N), generator=g)
+        ref = 0.5 * ref + x[rows]
+        out_full = torch.full((M + 64, N), 7.0, dtype=torch.float32, device=gpu_device)
+        out_full[:M] = x.to(gpu_device)
+        kw = dict(flags=capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32, alpha=0.5, residual=out_full[:M])
+    else:
+        ref = torch.nn.functional.silu(ref)
+        out_full = torch.full((M + 64, N), 7.0, dtype=torch.bfloat16, device=gpu_device)
+        kw = dict(flags=capi.GEMM_BIAS | capi.GEMM_SILU)
+    setv = ctx.lib.rs_debug_set_gemm_variant
+    setv.argtypes = [ctypes.c_int]
+    setv.restype = None
+    try:
+        setv(variant)
+        ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out_full[:M], bias=bias.to(gpu_device), **kw)
+        sync()
+    finally:
+        setv(0)
+    got = out_full[rows.to(gpu_device)].float().cpu()
+    tol = 2e-3 + (0.0 if residual else 2.0 ** -8) * ref.abs()
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), (int(bad.sum()), float((got - ref).abs().max()))
+    assert (out_full[M:].float() == 7.0).all(), "rows past M were written"
+
+
+@pytest.mark.parametrize("M", [35328 - 37, 300])
+def test_gemm_glu_epilogue(ctx, gpu_device, M):
+    """RS_GEMM_GLU: value / gate columns interleaved in blocks of 32 (the loader's pw1 row order), GLU applied to the
+    f32 accumulators, bf16 [M][N/2] out.  M = 300 is a problem the heuristics would give to the small-tile kernels:
+    the flag moves it to the big-tile kernel."""
+    from reazonspeech_amd.runtime.weights import glu_interleave_index
+    d, K = 1024, 1024
+    g = torch.Generator().manual_seed(M)
+    A = rb(torch.randn((M, K), generator=g))
+    W = rb(torch.randn((2 * d, K), generator=g) / K ** 0.5)
+    bias = torch.randn((2 * d,), generator=g)
+    rows = torch.cat([torch.arange(0, min(256, M)), torch.arange(M - 44, M)])
+    y = A[rows] @ W.t() + bias
+    ref = y[:, :d] * torch.sigmoid(y[:, d:])
+    idx = glu_interleave_index(d)
+    out = torch.full((M + 64, d), 7.0, dtype=torch.bfloat16, device=gpu_device)
+    ctx.gemm(bf(A).to(gpu_device), bf(W[idx]).to(gpu_device), out[:M], flags=capi.GEMM_BIAS | capi.GEMM_GLU,
+             bias=bias[idx].to(gpu_device))
+    sync()
+    got = out[rows.to(gpu_device)].float().cpu()
+    bad = (got - ref).abs() > 2e-3 + 2.0 ** -8 * ref.abs()
+    assert not bad.any(), (int(bad.sum()), float((got - ref).abs().max()))
+    assert (out[M:].float() == 7.0).all(), "rows past M were written"
+    with pytest.raises(capi.RsError):        # GLU takes a bias only
+        ctx.gemm(bf(A).to(gpu_device), bf(W[idx]).to(gpu_device), out[:M], flags=capi.GEMM_GLU | capi.GEMM_SILU)
+
+
 def test_gemm_big_rowmask(ctx, gpu_device):
     """the subsampling pointwise GEMM at a size that selects the big-tile (persistent) kernel: bias + ReLU + the
     per-utterance row mask (rows of frames at or past an utterance's length are zeroed), ragged last tile"""
@@ -212,6 +279,22 @@ def test_glu_dwconv_silu(ctx, gpu_device, T, lens):
                    lens_t.to(gpu_device), B, T, d, k, out)
     sync()
     assert (out.cpu().float().view(B, T, d) - ref).abs().max() <= 2e-2
+    # the other input layouts: value / gate columns interleaved in blocks of 32 (what the pw1 GEMM produces from the
+    # loader's row order) and GLU already applied by the GEMM epilogue (bf16 [B*T][d])
+    from reazonspeech_amd.runtime.weights import glu_interleave_index
+    out1 = torch.zeros_like(out)
+    ctx.glu_dwconv(bf(x[..., glu_interleave_index(d)]).reshape(B * T, 2 * d).to(gpu_device), w.t().contiguous().to(gpu_device),
+                   b.to(gpu_device), lens_t.to(gpu_device), B, T, d, k, out1, layout=capi.GLU_BLOCK32)
+    sync()
+    assert torch.equal(out1, out)
+    ug = rb(a * torch.sigmoid(gate))
+    um = ug * (torch.arange(T)[None, :] < lens_t[:, None])[:, :, None]
+    ref2 = torch.nn.functional.silu(torch.nn.functional.conv1d(um.transpose(1, 2), w[:, None, :], b, padding=4, groups=d).transpose(1, 2))
+    out2 = torch.zeros_like(out)
+    ctx.glu_dwconv(bf(ug).reshape(B * T, d).to(gpu_device), w.t().contiguous().to(gpu_device), b.to(gpu_device),
+                   lens_t.to(gpu_device), B, T, d, k, out2, layout=capi.GLU_APPLIED)
+    sync()
+    assert (out2.cpu().float().view(B, T, d) - ref2).abs().max() <= 2e-2
 
 
 @pytest.mark.parametrize("T,lens,window", [(19, [19, 14], None), (138, [138, 97, 5], None), (64, [64, 33], None),

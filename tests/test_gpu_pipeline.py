@@ -83,12 +83,20 @@ def test_frontend_pad_is_folded(gold, gpu_device):
     assert b1.n_ids.cpu().tolist() == b2.n_ids.cpu().tolist()
 
 
-def test_encoder_matches_oracle(tiny, gold):
+@pytest.mark.parametrize("fuse_glu", [1, 2])
+def test_encoder_matches_oracle(tiny, gold, fuse_glu):
+    """fuse_glu = 1: what this batch size selects (plain pw1 product, GLU in the depthwise kernel); 2: the conv
+    module's GLU in the pw1 GEMM epilogue (what the big batches run), against the oracle recipe with that rounding"""
     model, sd = tiny
     audio, lens = gold["audio"], gold["lengths"]
-    buf, enc = _run_stages(model, audio, lens)
+    model.ctx.set_option("fuse_glu", fuse_glu)
+    try:
+        buf, enc = _run_stages(model, audio, lens)
+    finally:
+        model.ctx.set_option("fuse_glu", 1)
     taps = {}
-    f_ref, el = om.forward_to_joint(TINY, sd, torch.from_numpy(audio), torch.from_numpy(lens), "bf16", taps)
+    f_ref, el = om.forward_to_joint(TINY, sd, torch.from_numpy(audio), torch.from_numpy(lens),
+                                    "bf16-fused-glu" if fuse_glu == 2 else "bf16", taps)
     assert buf.enc_lens.cpu().tolist() == el.tolist() == gold["hf_enc_lens"].tolist()
     enc, f = enc.cpu(), buf.joint_enc.cpu()
     hf = torch.from_numpy(gold["hf_enc"])

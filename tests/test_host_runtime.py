@@ -54,6 +54,13 @@ def test_prepare_weights_layouts():
     assert p["L0.att.qkv.w"].shape == (3 * d, d) and p["L0.att.qkv.b"].shape == (3 * d,)
     assert torch.equal(p["L0.att.qkv.w"][d:2 * d], sd["encoder.layers.0.self_attn.linear_k.weight"].to(torch.bfloat16))
     assert p["L1.conv.dw.w"].shape == (cfg.conv_kernel, d)
+    # pointwise_conv1 rows interleaved in blocks of 32: value rows 32j .. 32j+31, then their gate rows d + 32j ..
+    w1 = sd["encoder.layers.1.conv.pointwise_conv1.weight"].squeeze(-1).to(torch.bfloat16)
+    b1 = sd["encoder.layers.1.conv.pointwise_conv1.bias"]
+    assert p["L1.conv.pw1.w"].shape == (2 * d, d)
+    assert torch.equal(p["L1.conv.pw1.w"][64 * 3 + 5], w1[32 * 3 + 5]) and torch.equal(p["L1.conv.pw1.w"][64 * 3 + 32 + 5], w1[d + 32 * 3 + 5])
+    assert p["L1.conv.pw1.b"][64 * 2 + 31] == b1[32 * 2 + 31] and p["L1.conv.pw1.b"][64 * 2 + 32] == b1[d + 32 * 2]
+    assert sorted(W.glu_interleave_index(d).tolist()) == list(range(2 * d))
     H = cfg.pred_hidden
     # decode matrices are fragment-major: [n/16][k/16][lane = 16*kk + li][4]
     wl = torch.cat([sd["decoder.prediction.dec_rnn.lstm.weight_ih_l0"],

@@ -94,9 +94,12 @@ def test_bf16_recipe_stays_close_to_fp32(gold, sd):
     a, l = torch.from_numpy(gold["audio"]), torch.from_numpy(gold["lengths"])
     f32, el = om.forward_to_joint(TINY, sd, a, l, "fp32")
     f16, _ = om.forward_to_joint(TINY, sd, a, l, "bf16")
+    f16g, _ = om.forward_to_joint(TINY, sd, a, l, "bf16-fused-glu")      # GLU rounded after, not before
     for b in range(2):
         n = int(el[b])
         assert (f32[b, :n] - f16[b, :n]).abs().max() <= 0.1
+        assert (f32[b, :n] - f16g[b, :n]).abs().max() <= 0.1
+        assert 0 < (f16[b, :n] - f16g[b, :n]).abs().max() <= 0.05
 
 
 def test_attention_window_predicate():
