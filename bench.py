@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--beam", type=int, default=4, help="beam size of --decoding alsd")
     ap.add_argument("--buffer-sets", type=int, default=int(os.environ.get("RS_BUFFER_SETS", "2")),
                     help="resident batches the pipeline rotates through (2 = encoder i+1 waits for decode i-1)")
+    ap.add_argument("--dec-streams", type=int, default=int(os.environ.get("RS_DEC_STREAMS", "1")),
+                    help="decode consecutive batches on this many streams (2 needs three resident batches)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decode of each batch back to back on one stream")
     args = ap.parse_args()
@@ -170,7 +172,7 @@ def main():
     model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device=f"cuda:{local_rank}")
     # two resident batches (different utterances): the pipelined path alternates between them
     bufs, lens_all = [], []
-    n_sets = 4 if args.enc_streams == 2 else max(2, args.buffer_sets)
+    n_sets = 4 if args.enc_streams == 2 else max(2 + (args.dec_streams - 1), args.buffer_sets)
     for k in range(n_sets):
         audio, lens = synthetic_batch(args.batch, args.seconds, seed=1234 + 17 * rank + 1000 * k)
         b = model.stage([audio[i, :lens[i]] for i in range(args.batch)],
@@ -194,7 +196,7 @@ def main():
 
     def run_steps(n):
         if pipelined:
-            model.run_pipelined(bufs, n, after_decode=after_decode, enc_streams=args.enc_streams)
+            model.run_pipelined(bufs, n, after_decode=after_decode, enc_streams=args.enc_streams, dec_streams=args.dec_streams)
         else:
             for i in range(n):
                 model.run_device(bufs[i % n_sets])
@@ -225,10 +227,10 @@ def main():
     # memory first and its hypotheses are copied back after decode
     dt_host = None
     if pipelined and world == 1:
-        model.run_pipelined(bufs, 2, from_host=True, enc_streams=args.enc_streams)
+        model.run_pipelined(bufs, 2, from_host=True, enc_streams=args.enc_streams, dec_streams=args.dec_streams)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        model.run_pipelined(bufs, args.steps, from_host=True, enc_streams=args.enc_streams)
+        model.run_pipelined(bufs, args.steps, from_host=True, enc_streams=args.enc_streams, dec_streams=args.dec_streams)
         torch.cuda.synchronize()
         dt_host = time.perf_counter() - t1
 
@@ -266,7 +268,8 @@ def main():
                        "utterance_seconds": args.seconds, "parallelism": f"dp{world}",
                        "enc_frames": buf.tp_max, "resident_batches": n_sets, "mean_tokens_per_utt": round(mean_tokens, 1),
                        "max_tokens_per_utt": int(n_ids.max()),
-                       "schedule": ("2-stage pipeline: encoder(i+1) || decode(i) on two HIP streams"
+                       "schedule": (("2-stage pipeline: encoder(i+1) || decode(i) on two HIP streams" if args.dec_streams == 1 else
+                                     "2-stage pipeline: encoder(i+2) || decode(i+1), decode(i) on three HIP streams")
                                     + (" (encoders of consecutive batches on two streams)" if args.enc_streams == 2 else ""))
                                    if pipelined else "sequential"},
             "setup_s": round(setup_s, 1),

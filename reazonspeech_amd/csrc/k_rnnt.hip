@@ -830,7 +830,6 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     const bool screen = ctx->decode_screen && ctx->jout_w16 && ctx->jout_wrm && ctx->jout_bpad && ctx->jout_wmax && V <= 48 * 64 &&
                         J / SPLITK_TILE / 16 <= 8 && J / 32 <= 20;
 
-    const int rtiles = (B + 31) / 32;
     if (int rc = ensure_decode_lds(ctx); rc != RS_OK) return rc;
     const bool narrow = narrow_kernels_usable(ctx);
     auto lstm_and_pred = [&](int rows_bound) { launch_lstm_pred(ctx, st, B, rows_bound, narrow, s); };
@@ -883,9 +882,12 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
                     hipLaunchKernelGGL(rnnt_verify_kernel<48>, vg, dim3(256), 4 * J * 4 + 4 * 48 * 64 * 4, s, st, joint_enc, enc_lens, B, tp_max, J, V, Vpad,
                                        ctx->jout_wrm, ctx->jout_b, ctx->jout_wmax, d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
             } else {
-                hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(nct, rtiles), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H, J,
+                // both kernels walk the compacted alive list: only the row tiles / slots the bound covers are launched
+                // (next to the encoder every workgroup, even one that exits at once, has to wait for a free CU)
+                const int rts = (rows + 31) / 32 > 0 ? (rows + 31) / 32 : 1;
+                hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(nct, rts), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H, J,
                                    V, ctx->jout_w, ctx->jout_b, nct, steps, 1);
-                hipLaunchKernelGGL(rnnt_finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, st, enc_lens, B, nct,
+                hipLaunchKernelGGL(rnnt_finalize_kernel, dim3((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1), dim3(256), 0, s, st, enc_lens, B, nct,
                                    d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
             }
             lstm_and_pred(rows);

@@ -87,6 +87,8 @@ class AsrModel:
         self.pad_left = self.pad_right = int(pad_seconds * cfg.sample_rate)   # audio.py:80-82 via decode.py:4
         self._bufs = {}
         self._ctx_dec = None
+        self._ctx_dec2 = None
+        self._dec2_stream = None
         self._ctx_enc2 = None
         self._enc2_stream = None
         self._streams = None
@@ -105,7 +107,7 @@ class AsrModel:
         self._set_pos_tables(dev["pos.table"])
 
     def _contexts(self):
-        return [c for c in (self.ctx, self._ctx_dec, self._ctx_enc2) if c is not None]
+        return [c for c in (self.ctx, self._ctx_dec, self._ctx_dec2, self._ctx_enc2) if c is not None]
 
     def _set_pos_tables(self, table):
         """register the relative-position table (bf16 [2*cap-1][d]) and the derived per-layer tensors: the table
@@ -234,7 +236,7 @@ class AsrModel:
                         buf.enc_lens[lo:hi], ws, s)
 
     def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None, split_encoder: bool = None,
-                      from_host: bool = False, enc_streams: int = 1):
+                      from_host: bool = False, enc_streams: int = 1, dec_streams: int = 1):
         """Process `steps` batches (bufs[i % len(bufs)], inputs already in HBM) as a two-stage
         pipeline: the throughput-bound front-end + encoder of batch i+1 runs on one HIP stream while
         the latency-bound greedy decode of batch i (a dependency chain of small launches that leaves
@@ -245,8 +247,11 @@ class AsrModel:
         stream) and its hypotheses are copied back to the host after decode (the PCIe-inclusive
         boundary).  `enc_streams=2` (experimental) runs the encoders of consecutive batches on two
         streams (each with its full-size launches) so that one batch's HBM-bound kernels can overlap the
-        other's GEMMs; it needs four buffer sets."""
+        other's GEMMs; it needs four buffer sets.  `dec_streams=2` decodes consecutive batches on two streams
+        (two worker threads): next to the encoder a decode launch spends most of its time waiting for compute
+        units to free up, so two interleaved chains nearly double the decode rate; needs three buffer sets."""
         assert len(bufs) >= 2, "the pipeline needs two buffer sets"
+        assert dec_streams in (1, 2) and (dec_streams == 1 or len(bufs) >= 3), "two decode streams need three buffer sets"
         assert enc_streams in (1, 2) and (enc_streams == 1 or len(bufs) >= 4), "two encoder streams need four buffer sets"
         with torch.cuda.device(self.device):
             if split_encoder is None:
@@ -270,12 +275,22 @@ class AsrModel:
                 self._streams = (torch.cuda.Stream(device=self.device), dec)
             enc_stream, dec_stream = self._streams
             self._decode_policy(self._ctx_dec, bufs[0].B, pipelined=True)
+            dec_lanes = [(self._ctx_dec, dec_stream)]
+            if dec_streams == 2:
+                if self._ctx_dec2 is None:
+                    self._ctx_dec2 = self.ctx.clone()
+                    self._dec2_stream = torch.cuda.Stream(device=self.device, priority=getattr(dec_stream, "priority", -1))
+                self._decode_policy(self._ctx_dec2, bufs[0].B, pipelined=True)
+                dec_lanes.append((self._ctx_dec2, self._dec2_stream))
             enc_stream.wait_stream(torch.cuda.current_stream())
-            jobs: "queue.Queue" = queue.Queue()
+            queues = [queue.Queue() for _ in dec_lanes]
             done = [threading.Event() for _ in range(steps)]
+            hooked = [threading.Event() for _ in range(steps)]
             errors = []
 
-            def worker():
+            def worker(lane):
+                ctx_d, dec_stream = dec_lanes[lane]
+                jobs = queues[lane]
                 with torch.cuda.device(self.device):
                     while True:
                         item = jobs.get()
@@ -285,19 +300,35 @@ class AsrModel:
                         try:
                             dec_stream.wait_event(ev)
                             # decode scratch lives past the encoder's scratch in buf.ws_dec
-                            self.decode(self._ctx_dec, buf, buf.ws_dec, dec_stream.cuda_stream)
+                            self.decode(ctx_d, buf, buf.ws_dec, dec_stream.cuda_stream)
                             if from_host:
                                 with torch.cuda.stream(dec_stream):
                                     buf.h_out = (buf.n_ids.cpu(), buf.ids.cpu(), buf.frames.cpu())
                             if after_decode is not None:
+                                # hooks run in batch order whatever lane finishes first (a hook may issue a collective:
+                                # every rank has to issue them in the same order, from one thread at a time)
+                                if i > 0:
+                                    hooked[i - 1].wait()
                                 after_decode(buf)
                         except Exception as e:          # surfaced on the caller's thread below
                             errors.append(e)
                         finally:
+                            hooked[i].set()
                             done[i].set()
 
-            th = threading.Thread(target=worker, daemon=True)
-            th.start()
+            threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(len(dec_lanes))]
+            for th in threads:
+                th.start()
+
+            class _Jobs:          # batch i goes to decode lane i mod lanes
+                @staticmethod
+                def put(item):
+                    if item is None:
+                        for q in queues:
+                            q.put(None)
+                    else:
+                        queues[item[0] % len(queues)].put(item)
+            jobs = _Jobs
             nb = len(bufs)
             for i in range(steps):
                 buf = bufs[i % nb]
@@ -327,10 +358,12 @@ class AsrModel:
                 ev.record(enc_stream)
                 jobs.put((i, buf, ev))
             jobs.put(None)
-            th.join()
+            for th in threads:
+                th.join()
             torch.cuda.current_stream().wait_stream(enc_stream)
             torch.cuda.current_stream().wait_stream(self._enc2_stream)
-            torch.cuda.current_stream().wait_stream(dec_stream)
+            for _, ds in dec_lanes:
+                torch.cuda.current_stream().wait_stream(ds)
             if errors:
                 raise errors[0]
 

@@ -31,6 +31,11 @@ def main():
     quick = "--quick" in sys.argv
     variants = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [1, 2, 3, 4, 5]
     groups = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--group-m=")] or [None]
+    # row pitch of A / W in elements beyond K (power-of-two pitches can camp on a few L2 / HBM channels)
+    pad_a = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--pad-a=")] or [0])[0]
+    pad_w = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--pad-w=")] or [0])[0]
+    pad_c = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--pad-c=")] or [0])[0]
+    only = [a.split("=")[1] for a in sys.argv[1:] if a.startswith("--shape=")]
     dev = torch.device("cuda", 0)
     ctx = capi.Context(FASTCONFORMER_619M, 0)
     setv = ctx.lib.rs_debug_set_gemm_variant
@@ -41,12 +46,28 @@ def main():
     setg.restype = None
     g = torch.Generator(device="cpu").manual_seed(0)
     for name, m, n, k, flags in SHAPES:
+        if only and not any(o in name for o in only):
+            continue
         A = torch.randn((m, k), generator=g).to(torch.bfloat16).to(dev)
         W = (torch.randn((n, k), generator=g) / k ** 0.5).to(torch.bfloat16).to(dev)
+        if pad_a:
+            Ap = torch.zeros((m, k + pad_a), dtype=torch.bfloat16, device=dev)
+            Ap[:, :k] = A
+            A = Ap[:, :k]
+        if pad_w:
+            Wp = torch.zeros((n, k + pad_w), dtype=torch.bfloat16, device=dev)
+            Wp[:, :k] = W
+            W = Wp[:, :k]
         bias = torch.randn((n,), generator=g).to(dev)
         res = torch.randn((m, n), generator=g).to(dev) if flags & capi.GEMM_RESIDUAL else None
         glu = bool(flags & capi.GEMM_GLU)
         out = torch.empty((m, n // 2 if glu else n), dtype=torch.float32 if flags & capi.GEMM_OUT_F32 else torch.bfloat16, device=dev)
+        if pad_c:
+            out = torch.empty((m, out.shape[1] + pad_c), dtype=out.dtype, device=dev)[:, :out.shape[1]]
+            if res is not None:
+                rp = torch.empty((m, n + pad_c), dtype=res.dtype, device=dev)
+                rp[:, :n] = res
+                res = rp[:, :n]
         ref = A[:4096].float() @ W.float().t() + bias
         if glu:      # value / gate columns interleaved in blocks of 32
             r3 = ref.view(4096, n // 64, 2, 32)
@@ -79,7 +100,7 @@ def main():
                 ts.append(e0.elapsed_time(e1) / (1 if quick else 4))
             ts.sort()
             us = ts[len(ts) // 2] * 1e3
-            print(f"{name} M{m} N{n} K{k} v{v}{'' if gm is None else f' gm{gm}'}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
+            print(f"{name} M{m} N{n} K{k} v{v}{'' if gm is None else f' gm{gm}'}{f' padA{pad_a}' if pad_a else ''}{f' padW{pad_w}' if pad_w else ''}{f' padC{pad_c}' if pad_c else ''}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
         del A, W, out, res
     setv(0)
 

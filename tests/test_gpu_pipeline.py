@@ -200,6 +200,31 @@ def test_pipelined_schedule_equals_sequential(gpu_device):
             assert (r.ids, r.frames) == want[k]
 
 
+def test_two_decode_streams_equal_sequential(gpu_device):
+    """decode of consecutive batches on two streams (three resident batches): same hypotheses as the one-stream
+    path, and the after-decode hooks fire in batch order whichever lane finishes first"""
+    sd = synthetic_state_dict(TINY, 33, blank_bias=4.0)
+    model = AsrModel(TINY, sd, SyntheticTokenizer(TINY.vocab_size), device="cuda:0")
+    bufs, want = [], []
+    for k in range(3):
+        audio, lens = synthetic_batch(5, 3.0 if k != 1 else 0.9, seed=60 + k, ragged=True, min_seconds=0.5)   # batch 1 decodes fastest
+        waves = [audio[b, :lens[b]] for b in range(5)]
+        ref = model.transcribe_waveforms(waves)
+        want.append((ref.ids, ref.frames))
+        bufs.append(model.stage(waves, buf=model.new_buffers(5, 48000)))
+    order = []
+
+    def grab(buf):
+        torch.cuda.current_stream().synchronize()
+        k = [id(b) for b in bufs].index(id(buf))
+        r = model.collect(buf)
+        order.append((k, (r.ids, r.frames) == want[k]))
+
+    model.run_pipelined(bufs, 7, after_decode=grab, dec_streams=2)
+    assert [k for k, _ in order] == [i % 3 for i in range(7)]
+    assert all(ok for _, ok in order)
+
+
 def test_long_list_is_chunked_sorted_and_pipelined(gpu_device):
     """more utterances than max_batch: sorted by length, batches of max_batch through the pipeline,
     results in the caller's order and identical to one-at-a-time decoding"""
