@@ -19,7 +19,7 @@ for l in sys.stdin:
         print('   intervals', d.get('step_intervals_ms'))
 "; }
 for rep in 1 2; do
-for cfg in "RS_DEC_STREAMS=1" "RS_DEC_STREAMS=2" "RS_DEC_STREAMS=2 RS_DECODE_PRIORITY=0" "RS_DEC_STREAMS=2 RS_DECODE_NARROW=1"; do
+for cfg in "RS_DEC_STREAMS=1" "RS_DEC_STREAMS=2" "RS_DEC_STREAMS=2 RS_DECODE_PRIORITY=0" "RS_DEC_STREAMS=2 RS_DECODE_NARROW=1 RS_DECODE_SCREEN=0"; do
   echo "== $cfg (rep $rep)"
   env $cfg timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | sum
 done; done > ${O}_bench_ab.txt 2>&1
