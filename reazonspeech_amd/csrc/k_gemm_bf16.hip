@@ -1047,6 +1047,12 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
         {
             int em0 = __builtin_amdgcn_readfirstlane(cm0), en0 = __builtin_amdgcn_readfirstlane(cn0);
             asm volatile("" : "+s"(em0), "+s"(en0));
+            // Group 1 runs one barrier behind: its last in-loop barrier pairs with one more barrier of group 0.  Group 0
+            // passes it BEFORE its epilogue (after the last tile): placed after the epilogue, as it was, group 1 sat at
+            // that barrier until group 0 had issued its whole epilogue and the two epilogues ran back to back
+            // (profiles/r02u_gemm_tile_timeline.txt: group 1's "main loop" 2.2 - 4.2 us longer than group 0's).  At
+            // this point group 1 is past its last fragment reads, so nothing reads the ring any more.
+            if (!has_next && wm == 0) __builtin_amdgcn_s_barrier();
             if constexpr (L2PF > 0) {
                 // the compiler does not know about the discarded loads: retire them before their register can be reused
                 // (with a next tile in flight this also waits for its first K tile, which the loop would do anyway)
@@ -1068,7 +1074,216 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
             }
         }
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier at the start
+}
+
+// =====================================================================================================
+// Split-ring variant of the whole-line kernel (one tile per workgroup).
+//
+// What bounds gemm_lmf16_kernel's main loop is not the MFMA rate but the round trip of a K tile's DMAs
+// (profiles/r02u_gemm_tile_timeline.txt): its ring holds two K tiles, so all 56 - 64 KiB of K tile t + 1 are issued
+// during phase (t, 0) and must have landed by the end of phase (t, 1) — one K tile of lookahead, and the pieces a wave
+// issues last queue behind everything issued before them (the CU's L1 -> LDS path moves 64 B/clk: 64 KiB is ~0.5 us
+// of transfer on top of the latency).  A K tile takes ~1.4 us whatever the tile height (1.08 us of MFMA at 1.9 GHz
+// for 256 rows, 0.81 for 192).  LDS has no room for a third K tile, but it has room for HALF of one: here the
+// 160 KiB are five 32-KiB slots, a K tile is two parts (A rows, weight rows), part p lives in slot p mod 5, and
+// during K tile t a wave issues first its pieces of B(t+1) — needed at the end of this K tile, now with nothing
+// queued ahead of them — and then its pieces of A(t+2), which have a whole extra K tile to land.  The wait before
+// K tile t + 1 is a counted vmcnt(LA): the A(t+2) pieces just issued may stay in flight.
+// The epilogue scratch aliases slot 0 (the ring is dead by then: both wave groups are past their last fragment
+// reads when group 0 passes its extra barrier).
+template <int BM, int OUT, bool MASK, int NM0, int EPF = 1, bool TRACE = false>
+__global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
+    constexpr int BN = 256, WN = 4, NWAVES = 8;
+    constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int SLOT = 32768, NSLOT = 5;
+    constexpr int LA = BM / 8 / NWAVES, LB = BN / 8 / NWAVES, NP = LA + LB;   // DMA pieces (8 rows x 128 B) per wave and K tile
+    static_assert((BM == 256 || BM == 192) && LB == 4 && (MI % 2) == 0 && BM * 128 <= SLOT, "tile shapes: 256 x 256 or 192 x 256");
+    long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_w0 = 0, tr_stall = 0;
+    if constexpr (TRACE) { tr_t0 = __builtin_readcyclecounter(); tr_w0 = (long long)wall_clock64(); }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fch = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    char* scr = smem + wave * 4096;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, xslot = bid >> 3;
+    const int q8 = nwg >> 3, rr = nwg & 7;
+    const int xbase = xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8;
+    const int xcount = xcd < rr ? q8 + 1 : q8;
+    if (xslot >= xcount) return;
+    int m0, n0;
+    {
+        const int wg = xbase + xslot;
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = wg / per_group, r = wg - g * per_group;
+        const int left = p.tiles_m - g * p.group_m;
+        const int gm = left < p.group_m ? left : p.group_m;
+        const int tile_n = r / gm;
+        m0 = (g * p.group_m + (r - tile_n * gm)) * BM;
+        n0 = tile_n * BN;
+    }
+    // per-lane byte offsets of this wave's DMA pieces: lane = (row l >> 3 of the piece, physical chunk l & 7)
+    const int dr = lane >> 3, dpc = lane & 7;
+    unsigned off[NP];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        const int row = (wave + NWAVES * j) * 8 + dr;
+        int gr = m0 + row;
+        gr = gr < p.M ? gr : p.M - 1;
+        off[j] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        const int row = (wave * LB + j) * 8 + dr;
+        int gr = n0 + row;
+        gr = gr < p.N ? gr : p.N - 1;
+        off[LA + j] = (unsigned)gr * (unsigned)(p.ldw * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
+    }
+    auto dma_a = [&](int j, int t, int sl) {
+        glds16(off[j], reinterpret_cast<const char*>(p.A) + (size_t)t * 128, lds0 + sl * SLOT + (wave + NWAVES * j) * 1024);
+    };
+    auto dma_b = [&](int j, int t, int sl) {
+        glds16(off[LA + j], reinterpret_cast<const char*>(p.W) + (size_t)t * 128, lds0 + sl * SLOT + (wave * LB + j) * 1024);
+    };
+    auto frag = [&](const char* part, int row, int chunk) -> bf16x8_t {
+        return *reinterpret_cast<const bf16x8_t*>(part + row * 128 + ((chunk ^ swz64(row)) << 4));
+    };
+
+    const int nk = p.K / 64;                                      // K tiles, >= 2 (launcher)
+    // prologue: A(0) -> slot 0, B(0) -> slot 1, A(1) -> slot 2; K tile 0 is complete when all but the last LA landed
+#pragma unroll
+    for (int j = 0; j < LA; ++j) dma_a(j, 0, 0);
+#pragma unroll
+    for (int j = 0; j < LB; ++j) dma_b(j, 0, 1);
+#pragma unroll
+    for (int j = 0; j < LA; ++j) dma_a(j, 1, 2);
+    wait_vmcnt<LA>();
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind from here on
+    if constexpr (TRACE) tr_t1 = __builtin_readcyclecounter();
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NI; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.0f;
+
+    int sa = 0;                                                   // slot of A(t); B(t) = sa + 1, B(t+1) = sa + 3, A(t+2) = sa + 4 (mod 5)
+    for (int t = 0; t < nk; ++t) {
+        auto wrap = [](int v) { return v >= NSLOT ? v - NSLOT : v; };
+        const int sb = wrap(sa + 1), sbn = wrap(sa + 3), san = wrap(sa + 4);
+        const char* at = smem + sa * SLOT;
+        const char* bt = smem + sb * SLOT;
+        const bool has_b = t + 1 < nk, has_a = t + 2 < nk;
+        // piece q of this K tile's issue order: the LB pieces of B(t+1) first, then the LA pieces of A(t+2)
+        auto issue = [&](int q) {
+            if (q < LB) { if (has_b) dma_b(q, t + 1, sbn); }
+            else if (has_a) dma_a(q - LB, t + 2, san);
+        };
+        auto wait_next = [&]() {                                  // K tile t + 1 landed; A(t+2) may stay in flight
+            if (has_a) wait_vmcnt<LA>();
+            else wait_vmcnt<0>();
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t bfr[NI], af[MI];
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj) bfr[jj] = frag(bt, wn * TN + jj * 16 + frow, ks * 4 + fch);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = frag(at, wm * TM + i * 16 + frow, ks * 4 + fch);
+            if (ks == 0 && has_b) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qq = 0; qq < (NM0 < NP ? NM0 : NP); ++qq) issue(qq);
+            }
+            if (ks == 1 && has_b && wm == 1) {                    // group 1: one barrier behind, waits in its memory half
+                if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_next(); tr_stall += __builtin_readcyclecounter() - a; }
+                else wait_next();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            constexpr int REST = NP - (NM0 < NP ? NM0 : NP);      // pieces issued between the MFMAs of phase (t, 0)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < NI; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
+                if (REST > 0 && ks == 0 && i < REST && has_b) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(NP - REST + i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (ks == 1 && has_b && wm == 0) {                    // group 0: before the barrier its reads follow
+                if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_next(); tr_stall += __builtin_readcyclecounter() - a; }
+                else wait_next();
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sa = wrap(sa + 2);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier: nobody reads the ring any more
+    {
+        int em0 = __builtin_amdgcn_readfirstlane(m0), en0 = __builtin_amdgcn_readfirstlane(n0);
+        asm volatile("" : "+s"(em0), "+s"(en0));
+        if constexpr (TRACE) tr_t2 = __builtin_readcyclecounter();
+        pmf16_epilogue<MI, NI, OUT, MASK, EPF>(p, acc, scr, em0, en0, wm, wn, lane);
+        if constexpr (TRACE) {
+            const long long t3 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long t4 = __builtin_readcyclecounter();
+            if (lane == 0 && wn == 0) {
+                long long* tr = p.trace + ((size_t)(xbase + xslot) * 2 + wm) * 8;
+                tr[0] = tr_t1 - tr_t0; tr[1] = tr_t2 - tr_t1; tr[2] = t3 - tr_t2; tr[3] = t4 - t3; tr[4] = tr_stall;
+                tr[5] = bid; tr[6] = tr_w0; tr[7] = (long long)wall_clock64();
+            }
+        }
+    }
+}
+
+template <int BM, int NM0, int EPF = 1>
+int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
+    constexpr int LDS = 5 * 32768;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + 255) / 256;
+    const int nwg = p.tiles_m * p.tiles_n;
+    extern std::atomic<int> g_group_m;
+    p.group_m = g_group_m.load() > 0 ? g_group_m.load()
+              : (p.tiles_n == 4 ? (p.K >= 4096 ? 2 : 6) : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8)));
+    p.skew_cycles = 0;
+    const int out = (p.flags & RS_GEMM_RESIDUAL) ? 2 : ((p.flags & RS_GEMM_OUT_F32) ? 1 : ((p.flags & RS_GEMM_GLU) ? 3 : 0));
+    const bool mask = p.flags & RS_GEMM_ROWMASK;
+#define RS_SMF(O, MK, TR)                                                                                         \
+    do {                                                                                                          \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, MK, NM0, EPF, TR>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_smf16_kernel<BM, O, MK, NM0, EPF, TR>), dim3(nwg), dim3(512), LDS, s, p);       \
+    } while (0)
+    if (p.trace) {
+        if (out == 2 && !mask) RS_SMF(2, false, true);
+        else if (out == 0 && !mask) RS_SMF(0, false, true);
+        else return rs_fail(ctx, RS_EINVAL, "gemm trace: plain bf16 or residual output only");
+        return RS_OK;
+    }
+    if (out == 2 && !mask) RS_SMF(2, false, false);
+    else if (out == 1 && !mask) RS_SMF(1, false, false);
+    else if (out == 0 && !mask) RS_SMF(0, false, false);
+    else if (out == 0 && mask) RS_SMF(0, true, false);
+    else if (out == 3 && !mask) RS_SMF(3, false, false);
+    else return rs_fail(ctx, RS_EINVAL, "gemm: row mask with f32 output has no big-tile kernel");
+#undef RS_SMF
+    return RS_OK;
 }
 
 template <int BM, int NM0, int ABL = 0, int EPF = 1, int L2PF = 0>
@@ -1121,7 +1336,7 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
 // Process-wide A/B knobs (debug / tuning only; the defaults are the measured winners and nothing in the product
 // path writes them).  Atomics initialised once from the environment, so concurrent first launches from the encoder
 // thread and the decode worker are safe; they are deliberately not per-context: they select code paths, not state.
-extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve, g_res_prefetch, g_l2pf, g_l2pf_min_k;
+extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve, g_res_prefetch, g_l2pf, g_l2pf_min_k, g_ring;
 extern std::atomic<long long*> g_trace;
 void gemm_knobs_from_env();
 
@@ -1184,6 +1399,7 @@ std::atomic<int> g_reserve{0};   // CUs the persistent kernel leaves free when a
 // residual chunks requested ahead by the f32 epilogue: 3 (whole path 64.2 vs 64.5 ms/step with 1 and 65.0 with all 6:
 // profiles/r02u_bench_ab.txt; in isolation 6 is the fastest, in the pipeline its 24-load burst per wave is not)
 std::atomic<int> g_res_prefetch{3};
+std::atomic<int> g_ring{0};       // split-ring kernel for the big shapes (0 = the two-K-tile ring)
 std::atomic<int> g_l2pf{0}, g_l2pf_min_k{2048};   // L2 prefetch distance in K tiles (0 = off) for problems with K >= min_k
 void gemm_knobs_from_env() {
     static std::once_flag once;
@@ -1195,6 +1411,7 @@ void gemm_knobs_from_env() {
         env("RS_GEMM_RESERVE_CUS", g_reserve);    // CUs the persistent grid leaves to other streams (contexts may override)
         env("RS_GEMM_BIG", g_big);                // big-tile kernel family (DESIGN.md A/B knob table)
         env("RS_GEMM_RES_PREFETCH", g_res_prefetch);   // 3 (default) / 6 / 1 residual chunks in flight in the f32 epilogue
+        env("RS_GEMM_RING", g_ring);              // 1 / 2: split-ring kernel (gemm_smf16_kernel)
         env("RS_GEMM_L2PF", g_l2pf);              // 0 / 2 / 3: operand lines touched that many K tiles ahead
         env("RS_GEMM_L2PF_MIN_K", g_l2pf_min_k);  // ... for problems at least this deep
     });
@@ -1255,6 +1472,12 @@ static int gemm_pick_variant(const rs_gemm_args& a) {
         v += 30 + (g_persistent.load() == 2 ? 1000 : 0);
     // residual / f32 epilogue of the 192-row tile: deep residual prefetch (RS_GEMM_RES_PREFETCH=1 restores one chunk ahead)
     if (g_variant == 0 && v % 1000 == 62 && g_res_prefetch.load() != 1) v += g_res_prefetch.load() == 3 ? 30 : 20;
+    // split-ring kernel (RS_GEMM_RING: 1 = NM0 5, 2 = NM0 4)
+    if (g_variant == 0 && g_ring.load() > 0 && v >= 1000) {
+        const int k = v % 1000;
+        if (k == 60) v = g_ring.load() == 2 ? 1210 : 1200;
+        else if (k == 62 || k == 82 || k == 92) v = g_ring.load() == 2 ? 1212 : 1202;
+    }
     // long-K problems stream their A operand from HBM: L2 prefetch two (RS_GEMM_L2PF=3: three) K tiles ahead
     if (g_variant == 0 && g_l2pf.load() > 0 && a.K >= g_l2pf_min_k.load()) {
         if (v % 1000 == 92) v += g_l2pf.load() == 3 ? 20 : 10;
@@ -1264,7 +1487,7 @@ static int gemm_pick_variant(const rs_gemm_args& a) {
 }
 
 // the GLU epilogue (RS_GEMM_GLU) exists in the whole-line kernel only: 256- / 192-row tiles of 64-column wave tiles
-static bool gemm_variant_has_glu(int v) { const int k = v % 1000; return k == 50 || k == 52 || k == 60 || k == 62 || k == 70 || k == 72 || k == 82 || k == 92 || k == 100 || k == 110 || k == 102 || k == 112; }
+static bool gemm_variant_has_glu(int v) { const int k = v % 1000; return k == 50 || k == 52 || k == 60 || k == 62 || k == 70 || k == 72 || k == 82 || k == 92 || k == 100 || k == 110 || k == 102 || k == 112 || k == 200 || k == 202 || k == 210 || k == 212; }
 
 bool rs_gemm_has_glu(int M, int N, int K) {
     rs_gemm_args a{};
@@ -1332,6 +1555,11 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         case 82: rc = launch_lmf16<192, 5, 0, 6>(ctx, p, s, pgrid); break;
         case 92: rc = launch_lmf16<192, 5, 0, 3>(ctx, p, s, pgrid); break;
         // 1x0 / 1x2: L2 prefetch of the operand lines two / three K tiles ahead (see the kernel's L2PF)
+        // 20x: the split-ring kernel (B(t+1) first, A(t+2) a K tile further ahead), one tile per workgroup
+        case 200: rc = launch_smf16<256, 5>(ctx, p, s); break;
+        case 202: rc = launch_smf16<192, 5, 3>(ctx, p, s); break;
+        case 210: rc = launch_smf16<256, 4>(ctx, p, s); break;      // only the B pieces beside the fragment reads
+        case 212: rc = launch_smf16<192, 4, 3>(ctx, p, s); break;
         case 100: rc = launch_lmf16<256, 5, 0, 1, 2>(ctx, p, s, pgrid); break;
         case 110: rc = launch_lmf16<256, 5, 0, 1, 3>(ctx, p, s, pgrid); break;
         case 102: rc = launch_lmf16<192, 5, 0, 3, 2>(ctx, p, s, pgrid); break;

@@ -107,9 +107,10 @@ def test_gemm_big_tiles(ctx, gpu_device, N, K, residual, family):
     assert (out_full[M:].float() == 7.0).all(), "rows past M were written"
 
 
-@pytest.mark.parametrize("variant", [1062, 1082, 1092, 1102, 1112, 1100, 1110])
+@pytest.mark.parametrize("variant", [1062, 1082, 1092, 1102, 1112, 1100, 1110, 1200, 1202, 1210, 1212])
 def test_gemm_prefetch_variants(ctx, gpu_device, variant):
-    """the whole-line kernel's latency options — residual chunks requested 1 / 3 / 6 ahead in the f32 epilogue, operand
+    """(12xx: the split-ring kernel — five 32-KiB operand-part slots, B(t+1) issued first, A(t+2) a K tile further ahead,
+    epilogue scratch aliasing the ring.)  The whole-line kernel's latency options — residual chunks requested 1 / 3 / 6 ahead in the f32 epilogue, operand
     lines touched in L2 two / three K tiles ahead — compute the same thing: residual update IN PLACE (out aliases the
     residual, as in the encoder) for the 192-row variants, SiLU -> bf16 for the 256-row ones, ragged last tile"""
     import ctypes
@@ -147,8 +148,34 @@ def test_gemm_prefetch_variants(ctx, gpu_device, variant):
     assert (out_full[M:].float() == 7.0).all(), "rows past M were written"
 
 
+@pytest.mark.parametrize("variant", [1200, 1202])
+@pytest.mark.parametrize("M,N,K", [(4416, 512, 128), (5000, 256, 192), (70, 1024, 320), (2049, 768, 1024)])
+def test_gemm_split_ring_short_k(ctx, gpu_device, M, N, K, variant):
+    """the split-ring kernel at the edges of its schedule: two K tiles (only B(1) is ever issued in the loop), three
+    (one A(t+2)), five (the slot sequence wraps), ragged rows / columns; f32 output"""
+    import ctypes
+    g = torch.Generator().manual_seed(M + N + K)
+    A = rb(torch.randn((M, K), generator=g))
+    W = rb(torch.randn((N, K), generator=g) / K ** 0.5)
+    bias = torch.randn((N,), generator=g)
+    ref = A @ W.t() + bias
+    out = torch.full((M + 8, N), 7.0, dtype=torch.float32, device=gpu_device)
+    setv = ctx.lib.rs_debug_set_gemm_variant
+    setv.argtypes = [ctypes.c_int]
+    setv.restype = None
+    try:
+        setv(variant)
+        ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out[:M], flags=capi.GEMM_BIAS | capi.GEMM_OUT_F32, bias=bias.to(gpu_device))
+        sync()
+    finally:
+        setv(0)
+    assert (out[:M].cpu() - ref).abs().max() <= 2e-3
+    assert (out[M:] == 7.0).all()
+
+
+@pytest.mark.parametrize("variant", [0, 1200])
 @pytest.mark.parametrize("M", [35328 - 37, 300])
-def test_gemm_glu_epilogue(ctx, gpu_device, M):
+def test_gemm_glu_epilogue(ctx, gpu_device, M, variant):
     """RS_GEMM_GLU: value / gate columns interleaved in blocks of 32 (the loader's pw1 row order), GLU applied to the
     f32 accumulators, bf16 [M][N/2] out.  M = 300 is a problem the heuristics would give to the small-tile kernels:
     the flag moves it to the big-tile kernel."""
@@ -163,9 +190,17 @@ def test_gemm_glu_epilogue(ctx, gpu_device, M):
     ref = y[:, :d] * torch.sigmoid(y[:, d:])
     idx = glu_interleave_index(d)
     out = torch.full((M + 64, d), 7.0, dtype=torch.bfloat16, device=gpu_device)
-    ctx.gemm(bf(A).to(gpu_device), bf(W[idx]).to(gpu_device), out[:M], flags=capi.GEMM_BIAS | capi.GEMM_GLU,
-             bias=bias[idx].to(gpu_device))
-    sync()
+    import ctypes
+    setv = ctx.lib.rs_debug_set_gemm_variant
+    setv.argtypes = [ctypes.c_int]
+    setv.restype = None
+    try:
+        setv(variant)
+        ctx.gemm(bf(A).to(gpu_device), bf(W[idx]).to(gpu_device), out[:M], flags=capi.GEMM_BIAS | capi.GEMM_GLU,
+                 bias=bias[idx].to(gpu_device))
+        sync()
+    finally:
+        setv(0)
     got = out[rows.to(gpu_device)].float().cpu()
     bad = (got - ref).abs() > 2e-3 + 2.0 ** -8 * ref.abs()
     assert not bad.any(), (int(bad.sum()), float((got - ref).abs().max()))
