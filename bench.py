@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--beam", type=int, default=4, help="beam size of --decoding alsd")
     ap.add_argument("--buffer-sets", type=int, default=int(os.environ.get("RS_BUFFER_SETS", "2")),
                     help="resident batches the pipeline rotates through (2 = encoder i+1 waits for decode i-1)")
-    ap.add_argument("--dec-streams", type=int, default=int(os.environ.get("RS_DEC_STREAMS", "1")),
+    ap.add_argument("--dec-streams", type=int, default=int(os.environ.get("RS_DEC_STREAMS", "2")),
                     help="decode consecutive batches on this many streams (2 needs three resident batches)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decode of each batch back to back on one stream")
@@ -289,7 +289,7 @@ def main():
                     traffic = json.load(fp)["hbm_bytes_per_launch"]
             except Exception:
                 pass
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_lmf16_kernel (all encoder linears; gemm_bf16_kernel for the small shapes)",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_smf16_kernel (all encoder linears; gemm_bf16_kernel for the small shapes)",
                                "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (PMC, profiles/gemm_traffic.json)",

@@ -1399,7 +1399,10 @@ std::atomic<int> g_reserve{0};   // CUs the persistent kernel leaves free when a
 // residual chunks requested ahead by the f32 epilogue: 3 (whole path 64.2 vs 64.5 ms/step with 1 and 65.0 with all 6:
 // profiles/r02u_bench_ab.txt; in isolation 6 is the fastest, in the pipeline its 24-load burst per wave is not)
 std::atomic<int> g_res_prefetch{3};
-std::atomic<int> g_ring{0};       // split-ring kernel for the big shapes (0 = the two-K-tile ring)
+// split-ring kernel for the big shapes: 2 (default) = B pieces beside the fragment reads, A pieces between the MFMAs;
+// 1 = five pieces beside the reads; 0 = the two-K-tile ring (gemm_lmf16_kernel).  Same box, whole path:
+// 64.0 -> 61.7 ms/step, ffn_down 314 -> 276 us (profiles/r02x_*)
+std::atomic<int> g_ring{2};
 std::atomic<int> g_l2pf{0}, g_l2pf_min_k{2048};   // L2 prefetch distance in K tiles (0 = off) for problems with K >= min_k
 void gemm_knobs_from_env() {
     static std::once_flag once;
@@ -1411,7 +1414,7 @@ void gemm_knobs_from_env() {
         env("RS_GEMM_RESERVE_CUS", g_reserve);    // CUs the persistent grid leaves to other streams (contexts may override)
         env("RS_GEMM_BIG", g_big);                // big-tile kernel family (DESIGN.md A/B knob table)
         env("RS_GEMM_RES_PREFETCH", g_res_prefetch);   // 3 (default) / 6 / 1 residual chunks in flight in the f32 epilogue
-        env("RS_GEMM_RING", g_ring);              // 1 / 2: split-ring kernel (gemm_smf16_kernel)
+        env("RS_GEMM_RING", g_ring);              // 2 (default) / 1: split-ring kernel (gemm_smf16_kernel); 0: gemm_lmf16_kernel
         env("RS_GEMM_L2PF", g_l2pf);              // 0 / 2 / 3: operand lines touched that many K tiles ahead
         env("RS_GEMM_L2PF_MIN_K", g_l2pf_min_k);  // ... for problems at least this deep
     });

@@ -92,6 +92,7 @@ class AsrModel:
         self._ctx_enc2 = None
         self._enc2_stream = None
         self._streams = None
+        self._streams_prio = None
         self.pos_cap = 0
         with torch.cuda.device(self.device):
             self.ctx = capi.Context(cfg, index)
@@ -259,27 +260,34 @@ class AsrModel:
                 # 79.8 ms/step, profiles/r01h_bench_matrix_split.txt) — the GEMM grids halve and the
                 # tile rounds quantise worse than the overlap wins; kept as an opt-in experiment
                 split_encoder = os.environ.get("RS_SPLIT_ENCODER", "0") != "0"
+            # the decode chain of ONE stream is latency-critical (its workgroups should take the first free slots: high
+            # priority); with two decode lanes it has a whole extra encoder period of slack and normal priority leaves
+            # the GEMM rounds alone (profiles/r02w_bench_ab.txt)
+            dec_prio = int(os.environ.get("RS_DECODE_PRIORITY", "0" if dec_streams == 2 else "-1"))
             if self._ctx_dec is None:
                 self._ctx_dec = self.ctx.clone()
                 self._ctx_enc2 = self.ctx.clone()
                 self._enc2_stream = torch.cuda.Stream(device=self.device)
-                # the decode chain is latency-critical: its workgroups should take the first free slots
+            if self._streams is None or self._streams_prio != dec_prio:
                 dec_cus = int(os.environ.get("RS_DECODE_CUS", "0"))
-                dec_prio = int(os.environ.get("RS_DECODE_PRIORITY", "-1"))
                 if dec_cus > 0:
                     # decode confined to a slice of the chip (A/B knob): raw HIP stream with a CU mask
                     self._dec_raw = capi.create_stream(self.device.index, dec_cus, self.ctx.n_cus(), dec_prio)
                     dec = torch.cuda.ExternalStream(self._dec_raw, device=self.device)
                 else:
                     dec = torch.cuda.Stream(device=self.device, priority=dec_prio)
-                self._streams = (torch.cuda.Stream(device=self.device), dec)
+                enc = self._streams[0] if self._streams is not None else torch.cuda.Stream(device=self.device)
+                self._streams = (enc, dec)
+                self._streams_prio = dec_prio
+                self._dec2_stream = None
             enc_stream, dec_stream = self._streams
             self._decode_policy(self._ctx_dec, bufs[0].B, pipelined=True)
             dec_lanes = [(self._ctx_dec, dec_stream)]
             if dec_streams == 2:
                 if self._ctx_dec2 is None:
                     self._ctx_dec2 = self.ctx.clone()
-                    self._dec2_stream = torch.cuda.Stream(device=self.device, priority=getattr(dec_stream, "priority", -1))
+                if self._dec2_stream is None:
+                    self._dec2_stream = torch.cuda.Stream(device=self.device, priority=dec_prio)
                 self._decode_policy(self._ctx_dec2, bufs[0].B, pipelined=True)
                 dec_lanes.append((self._ctx_dec2, self._dec2_stream))
             enc_stream.wait_stream(torch.cuda.current_stream())

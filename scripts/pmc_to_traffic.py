@@ -19,7 +19,7 @@ for line in open(src):
     tot_n += n
     tot_b += n * (rd + wr)
 out = {
-    "kernel": "all GEMM launches of the encoder (gemm_lmf16_kernel: whole-line cross-tile kernel; gemm_bf16_kernel: small shapes)",
+    "kernel": "all GEMM launches of the encoder (gemm_smf16_kernel: whole-line split-ring kernel; gemm_bf16_kernel: small shapes)",
     "hbm_bytes_per_launch": round(tot_b / tot_n),
     "per_kernel": per,
     "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-pipeline`; "
