@@ -860,11 +860,7 @@ __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 // ABL (profiling builds): 1 = no MFMAs, 2 = no DMAs in the main loop, 3 = no fragment reads (wrong results);
 // 4 = correct results plus a per-tile timeline in p.trace (scripts/gemm_trace.py).
 // EPF: residual prefetch depth of the f32 epilogue in 16-row chunks (pmf16_epilogue).
-// L2PF: every wave touches 64 operand lines (128 B each) of K tile t + L2PF with one discarded dword load per K tile,
-// issued right after the DMAs of K tile t + 1 (0 = off).  The ring looks ahead ONE K tile (~1.5 us): enough for
-// operands that sit in L2 / the infinity cache, not for an A matrix streamed from HBM (ffn_down: 289 MB, rows 8 KiB
-// apart) — there wave group 1 sat 22 of 100 us per tile in the K-tile wait (profiles/r02u_gemm_tile_timeline.txt).
-template <int BM, int OUT, bool MASK, int NM0, int ABL = 0, int EPF = 1, int L2PF = 0>
+template <int BM, int OUT, bool MASK, int NM0, int ABL = 0, int EPF = 1>
 __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
     constexpr bool TRACE = ABL == 4;
     long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_w0 = 0, tr_stall = 0;
@@ -934,31 +930,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
     int m0, n0;
     tile_origin(slot, m0, n0);
     lane_offsets(m0, n0);
-    // L2 prefetch: waves 0 .. BM/64-1 cover the A rows of the tile (lane = row), the next four the weight rows
-    constexpr int PFA = BM / 64;
-    const bool pf_is_a = wave < PFA;
-    unsigned pf_off = 0;
-    unsigned pf_sink = 0;                                         // destination of the discarded loads (kept live to the end)
-    auto pf_offsets = [&](int m0_, int n0_) {
-        if constexpr (L2PF > 0) {
-            int w = pf_is_a ? wave : wave - PFA;
-            w = w < 4 ? w : 3;
-            int gr = (pf_is_a ? m0_ : n0_) + w * 64 + lane;
-            const int lim = pf_is_a ? p.M : p.N;
-            gr = gr < lim ? gr : lim - 1;
-            pf_off = (unsigned)gr * (unsigned)((pf_is_a ? p.lda : p.ldw) * 2);
-        }
-    };
-    pf_offsets(m0, n0);
-    auto l2_prefetch = [&](int t) {
-        if constexpr (L2PF > 0) {
-            t = t < nk ? t : nk - 1;
-            const char* base = (pf_is_a ? reinterpret_cast<const char*>(p.A) : reinterpret_cast<const char*>(p.W)) + (size_t)t * 128;
-            asm volatile("global_load_dword %0, %1, %2 nt" : "+v"(pf_sink) : "v"(pf_off), "s"(base) : "memory");
-        }
-    };
-    // K-tile waits: the one prefetch load issued after the DMAs may still be in flight
-    auto wait_ktile = [&]() { if constexpr (L2PF > 0) wait_vmcnt<1>(); else wait_vmcnt<0>(); };
+    auto wait_ktile = [&]() { wait_vmcnt<0>(); };
     int gc = 0;                                                   // K tiles consumed so far (ring position)
 #pragma unroll
     for (int qq = 0; qq < NP; ++qq) dma(qq, 0, 0);
@@ -988,7 +960,6 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
             if (!own && has_next) {                               // all DMAs of this tile are issued: switch to the next tile
                 tile_origin(j + nslots, m0, n0);
                 lane_offsets(m0, n0);
-                pf_offsets(m0, n0);
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -1027,11 +998,6 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
                         dma(NP - REST + i, tn, nbuf);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (L2PF > 0 && ks == 0 && i == (REST > 0 ? REST : 0) && more) {   // after the last DMA of K tile t + 1
-                        __builtin_amdgcn_sched_barrier(0);
-                        l2_prefetch(own ? t + L2PF : L2PF - 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
                 if (ks == 1 && more && wm == 0) {                           // group 0: before the barrier its reads follow
                     if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_ktile(); tr_stall += __builtin_readcyclecounter() - a; }
@@ -1053,11 +1019,6 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
             // (profiles/r02u_gemm_tile_timeline.txt: group 1's "main loop" 2.2 - 4.2 us longer than group 0's).  At
             // this point group 1 is past its last fragment reads, so nothing reads the ring any more.
             if (!has_next && wm == 0) __builtin_amdgcn_s_barrier();
-            if constexpr (L2PF > 0) {
-                // the compiler does not know about the discarded loads: retire them before their register can be reused
-                // (with a next tile in flight this also waits for its first K tile, which the loop would do anyway)
-                if (!has_next) { wait_vmcnt<0>(); asm volatile("" :: "v"(pf_sink)); }
-            }
             if constexpr (TRACE) tr_t2 = __builtin_readcyclecounter();
             pmf16_epilogue<MI, NI, OUT, MASK, EPF>(p, acc, scr, em0, en0, wm, wn, lane);
             if constexpr (TRACE) {
@@ -1253,239 +1214,6 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     }
 }
 
-// =====================================================================================================
-// One 64-deep phase per K tile on the split ring (experimental, RS_GEMM_RING=3).
-//
-// gemm_smf16_kernel's 256-row main loop runs at 79 % of the MFMA rate of its clock: every barrier interval holds 512
-// MFMA cycles plus ~165 cycles of barrier / wait / issue overhead (profiles/r02x_gemm_tile_timeline.txt), and a K tile
-// is four such intervals.  Here a wave reads the fragments of BOTH k halves in its memory half (24 instead of 12:
-// 96 fragment registers) and runs all 64 MFMAs of the K tile in one MFMA half: two intervals per K tile.
-// Interval s: group 0 = memory half of K tile s/2 (s even) or its MFMA half (s odd); group 1 the same one interval
-// later.  K tile t is last read in interval 2t+1 (group 1) and K tile t+1 first read in interval 2t+2 (group 0), so
-//   * group 0 issues its pieces of B(t+1) in its memory half of t (interval 2t), its pieces of A(t+2) between the
-//     MFMAs of t (interval 2t+1), and waits (vmcnt(LA)) at the end of that MFMA half;
-//   * group 1 issues its pieces of B(t+2) and A(t+3) between the MFMAs of ITS K tile t (interval 2t+2: the slots of
-//     A(t) and B(t), whose last reads were its own, one interval earlier), and waits for K tile t+1 at the end of its
-//     memory half of t (interval 2t+1); its pieces of B(1) / A(2) go out before the loop.
-// Every piece has about a K tile of time to land, as in gemm_smf16_kernel.
-template <int BM, int OUT, bool MASK, int EPF = 1, bool TRACE = false>
-__global__ __launch_bounds__(512, 2) void gemm_tmf16_kernel(GemmParams p) {
-    constexpr int BN = 256, WN = 4, NWAVES = 8;
-    constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
-    constexpr int SLOT = 32768, NSLOT = 5;
-    constexpr int LA = BM / 8 / NWAVES, LB = BN / 8 / NWAVES, NP = LA + LB;
-    static_assert((BM == 256 || BM == 192) && LB == 4 && (MI % 2) == 0 && BM * 128 <= SLOT && NP <= MI + 2, "tile shapes: 256 x 256 or 192 x 256");
-    long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_w0 = 0, tr_stall = 0;
-    if constexpr (TRACE) { tr_t0 = __builtin_readcyclecounter(); tr_w0 = (long long)wall_clock64(); }
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int frow = lane & 15, fch = lane >> 4;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    char* scr = smem + wave * 4096;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, xslot = bid >> 3;
-    const int q8 = nwg >> 3, rr = nwg & 7;
-    const int xbase = xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8;
-    const int xcount = xcd < rr ? q8 + 1 : q8;
-    if (xslot >= xcount) return;
-    int m0, n0;
-    {
-        const int wg = xbase + xslot;
-        const int per_group = p.group_m * p.tiles_n;
-        const int g = wg / per_group, r = wg - g * per_group;
-        const int left = p.tiles_m - g * p.group_m;
-        const int gm = left < p.group_m ? left : p.group_m;
-        const int tile_n = r / gm;
-        m0 = (g * p.group_m + (r - tile_n * gm)) * BM;
-        n0 = tile_n * BN;
-    }
-    const int dr = lane >> 3, dpc = lane & 7;
-    unsigned off[NP];
-#pragma unroll
-    for (int j = 0; j < LA; ++j) {
-        const int row = (wave + NWAVES * j) * 8 + dr;
-        int gr = m0 + row;
-        gr = gr < p.M ? gr : p.M - 1;
-        off[j] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < LB; ++j) {
-        const int row = (wave * LB + j) * 8 + dr;
-        int gr = n0 + row;
-        gr = gr < p.N ? gr : p.N - 1;
-        off[LA + j] = (unsigned)gr * (unsigned)(p.ldw * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
-    }
-    auto dma_a = [&](int j, int t, int sl) {
-        glds16(off[j], reinterpret_cast<const char*>(p.A) + (size_t)t * 128, lds0 + sl * SLOT + (wave + NWAVES * j) * 1024);
-    };
-    auto dma_b = [&](int j, int t, int sl) {
-        glds16(off[LA + j], reinterpret_cast<const char*>(p.W) + (size_t)t * 128, lds0 + sl * SLOT + (wave * LB + j) * 1024);
-    };
-    auto frag = [&](const char* part, int row, int chunk) -> bf16x8_t {
-        return *reinterpret_cast<const bf16x8_t*>(part + row * 128 + ((chunk ^ swz64(row)) << 4));
-    };
-    auto wrap = [](int v) { return v >= NSLOT ? v - NSLOT : v; };
-
-    const int nk = p.K / 64;                                      // K tiles, >= 2 (launcher)
-#pragma unroll
-    for (int j = 0; j < LA; ++j) dma_a(j, 0, 0);
-#pragma unroll
-    for (int j = 0; j < LB; ++j) dma_b(j, 0, 1);
-#pragma unroll
-    for (int j = 0; j < LA; ++j) dma_a(j, 1, 2);
-    wait_vmcnt<LA>();
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) {
-        // group 1 runs one barrier behind from here on; its pieces of B(1) and A(2) go out in the interval it skips
-#pragma unroll
-        for (int j = 0; j < LB; ++j) dma_b(j, 1, 3);
-        if (nk > 2) {
-#pragma unroll
-            for (int j = 0; j < LA; ++j) dma_a(j, 2, 4);
-        }
-        __builtin_amdgcn_s_barrier();
-    }
-    if constexpr (TRACE) tr_t1 = __builtin_readcyclecounter();
-
-    f32x4_t acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int jj = 0; jj < NI; ++jj)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.0f;
-
-    int sa = 0;                                                   // slot of A(t); B(t) = sa + 1, B(t+1) = sa + 3, A(t+2) = sa + 4 (mod 5)
-    for (int t = 0; t < nk; ++t) {
-        const int sb = wrap(sa + 1), sbn = wrap(sa + 3), san = wrap(sa + 4);
-        const char* at = smem + sa * SLOT;
-        const char* bt = smem + sb * SLOT;
-        const bool has1 = t + 1 < nk, has2 = t + 2 < nk, has3 = t + 3 < nk;
-        // piece q of a wave's issue list during its MFMA half
-        //   group 0: the LA pieces of A(t+2)                        (its B(t+1) pieces went out in the memory half)
-        //   group 1: the LB pieces of B(t+2) -> slot of A(t), then the LA pieces of A(t+3) -> slot of B(t)
-        auto issue_mfma_half = [&](int q) {
-            if (wm == 0) { if (q < LA && has2) dma_a(q, t + 2, san); }
-            else if (q < LB) { if (has2) dma_b(q, t + 2, sa); }
-            else if (q < NP && has3) dma_a(q - LB, t + 3, sb);
-        };
-        bf16x8_t bfr[2][NI], af[2][MI];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int jj = 0; jj < NI; ++jj) bfr[ks][jj] = frag(bt, wn * TN + jj * 16 + frow, ks * 4 + fch);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[ks][i] = frag(at, wm * TM + i * 16 + frow, ks * 4 + fch);
-        }
-        if (wm == 0 && has1) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int qq = 0; qq < LB; ++qq) dma_b(qq, t + 1, sbn);
-        }
-        if (wm == 1 && has1) {                                    // group 1: K tile t + 1 landed (its A(t+2) pieces may stay in flight)
-            if constexpr (TRACE) {
-                const long long a = __builtin_readcyclecounter();
-                if (has2) wait_vmcnt<LA>(); else wait_vmcnt<0>();
-                tr_stall += __builtin_readcyclecounter() - a;
-            } else {
-                if (has2) wait_vmcnt<LA>(); else wait_vmcnt<0>();
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int jj = 0; jj < NI; ++jj)
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][jj], af[ks][i], acc[i][jj], 0, 0, 0);
-                if (ks == 0 && has2) {                            // pieces NP-ish: one per MFMA row of the first k half (+ the rest with the second)
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_mfma_half(i);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (ks == 1 && i + MI < NP && has2) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_mfma_half(i + MI);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        if (wm == 0 && has1) {                                    // group 0: before the barrier its reads of K tile t + 1 follow
-            if constexpr (TRACE) {
-                const long long a = __builtin_readcyclecounter();
-                if (has2) wait_vmcnt<LA>(); else wait_vmcnt<0>();
-                tr_stall += __builtin_readcyclecounter() - a;
-            } else {
-                if (has2) wait_vmcnt<LA>(); else wait_vmcnt<0>();
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        sa = wrap(sa + 2);
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier: nobody reads the ring any more
-    {
-        int em0 = __builtin_amdgcn_readfirstlane(m0), en0 = __builtin_amdgcn_readfirstlane(n0);
-        asm volatile("" : "+s"(em0), "+s"(en0));
-        if constexpr (TRACE) tr_t2 = __builtin_readcyclecounter();
-        pmf16_epilogue<MI, NI, OUT, MASK, EPF>(p, acc, scr, em0, en0, wm, wn, lane);
-        if constexpr (TRACE) {
-            const long long t3 = __builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const long long t4 = __builtin_readcyclecounter();
-            if (lane == 0 && wn == 0) {
-                long long* tr = p.trace + ((size_t)(xbase + xslot) * 2 + wm) * 8;
-                tr[0] = tr_t1 - tr_t0; tr[1] = tr_t2 - tr_t1; tr[2] = t3 - tr_t2; tr[3] = t4 - t3; tr[4] = tr_stall;
-                tr[5] = bid; tr[6] = tr_w0; tr[7] = (long long)wall_clock64();
-            }
-        }
-    }
-}
-
-template <int BM, int EPF = 1>
-int launch_tmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
-    constexpr int LDS = 5 * 32768;
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + 255) / 256;
-    const int nwg = p.tiles_m * p.tiles_n;
-    extern std::atomic<int> g_group_m;
-    p.group_m = g_group_m.load() > 0 ? g_group_m.load()
-              : (p.tiles_n == 4 ? (p.K >= 4096 ? 2 : 6) : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8)));
-    p.skew_cycles = 0;
-    const int out = (p.flags & RS_GEMM_RESIDUAL) ? 2 : ((p.flags & RS_GEMM_OUT_F32) ? 1 : ((p.flags & RS_GEMM_GLU) ? 3 : 0));
-    const bool mask = p.flags & RS_GEMM_ROWMASK;
-#define RS_TMF(O, MK, TR)                                                                                         \
-    do {                                                                                                          \
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_tmf16_kernel<BM, O, MK, EPF, TR>, LDS); rc != RS_OK) return rc; \
-        hipLaunchKernelGGL((gemm_tmf16_kernel<BM, O, MK, EPF, TR>), dim3(nwg), dim3(512), LDS, s, p);            \
-    } while (0)
-    if (p.trace) {
-        if (out == 2 && !mask) RS_TMF(2, false, true);
-        else if (out == 0 && !mask) RS_TMF(0, false, true);
-        else return rs_fail(ctx, RS_EINVAL, "gemm trace: plain bf16 or residual output only");
-        return RS_OK;
-    }
-    if (out == 2 && !mask) RS_TMF(2, false, false);
-    else if (out == 1 && !mask) RS_TMF(1, false, false);
-    else if (out == 0 && !mask) RS_TMF(0, false, false);
-    else if (out == 0 && mask) RS_TMF(0, true, false);
-    else if (out == 3 && !mask) RS_TMF(3, false, false);
-    else return rs_fail(ctx, RS_EINVAL, "gemm: row mask with f32 output has no big-tile kernel");
-#undef RS_TMF
-    return RS_OK;
-}
-
 template <int BM, int NM0, int EPF = 1>
 int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     constexpr int LDS = 5 * 32768;
@@ -1519,7 +1247,7 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     return RS_OK;
 }
 
-template <int BM, int NM0, int ABL = 0, int EPF = 1, int L2PF = 0>
+template <int BM, int NM0, int ABL = 0, int EPF = 1>
 int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
     constexpr int BN = 256;
     constexpr int LDS = 2 * (BM + BN) * 128 + 8 * 4096;
@@ -1543,18 +1271,18 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
     if (p.trace) {      // debug build of the same kernel that records a per-tile timeline (one tile per workgroup only)
         if (mask || out == 1 || out == 3 || grid != nwg) return rs_fail(ctx, RS_EINVAL, "gemm trace: plain bf16 or residual output, one tile per workgroup");
         if (out == 2) {
-            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 2, false, NM0, 4, EPF, L2PF>, LDS); rc != RS_OK) return rc;
-            hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 2, false, NM0, 4, EPF, L2PF>), dim3(grid), dim3(512), LDS, s, p);
+            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 2, false, NM0, 4, EPF>, LDS); rc != RS_OK) return rc;
+            hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 2, false, NM0, 4, EPF>), dim3(grid), dim3(512), LDS, s, p);
         } else {
-            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 0, false, NM0, 4, EPF, L2PF>, LDS); rc != RS_OK) return rc;
-            hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 0, false, NM0, 4, EPF, L2PF>), dim3(grid), dim3(512), LDS, s, p);
+            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, 0, false, NM0, 4, EPF>, LDS); rc != RS_OK) return rc;
+            hipLaunchKernelGGL((gemm_lmf16_kernel<BM, 0, false, NM0, 4, EPF>), dim3(grid), dim3(512), LDS, s, p);
         }
         return RS_OK;
     }
 #define RS_LMF(O, MK)                                                                                         \
     do {                                                                                                      \
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, O, MK, NM0, 0, EPF, L2PF>, LDS); rc != RS_OK) return rc; \
-        hipLaunchKernelGGL((gemm_lmf16_kernel<BM, O, MK, NM0, 0, EPF, L2PF>), dim3(grid), dim3(512), LDS, s, p);      \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_lmf16_kernel<BM, O, MK, NM0, 0, EPF>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_lmf16_kernel<BM, O, MK, NM0, 0, EPF>), dim3(grid), dim3(512), LDS, s, p);      \
     } while (0)
     if (out == 2 && !mask) RS_LMF(2, false);
     else if (out == 1 && !mask) RS_LMF(1, false);
@@ -1569,7 +1297,7 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
 // Process-wide A/B knobs (debug / tuning only; the defaults are the measured winners and nothing in the product
 // path writes them).  Atomics initialised once from the environment, so concurrent first launches from the encoder
 // thread and the decode worker are safe; they are deliberately not per-context: they select code paths, not state.
-extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve, g_res_prefetch, g_l2pf, g_l2pf_min_k, g_ring;
+extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve, g_res_prefetch, g_ring;
 extern std::atomic<long long*> g_trace;
 void gemm_knobs_from_env();
 
@@ -1636,7 +1364,6 @@ std::atomic<int> g_res_prefetch{3};
 // 1 = five pieces beside the reads; 0 = the two-K-tile ring (gemm_lmf16_kernel).  Same box, whole path:
 // 64.0 -> 61.7 ms/step, ffn_down 314 -> 276 us (profiles/r02x_*)
 std::atomic<int> g_ring{2};
-std::atomic<int> g_l2pf{0}, g_l2pf_min_k{2048};   // L2 prefetch distance in K tiles (0 = off) for problems with K >= min_k
 void gemm_knobs_from_env() {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1648,8 +1375,6 @@ void gemm_knobs_from_env() {
         env("RS_GEMM_BIG", g_big);                // big-tile kernel family (DESIGN.md A/B knob table)
         env("RS_GEMM_RES_PREFETCH", g_res_prefetch);   // 3 (default) / 6 / 1 residual chunks in flight in the f32 epilogue
         env("RS_GEMM_RING", g_ring);              // 2 (default) / 1: split-ring kernel (gemm_smf16_kernel); 0: gemm_lmf16_kernel
-        env("RS_GEMM_L2PF", g_l2pf);              // 0 / 2 / 3: operand lines touched that many K tiles ahead
-        env("RS_GEMM_L2PF_MIN_K", g_l2pf_min_k);  // ... for problems at least this deep
     });
 }
 
@@ -1711,20 +1436,14 @@ static int gemm_pick_variant(const rs_gemm_args& a) {
     // split-ring kernel (RS_GEMM_RING: 1 = NM0 5, 2 = NM0 4)
     if (g_variant == 0 && g_ring.load() > 0 && v >= 1000) {
         const int k = v % 1000;
-        const int r = g_ring.load();       // 3 / 4: one-phase kernel for the 256-row / for both tile heights (experimental)
-        if (k == 60) v = r >= 3 ? 1300 : (r == 2 ? 1210 : 1200);
-        else if (k == 62 || k == 82 || k == 92) v = r == 4 ? 1302 : (r == 1 ? 1202 : 1212);
-    }
-    // long-K problems stream their A operand from HBM: L2 prefetch two (RS_GEMM_L2PF=3: three) K tiles ahead
-    if (g_variant == 0 && g_l2pf.load() > 0 && a.K >= g_l2pf_min_k.load()) {
-        if (v % 1000 == 92) v += g_l2pf.load() == 3 ? 20 : 10;
-        else if (v % 1000 == 60) v += g_l2pf.load() == 3 ? 50 : 40;
+        if (k == 60) v = g_ring.load() == 1 ? 1200 : 1210;
+        else if (k == 62 || k == 82 || k == 92) v = g_ring.load() == 1 ? 1202 : 1212;
     }
     return v;
 }
 
 // the GLU epilogue (RS_GEMM_GLU) exists in the whole-line kernel only: 256- / 192-row tiles of 64-column wave tiles
-static bool gemm_variant_has_glu(int v) { const int k = v % 1000; return k == 50 || k == 52 || k == 60 || k == 62 || k == 70 || k == 72 || k == 82 || k == 92 || k == 100 || k == 110 || k == 102 || k == 112 || k == 200 || k == 202 || k == 210 || k == 212 || k == 300 || k == 302; }
+static bool gemm_variant_has_glu(int v) { const int k = v % 1000; return k == 50 || k == 52 || k == 60 || k == 62 || k == 70 || k == 72 || k == 82 || k == 92 || k == 200 || k == 202 || k == 210 || k == 212; }
 
 bool rs_gemm_has_glu(int M, int N, int K) {
     rs_gemm_args a{};
@@ -1791,19 +1510,11 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         // 82 / 92: 62 with every / three of the six residual chunks of the f32 epilogue requested up front
         case 82: rc = launch_lmf16<192, 5, 0, 6>(ctx, p, s, pgrid); break;
         case 92: rc = launch_lmf16<192, 5, 0, 3>(ctx, p, s, pgrid); break;
-        // 1x0 / 1x2: L2 prefetch of the operand lines two / three K tiles ahead (see the kernel's L2PF)
         // 20x: the split-ring kernel (B(t+1) first, A(t+2) a K tile further ahead), one tile per workgroup
         case 200: rc = launch_smf16<256, 5>(ctx, p, s); break;
         case 202: rc = launch_smf16<192, 5, 3>(ctx, p, s); break;
         case 210: rc = launch_smf16<256, 4>(ctx, p, s); break;      // only the B pieces beside the fragment reads
         case 212: rc = launch_smf16<192, 4, 3>(ctx, p, s); break;
-        // 30x: the split ring with one 64-deep phase per K tile (experimental)
-        case 300: rc = launch_tmf16<256>(ctx, p, s); break;
-        case 302: rc = launch_tmf16<192, 3>(ctx, p, s); break;
-        case 100: rc = launch_lmf16<256, 5, 0, 1, 2>(ctx, p, s, pgrid); break;
-        case 110: rc = launch_lmf16<256, 5, 0, 1, 3>(ctx, p, s, pgrid); break;
-        case 102: rc = launch_lmf16<192, 5, 0, 3, 2>(ctx, p, s, pgrid); break;
-        case 112: rc = launch_lmf16<192, 5, 0, 3, 3>(ctx, p, s, pgrid); break;
         case 70: rc = launch_lmf16<256, 3>(ctx, p, s, pgrid); break;
         case 72: rc = launch_lmf16<192, 3>(ctx, p, s, pgrid); break;
         case 1: rc = launch_variant<128, 128, 64, 2, 2, 2>(ctx, p, s); break;   // small problems
