@@ -143,20 +143,24 @@ class AsrModel:
 
     BUCKET = 16000      # cached buffer sets are sized in whole seconds of audio
 
-    def _decode_policy(self, ctx, B, pipelined):
+    def _decode_policy(self, ctx, B, pipelined, lanes=1):
         """Pick the decode kernel family for a call (all are bit-identical; tests/test_gpu_fullsize.py).  Measured on
-        MI355X (profiles/r02o_pipeline_decode_variants_ab.txt, r02q_small_batch_decode_ab.txt):
-          * what a step costs next to the encoder GEMMs of the pipeline is the number of launches and of workgroups that
-            must find free CUs, not the length of each kernel on an idle chip: at B = 256 the wide-tile kernels with
-            the exact joint (5 launches, 40-workgroup LSTM) give 65.5 ms per step, screened / narrow 66.5-68.5;
+        MI355X (profiles/r02o_pipeline_decode_variants_ab.txt, r02q_small_batch_decode_ab.txt, r02zz_decode_family_ab.txt):
+          * ONE decode stream next to the encoder is on the critical path: what a step costs there is the number of
+            launches and of workgroups that must find free CUs, not the length of each kernel on an idle chip: at
+            B = 256 the wide-tile kernels with the exact joint (5 launches, 40-workgroup LSTM) give 65.5 ms per step,
+            screened / narrow 66.5-68.5;
+          * TWO decode lanes have an encoder period of slack each: then the family with the least exact-f32 work wins,
+            because its CU time is what the GEMMs lose (screened joint + narrow tiles 59.0 ms, wide / exact 60.0);
           * small batches are decode-bound: narrow tiles + exact joint win (B = 32: 19.6 ms vs 25.8 wide, 22.6 screened);
           * big batches on an otherwise idle chip (sequential schedule): screened joint + narrow tiles (79.9 vs 84.7 ms).
         $RS_DECODE_SCREEN / $RS_DECODE_NARROW override (A/B runs)."""
         if "RS_DECODE_SCREEN" in os.environ or "RS_DECODE_NARROW" in os.environ:
             return
         big = B >= 128
-        ctx.set_option("decode_narrow", 0 if (pipelined and big) else 1)
-        ctx.set_option("decode_screen", 1 if (big and not pipelined) else 0)
+        critical = pipelined and lanes == 1
+        ctx.set_option("decode_narrow", 0 if (critical and big) else 1)
+        ctx.set_option("decode_screen", 1 if (big and not critical) else 0)
 
     def buffers(self, B, l_max) -> _Buffers:
         """a cached buffer set for B utterances of up to l_max samples.  Lengths are bucketed to whole seconds and a
@@ -281,14 +285,14 @@ class AsrModel:
                 self._streams_prio = dec_prio
                 self._dec2_stream = None
             enc_stream, dec_stream = self._streams
-            self._decode_policy(self._ctx_dec, bufs[0].B, pipelined=True)
+            self._decode_policy(self._ctx_dec, bufs[0].B, pipelined=True, lanes=dec_streams)
             dec_lanes = [(self._ctx_dec, dec_stream)]
             if dec_streams == 2:
                 if self._ctx_dec2 is None:
                     self._ctx_dec2 = self.ctx.clone()
                 if self._dec2_stream is None:
                     self._dec2_stream = torch.cuda.Stream(device=self.device, priority=dec_prio)
-                self._decode_policy(self._ctx_dec2, bufs[0].B, pipelined=True)
+                self._decode_policy(self._ctx_dec2, bufs[0].B, pipelined=True, lanes=dec_streams)
                 dec_lanes.append((self._ctx_dec2, self._dec2_stream))
             enc_stream.wait_stream(torch.cuda.current_stream())
             queues = [queue.Queue() for _ in dec_lanes]
