@@ -146,8 +146,8 @@ def main():
     ap.add_argument("--decoding", default="greedy_batch", choices=["greedy_batch", "alsd"],
                     help="decode strategy: the headline metric is greedy; alsd = the device beam search (extra line for profiles/)")
     ap.add_argument("--beam", type=int, default=4, help="beam size of --decoding alsd")
-    ap.add_argument("--buffer-sets", type=int, default=int(os.environ.get("RS_BUFFER_SETS", "2")),
-                    help="resident batches the pipeline rotates through (2 = encoder i+1 waits for decode i-1)")
+    ap.add_argument("--buffer-sets", type=int, default=int(os.environ.get("RS_BUFFER_SETS", "4")),
+                    help="resident batches the pipeline rotates through (at least 1 + decode streams)")
     ap.add_argument("--dec-streams", type=int, default=int(os.environ.get("RS_DEC_STREAMS", "2")),
                     help="decode consecutive batches on this many streams (2 needs three resident batches)")
     ap.add_argument("--no-pipeline", action="store_true",
