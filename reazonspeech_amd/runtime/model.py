@@ -241,7 +241,7 @@ class AsrModel:
                         buf.enc_lens[lo:hi], ws, s)
 
     def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None, split_encoder: bool = None,
-                      from_host: bool = False, enc_streams: int = 1, dec_streams: int = 1):
+                      from_host: bool = False, enc_streams: int = 1, dec_streams: int = 1, before_encoder=None):
         """Process `steps` batches (bufs[i % len(bufs)], inputs already in HBM) as a two-stage
         pipeline: the throughput-bound front-end + encoder of batch i+1 runs on one HIP stream while
         the latency-bound greedy decode of batch i (a dependency chain of small launches that leaves
@@ -254,7 +254,8 @@ class AsrModel:
         streams (each with its full-size launches) so that one batch's HBM-bound kernels can overlap the
         other's GEMMs; it needs four buffer sets.  `dec_streams=2` decodes consecutive batches on two streams
         (two worker threads): next to the encoder a decode launch spends most of its time waiting for compute
-        units to free up, so two interleaved chains nearly double the decode rate; needs three buffer sets."""
+        units to free up, so two interleaved chains nearly double the decode rate; needs three buffer sets.
+        `before_encoder(i)` is called on the caller's thread right before batch i's encoder is enqueued."""
         assert len(bufs) >= 2, "the pipeline needs two buffer sets"
         assert dec_streams in (1, 2) and (dec_streams == 1 or len(bufs) >= 3), "two decode streams need three buffer sets"
         assert enc_streams in (1, 2) and (enc_streams == 1 or len(bufs) >= 4), "two encoder streams need four buffer sets"
@@ -346,6 +347,8 @@ class AsrModel:
                 buf = bufs[i % nb]
                 if i >= nb:
                     done[i - nb].wait()           # this buffer set's previous decode must be finished
+                if before_encoder is not None:
+                    before_encoder(i)
                 if from_host:
                     with torch.cuda.stream(self._enc2_stream if (enc_streams == 2 and (i & 1)) else enc_stream):
                         buf.audio.copy_(buf.h_audio, non_blocking=True)
