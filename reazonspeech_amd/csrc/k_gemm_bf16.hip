@@ -3,12 +3,15 @@
 //   out[M][N] = epilogue( A[M][K] . W[N][K]^T )        A, W row-major bf16 (K contiguous)
 //
 // These kernels carry every dense contraction of the encoder (SURVEY.md §8a rows S2-S4, L2, L3, L6
-// pw1/pw2, D1): 96.8 % of the path's FLOPs.  Two families share the staging, tile-order and epilogue ideas:
+// pw1/pw2, D1): 96.8 % of the path's FLOPs.  Families, newest first (all share the staging, tile-order and epilogue
+// ideas; the older ones stay selectable for A/B runs, DESIGN.md §4 "A/B knobs"):
 //
-//   gemm_mf16_kernel  (default for the big shapes)  v_mfma_f32_16x16x32_bf16, 256x256 / 192x256 tiles, ring of
-//       four 32-deep granules, ping-pong wave groups.  It exists because the chip is package-power limited in
-//       the sustained regime and this MFMA shape costs fewer joules per FLOP.
-//   gemm_bf16_kernel  v_mfma_f32_32x32x16_bf16; template parameters BM x BN tile, WM x WN waves, BK-deep K steps
+//   gemm_smf16_kernel (default for the big shapes)  v_mfma_f32_16x16x32_bf16, 256x256 / 192x256 tiles, 64-deep K
+//       tiles fetched as whole cache lines, LDS = five 32-KiB operand-part slots ("split ring": B(t+1) issued first,
+//       A(t+2) one K tile further ahead), ping-pong wave groups, LDS-staged epilogue incl. the conv module's GLU.
+//   gemm_lmf16_kernel  its predecessor: ring of two whole K tiles, optionally persistent (RS_GEMM_RING=0).
+//   gemm_mf16_kernel   16x16x32 MFMA over a ring of four 32-deep granules (round 1; RS_GEMM_PERSISTENT=0).
+//   gemm_bf16_kernel   v_mfma_f32_32x32x16_bf16; template parameters BM x BN tile, WM x WN waves, BK-deep K steps
 //       through an NST-stage LDS ring; serves the small / narrow problems (128x128 tiles) and stays selectable
 //       for the big ones (RS_GEMM_BIG=1).
 //
@@ -21,9 +24,10 @@
 //     again on the read.
 //   * blockIdx -> tile mapping is XCD-aware (each of the 8 XCDs, private L2, walks a contiguous run of tiles)
 //     and grouped (group_m A row panels x a few weight tiles run together on an XCD).
-//   * epilogue in registers: the weight fragment is the MFMA A operand, so each lane ends up with consecutive
-//     output columns of one row: +bias, ReLU/SiLU, *alpha, +residual (f32, prefetched), per-utterance row
-//     mask, 16-byte f32 / 8-16-byte bf16 stores, no LDS round trip.
+//   * epilogue: the weight fragment is the MFMA A operand, so each lane ends up with consecutive output columns
+//     of one row: +bias, ReLU / SiLU / GLU, *alpha, +residual (f32, prefetched), per-utterance row mask.  The
+//     whole-line kernels pass the result through a per-wave LDS scratch so that every global store is a full
+//     128 / 256-byte row segment; the older families store from registers.
 #include <stdlib.h>
 
 #include <atomic>
