@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: variants 1102 / 1112 / 1100 / 1110 and RS_GEMM_L2PF (L2 operand prefetch) were rejected by this run and removed
+# from the tree afterwards; they exist in the history at e1dfbef (records: profiles/r02v_*).
 # round-2 (second session) experiment pack 2: L2 prefetch of the long-K GEMM operands, GLU fused into the pw1 GEMM
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: variants 1300 / 1302 and RS_GEMM_RING=3/4 (gemm_tmf16_kernel, one 64-deep phase per K tile) were rejected by this
+# run and removed from the tree afterwards; they exist in the history at e1dfbef (records: profiles/r02y_*).
 # round-2 (second session) experiment pack 5: one 64-deep phase per K tile on the split ring (gemm_tmf16_kernel)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
