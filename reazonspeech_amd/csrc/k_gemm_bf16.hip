@@ -1056,7 +1056,14 @@ __global__ __launch_bounds__(512, 2) void gemm_lmf16_kernel(GemmParams p) {
 // K tile t + 1 is a counted vmcnt(LA): the A(t+2) pieces just issued may stay in flight.
 // The epilogue scratch aliases slot 0 (the ring is dead by then: both wave groups are past their last fragment
 // reads when group 0 passes its extra barrier).
-template <int BM, int OUT, bool MASK, int NM0, int EPF = 1, bool TRACE = false>
+//
+// PP = false (EXPERIMENTAL, never validated on hardware: written after the round's GPU minutes were spent; opt-in with
+// RS_GEMM_RING=5, tests behind RS_TEST_EXPERIMENTAL=1): no ping-pong — all eight waves run the same schedule and meet at
+// ONE barrier per K tile (RAW for K tile t+1, WAR for the slots of K tile t) instead of four; the overlap of one
+// wave's fragment reads with the other's MFMAs is left to the two waves that share a SIMD.  The timeline shows ~165
+// cycles of barrier / wait overhead per 512-cycle MFMA interval; this is the cheapest way to find out how much of it
+// the explicit ping-pong buys back.
+template <int BM, int OUT, bool MASK, int NM0, int EPF = 1, bool TRACE = false, bool PP = true>
 __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     constexpr int BN = 256, WN = 4, NWAVES = 8;
     constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -1128,7 +1135,7 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     for (int j = 0; j < LA; ++j) dma_a(j, 1, 2);
     wait_vmcnt<LA>();
     __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind from here on
+    if (PP && wm == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind from here on
     if constexpr (TRACE) tr_t1 = __builtin_readcyclecounter();
 
     f32x4_t acc[MI][NI];
@@ -1167,13 +1174,13 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
 #pragma unroll
                 for (int qq = 0; qq < (NM0 < NP ? NM0 : NP); ++qq) issue(qq);
             }
-            if (ks == 1 && has_b && wm == 1) {                    // group 1: one barrier behind, waits in its memory half
+            if (PP && ks == 1 && has_b && wm == 1) {              // group 1: one barrier behind, waits in its memory half
                 if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_next(); tr_stall += __builtin_readcyclecounter() - a; }
                 else wait_next();
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+            if constexpr (PP) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             constexpr int REST = NP - (NM0 < NP ? NM0 : NP);      // pieces issued between the MFMAs of phase (t, 0)
@@ -1188,18 +1195,18 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (ks == 1 && has_b && wm == 0) {                    // group 0: before the barrier its reads follow
+            if (ks == 1 && has_b && (wm == 0 || !PP)) {           // group 0 (without ping-pong: every wave): before the barrier its reads follow
                 if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_next(); tr_stall += __builtin_readcyclecounter() - a; }
                 else wait_next();
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+            if (PP || ks == 1) __builtin_amdgcn_s_barrier();      // without ping-pong: the one barrier of the K tile
             __builtin_amdgcn_sched_barrier(0);
         }
         sa = wrap(sa + 2);
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier: nobody reads the ring any more
+    if (PP && wm == 0) __builtin_amdgcn_s_barrier();             // pairs with group 1's extra barrier: nobody reads the ring any more
     {
         int em0 = __builtin_amdgcn_readfirstlane(m0), en0 = __builtin_amdgcn_readfirstlane(n0);
         asm volatile("" : "+s"(em0), "+s"(en0));
@@ -1218,7 +1225,7 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     }
 }
 
-template <int BM, int NM0, int EPF = 1>
+template <int BM, int NM0, int EPF = 1, bool PP = true>
 int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     constexpr int LDS = 5 * 32768;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -1232,8 +1239,8 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     const bool mask = p.flags & RS_GEMM_ROWMASK;
 #define RS_SMF(O, MK, TR)                                                                                         \
     do {                                                                                                          \
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, MK, NM0, EPF, TR>, LDS); rc != RS_OK) return rc; \
-        hipLaunchKernelGGL((gemm_smf16_kernel<BM, O, MK, NM0, EPF, TR>), dim3(nwg), dim3(512), LDS, s, p);       \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, MK, NM0, EPF, TR, PP>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_smf16_kernel<BM, O, MK, NM0, EPF, TR, PP>), dim3(nwg), dim3(512), LDS, s, p);   \
     } while (0)
     if (p.trace) {
         if (out == 2 && !mask) RS_SMF(2, false, true);
@@ -1378,7 +1385,7 @@ void gemm_knobs_from_env() {
         env("RS_GEMM_RESERVE_CUS", g_reserve);    // CUs the persistent grid leaves to other streams (contexts may override)
         env("RS_GEMM_BIG", g_big);                // big-tile kernel family (DESIGN.md A/B knob table)
         env("RS_GEMM_RES_PREFETCH", g_res_prefetch);   // 3 (default) / 6 / 1 residual chunks in flight in the f32 epilogue
-        env("RS_GEMM_RING", g_ring);              // 2 (default) / 1: split-ring kernel (gemm_smf16_kernel); 0: gemm_lmf16_kernel
+        env("RS_GEMM_RING", g_ring);              // 2 (default) / 1: split-ring kernel (gemm_smf16_kernel); 0: gemm_lmf16_kernel; 5: experimental (no ping-pong)
     });
 }
 
@@ -1440,14 +1447,15 @@ static int gemm_pick_variant(const rs_gemm_args& a) {
     // split-ring kernel (RS_GEMM_RING: 1 = NM0 5, 2 = NM0 4)
     if (g_variant == 0 && g_ring.load() > 0 && v >= 1000) {
         const int k = v % 1000;
-        if (k == 60) v = g_ring.load() == 1 ? 1200 : 1210;
-        else if (k == 62 || k == 82 || k == 92) v = g_ring.load() == 1 ? 1202 : 1212;
+        const int r = g_ring.load();       // 5: the experimental no-ping-pong build
+        if (k == 60) v = r == 1 ? 1200 : (r == 5 ? 1220 : 1210);
+        else if (k == 62 || k == 82 || k == 92) v = r == 1 ? 1202 : (r == 5 ? 1222 : 1212);
     }
     return v;
 }
 
 // the GLU epilogue (RS_GEMM_GLU) exists in the whole-line kernel only: 256- / 192-row tiles of 64-column wave tiles
-static bool gemm_variant_has_glu(int v) { const int k = v % 1000; return k == 50 || k == 52 || k == 60 || k == 62 || k == 70 || k == 72 || k == 82 || k == 92 || k == 200 || k == 202 || k == 210 || k == 212; }
+static bool gemm_variant_has_glu(int v) { const int k = v % 1000; return k == 50 || k == 52 || k == 60 || k == 62 || k == 70 || k == 72 || k == 82 || k == 92 || k == 200 || k == 202 || k == 210 || k == 212 || k == 220 || k == 222; }
 
 bool rs_gemm_has_glu(int M, int N, int K) {
     rs_gemm_args a{};
@@ -1519,6 +1527,8 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         case 202: rc = launch_smf16<192, 5, 3>(ctx, p, s); break;
         case 210: rc = launch_smf16<256, 4>(ctx, p, s); break;      // only the B pieces beside the fragment reads
         case 212: rc = launch_smf16<192, 4, 3>(ctx, p, s); break;
+        case 220: rc = launch_smf16<256, 4, 1, false>(ctx, p, s); break;   // EXPERIMENTAL: no ping-pong, one barrier per K tile
+        case 222: rc = launch_smf16<192, 4, 3, false>(ctx, p, s); break;
         case 70: rc = launch_lmf16<256, 3>(ctx, p, s, pgrid); break;
         case 72: rc = launch_lmf16<192, 3>(ctx, p, s, pgrid); break;
         case 1: rc = launch_variant<128, 128, 64, 2, 2, 2>(ctx, p, s); break;   // small problems

@@ -18,6 +18,11 @@ from oracle import model as om
 
 pytestmark = pytest.mark.gpu
 
+# kernel builds that were written after a round's GPU minutes were spent and have never run on hardware are kept out
+# of the default suite: RS_TEST_EXPERIMENTAL=1 adds them to the GEMM variant tests (DESIGN.md §8 "Next")
+import os
+EXPERIMENTAL_GEMM = [1220, 1222] if os.environ.get("RS_TEST_EXPERIMENTAL") == "1" else []
+
 
 @pytest.fixture(scope="module")
 def ctx(gpu_device):
@@ -107,7 +112,7 @@ def test_gemm_big_tiles(ctx, gpu_device, N, K, residual, family):
     assert (out_full[M:].float() == 7.0).all(), "rows past M were written"
 
 
-@pytest.mark.parametrize("variant", [1062, 1082, 1092, 1060, 1200, 1202, 1210, 1212])
+@pytest.mark.parametrize("variant", [1062, 1082, 1092, 1060, 1200, 1202, 1210, 1212] + EXPERIMENTAL_GEMM)
 def test_gemm_prefetch_variants(ctx, gpu_device, variant):
     """12xx: the split-ring kernel (five 32-KiB operand-part slots, B(t+1) issued first, A(t+2) a K tile further ahead,
     epilogue scratch aliasing the ring; the default); 10xx: its two-K-tile-ring predecessor with the residual chunks of
@@ -148,7 +153,7 @@ def test_gemm_prefetch_variants(ctx, gpu_device, variant):
     assert (out_full[M:].float() == 7.0).all(), "rows past M were written"
 
 
-@pytest.mark.parametrize("variant", [1210, 1212])
+@pytest.mark.parametrize("variant", [1210, 1212] + EXPERIMENTAL_GEMM)
 @pytest.mark.parametrize("M,N,K", [(4416, 512, 128), (5000, 256, 192), (70, 1024, 320), (2049, 768, 1024)])
 def test_gemm_split_ring_short_k(ctx, gpu_device, M, N, K, variant):
     """the split-ring kernel at the edges of its schedule: two K tiles (only B(1) is ever issued in the loop), three
