@@ -397,3 +397,31 @@ def test_read_nemo_like_archive(tmp_path):
     _nemo_like_archive(path, sd, NEMO_YAML % dict(fill, strategy="maes"), spm_model, gz=False)
     with pytest.warns(RuntimeWarning, match="greedily"):
         assert W.read_nemo(path)[0].decoding == "greedy_batch"
+
+
+def test_decode_policy_table(monkeypatch):
+    """which decode kernel family a call gets (all are bit-identical; the choice is measured):
+    one decode stream next to the encoder -> wide tiles + exact joint; two lanes (slack) or an idle chip -> screened
+    joint + narrow tiles; small batches -> narrow tiles + exact joint; the environment overrides"""
+    from reazonspeech_amd.runtime.model import AsrModel
+
+    class Ctx:
+        def __init__(self):
+            self.opts = {}
+
+        def set_option(self, k, v):
+            self.opts[k] = v
+
+    def pick(B, pipelined, lanes=1):
+        c = Ctx()
+        AsrModel._decode_policy(None, c, B, pipelined, lanes)
+        return c.opts
+
+    monkeypatch.delenv("RS_DECODE_SCREEN", raising=False)
+    monkeypatch.delenv("RS_DECODE_NARROW", raising=False)
+    assert pick(256, True, 1) == {"decode_narrow": 0, "decode_screen": 0}
+    assert pick(256, True, 2) == {"decode_narrow": 1, "decode_screen": 1}
+    assert pick(256, False) == {"decode_narrow": 1, "decode_screen": 1}
+    assert pick(32, True, 1) == pick(32, True, 2) == pick(32, False) == {"decode_narrow": 1, "decode_screen": 0}
+    monkeypatch.setenv("RS_DECODE_SCREEN", "0")
+    assert pick(256, True, 2) == {}
