@@ -1308,7 +1308,7 @@ int launch_lmf16(rs_ctx* ctx, GemmParams& p, hipStream_t s, int grid_cap) {
 // Process-wide A/B knobs (debug / tuning only; the defaults are the measured winners and nothing in the product
 // path writes them).  Atomics initialised once from the environment, so concurrent first launches from the encoder
 // thread and the decode worker are safe; they are deliberately not per-context: they select code paths, not state.
-extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve, g_res_prefetch, g_ring;
+extern std::atomic<int> g_skew, g_persistent, g_group_m, g_variant, g_big, g_reserve, g_res_prefetch, g_ring, g_192_pct;
 extern std::atomic<long long*> g_trace;
 void gemm_knobs_from_env();
 
@@ -1371,6 +1371,7 @@ std::atomic<int> g_reserve{0};   // CUs the persistent kernel leaves free when a
 // residual chunks requested ahead by the f32 epilogue: 3 (whole path 64.2 vs 64.5 ms/step with 1 and 65.0 with all 6:
 // profiles/r02u_bench_ab.txt; in isolation 6 is the fastest, in the pipeline its 24-load burst per wave is not)
 std::atomic<int> g_res_prefetch{3};
+std::atomic<int> g_192_pct{88};   // the 192-row tile is chosen when its rounds x height is below this percentage of the 256-row tile's
 // split-ring kernel for the big shapes: 2 (default) = B pieces beside the fragment reads, A pieces between the MFMAs;
 // 1 = five pieces beside the reads; 0 = the two-K-tile ring (gemm_lmf16_kernel).  Same box, whole path:
 // 64.0 -> 61.7 ms/step, ffn_down 314 -> 276 us (profiles/r02x_*)
@@ -1385,6 +1386,7 @@ void gemm_knobs_from_env() {
         env("RS_GEMM_RESERVE_CUS", g_reserve);    // CUs the persistent grid leaves to other streams (contexts may override)
         env("RS_GEMM_BIG", g_big);                // big-tile kernel family (DESIGN.md A/B knob table)
         env("RS_GEMM_RES_PREFETCH", g_res_prefetch);   // 3 (default) / 6 / 1 residual chunks in flight in the f32 epilogue
+        env("RS_GEMM_192_PCT", g_192_pct);        // tile-height rule (88)
         env("RS_GEMM_RING", g_ring);              // 2 (default) / 1: split-ring kernel (gemm_smf16_kernel); 0: gemm_lmf16_kernel; 5: experimental (no ping-pong)
     });
 }
@@ -1421,7 +1423,9 @@ static int gemm_pick_variant(const rs_gemm_args& a) {
             // a quarter (N = 1024: 3 rounds of 256 rows -> 3 of 192), not for 7 -> 6.75 or 5 -> 4.5
             // (profiles/r01q_kernel_stats.txt: qkv 245 -> 273 us, pw1 177 -> 187 us with it)
             const long c192 = ((t192 + CUS - 1) / CUS) * 192, c256 = ((t256 + CUS - 1) / CUS) * 256;
-            v = c192 * 100 < c256 * 88 ? 10 : 2;
+            // (threshold re-tunable: RS_GEMM_192_PCT; with the split ring the 192-row tile lost most of its per-row
+            // handicap — 1.2 vs 1.4 us per K tile — so the rule of round 1 may be too strict: DESIGN.md §8)
+            v = c192 * 100 < c256 * g_192_pct.load() ? 10 : 2;
         }
         const int big = g_big;    // A/B knob for whole-pipeline runs: remap the 256x256 choice
         // big == 0: the 16x16x32 kernels (whole path 71.7 -> 69.5 ms/step with them: profiles/r01w_*);
