@@ -131,6 +131,28 @@ def parity_vs_cpu_leg(model, cfg, sd, audio, lens, outputs):
             "decode_bit_exact_given_same_joint_enc": bool(bit_exact)}
 
 
+def decode_family_check(model, buf):
+    """The pipeline's decode kernel family at this batch size (screened joint + narrow tiles with two decode lanes)
+    against the exact-joint / wide-tile family on the SAME joint-encoder tensor of a whole benchmark batch: the ids and
+    emission frames must be identical (the C oracle pins the families at B <= 37 in tests/; this is the same property
+    at the benchmark batch, where the oracle would take minutes)."""
+    ctx = model.ctx
+    stream = torch.cuda.current_stream().cuda_stream
+    got = []
+    try:
+        for screen, narrow in ((1, 1), (0, 0)):
+            ctx.set_option("decode_screen", screen)
+            ctx.set_option("decode_narrow", narrow)
+            model.decode(ctx, buf, buf.ws, stream)
+            torch.cuda.synchronize()
+            r = model.collect(buf)
+            got.append((r.ids, r.frames))
+    finally:
+        model._decode_policy(ctx, buf.B, pipelined=False)
+    return {"batch": buf.B, "families": "screened joint + narrow tiles vs exact joint + wide tiles",
+            "ids_and_frames_identical": got[0] == got[1], "tokens": sum(len(x) for x in got[0][0])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,6 +346,13 @@ def main():
                 out["parity"] = parity_vs_cpu_leg(model, cfg, sd, audio0, lens0, cpu_outputs)
             except Exception as e:               # the bench line must still be printed
                 out["parity"] = {"error": repr(e)}
+        if world == 1 and not alsd and not args.tiny:
+            if not isinstance(out.get("parity"), dict):
+                out["parity"] = {}
+            try:
+                out["parity"]["decode_families_whole_batch"] = decode_family_check(model, bufs[0])
+            except Exception as e:               # the bench line must still be printed
+                out["parity"]["decode_families_whole_batch"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     rdist.shutdown()
 
