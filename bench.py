@@ -7,14 +7,20 @@
 
 One "step" = one pass of the whole hot path (log-mel front-end -> 24-layer FastConformer encoder
 -> joint projection -> batched greedy RNN-T decode) over one batch of 256 synthetic 10 s
-utterances per GPU, inputs already resident in HBM when the timed region starts (the bench contract's
-definition of `value`; the host-to-host rate — pinned float32 in, token ids out, H2D and D2H inside the
-timed region, SURVEY.md §8d — is reported next to it as `value_pcie_inclusive`).  Weak scaling: every rank
-processes its own 256 utterances (BASELINE.json configs[2]: 2048 = 8 x 256); with N > 1 every step ends
-with the one collective of the path, an RCCL all_gather of that step's hypotheses, issued from the decode
-worker as soon as the batch is decoded.  Rank 0 prints ONE JSON line, which also carries `roofline`
-(dominant kernel class, HIP events on the launch stream), `cpu_baseline` (the CPU oracle on a bounded
-sample) and `parity` (the HIP path against that CPU leg's outputs on the same utterances).
+utterances per GPU.  `value` follows the bench contract: inputs already resident in HBM when the timed region
+starts.  Next to it the same JSON line carries what SURVEY.md §8(d) defines — the host-to-host rate through the
+PUBLIC boundary: `value_host_to_ids` (AsrModel.transcribe_waveforms: host float32 lists -> token ids, H2D / D2H,
+sorting, staging and the pipeline fill and drain inside the clock) and `value_transcribe_batch` (the same through
+`transcribe_batch`, text post-processing included) — and `configs`: BASELINE configs[1] (B = 32), the ragged set of
+§8(d) (lengths U(2 s, 10 s), seed 1235), the reference checkpoint's real decode strategy (ALSD beam 4) and the
+limited-context attention variant the shipped model is believed to use ([128, 128] + 1 global token).
+Weak scaling: every rank processes its own 256 utterances (BASELINE.json configs[2]: 2048 = 8 x 256); with N > 1
+every step ends with the one collective of the path, an RCCL all_gather of that step's hypotheses, issued from the
+decode worker as soon as the batch is decoded.  Rank 0 prints ONE JSON line, which also carries `roofline`
+(dominant kernel class, HIP events on the launch stream), `cpu_baseline` (the CPU oracle on a bounded sample) and
+`parity`: rows 0..7 of the TIMED configuration's B = 256 batch (the same audio as the CPU leg) against the fp32 oracle,
+bit-compared with the same utterances run alone, with every greedy-id difference audited against the oracle's logit
+margins (oracle/audit.py).
 """
 import argparse
 import json
@@ -95,39 +101,60 @@ def edit_distance(a, b):
     return prev[-1]
 
 
-def parity_vs_cpu_leg(model, cfg, sd, audio, lens, outputs):
-    """The CPU leg's outputs are the checker of the same utterances through the HIP path (one batch, padding folded
-    into the kernel): encoder output and joint projection error against the fp32 oracle, greedy ids against the
-    oracle's end-to-end ids (bf16 encoder noise can flip near-ties, so this is an agreement rate), and the decode
-    kernels alone — C greedy on the HIP joint projection — which must agree bit for bit."""
-    from oracle import greedy as og
+def parity_vs_cpu_leg(model, cfg, sd, buf256, audio, lens, outputs):
+    """The CPU leg's outputs are the checker of the same utterances through the HIP path AS THE BENCHMARK RUNS THEM:
+    rows 0 .. k-1 of the resident B = 256 batch (`buf256` holds the same audio as the CPU leg), i.e. the tile heights
+    and launch geometry of the timed region.  Reported: encoder output / joint projection error against the fp32
+    oracle; whether the same utterances run ALONE (B = 1 each) give the same bits as inside the batch; greedy ids
+    against the oracle's end-to-end ids with a flip audit (every difference must start at a decision whose oracle
+    margin is below the Lipschitz bound of the measured encoder difference: oracle/audit.py); and the decode kernels
+    alone — C greedy on the HIP joint projection — which must agree bit for bit."""
+    from oracle import greedy as og, audit
     k = len(outputs)
     if k == 0:
         return None
-    buf = model.stage([audio[b, :int(lens[b])] for b in range(k)])
-    enc = torch.zeros((k, buf.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
-    model.run_device(buf, want_enc=enc)
+    B = buf256.B
+    enc = torch.zeros((B, buf256.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
+    model.run_device(buf256, want_enc=enc)
     torch.cuda.synchronize()
-    got = model.collect(buf)
-    enc, f = enc.cpu(), buf.joint_enc.cpu()
+    got = model.collect(buf256)
+    enc_rows, f_rows = enc[:k].cpu(), buf256.joint_enc[:k].cpu()
+    del enc
+    # the same utterances alone: one launch chain each, tiny-M tiles
+    alone_bits = True
+    for b in range(k):
+        one = model.stage([audio[b, :int(lens[b])]])
+        e1 = torch.zeros((1, one.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
+        model.run_device(one, want_enc=e1)
+        torch.cuda.synchronize()
+        r1 = model.collect(one)
+        n = r1.enc_lens[0]
+        alone_bits &= bool(torch.equal(e1[0, :n].cpu(), enc_rows[b, :n]) and torch.equal(one.joint_enc[0, :n].cpu(), f_rows[b, :n])
+                           and r1.ids[0] == got.ids[b] and r1.frames[0] == got.frames[b])
     e_max = e_sum = j_max = j_sum = cnt_e = cnt_j = 0.0
     exact = dist = ref_tokens = 0
+    audits, equal = [], []
     for b, (f_ref, enc_ref, ids_ref, frames_ref) in enumerate(outputs):
         n = f_ref.shape[0]
         assert got.enc_lens[b] == n, (got.enc_lens[b], n)
-        de, dj = (enc[b, :n] - enc_ref).abs(), (f[b, :n] - f_ref).abs()
+        de, dj = (enc_rows[b, :n] - enc_ref).abs(), (f_rows[b, :n] - f_ref).abs()
         e_max, j_max = max(e_max, de.max().item()), max(j_max, dj.max().item())
         e_sum, j_sum, cnt_e, cnt_j = e_sum + de.sum().item(), j_sum + dj.sum().item(), cnt_e + de.numel(), cnt_j + dj.numel()
-        exact += int(got.ids[b] == ids_ref)
+        equal.append(got.ids[b] == ids_ref)
+        exact += int(equal[-1])
         dist += edit_distance(got.ids[b], ids_ref)
         ref_tokens += len(ids_ref)
-    same = og.rnnt_greedy(cfg, sd, f.numpy(), buf.enc_lens.cpu().numpy())
+        audits.append(audit.flip_audit(cfg, sd, f_ref.numpy(), f_rows[b, :n].numpy(), n, got.ids[b], got.frames[b]))
+    same = og.rnnt_greedy(cfg, sd, f_rows.numpy(), np.asarray(got.enc_lens[:k], np.int32))
     bit_exact = all(got.ids[b] == same[b][0] and got.frames[b] == same[b][1] for b in range(k))
-    return {"utterances": k, "checker": "fp32 CPU oracle (cpu_baseline leg), same audio",
+    return {"utterances": k, "rows": f"0..{k - 1} of the resident B = {B} batch (the timed configuration's launch geometry)",
+            "checker": "fp32 CPU oracle (cpu_baseline leg), same audio",
             "encoder_max_err": round(e_max, 4), "encoder_mean_err": round(e_sum / cnt_e, 5),
             "joint_enc_max_err": round(j_max, 4), "joint_enc_mean_err": round(j_sum / cnt_j, 5),
+            "alone_equals_inside_batch_bits": alone_bits,
             "greedy_ids_exact_match": f"{exact}/{k}",
             "token_agreement": round(1.0 - dist / max(ref_tokens, 1), 4), "reference_tokens": ref_tokens,
+            "flip_audit": audit.summarize(audits, equal),
             "decode_bit_exact_given_same_joint_enc": bool(bit_exact)}
 
 
@@ -153,6 +180,104 @@ def decode_family_check(model, buf):
             "ids_and_frames_identical": got[0] == got[1], "tokens": sum(len(x) for x in got[0][0])}
 
 
+def timed_pipeline(model, bufs, steps, warmup, dec_streams):
+    """RTFx-style short run of resident batches through the pipeline -> seconds for `steps` steps"""
+    model.run_pipelined(bufs, warmup, dec_streams=dec_streams)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.run_pipelined(bufs, steps, dec_streams=dec_streams)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def resident_sets(model, batch, seconds, n_sets, seed0):
+    bufs, lens_all, host = [], [], []
+    for k in range(n_sets):
+        audio, lens = synthetic_batch(batch, seconds, seed=seed0 + 1000 * k)
+        b = model.stage([audio[i, :lens[i]] for i in range(batch)], buf=model.new_buffers(batch, int(seconds * 16000)))
+        torch.cuda.synchronize()
+        bufs.append(b)
+        lens_all.append(lens)
+        host.append((audio, lens))
+    return bufs, lens_all, host
+
+
+def extra_configs(model, cfg, sd, args, host_sets):
+    """The other configurations the survey names, each a short run inside this one process (they are reported in the
+    `configs` object, never as `value`)."""
+    out = {}
+    n_sets = len(host_sets)
+    # BASELINE configs[1]: batch 32 x 10 s on one GPU
+    try:
+        bufs32, lens32, _ = resident_sets(model, 32, args.seconds, n_sets, 4321)
+        dt = timed_pipeline(model, bufs32, 24, 4, args.dec_streams)
+        out["b32"] = {"workload": "32 x 10 s per step (BASELINE configs[1]), HBM-resident, pipelined",
+                      "value": round(sum(float(lens32[i % n_sets].sum()) for i in range(24)) / 16000.0 / dt, 1),
+                      "ms_per_step": round(dt / 24 * 1e3, 3)}
+        del bufs32
+    except Exception as e:
+        out["b32"] = {"error": repr(e)}
+    # SURVEY §8(d) ragged set: lengths U(2 s, 10 s), seed 1235, through the host-to-host boundary (sorted, tight padding)
+    try:
+        n = 4 * args.batch
+        audio, lens = synthetic_batch(n, args.seconds, seed=1235, ragged=True, min_seconds=2.0)
+        waves = [audio[i, :lens[i]] for i in range(n)]
+        model.transcribe_waveforms(waves[:2 * args.batch], max_batch=args.batch)      # warm the pool / kernels
+        t0 = time.perf_counter()
+        res = model.transcribe_waveforms(waves, max_batch=args.batch)
+        dt = time.perf_counter() - t0
+        out["ragged_u2_10"] = {"workload": f"{n} utterances, lengths U(2 s, 10 s) seed 1235, host float32 -> token ids "
+                                           f"(length-sorted batches of {args.batch}, each padded to its own longest utterance)",
+                               "value": round(float(lens.sum()) / 16000.0 / dt, 1), "wall_ms": round(dt * 1e3, 1),
+                               "tokens": sum(len(x) for x in res.ids)}
+        del audio, waves
+    except Exception as e:
+        out["ragged_u2_10"] = {"error": repr(e)}
+    # the reference checkpoint's decode strategy (decode.py:29,38-41): ALSD, beam 4
+    for key, cfg2, what in (
+            ("alsd4", cfg.with_(decoding="alsd", beam_size=4), "ALSD beam-4 decode (max_target_len 2.0)"),
+            ("window_128_128_g1", cfg.with_(att_left=128, att_right=128, n_global=1),
+             "limited-context attention [128, 128] + 1 global token (SURVEY row L5), greedy decode")):
+        try:
+            m2 = AsrModel(cfg2, sd, SyntheticTokenizer(cfg2.vocab_size), device=str(model.device))
+            bufs2 = [m2.stage([a[i, :l[i]] for i in range(args.batch)], buf=m2.new_buffers(args.batch, int(args.seconds * 16000)))
+                     for a, l in host_sets]
+            torch.cuda.synchronize()
+            steps = 8
+            dt = timed_pipeline(m2, bufs2, steps, 3, args.dec_streams)
+            out[key] = {"workload": f"{args.batch} x {args.seconds:g} s per step, {what}, HBM-resident, pipelined",
+                        "value": round(sum(float(host_sets[i % n_sets][1].sum()) for i in range(steps)) / 16000.0 / dt, 1),
+                        "ms_per_step": round(dt / steps * 1e3, 3)}
+            if key.startswith("window"):
+                out[key]["parity"] = window_parity(m2, cfg2, sd, host_sets[0])
+            del bufs2, m2
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out[key] = {"error": repr(e)}
+    return out
+
+
+def window_parity(model, cfg, sd, host_set, k=2):
+    """limited-context attention at the benchmark geometry: k utterances of the resident batch against the fp32 oracle
+    run with the same attention predicate (oracle/model.py: attention_allowed)"""
+    from oracle import model as om
+    audio, lens = host_set
+    buf = model.stage([audio[b, :int(lens[b])] for b in range(k)])
+    enc = torch.zeros((k, buf.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
+    model.run_device(buf, want_enc=enc)
+    torch.cuda.synchronize()
+    e_max = e_sum = cnt = 0.0
+    for b in range(k):
+        wav = np.pad(audio[b, :int(lens[b])], 8000)
+        taps = {}
+        f, el = om.forward_to_joint(cfg, sd, torch.from_numpy(wav)[None], torch.tensor([len(wav)]), "fp32", taps)
+        n = int(el[0])
+        d = (enc[b, :n].cpu() - taps["enc"][0, :n]).abs()
+        e_max, e_sum, cnt = max(e_max, d.max().item()), e_sum + d.sum().item(), cnt + d.numel()
+    return {"utterances": k, "checker": "fp32 CPU oracle with the same attention predicate",
+            "encoder_max_err": round(e_max, 4), "encoder_mean_err": round(e_sum / cnt, 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,11 +288,13 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="debug: 2-layer toy config (NOT a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--enc-streams", type=int, default=int(os.environ.get("RS_ENC_STREAMS", "1")),
-                    help="experimental: encoders of consecutive batches on two streams (four resident batches)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` object (B = 32, ragged, ALSD, windowed)")
+    ap.add_argument("--api-batches", type=int, default=8,
+                    help="batches of --batch utterances pushed through the public host-to-host boundary (8 x 256 = BASELINE configs[2]'s 2048)")
     ap.add_argument("--decoding", default="greedy_batch", choices=["greedy_batch", "alsd"],
                     help="decode strategy: the headline metric is greedy; alsd = the device beam search (extra line for profiles/)")
     ap.add_argument("--beam", type=int, default=4, help="beam size of --decoding alsd")
+    ap.add_argument("--att-context", default="", help="left,right,n_global: limited-context attention (extra line for profiles/)")
     ap.add_argument("--buffer-sets", type=int, default=int(os.environ.get("RS_BUFFER_SETS", "4")),
                     help="resident batches the pipeline rotates through (at least 1 + decode streams)")
     ap.add_argument("--dec-streams", type=int, default=int(os.environ.get("RS_DEC_STREAMS", "2")),
@@ -189,21 +316,17 @@ def main():
     alsd = args.decoding == "alsd"
     if alsd:
         cfg = cfg.with_(decoding="alsd", beam_size=args.beam)
+    if args.att_context:
+        left, right, n_glob = (int(x) for x in args.att_context.split(","))
+        cfg = cfg.with_(att_left=left, att_right=right, n_global=n_glob)
     t0 = time.time()
     sd = synthetic_state_dict(cfg, seed=0)
     model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device=f"cuda:{local_rank}")
-    # two resident batches (different utterances): the pipelined path alternates between them
-    bufs, lens_all = [], []
-    n_sets = 4 if args.enc_streams == 2 else max(2 + (args.dec_streams - 1), args.buffer_sets)
-    for k in range(n_sets):
-        audio, lens = synthetic_batch(args.batch, args.seconds, seed=1234 + 17 * rank + 1000 * k)
-        b = model.stage([audio[i, :lens[i]] for i in range(args.batch)],
-                        buf=model.new_buffers(args.batch, int(args.seconds * 16000)))
-        torch.cuda.synchronize()
-        bufs.append(b)
-        lens_all.append(lens)
+    # resident batches (different utterances): the pipelined path rotates through them
+    n_sets = max(2 + (args.dec_streams - 1), args.buffer_sets)
+    bufs, lens_all, host_sets = resident_sets(model, args.batch, args.seconds, n_sets, 1234 + 17 * rank)
     buf = bufs[0]
-    audio0, lens0 = synthetic_batch(args.batch, args.seconds, seed=1234 + 17 * rank)
+    audio0, lens0 = host_sets[0]
     setup_s = time.time() - t0
     pipelined = not args.no_pipeline
 
@@ -231,8 +354,7 @@ def main():
 
     def run_steps(n):
         if pipelined:
-            model.run_pipelined(bufs, n, after_decode=after_decode, enc_streams=args.enc_streams, dec_streams=args.dec_streams,
-                                before_encoder=before_encoder)
+            model.run_pipelined(bufs, n, after_decode=after_decode, dec_streams=args.dec_streams, before_encoder=before_encoder)
         else:
             for i in range(n):
                 before_encoder(i)
@@ -252,6 +374,8 @@ def main():
     torch.cuda.synchronize()
     rdist.barrier()
     dt = time.perf_counter() - t0
+    if world > 1:        # every rank's own clock (rank 0 reports the maximum): scripts/scale.sh lists them
+        print(f"rank {rank}: {dt / args.steps * 1e3:.3f} ms/step over {args.steps} steps", file=sys.stderr, flush=True)
     prof_state["on"] = False
     gemm = model.ctx.profile_read(capi.PROF_GEMM) if prof else None
     model.ctx.profile_enable(0)
@@ -261,16 +385,46 @@ def main():
     intervals = sorted(b - a for a, b in zip(marks[1:-1], marks[2:])) if len(marks) > 3 else []
     median_ms = intervals[len(intervals) // 2] * 1e3 if intervals else None
 
-    # PCIe-inclusive rate (never `value`): same steps, but every batch is copied from pinned host
+    # PCIe-inclusive rate of the SAME resident-batch loop (never `value`): every batch is copied from pinned host
     # memory first and its hypotheses are copied back after decode
     dt_host = None
     if pipelined and world == 1:
-        model.run_pipelined(bufs, 2, from_host=True, enc_streams=args.enc_streams, dec_streams=args.dec_streams)
+        model.run_pipelined(bufs, 2, from_host=True, dec_streams=args.dec_streams)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        model.run_pipelined(bufs, args.steps, from_host=True, enc_streams=args.enc_streams, dec_streams=args.dec_streams)
+        model.run_pipelined(bufs, args.steps, from_host=True, dec_streams=args.dec_streams)
         torch.cuda.synchronize()
         dt_host = time.perf_counter() - t1
+
+    # SURVEY.md §8(d)'s metric through the PUBLIC boundary: a list of host float32 utterances in, token ids (and, second
+    # figure, TranscribeResult text) out — sorting, pinned staging, H2D, the pipeline's fill and drain, D2H all inside
+    api = None
+    if world == 1 and not args.tiny and args.api_batches > 0:
+        try:
+            from reazonspeech_amd.nemo.asr import transcribe_batch, audio_from_numpy, TranscribeConfig
+            waves = [host_sets[k % n_sets][0][i, :host_sets[k % n_sets][1][i]] for k in range(args.api_batches) for i in range(args.batch)]
+            secs = sum(len(w) for w in waves) / 16000.0
+            model.transcribe_waveforms(waves[:3 * args.batch], max_batch=args.batch)          # allocate the pool, warm up
+            runs = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                res = model.transcribe_waveforms(waves, max_batch=args.batch)
+                runs.append(time.perf_counter() - t1)
+            audios = [audio_from_numpy(w, 16000) for w in waves]
+            t1 = time.perf_counter()
+            texts = transcribe_batch(model, audios, TranscribeConfig(verbose=False))
+            dt_text = time.perf_counter() - t1
+            runs.sort()
+            api = {"utterances": len(waves), "audio_seconds": round(secs, 1),
+                   "value_host_to_ids": round(secs / runs[len(runs) // 2], 1), "wall_ms_runs": [round(r * 1e3, 1) for r in runs],
+                   "value_transcribe_batch": round(secs / dt_text, 1), "wall_ms_transcribe_batch": round(dt_text * 1e3, 1),
+                   "tokens": sum(len(x) for x in res.ids), "results": len(texts),
+                   "what": "AsrModel.transcribe_waveforms / transcribe_batch on a host list: length sort, pinned staging by a "
+                           "stager thread, H2D, 4 resident batches / 2 decode lanes, D2H; pipeline fill and drain included "
+                           "(median of 3 for host_to_ids)"}
+            del audios, waves
+        except Exception as e:               # the bench line must still be printed
+            api = {"error": repr(e)}
 
     # the same GEMM launches without the decode stream next to them (sequential schedule, 2 steps): how much of the
     # in-pipeline figure is CU sharing with the decode kernels rather than the kernel itself
@@ -302,20 +456,24 @@ def main():
             "config": {"workload": f"FastConformer-RNNT {cfg.n_params() / 1e6:.0f}M, {args.batch} x "
                                    f"{args.seconds:g} s utterances per GPU (+0.5 s pad each side), "
                                    + (f"ALSD beam-{args.beam} decode (max_target_len {cfg.alsd_max_target_len:g})" if alsd else "greedy decode") + ", "
-                                   "random-init weights", "global_batch": args.batch * world,
+                                   + (f"attention context [{cfg.att_left}, {cfg.att_right}] + {cfg.n_global} global, " if cfg.att_left >= 0 else "")
+                                   + "random-init weights, inputs resident in HBM", "global_batch": args.batch * world,
                        "utterance_seconds": args.seconds, "parallelism": f"dp{world}",
                        "enc_frames": buf.tp_max, "resident_batches": n_sets, "mean_tokens_per_utt": round(mean_tokens, 1),
                        "max_tokens_per_utt": int(n_ids.max()),
-                       "schedule": (("2-stage pipeline: encoder(i+1) || decode(i) on two HIP streams" if args.dec_streams == 1 else
-                                     "2-stage pipeline: encoder(i+2) || decode(i+1), decode(i) on three HIP streams")
-                                    + (" (encoders of consecutive batches on two streams)" if args.enc_streams == 2 else ""))
+                       "schedule": ("2-stage pipeline: encoder(i+1) || decode(i) on two HIP streams" if args.dec_streams == 1 else
+                                    "2-stage pipeline: encoder(i+2) || decode(i+1), decode(i) on three HIP streams")
                                    if pipelined else "sequential"},
             "setup_s": round(setup_s, 1),
         }
         if dt_host:
-            # SURVEY.md §8d's wall clock: pinned host float32 -> H2D -> path -> D2H of the hypotheses
             out["value_pcie_inclusive"] = round(audio_seconds / dt_host, 1)
             out["ms_per_step_pcie_inclusive"] = round(dt_host / args.steps * 1e3, 3)
+        if api:
+            out["host_boundary"] = api
+            if "value_host_to_ids" in api:
+                out["value_host_to_ids"] = api["value_host_to_ids"]
+                out["value_transcribe_batch"] = api["value_transcribe_batch"]
         gf = algorithmic_gflop_per_utt(cfg, buf.tp_max, mean_tokens)
         out["algorithmic_tflops_whole_path"] = round(gf * args.batch * world * args.steps / dt / 1e3, 1)
         if gemm and gemm["launches"]:
@@ -327,7 +485,7 @@ def main():
                     traffic = json.load(fp)["hbm_bytes_per_launch"]
             except Exception:
                 pass
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_smf16_kernel (all encoder linears; gemm_bf16_kernel for the small shapes)",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_smf16_kernel (every dense contraction of the encoder)",
                                "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (PMC, profiles/gemm_traffic.json)",
@@ -343,7 +501,7 @@ def main():
             budget, k = (5.0, 2) if args.tiny else (20.0, 8)
             out["cpu_baseline"], cpu_outputs = cpu_baseline(cfg, sd, audio0, lens0, seconds_budget=budget, max_utt=k)
             try:
-                out["parity"] = parity_vs_cpu_leg(model, cfg, sd, audio0, lens0, cpu_outputs)
+                out["parity"] = parity_vs_cpu_leg(model, cfg, sd, bufs[0], audio0, lens0, cpu_outputs)
             except Exception as e:               # the bench line must still be printed
                 out["parity"] = {"error": repr(e)}
         if world == 1 and not alsd and not args.tiny:
@@ -353,6 +511,8 @@ def main():
                 out["parity"]["decode_families_whole_batch"] = decode_family_check(model, bufs[0])
             except Exception as e:               # the bench line must still be printed
                 out["parity"]["decode_families_whole_batch"] = {"error": repr(e)}
+        if world == 1 and not args.tiny and not args.no_extra_configs and not alsd and not args.att_context:
+            out["configs"] = extra_configs(model, cfg, sd, args, host_sets)
         print(json.dumps(out), flush=True)
     rdist.shutdown()
 

@@ -1,0 +1,116 @@
+"""Flip audit of greedy RNN-T decisions.  TEST INFRASTRUCTURE (oracle/__init__.py).
+
+Greedy ids of the HIP path against the END-TO-END fp32 oracle are not an identity: the two sides feed the (exact,
+fixed-order float32) decode loop with joint-encoder tensors that differ by the encoder's bf16 noise, and an argmax
+whose top two logits are closer than that noise can move them may flip.  This module turns "token agreement 0.94" into
+"exact except provable near-ties" ([UPSTREAM] GreedyBatchedRNNTInfer; restated at oracle/model.py: greedy_torch):
+
+  * it walks the HIP hypothesis' own decision path (the tokens it emitted at each frame, then the blank that advanced
+    the frame) with the prediction network in float64, so at every decision point both sides share the same history
+    (same `g`) and differ ONLY in the encoder projection row f[t];
+  * at each point it evaluates the joint on the oracle's row (z_ref) and on the HIP row (z_hip).  Where the two argmaxes
+    differ ("local flip"), ReLU being 1-Lipschitz gives
+        z_ref[k_ref] - z_ref[k_hip]  <=  (|w[k_ref]| + |w[k_hip]|) * |f_ref[t] - f_hip[t]|_2
+    so a flip is only possible when the oracle's own margin between the two candidates is below that bound;
+  * every difference between the two id sequences starts at a local flip: an utterance with no local flip along its
+    path must have ids identical to the oracle's end-to-end ids (checked by the callers).
+"""
+import numpy as np
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+class _PredNet:
+    """Embedding -> LSTM (gate order i, f, g, o) -> Linear, float64 ([UPSTREAM] RNNTDecoder.predict, RNNTJoint.pred)"""
+
+    def __init__(self, cfg, sd):
+        P = "decoder.prediction.dec_rnn.lstm."
+        f64 = lambda k: sd[k].detach().cpu().numpy().astype(np.float64)  # noqa: E731
+        self.cfg = cfg
+        self.emb = f64("decoder.prediction.embed.weight")
+        self.w = [np.concatenate([f64(P + f"weight_ih_l{l}"), f64(P + f"weight_hh_l{l}")], axis=1) for l in range(cfg.pred_layers)]
+        self.b = [f64(P + f"bias_ih_l{l}") + f64(P + f"bias_hh_l{l}") for l in range(cfg.pred_layers)]
+        self.wp, self.bp = f64("joint.pred.weight"), f64("joint.pred.bias")
+        H = cfg.pred_hidden
+        self.h = [np.zeros(H) for _ in range(cfg.pred_layers)]
+        self.c = [np.zeros(H) for _ in range(cfg.pred_layers)]
+
+    def step(self, token):
+        H = self.cfg.pred_hidden
+        x = self.emb[token]
+        for l in range(self.cfg.pred_layers):
+            z = self.w[l] @ np.concatenate([x, self.h[l]]) + self.b[l]
+            i, f, g, o = _sigmoid(z[:H]), _sigmoid(z[H:2 * H]), np.tanh(z[2 * H:3 * H]), _sigmoid(z[3 * H:])
+            self.c[l] = f * self.c[l] + i * g
+            self.h[l] = o * np.tanh(self.c[l])
+            x = self.h[l]
+        return self.wp @ x + self.bp
+
+
+def flip_audit(cfg, sd, f_ref, f_hip, enc_len, hip_ids, hip_frames):
+    """f_ref / f_hip: float arrays [>= enc_len, J] (oracle / HIP joint-encoder projection of ONE utterance);
+    hip_ids / hip_frames: the HIP hypothesis.  Returns a dict:
+      decisions      decision points walked (every emitted token and every frame-advancing blank)
+      flips          list of {frame, k_ref, k_hip, margin_ref, bound, delta_f} for local flips
+      margins        float64 array: the oracle's top-1 minus top-2 logit at every decision point
+      path_ok        the float64 argmax on the HIP rows reproduces the HIP hypothesis at every point whose float64
+                     top-2 margin exceeds 1e-3 (sanity of the walk itself; the bit-exact statement is the C oracle's)
+    """
+    f_ref = np.asarray(f_ref, np.float64)
+    f_hip = np.asarray(f_hip, np.float64)
+    wo = sd["joint.joint_net.2.weight"].detach().cpu().numpy().astype(np.float64)
+    bo = sd["joint.joint_net.2.bias"].detach().cpu().numpy().astype(np.float64)
+    wnorm = np.linalg.norm(wo, axis=1)
+    blank = cfg.blank_id
+    by_frame = {}
+    for k, t in zip(hip_ids, hip_frames):
+        by_frame.setdefault(int(t), []).append(int(k))
+    pred = _PredNet(cfg, sd)
+    g = pred.step(blank)
+    flips, margins, path_ok = [], [], True
+    n_dec = 0
+    for t in range(int(enc_len)):
+        toks = by_frame.get(t, [])
+        path = toks + ([blank] if len(toks) < cfg.max_symbols else [])
+        for k in path:
+            z_ref = wo @ np.maximum(f_ref[t] + g, 0.0) + bo
+            z_hip = wo @ np.maximum(f_hip[t] + g, 0.0) + bo
+            n_dec += 1
+            top = np.argpartition(z_ref, -2)[-2:]
+            margins.append(float(abs(z_ref[top[1]] - z_ref[top[0]])))
+            k_hip_f64 = int(np.argmax(z_hip))
+            if k_hip_f64 != k:
+                srt = np.sort(z_hip)
+                if srt[-1] - z_hip[k] > 1e-3:
+                    path_ok = False
+            k_ref = int(np.argmax(z_ref))
+            if k_ref != k:
+                df = float(np.linalg.norm(f_ref[t] - f_hip[t]))
+                flips.append({"frame": t, "k_ref": k_ref, "k_hip": k, "margin_ref": float(z_ref[k_ref] - z_ref[k]),
+                              "bound": float((wnorm[k_ref] + wnorm[k]) * df), "delta_f": df})
+            if k != blank:
+                g = pred.step(k)
+    return {"decisions": n_dec, "flips": flips, "margins": np.asarray(margins), "path_ok": path_ok}
+
+
+def summarize(audits, ids_equal):
+    """fold per-utterance audits into the numbers the parity reports carry.  `ids_equal[b]`: HIP ids == oracle
+    end-to-end ids.  The implication `no local flip => ids equal` is returned as `explained` (must be all True)."""
+    margins = np.concatenate([a["margins"] for a in audits]) if audits else np.zeros(0)
+    flips = [f for a in audits for f in a["flips"]]
+    explained = [bool(eq) or len(a["flips"]) > 0 for a, eq in zip(audits, ids_equal)]
+    out = {"decisions": int(sum(a["decisions"] for a in audits)), "local_flips": len(flips),
+           "utterances_without_flip": int(sum(len(a["flips"]) == 0 for a in audits)),
+           "every_id_difference_starts_at_a_flip": all(explained),
+           "walk_reproduces_hip_path": all(a["path_ok"] for a in audits)}
+    if len(margins):
+        out["oracle_margin_median"] = float(np.median(margins))
+        out["oracle_margin_p05"] = float(np.percentile(margins, 5))
+    if flips:
+        fm = np.asarray([f["margin_ref"] for f in flips])
+        out["flip_margin_max"] = float(fm.max())
+        out["flip_margin_over_bound_max"] = float(max(f["margin_ref"] / max(f["bound"], 1e-30) for f in flips))
+        out["flip_margin_percentile_of_all_margins_max"] = float((margins < fm.max()).mean() * 100.0)
+    return out

@@ -338,7 +338,7 @@ int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, int layout, const float
         const size_t lds = (size_t)(TTF + 9 - 1) * CT * sizeof(float);
 #define RS_GLU_FAST(LY)                                                                                                   \
         do {                                                                                                              \
-            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)glu_dwconv_silu_fast_kernel<9, R, LY>, (int)lds); rc != RS_OK) return rc; \
+            if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)glu_dwconv_silu_fast_kernel<9, R, LY>, (int)lds); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s); return rc; } \
             hipLaunchKernelGGL((glu_dwconv_silu_fast_kernel<9, R, LY>), grid, block, lds, s, x, w, b, lens, T, d, out);   \
         } while (0)
         if (layout == 0) RS_GLU_FAST(0);

@@ -416,7 +416,7 @@ int rs_rnnt_alsd_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     RS_HIP(ctx, hipMemsetAsync(hset[0], 0, 2 * pl.state, s));
     hipLaunchKernelGGL(alsd_init_kernel, dim3(1), dim3(256), 0, s, st[0], as, enc_lens, B, W, d.blank_id, ratio, abs_len);
     // start of sequence: blank token from zero state, slot 0 of every utterance (list built by the init kernel)
-    if (int rc = rs_rnnt_launch_lstm_pred(ctx, &st[0], rows, s); rc != RS_OK) return rc;
+    if (int rc = rs_rnnt_launch_lstm_pred(ctx, &st[0], rows, s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
     RS_CHECK_LAUNCH(ctx, "alsd init");
 
     const int CHUNK = 16;
@@ -426,12 +426,12 @@ int rs_rnnt_alsd_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     while (!finished && i <= max_steps) {
         for (int c = 0; c < CHUNK && i <= max_steps; ++c, ++i) {
             const int p = i & 1, pn = p ^ 1;
-            if (int rc = rs_rnnt_launch_joint_logits(ctx, &st[p], joint_enc, rows, tp_max, W, i, s); rc != RS_OK) return rc;
+            if (int rc = rs_rnnt_launch_joint_logits(ctx, &st[p], joint_enc, rows, tp_max, W, i, s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
             hipLaunchKernelGGL(alsd_select_kernel, dim3(B), dim3(64 * W), 0, s, st[p], as, zbuf, zstride, enc_lens, B, W, V,
                                d.blank_id, i, ratio, abs_len, score_norm, merge, out_cap, ids, steps, n_ids, scores);
             hipLaunchKernelGGL(alsd_reorder_kernel, dim3(rows), dim3(256), 0, s, as, pn, W, rows, L, H, J, hset[p], cset[p],
                                gset[p], hset[pn], cset[pn], gset[pn]);
-            if (int rc = rs_rnnt_launch_lstm_pred(ctx, &st[pn], rows, s); rc != RS_OK) return rc;
+            if (int rc = rs_rnnt_launch_lstm_pred(ctx, &st[pn], rows, s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
         }
         RS_CHECK_LAUNCH(ctx, "alsd step");
         RS_HIP(ctx, hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, s));

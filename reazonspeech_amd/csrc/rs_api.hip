@@ -35,8 +35,15 @@ int rs_ensure_dynamic_lds(rs_ctx* ctx, const void* func, int bytes) {
     std::lock_guard<std::mutex> lock(mu);
     const auto key = std::make_pair(ctx->device, func);
     if (done.count(key)) return RS_OK;
-    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
-        return rs_fail(ctx, RS_EHIP, "cannot reserve %d bytes of dynamic LDS on device %d", bytes, ctx->device);
+    // the attribute applies to the calling thread's CURRENT device: set it on the context's device whatever is current
+    // (a caller may drive two GPUs from one thread), and leave the caller's current device as it was
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return rs_fail(ctx, RS_EHIP, "hipGetDevice failed");
+    if (cur != ctx->device && hipSetDevice(ctx->device) != hipSuccess)
+        return rs_fail(ctx, RS_EHIP, "hipSetDevice(%d) failed", ctx->device);
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (cur != ctx->device) hipSetDevice(cur);
+    if (e != hipSuccess) return rs_fail(ctx, RS_EHIP, "cannot reserve %d bytes of dynamic LDS on device %d", bytes, ctx->device);
     done.insert(key);
     return RS_OK;
 }
@@ -208,11 +215,15 @@ int rs_finalize(rs_ctx* ctx) {
             ctx->lstm_w4[l] = nullptr;
             if (ctx->tensors.count(nm)) { r.get(nm, 4 * H * 2 * H, ctx->lstm_w4[l]); if (r.rc != RS_OK) return r.rc; }
         }
-        const char* e = getenv("RS_DECODE_SCREEN");       // A/B knob: 0 = exact evaluation of every column
-        ctx->decode_screen = !(e && atoi(e) == 0);
-        if (const char* nw = getenv("RS_DECODE_NARROW")) ctx->decode_narrow = atoi(nw) != 0;         // A/B knob: 0 = the wide-tile kernels of round 1
-        if (const char* fg = getenv("RS_FUSE_GLU")) ctx->fuse_glu = atoi(fg);                  // A/B knob: 0 = GLU in the conv kernel
-        if (const char* pw = getenv("RS_DECODE_PERSIST_WGS")) ctx->decode_persist_wgs = atoi(pw);   // A/B knob: > 0 = one persistent launch per batch
+        // $RS_* A/B knobs are defaults: applied ONCE per context (rs_finalize runs again after every rs_set_tensor, e.g.
+        // when the position tables grow; a value chosen with rs_set_option must survive that)
+        if (!ctx->env_read) {
+            ctx->env_read = true;
+            if (const char* e = getenv("RS_DECODE_SCREEN")) ctx->decode_screen = atoi(e) != 0;     // 0 = exact evaluation of every column
+            if (const char* nw = getenv("RS_DECODE_NARROW")) ctx->decode_narrow = atoi(nw) != 0;   // 0 = the wide-tile kernels of round 1
+            if (const char* fg = getenv("RS_FUSE_GLU")) ctx->fuse_glu = atoi(fg) != 0;             // 0 = GLU in the conv kernel
+            if (const char* pw = getenv("RS_DECODE_PERSIST_WGS")) ctx->decode_persist_wgs = atoi(pw);   // > 0 = one persistent launch per batch
+        }
     }
     auto it = ctx->tensors.find("pos.table");
     if (it == ctx->tensors.end()) return rs_fail(ctx, RS_EMISSING, "weight tensor 'pos.table' was not registered");
@@ -235,11 +246,14 @@ int rs_finalize(rs_ctx* ctx) {
 int rs_stream_create(void** out, int device, const uint32_t* cu_mask, int n_words, int priority) {
     if (!out) return RS_EINVAL;
     *out = nullptr;
-    if (hipSetDevice(device) != hipSuccess) return RS_EHIP;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return RS_EHIP;
+    if (cur != device && hipSetDevice(device) != hipSuccess) return RS_EHIP;
     hipStream_t s = nullptr;
     hipError_t e;
     if (cu_mask && n_words > 0) e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask);
     else e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
+    if (cur != device) hipSetDevice(cur);          // the caller's current device is not a side effect of this call
     if (e != hipSuccess) return RS_EHIP;
     *out = (void*)s;
     return RS_OK;
@@ -260,13 +274,8 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
         return RS_OK;
     }
     if (!strcmp(key, "fuse_glu")) {
-        if (value < 0 || value > 2) return rs_fail(ctx, RS_EINVAL, "fuse_glu must be 0, 1 or 2");
+        if (value < 0 || value > 1) return rs_fail(ctx, RS_EINVAL, "fuse_glu must be 0 or 1");
         ctx->fuse_glu = value;
-        return RS_OK;
-    }
-    if (!strcmp(key, "gemm_reserved_cus")) {
-        if (value < -1 || value > 248) return rs_fail(ctx, RS_EINVAL, "gemm_reserved_cus must be -1 .. 248");
-        ctx->gemm_reserved_cus = value;
         return RS_OK;
     }
     return rs_fail(ctx, RS_EINVAL, "unknown option '%s'", key);
@@ -415,8 +424,9 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         return rs_launch_gemm(ctx, g, s);
     };
     const int RES = RS_GEMM_BIAS | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32;
-    // fuse_glu: 1 = where the big-tile GEMM kernel is the natural choice for pw1, 2 = always (tests), 0 = never
-    const bool glu_fused = (dm % 32) == 0 && dm >= 128 && (ctx->fuse_glu == 2 || (ctx->fuse_glu == 1 && rs_gemm_has_glu(M, 2 * dm, dm)));
+    // fuse_glu (default 1): the GLU is applied to the float32 pw1 accumulators in the GEMM epilogue for EVERY batch
+    // size — one rounding point, so an utterance's arithmetic does not depend on the batch it rides in
+    const bool glu_fused = ctx->fuse_glu != 0 && (dm % 32) == 0;
 
     for (int i = 0; i < d.n_layers; ++i) {
         const rs_layer_w& L = ctx->layers[i];
@@ -435,9 +445,9 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         RS_TRY(gemm(ctxb, dm, L.out_w, dm, x, dm, M, dm, RES, L.out_b, 1.0f, x));
         // conv module
         RS_TRY(rs_launch_layernorm(ctx, x, L.ln_conv_g, L.ln_conv_b, M, dm, d.ln_eps, hn, nullptr, s));
-        // pw1's weight rows are interleaved (values / gates in blocks of 32): with the big-tile kernel the GLU is
-        // applied in the GEMM epilogue ([M][d] out, half the bytes written and read back); small problems keep
-        // the plain product and the conv kernel pairs the columns up itself
+        // pw1's weight rows are interleaved (values / gates in blocks of 32): the GLU is applied in the GEMM
+        // epilogue ([M][d] out, half the bytes written and read back); with fuse_glu = 0 the plain product is
+        // stored and the conv kernel pairs the columns up itself
         if (glu_fused) {
             RS_TRY(gemm(hn, dm, L.pw1_w, dm, big, dm, M, 2 * dm, RS_GEMM_BIAS | RS_GEMM_GLU, L.pw1_b, 1.0f, nullptr));
             RS_TRY(rs_launch_glu_dwconv(ctx, big, RS_GLU_APPLIED, L.dw_w, L.dw_b, lens, B, Tp, dm, d.conv_kernel, ctxb, s));

@@ -99,8 +99,9 @@ struct rs_ctx {
     // position table cache: the caller registers "pos_table.<T>" tensors (bf16 [2T-1][d])
     // options (rs_set_option)
     int n_cus = 0;                  // compute units of the device (queried on first use)
-    int fuse_glu = 1;               // conv module: GLU in the pw1 GEMM epilogue where the big-tile kernel serves it (0: never; $RS_FUSE_GLU)
-    int gemm_reserved_cus = -1;     // CUs the persistent GEMM grid leaves to other streams; -1 = process default
+    int fuse_glu = 1;               // conv module: 1 = GLU in the pw1 GEMM epilogue (every batch size: one rounding point, batch-invariant);
+                                    // 0 = plain pw1 product, GLU in the depthwise kernel ($RS_FUSE_GLU; A/B and layout tests)
+    bool env_read = false;          // the $RS_* defaults were applied (once, by the first rs_finalize; rs_set_option wins afterwards)
     // parity taps (rs_encoder_set_taps): copies of the residual stream taken inside rs_encoder_forward
     float* tap_sub = nullptr;
     float* tap_layers = nullptr;
@@ -152,7 +153,6 @@ struct rs_gemm_args {
     const int32_t* mask_lens; int mask_rows_per_step; int mask_steps;
 };
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s);
-bool rs_gemm_has_glu(int M, int N, int K);    // would rs_launch_gemm serve a bf16-out problem of this shape with a GLU-capable kernel
 int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float* b, int M, int d, float eps,
                         uint16_t* out_bf16, float* out_f32, hipStream_t s);
 int rs_launch_layernorm2(rs_ctx* ctx, const float* x, const float* g1, const float* b1, const float* g2, const float* b2,

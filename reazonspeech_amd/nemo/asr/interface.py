@@ -53,6 +53,15 @@ class TranscribeConfig:
     raw_hypothesis: bool = False
 
 
+#: What the beam search's `timestamp[idx]` holds relative to the alignment step i = frame + labels emitted before
+#: (the index the device kernel records): `timestamp[idx] = i + ALSD_TIMESTAMP_OFFSET`.  With 1 the reference's
+#: conversion `frame = step - idx - 1` (decode.py:48) returns the emission frame itself, i.e. subword time =
+#: 0.08 * frame - 0.5 s — the semantics this package documents.  NeMo's own ALSD bookkeeping is [UPSTREAM] and could
+#: not be checked here (a +-1 frame = 80 ms ambiguity in subword / segment times; text and ids
+#: are unaffected): if a real NeMo hypothesis shows `timestamp[idx] = i`, set this to 0 — the one place to flip.
+ALSD_TIMESTAMP_OFFSET = 1
+
+
 class _IdSequence(list):
     """A list of ints that also answers `.tolist()` like the tensor NeMo returns
     (decode.py:40 calls `hyp.y_sequence.tolist()`)."""
@@ -83,3 +92,13 @@ class Hypothesis:
         frames = [int(f) for f in frames]
         steps = [f + idx + 1 for idx, f in enumerate(frames)]
         return cls(_IdSequence([int(blank_id)] + ids), steps, frames)
+
+    @classmethod
+    def from_alsd(cls, ids, steps, blank_id, offset=None):
+        """Beam-search result: `steps[idx]` is the alignment index i = frame + labels before (what rs_rnnt_alsd
+        records); the timestamps handed to the reference post-processor are `i + ALSD_TIMESTAMP_OFFSET`."""
+        off = ALSD_TIMESTAMP_OFFSET if offset is None else int(offset)
+        ids = [int(i) for i in ids]
+        steps = [int(s) for s in steps]
+        frames = [s - idx for idx, s in enumerate(steps)]
+        return cls(_IdSequence([int(blank_id)] + ids), [s + off for s in steps], frames)

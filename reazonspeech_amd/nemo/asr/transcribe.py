@@ -99,10 +99,12 @@ def transcribe_batch(model, audios, config=None, distributed=False):
     decoded = model.transcribe_waveforms_sharded(waves) if distributed else model.transcribe_waveforms(waves)
     results = []
     for k, (ids, frames) in enumerate(zip(decoded.ids, decoded.frames)):
-        # greedy and ALSD results share one adapter: labels + the encoder frame each was emitted at
-        hyp = Hypothesis.from_greedy(ids, frames, model.cfg.blank_id)
         if decoded.scores is not None:
+            # beam search: alignment steps (frame + labels before) through the adapter with the documented offset
+            hyp = Hypothesis.from_alsd(ids, [f + idx for idx, f in enumerate(frames)], model.cfg.blank_id)
             hyp.score = decoded.scores[k]
+        else:
+            hyp = Hypothesis.from_greedy(ids, frames, model.cfg.blank_id)
         ret = decode_hypothesis(model, hyp)
         if config.raw_hypothesis:
             ret.hypothesis = hyp

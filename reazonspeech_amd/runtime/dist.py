@@ -94,35 +94,45 @@ def sharded_decode(lengths: Sequence[int], run_local, counters=None):
     mechanism: one process per GPU, pkg/evaluation/src/base.py:194-212, examples/rs-nemo/eval.py:24-28).
 
     Every rank calls this with the SAME `lengths` (samples per utterance, caller order).  The utterances are dealt
-    to ranks by `shard_by_length`, rank r decodes its shard with `run_local(indices) -> (ids, frames, enc_lens)`
-    (lists in shard order), and ONE all_gather of the padded hypotheses (ids | frames | counts | encoder lengths
-    fused into one int32 payload per rank) returns every utterance's result to every rank, restored to caller order.
-    There is no other collective besides a MAX all_reduce that agrees on the payload width.
+    to ranks by `shard_by_length`, rank r decodes its shard with `run_local(indices) -> (ids, frames, enc_lens[, scores])`
+    (lists in shard order; `scores` = hypothesis log-probabilities of the beam search, or None), and ONE all_gather of
+    the padded hypotheses (count | encoder length | score bits | ids | frames fused into one int32 payload per rank)
+    returns every utterance's result to every rank, restored to caller order.  There is no other collective besides a
+    MAX all_reduce that agrees on the payload width.
 
-    -> (ids, frames, enc_lens): lists of length len(lengths) in caller order."""
+    -> (ids, frames, enc_lens, scores): lists of length len(lengths) in caller order (`scores` None when no rank had any)."""
     n = len(lengths)
     W, r = world_size(), rank()
     shards = shard_by_length(lengths, W)
-    ids, frames, enc_lens = run_local(list(shards[r]))
+    res = run_local(list(shards[r]))
+    ids, frames, enc_lens = res[0], res[1], res[2]
+    scores = res[3] if len(res) > 3 else None
     assert len(ids) == len(frames) == len(enc_lens) == len(shards[r]), "run_local must answer for every index it was given"
+    assert scores is None or len(scores) == len(ids)
     if W == 1:
-        out = ([None] * n, [None] * n, [None] * n)
+        out = ([None] * n, [None] * n, [None] * n, [None] * n if scores is not None else None)
         for k, i in enumerate(shards[0]):
             out[0][i], out[1][i], out[2][i] = list(ids[k]), list(frames[k]), int(enc_lens[k])
+            if scores is not None:
+                out[3][i] = float(scores[k])
         return out
     dev = _collective_device()
     u_local = max((len(x) for x in ids), default=0)
-    um = torch.tensor([u_local], dtype=torch.int32, device=dev)
+    # one small all_reduce agrees on the payload width and on whether scores travel (an empty shard has none to show)
+    um = torch.tensor([u_local, 1 if scores is not None else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(um, op=dist.ReduceOp.MAX)
-    U = int(um.item())
+    U, has_scores = int(um[0].item()), bool(um[1].item())
     bmax = max(len(s) for s in shards)
-    pay = torch.zeros((bmax, 2 + 2 * U), dtype=torch.int32)
+    HEAD = 3
+    pay = torch.zeros((bmax, HEAD + 2 * U), dtype=torch.int32)
+    if scores is not None and len(scores):
+        pay[:len(scores), 2] = torch.tensor(list(scores), dtype=torch.float32).view(torch.int32)   # bit-cast: scores stay exact
     for k in range(len(ids)):
         u = len(ids[k])
         pay[k, 0], pay[k, 1] = u, int(enc_lens[k])
         if u:
-            pay[k, 2:2 + u] = torch.as_tensor(ids[k], dtype=torch.int32)
-            pay[k, 2 + U:2 + U + u] = torch.as_tensor(frames[k], dtype=torch.int32)
+            pay[k, HEAD:HEAD + u] = torch.as_tensor(ids[k], dtype=torch.int32)
+            pay[k, HEAD + U:HEAD + U + u] = torch.as_tensor(frames[k], dtype=torch.int32)
     pay = pay.to(dev).contiguous()
     got = torch.empty((W,) + tuple(pay.shape), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(got.view(-1), pay.view(-1))
@@ -130,11 +140,14 @@ def sharded_decode(lengths: Sequence[int], run_local, counters=None):
         counters["collectives"] = counters.get("collectives", 0) + 1
         counters["bytes"] = counters.get("bytes", 0) + got.numel() * 4
     got = got.cpu()
-    out = ([None] * n, [None] * n, [None] * n)
+    sc = got[:, :, 2].contiguous().view(torch.float32)
+    out = ([None] * n, [None] * n, [None] * n, [None] * n if has_scores else None)
     for rr in range(W):
         for k, i in enumerate(shards[rr]):
             u = int(got[rr, k, 0])
-            out[0][i] = got[rr, k, 2:2 + u].tolist()
-            out[1][i] = got[rr, k, 2 + U:2 + U + u].tolist()
+            out[0][i] = got[rr, k, HEAD:HEAD + u].tolist()
+            out[1][i] = got[rr, k, HEAD + U:HEAD + U + u].tolist()
             out[2][i] = int(got[rr, k, 1])
+            if has_scores:
+                out[3][i] = float(sc[rr, k])
     return out

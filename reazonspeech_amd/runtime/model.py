@@ -63,11 +63,64 @@ class _Buffers:
         self.ws = torch.empty((ctx.workspace_bytes(B, self.l_pad),), dtype=torch.uint8, device=dev)
         # the decoder of batch i overlaps the encoder of batch i+1 in the pipelined path: own scratch
         self.ws_dec = torch.empty((ctx.workspace_bytes(B, 16),), dtype=torch.uint8, device=dev)
-        # second encoder scratch: the pipelined path runs the two halves of a batch on two streams
-        self.ws2 = None
-        # pinned staging for the host boundary
+        # pinned staging for the host boundary (inputs, and the hypotheses on the way back)
         self.h_audio = torch.zeros((B, l_max), dtype=f32).pin_memory()
         self.h_lens = torch.zeros((B,), dtype=i32).pin_memory()
+        self.h_out = None
+        self.step = -1                   # index of the pipeline step this buffer set currently carries (run_pipelined)
+        self._model = model
+
+    def narrow(self, l_max):
+        """The same memory with the geometry of a batch whose longest utterance has `l_max` samples: tight padding for a
+        group of short utterances without another allocation (the kernels take extents and strides as arguments and mask
+        by per-utterance length, so results do not depend on the padded extent)."""
+        l_max = (max(int(l_max), 1) + 63) // 64 * 64
+        if l_max >= self.l_max:
+            return self
+        return _BufView(self, l_max)
+
+
+class _BufView:
+    """a `_Buffers` re-viewed for a smaller padded extent (see `_Buffers.narrow`); shares every allocation"""
+
+    def __init__(self, base, l_max):
+        model = base._model
+        cfg, ctx = model.cfg, model.ctx
+        self.base, self.B, self.l_max = base, base.B, l_max
+        self.l_pad = l_max + model.pad_left + model.pad_right
+        self.t_max = max(ctx.mel_frames(self.l_pad), 1)
+        self.tp_max = max(ctx.enc_frames(self.t_max), 1)
+        self.u_max = self.tp_max * cfg.max_symbols
+        if cfg.decoding == "alsd":
+            self.u_max = max(1, self.tp_max + alsd_label_budget(self.tp_max, cfg.alsd_max_target_len))
+        B = self.B
+
+        def cut(t, *shape):
+            n = 1
+            for d in shape:
+                n *= d
+            return t.view(-1)[:n].view(*shape)
+
+        self.audio, self.lens = base.audio, base.lens          # rows keep the full pitch (the stride is an argument)
+        self.feats = cut(base.feats, B, self.t_max, cfg.n_mels)
+        self.n_frames = base.n_frames
+        self.joint_enc = cut(base.joint_enc, B, self.tp_max, cfg.joint_hidden)
+        self.enc_lens = base.enc_lens
+        self.ids = cut(base.ids, B, self.u_max)
+        self.frames = cut(base.frames, B, self.u_max)
+        self.n_ids, self.scores = base.n_ids, base.scores
+        self.ws, self.ws_dec = base.ws, base.ws_dec
+        self.h_audio, self.h_lens = base.h_audio, base.h_lens
+        self.h_out = None
+        self.step = -1
+
+    @property
+    def ws_alsd(self):
+        return self.base.ws_alsd
+
+    @ws_alsd.setter
+    def ws_alsd(self, v):
+        self.base.ws_alsd = v
 
 
 class AsrModel:
@@ -89,8 +142,6 @@ class AsrModel:
         self._ctx_dec = None
         self._ctx_dec2 = None
         self._dec2_stream = None
-        self._ctx_enc2 = None
-        self._enc2_stream = None
         self._streams = None
         self._streams_prio = None
         self.pos_cap = 0
@@ -108,7 +159,7 @@ class AsrModel:
         self._set_pos_tables(dev["pos.table"])
 
     def _contexts(self):
-        return [c for c in (self.ctx, self._ctx_dec, self._ctx_dec2, self._ctx_enc2) if c is not None]
+        return [c for c in (self.ctx, self._ctx_dec, self._ctx_dec2) if c is not None]
 
     def _set_pos_tables(self, table):
         """register the relative-position table (bf16 [2*cap-1][d]) and the derived per-layer tensors: the table
@@ -206,8 +257,8 @@ class AsrModel:
             ctx.rnnt_greedy(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, buf.u_max, buf.ids, buf.frames, buf.n_ids,
                             ws, stream)
             return
-        if buf.ws_alsd is None:
-            n = ctx.alsd_workspace_bytes(buf.B, cfg.beam_size, buf.tp_max, cfg.alsd_max_target_len)
+        n = ctx.alsd_workspace_bytes(buf.B, cfg.beam_size, buf.tp_max, cfg.alsd_max_target_len)
+        if buf.ws_alsd is None or buf.ws_alsd.numel() < n:       # (a narrowed view may have sized it for a shorter batch)
             buf.ws_alsd = torch.empty((n,), dtype=torch.uint8, device=self.device)
         ctx.rnnt_alsd(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, cfg.beam_size, cfg.alsd_max_target_len,
                       cfg.beam_score_norm, False, buf.ids, buf.frames, buf.n_ids, buf.scores, buf.ws_alsd, stream)
@@ -220,59 +271,37 @@ class AsrModel:
                      buf.ws, stream)
         ctx.encoder(buf.feats, buf.n_frames, buf.B, buf.t_max, None, buf.joint_enc, buf.enc_lens, buf.ws, stream)
 
-    def run_encoder_split(self, buf: _Buffers, streams):
-        """front-end + encoder of one batch as two independent half-batches on two streams: the
-        memory-bound kernels of one half (LayerNorm, attention, conv, GEMM epilogues) overlap the
-        MFMA-bound main loops of the other, and each GEMM's partial last round of tiles is filled
-        by the other stream's work."""
-        B = buf.B
-        h0 = (B + 1) // 2
-        if buf.ws2 is None:
-            buf.ws2 = torch.empty((self.ctx.workspace_bytes(B - h0 if B > h0 else 1, buf.l_pad),), dtype=torch.uint8,
-                                  device=self.device)
-        parts = ((0, h0, self.ctx, buf.ws, streams[0]), (h0, B, self._ctx_enc2, buf.ws2, streams[1]))
-        for lo, hi, ctx, ws, st in parts:
-            if hi <= lo:
-                continue
-            s = st.cuda_stream
-            ctx.frontend(buf.audio[lo:hi], buf.lens[lo:hi], self.pad_left, self.pad_right, buf.t_max, buf.feats[lo:hi],
-                         buf.n_frames[lo:hi], ws, s)
-            ctx.encoder(buf.feats[lo:hi], buf.n_frames[lo:hi], hi - lo, buf.t_max, None, buf.joint_enc[lo:hi],
-                        buf.enc_lens[lo:hi], ws, s)
+    def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None, from_host: bool = False,
+                      dec_streams: int = 1, before_encoder=None, fill=None):
+        """Process `steps` batches as a pipeline with up to len(bufs) batches in flight: the throughput-bound front-end +
+        encoder of batch i+1 (i+2) runs on one HIP stream while the latency-bound decode of batch i (and i+1) — a
+        dependency chain of small launches that leaves most CUs idle — runs on one (two) more streams, each driven by a
+        worker thread (ctypes releases the GIL; the decode entry points synchronise only their own stream).  Every batch
+        is fully decoded when this returns.
 
-    def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None, split_encoder: bool = None,
-                      from_host: bool = False, enc_streams: int = 1, dec_streams: int = 1, before_encoder=None):
-        """Process `steps` batches (bufs[i % len(bufs)], inputs already in HBM) as a two-stage
-        pipeline: the throughput-bound front-end + encoder of batch i+1 runs on one HIP stream while
-        the latency-bound greedy decode of batch i (a dependency chain of small launches that leaves
-        most CUs idle) runs on a second stream, driven by a worker thread (ctypes releases the GIL;
-        rs_rnnt_greedy synchronises only its own stream).  Every batch is fully decoded when this
-        returns.  `after_decode(buf)` is called on the worker thread after each batch.  With
-        `from_host` every batch is first copied from its pinned host buffer (H2D on the encoder
-        stream) and its hypotheses are copied back to the host after decode (the PCIe-inclusive
-        boundary).  `enc_streams=2` (experimental) runs the encoders of consecutive batches on two
-        streams (each with its full-size launches) so that one batch's HBM-bound kernels can overlap the
-        other's GEMMs; it needs four buffer sets.  `dec_streams=2` decodes consecutive batches on two streams
-        (two worker threads): next to the encoder a decode launch spends most of its time waiting for compute
-        units to free up, so two interleaved chains nearly double the decode rate; needs three buffer sets.
-        `before_encoder(i)` is called on the caller's thread right before batch i's encoder is enqueued."""
-        assert len(bufs) >= 2, "the pipeline needs two buffer sets"
-        assert dec_streams in (1, 2) and (dec_streams == 1 or len(bufs) >= 3), "two decode streams need three buffer sets"
-        assert enc_streams in (1, 2) and (enc_streams == 1 or len(bufs) >= 4), "two encoder streams need four buffer sets"
+        bufs            resident buffer sets; step i uses bufs[i % len(bufs)] (or what `fill` returned for it) and waits
+                        for that set's previous decode.  Two decode lanes need at least three sets.
+        after_decode    `after_decode(buf)` on the decode worker right after batch `buf.step` is decoded (and, with
+                        `from_host`, its hypotheses are in `buf.h_out` on the host).  Hooks run in batch order whichever
+                        lane finishes first (a hook may issue a collective: every rank has to issue them in the same
+                        order, from one thread at a time).
+        from_host       every batch is first copied from its pinned host buffer (H2D on the encoder stream) and its
+                        hypotheses are copied back after decode: the host-to-host boundary of SURVEY.md §8(d).
+        fill            `fill(i, buf) -> buf or a narrowed view of it`: a stager thread calls it for step i as soon as the
+                        buffer set's previous use is over, to put batch i into the pinned staging buffers (implies
+                        `from_host`) while the GPU works on the batches before it; the encoder of step i waits for it.
+        before_encoder  `before_encoder(i)` on the caller's thread right before batch i's encoder is enqueued."""
+        nb = len(bufs)
+        assert nb >= 2 or steps <= 1, "the pipeline needs two buffer sets"
+        assert dec_streams in (1, 2) and (dec_streams == 1 or nb >= 3), "two decode streams need three buffer sets"
+        from_host = from_host or fill is not None
         with torch.cuda.device(self.device):
-            if split_encoder is None:
-                # measured on MI355X: splitting the encoder batch over two streams LOSES ~5 % (83.8 vs
-                # 79.8 ms/step, profiles/r01h_bench_matrix_split.txt) — the GEMM grids halve and the
-                # tile rounds quantise worse than the overlap wins; kept as an opt-in experiment
-                split_encoder = os.environ.get("RS_SPLIT_ENCODER", "0") != "0"
             # the decode chain of ONE stream is latency-critical (its workgroups should take the first free slots: high
             # priority); with two decode lanes it has a whole extra encoder period of slack and normal priority leaves
             # the GEMM rounds alone (profiles/r02w_bench_ab.txt)
             dec_prio = int(os.environ.get("RS_DECODE_PRIORITY", "0" if dec_streams == 2 else "-1"))
             if self._ctx_dec is None:
                 self._ctx_dec = self.ctx.clone()
-                self._ctx_enc2 = self.ctx.clone()
-                self._enc2_stream = torch.cuda.Stream(device=self.device)
             if self._streams is None or self._streams_prio != dec_prio:
                 dec_cus = int(os.environ.get("RS_DECODE_CUS", "0"))
                 if dec_cus > 0:
@@ -299,10 +328,13 @@ class AsrModel:
             queues = [queue.Queue() for _ in dec_lanes]
             done = [threading.Event() for _ in range(steps)]
             hooked = [threading.Event() for _ in range(steps)]
+            staged = [threading.Event() for _ in range(steps)]
+            views = [None] * steps
             errors = []
+            stop = threading.Event()
 
             def worker(lane):
-                ctx_d, dec_stream = dec_lanes[lane]
+                ctx_d, stream = dec_lanes[lane]
                 jobs = queues[lane]
                 with torch.cuda.device(self.device):
                     while True:
@@ -311,15 +343,14 @@ class AsrModel:
                             return
                         i, buf, ev = item
                         try:
-                            dec_stream.wait_event(ev)
+                            stream.wait_event(ev)
                             # decode scratch lives past the encoder's scratch in buf.ws_dec
-                            self.decode(ctx_d, buf, buf.ws_dec, dec_stream.cuda_stream)
+                            self.decode(ctx_d, buf, buf.ws_dec, stream.cuda_stream)
                             if from_host:
-                                with torch.cuda.stream(dec_stream):
-                                    buf.h_out = (buf.n_ids.cpu(), buf.ids.cpu(), buf.frames.cpu())
+                                with torch.cuda.stream(stream):
+                                    buf.h_out = (buf.n_ids.cpu(), buf.ids.cpu(), buf.frames.cpu(), buf.enc_lens.cpu(),
+                                                 buf.scores.cpu() if self.cfg.decoding == "alsd" else None)
                             if after_decode is not None:
-                                # hooks run in batch order whatever lane finishes first (a hook may issue a collective:
-                                # every rank has to issue them in the same order, from one thread at a time)
                                 if i > 0:
                                     hooked[i - 1].wait()
                                 after_decode(buf)
@@ -329,54 +360,55 @@ class AsrModel:
                             hooked[i].set()
                             done[i].set()
 
+            def stager():
+                # host side of the pipeline: batch i goes into its pinned staging buffers as soon as the buffer set is
+                # free again (its previous batch decoded, hence its H2D long finished)
+                for i in range(steps):
+                    try:
+                        while i >= nb and not done[i - nb].wait(0.05):
+                            if stop.is_set():
+                                return
+                        if errors or stop.is_set():
+                            return
+                        views[i] = fill(i, bufs[i % nb])
+                    except Exception as e:
+                        errors.append(e)
+                    finally:
+                        staged[i].set()
+
             threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(len(dec_lanes))]
+            if fill is not None:
+                threads.append(threading.Thread(target=stager, daemon=True))
             for th in threads:
                 th.start()
-
-            class _Jobs:          # batch i goes to decode lane i mod lanes
-                @staticmethod
-                def put(item):
-                    if item is None:
-                        for q in queues:
-                            q.put(None)
-                    else:
-                        queues[item[0] % len(queues)].put(item)
-            jobs = _Jobs
-            nb = len(bufs)
             for i in range(steps):
-                buf = bufs[i % nb]
-                if i >= nb:
-                    done[i - nb].wait()           # this buffer set's previous decode must be finished
+                if fill is not None:
+                    staged[i].wait()
+                    if errors:
+                        break
+                    buf = views[i]
+                else:
+                    buf = bufs[i % nb]
+                    if i >= nb:
+                        done[i - nb].wait()           # this buffer set's previous decode must be finished
+                buf.step = i
                 if before_encoder is not None:
                     before_encoder(i)
                 if from_host:
-                    with torch.cuda.stream(self._enc2_stream if (enc_streams == 2 and (i & 1)) else enc_stream):
-                        buf.audio.copy_(buf.h_audio, non_blocking=True)
+                    with torch.cuda.stream(enc_stream):          # only the columns this batch's geometry reads
+                        w = buf.l_max
+                        buf.audio[:, :w].copy_(buf.h_audio[:, :w], non_blocking=True)
                         buf.lens.copy_(buf.h_lens, non_blocking=True)
-                if enc_streams == 2 and (i & 1):
-                    # odd batches: second context (a context is bound to one stream) on the second stream
-                    es = self._enc2_stream
-                    if i < 2:
-                        es.wait_stream(torch.cuda.current_stream())
-                    self.run_encoder(buf, es.cuda_stream, ctx=self._ctx_enc2)
-                    ev = torch.cuda.Event()
-                    ev.record(es)
-                    jobs.put((i, buf, ev))
-                    continue
-                if split_encoder and buf.B >= 2:
-                    self._enc2_stream.wait_stream(enc_stream)       # keep batch order across both halves
-                    self.run_encoder_split(buf, (enc_stream, self._enc2_stream))
-                    enc_stream.wait_stream(self._enc2_stream)
-                else:
-                    self.run_encoder(buf, enc_stream.cuda_stream)
+                self.run_encoder(buf, enc_stream.cuda_stream)
                 ev = torch.cuda.Event()
                 ev.record(enc_stream)
-                jobs.put((i, buf, ev))
-            jobs.put(None)
+                queues[i % len(queues)].put((i, buf, ev))          # batch i goes to decode lane i mod lanes
+            stop.set()                  # (an error may have ended the loop early: release the stager)
+            for q in queues:
+                q.put(None)
             for th in threads:
                 th.join()
             torch.cuda.current_stream().wait_stream(enc_stream)
-            torch.cuda.current_stream().wait_stream(self._enc2_stream)
             for _, ds in dec_lanes:
                 torch.cuda.current_stream().wait_stream(ds)
             if errors:
@@ -387,6 +419,25 @@ class AsrModel:
         with torch.cuda.device(self.device):
             return _Buffers(self, B, (max(int(l_max), 1) + 63) // 64 * 64)
 
+    def fill_host(self, waveforms: Sequence[np.ndarray], buf):
+        """copy host waveforms (16 kHz mono float32, un-padded) into the buffer set's pinned staging buffers; the tail of
+        every row is zeroed (the kernels mask by length, this only keeps the padding deterministic).  Returns the view of
+        `buf` narrowed to this batch's longest utterance."""
+        assert len(waveforms) <= buf.B
+        longest = max((len(w) for w in waveforms), default=0)
+        view = buf.narrow(longest)
+        assert view.l_max >= longest
+        ha = buf.h_audio.numpy()
+        hl = buf.h_lens.numpy()
+        width = view.l_max
+        for b, w in enumerate(waveforms):
+            n = len(w)
+            ha[b, :n] = w
+            ha[b, n:width] = 0.0
+            hl[b] = n
+        hl[len(waveforms):] = 0          # a short last group: empty utterances (length 0 decodes to nothing)
+        return view
+
     def stage(self, waveforms: Sequence[np.ndarray], l_max: Optional[int] = None, buf: Optional[_Buffers] = None) -> _Buffers:
         """copy host waveforms (16 kHz mono float32, un-padded) into a pinned buffer and on to HBM"""
         B = len(waveforms)
@@ -396,7 +447,6 @@ class AsrModel:
         if buf is None:
             buf = self.buffers(B, l_max)
         assert buf.B == B and buf.l_max >= longest
-        # rows past each utterance's length are masked by the kernels, but keep the tail deterministic
         ha = buf.h_audio.numpy()
         hl = buf.h_lens.numpy()
         for b, w in enumerate(waveforms):
@@ -409,14 +459,16 @@ class AsrModel:
             buf.lens.copy_(buf.h_lens, non_blocking=True)
         return buf
 
-    def collect(self, buf: _Buffers) -> DecodedBatch:
-        n = buf.n_ids.cpu().numpy()
-        ids = buf.ids.cpu().numpy()
-        frames = buf.frames.cpu().numpy()
-        el = buf.enc_lens.cpu().numpy()
+    def collect(self, buf, host=None) -> DecodedBatch:
+        """hypotheses of a decoded batch as host lists; `host` = the (n_ids, ids, frames, enc_lens, scores) tensors a
+        pipeline worker already copied back (buf.h_out), otherwise they are fetched here"""
+        if host is None:
+            host = (buf.n_ids.cpu(), buf.ids.cpu(), buf.frames.cpu(), buf.enc_lens.cpu(),
+                    buf.scores.cpu() if self.cfg.decoding == "alsd" else None)
+        n, ids, frames, el = (t.numpy() for t in host[:4])
         if self.cfg.decoding == "alsd":      # alignment step i = frame + labels emitted before
             frames = frames - np.arange(frames.shape[1], dtype=frames.dtype)[None, :]
-            scores = buf.scores.cpu().numpy().tolist()
+            scores = host[4].numpy().tolist()
         else:
             scores = None
         return DecodedBatch([ids[b, :n[b]].tolist() for b in range(buf.B)],
@@ -425,26 +477,43 @@ class AsrModel:
     def transcribe_waveforms_sharded(self, waveforms: Sequence[np.ndarray], max_batch: int = 256) -> DecodedBatch:
         """SPMD form of `transcribe_waveforms` for one process per GPU (`torch.distributed` initialised, RCCL):
         every rank passes the same list, decodes its length-balanced shard on its own GPU and receives all
-        hypotheses in the caller's order after the path's one collective (runtime/dist.py: sharded_decode).
-        With a single process it is `transcribe_waveforms`."""
+        hypotheses (ids, frames, encoder lengths and — beam search — scores) in the caller's order after the path's one
+        collective (runtime/dist.py: sharded_decode).  With a single process it is `transcribe_waveforms`."""
         from . import dist as rdist
 
         def run_local(indices):
             res = self.transcribe_waveforms([waveforms[i] for i in indices], max_batch=max_batch)
-            return res.ids, res.frames, res.enc_lens
+            return res.ids, res.frames, res.enc_lens, res.scores
 
-        ids, frames, enc_lens = rdist.sharded_decode([len(w) for w in waveforms], run_local)
-        return DecodedBatch(ids, frames, enc_lens)
+        ids, frames, enc_lens, scores = rdist.sharded_decode([len(w) for w in waveforms], run_local)
+        return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.decoding == "alsd" else None)
+
+    POOL_SETS = 4       # resident batches of the host-to-host pipeline (encoder(i+2) || decode(i+1), decode(i) + one being staged)
+
+    def _pool(self, B, l_max, n_sets):
+        """buffer sets of the host-to-host pipeline, kept across calls (pinned staging is expensive to allocate);
+        bucketed to whole seconds like `buffers`, one geometry at a time"""
+        l_max = (max(int(l_max), 1) + self.BUCKET - 1) // self.BUCKET * self.BUCKET
+        key = getattr(self, "_pool_key", None)
+        if key is None or key[0] != B or not (l_max <= key[1] <= 2 * l_max) or len(self._pool_sets) < n_sets:
+            self._pool_sets = []              # drop the old geometry before allocating the new one
+            self._pool_key = (B, l_max)
+            with torch.cuda.device(self.device):
+                self._pool_sets = [_Buffers(self, B, l_max) for _ in range(n_sets)]
+        return self._pool_sets[:n_sets]
 
     def transcribe_waveforms(self, waveforms: Sequence[np.ndarray], max_batch: int = 256) -> DecodedBatch:
         """host float32 waveforms -> token ids / frames (the batched boundary).
 
-        Up to `max_batch` utterances run as one batch.  Longer lists are sorted by length, cut into
-        batches of `max_batch` (tight padding per batch) and pushed through the two-stage pipeline
-        (encoder of batch i+1 || decode of batch i); results come back in the caller's order."""
+        Up to `max_batch` utterances run as one batch.  Longer lists are sorted by length, cut into batches of
+        `max_batch` (each padded only to ITS longest utterance) and pushed through the persistent pipeline of
+        `run_pipelined` — four resident batches, two decode lanes, a stager thread that fills the pinned buffers of
+        batch i+2 / i+3 while the GPU works on the batches before them, H2D on the encoder stream, hypotheses copied back
+        by the decode workers: no drain between batches.  Results come back in the caller's order."""
         n = len(waveforms)
         if n == 0:
             return DecodedBatch([], [], [])
+        waveforms = [np.asarray(w, dtype=np.float32) for w in waveforms]
         if n <= max_batch:
             buf = self.stage(waveforms)
             self.run_device(buf)
@@ -453,37 +522,17 @@ class AsrModel:
         ids, frames, enc_lens, scores = [None] * n, [None] * n, [None] * n, [None] * n
         groups = [order[i:i + max_batch] for i in range(0, n, max_batch)]
         l_max = max(len(w) for w in waveforms)
-        pool = [self.new_buffers(max_batch, l_max), self.new_buffers(max_batch, l_max)]
+        n_sets = min(self.POOL_SETS, len(groups))
+        pool = self._pool(max_batch, l_max, n_sets)
 
-        def fill(buf, group):
-            # short last group: pad with empty utterances (length 0 decodes to nothing)
-            waves = [waveforms[i] for i in group] + [np.zeros(0, np.float32)] * (max_batch - len(group))
-            self.stage(waves, buf=buf)
+        def fill(i, buf):
+            return self.fill_host([waveforms[k] for k in groups[i]], buf)
 
-        def harvest(buf, group):
-            torch.cuda.current_stream().synchronize()
-            res = self.collect(buf)
-            for k, i in enumerate(group):
+        def harvest(buf):
+            res = self.collect(buf, host=buf.h_out)
+            for k, i in enumerate(groups[buf.step]):
                 ids[i], frames[i], enc_lens[i] = res.ids[k], res.frames[k], res.enc_lens[k]
                 scores[i] = res.scores[k] if res.scores is not None else None
 
-        # the pipeline needs inputs resident before a step starts: stage two groups ahead of use
-        pending = {}
-
-        def after(buf):
-            harvest(buf, pending.pop(id(buf)))
-
-        # process pairs of groups through run_pipelined so staging of the next pair never races the
-        # encoder of the current one
-        for g0 in range(0, len(groups), 2):
-            pair = groups[g0:g0 + 2]
-            for k, group in enumerate(pair):
-                fill(pool[k], group)
-                pending[id(pool[k])] = group
-            torch.cuda.current_stream().synchronize()
-            if len(pair) == 2:
-                self.run_pipelined(pool, 2, after_decode=after)
-            else:
-                self.run_device(pool[0])
-                after(pool[0])
+        self.run_pipelined(pool, len(groups), after_decode=harvest, fill=fill, dec_streams=2 if n_sets >= 3 else 1)
         return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.decoding == "alsd" else None)

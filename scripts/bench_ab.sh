@@ -7,7 +7,7 @@ vals=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do vals+=("$1"); shift; done
 for rep in $(seq 1 ${REPS:-2}); do
 for v in "${vals[@]}"; do
   echo "== $var=$v (rep $rep) $*"
-  env $var=$v timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "
+  env $var=$v timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extra-configs --api-batches 0 "$@" 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

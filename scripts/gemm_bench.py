@@ -1,7 +1,9 @@
-"""A/B the GEMM kernel variants on the shapes of the 619M encoder (run on the GPU box).
+"""A/B the GEMM tile heights / main-loop schedules on the shapes of the 619M encoder (run on the GPU box).
 
-    python scripts/gemm_bench.py [variants...]
-Prints per shape and variant: correctness vs a torch bf16 matmul, median microseconds, TFLOP/s.
+    python scripts/gemm_bench.py [TILE:SCHED ...] [--batch=32] [--shape=ffn] [--group-m=N] [--quick]
+TILE = 0 (what the launcher picks), 256, 192, 128, 64; SCHED = 0 (ping-pong, two phases per K tile), 1 (no ping-pong),
+2 (ping-pong, four phases per K tile).  Prints per shape and variant: correctness vs a torch bf16 matmul, median
+microseconds, TFLOP/s.  The variants are interleaved per shape inside one process (guide §5.4 rule 24).
 """
 import ctypes
 import os
@@ -13,7 +15,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reazonspeech_amd.runtime import capi                     # noqa: E402
 from reazonspeech_amd.runtime.config import FASTCONFORMER_619M  # noqa: E402
 
-M = 35328
+BATCH = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--batch=")] or [256])[0]
+M = BATCH * 138
 SHAPES = [  # name, M, N, K, flags
     ("ffn_up  silu->bf16", M, 4096, 1024, capi.GEMM_BIAS | capi.GEMM_SILU),
     ("ffn_down res->f32 ", M, 1024, 4096, capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32),
@@ -21,15 +24,15 @@ SHAPES = [  # name, M, N, K, flags
     ("out/pw2 res->f32  ", M, 1024, 1024, capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32),
     ("pw1     bias->bf16", M, 2048, 1024, capi.GEMM_BIAS),
     ("pw1     glu ->bf16", M, 2048, 1024, capi.GEMM_BIAS | capi.GEMM_GLU),
-    ("sub_pw1 relu->bf16", 256 * 275 * 20, 256, 256, capi.GEMM_BIAS | capi.GEMM_RELU),
-    ("sub_pw2 relu->bf16", 256 * 138 * 10, 256, 256, capi.GEMM_BIAS | capi.GEMM_RELU),
+    ("sub_pw1 relu->bf16", BATCH * 275 * 20, 256, 256, capi.GEMM_BIAS | capi.GEMM_RELU),
+    ("sub_pw2 relu->bf16", BATCH * 138 * 10, 256, 256, capi.GEMM_BIAS | capi.GEMM_RELU),
     ("sub_out ->f32     ", M, 1024, 2560, capi.GEMM_BIAS | capi.GEMM_OUT_F32),
 ]
 
 
 def main():
     quick = "--quick" in sys.argv
-    variants = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [1, 2, 3, 4, 5]
+    variants = [tuple(int(x) for x in (v + ":0").split(":")[:2]) for v in sys.argv[1:] if not v.startswith("--")] or [(0, 0)]
     groups = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--group-m=")] or [None]
     # row pitch of A / W in elements beyond K (power-of-two pitches can camp on a few L2 / HBM channels)
     pad_a = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--pad-a=")] or [0])[0]
@@ -38,9 +41,15 @@ def main():
     only = [a.split("=")[1] for a in sys.argv[1:] if a.startswith("--shape=")]
     dev = torch.device("cuda", 0)
     ctx = capi.Context(FASTCONFORMER_619M, 0)
-    setv = ctx.lib.rs_debug_set_gemm_variant
-    setv.argtypes = [ctypes.c_int]
-    setv.restype = None
+    sett, sets, pick = ctx.lib.rs_debug_set_gemm_tile, ctx.lib.rs_debug_set_gemm_sched, ctx.lib.rs_debug_gemm_tile_height
+    for f in (sett, sets):
+        f.argtypes = [ctypes.c_int]
+        f.restype = None
+    pick.argtypes = [ctypes.c_int] * 4
+
+    def setv(v):
+        sett(v[0])
+        sets(v[1])
     setg = ctx.lib.rs_debug_set_gemm_group_m
     setg.argtypes = [ctypes.c_int]
     setg.restype = None
@@ -86,7 +95,7 @@ def main():
                 ctx.gemm(A, W, out, flags=flags, bias=bias, residual=res)
                 torch.cuda.synchronize()
             except capi.RsError as e:
-                print(f"{name} v{v}: {e}")
+                print(f"{name} {v}: {e}")
                 continue
             err = (out[:4096].float() - ref).abs().max().item()
             ts = []
@@ -100,9 +109,10 @@ def main():
                 ts.append(e0.elapsed_time(e1) / (1 if quick else 4))
             ts.sort()
             us = ts[len(ts) // 2] * 1e3
-            print(f"{name} M{m} N{n} K{k} v{v}{'' if gm is None else f' gm{gm}'}{f' padA{pad_a}' if pad_a else ''}{f' padW{pad_w}' if pad_w else ''}{f' padC{pad_c}' if pad_c else ''}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
+            v = f"{v[0] or pick(m, n, k, 256)}{'*' if not v[0] else ''}:s{v[1]}"
+            print(f"{name} M{m} N{n} K{k} tile {v}{'' if gm is None else f' gm{gm}'}{f' padA{pad_a}' if pad_a else ''}{f' padW{pad_w}' if pad_w else ''}{f' padC{pad_c}' if pad_c else ''}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
         del A, W, out, res
-    setv(0)
+    setv((0, 0))
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 cd /tmp && cd - >/dev/null
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-profile > gpurun_out/prof_$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-extra-configs --api-batches 0 --no-profile > gpurun_out/prof_$TAG.log 2>&1
 tail -3 gpurun_out/prof_$TAG.log
 find $OUT -name "*stats*" | head
 F=$(find $OUT -name "*kernel_stats.csv" | head -1)

@@ -165,3 +165,19 @@ def test_transcribe_with_alsd_strategy(gpu_device):
     from reazonspeech_amd.nemo.asr import transcribe
     one = transcribe(model, audios[1])
     assert one.text == res[1].text and [s.seconds for s in one.subwords] == [s.seconds for s in res[1].subwords]
+
+
+def test_alsd_long_list_through_the_host_pipeline(gpu_device):
+    """more utterances than max_batch with the beam search: length-sorted groups through the persistent host pipeline
+    (narrowed buffer views, two decode lanes, hypotheses and float32 scores copied back by the decode workers) give,
+    per utterance, exactly what decoding it alone gives — ids, frames and score bits"""
+    from reazonspeech_amd.nemo.asr import load_model
+    model = load_model(device="cuda:0", config=TINY, decoding="alsd", beam_size=2)
+    audio, lens = synthetic_batch(11, 2.0, seed=21, ragged=True, min_seconds=0.4)
+    waves = [audio[b, :lens[b]] for b in range(11)]
+    got = model.transcribe_waveforms(waves, max_batch=4)
+    assert got.scores is not None and len(got.ids) == 11
+    for b in (0, 4, 7, 10):
+        alone = model.transcribe_waveforms([waves[b]])
+        assert got.ids[b] == alone.ids[0] and got.frames[b] == alone.frames[0]
+        assert same_bits(got.scores[b], alone.scores[0])

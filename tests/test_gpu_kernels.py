@@ -18,10 +18,24 @@ from oracle import model as om
 
 pytestmark = pytest.mark.gpu
 
-# kernel builds that were written after a round's GPU minutes were spent and have never run on hardware are kept out
-# of the default suite: RS_TEST_EXPERIMENTAL=1 adds them to the GEMM variant tests (DESIGN.md §8 "Next")
-import os
-EXPERIMENTAL_GEMM = [1220, 1222] if os.environ.get("RS_TEST_EXPERIMENTAL") == "1" else []
+import contextlib
+import ctypes
+
+
+@contextlib.contextmanager
+def gemm_knobs(ctx, tile=0, sched=0):
+    """force the GEMM tile height (256 / 192 / 128 / 64; 0 = by shape) and main-loop schedule for the calls inside"""
+    lib = ctx.lib
+    for f in (lib.rs_debug_set_gemm_tile, lib.rs_debug_set_gemm_sched):
+        f.argtypes = [ctypes.c_int]
+        f.restype = None
+    try:
+        lib.rs_debug_set_gemm_tile(tile)
+        lib.rs_debug_set_gemm_sched(sched)
+        yield
+    finally:
+        lib.rs_debug_set_gemm_tile(0)
+        lib.rs_debug_set_gemm_sched(0)
 
 
 @pytest.fixture(scope="module")
@@ -70,14 +84,13 @@ def test_gemm_shapes(ctx, gpu_device, M, N, K):
     assert err <= 2e-3, err
 
 
-@pytest.mark.parametrize("family", ["mfma16x16x32", "mfma32x32x16"])
+@pytest.mark.parametrize("tile", [0, 256, 192, 128, 64])
 @pytest.mark.parametrize("N,K,residual", [(4096, 1024, False), (1024, 4096, True), (1024, 256, True)])
-def test_gemm_big_tiles(ctx, gpu_device, N, K, residual, family):
-    """The benchmark-geometry launches (M = 35 328 - 37 rows: ragged last tile) go to the 256x256 / 192x256
-    kernels, which the small shapes above never select.  Both MFMA families are checked on three row
-    bands (first, middle, ragged tail) against a float32 reference of the bf16-rounded operands, and the
-    rows past M must stay untouched."""
-    import ctypes
+def test_gemm_big_tiles(ctx, gpu_device, N, K, residual, tile):
+    """The benchmark-geometry launches (M = 35 328 - 37 rows: ragged last tile) at every tile height of the kernel (0 =
+    what the launcher picks: 256 rows for the bf16 shapes, 192 for the N = 1024 residual family), checked on three row
+    bands (first, middle, ragged tail) against a float32 reference of the bf16-rounded operands; the rows past M must
+    stay untouched."""
     M = 35328 - 37
     g = torch.Generator().manual_seed(N + K)
     A = rb(torch.randn((M, K), generator=g))
@@ -94,17 +107,10 @@ def test_gemm_big_tiles(ctx, gpu_device, N, K, residual, family):
         ref = torch.nn.functional.silu(ref)
         flags, alpha = capi.GEMM_BIAS | capi.GEMM_SILU, 1.0
         out_full = torch.full((M + 64, N), 7.0, dtype=torch.bfloat16, device=gpu_device)
-    setv = ctx.lib.rs_debug_set_gemm_variant
-    setv.argtypes = [ctypes.c_int]
-    setv.restype = None
-    try:
-        if family == "mfma32x32x16":
-            setv(10 if residual else 2)        # the kernels the default replaced (192x256 residual, 256x256 plain)
+    with gemm_knobs(ctx, tile=tile):
         ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out_full[:M], flags=flags, bias=bias.to(gpu_device),
                  alpha=alpha, residual=res.to(gpu_device) if residual else None)
         sync()
-    finally:
-        setv(0)
     got = out_full[rows.to(gpu_device)].float().cpu()
     tol = 2e-3 + (0.0 if residual else 2.0 ** -8) * ref.abs()      # bf16 output: one rounding of the result
     bad = ((got - ref).abs() > tol)
@@ -112,16 +118,15 @@ def test_gemm_big_tiles(ctx, gpu_device, N, K, residual, family):
     assert (out_full[M:].float() == 7.0).all(), "rows past M were written"
 
 
-@pytest.mark.parametrize("variant", [1062, 1082, 1092, 1060, 1200, 1202, 1210, 1212] + EXPERIMENTAL_GEMM)
-def test_gemm_prefetch_variants(ctx, gpu_device, variant):
-    """12xx: the split-ring kernel (five 32-KiB operand-part slots, B(t+1) issued first, A(t+2) a K tile further ahead,
-    epilogue scratch aliasing the ring; the default); 10xx: its two-K-tile-ring predecessor with the residual chunks of
-    the f32 epilogue requested 1 / 3 / 6 ahead.  All compute the same thing: residual update IN PLACE (out aliases the
-    residual, as in the encoder) for the 192-row variants, SiLU -> bf16 for the 256-row ones, ragged last tile"""
-    import ctypes
+@pytest.mark.parametrize("tile,sched", [(256, 0), (192, 0), (256, 1), (192, 1), (256, 2), (192, 2)])
+def test_gemm_schedules(ctx, gpu_device, tile, sched):
+    """the main-loop schedules of the 256- / 192-row tiles (0 = ping-pong wave groups, two phases per K tile — the
+    default; 1 = no ping-pong, one barrier per K tile; 2 = ping-pong, four phases per K tile) compute the same thing:
+    residual update IN PLACE (out aliases the residual, as in the encoder) for the 192-row tile, SiLU -> bf16 for the
+    256-row one, ragged last tile"""
     M, N, K = 35328 - 37, 1024, 4096
-    residual = variant % 10 == 2
-    g = torch.Generator().manual_seed(variant)
+    residual = tile == 192
+    g = torch.Generator().manual_seed(tile + sched)
     A = rb(torch.randn((M, K), generator=g))
     W = rb(torch.randn((N, K), generator=g) / K ** 0.5)
     bias = torch.randn((N,), generator=g)
@@ -137,15 +142,9 @@ def test_gemm_prefetch_variants(ctx, gpu_device, variant):
         ref = torch.nn.functional.silu(ref)
         out_full = torch.full((M + 64, N), 7.0, dtype=torch.bfloat16, device=gpu_device)
         kw = dict(flags=capi.GEMM_BIAS | capi.GEMM_SILU)
-    setv = ctx.lib.rs_debug_set_gemm_variant
-    setv.argtypes = [ctypes.c_int]
-    setv.restype = None
-    try:
-        setv(variant)
+    with gemm_knobs(ctx, tile=tile, sched=sched):
         ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out_full[:M], bias=bias.to(gpu_device), **kw)
         sync()
-    finally:
-        setv(0)
     got = out_full[rows.to(gpu_device)].float().cpu()
     tol = 2e-3 + (0.0 if residual else 2.0 ** -8) * ref.abs()
     bad = (got - ref).abs() > tol
@@ -153,37 +152,65 @@ def test_gemm_prefetch_variants(ctx, gpu_device, variant):
     assert (out_full[M:].float() == 7.0).all(), "rows past M were written"
 
 
-@pytest.mark.parametrize("variant", [1210, 1212] + EXPERIMENTAL_GEMM)
-@pytest.mark.parametrize("M,N,K", [(4416, 512, 128), (5000, 256, 192), (70, 1024, 320), (2049, 768, 1024)])
-def test_gemm_split_ring_short_k(ctx, gpu_device, M, N, K, variant):
-    """the split-ring kernel at the edges of its schedule: two K tiles (only B(1) is ever issued in the loop), three
+@pytest.mark.parametrize("tile", [256, 192, 128, 64])
+@pytest.mark.parametrize("M,N,K", [(4416, 512, 128), (5000, 256, 192), (70, 1024, 320), (2049, 768, 1024), (300, 640, 64)])
+def test_gemm_split_ring_short_k(ctx, gpu_device, M, N, K, tile):
+    """the split ring at the edges of its schedule: ONE K tile (nothing is issued in the loop), two (only B(1)), three
     (one A(t+2)), five (the slot sequence wraps), ragged rows / columns; f32 output"""
-    import ctypes
     g = torch.Generator().manual_seed(M + N + K)
     A = rb(torch.randn((M, K), generator=g))
     W = rb(torch.randn((N, K), generator=g) / K ** 0.5)
     bias = torch.randn((N,), generator=g)
     ref = A @ W.t() + bias
     out = torch.full((M + 8, N), 7.0, dtype=torch.float32, device=gpu_device)
-    setv = ctx.lib.rs_debug_set_gemm_variant
-    setv.argtypes = [ctypes.c_int]
-    setv.restype = None
-    try:
-        setv(variant)
+    with gemm_knobs(ctx, tile=tile):
         ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out[:M], flags=capi.GEMM_BIAS | capi.GEMM_OUT_F32, bias=bias.to(gpu_device))
         sync()
-    finally:
-        setv(0)
     assert (out[:M].cpu() - ref).abs().max() <= 2e-3
     assert (out[M:] == 7.0).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1060])
+def test_gemm_is_tile_and_batch_invariant(ctx, gpu_device):
+    """The batch-invariance contract of the encoder at the operator: an output row is the same BITS whatever the tile
+    height or schedule, wherever the row sits in the matrix and however many rows ride along (an utterance alone vs
+    inside a batch of 256).  Every epilogue: bf16 + SiLU, f32 residual, GLU."""
+    M, K, d = 35328 - 37, 1024, 1024
+    g = torch.Generator().manual_seed(99)
+    A = bf(torch.randn((M, K), generator=g)).to(gpu_device)
+    W = bf(torch.randn((2 * d, K), generator=g) / K ** 0.5).to(gpu_device)
+    bias = torch.randn((2 * d,), generator=g).to(gpu_device)
+    x = torch.randn((M, d), generator=g).to(gpu_device)
+    lo, n = 20010, 138                       # "one utterance": 138 rows out of the middle of the batch
+
+    def run(a, res, tile, sched):
+        outs = []
+        with gemm_knobs(ctx, tile=tile, sched=sched):
+            o = torch.zeros((a.shape[0], d), dtype=torch.bfloat16, device=gpu_device)
+            ctx.gemm(a, W[:d], o, flags=capi.GEMM_BIAS | capi.GEMM_SILU, bias=bias[:d])
+            outs.append(o)
+            o = res.clone()
+            ctx.gemm(a, W[d:], o, flags=capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32, bias=bias[d:], alpha=0.5, residual=o)
+            outs.append(o)
+            o = torch.zeros((a.shape[0], d), dtype=torch.bfloat16, device=gpu_device)
+            ctx.gemm(a, W, o, flags=capi.GEMM_BIAS | capi.GEMM_GLU, bias=bias)
+            outs.append(o)
+            sync()
+        return outs
+
+    base = run(A, x, 0, 0)
+    for tile, sched in [(256, 0), (192, 0), (128, 0), (64, 0), (256, 1), (192, 2), (256, 2)]:
+        for got, want in zip(run(A, x, tile, sched), base):
+            assert torch.equal(got, want), (tile, sched)
+    alone = run(A[lo:lo + n].contiguous(), x[lo:lo + n].contiguous(), 0, 0)        # picks the 64-row tile on its own
+    for got, want in zip(alone, base):
+        assert torch.equal(got, want[lo:lo + n])
+
+
+@pytest.mark.parametrize("tile", [0, 64, 256])
 @pytest.mark.parametrize("M", [35328 - 37, 300])
-def test_gemm_glu_epilogue(ctx, gpu_device, M, variant):
+def test_gemm_glu_epilogue(ctx, gpu_device, M, tile):
     """RS_GEMM_GLU: value / gate columns interleaved in blocks of 32 (the loader's pw1 row order), GLU applied to the
-    f32 accumulators, bf16 [M][N/2] out.  M = 300 is a problem the heuristics would give to the small-tile kernels:
-    the flag moves it to the big-tile kernel."""
+    f32 accumulators, bf16 [M][N/2] out."""
     from reazonspeech_amd.runtime.weights import glu_interleave_index
     d, K = 1024, 1024
     g = torch.Generator().manual_seed(M)
@@ -195,17 +222,10 @@ def test_gemm_glu_epilogue(ctx, gpu_device, M, variant):
     ref = y[:, :d] * torch.sigmoid(y[:, d:])
     idx = glu_interleave_index(d)
     out = torch.full((M + 64, d), 7.0, dtype=torch.bfloat16, device=gpu_device)
-    import ctypes
-    setv = ctx.lib.rs_debug_set_gemm_variant
-    setv.argtypes = [ctypes.c_int]
-    setv.restype = None
-    try:
-        setv(variant)
+    with gemm_knobs(ctx, tile=tile):
         ctx.gemm(bf(A).to(gpu_device), bf(W[idx]).to(gpu_device), out[:M], flags=capi.GEMM_BIAS | capi.GEMM_GLU,
                  bias=bias[idx].to(gpu_device))
         sync()
-    finally:
-        setv(0)
     got = out[rows.to(gpu_device)].float().cpu()
     bad = (got - ref).abs() > 2e-3 + 2.0 ** -8 * ref.abs()
     assert not bad.any(), (int(bad.sum()), float((got - ref).abs().max()))
@@ -215,7 +235,7 @@ def test_gemm_glu_epilogue(ctx, gpu_device, M, variant):
 
 
 def test_gemm_big_rowmask(ctx, gpu_device):
-    """the subsampling pointwise GEMM at a size that selects the big-tile (persistent) kernel: bias + ReLU + the
+    """the subsampling pointwise GEMM at its benchmark-like size (256-row tiles, N = one tile wide): bias + ReLU + the
     per-utterance row mask (rows of frames at or past an utterance's length are zeroed), ragged last tile"""
     g = torch.Generator().manual_seed(17)
     B, T, Fq, K, N = 37, 275, 20, 256, 256

@@ -83,10 +83,10 @@ def test_frontend_pad_is_folded(gold, gpu_device):
     assert b1.n_ids.cpu().tolist() == b2.n_ids.cpu().tolist()
 
 
-@pytest.mark.parametrize("fuse_glu", [1, 2])
+@pytest.mark.parametrize("fuse_glu", [1, 0])
 def test_encoder_matches_oracle(tiny, gold, fuse_glu):
-    """fuse_glu = 1: what this batch size selects (plain pw1 product, GLU in the depthwise kernel); 2: the conv
-    module's GLU in the pw1 GEMM epilogue (what the big batches run), against the oracle recipe with that rounding"""
+    """fuse_glu = 1 (the default at every batch size): the conv module's GLU in the pw1 GEMM epilogue, against the
+    oracle recipe with that rounding point; 0: plain pw1 product, GLU in the depthwise kernel (the other layout)"""
     model, sd = tiny
     audio, lens = gold["audio"], gold["lengths"]
     model.ctx.set_option("fuse_glu", fuse_glu)
@@ -96,7 +96,7 @@ def test_encoder_matches_oracle(tiny, gold, fuse_glu):
         model.ctx.set_option("fuse_glu", 1)
     taps = {}
     f_ref, el = om.forward_to_joint(TINY, sd, torch.from_numpy(audio), torch.from_numpy(lens),
-                                    "bf16-fused-glu" if fuse_glu == 2 else "bf16", taps)
+                                    "bf16-fused-glu" if fuse_glu == 1 else "bf16", taps)
     assert buf.enc_lens.cpu().tolist() == el.tolist() == gold["hf_enc_lens"].tolist()
     enc, f = enc.cpu(), buf.joint_enc.cpu()
     hf = torch.from_numpy(gold["hf_enc"])
@@ -149,16 +149,40 @@ def test_decode_bit_exact_many_utterances(gpu_device):
 
 
 def test_end_to_end_ids_vs_oracle(tiny, gold):
-    """whole path: ids from the HIP path vs the oracle run end to end in the bf16 recipe.  The
-    encoders differ by bf16 rounding noise, so this is an agreement check on top of the two
-    bit-exact / tolerance checks above; on this fixture they agree exactly."""
+    """whole path: ids from the HIP path vs the oracle run end to end in the same bf16 recipe (GLU in the pw1
+    epilogue).  The encoders differ by f32 accumulation order, which a bf16 rounding can amplify, so greedy ids are an
+    agreement check on top of the bit-exact / tolerance checks above: every difference must be explained by the flip
+    audit (a decision whose oracle margin is below the Lipschitz bound of the measured difference).  On this fixture
+    the ids agree exactly, with the oracle and with the HF golden."""
+    from oracle import audit
     model, sd = tiny
     audio, lens = gold["audio"], gold["lengths"]
-    got = model.transcribe_waveforms([audio[b, :int(lens[b])] for b in range(2)])
-    f_ref, el = om.forward_to_joint(TINY, sd, torch.from_numpy(audio), torch.from_numpy(lens), "bf16")
+    buf, _ = _run_stages(model, audio, lens, want_enc=False)
+    got = model.collect(buf)
+    f_hip = buf.joint_enc.cpu().numpy()
+    f_ref, el = om.forward_to_joint(TINY, sd, torch.from_numpy(audio), torch.from_numpy(lens), "bf16-fused-glu")
     ref = og.rnnt_greedy(TINY, sd, f_ref.numpy(), el.numpy())
-    assert got.ids == [r[0] for r in ref]
-    assert got.ids == [[int(x) for x in gold["hf_ids"][b, :gold["hf_n_ids"][b]]] for b in range(2)]
+    audits = [audit.flip_audit(TINY, sd, f_ref[b].numpy(), f_hip[b], int(el[b]), got.ids[b], got.frames[b]) for b in range(2)]
+    equal = [got.ids[b] == ref[b][0] for b in range(2)]
+    s = audit.summarize(audits, equal)
+    assert s["walk_reproduces_hip_path"] and s["every_id_difference_starts_at_a_flip"], s
+    for a in audits:
+        for fl in a["flips"]:
+            assert fl["margin_ref"] <= fl["bound"] * (1 + 1e-9) + 1e-12, fl
+    hf = [[int(x) for x in gold["hf_ids"][b, :gold["hf_n_ids"][b]]] for b in range(2)]
+    if s["local_flips"] == 0:
+        assert got.ids == [r[0] for r in ref]
+    assert sum(edit_d(got.ids[b], hf[b]) for b in range(2)) <= 2, "HIP ids drifted from the HF golden"
+
+
+def edit_d(a, b):
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
 
 
 def test_batch_invariance(gpu_device):

@@ -159,3 +159,17 @@ def test_reference_import_path_and_console_script():
     assert TranscribeConfig is impl.TranscribeConfig
     assert not os.path.exists(os.path.join(root, "reazonspeech", "__init__.py"))          # namespace package
     assert not os.path.exists(os.path.join(root, "reazonspeech", "nemo", "__init__.py"))
+
+
+def test_alsd_adapter_offset_is_one_documented_constant():
+    """Hypothesis.from_alsd: alignment steps + ALSD_TIMESTAMP_OFFSET; with the default the reference's
+    `step - idx - 1` (decode.py:48) recovers the emission frame, as from_greedy does"""
+    from reazonspeech_amd.nemo.asr import interface as I
+    ids, frames = [7, 8, 9], [0, 10, 10]
+    steps = [f + i for i, f in enumerate(frames)]
+    a = I.Hypothesis.from_alsd(ids, steps, blank_id=99)
+    g = I.Hypothesis.from_greedy(ids, frames, blank_id=99)
+    assert I.ALSD_TIMESTAMP_OFFSET == 1
+    assert a.y_sequence == g.y_sequence and a.timestamp == g.timestamp and a.frames == frames
+    assert [t - i - 1 for i, t in enumerate(a.timestamp)] == frames
+    assert I.Hypothesis.from_alsd(ids, steps, 99, offset=0).timestamp == steps

@@ -231,10 +231,57 @@ def test_sharded_decode_gloo_world2(tmp_path):
         out, calls, counters, empty = torch.load(os.path.join(str(tmp_path), f"s{r}.pt"))
         assert out == want
         assert len(calls) == 1 and counters["collectives"] == 1
-        assert empty == ([], [], [])
+        assert empty == ([], [], [], None)
         seen.append(calls[0])
     assert sorted(seen[0] + seen[1]) == list(range(7)) and len(seen[0]) == 4 and len(seen[1]) == 3
     assert max(lengths[i] for i in seen[0]) <= min(lengths[i] for i in seen[1])   # contiguous in sorted order
+
+
+def _fake_beam_decode(lengths):
+    """like _fake_decode, plus a float32 'score' per utterance (what the beam search returns) with awkward bit patterns"""
+    import numpy as np
+
+    def run_local(indices):
+        ids, frames, el = _fake_decode(lengths)(indices)
+        scores = [float(np.float32(-0.1) * np.float32(lengths[i] % 977) - np.float32(1e-7) * np.float32(i)) for i in indices]
+        return ids, frames, el, scores
+    return run_local
+
+
+def _sharded8_worker(rank, world, port, out_dir):
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    rdist.init("gloo")
+    rng = np.random.default_rng(1235)
+    lengths = rng.integers(2 * 16000, 10 * 16000 + 1, size=2048).tolist()      # BASELINE configs[2]: 2048 = 8 x 256, ragged
+    counters = {}
+    out = rdist.sharded_decode(lengths, _fake_beam_decode(lengths), counters)
+    few = rdist.sharded_decode(lengths[:5], _fake_beam_decode(lengths[:5]))      # 5 utterances on 8 ranks: three empty shards
+    if rank in (0, world - 1):
+        torch.save((out, counters, few), os.path.join(out_dir, f"w{rank}.pt"))
+    rdist.shutdown()
+
+
+def test_sharded_decode_gloo_world8_2048_ragged(tmp_path):
+    """BASELINE configs[2] on 8 CPU ranks: 2048 ragged utterances dealt as 8 length-sorted shards of 256, one
+    all_gather per call, caller order restored, float32 scores bit-exact through the int32 payload, and a call with
+    fewer utterances than ranks (empty shards) still completes with the same answer on every rank"""
+    import numpy as np
+    world, port = 8, _free_port()
+    mp.spawn(_sharded8_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(1235)
+    lengths = rng.integers(2 * 16000, 10 * 16000 + 1, size=2048).tolist()
+    want = rdist.sharded_decode(lengths, _fake_beam_decode(lengths))              # world = 1 path
+    want_few = rdist.sharded_decode(lengths[:5], _fake_beam_decode(lengths[:5]))
+    shards = rdist.shard_by_length(lengths, world)
+    assert [len(s) for s in shards] == [256] * 8
+    assert all(max(lengths[i] for i in shards[r]) <= min(lengths[i] for i in shards[r + 1]) for r in range(7))
+    for r in (0, world - 1):
+        out, counters, few = torch.load(os.path.join(str(tmp_path), f"w{r}.pt"))
+        assert out[0] == want[0] and out[1] == want[1] and out[2] == want[2]
+        assert np.array_equal(np.asarray(out[3], np.float32).view(np.int32), np.asarray(want[3], np.float32).view(np.int32))
+        assert counters["collectives"] == 1
+        assert few[:3] == want_few[:3] and few[3] == want_few[3]
 
 
 # ---- .nemo archives shaped like NeMo writes them (not produced by this repo's write_nemo) -------------------------
