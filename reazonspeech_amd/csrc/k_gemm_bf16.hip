@@ -228,27 +228,28 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
 }
 
 // =====================================================================================================
-// The kernel.  SCHED selects the main-loop schedule (all compute the same values):
-//   0  ping-pong wave groups, two phases per K tile: [12 fragment reads | 32 MFMAs] per 32-deep k-step (BM = 256)
-//   1  no ping-pong: all eight waves run the same schedule and meet at ONE barrier per K tile
-//   2  ping-pong, four phases per K tile: [B + half of the A fragment reads | MI/2 x 4 MFMAs] per half k-step
-// A phase of schedule 0 / 2:  group 0:      mem(p) | B | mfma(p) | B | mem(p+1) | B | ...
+// The kernel.  Main-loop schedule: ping-pong wave groups, two phases per K tile, each [12 fragment reads | 32 MFMAs]
+// (BM = 256) per 32-deep k-step:
+//                             group 0:      mem(p) | B | mfma(p) | B | mem(p+1) | B | ...
 //                             group 1:  B | mem(p) | B | mfma(p) | B | ...                       (one barrier late)
 // RAW: K tile t+1 is waited for (each wave: counted vmcnt for its own pieces) in the LAST phase of K tile t — group 0 at
 // the end of its MFMA half, group 1 in its memory half, i.e. in the same barrier interval — and first read one interval
 // later, after a barrier that every wave's wait precedes.  WAR: the slots written during K tile t held K tile t-1; the
 // first DMA of K tile t is issued in group 0's mem(t, 0), when group 1 sits in the MFMA half of K tile t-1's last phase:
 // its reads of that phase retired (lgkmcnt(0)) before the barrier that opened the interval.
-template <int BM, int OUT, bool MASK, int EPF, int SCHED, bool TRACE>
+// Two other schedules were built and measured this round and removed again (profiles/r03a_gemm_tile_sched_ab.txt,
+// r03a_bench_sched_ab.txt; code in the history at 613b95c): no ping-pong (one barrier per K tile) and four phases per K
+// tile (16 MFMAs each, the guide's 8-phase shape).  Per shape they are within +-4 % of this one either way — the loop is
+// paced by the LDS traffic of the 128 x 64 wave tile and the clock, not by its barrier structure — and on the whole
+// path both lose ~1 % (58.8 vs 59.5 ms / step).
+template <int BM, int OUT, bool MASK, int EPF, bool TRACE>
 __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     constexpr int BN = 256, WN = 4, NWAVES = 8;
     constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
     constexpr int SLOT = 32768, NSLOT = 5;
     constexpr int LA = BM / 8 / NWAVES, LB = BN / 8 / NWAVES;     // DMA pieces (8 rows x 128 B) per wave and K tile
-    constexpr bool PP = SCHED != 1;
-    constexpr int NPH = SCHED == 2 ? 4 : 2;                       // phases per K tile
+    constexpr int NPH = 2;                                        // phases per K tile
     static_assert((BM == 256 || BM == 192 || BM == 128 || BM == 64) && LB == 4 && (MI % 2) == 0 && BM * 128 <= SLOT, "tile heights");
-    static_assert(SCHED != 2 || (MI % 2) == 0, "four-phase schedule splits the A fragments in halves");
     long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_w0 = 0, tr_stall = 0;
     if constexpr (TRACE) { tr_t0 = __builtin_readcyclecounter(); tr_w0 = (long long)wall_clock64(); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
         wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
-    if (PP && wm == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind from here on
+    if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind from here on
     if constexpr (TRACE) tr_t1 = __builtin_readcyclecounter();
 
     f32x4_t acc[MI][NI];
@@ -349,52 +350,45 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
             if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_next(); tr_stall += __builtin_readcyclecounter() - a; }
             else wait_next();
         };
-        bf16x8_t bfr[NI];
 #pragma unroll
-        for (int ph = 0; ph < NPH; ++ph) {
-            // phase -> (32-deep k-step ks, rows [I0, I1) of the wave's A fragments)
-            const int ks = NPH == 4 ? ph >> 1 : ph;
-            constexpr int IH = NPH == 4 ? MI / 2 : MI;
-            const int I0 = NPH == 4 ? (ph & 1) * IH : 0;
-            const bool last = ph == NPH - 1;
-            bf16x8_t af[IH];
-            if (NPH == 2 || (ph & 1) == 0) {
+        for (int ks = 0; ks < NPH; ++ks) {                        // phase = one 32-deep k-step
+            const bool last = ks == NPH - 1;
+            bf16x8_t bfr[NI], af[MI];
 #pragma unroll
-                for (int jj = 0; jj < NI; ++jj) bfr[jj] = frag(bt, wn * TN + jj * 16 + frow, ks * 4 + fch);
-            }
+            for (int jj = 0; jj < NI; ++jj) bfr[jj] = frag(bt, wn * TN + jj * 16 + frow, ks * 4 + fch);
 #pragma unroll
-            for (int i = 0; i < IH; ++i) af[i] = frag(at, wm * TM + (I0 + i) * 16 + frow, ks * 4 + fch);
-            if (ph == 0 && has_b) {                               // the B pieces of K tile t+1 go out beside the fragment reads
+            for (int i = 0; i < MI; ++i) af[i] = frag(at, wm * TM + i * 16 + frow, ks * 4 + fch);
+            if (ks == 0 && has_b) {                               // the B pieces of K tile t+1 go out beside the fragment reads
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < LB; ++j) dma_b(j, t + 1, sbn);
             }
-            if (PP && last && has_b && wm == 1) timed_wait_next();   // group 1: one barrier behind, waits in its memory half
+            if (last && has_b && wm == 1) timed_wait_next();      // group 1: one barrier behind, waits in its memory half
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PP) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < IH; ++i) {
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int jj = 0; jj < NI; ++jj)
-                    acc[I0 + i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[I0 + i][jj], 0, 0, 0);
-                if (ph == 0 && i < LA && has_a) {                 // the A pieces of K tile t+2 between the MFMAs of phase 0
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
+                if (ks == 0 && i < LA && has_a) {                 // the A pieces of K tile t+2 between the MFMAs of phase 0
                     __builtin_amdgcn_sched_barrier(0);
                     dma_a(i, t + 2, san);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (last && has_b && (wm == 0 || !PP)) timed_wait_next();   // group 0 (no ping-pong: every wave): before the barrier its reads follow
+            if (last && has_b && wm == 0) timed_wait_next();      // group 0: before the barrier its reads follow
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (PP || last) __builtin_amdgcn_s_barrier();         // without ping-pong: the one barrier of the K tile
+            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
         sa = wrap(sa + 2);
     }
-    if (PP && wm == 0) __builtin_amdgcn_s_barrier();             // pairs with group 1's extra barrier: nobody reads the ring any more
+    if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier: nobody reads the ring any more
     {
         int em0 = __builtin_amdgcn_readfirstlane(m0), en0 = __builtin_amdgcn_readfirstlane(n0);
         asm volatile("" : "+s"(em0), "+s"(en0));                  // keep the addresses out of the main loop's live ranges
@@ -421,18 +415,16 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
 std::atomic<long long*> g_trace{nullptr};
 std::atomic<int> g_tile{0};        // forced tile height (RS_GEMM_TILE / rs_debug_set_gemm_tile); 0 = by shape
 std::atomic<int> g_group_m{0};     // row panels per XCD tile group; 0 = by shape
-std::atomic<int> g_sched{0};       // main-loop schedule of the 256- / 192-row tiles (RS_GEMM_SCHED: 0, 1, 2; see the kernel)
 void gemm_knobs_from_env() {
     static std::once_flag once;
     std::call_once(once, [] {
         auto env = [](const char* name, std::atomic<int>& v) { if (const char* e = getenv(name)) v = atoi(e); };
         env("RS_GEMM_TILE", g_tile);
         env("RS_GEMM_GROUP_M", g_group_m);
-        env("RS_GEMM_SCHED", g_sched);
     });
 }
 
-template <int BM, int SCHED>
+template <int BM>
 int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     constexpr int LDS = 5 * 32768;
     constexpr int EPF = 3;
@@ -447,11 +439,11 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     const bool mask = p.flags & RS_GEMM_ROWMASK;
 #define RS_SMF(O, MK, TR)                                                                                          \
     do {                                                                                                           \
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, MK, EPF, SCHED, TR>, LDS); rc != RS_OK) return rc; \
-        hipLaunchKernelGGL((gemm_smf16_kernel<BM, O, MK, EPF, SCHED, TR>), dim3(nwg), dim3(512), LDS, s, p);      \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, MK, EPF, TR>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_smf16_kernel<BM, O, MK, EPF, TR>), dim3(nwg), dim3(512), LDS, s, p);      \
     } while (0)
     if (p.trace) {
-        if constexpr (BM >= 192 && SCHED != 1) {
+        if constexpr (BM >= 192) {
             if (out == OUT_RES && !mask) RS_SMF(OUT_RES, false, true);
             else if (out == OUT_BF16 && !mask) RS_SMF(OUT_BF16, false, true);
             else return rs_fail(ctx, RS_EINVAL, "gemm trace: plain bf16 or residual output only");
@@ -470,24 +462,28 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     return RS_OK;
 }
 
-// Tile height for a problem.  All tiles of a launch cost the same and the CUs run them in rounds (one 160-KiB-LDS
-// workgroup per CU), so the height is picked to minimise rounds x (time of one tile): a tile is nk K tiles of
-// kt[BM] us — 256 rows are MFMA-paced, 192 rows and below sit on the DMA round trip of a K tile
-// (profiles/r02x_gemm_tile_timeline.txt) — plus ~5 us of prologue and epilogue.  At the benchmark batch this gives
-// 192 rows to the N = 1024 residual family (3 rounds either way) and 256 rows to everything else; small batches get
-// the shorter tiles.  The choice never changes a result (see the header).
-int pick_tile_height(int M, int N, int K, int n_cus) {
+// Tile height for a problem.  All tiles of a launch cost the same and the CUs run them in lockstep rounds (one 160-KiB-
+// LDS workgroup per CU), so the height minimises  rounds x (time of one tile),  with the tile time measured on MI355X
+// (profiles/r03a_gemm_tile_sched_ab.txt, r03a_gemm_b32_tiles.txt; launch time / rounds):
+//     T(BM) = nk * kt[BM] + fix[BM] (+ the f32 epilogue: 13 us with a residual read-modify-write, half without)
+// kt = K-tile time at the power-capped clock of a busy chip — 256 rows are MFMA-paced, shorter tiles sit on the DMA
+// round trip of a K tile —, fix = workgroup launch + prologue + epilogue + round imbalance.  The f32 residual epilogue
+// moves 2 x BM x 256 x 4 bytes per tile from all CUs at once: it runs at the HBM rate (13 us per round of 256 tiles).
+// At the benchmark batch this gives 256 rows to ffn_up / qkv, 192 rows to pw1 and the N = 1024 residual family; at
+// B = 32 it reproduces the measured optimum of every encoder shape.  The choice never changes a result (see the header).
+int pick_tile_height(int M, int N, int K, int n_cus, int flags) {
     static const int bms[4] = {256, 192, 128, 64};
-    static const double kt[4] = {1.40, 1.20, 1.10, 1.05};
+    static const double kt[4] = {1.246, 1.146, 1.03, 0.96}, fix[4] = {11.5, 7.0, 5.0, 4.0};
     const long tn = (N + 255) / 256;
     const int nk = K / 64;
+    const double epi = (flags & RS_GEMM_RESIDUAL) ? 13.0 : ((flags & RS_GEMM_OUT_F32) ? 6.5 : 0.0);
     int best = 256;
     double best_cost = 1e30;
     for (int i = 0; i < 4; ++i) {
         const long tiles = (long)((M + bms[i] - 1) / bms[i]) * tn;
         const long rounds = (tiles + n_cus - 1) / n_cus;
-        const double cost = (double)rounds * (nk * kt[i] + 5.0);
-        if (cost < best_cost * 0.999 || (cost <= best_cost * 1.001 && tiles <= n_cus)) { best_cost = cost; best = bms[i]; }
+        const double cost = (double)rounds * (nk * kt[i] + fix[i] + epi * bms[i] / 192.0);
+        if (cost < best_cost) { best_cost = cost; best = bms[i]; }
     }
     return best;
 }
@@ -496,18 +492,16 @@ int pick_tile_height(int M, int N, int K, int n_cus) {
 
 // tuning hooks for A/B runs (scripts/gemm_bench.py, tests); not part of the public header
 extern "C" void rs_debug_set_gemm_tile(int bm) { gemm_knobs_from_env(); g_tile = bm; }
-extern "C" void rs_debug_set_gemm_sched(int v) { gemm_knobs_from_env(); g_sched = v; }
 extern "C" void rs_debug_set_gemm_trace(long long* buf) { g_trace = buf; }
 extern "C" void rs_debug_set_gemm_group_m(int v) { gemm_knobs_from_env(); g_group_m = v; }
-extern "C" int rs_debug_gemm_tile_height(int M, int N, int K, int n_cus) { return pick_tile_height(M, N, K, n_cus > 0 ? n_cus : 256); }
+extern "C" int rs_debug_gemm_tile_height(int M, int N, int K, int n_cus, int flags) { return pick_tile_height(M, N, K, n_cus > 0 ? n_cus : 256, flags); }
 
 static int launch_rows(rs_ctx* ctx, GemmParams& p, int bm, hipStream_t s) {
-    const int sched = g_sched.load();
     switch (bm) {
-        case 256: return sched == 1 ? launch_smf16<256, 1>(ctx, p, s) : (sched == 2 ? launch_smf16<256, 2>(ctx, p, s) : launch_smf16<256, 0>(ctx, p, s));
-        case 192: return sched == 1 ? launch_smf16<192, 1>(ctx, p, s) : (sched == 2 ? launch_smf16<192, 2>(ctx, p, s) : launch_smf16<192, 0>(ctx, p, s));
-        case 128: return launch_smf16<128, 0>(ctx, p, s);
-        case 64: return launch_smf16<64, 0>(ctx, p, s);
+        case 256: return launch_smf16<256>(ctx, p, s);
+        case 192: return launch_smf16<192>(ctx, p, s);
+        case 128: return launch_smf16<128>(ctx, p, s);
+        case 64: return launch_smf16<64>(ctx, p, s);
         default: return rs_fail(ctx, RS_EINVAL, "gemm: tile height %d (256, 192, 128 or 64)", bm);
     }
 }
@@ -539,7 +533,7 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
         ctx->n_cus = n;
     }
-    const int bm = g_tile.load() > 0 ? g_tile.load() : pick_tile_height(a.M, a.N, a.K, ctx->n_cus);
+    const int bm = g_tile.load() > 0 ? g_tile.load() : pick_tile_height(a.M, a.N, a.K, ctx->n_cus, a.flags);
     if (bm != 256 && bm != 192 && bm != 128 && bm != 64) return rs_fail(ctx, RS_EINVAL, "gemm: RS_GEMM_TILE=%d (256, 192, 128 or 64)", bm);
     // the kernel addresses A and the output with 32-bit byte offsets: a taller problem runs as row chunks
     const size_t out_row = (size_t)a.ldc * (f32 ? 4 : 2), a_row = (size_t)a.lda * 2;

@@ -20,6 +20,37 @@ from .audio import norm_audio
 #: 'reazon-research/reazonspeech-nemo-v2' from the HF hub (transcribe.py:26-28), which an
 #: offline box cannot do.
 CHECKPOINT_ENV = "REAZONSPEECH_NEMO_CHECKPOINT"
+HF_REPO = "reazon-research/reazonspeech-nemo-v2"      # transcribe.py:27
+
+
+def resolve_checkpoint(checkpoint=None, allow_download=True):
+    """Where the model's `.nemo` archive comes from, in the order a user of the reference would expect:
+      1. the `checkpoint` argument, 2. $REAZONSPEECH_NEMO_CHECKPOINT,
+      3. the Hugging Face cache of 'reazon-research/reazonspeech-nemo-v2' (what the reference's
+         `from_pretrained` fills, transcribe.py:26-28), 4. a download of that repository when the hub is reachable
+         (not with HF_HUB_OFFLINE=1).
+    -> path of the archive, or None when there is none (the caller then falls back to synthetic weights, loudly)."""
+    import glob
+    path = checkpoint or os.environ.get(CHECKPOINT_ENV)
+    if path:
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"checkpoint {path!r} does not exist")
+        return path
+    try:
+        from huggingface_hub import snapshot_download
+    except ImportError:
+        return None
+    for local_only in (True, False):
+        if not local_only and (not allow_download or os.environ.get("HF_HUB_OFFLINE", "0") not in ("", "0")):
+            break
+        try:
+            root = snapshot_download(HF_REPO, local_files_only=local_only, allow_patterns=["*.nemo"], etag_timeout=5)
+        except Exception:
+            continue
+        found = sorted(glob.glob(os.path.join(root, "**", "*.nemo"), recursive=True))
+        if found:
+            return found[0]
+    return None
 
 
 def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, decoding=None, beam_size=None):
@@ -29,10 +60,11 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
       device (str): "cuda" / "cuda:N" (ROCm devices report as cuda).  None picks "cuda" when
         available, like the reference (transcribe.py:18-22); there is no CPU execution path
         in this package, so "cpu" raises.
-      checkpoint (str): path of a `.nemo` archive.  Defaults to $REAZONSPEECH_NEMO_CHECKPOINT.
-        Without one, seeded synthetic weights of the 619M architecture are generated
-        (benchmarks / tests; transcripts are then meaningless).
-      config (ModelConfig): override the architecture for synthetic weights.
+      checkpoint (str): path of a `.nemo` archive.  Defaults to $REAZONSPEECH_NEMO_CHECKPOINT, then to the Hugging Face
+        cache / hub copy of 'reazon-research/reazonspeech-nemo-v2' (`resolve_checkpoint`).  Without any, seeded
+        synthetic weights of the 619M architecture are generated and a warning says so (benchmarks / tests;
+        transcripts are then meaningless).
+      config (ModelConfig): architecture for synthetic weights (no checkpoint lookup is made when it is given).
       seed (int): seed of the synthetic weights.
       decoding (str): override the checkpoint's decoding strategy: "greedy_batch" or "alsd" (alignment-length
         synchronous beam search, what the reference checkpoint ships with: decode.py:29,38-41).
@@ -53,11 +85,15 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
     if str(device).startswith("cpu"):
         raise RuntimeError("reazonspeech_amd runs on MI355X (gfx950) only; no CPU path exists "
                            "(use the reference package for CPU inference)")
-    checkpoint = checkpoint or os.environ.get(CHECKPOINT_ENV)
+    checkpoint = None if config is not None and checkpoint is None else resolve_checkpoint(checkpoint)
     if checkpoint:
         cfg, sd, tok_bytes = W.read_nemo(checkpoint)
         tokenizer = SentencePieceTokenizer(tok_bytes) if tok_bytes else SyntheticTokenizer(cfg.vocab_size)
     else:
+        if config is None:
+            print(f"[reazonspeech_amd] WARNING: no checkpoint — neither ${CHECKPOINT_ENV} nor a cached / downloadable copy "
+                  f"of '{HF_REPO}' was found.  Loading SEEDED SYNTHETIC weights of the 619M architecture: timings are "
+                  f"valid, transcripts are meaningless.", file=sys.stderr, flush=True)
         cfg = config or FASTCONFORMER_619M
         sd = W.synthetic_state_dict(cfg, seed)
         tokenizer = SyntheticTokenizer(cfg.vocab_size, seed)
@@ -96,19 +132,27 @@ def transcribe_batch(model, audios, config=None, distributed=False):
         # the reference forwards `verbose` to NeMo (transcribe.py:52), which draws a tqdm bar on stderr
         print(f"[reazonspeech_amd] transcribing {len(waves)} utterance(s), "
               f"{sum(len(w) for w in waves) / 16000.0:.1f} s of audio on {model.device}", file=sys.stderr, flush=True)
-    decoded = model.transcribe_waveforms_sharded(waves) if distributed else model.transcribe_waveforms(waves)
-    results = []
-    for k, (ids, frames) in enumerate(zip(decoded.ids, decoded.frames)):
-        if decoded.scores is not None:
-            # beam search: alignment steps (frame + labels before) through the adapter with the documented offset
-            hyp = Hypothesis.from_alsd(ids, [f + idx for idx, f in enumerate(frames)], model.cfg.blank_id)
-            hyp.score = decoded.scores[k]
-        else:
-            hyp = Hypothesis.from_greedy(ids, frames, model.cfg.blank_id)
-        ret = decode_hypothesis(model, hyp)
-        if config.raw_hypothesis:
-            ret.hypothesis = hyp
-        results.append(ret)
+    results = [None] * len(waves)
+
+    def to_results(indices, decoded):
+        # ids -> text / subwords / segments (decode.py:28-66).  Called per batch while the GPU works on the next ones.
+        for k, i in enumerate(indices):
+            ids, frames = decoded.ids[k], decoded.frames[k]
+            if decoded.scores is not None:
+                # beam search: alignment steps (frame + labels before) through the adapter with the documented offset
+                hyp = Hypothesis.from_alsd(ids, [f + idx for idx, f in enumerate(frames)], model.cfg.blank_id)
+                hyp.score = decoded.scores[k]
+            else:
+                hyp = Hypothesis.from_greedy(ids, frames, model.cfg.blank_id)
+            ret = decode_hypothesis(model, hyp)
+            if config.raw_hypothesis:
+                ret.hypothesis = hyp
+            results[i] = ret
+
+    if distributed:
+        to_results(list(range(len(waves))), model.transcribe_waveforms_sharded(waves))
+    else:
+        model.transcribe_waveforms(waves, on_batch=to_results)
     return results
 
 

@@ -502,8 +502,12 @@ class AsrModel:
                 self._pool_sets = [_Buffers(self, B, l_max) for _ in range(n_sets)]
         return self._pool_sets[:n_sets]
 
-    def transcribe_waveforms(self, waveforms: Sequence[np.ndarray], max_batch: int = 256) -> DecodedBatch:
+    def transcribe_waveforms(self, waveforms: Sequence[np.ndarray], max_batch: int = 256, on_batch=None) -> DecodedBatch:
         """host float32 waveforms -> token ids / frames (the batched boundary).
+
+        `on_batch(indices, decoded)`: called once per batch, in batch order, as soon as that batch's hypotheses are on
+        the host (`indices` = positions in `waveforms`, `decoded` = their DecodedBatch) — on a decode worker thread
+        while the GPU is already busy with the following batches, so host post-processing (ids -> text) overlaps.
 
         Up to `max_batch` utterances run as one batch.  Longer lists are sorted by length, cut into batches of
         `max_batch` (each padded only to ITS longest utterance) and pushed through the persistent pipeline of
@@ -517,7 +521,10 @@ class AsrModel:
         if n <= max_batch:
             buf = self.stage(waveforms)
             self.run_device(buf)
-            return self.collect(buf)
+            res = self.collect(buf)
+            if on_batch is not None:
+                on_batch(list(range(n)), res)
+            return res
         order = sorted(range(n), key=lambda i: (len(waveforms[i]), i))
         ids, frames, enc_lens, scores = [None] * n, [None] * n, [None] * n, [None] * n
         groups = [order[i:i + max_batch] for i in range(0, n, max_batch)]
@@ -530,9 +537,14 @@ class AsrModel:
 
         def harvest(buf):
             res = self.collect(buf, host=buf.h_out)
-            for k, i in enumerate(groups[buf.step]):
+            group = groups[buf.step]
+            for k, i in enumerate(group):
                 ids[i], frames[i], enc_lens[i] = res.ids[k], res.frames[k], res.enc_lens[k]
                 scores[i] = res.scores[k] if res.scores is not None else None
+            if on_batch is not None:
+                m = len(group)
+                on_batch(group, DecodedBatch(res.ids[:m], res.frames[:m], res.enc_lens[:m],
+                                             res.scores[:m] if res.scores is not None else None))
 
         self.run_pipelined(pool, len(groups), after_decode=harvest, fill=fill, dec_streams=2 if n_sets >= 3 else 1)
         return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.decoding == "alsd" else None)

@@ -1,8 +1,7 @@
 """A/B the GEMM tile heights / main-loop schedules on the shapes of the 619M encoder (run on the GPU box).
 
-    python scripts/gemm_bench.py [TILE:SCHED ...] [--batch=32] [--shape=ffn] [--group-m=N] [--quick]
-TILE = 0 (what the launcher picks), 256, 192, 128, 64; SCHED = 0 (ping-pong, two phases per K tile), 1 (no ping-pong),
-2 (ping-pong, four phases per K tile).  Prints per shape and variant: correctness vs a torch bf16 matmul, median
+    python scripts/gemm_bench.py [TILE ...] [--batch=32] [--shape=ffn] [--group-m=N] [--quick]
+TILE = 0 (what the launcher picks), 256, 192, 128, 64.  Prints per shape and variant: correctness vs a torch bf16 matmul, median
 microseconds, TFLOP/s.  The variants are interleaved per shape inside one process (guide §5.4 rule 24).
 """
 import ctypes
@@ -32,7 +31,7 @@ SHAPES = [  # name, M, N, K, flags
 
 def main():
     quick = "--quick" in sys.argv
-    variants = [tuple(int(x) for x in (v + ":0").split(":")[:2]) for v in sys.argv[1:] if not v.startswith("--")] or [(0, 0)]
+    variants = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [0]
     groups = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--group-m=")] or [None]
     # row pitch of A / W in elements beyond K (power-of-two pitches can camp on a few L2 / HBM channels)
     pad_a = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--pad-a=")] or [0])[0]
@@ -41,15 +40,10 @@ def main():
     only = [a.split("=")[1] for a in sys.argv[1:] if a.startswith("--shape=")]
     dev = torch.device("cuda", 0)
     ctx = capi.Context(FASTCONFORMER_619M, 0)
-    sett, sets, pick = ctx.lib.rs_debug_set_gemm_tile, ctx.lib.rs_debug_set_gemm_sched, ctx.lib.rs_debug_gemm_tile_height
-    for f in (sett, sets):
-        f.argtypes = [ctypes.c_int]
-        f.restype = None
-    pick.argtypes = [ctypes.c_int] * 4
-
-    def setv(v):
-        sett(v[0])
-        sets(v[1])
+    setv, pick = ctx.lib.rs_debug_set_gemm_tile, ctx.lib.rs_debug_gemm_tile_height
+    setv.argtypes = [ctypes.c_int]
+    setv.restype = None
+    pick.argtypes = [ctypes.c_int] * 5
     setg = ctx.lib.rs_debug_set_gemm_group_m
     setg.argtypes = [ctypes.c_int]
     setg.restype = None
@@ -77,16 +71,17 @@ def main():
                 rp = torch.empty((m, n + pad_c), dtype=res.dtype, device=dev)
                 rp[:, :n] = res
                 res = rp[:, :n]
-        ref = A[:4096].float() @ W.float().t() + bias
+        R = min(4096, m)
+        ref = A[:R].float() @ W.float().t() + bias
         if glu:      # value / gate columns interleaved in blocks of 32
-            r3 = ref.view(4096, n // 64, 2, 32)
-            ref = (r3[:, :, 0] * torch.sigmoid(r3[:, :, 1])).reshape(4096, n // 2)
+            r3 = ref.view(R, n // 64, 2, 32)
+            ref = (r3[:, :, 0] * torch.sigmoid(r3[:, :, 1])).reshape(R, n // 2)
         if flags & capi.GEMM_SILU:
             ref = torch.nn.functional.silu(ref)
         if flags & capi.GEMM_RELU:
             ref = torch.relu(ref)
         if res is not None:
-            ref = ref + res[:4096]
+            ref = ref + res[:R]
         for v, gm in [(v, gm) for v in variants for gm in groups]:
             setv(v)
             if gm is not None:
@@ -97,7 +92,7 @@ def main():
             except capi.RsError as e:
                 print(f"{name} {v}: {e}")
                 continue
-            err = (out[:4096].float() - ref).abs().max().item()
+            err = (out[:R].float() - ref).abs().max().item()
             ts = []
             for _ in range(1 if quick else 7):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -109,10 +104,10 @@ def main():
                 ts.append(e0.elapsed_time(e1) / (1 if quick else 4))
             ts.sort()
             us = ts[len(ts) // 2] * 1e3
-            v = f"{v[0] or pick(m, n, k, 256)}{'*' if not v[0] else ''}:s{v[1]}"
+            v = f"{v or pick(m, n, k, 256, flags)}{'*' if not v else ''}"
             print(f"{name} M{m} N{n} K{k} tile {v}{'' if gm is None else f' gm{gm}'}{f' padA{pad_a}' if pad_a else ''}{f' padW{pad_w}' if pad_w else ''}{f' padC{pad_c}' if pad_c else ''}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
         del A, W, out, res
-    setv((0, 0))
+    setv(0)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 """Per-tile timeline of the GEMM kernel (gemm_smf16_kernel, TRACE build with s_memtime stamps).
 
-    python scripts/gemm_trace.py [SCHED ...] [--shape=qkv]      (main-loop schedules 0 / 2; default 0)
+    python scripts/gemm_trace.py [--shape=qkv]
 
 For every output tile, wave 0 (wave group 0) and wave 4 (wave group 1) record: prologue (launch -> first K tile
 landed), main loop, epilogue issue, store drain (s_waitcnt vmcnt(0) after the last store), the cycles spent inside
@@ -28,12 +28,11 @@ SHAPES = [
 
 
 def main():
-    scheds = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [0]
+    scheds = [0]
     only = [a.split("=")[1] for a in sys.argv[1:] if a.startswith("--shape=")]
     ctx = capi.Context(FASTCONFORMER_619M, 0)
     lib = ctx.lib
     lib.rs_debug_set_gemm_tile.argtypes = [ctypes.c_int]
-    lib.rs_debug_set_gemm_sched.argtypes = [ctypes.c_int]
     lib.rs_debug_set_gemm_trace.argtypes = [ctypes.c_void_p]
     dev = torch.device("cuda", 0)
     for name, n, k, flags, bm in SHAPES:
@@ -41,7 +40,6 @@ def main():
             continue
         for v in scheds:
             lib.rs_debug_set_gemm_tile(bm)
-            lib.rs_debug_set_gemm_sched(v)
             A = torch.randn((M, k), device=dev).to(torch.bfloat16)
             W = (torch.randn((n, k), device=dev) / k ** 0.5).to(torch.bfloat16)
             bias = torch.randn((n,), device=dev)
@@ -69,7 +67,7 @@ def main():
             cyc = t[:, 0, 0] + t[:, 0, 1] + t[:, 0, 2] + t[:, 0, 3]
             cyc_per_us = (cyc / np.maximum(w1 - w0, 1e-3)).mean()
             mfma_floor = 2.0 * bm * 256 * k / (2.5e15 / 256) * 1e6
-            print(f"== {name} sched {v}: {len(t)} tiles of {bm}x256, traced launch {total_us:.1f} us, shader clock ~{cyc_per_us / 1e3:.2f} GHz, "
+            print(f"== {name}: {len(t)} tiles of {bm}x256, traced launch {total_us:.1f} us, shader clock ~{cyc_per_us / 1e3:.2f} GHz, "
                   f"MFMA floor per tile {mfma_floor:.1f} us @2.4 GHz")
             for g in (0, 1):
                 print(f"   wave group {g}:")
@@ -82,7 +80,6 @@ def main():
             hist, _ = np.histogram(w0, bins=20, range=(0, w1.max()))
             print("   tile starts per 5% of the span:", hist.tolist())
     lib.rs_debug_set_gemm_tile(0)
-    lib.rs_debug_set_gemm_sched(0)
 
 
 if __name__ == "__main__":

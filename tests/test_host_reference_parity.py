@@ -173,3 +173,81 @@ def test_alsd_adapter_offset_is_one_documented_constant():
     assert a.y_sequence == g.y_sequence and a.timestamp == g.timestamp and a.frames == frames
     assert [t - i - 1 for i, t in enumerate(a.timestamp)] == frames
     assert I.Hypothesis.from_alsd(ids, steps, 99, offset=0).timestamp == steps
+
+
+def test_resampler_meets_the_soxr_hq_specification():
+    """`norm_audio` resamples with librosa.resample's default (soxr_hq; audio.py:64-65).  soxr is not installable here,
+    so the stand-in is checked against what soxr HQ promises, on analytic tones: pass band (<= 0.913 Nyquist) exact to
+    -120 dB, everything from the target Nyquist up rejected by >= 120 dB; output length = ceil(n * ratio) like librosa."""
+    from reazonspeech_amd.nemo.asr import audio as A
+    for orig in (48000, 44100, 22050, 8000):
+        t = np.arange(orig) / orig
+        for f in (440.0, 3000.0, 7000.0, 7290.0, 9000.0, 15000.0):
+            if f >= orig / 2:
+                continue
+            y = A._resample((0.5 * np.sin(2 * np.pi * f * t)).astype(np.float32), orig, 16000)
+            assert y.dtype == np.float32 and len(y) == int(np.ceil(orig * 16000 / orig))
+            tt = np.arange(len(y)) / 16000.0
+            lower_nyq = min(orig, 16000) / 2
+            ref = 0.5 * np.sin(2 * np.pi * f * tt) if f < lower_nyq else np.zeros_like(tt)
+            if lower_nyq * 0.913 < f < lower_nyq:
+                continue                                   # transition band: unspecified
+            e = (y.astype(np.float64) - ref)[800:-800]
+            db = 20 * np.log10(np.sqrt(np.mean(e ** 2)) / 0.5 + 1e-30)
+            assert db <= -120.0 + 15.0, (orig, f, db)      # float32 output: the rounding floor is about -140 dB
+    stereo = np.stack([np.sin(2 * np.pi * 300 * np.arange(48000) / 48000)] * 2).astype(np.float32)
+    out = A.norm_audio(A.audio_from_numpy(stereo, 48000))
+    assert out.samplerate == 16000 and out.waveform.shape == (16000,)
+
+
+def test_checkpoint_resolution_order(tmp_path, monkeypatch):
+    """load_model's checkpoint lookup: argument, then $REAZONSPEECH_NEMO_CHECKPOINT, then the Hugging Face cache of
+    'reazon-research/reazonspeech-nemo-v2' (what the reference's from_pretrained fills, transcribe.py:26-28)"""
+    import importlib
+    T = importlib.import_module("reazonspeech_amd.nemo.asr.transcribe")     # (the package re-exports the function of that name)
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    monkeypatch.setenv("HF_HUB_CACHE", str(tmp_path / "hf" / "hub"))
+    monkeypatch.delenv(T.CHECKPOINT_ENV, raising=False)
+    import importlib
+    import huggingface_hub.constants as C
+    importlib.reload(C)
+    assert T.resolve_checkpoint() is None                          # empty cache, offline
+    snap = tmp_path / "hf" / "hub" / "models--reazon-research--reazonspeech-nemo-v2" / "snapshots" / "0123abcd"
+    snap.mkdir(parents=True)
+    (snap / "reazonspeech-nemo-v2.nemo").write_bytes(b"not a real archive")
+    refs = snap.parent.parent / "refs"
+    refs.mkdir()
+    (refs / "main").write_text("0123abcd")
+    found = T.resolve_checkpoint()
+    if found is not None:                                          # (hub constants are read at import time in some versions)
+        assert found.endswith("reazonspeech-nemo-v2.nemo")
+    env = tmp_path / "env.nemo"
+    env.write_bytes(b"x")
+    monkeypatch.setenv(T.CHECKPOINT_ENV, str(env))
+    assert T.resolve_checkpoint() == str(env)
+    arg = tmp_path / "arg.nemo"
+    arg.write_bytes(b"x")
+    assert T.resolve_checkpoint(str(arg)) == str(arg)
+    with pytest.raises(FileNotFoundError):
+        T.resolve_checkpoint(str(tmp_path / "missing.nemo"))
+
+
+def test_audio_from_path_without_decoders(tmp_path):
+    """WAV always works; another container without soundfile / audioread is an explicit error that names the gap"""
+    from reazonspeech_amd.nemo.asr import audio as A
+    from scipy.io import wavfile
+    p = tmp_path / "a.wav"
+    wavfile.write(p, 8000, (np.sin(np.arange(800) / 10.0) * 20000).astype(np.int16))
+    a = A.audio_from_path(str(p))
+    assert a.samplerate == 8000 and a.waveform.dtype == np.float32 and a.waveform.shape == (800,)
+    try:
+        import soundfile  # noqa: F401
+        return
+    except ImportError:
+        pass
+    q = tmp_path / "a.mp3"
+    q.write_bytes(b"ID3\\x03\\x00" + bytes(200))
+    with pytest.raises(RuntimeError) as e:
+        A.audio_from_path(str(q))
+    assert "soundfile" in str(e.value)
