@@ -45,6 +45,7 @@ struct GemmParams {
     int mask_row0;     // global row index of this launch's row 0 (launches chunked over M: see rs_launch_gemm)
     int tiles_m, tiles_n;
     int group_m;       // row panels per XCD tile group
+    int pairs;         // 1: a workgroup runs two consecutive tiles of its XCD's run (see tiles_of_slot); 0: one tile
     long long* trace;  // debug: per-tile timestamps (scripts/gemm_trace.py); nullptr in production
 };
 
@@ -71,6 +72,19 @@ __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigne
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
+
+// Work split of one XCD's run of `xcount` tiles over its workgroups.  A tile costs ~5 us on top of its own time when it is
+// a workgroup of its own (launch of a 160-KiB-LDS, 512-thread group + the imbalance of a lockstep round:
+// profiles/r03a_gemm_tile_sched_ab.txt), so a workgroup runs TWO consecutive tiles back to back — except in the last
+// round, which is dealt as single tiles so that all 32 CUs of the XCD stay busy to the end:
+//   xcount = 2 * pairs + singles;  singles = xcount mod 64 when that is at most 32 (one more, half-length round), else the
+//   remainder is paired up too.  Slots [0, pairs) run tiles 2s, 2s+1; slots [pairs, pairs + singles) one tile each.
+__host__ __device__ inline void xcd_split(int xcount, int pair_mode, int& n_pairs, int& n_singles) {
+    if (!pair_mode) { n_pairs = 0; n_singles = xcount; return; }
+    const int rem = xcount % 64;
+    n_singles = rem <= 32 ? rem : (xcount & 1);
+    n_pairs = (xcount - n_singles) / 2;
+}
 
 // ---- epilogue (no workgroup barrier: the scratch is per wave, LDS operations of one wave execute in order).
 // bf16 output: chunks of 32 rows x 64 columns; f32: 16 rows x 64 columns; both 4 KiB, 16-byte pieces XOR-swizzled by
@@ -270,10 +284,15 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     const int q8 = nwg >> 3, rr = nwg & 7;
     const int xbase = xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8;
     const int xcount = xcd < rr ? q8 + 1 : q8;
-    if (xslot >= xcount) return;
+    int n_pairs, n_singles;
+    xcd_split(xcount, p.pairs, n_pairs, n_singles);
+    if (xslot >= n_pairs + n_singles) return;
+    const int first_tile = xslot < n_pairs ? 2 * xslot : 2 * n_pairs + (xslot - n_pairs);
+    const int n_my = xslot < n_pairs ? 2 : 1;
+  for (int it = 0; it < n_my; ++it) {
     int m0, n0;
     {
-        const int wg = xbase + xslot;
+        const int wg = xbase + first_tile + it;
         const int per_group = p.group_m * p.tiles_n;
         const int g = wg / per_group, r = wg - g * per_group;
         const int left = p.tiles_m - g * p.group_m;
@@ -401,12 +420,21 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const long long t4 = __builtin_readcyclecounter();
             if (lane == 0 && wn == 0) {
-                long long* tr = p.trace + ((size_t)(xbase + xslot) * 2 + wm) * 8;
+                long long* tr = p.trace + ((size_t)(xbase + first_tile + it) * 2 + wm) * 8;
                 tr[0] = tr_t1 - tr_t0; tr[1] = tr_t2 - tr_t1; tr[2] = t3 - tr_t2; tr[3] = t4 - t3; tr[4] = tr_stall;
                 tr[5] = bid; tr[6] = tr_w0; tr[7] = (long long)wall_clock64();   // 100 MHz, chip-wide
             }
+            tr_t0 = __builtin_readcyclecounter(); tr_w0 = (long long)wall_clock64(); tr_stall = 0;
         }
     }
+    if (it + 1 < n_my) {
+        // second tile of the pair: every wave is done with the ring and with its epilogue scratch (which aliases slot 0)
+        // before anybody's DMA of the next tile lands there.  The epilogue's stores stay in flight: they are older than
+        // the DMAs issued next, vmcnt retires in order, so the counted waits of the next prologue cover them.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+  }
 }
 
 // Process-wide A/B knobs (debug / tuning only; the defaults are the measured winners and nothing in the product path
@@ -415,12 +443,14 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
 std::atomic<long long*> g_trace{nullptr};
 std::atomic<int> g_tile{0};        // forced tile height (RS_GEMM_TILE / rs_debug_set_gemm_tile); 0 = by shape
 std::atomic<int> g_group_m{0};     // row panels per XCD tile group; 0 = by shape
+std::atomic<int> g_pairs{1};       // two tiles per workgroup (RS_GEMM_PAIRS; 0 = one tile per workgroup)
 void gemm_knobs_from_env() {
     static std::once_flag once;
     std::call_once(once, [] {
         auto env = [](const char* name, std::atomic<int>& v) { if (const char* e = getenv(name)) v = atoi(e); };
         env("RS_GEMM_TILE", g_tile);
         env("RS_GEMM_GROUP_M", g_group_m);
+        env("RS_GEMM_PAIRS", g_pairs);
     });
 }
 
@@ -430,7 +460,19 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     constexpr int EPF = 3;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + 255) / 256;
-    const int nwg = p.tiles_m * p.tiles_n;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    p.pairs = g_pairs.load() != 0 && !p.trace;
+    int nwg;                                                      // 8 x the workgroups of the fullest XCD run (the others exit at once)
+    {
+        int np, ns;
+        xcd_split((ntiles + 7) / 8, p.pairs, np, ns);
+        nwg = 8 * (np + ns);
+        if (ntiles % 8 && ntiles > 8) {                           // runs of q and q + 1 tiles: size the grid for the larger need
+            int np2, ns2;
+            xcd_split(ntiles / 8, p.pairs, np2, ns2);
+            if (8 * (np2 + ns2) > nwg) nwg = 8 * (np2 + ns2);
+        }
+    }
     // row panels per XCD tile group (profiles/r02r_gemm_group_m_sweep.txt): N = 1024 (4 weight tiles) likes 2 panels at
     // K = 4096 and 6 below; one-tile-wide problems (the subsampling GEMMs) 16; everything else is flat from 6 up
     p.group_m = g_group_m.load() > 0 ? g_group_m.load()
@@ -494,6 +536,7 @@ int pick_tile_height(int M, int N, int K, int n_cus, int flags) {
 extern "C" void rs_debug_set_gemm_tile(int bm) { gemm_knobs_from_env(); g_tile = bm; }
 extern "C" void rs_debug_set_gemm_trace(long long* buf) { g_trace = buf; }
 extern "C" void rs_debug_set_gemm_group_m(int v) { gemm_knobs_from_env(); g_group_m = v; }
+extern "C" void rs_debug_set_gemm_pairs(int v) { gemm_knobs_from_env(); g_pairs = v; }
 extern "C" int rs_debug_gemm_tile_height(int M, int N, int K, int n_cus, int flags) { return pick_tile_height(M, N, K, n_cus > 0 ? n_cus : 256, flags); }
 
 static int launch_rows(rs_ctx* ctx, GemmParams& p, int bm, hipStream_t s) {

@@ -25,10 +25,10 @@ def main():
         print(f"{short[:64]:<64} {c:>7} {s / 1e6:>10.3f} {a / 1e3:>10.2f} {mn / 1e3:>9.2f} {mx / 1e3:>9.2f} {s / total:>6.1%}")
     if "grid_x" in cols:
         # the GEMM family again, split by launch geometry (= problem shape): workgroups = grid_x / workgroup_x
-        print("\n# GEMM kernels (gemm_mf16_kernel, gemm_bf16_kernel) by launch geometry")
+        print("\n# GEMM kernel (gemm_smf16_kernel) by launch geometry (workgroups; two tiles per workgroup except in the last round)")
         print(f"{'kernel':<64} {'tiles':>7} {'calls':>7} {'avg_us':>10} {'min_us':>9} {'total_ms':>10}")
         q = (f"select {name_col}, grid_x / workgroup_x, count(*), avg(end - start), min(end - start), sum(end - start) "
-             f"from kernels where {name_col} like '%gemm_%16_kernel%' group by {name_col}, grid_x / workgroup_x order by 6 desc")
+             f"from kernels where {name_col} like '%gemm_smf16_kernel%' group by {name_col}, grid_x / workgroup_x order by 6 desc")
         for n, g, c, a, mn, sm in cur.execute(q).fetchall():
             short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             print(f"{short[:64]:<64} {g:>7} {c:>7} {a / 1e3:>10.2f} {mn / 1e3:>9.2f} {sm / 1e6:>10.3f}")

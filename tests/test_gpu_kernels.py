@@ -23,16 +23,20 @@ import ctypes
 
 
 @contextlib.contextmanager
-def gemm_knobs(ctx, tile=0):
-    """force the GEMM tile height (256 / 192 / 128 / 64; 0 = by shape) for the calls inside"""
+def gemm_knobs(ctx, tile=0, pairs=1):
+    """force the GEMM tile height (256 / 192 / 128 / 64; 0 = by shape) and the tiles-per-workgroup mode (1 = pairs, the
+    default; 0 = one tile per workgroup) for the calls inside"""
     lib = ctx.lib
-    lib.rs_debug_set_gemm_tile.argtypes = [ctypes.c_int]
-    lib.rs_debug_set_gemm_tile.restype = None
+    for f in (lib.rs_debug_set_gemm_tile, lib.rs_debug_set_gemm_pairs):
+        f.argtypes = [ctypes.c_int]
+        f.restype = None
     try:
         lib.rs_debug_set_gemm_tile(tile)
+        lib.rs_debug_set_gemm_pairs(pairs)
         yield
     finally:
         lib.rs_debug_set_gemm_tile(0)
+        lib.rs_debug_set_gemm_pairs(1)
 
 
 @pytest.fixture(scope="module")
@@ -159,7 +163,7 @@ def test_gemm_split_ring_short_k(ctx, gpu_device, M, N, K, tile):
 
 def test_gemm_is_tile_and_batch_invariant(ctx, gpu_device):
     """The batch-invariance contract of the encoder at the operator: an output row is the same BITS whatever the tile
-    height, wherever the row sits in the matrix and however many rows ride along (an utterance alone vs
+    height and whether a workgroup runs one tile or two, wherever the row sits in the matrix and however many rows ride along (an utterance alone vs
     inside a batch of 256).  Every epilogue: bf16 + SiLU, f32 residual, GLU."""
     M, K, d = 35328 - 37, 1024, 1024
     g = torch.Generator().manual_seed(99)
@@ -169,9 +173,9 @@ def test_gemm_is_tile_and_batch_invariant(ctx, gpu_device):
     x = torch.randn((M, d), generator=g).to(gpu_device)
     lo, n = 20010, 138                       # "one utterance": 138 rows out of the middle of the batch
 
-    def run(a, res, tile):
+    def run(a, res, tile, pairs=1):
         outs = []
-        with gemm_knobs(ctx, tile=tile):
+        with gemm_knobs(ctx, tile=tile, pairs=pairs):
             o = torch.zeros((a.shape[0], d), dtype=torch.bfloat16, device=gpu_device)
             ctx.gemm(a, W[:d], o, flags=capi.GEMM_BIAS | capi.GEMM_SILU, bias=bias[:d])
             outs.append(o)
@@ -185,12 +189,34 @@ def test_gemm_is_tile_and_batch_invariant(ctx, gpu_device):
         return outs
 
     base = run(A, x, 0)
-    for tile in (256, 192, 128, 64):
-        for got, want in zip(run(A, x, tile), base):
-            assert torch.equal(got, want), tile
+    for tile, pairs in ((256, 1), (192, 1), (128, 1), (64, 1), (0, 0), (256, 0), (192, 0)):
+        for got, want in zip(run(A, x, tile, pairs), base):
+            assert torch.equal(got, want), (tile, pairs)
     alone = run(A[lo:lo + n].contiguous(), x[lo:lo + n].contiguous(), 0)           # picks the 64-row tile on its own
     for got, want in zip(alone, base):
         assert torch.equal(got, want[lo:lo + n])
+
+
+@pytest.mark.parametrize("tiles_m", [1, 2, 7, 8, 9, 16, 33, 64, 65, 257, 511, 520, 771])
+def test_gemm_pairs_cover_every_tile_once(ctx, gpu_device, tiles_m):
+    """two tiles per workgroup: every XCD run length around the pair / single split (empty runs, a lone tile, odd and
+    even runs, exactly one round, one round + 1, several rounds + a short one) writes every output tile exactly once"""
+    bm, N, K = 64, 256, 128
+    M = tiles_m * bm - 5
+    g = torch.Generator().manual_seed(tiles_m)
+    A = rb(torch.randn((M, K), generator=g))
+    W = rb(torch.randn((N, K), generator=g) / K ** 0.5)
+    ref = A @ W.t()
+    outs = []
+    for pairs in (1, 0):
+        out = torch.full((M + 8, N), 7.0, dtype=torch.float32, device=gpu_device)
+        with gemm_knobs(ctx, tile=bm, pairs=pairs):
+            ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out[:M], flags=capi.GEMM_OUT_F32)
+            sync()
+        assert (out[:M].cpu() - ref).abs().max() <= 2e-3, pairs
+        assert (out[M:] == 7.0).all()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("tile", [0, 64, 256])
