@@ -144,10 +144,10 @@ int rs_stream_create(void** stream_out, int device, const uint32_t* cu_mask, int
 int rs_stream_destroy(void* stream);
 
 /* Scheduling options of a context (no reference counterpart).
- *   "gemm_reserved_cus"  compute units the persistent GEMM grid leaves free for work on OTHER streams (the
- *                        two-stage pipeline runs batch i's greedy decode next to batch i+1's encoder; a GEMM
- *                        workgroup owns every register of its CU for the whole launch).  -1 = process default
- *                        ($RS_GEMM_RESERVE_CUS, 0).
+ *   "fuse_glu"           1 (default): the conv module's GLU is applied to the float32 accumulators of the pw1 GEMM in its
+ *                        epilogue, for EVERY batch size (one rounding point: an utterance's arithmetic does not depend on
+ *                        the batch it rides in); 0 = the plain pw1 product is stored and the depthwise kernel applies the
+ *                        GLU (moves one bf16 rounding; A/B and layout tests; $RS_FUSE_GLU).
  *   "decode_screen"      1 (default when the tensors joint.out.w16 / .wrm / .bpad / .wmax are registered): the joint's
  *                        output layer runs as a bf16 screening GEMM followed by an exact float32 evaluation of every
  *                        column that can still be the argmax (bit-identical result); 0 = every column in exact float32.
@@ -225,13 +225,15 @@ int rs_profile_reset(rs_ctx* ctx);
 
 /* ---- single-operator entry points (parity tests call these one by one) -------------------*/
 
-/* C[M][N] = epilogue(A[M][K] . W[N][K]^T); A, W bf16 row-major, K % 64 == 0.
- * flags: see RS_GEMM_* ; bias f32[N]; residual f32[M][ldc] (may alias out when out is f32). */
+/* C[M][N] = epilogue(A[M][K] . W[N][K]^T); A, W bf16 row-major, K % 64 == 0; bf16 output needs N % 8 == 0, f32 N % 4 == 0.
+ * flags: see RS_GEMM_* ; bias f32[N]; residual f32[M][ldc] (may alias out when out is f32); RS_GEMM_ROWMASK combines
+ * with bf16 output only.  One kernel family serves every shape and an output row's bits do not depend on M or on the
+ * tile height the launcher picks (batch invariance of the encoder). */
 enum { RS_GEMM_BIAS = 1, RS_GEMM_RELU = 2, RS_GEMM_SILU = 4, RS_GEMM_RESIDUAL = 8,
        RS_GEMM_OUT_F32 = 16, RS_GEMM_ROWMASK = 32,
        /* out bf16[M][N/2] = (a + bias_a) * sigmoid(g + bias_g): columns 64j .. 64j+31 of the product are values,
         * 64j+32 .. 64j+63 their gates (weight rows interleaved in blocks of 32, see rs_set_tensor); bias only,
-        * N % 64 == 0, K >= 128; always served by the big-tile kernel */
+        * N % 64 == 0 */
        RS_GEMM_GLU = 64 };
 int rs_gemm_bf16(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                  void* out, int ldc, int M, int N, int K, int flags, const float* bias, float alpha,
