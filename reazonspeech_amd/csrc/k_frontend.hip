@@ -80,14 +80,13 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
         // ---- two frames -> bit-reversed LDS order.  A circular shift of the FFT input only changes the
         // phase, so the 400 samples go to slots 0..399 directly.
         float2* z = buf[wave];
-        // The wave walks the LDS slots in order (conflict-free 8-byte stores) and gathers the sample of the bit-reversed
-        // index from the 2-KiB window of the signal its two frames cover (L1-resident): scattering the stores instead put
-        // the 32 lanes of a store group on two banks (16-way conflicts: half of this kernel's LDS cycles, r02z PMC).
+        // (tried this round: walking the LDS slots in order and GATHERING the sample of the bit-reversed index from global
+        // memory instead — the scattered store below puts a 32-lane store group on two banks — made the kernel slower,
+        // 663 -> 963 us: 64 scattered 4-byte loads per instruction cost more than the 16-way conflict.  profiles/r03c_kernel_stats.txt)
 #pragma unroll
         for (int q = 0; q < NFFT / 64; ++q) {
-            const int slot = q * 64 + lane;
-            const int n = bitrev9(slot);
-            z[slot] = make_float2(sample(t, n), sample(t + 1, n));
+            const int n = q * 64 + lane;
+            z[bitrev9(n)] = make_float2(sample(t, n), sample(t + 1, n));
         }
         wave_sync();
         // ---- 9 radix-2 DIT stages, 256 butterflies each (4 per lane)

@@ -45,7 +45,7 @@ struct GemmParams {
     int mask_row0;     // global row index of this launch's row 0 (launches chunked over M: see rs_launch_gemm)
     int tiles_m, tiles_n;
     int group_m;       // row panels per XCD tile group
-    int pairs;         // 1: a workgroup runs two consecutive tiles of its XCD's run (see tiles_of_slot); 0: one tile
+    int pairs;         // > 0: a workgroup runs two consecutive tiles of its XCD's run (xcd_split); 2: the LDS ring carries over; 0: one tile
     long long* trace;  // debug: per-tile timestamps (scripts/gemm_trace.py); nullptr in production
 };
 
@@ -272,7 +272,6 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 15, fch = lane >> 4;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    char* scr = smem + wave * 4096;                               // epilogue scratch aliases slot 0 (the ring is dead by then)
 
     // XCD-aware, bijective tile order: workgroups b, b+8, b+16 .. run on one XCD (private L2); that XCD owns a
     // contiguous run of tiles.  Inside the run tiles are grouped: group_m row panels form a group that is walked
@@ -289,10 +288,14 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     if (xslot >= n_pairs + n_singles) return;
     const int first_tile = xslot < n_pairs ? 2 * xslot : 2 * n_pairs + (xslot - n_pairs);
     const int n_my = xslot < n_pairs ? 2 : 1;
-  for (int it = 0; it < n_my; ++it) {
-    int m0, n0;
-    {
-        const int wg = xbase + first_tile + it;
+    const int nk = p.K / 64;                                      // K tiles, >= 1
+    // The LDS ring keeps running from the first tile of a pair into the second when a tile has at least two K tiles
+    // (p.pairs == 2): the last K tiles of tile 0 already issue the DMAs of tile 1's first K tiles, which land during
+    // tile 0's epilogue, and tile 1 starts without a prologue.  Otherwise every tile restarts the ring (p.pairs == 1).
+    const bool carry = p.pairs == 2 && nk >= 2;
+    const int dr = lane >> 3, dpc = lane & 7;                     // lane = (row l >> 3 of a DMA piece, physical chunk l & 7)
+    auto tile_origin = [&](int j, int& m0, int& n0) {
+        const int wg = xbase + first_tile + j;
         const int per_group = p.group_m * p.tiles_n;
         const int g = wg / per_group, r = wg - g * per_group;
         const int left = p.tiles_m - g * p.group_m;
@@ -300,49 +303,66 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
         const int tile_n = r / gm;
         m0 = (g * p.group_m + (r - tile_n * gm)) * BM;
         n0 = tile_n * BN;
-    }
-    // per-lane byte offsets of this wave's DMA pieces: lane = (row l >> 3 of the piece, physical chunk l & 7);
-    // rows past the matrix are clamped to its last row (their products land in masked outputs)
-    const int dr = lane >> 3, dpc = lane & 7;
-    unsigned off[LA + LB];
-#pragma unroll
-    for (int j = 0; j < LA; ++j) {
-        const int row = (wave + NWAVES * j) * 8 + dr;
-        int gr = m0 + row;
-        gr = gr < p.M ? gr : p.M - 1;
-        off[j] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < LB; ++j) {
-        const int row = (wave * LB + j) * 8 + dr;
-        int gr = n0 + row;
-        gr = gr < p.N ? gr : p.N - 1;
-        off[LA + j] = (unsigned)gr * (unsigned)(p.ldw * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
-    }
-    auto dma_a = [&](int j, int t, int sl) {
-        glds16(off[j], reinterpret_cast<const char*>(p.A) + (size_t)t * 128, lds0 + sl * SLOT + (wave + NWAVES * j) * 1024);
     };
-    auto dma_b = [&](int j, int t, int sl) {
-        glds16(off[LA + j], reinterpret_cast<const char*>(p.W) + (size_t)t * 128, lds0 + sl * SLOT + (wave * LB + j) * 1024);
+    // per-lane byte offsets of this wave's DMA pieces; rows past the matrix are clamped to its last row (their
+    // products land in masked outputs)
+    auto lane_offsets = [&](int m0, int n0, unsigned (&o)[LA + LB]) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int row = (wave + NWAVES * j) * 8 + dr;
+            int gr = m0 + row;
+            gr = gr < p.M ? gr : p.M - 1;
+            o[j] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const int row = (wave * LB + j) * 8 + dr;
+            int gr = n0 + row;
+            gr = gr < p.N ? gr : p.N - 1;
+            o[LA + j] = (unsigned)gr * (unsigned)(p.ldw * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
+        }
     };
     auto frag = [&](const char* part, int row, int chunk) -> bf16x8_t {
         return *reinterpret_cast<const bf16x8_t*>(part + row * 128 + ((chunk ^ swz64(row)) << 4));
     };
+    auto wrap = [](int v) { return v >= NSLOT ? v - NSLOT : v; };
 
-    const int nk = p.K / 64;                                      // K tiles, >= 1
-    // prologue: A(0) -> slot 0, B(0) -> slot 1, A(1) -> slot 2; K tile 0 is complete when all but the last LA landed
+    int m0, n0;
+    unsigned off[LA + LB], offn[LA + LB];
+    tile_origin(0, m0, n0);
+    lane_offsets(m0, n0, off);
+    int sa = 0;                                                   // slot of A(t); B(t) = sa + 1, B(t+1) = sa + 3, A(t+2) = sa + 4 (mod 5)
+  for (int it = 0; it < n_my; ++it) {
+    const bool has_next = carry && it + 1 < n_my;                 // the ring runs on into another tile
+    int m1 = m0, n1 = n0;
+    if (has_next) { tile_origin(it + 1, m1, n1); lane_offsets(m1, n1, offn); }
+    // piece j of K tile k (k >= nk: K tile k - nk of the NEXT tile) into slot sl
+    auto dma_a = [&](int j, int k, int sl) {
+        const bool nx = k >= nk;
+        glds16(nx ? offn[j] : off[j], reinterpret_cast<const char*>(p.A) + (size_t)(nx ? k - nk : k) * 128,
+               lds0 + sl * SLOT + (wave + NWAVES * j) * 1024);
+    };
+    auto dma_b = [&](int j, int k, int sl) {
+        const bool nx = k >= nk;
+        glds16(nx ? offn[LA + j] : off[LA + j], reinterpret_cast<const char*>(p.W) + (size_t)(nx ? k - nk : k) * 128,
+               lds0 + sl * SLOT + (wave * LB + j) * 1024);
+    };
+    if (it == 0 || !carry) {
+        // prologue: A(0) -> slot 0, B(0) -> slot 1, A(1) -> slot 2; K tile 0 is complete when all but the last LA landed
+        sa = 0;
 #pragma unroll
-    for (int j = 0; j < LA; ++j) dma_a(j, 0, 0);
+        for (int j = 0; j < LA; ++j) dma_a(j, 0, 0);
 #pragma unroll
-    for (int j = 0; j < LB; ++j) dma_b(j, 0, 1);
-    if (nk > 1) {
+        for (int j = 0; j < LB; ++j) dma_b(j, 0, 1);
+        if (nk > 1) {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) dma_a(j, 1, 2);
-        wait_vmcnt<LA>();
-    } else {
-        wait_vmcnt<0>();
+            for (int j = 0; j < LA; ++j) dma_a(j, 1, 2);
+            wait_vmcnt<LA>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
     }
-    __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind from here on
     if constexpr (TRACE) tr_t1 = __builtin_readcyclecounter();
 
@@ -354,13 +374,11 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.0f;
 
-    int sa = 0;                                                   // slot of A(t); B(t) = sa + 1, B(t+1) = sa + 3, A(t+2) = sa + 4 (mod 5)
     for (int t = 0; t < nk; ++t) {
-        auto wrap = [](int v) { return v >= NSLOT ? v - NSLOT : v; };
         const int sb = wrap(sa + 1), sbn = wrap(sa + 3), san = wrap(sa + 4);
         const char* at = smem + sa * SLOT;
         const char* bt = smem + sb * SLOT;
-        const bool has_b = t + 1 < nk, has_a = t + 2 < nk;
+        const bool has_b = t + 1 < nk || has_next, has_a = t + 2 < nk || has_next;
         auto wait_next = [&]() {                                  // K tile t + 1 landed; A(t+2) may stay in flight
             if (has_a) wait_vmcnt<LA>();
             else wait_vmcnt<0>();
@@ -407,11 +425,15 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
         }
         sa = wrap(sa + 2);
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier: nobody reads the ring any more
+    if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier: nobody reads this tile's parts any more
     {
         int em0 = __builtin_amdgcn_readfirstlane(m0), en0 = __builtin_amdgcn_readfirstlane(n0);
         asm volatile("" : "+s"(em0), "+s"(en0));                  // keep the addresses out of the main loop's live ranges
         if constexpr (TRACE) tr_t2 = __builtin_readcyclecounter();
+        // Epilogue scratch: 4 KiB per wave in the slot that held this tile's LAST A part.  With the ring carried on,
+        // slots sa .. sa+2 hold the next tile's A(0), B(0), A(1) (landed or in flight); sa+3 (= last A) and sa+4 (= last
+        // B) are dead until the next tile's first K tile issues its DMAs, which happens after the barrier below.
+        char* scr = smem + wrap(sa + 3) * SLOT + wave * 4096;
         smf16_epilogue<MI, NI, OUT, MASK, EPF>(p, acc, scr, em0, en0, wm, wn, lane);
         if constexpr (TRACE) {
             // wave 0 (group 0) and wave 4 (group 1) each write a record: [0] prologue, [1] main loop, [2] epilogue
@@ -428,11 +450,19 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
         }
     }
     if (it + 1 < n_my) {
-        // second tile of the pair: every wave is done with the ring and with its epilogue scratch (which aliases slot 0)
-        // before anybody's DMA of the next tile lands there.  The epilogue's stores stay in flight: they are older than
-        // the DMAs issued next, vmcnt retires in order, so the counted waits of the next prologue cover them.
+        // second tile of the pair: every wave is done with this tile's parts and with its epilogue scratch before
+        // anybody's next DMA lands there.  The epilogue's loads / stores stay in flight: they are younger than the carried
+        // DMAs and older than the ones issued next, vmcnt retires in order, so the counted waits of the next tile cover them.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (has_next) {
+            m0 = m1; n0 = n1;
+#pragma unroll
+            for (int j = 0; j < LA + LB; ++j) off[j] = offn[j];
+        } else {
+            tile_origin(it + 1, m0, n0);
+            lane_offsets(m0, n0, off);
+        }
     }
   }
 }
@@ -443,7 +473,8 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
 std::atomic<long long*> g_trace{nullptr};
 std::atomic<int> g_tile{0};        // forced tile height (RS_GEMM_TILE / rs_debug_set_gemm_tile); 0 = by shape
 std::atomic<int> g_group_m{0};     // row panels per XCD tile group; 0 = by shape
-std::atomic<int> g_pairs{1};       // two tiles per workgroup (RS_GEMM_PAIRS; 0 = one tile per workgroup)
+std::atomic<int> g_pairs{2};       // RS_GEMM_PAIRS: 2 = two tiles per workgroup with the LDS ring carried from the first into the second,
+                                   // 1 = two tiles, the ring restarts, 0 = one tile per workgroup
 void gemm_knobs_from_env() {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -461,7 +492,7 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + 255) / 256;
     const int ntiles = p.tiles_m * p.tiles_n;
-    p.pairs = g_pairs.load() != 0 && !p.trace;
+    p.pairs = p.trace ? 0 : g_pairs.load();
     int nwg;                                                      // 8 x the workgroups of the fullest XCD run (the others exit at once)
     {
         int np, ns;

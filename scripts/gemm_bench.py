@@ -1,7 +1,7 @@
 """A/B the GEMM tile heights / main-loop schedules on the shapes of the 619M encoder (run on the GPU box).
 
     python scripts/gemm_bench.py [TILE[p0|p1] ...] [--batch=32] [--shape=ffn] [--group-m=N] [--quick]
-TILE = 0 (what the launcher picks), 256, 192, 128, 64; suffix p0 = one tile per workgroup, p1 (default) = pairs.  Prints per shape and variant: correctness vs a torch bf16 matmul, median
+TILE = 0 (what the launcher picks), 256, 192, 128, 64; suffix p0 = one tile per workgroup, p1 = pairs (ring restarted), p2 (default) = pairs with the ring carried over.  Prints per shape and variant: correctness vs a torch bf16 matmul, median
 microseconds, TFLOP/s.  The variants are interleaved per shape inside one process (guide §5.4 rule 24).
 """
 import ctypes
@@ -31,7 +31,7 @@ SHAPES = [  # name, M, N, K, flags
 
 def main():
     quick = "--quick" in sys.argv
-    variants = [(int(v.split("p")[0]), int(v.split("p")[1]) if "p" in v else 1) for v in sys.argv[1:] if not v.startswith("--")] or [(0, 1)]
+    variants = [(int(v.split("p")[0]), int(v.split("p")[1]) if "p" in v else 2) for v in sys.argv[1:] if not v.startswith("--")] or [(0, 2)]
     groups = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--group-m=")] or [None]
     # row pitch of A / W in elements beyond K (power-of-two pitches can camp on a few L2 / HBM channels)
     pad_a = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--pad-a=")] or [0])[0]
@@ -112,7 +112,7 @@ def main():
             v = f"{v[0] or pick(m, n, k, 256, flags)}{'*' if not v[0] else ''} p{v[1]}"
             print(f"{name} M{m} N{n} K{k} tile {v}{'' if gm is None else f' gm{gm}'}{f' padA{pad_a}' if pad_a else ''}{f' padW{pad_w}' if pad_w else ''}{f' padC{pad_c}' if pad_c else ''}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
         del A, W, out, res
-    setv((0, 1))
+    setv((0, 2))
 
 
 if __name__ == "__main__":

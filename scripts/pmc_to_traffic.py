@@ -15,11 +15,13 @@ for line in open(src):
     if not m:
         continue
     name, n, rd, wr = m.group(1), int(m.group(2)), float(m.group(3)) * 1e6, float(m.group(4)) * 1e6
+    if name.startswith("gemm_smf16_kernel<64,"):
+        continue            # the 24 position-table projections of model load (64-row tiles): not part of a step
     per[name] = {"launches": n, "read_bytes": rd, "write_bytes": wr}
     tot_n += n
     tot_b += n * (rd + wr)
 out = {
-    "kernel": "all GEMM launches of the encoder (gemm_smf16_kernel: whole-line split-ring kernel; gemm_bf16_kernel: small shapes)",
+    "kernel": "all GEMM launches of one encoder pass at B = 256 (gemm_smf16_kernel, every tile height / epilogue in use)",
     "hbm_bytes_per_launch": round(tot_b / tot_n),
     "per_kernel": per,
     "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-pipeline`; "

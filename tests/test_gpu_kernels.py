@@ -23,9 +23,10 @@ import ctypes
 
 
 @contextlib.contextmanager
-def gemm_knobs(ctx, tile=0, pairs=1):
-    """force the GEMM tile height (256 / 192 / 128 / 64; 0 = by shape) and the tiles-per-workgroup mode (1 = pairs, the
-    default; 0 = one tile per workgroup) for the calls inside"""
+def gemm_knobs(ctx, tile=0, pairs=2):
+    """force the GEMM tile height (256 / 192 / 128 / 64; 0 = by shape) and the tiles-per-workgroup mode (2 = pairs with
+    the LDS ring carried from the first tile into the second, the default; 1 = pairs, ring restarted; 0 = one tile per
+    workgroup) for the calls inside"""
     lib = ctx.lib
     for f in (lib.rs_debug_set_gemm_tile, lib.rs_debug_set_gemm_pairs):
         f.argtypes = [ctypes.c_int]
@@ -36,7 +37,7 @@ def gemm_knobs(ctx, tile=0, pairs=1):
         yield
     finally:
         lib.rs_debug_set_gemm_tile(0)
-        lib.rs_debug_set_gemm_pairs(1)
+        lib.rs_debug_set_gemm_pairs(2)
 
 
 @pytest.fixture(scope="module")
@@ -173,7 +174,7 @@ def test_gemm_is_tile_and_batch_invariant(ctx, gpu_device):
     x = torch.randn((M, d), generator=g).to(gpu_device)
     lo, n = 20010, 138                       # "one utterance": 138 rows out of the middle of the batch
 
-    def run(a, res, tile, pairs=1):
+    def run(a, res, tile, pairs=2):
         outs = []
         with gemm_knobs(ctx, tile=tile, pairs=pairs):
             o = torch.zeros((a.shape[0], d), dtype=torch.bfloat16, device=gpu_device)
@@ -189,7 +190,7 @@ def test_gemm_is_tile_and_batch_invariant(ctx, gpu_device):
         return outs
 
     base = run(A, x, 0)
-    for tile, pairs in ((256, 1), (192, 1), (128, 1), (64, 1), (0, 0), (256, 0), (192, 0)):
+    for tile, pairs in ((256, 2), (192, 2), (128, 2), (64, 2), (0, 1), (256, 1), (192, 1), (0, 0), (256, 0), (192, 0)):
         for got, want in zip(run(A, x, tile, pairs), base):
             assert torch.equal(got, want), (tile, pairs)
     alone = run(A[lo:lo + n].contiguous(), x[lo:lo + n].contiguous(), 0)           # picks the 64-row tile on its own
@@ -197,18 +198,21 @@ def test_gemm_is_tile_and_batch_invariant(ctx, gpu_device):
         assert torch.equal(got, want[lo:lo + n])
 
 
+@pytest.mark.parametrize("K", [64, 128, 320])
 @pytest.mark.parametrize("tiles_m", [1, 2, 7, 8, 9, 16, 33, 64, 65, 257, 511, 520, 771])
-def test_gemm_pairs_cover_every_tile_once(ctx, gpu_device, tiles_m):
+def test_gemm_pairs_cover_every_tile_once(ctx, gpu_device, tiles_m, K):
     """two tiles per workgroup: every XCD run length around the pair / single split (empty runs, a lone tile, odd and
-    even runs, exactly one round, one round + 1, several rounds + a short one) writes every output tile exactly once"""
-    bm, N, K = 64, 256, 128
+    even runs, exactly one round, one round + 1, several rounds + a short one) writes every output tile exactly once —
+    with the ring carried across the pair (K >= 128: two and five K tiles, the slot sequence wraps inside the second
+    tile) and restarted (K = 64: a single K tile cannot carry)"""
+    bm, N = 64, 256
     M = tiles_m * bm - 5
     g = torch.Generator().manual_seed(tiles_m)
     A = rb(torch.randn((M, K), generator=g))
     W = rb(torch.randn((N, K), generator=g) / K ** 0.5)
     ref = A @ W.t()
     outs = []
-    for pairs in (1, 0):
+    for pairs in (2, 1, 0):
         out = torch.full((M + 8, N), 7.0, dtype=torch.float32, device=gpu_device)
         with gemm_knobs(ctx, tile=bm, pairs=pairs):
             ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out[:M], flags=capi.GEMM_OUT_F32)
@@ -216,7 +220,7 @@ def test_gemm_pairs_cover_every_tile_once(ctx, gpu_device, tiles_m):
         assert (out[:M].cpu() - ref).abs().max() <= 2e-3, pairs
         assert (out[M:] == 7.0).all()
         outs.append(out)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("tile", [0, 64, 256])
