@@ -139,9 +139,7 @@ class AsrModel:
         self.device = torch.device("cuda", index)
         self.pad_left = self.pad_right = int(pad_seconds * cfg.sample_rate)   # audio.py:80-82 via decode.py:4
         self._bufs = {}
-        self._ctx_dec = None
-        self._ctx_dec2 = None
-        self._dec2_stream = None
+        self._dec_lanes = []            # [(context, stream)] of the decode lanes beyond what was needed so far
         self._streams = None
         self._streams_prio = None
         self.pos_cap = 0
@@ -159,7 +157,7 @@ class AsrModel:
         self._set_pos_tables(dev["pos.table"])
 
     def _contexts(self):
-        return [c for c in (self.ctx, self._ctx_dec, self._ctx_dec2) if c is not None]
+        return [self.ctx] + [c for c, _ in self._dec_lanes]
 
     def _set_pos_tables(self, table):
         """register the relative-position table (bf16 [2*cap-1][d]) and the derived per-layer tensors: the table
@@ -280,7 +278,8 @@ class AsrModel:
         is fully decoded when this returns.
 
         bufs            resident buffer sets; step i uses bufs[i % len(bufs)] (or what `fill` returned for it) and waits
-                        for that set's previous decode.  Two decode lanes need at least three sets.
+                        for that set's previous decode.  n decode lanes (`dec_streams`; batch i goes to lane i mod n)
+                        need at least n + 1 sets.
         after_decode    `after_decode(buf)` on the decode worker right after batch `buf.step` is decoded (and, with
                         `from_host`, its hypotheses are in `buf.h_out` on the host).  Hooks run in batch order whichever
                         lane finishes first (a hook may issue a collective: every rank has to issue them in the same
@@ -293,37 +292,35 @@ class AsrModel:
         before_encoder  `before_encoder(i)` on the caller's thread right before batch i's encoder is enqueued."""
         nb = len(bufs)
         assert nb >= 2 or steps <= 1, "the pipeline needs two buffer sets"
-        assert dec_streams in (1, 2) and (dec_streams == 1 or nb >= 3), "two decode streams need three buffer sets"
+        assert dec_streams >= 1 and (dec_streams == 1 or nb >= dec_streams + 1), "n decode streams need n + 1 buffer sets"
         from_host = from_host or fill is not None
         with torch.cuda.device(self.device):
             # the decode chain of ONE stream is latency-critical (its workgroups should take the first free slots: high
-            # priority); with two decode lanes it has a whole extra encoder period of slack and normal priority leaves
-            # the GEMM rounds alone (profiles/r02w_bench_ab.txt)
-            dec_prio = int(os.environ.get("RS_DECODE_PRIORITY", "0" if dec_streams == 2 else "-1"))
-            if self._ctx_dec is None:
-                self._ctx_dec = self.ctx.clone()
+            # priority); with several decode lanes each has whole extra encoder periods of slack and normal priority
+            # leaves the GEMM rounds alone (profiles/r02w_bench_ab.txt)
+            dec_prio = int(os.environ.get("RS_DECODE_PRIORITY", "0" if dec_streams >= 2 else "-1"))
             if self._streams is None or self._streams_prio != dec_prio:
-                dec_cus = int(os.environ.get("RS_DECODE_CUS", "0"))
-                if dec_cus > 0:
-                    # decode confined to a slice of the chip (A/B knob): raw HIP stream with a CU mask
-                    self._dec_raw = capi.create_stream(self.device.index, dec_cus, self.ctx.n_cus(), dec_prio)
-                    dec = torch.cuda.ExternalStream(self._dec_raw, device=self.device)
-                else:
-                    dec = torch.cuda.Stream(device=self.device, priority=dec_prio)
                 enc = self._streams[0] if self._streams is not None else torch.cuda.Stream(device=self.device)
-                self._streams = (enc, dec)
+                self._streams = (enc,)
                 self._streams_prio = dec_prio
-                self._dec2_stream = None
-            enc_stream, dec_stream = self._streams
-            self._decode_policy(self._ctx_dec, bufs[0].B, pipelined=True, lanes=dec_streams)
-            dec_lanes = [(self._ctx_dec, dec_stream)]
-            if dec_streams == 2:
-                if self._ctx_dec2 is None:
-                    self._ctx_dec2 = self.ctx.clone()
-                if self._dec2_stream is None:
-                    self._dec2_stream = torch.cuda.Stream(device=self.device, priority=dec_prio)
-                self._decode_policy(self._ctx_dec2, bufs[0].B, pipelined=True, lanes=dec_streams)
-                dec_lanes.append((self._ctx_dec2, self._dec2_stream))
+                self._dec_lanes = [(c, None) for c, _ in self._dec_lanes]       # keep the contexts, remake the streams
+            enc_stream = self._streams[0]
+            dec_cus = int(os.environ.get("RS_DECODE_CUS", "0"))
+            while len(self._dec_lanes) < dec_streams:
+                self._dec_lanes.append((self.ctx.clone(), None))
+            dec_lanes = []
+            for k in range(dec_streams):
+                ctx_d, st = self._dec_lanes[k]
+                if st is None:
+                    if dec_cus > 0:
+                        # decode confined to a slice of the chip (A/B knob): raw HIP stream with a CU mask
+                        raw = capi.create_stream(self.device.index, dec_cus, self.ctx.n_cus(), dec_prio)
+                        st = torch.cuda.ExternalStream(raw, device=self.device)
+                    else:
+                        st = torch.cuda.Stream(device=self.device, priority=dec_prio)
+                    self._dec_lanes[k] = (ctx_d, st)
+                self._decode_policy(ctx_d, bufs[0].B, pipelined=True, lanes=dec_streams)
+                dec_lanes.append((ctx_d, st))
             enc_stream.wait_stream(torch.cuda.current_stream())
             queues = [queue.Queue() for _ in dec_lanes]
             done = [threading.Event() for _ in range(steps)]

@@ -249,6 +249,31 @@ def test_two_decode_streams_equal_sequential(gpu_device):
     assert all(ok for _, ok in order)
 
 
+def test_three_decode_lanes_equal_sequential(gpu_device):
+    """n decode lanes (batch i -> lane i mod n; n + 1 resident batches): same hypotheses as the one-stream path, hooks in
+    batch order"""
+    sd = synthetic_state_dict(TINY, 34, blank_bias=4.0)
+    model = AsrModel(TINY, sd, SyntheticTokenizer(TINY.vocab_size), device="cuda:0")
+    bufs, want = [], []
+    for k in range(4):
+        audio, lens = synthetic_batch(4, 2.5 if k != 2 else 0.8, seed=80 + k, ragged=True, min_seconds=0.5)
+        waves = [audio[b, :lens[b]] for b in range(4)]
+        ref = model.transcribe_waveforms(waves)
+        want.append((ref.ids, ref.frames))
+        bufs.append(model.stage(waves, buf=model.new_buffers(4, 40000)))
+    order = []
+
+    def grab(buf):
+        torch.cuda.current_stream().synchronize()
+        k = [id(b) for b in bufs].index(id(buf))
+        r = model.collect(buf)
+        order.append((buf.step, k, (r.ids, r.frames) == want[k]))
+
+    model.run_pipelined(bufs, 9, after_decode=grab, dec_streams=3)
+    assert [s for s, _, _ in order] == list(range(9)) and [k for _, k, _ in order] == [i % 4 for i in range(9)]
+    assert all(ok for _, _, ok in order)
+
+
 def test_long_list_is_chunked_sorted_and_pipelined(gpu_device):
     """more utterances than max_batch: sorted by length, batches of max_batch through the pipeline,
     results in the caller's order and identical to one-at-a-time decoding"""

@@ -472,3 +472,25 @@ def test_decode_policy_table(monkeypatch):
     assert pick(32, True, 1) == pick(32, True, 2) == pick(32, False) == {"decode_narrow": 1, "decode_screen": 0}
     monkeypatch.setenv("RS_DECODE_SCREEN", "0")
     assert pick(256, True, 2) == {}
+
+
+def test_gemm_tile_height_rule():
+    """the launcher's tile-height rule (host arithmetic inside librs_asr.so, callable without a GPU) gives the choices
+    DESIGN.md §4 documents: 256 rows for ffn_up / qkv and 192 for pw1 and the N = 1024 residual family at the benchmark
+    batch, the measured optimum of every encoder shape at B = 32, 64-row tiles for a lone utterance"""
+    import ctypes
+    from reazonspeech_amd.runtime import capi
+    lib = capi.load()
+    pick = lib.rs_debug_gemm_tile_height
+    pick.argtypes = [ctypes.c_int] * 5
+    pick.restype = ctypes.c_int
+    RES, F32 = capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32 | capi.GEMM_BIAS, capi.GEMM_OUT_F32 | capi.GEMM_BIAS
+    shapes = {"ffn_up": (4096, 1024, capi.GEMM_BIAS | capi.GEMM_SILU), "ffn_down": (1024, 4096, RES), "qkv": (3072, 1024, capi.GEMM_BIAS),
+              "out": (1024, 1024, RES), "pw1": (2048, 1024, capi.GEMM_BIAS | capi.GEMM_GLU), "sub_out": (1024, 2560, F32)}
+    want = {256: dict(ffn_up=256, ffn_down=192, qkv=256, out=192, pw1=192, sub_out=192),
+            32: dict(ffn_up=192, ffn_down=128, qkv=256, out=128, pw1=192, sub_out=128),      # profiles/r03a_gemm_b32_tiles.txt
+            1: dict(ffn_up=64, ffn_down=64, qkv=64, out=64, pw1=64, sub_out=64)}
+    for B, table in want.items():
+        for name, bm in table.items():
+            N, K, flags = shapes[name]
+            assert pick(B * 138, N, K, 256, flags) == bm, (B, name)
