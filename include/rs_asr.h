@@ -153,12 +153,7 @@ int rs_stream_destroy(void* stream);
  *                        column that can still be the argmax (bit-identical result); 0 = every column in exact float32.
  *   "decode_narrow"      1 (default): LSTM / prediction-projection kernels with one 16-column tile per workgroup (4x the
  *                        workgroups, a quarter of the per-launch latency on an idle chip); 0 = the wide-tile kernels, which
- *                        need fewer free CUs per launch and do better next to the encoder GEMMs of the two-stage pipeline.
- *   "decode_persist_wgs" > 0: the whole greedy loop of a batch is ONE persistent launch on that many 512-thread
- *                        workgroups with in-kernel grid barriers between the phases of a step ($RS_DECODE_PERSIST_WGS).
- *                        Bit-identical, but measured SLOWER than one launch per phase (five agent-scope barriers per
- *                        step cost more than five launch boundaries: profiles/r02p_persistent_decode_ab.txt), so the
- *                        default is 0. */
+ *                        need fewer free CUs per launch and do better next to the encoder GEMMs of the two-stage pipeline. */
 int rs_set_option(rs_ctx* ctx, const char* key, int value);
 
 /* Parity taps (tests only; no reference counterpart — NeMo exposes intermediate activations through

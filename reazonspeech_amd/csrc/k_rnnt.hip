@@ -781,11 +781,6 @@ int rs_rnnt_launch_joint_logits(rs_ctx* ctx, const void* st_ptr, const float* jo
 }
 
 // --------------------------------------------------------------------------------------------------
-size_t rs_rnnt_persist_lds_bytes(int J);
-int rs_rnnt_persist_launch(rs_ctx* ctx, const void* st_ptr, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max,
-                           int u_max, int max_steps, int32_t* ids, int32_t* frames, int32_t* n_ids, unsigned* sync, int n_wgs,
-                           hipStream_t s);
-
 size_t rs_rnnt_workspace_bytes(const rs_ctx* ctx, int B) {
     const rs_dims& d = ctx->d;
     const int L = d.pred_layers, H = d.pred_hidden, J = d.joint_hidden;
@@ -838,28 +833,13 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     RS_HIP(ctx, hipMemsetAsync(st.h, 0, 2 * rs_align(state_bytes), s));   // h and c are adjacent
     RS_HIP(ctx, hipMemsetAsync(st.g, 0, (size_t)B * J * 4, s));
     hipLaunchKernelGGL(rnnt_init_kernel, dim3(1), dim3(256), 0, s, st, enc_lens, B, d.blank_id, n_ids);
-    if (!(ctx->decode_persist_wgs > 0 && screen && narrow)) lstm_and_pred(B);  // SOS: blank token, zero state, all rows (the persistent kernel does its own)
+    lstm_and_pred(B);  // SOS: blank token, zero state, all rows
     RS_CHECK_LAUNCH(ctx, "rnnt init");
 
     const int max_steps = tp_max + (u_max < tp_max * d.max_symbols ? u_max : tp_max * d.max_symbols) + 1;
-    // ---- one persistent launch per batch (k_rnnt_persist.hip): needs the screened joint and the narrow-tile weights
-    int persist_wgs = ctx->decode_persist_wgs;
-    if (persist_wgs > 0 && screen && narrow) {
-        unsigned* sync = reinterpret_cast<unsigned*>(st.counters + 8);      // words 8..10 of the 16-word counter block
-        RS_HIP(ctx, hipMemsetAsync(sync, 0, 8 * sizeof(unsigned), s));
-        if (int rc = rs_rnnt_persist_launch(ctx, &st, joint_enc, enc_lens, B, tp_max, u_max, max_steps, ids, frames, n_ids, sync,
-                                            persist_wgs, s); rc != RS_OK) return rc;
-        RS_CHECK_LAUNCH(ctx, "rnnt persistent decode");
-        int32_t hc[16] = {0};
-        RS_HIP(ctx, hipMemcpyAsync(hc, st.counters, sizeof hc, hipMemcpyDeviceToHost, s));
-        RS_HIP(ctx, hipStreamSynchronize(s));
-        rs_prof_end(ctx, RS_PROF_DECODE, s);
-        if (hc[9] != 0) return rs_fail(ctx, RS_ESTATE, "rnnt: grid barrier of the persistent decode kernel timed out");
-        if (hc[1]) return rs_fail(ctx, RS_EOVERFLOW, "rnnt: an utterance emitted more than u_max=%d tokens", u_max);
-        if (hc[2] != 0 && hc[3] != 0) return rs_fail(ctx, RS_ESTATE, "rnnt: decode did not finish in %d steps", max_steps);
-        if (hc[2 + (hc[10] & 1)] != 0) return rs_fail(ctx, RS_ESTATE, "rnnt: decode did not finish in %d steps", max_steps);
-        return RS_OK;
-    }
+    // (the whole loop as ONE persistent launch with agent-scope grid barriers between the phases of a step was built and
+    // measured in round 2 — bit-identical, slower: five barriers per step cost more than five launch boundaries,
+    // profiles/r02p_persistent_decode_ab.txt — and removed this round; k_rnnt_persist.hip is in the history at 6afb282)
     const int CHUNK = 16;
     int32_t host_counters[4] = {0, 0, 0, 0};
     int steps = 0, alive_bound = B;

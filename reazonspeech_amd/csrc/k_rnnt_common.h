@@ -1,5 +1,5 @@
-// k_rnnt_common.h — pieces shared by the decode translation units (k_rnnt.hip: one launch per phase,
-// k_rnnt_persist.hip: one persistent launch per batch).  Both are compiled with -ffp-contract=off.
+// k_rnnt_common.h — pieces shared by the decode translation units (k_rnnt.hip: greedy, k_rnnt_alsd.hip: beam search).
+// Both are compiled with -ffp-contract=off.
 #pragma once
 #include "rs_common.h"
 

@@ -222,7 +222,6 @@ int rs_finalize(rs_ctx* ctx) {
             if (const char* e = getenv("RS_DECODE_SCREEN")) ctx->decode_screen = atoi(e) != 0;     // 0 = exact evaluation of every column
             if (const char* nw = getenv("RS_DECODE_NARROW")) ctx->decode_narrow = atoi(nw) != 0;   // 0 = the wide-tile kernels of round 1
             if (const char* fg = getenv("RS_FUSE_GLU")) ctx->fuse_glu = atoi(fg) != 0;             // 0 = GLU in the conv kernel
-            if (const char* pw = getenv("RS_DECODE_PERSIST_WGS")) ctx->decode_persist_wgs = atoi(pw);   // > 0 = one persistent launch per batch
         }
     }
     auto it = ctx->tensors.find("pos.table");
@@ -268,11 +267,6 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return RS_EINVAL;
     if (!strcmp(key, "decode_screen")) { ctx->decode_screen = value != 0; return RS_OK; }
     if (!strcmp(key, "decode_narrow")) { ctx->decode_narrow = value != 0; return RS_OK; }
-    if (!strcmp(key, "decode_persist_wgs")) {
-        if (value < 0 || value > 256) return rs_fail(ctx, RS_EINVAL, "decode_persist_wgs must be 0 .. 256");
-        ctx->decode_persist_wgs = value;
-        return RS_OK;
-    }
     if (!strcmp(key, "fuse_glu")) {
         if (value < 0 || value > 1) return rs_fail(ctx, RS_EINVAL, "fuse_glu must be 0 or 1");
         ctx->fuse_glu = value;

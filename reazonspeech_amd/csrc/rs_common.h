@@ -95,7 +95,6 @@ struct rs_ctx {
     const float *jout_wrm = nullptr, *jout_bpad = nullptr, *jout_wmax = nullptr;
     bool decode_screen = true;
     bool decode_narrow = true;      // narrow-tile LSTM / projection kernels (k_rnnt.hip)
-    int decode_persist_wgs = 0;     // > 0: the whole decode loop as one persistent launch on that many workgroups (k_rnnt_persist.hip; measured slower: opt-in)
     // position table cache: the caller registers "pos_table.<T>" tensors (bf16 [2T-1][d])
     // options (rs_set_option)
     int n_cus = 0;                  // compute units of the device (queried on first use)

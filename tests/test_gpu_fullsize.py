@@ -230,11 +230,10 @@ def test_encoder_619m_vs_bf16_oracle_with_taps(full, fuse_glu):
 
 
 @pytest.mark.parametrize("options", [dict(decode_screen=0, decode_narrow=0), dict(decode_screen=0, decode_narrow=1),
-                                     dict(decode_screen=1, decode_narrow=0), dict(decode_screen=1, decode_narrow=1),
-                                     dict(decode_persist_wgs=12)])
+                                     dict(decode_screen=1, decode_narrow=0), dict(decode_screen=1, decode_narrow=1)])
 def test_every_decode_kernel_family_is_bit_exact(wide, options):
-    """the four ways the library can run the greedy loop — wide / narrow LSTM tiles, exact / screened joint, one
-    launch per phase / one persistent launch with grid barriers — emit identical ids and frames (the oracle's)"""
+    """the four ways the library can run the greedy loop — wide / narrow LSTM tiles x exact / screened joint — emit
+    identical ids and frames (the oracle's)"""
     model, sd = wide
     cfg = model.cfg
     g = torch.Generator().manual_seed(4)
