@@ -10,8 +10,8 @@
 //
 // HBM-bound by construction: the audio is read once (each sample is touched by ~3 overlapping
 // frames, served by L2), the 257-bin spectrum lives only in LDS, and 80 floats per frame go out.
-// The 512-point FFT is a radix-2 in-LDS transform, one frame per wave; this is integer/float
-// streaming work, deliberately NOT reshaped into a DFT GEMM.
+// The 512-point FFT is an 8 x 8 x 8 register transform with two LDS transposes, two frames per wave; this is
+// integer/float streaming work, deliberately NOT reshaped into a DFT GEMM.
 #include "rs_common.h"
 
 namespace {
@@ -37,14 +37,50 @@ __device__ __forceinline__ float fetch_sample(const float* __restrict__ a, int i
     return (j >= 0 && j < len) ? a[j] : 0.0f;
 }
 
-__device__ __forceinline__ int bitrev9(int v) { return (int)(__brev((unsigned)v) >> 23); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+
+// forward 8-point DFT of eight complex values in registers (three radix-2 decimation-in-frequency stages), natural order out
+__device__ __forceinline__ void dft8(float2 (&a)[8]) {
+    constexpr float S = 0.70710678118654752f;
+    float2 b[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b[j] = make_float2(a[j].x + a[j + 4].x, a[j].y + a[j + 4].y);
+        b[j + 4] = make_float2(a[j].x - a[j + 4].x, a[j].y - a[j + 4].y);
+    }
+    b[5] = make_float2(S * (b[5].x + b[5].y), S * (b[5].y - b[5].x));          // * W8^1 = (1 - i) / sqrt 2
+    b[6] = make_float2(b[6].y, -b[6].x);                                         // * W8^2 = -i
+    b[7] = make_float2(S * (b[7].y - b[7].x), -S * (b[7].x + b[7].y));          // * W8^3 = (-1 - i) / sqrt 2
+    float2 c[8];
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+        c[h + 0] = make_float2(b[h].x + b[h + 2].x, b[h].y + b[h + 2].y);
+        c[h + 2] = make_float2(b[h].x - b[h + 2].x, b[h].y - b[h + 2].y);
+        c[h + 1] = make_float2(b[h + 1].x + b[h + 3].x, b[h + 1].y + b[h + 3].y);
+        const float2 d = make_float2(b[h + 1].x - b[h + 3].x, b[h + 1].y - b[h + 3].y);
+        c[h + 3] = make_float2(d.y, -d.x);                                       // * -i
+    }
+    a[0] = make_float2(c[0].x + c[1].x, c[0].y + c[1].y); a[4] = make_float2(c[0].x - c[1].x, c[0].y - c[1].y);
+    a[2] = make_float2(c[2].x + c[3].x, c[2].y + c[3].y); a[6] = make_float2(c[2].x - c[3].x, c[2].y - c[3].y);
+    a[1] = make_float2(c[4].x + c[5].x, c[4].y + c[5].y); a[5] = make_float2(c[4].x - c[5].x, c[4].y - c[5].y);
+    a[3] = make_float2(c[6].x + c[7].x, c[6].y + c[7].y); a[7] = make_float2(c[6].x - c[7].x, c[6].y - c[7].y);
+}
 
 // One wave transforms TWO frames per 512-point complex FFT (frame t in the real part, t+1 in the
 // imaginary part; the two real spectra are separated afterwards: X_a[k] = (Z[k] + conj Z[N-k]) / 2,
-// X_b[k] = (Z[k] - conj Z[N-k]) / 2i).  Everything a wave touches in LDS is its own, so the stages are
-// separated by wave-level fences, not workgroup barriers; the twiddles are staged once per workgroup.
+// X_b[k] = (Z[k] - conj Z[N-k]) / 2i).  The FFT is 512 = 8 x 8 x 8 (Cooley-Tukey): every lane holds eight complex values
+// and runs three 8-point DFTs in registers, with two transposes through the wave's own LDS buffer between them —
+// three LDS round trips per transform where a radix-2 in-LDS FFT makes nine (that version spent its time in LDS: 51 %
+// bank conflicts, profiles/r02z_pmc_per_kernel.txt).  Layouts (in complex slots; a ds_*_b64 serves 32 lanes per cycle,
+// conflict-free when their slots differ mod 32):
+//   n = l + 64 k:  lane l, element k  -- DFT over k -> y[l][k1], * W512^(l k1) -> slot k1 * 68 + l
+//   lane (k1 = j & 7, l2 = j >> 3) reads y[l2 + 8 l1][k1] -- DFT over l1 -> z[k1][l2][m1], * W64^(l2 m1)
+//                                                                         -> slot m1 * 64 + ((l2 * 8 + k1 + 8 m1) & 63)
+//   lane (k1, m1 = j >> 3) reads z[k1][.][m1] -- DFT over l2 -> Z[k1 + 8 (m1 + 8 m2)] -> slot j + 64 m2 (natural order)
+// Everything a wave touches in LDS is its own, so the steps are separated by wave-level fences, not workgroup
+// barriers; the twiddles are staged once per workgroup.
 __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
-    __shared__ float2 buf[WAVES][NFFT];
+    __shared__ float2 buf[WAVES][8 * 68];
     __shared__ float pw[WAVES][2][NBIN + 3];
     __shared__ float2 tw[NFFT / 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -63,6 +99,11 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
+    // W512^j = (cos, -sin)(2 pi j / 512) for j in [0, 512): the table holds the first half, the second is its negation
+    auto w512 = [&](int j) -> float2 {
+        const float2 w = tw[j & 255];
+        return (j & 256) ? make_float2(-w.x, -w.y) : w;
+    };
     // windowed, pre-emphasised sample n of frame t (0 outside the frame / the padded signal)
     auto sample = [&](int t, int n) -> float {
         if (t >= n_valid || t >= p.t_max || n >= p.win_length) return 0.0f;
@@ -73,46 +114,38 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
         const float y = (i >= 1) ? x0 - p.preemph * x1 : x0;
         return y * p.window[n];
     };
+    const int k1 = lane & 7, hi = lane >> 3;              // (k1, l2) in the second step, (k1, m1) in the third
 
     for (int fi = 0; fi < FRAMES_PER_WAVE; fi += 2) {
         const int t = frame_base + fi;
         if (t >= n_valid || t >= p.t_max) break;          // wave-uniform
-        // ---- two frames -> bit-reversed LDS order.  A circular shift of the FFT input only changes the
-        // phase, so the 400 samples go to slots 0..399 directly.
         float2* z = buf[wave];
-        // (tried this round: walking the LDS slots in order and GATHERING the sample of the bit-reversed index from global
-        // memory instead — the scattered store below puts a 32-lane store group on two banks — made the kernel slower,
-        // 663 -> 963 us: 64 scattered 4-byte loads per instruction cost more than the 16-way conflict.  profiles/r03c_kernel_stats.txt)
+        // ---- step 1: two frames, samples n = lane + 64 k.  A circular shift of the FFT input only changes the phase,
+        // so the 400 samples sit at n = 0 .. 399 directly.
+        float2 v[8];
 #pragma unroll
-        for (int q = 0; q < NFFT / 64; ++q) {
-            const int n = q * 64 + lane;
-            z[bitrev9(n)] = make_float2(sample(t, n), sample(t + 1, n));
-        }
+        for (int k = 0; k < 8; ++k) v[k] = make_float2(sample(t, lane + 64 * k), sample(t + 1, lane + 64 * k));
+        dft8(v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) z[q * 68 + lane] = q ? cmul(v[q], w512(lane * q)) : v[q];
         wave_sync();
-        // ---- 9 radix-2 DIT stages, 256 butterflies each (4 per lane)
+        // ---- step 2: DFT over l1 for (k1, l2)
 #pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            const int half = 1 << s;
-            float2 u[4], v[4], w[4];
-            int i0[4];
+        for (int l1 = 0; l1 < 8; ++l1) v[l1] = z[k1 * 68 + hi + 8 * l1];
+        wave_sync();                                       // every lane has its eight values before the buffer is rewritten
+        dft8(v);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int tb = q * 64 + lane;
-                const int pos = tb & (half - 1);
-                i0[q] = ((tb >> s) << (s + 1)) + pos;
-                w[q] = tw[pos << (8 - s)];
-                u[q] = z[i0[q]];
-                v[q] = z[i0[q] + half];
-            }
+        for (int m1 = 0; m1 < 8; ++m1)
+            z[m1 * 64 + ((hi * 8 + k1 + 8 * m1) & 63)] = m1 ? cmul(v[m1], w512(8 * hi * m1)) : v[m1];
+        wave_sync();
+        // ---- step 3: DFT over l2 for (k1, m1): Z[k1 + 8 (m1 + 8 m2)] = natural slot lane + 64 m2
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float tr = v[q].x * w[q].x - v[q].y * w[q].y;
-                const float ti = v[q].x * w[q].y + v[q].y * w[q].x;
-                z[i0[q]] = make_float2(u[q].x + tr, u[q].y + ti);
-                z[i0[q] + half] = make_float2(u[q].x - tr, u[q].y - ti);
-            }
-            wave_sync();
-        }
+        for (int l2 = 0; l2 < 8; ++l2) v[l2] = z[hi * 64 + ((l2 * 8 + k1 + 8 * hi) & 63)];
+        wave_sync();
+        dft8(v);
+#pragma unroll
+        for (int m2 = 0; m2 < 8; ++m2) z[lane + 64 * m2] = v[m2];
+        wave_sync();
         // ---- split the two spectra, power of bins 0..256
         for (int k = lane; k < NBIN; k += 64) {
             const float2 zk = z[k], zn = z[(NFFT - k) & (NFFT - 1)];
