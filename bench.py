@@ -209,16 +209,12 @@ def extra_configs(model, cfg, sd, args, host_sets):
     n_sets = len(host_sets)
     # BASELINE configs[1]: batch 32 x 10 s on one GPU
     try:
-        # a batch of 32 decodes in ~20 ms but its encoder takes ~9: three decode lanes (five resident batches) keep
-        # the encoder stream busy
-        lanes32 = 3
-        bufs32, lens32, _ = resident_sets(model, 32, args.seconds, lanes32 + 2, 4321)
-        dt = timed_pipeline(model, bufs32, 30, 5, lanes32)
-        out["b32"] = {"workload": f"32 x 10 s per step (BASELINE configs[1]), HBM-resident, pipelined, {lanes32} decode lanes",
-                      "value": round(sum(float(lens32[i % len(bufs32)].sum()) for i in range(30)) / 16000.0 / dt, 1),
+        # (three decode lanes were tried for this decode-bound size and lose: 14.1 vs 12.1 ms/step, profiles/r03e_bench.json)
+        bufs32, lens32, _ = resident_sets(model, 32, args.seconds, n_sets, 4321)
+        dt = timed_pipeline(model, bufs32, 30, 5, args.dec_streams)
+        out["b32"] = {"workload": "32 x 10 s per step (BASELINE configs[1]), HBM-resident, pipelined",
+                      "value": round(sum(float(lens32[i % n_sets].sum()) for i in range(30)) / 16000.0 / dt, 1),
                       "ms_per_step": round(dt / 30 * 1e3, 3)}
-        dt2 = timed_pipeline(model, bufs32[:4], 30, 5, 2)
-        out["b32"]["ms_per_step_two_lanes"] = round(dt2 / 30 * 1e3, 3)
         del bufs32
     except Exception as e:
         out["b32"] = {"error": repr(e)}
