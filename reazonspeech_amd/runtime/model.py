@@ -532,16 +532,43 @@ class AsrModel:
         def fill(i, buf):
             return self.fill_host([waveforms[k] for k in groups[i]], buf)
 
+        # `on_batch` runs on its own thread, in batch order: a decode lane that ran the caller's post-processing itself
+        # would start its next batch that much later (ids -> text is ~25 ms of Python per 256 utterances)
+        post_q = queue.Queue() if on_batch is not None else None
+        post_err = []
+
+        def post_worker():
+            while True:
+                item = post_q.get()
+                if item is None:
+                    return
+                try:
+                    if not post_err:
+                        on_batch(*item)
+                except Exception as e:          # surfaced on the caller's thread below
+                    post_err.append(e)
+
         def harvest(buf):
             res = self.collect(buf, host=buf.h_out)
             group = groups[buf.step]
             for k, i in enumerate(group):
                 ids[i], frames[i], enc_lens[i] = res.ids[k], res.frames[k], res.enc_lens[k]
                 scores[i] = res.scores[k] if res.scores is not None else None
-            if on_batch is not None:
+            if post_q is not None:
                 m = len(group)
-                on_batch(group, DecodedBatch(res.ids[:m], res.frames[:m], res.enc_lens[:m],
-                                             res.scores[:m] if res.scores is not None else None))
+                post_q.put((group, DecodedBatch(res.ids[:m], res.frames[:m], res.enc_lens[:m],
+                                                res.scores[:m] if res.scores is not None else None)))
 
-        self.run_pipelined(pool, len(groups), after_decode=harvest, fill=fill, dec_streams=2 if n_sets >= 3 else 1)
+        post = None
+        if post_q is not None:
+            post = threading.Thread(target=post_worker, daemon=True)
+            post.start()
+        try:
+            self.run_pipelined(pool, len(groups), after_decode=harvest, fill=fill, dec_streams=2 if n_sets >= 3 else 1)
+        finally:
+            if post is not None:
+                post_q.put(None)
+                post.join()
+        if post_err:
+            raise post_err[0]
         return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.decoding == "alsd" else None)
