@@ -21,6 +21,8 @@ constexpr int NBIN = 257;
 constexpr int FB_MAXW = 32;          // widest Slaney filter has 18 taps at 80 mels / 512 fft
 constexpr int WAVES = 4;
 constexpr int FRAMES_PER_WAVE = 4;   // frames per block = 16
+constexpr int MAX_HOP = 256;         // the workgroup's span of the signal is staged in LDS: (frames per block - 1) * hop + n_fft samples
+constexpr int SPAN_MAX = (WAVES * FRAMES_PER_WAVE - 1) * MAX_HOP + NFFT;
 
 struct FrontParams {
     const float* audio; const int32_t* lens; float* raw; int32_t* n_frames;
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
     __shared__ float2 buf[WAVES][8 * 68];
     __shared__ float pw[WAVES][2][NBIN + 3];
     __shared__ float2 tw[NFFT / 2];
+    __shared__ float ys[SPAN_MAX];
+    __shared__ float win_s[NFFT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int len = p.lens[b];
@@ -92,9 +96,26 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
     const float* a = p.audio + (size_t)b * p.audio_stride;
     if ((int)blockIdx.x * WAVES * FRAMES_PER_WAVE >= min(n_valid, p.t_max)) return;  // block-uniform
     tw[threadIdx.x] = reinterpret_cast<const float2*>(p.twiddle)[threadIdx.x];      // 256 threads, 256 twiddles
+    // The padded, pre-emphasised signal under this workgroup's 16 frames goes through LDS once (coalesced loads; the
+    // samples of a frame were fetched lane by lane before: 48 small loads per lane and transform) together with the
+    // window, zero beyond its length.  Index i runs in the PADDED signal (reference: after pad_audio); everything
+    // outside [0, Lp) is zero, and y[0] = x[0] has no predecessor.
+    const int centre_off = (NFFT - p.win_length) / 2;     // 56: window centred in the 512 frame
+    const int f0 = blockIdx.x * WAVES * FRAMES_PER_WAVE;
+    const int i_base = f0 * p.hop - NFFT / 2 + centre_off;
+    const int span = (WAVES * FRAMES_PER_WAVE - 1) * p.hop + NFFT;
+    for (int idx = threadIdx.x; idx < span; idx += blockDim.x) {
+        const int i = i_base + idx;
+        float y = 0.0f;
+        if (i >= 0 && i < Lp) {
+            const float x0 = fetch_sample(a, i, p.pad_left, len);
+            y = i >= 1 ? x0 - p.preemph * fetch_sample(a, i - 1, p.pad_left, len) : x0;
+        }
+        ys[idx] = y;
+    }
+    for (int idx = threadIdx.x; idx < NFFT; idx += blockDim.x) win_s[idx] = idx < p.win_length ? p.window[idx] : 0.0f;
     __syncthreads();
     const int frame_base = (blockIdx.x * WAVES + wave) * FRAMES_PER_WAVE;
-    const int centre_off = (NFFT - p.win_length) / 2;     // 56: window centred in the 512 frame
     auto wave_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -104,15 +125,10 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
         const float2 w = tw[j & 255];
         return (j & 256) ? make_float2(-w.x, -w.y) : w;
     };
-    // windowed, pre-emphasised sample n of frame t (0 outside the frame / the padded signal)
+    // windowed, pre-emphasised sample n of frame t (0 for a frame past the utterance)
     auto sample = [&](int t, int n) -> float {
-        if (t >= n_valid || t >= p.t_max || n >= p.win_length) return 0.0f;
-        const int i = t * p.hop - NFFT / 2 + centre_off + n;  // index in the padded signal
-        if (i < 0 || i >= Lp) return 0.0f;
-        const float x0 = fetch_sample(a, i, p.pad_left, len);
-        const float x1 = (i >= 1) ? fetch_sample(a, i - 1, p.pad_left, len) : 0.0f;
-        const float y = (i >= 1) ? x0 - p.preemph * x1 : x0;
-        return y * p.window[n];
+        if (t >= n_valid || t >= p.t_max) return 0.0f;
+        return ys[(t - f0) * p.hop + n] * win_s[n];
     };
     const int k1 = lane & 7, hi = lane >> 3;              // (k1, l2) in the second step, (k1, m1) in the third
 
@@ -256,8 +272,8 @@ int rs_launch_frontend(rs_ctx* ctx, const float* audio, const int32_t* lens, int
     const rs_dims& d = ctx->d;
     if (B <= 0 || t_max <= 0) return RS_OK;
     if (d.n_fft != NFFT) return rs_fail(ctx, RS_EINVAL, "frontend: only n_fft=512 is built");
-    if (d.n_mels > 128 || d.n_mels % 4 || d.win_length > NFFT)
-        return rs_fail(ctx, RS_EINVAL, "frontend: n_mels must be a multiple of 4 up to 128, win<=512");
+    if (d.n_mels > 128 || d.n_mels % 4 || d.win_length > NFFT || d.hop_length < 1 || d.hop_length > MAX_HOP)
+        return rs_fail(ctx, RS_EINVAL, "frontend: n_mels must be a multiple of 4 up to 128, win <= 512, hop <= %d", MAX_HOP);
     FrontParams p;
     p.audio = audio; p.lens = lens; p.raw = raw; p.n_frames = n_frames;
     p.window = ctx->fe_window; p.twiddle = ctx->fe_twiddle; p.fb_idx = ctx->fe_fb_idx; p.fb_w = ctx->fe_fb_w;
