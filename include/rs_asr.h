@@ -105,6 +105,15 @@ size_t rs_workspace_bytes(const rs_ctx* ctx, int B, int max_samples);
 int rs_mel_frames(const rs_ctx* ctx, int n_samples);   /* floor(L / hop) */
 int rs_enc_frames(const rs_ctx* ctx, int n_mel_frames); /* three k3 s2 p1 convs */
 
+/* ---- host staging (A4: `torch.from_numpy` + list wrap, transcribe.py:46-50, for a whole batch) -------------------
+ * Pure host function, no device work: gathers `n_rows` utterances (host float32, 16 kHz mono, un-padded) into the
+ * caller's pinned staging matrix dst[total_rows][dst_pitch], zero-filling every row from its length up to `width`
+ * (the batch's padded extent) and writing the lengths (0 for rows n_rows .. total_rows - 1: a short last batch).
+ * One call per batch instead of one interpreter-level copy per utterance: a Python binding releases its interpreter lock
+ * for the call, so the staging of batch i+2 does not contend with host post-processing of batch i. */
+int rs_host_stage_rows(float* dst, size_t dst_pitch, int width, const float* const* rows, const int32_t* lens,
+                       int n_rows, int total_rows, int32_t* dst_lens);
+
 /* ---- stage 1: log-mel front-end -------------------------------------------------------
  * Replaces: pad_audio (pkg/nemo-asr/src/audio.py:70-83, folded into the load: the kernel
  * reads `audio[b][i - pad_left]` and treats everything outside [0, lens[b]) as 0) and NeMo's

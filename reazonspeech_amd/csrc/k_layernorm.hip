@@ -283,11 +283,83 @@ __global__ __launch_bounds__(256) void glu_dwconv_silu_fast_kernel(const uint16_
     }
 }
 
+// The already-gated layout ([M][d] bf16: the GLU was applied by the pw1 GEMM epilogue — the product default) needs no
+// arithmetic while staging, so its rows go HBM -> LDS as they are, by global_load_lds_dwordx4 (a wave instruction copies
+// two 512-byte rows of the 256-channel tile; no VGPR round trip, no float conversion, half the LDS bytes of the f32
+// tile above and conflict-free 16-byte reads).  Zero padding / the frame mask are applied when a row is read.
+template <int K, int R>
+__global__ __launch_bounds__(256) void dwconv_silu_dma_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, const int32_t* __restrict__ lens,
+                                                              int T, int d, uint16_t* __restrict__ out) {
+    constexpr int TTF = 8 * R, ROWS = TTF + K - 1, HALF = (K - 1) / 2;
+    static_assert(ROWS % 2 == 0, "a DMA instruction copies two rows");
+    __shared__ __attribute__((aligned(16))) uint16_t tile[ROWS * CT];
+    const int b = blockIdx.z, c0 = blockIdx.y * CT, t0 = blockIdx.x * TTF;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int len = lens[b];
+    const int c = c0 + cg * 8;
+    for (int inst = wave; inst < ROWS / 2; inst += 4) {           // wave-uniform trip count
+        const int r = 2 * inst + (lane >> 5);
+        int t = t0 + r - HALF;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);                     // clamped address, masked at the read
+        const uint16_t* src = x + ((size_t)b * T + t) * d + c0 + (lane & 31) * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tile + inst * 2 * CT), 16, 0, 0);
+    }
+    float wt[K][8];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        *reinterpret_cast<float4*>(&wt[j][0]) = *reinterpret_cast<const float4*>(w + (size_t)j * d + c);
+        *reinterpret_cast<float4*>(&wt[j][4]) = *reinterpret_cast<const float4*>(w + (size_t)j * d + c + 4);
+    }
+    float acc[R][8];
+    {
+        float bb[8];
+        *reinterpret_cast<float4*>(&bb[0]) = *reinterpret_cast<const float4*>(bias + c);
+        *reinterpret_cast<float4*>(&bb[4]) = *reinterpret_cast<const float4*>(bias + c + 4);
+#pragma unroll
+        for (int o = 0; o < R; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = bb[e];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's rows landed; the barrier covers the others'
+    __syncthreads();
+#pragma unroll
+    for (int row = 0; row < R + K - 1; ++row) {
+        const int t = t0 + tl * R + row - HALF;
+        const bool ok = t >= 0 && t < T && t < len;
+        const u16x8_t a = *reinterpret_cast<const u16x8_t*>(tile + (tl * R + row) * CT + cg * 8);
+        float xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = ok ? bf16_to_f32(a[e]) : 0.0f;
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            const int j = row - o;               // tap index, compile-time after unrolling
+            if (j >= 0 && j < K) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(xv[e], wt[j][e], acc[o][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+        const int t = t0 + tl * R + o;
+        if (t < T) {
+            u16x8_t ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16(silu_f(acc[o][e]));
+            *reinterpret_cast<u16x8_t*>(out + ((size_t)b * T + t) * d + c) = ov;
+        }
+    }
+}
+
 int g_glu_generic = 0;
 
 }  // namespace
 
-// A/B hook (scripts/glu_bench.py): force the generic any-kernel-size path
+// A/B hook (scripts/elementwise_bench.py): 1 = the generic any-kernel-size path, 2 = the f32-tile fast kernel also for the
+// gated layout (instead of the DMA-staged one)
 extern "C" void rs_debug_set_glu_generic(int v) { g_glu_generic = v; }
 
 int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float* b, int M, int d, float eps,
@@ -331,7 +403,7 @@ int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, int layout, const float
     if (layout < 0 || layout > 2) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: unknown input layout %d", layout);
     const double bytes = (double)B * T * d * ((layout == 2 ? 2.0 : 4.0) + 2.0);
     rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, (double)B * T * d * (2.0 * k + 12.0), bytes);
-    if (k == 9 && !g_glu_generic) {
+    if (k == 9 && g_glu_generic != 1) {
         // register-window fast path (the FastConformer kernel size); 48-frame tiles
         constexpr int R = 6, TTF = 8 * R;
         const dim3 grid((T + TTF - 1) / TTF, d / CT, B), block(256);
@@ -343,7 +415,8 @@ int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, int layout, const float
         } while (0)
         if (layout == 0) RS_GLU_FAST(0);
         else if (layout == 1) RS_GLU_FAST(1);
-        else RS_GLU_FAST(2);
+        else if (g_glu_generic == 2) RS_GLU_FAST(2);          // A/B: the f32-tile kernel on the gated layout
+        else hipLaunchKernelGGL((dwconv_silu_dma_kernel<9, R>), grid, block, 0, s, x, w, b, lens, T, d, out);
 #undef RS_GLU_FAST
     } else {
         const dim3 grid((T + TT - 1) / TT, d / CT, B), block(256);

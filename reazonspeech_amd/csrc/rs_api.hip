@@ -339,6 +339,22 @@ size_t rs_workspace_bytes(const rs_ctx* ctx, int B, int max_samples) {
     return m > dec ? m : dec;
 }
 
+int rs_host_stage_rows(float* dst, size_t dst_pitch, int width, const float* const* rows, const int32_t* lens,
+                       int n_rows, int total_rows, int32_t* dst_lens) {
+    if (!dst || !dst_lens || n_rows < 0 || total_rows < n_rows || width < 0 || (size_t)width > dst_pitch) return RS_EINVAL;
+    if (n_rows > 0 && (!rows || !lens)) return RS_EINVAL;
+    for (int b = 0; b < n_rows; ++b) {
+        const int n = lens[b];
+        if (n < 0 || n > width || (n > 0 && !rows[b])) return RS_EINVAL;
+        float* row = dst + (size_t)b * dst_pitch;
+        if (n > 0) memcpy(row, rows[b], (size_t)n * sizeof(float));
+        if (n < width) memset(row + n, 0, (size_t)(width - n) * sizeof(float));
+        dst_lens[b] = n;
+    }
+    for (int b = n_rows; b < total_rows; ++b) dst_lens[b] = 0;
+    return RS_OK;
+}
+
 int rs_frontend_logmel(rs_ctx* ctx, const float* audio, const int32_t* lens, int B, int audio_stride,
                        int pad_left, int pad_right, int t_max, float* feats, int32_t* n_frames, void* workspace,
                        size_t workspace_bytes, void* stream) {

@@ -28,7 +28,7 @@ EXPORTS = [
     "rs_workspace_bytes", "rs_mel_frames", "rs_enc_frames", "rs_frontend_logmel", "rs_encoder_forward",
     "rs_rnnt_greedy", "rs_profile_enable", "rs_profile_read", "rs_profile_reset", "rs_gemm_bf16",
     "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_glu_dwconv_silu_layout", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
-    "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes",
+    "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes", "rs_host_stage_rows",
 ]
 
 
@@ -92,6 +92,7 @@ def load():
     lib.rs_enc_frames.argtypes = [vp, c_int]
     lib.rs_frontend_logmel.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_size_t, vp]
     lib.rs_encoder_forward.argtypes = [vp, vp, vp, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
+    lib.rs_host_stage_rows.argtypes = [vp, c_size_t, c_int, POINTER(c_void_p), POINTER(c_int32), c_int, c_int, vp]
     lib.rs_set_option.argtypes = [vp, c_char_p, c_int]
     lib.rs_stream_create.argtypes = [POINTER(c_void_p), c_int, POINTER(ctypes.c_uint32), c_int, c_int]
     lib.rs_stream_destroy.argtypes = [vp]
@@ -122,6 +123,21 @@ def _ptr(t):
     if t is None:
         return None
     return c_void_p(t.data_ptr())
+
+
+def host_stage_rows(dst, width, waveforms, dst_lens):
+    """gather host float32 utterances into the pinned staging matrix `dst` (torch float32 [rows][pitch]) with ONE call that
+    runs without the interpreter lock (rs_host_stage_rows); `dst_lens` = torch int32 [rows]"""
+    import numpy as np
+    lib = load()
+    n = len(waveforms)
+    rows = [np.ascontiguousarray(w, dtype=np.float32) for w in waveforms]      # (no copy for float32 C-contiguous input)
+    ptrs = (c_void_p * max(n, 1))(*[r.ctypes.data for r in rows])
+    lens = (c_int32 * max(n, 1))(*[len(r) for r in rows])
+    rc = lib.rs_host_stage_rows(c_void_p(dst.data_ptr()), dst.stride(0), int(width), ptrs, lens, n, dst.shape[0],
+                                c_void_p(dst_lens.data_ptr()))
+    if rc != RS_OK:
+        raise RsError(rc, "rs_host_stage_rows: bad arguments")
 
 
 def create_stream(device_index, n_cus=0, total_cus=256, priority=0):

@@ -424,15 +424,9 @@ class AsrModel:
         longest = max((len(w) for w in waveforms), default=0)
         view = buf.narrow(longest)
         assert view.l_max >= longest
-        ha = buf.h_audio.numpy()
-        hl = buf.h_lens.numpy()
-        width = view.l_max
-        for b, w in enumerate(waveforms):
-            n = len(w)
-            ha[b, :n] = w
-            ha[b, n:width] = 0.0
-            hl[b] = n
-        hl[len(waveforms):] = 0          # a short last group: empty utterances (length 0 decodes to nothing)
+        # one native call for the whole batch (it runs without the interpreter lock: a per-utterance numpy copy would
+        # queue behind whatever Python thread holds it — the ids -> text post-processing of an earlier batch)
+        capi.host_stage_rows(buf.h_audio, view.l_max, waveforms, buf.h_lens)
         return view
 
     def stage(self, waveforms: Sequence[np.ndarray], l_max: Optional[int] = None, buf: Optional[_Buffers] = None) -> _Buffers:

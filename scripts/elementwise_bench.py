@@ -44,6 +44,18 @@ for generic in (1, 0, 1, 0):
     print(f"glu_dwconv_silu {'generic' if generic else 'window '}: {us:7.1f} us  {B * T * d * 6 / us / 1e6:5.2f} TB/s")
 print("max |generic - window| =", (outs[0] - outs[1]).abs().max().item())
 
+# the gated layout (GLU applied by the pw1 GEMM: the product default): DMA-staged bf16 tile vs the f32-tile kernel
+xg = torch.randn((B * T, d), generator=g).to(torch.bfloat16).to(dev)
+outs = []
+for mode in (2, 0, 2, 0):
+    lib.rs_debug_set_glu_generic(mode)
+    out = torch.empty((B * T, d), dtype=torch.bfloat16, device=dev)
+    us = timed(lambda: ctx.glu_dwconv(xg, w, bias, lens, B, T, d, k, out, layout=capi.GLU_APPLIED))
+    outs.append(out.float().cpu())
+    print(f"dwconv_silu (gated in) {'f32 tile ' if mode else 'dma bf16 '}: {us:7.1f} us  {B * T * d * 4 / us / 1e6:5.2f} TB/s")
+print("max |f32 tile - dma| =", (outs[0] - outs[1]).abs().max().item())
+lib.rs_debug_set_glu_generic(0)
+
 xf = torch.randn((B * T, d), generator=g).to(dev)
 gamma, beta = torch.ones(d, device=dev), torch.zeros(d, device=dev)
 ob = torch.empty((B * T, d), dtype=torch.bfloat16, device=dev)

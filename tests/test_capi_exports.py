@@ -67,3 +67,20 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f), encoding="utf-8").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "librs_oracle" not in text, f
+
+
+def test_host_stage_rows_gathers_a_ragged_batch():
+    """rs_host_stage_rows (pure host code of the C ABI): rows copied, tails zeroed up to the batch width only, lengths
+    written, rows of a short last batch get length 0, bad arguments are rejected"""
+    import numpy as np
+    import torch
+    dst = torch.full((5, 100), 7.0)
+    lens = torch.full((5,), -1, dtype=torch.int32)
+    waves = [np.arange(10, dtype=np.float32), np.zeros(0, np.float32), np.arange(64, dtype=np.float64)[::2]]
+    capi.host_stage_rows(dst, 64, waves, lens)
+    assert lens.tolist() == [10, 0, 32, 0, 0]
+    assert dst[0, :10].tolist() == list(range(10)) and (dst[0, 10:64] == 0).all() and (dst[0, 64:] == 7).all()
+    assert (dst[1, :64] == 0).all() and dst[2, :32].tolist() == list(range(0, 64, 2)) and (dst[2, 32:64] == 0).all()
+    assert (dst[3:] == 7).all()                       # rows past the batch keep their bytes; only their length is reset
+    with pytest.raises(capi.RsError):
+        capi.host_stage_rows(dst, 8, waves, lens)     # an utterance longer than the width
