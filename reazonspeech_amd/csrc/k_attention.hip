@@ -53,6 +53,9 @@ __device__ __forceinline__ int vt_pos(int key) {
 }
 
 // One workgroup = (batch b, head h, up to 6 query blocks of 32); one wave = one query block.
+// (Tried in round 3: delaying every second workgroup of the first dispatch round by 2k .. 14k cycles so that the Q / K / V
+// prologue bursts of the two halves of the chip stop coinciding — no effect, 154 - 156 us either way:
+// profiles/r03i_attn_skew_ab.txt.  The prologues are not what paces the launch.)
 // WINDOW: limited-context / global-token masks compiled in (full attention otherwise: no per-score branches)
 template <bool TRACE, bool WINDOW>
 __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
