@@ -218,6 +218,21 @@ def extra_configs(model, cfg, sd, args, host_sets):
         del bufs32
     except Exception as e:
         out["b32"] = {"error": repr(e)}
+    # the reference's own call pattern: ONE utterance per transcribe() (batch_size=1, transcribe.py:48-50), host to host
+    try:
+        wave = host_sets[0][0][0, :int(host_sets[0][1][0])]
+        model.transcribe_waveforms([wave])
+        lat = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            r1 = model.transcribe_waveforms([wave])
+            lat.append(time.perf_counter() - t0)
+        lat.sort()
+        out["b1_latency"] = {"workload": f"one {len(wave) / 16000.0:g} s utterance per call (the reference's batch_size=1), host float32 -> token ids",
+                             "latency_ms_median": round(lat[len(lat) // 2] * 1e3, 2), "latency_ms_min": round(lat[0] * 1e3, 2),
+                             "value": round(len(wave) / 16000.0 / lat[len(lat) // 2], 1), "tokens": len(r1.ids[0])}
+    except Exception as e:
+        out["b1_latency"] = {"error": repr(e)}
     # SURVEY §8(d) ragged set: lengths U(2 s, 10 s), seed 1235, through the host-to-host boundary (sorted, tight padding)
     try:
         n = 4 * args.batch
