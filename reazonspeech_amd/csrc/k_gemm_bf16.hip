@@ -58,6 +58,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
@@ -256,7 +258,7 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
 // tile (16 MFMAs each, the guide's 8-phase shape).  Per shape they are within +-4 % of this one either way — the loop is
 // paced by the LDS traffic of the 128 x 64 wave tile and the clock, not by its barrier structure — and on the whole
 // path both lose ~1 % (58.8 vs 59.5 ms / step).
-template <int BM, int OUT, bool MASK, int EPF, bool TRACE>
+template <int BM, int OUT, bool MASK, int EPF, bool TRACE, bool R3 = false>
 __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     constexpr int BN = 256, WN = 4, NWAVES = 8;
     constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -264,6 +266,12 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     constexpr int LA = BM / 8 / NWAVES, LB = BN / 8 / NWAVES;     // DMA pieces (8 rows x 128 B) per wave and K tile
     constexpr int NPH = 2;                                        // phases per K tile
     static_assert((BM == 256 || BM == 192 || BM == 128 || BM == 64) && LB == 4 && (MI % 2) == 0 && BM * 128 <= SLOT, "tile heights");
+    // R3 (128-row tiles only): the LDS is THREE whole K-tile stages of 48 KiB (A 16 KiB | B 32 KiB) instead of the five
+    // part slots: during K tile t a wave issues ALL of K tile t+2, so both operands have a whole K tile more to land
+    // (the split ring gives that to A only; its B(t+1) must arrive within the K tile it was issued in, and short tiles
+    // sit on exactly that round trip).  Waits leave K tile t+2 (LA + LB pieces) in flight.
+    constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + SLOT;
+    static_assert(!R3 || 3 * STAGE <= NSLOT * SLOT, "three stages must fit the 160 KiB");
     long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_w0 = 0, tr_stall = 0;
     if constexpr (TRACE) { tr_t0 = __builtin_readcyclecounter(); tr_w0 = (long long)wall_clock64(); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -337,27 +345,34 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     int m1 = m0, n1 = n0;
     if (has_next) { tile_origin(it + 1, m1, n1); lane_offsets(m1, n1, offn); }
     // piece j of K tile k (k >= nk: K tile k - nk of the NEXT tile) into slot sl
-    auto dma_a = [&](int j, int k, int sl) {
+    auto dma_a = [&](int j, int k, int dst) {                     // dst: byte offset of the part in LDS
         const bool nx = k >= nk;
         glds16(nx ? offn[j] : off[j], reinterpret_cast<const char*>(p.A) + (size_t)(nx ? k - nk : k) * 128,
-               lds0 + sl * SLOT + (wave + NWAVES * j) * 1024);
+               lds0 + dst + (wave + NWAVES * j) * 1024);
     };
-    auto dma_b = [&](int j, int k, int sl) {
+    auto dma_b = [&](int j, int k, int dst) {
         const bool nx = k >= nk;
         glds16(nx ? offn[LA + j] : off[LA + j], reinterpret_cast<const char*>(p.W) + (size_t)(nx ? k - nk : k) * 128,
-               lds0 + sl * SLOT + (wave * LB + j) * 1024);
+               lds0 + dst + (wave * LB + j) * 1024);
     };
     if (it == 0 || !carry) {
         // prologue: A(0) -> slot 0, B(0) -> slot 1, A(1) -> slot 2; K tile 0 is complete when all but the last LA landed
+        // (R3: K tiles 0 and 1 whole -> stages 0 and 1; all but the last LA + LB)
         sa = 0;
 #pragma unroll
         for (int j = 0; j < LA; ++j) dma_a(j, 0, 0);
 #pragma unroll
-        for (int j = 0; j < LB; ++j) dma_b(j, 0, 1);
+        for (int j = 0; j < LB; ++j) dma_b(j, 0, R3 ? A_BYTES : SLOT);
         if (nk > 1) {
 #pragma unroll
-            for (int j = 0; j < LA; ++j) dma_a(j, 1, 2);
-            wait_vmcnt<LA>();
+            for (int j = 0; j < LA; ++j) dma_a(j, 1, R3 ? STAGE : 2 * SLOT);
+            if constexpr (R3) {
+#pragma unroll
+                for (int j = 0; j < LB; ++j) dma_b(j, 1, STAGE + A_BYTES);
+                wait_vmcnt<LA + LB>();
+            } else {
+                wait_vmcnt<LA>();
+            }
         } else {
             wait_vmcnt<0>();
         }
@@ -375,13 +390,26 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
             for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.0f;
 
     for (int t = 0; t < nk; ++t) {
-        const int sb = wrap(sa + 1), sbn = wrap(sa + 3), san = wrap(sa + 4);
-        const char* at = smem + sa * SLOT;
-        const char* bt = smem + sb * SLOT;
-        const bool has_b = t + 1 < nk || has_next, has_a = t + 2 < nk || has_next;
-        auto wait_next = [&]() {                                  // K tile t + 1 landed; A(t+2) may stay in flight
-            if (has_a) wait_vmcnt<LA>();
-            else wait_vmcnt<0>();
+        // split ring: sa = slot of A(t); B(t) = sa + 1; this K tile issues B(t+1) -> sa + 3 and A(t+2) -> sa + 4 (mod 5).
+        // R3: sa = stage of K tile t (mod 3); this K tile issues B(t+2), A(t+2) -> stage sa + 2.
+        auto wrap3 = [](int v) { return v >= 3 ? v - 3 : v; };
+        const int a_cur = R3 ? sa * STAGE : sa * SLOT;
+        const int b_cur = R3 ? a_cur + A_BYTES : wrap(sa + 1) * SLOT;
+        const int bdst = R3 ? wrap3(sa + 2) * STAGE + A_BYTES : wrap(sa + 3) * SLOT;
+        const int adst = R3 ? wrap3(sa + 2) * STAGE : wrap(sa + 4) * SLOT;
+        constexpr int KB = R3 ? 2 : 1;                            // how many K tiles ahead the B pieces are issued
+        const char* at = smem + a_cur;
+        const char* bt = smem + b_cur;
+        const bool has_1 = t + 1 < nk || has_next;                // a K tile follows (in this tile or the next)
+        const bool has_b = t + KB < nk || has_next, has_a = t + 2 < nk || has_next;
+        auto wait_next = [&]() {                                  // K tile t + 1 landed; what was issued for t + 2 may stay in flight
+            if constexpr (R3) {
+                if (has_a) wait_vmcnt<LA + LB>();
+                else wait_vmcnt<0>();
+            } else {
+                if (has_a) wait_vmcnt<LA>();
+                else wait_vmcnt<0>();
+            }
         };
         auto timed_wait_next = [&]() {
             if constexpr (TRACE) { const long long a = __builtin_readcyclecounter(); wait_next(); tr_stall += __builtin_readcyclecounter() - a; }
@@ -398,9 +426,9 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
             if (ks == 0 && has_b) {                               // the B pieces of K tile t+1 go out beside the fragment reads
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < LB; ++j) dma_b(j, t + 1, sbn);
+                for (int j = 0; j < LB; ++j) dma_b(j, t + KB, bdst);
             }
-            if (last && has_b && wm == 1) timed_wait_next();      // group 1: one barrier behind, waits in its memory half
+            if (last && has_1 && wm == 1) timed_wait_next();      // group 1: one barrier behind, waits in its memory half
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -413,17 +441,17 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
                     acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
                 if (ks == 0 && i < LA && has_a) {                 // the A pieces of K tile t+2 between the MFMAs of phase 0
                     __builtin_amdgcn_sched_barrier(0);
-                    dma_a(i, t + 2, san);
+                    dma_a(i, t + 2, adst);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (last && has_b && wm == 0) timed_wait_next();      // group 0: before the barrier its reads follow
+            if (last && has_1 && wm == 0) timed_wait_next();      // group 0: before the barrier its reads follow
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
-        sa = wrap(sa + 2);
+        sa = R3 ? wrap3(sa + 1) : wrap(sa + 2);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();                   // pairs with group 1's extra barrier: nobody reads this tile's parts any more
     {
@@ -433,7 +461,8 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
         // Epilogue scratch: 4 KiB per wave in the slot that held this tile's LAST A part.  With the ring carried on,
         // slots sa .. sa+2 hold the next tile's A(0), B(0), A(1) (landed or in flight); sa+3 (= last A) and sa+4 (= last
         // B) are dead until the next tile's first K tile issues its DMAs, which happens after the barrier below.
-        char* scr = smem + wrap(sa + 3) * SLOT + wave * 4096;
+        // (R3: stages sa, sa+1 hold the next tile's K tiles 0 and 1; sa+2 — the last K tile — is dead.)
+        char* scr = smem + (R3 ? (sa + 2 >= 3 ? sa - 1 : sa + 2) * STAGE : wrap(sa + 3) * SLOT) + wave * 4096;
         smf16_epilogue<MI, NI, OUT, MASK, EPF>(p, acc, scr, em0, en0, wm, wn, lane);
         if constexpr (TRACE) {
             // wave 0 (group 0) and wave 4 (group 1) each write a record: [0] prologue, [1] main loop, [2] epilogue
@@ -473,6 +502,7 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
 std::atomic<long long*> g_trace{nullptr};
 std::atomic<int> g_tile{0};        // forced tile height (RS_GEMM_TILE / rs_debug_set_gemm_tile); 0 = by shape
 std::atomic<int> g_group_m{0};     // row panels per XCD tile group; 0 = by shape
+std::atomic<int> g_ring3{0};       // RS_GEMM_RING3: 1 = 128-row tiles on the three-stage ring (R3)
 std::atomic<int> g_pairs{2};       // RS_GEMM_PAIRS: 2 = two tiles per workgroup with the LDS ring carried from the first into the second,
                                    // 1 = two tiles, the ring restarts, 0 = one tile per workgroup
 void gemm_knobs_from_env() {
@@ -482,10 +512,11 @@ void gemm_knobs_from_env() {
         env("RS_GEMM_TILE", g_tile);
         env("RS_GEMM_GROUP_M", g_group_m);
         env("RS_GEMM_PAIRS", g_pairs);
+        env("RS_GEMM_RING3", g_ring3);
     });
 }
 
-template <int BM>
+template <int BM, bool R3 = false>
 int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     constexpr int LDS = 5 * 32768;
     constexpr int EPF = 3;
@@ -512,8 +543,8 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     const bool mask = p.flags & RS_GEMM_ROWMASK;
 #define RS_SMF(O, MK, TR)                                                                                          \
     do {                                                                                                           \
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, MK, EPF, TR>, LDS); rc != RS_OK) return rc; \
-        hipLaunchKernelGGL((gemm_smf16_kernel<BM, O, MK, EPF, TR>), dim3(nwg), dim3(512), LDS, s, p);      \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, MK, EPF, TR, R3>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_smf16_kernel<BM, O, MK, EPF, TR, R3>), dim3(nwg), dim3(512), LDS, s, p);  \
     } while (0)
     if (p.trace) {
         if constexpr (BM >= 192) {
@@ -568,13 +599,14 @@ extern "C" void rs_debug_set_gemm_tile(int bm) { gemm_knobs_from_env(); g_tile =
 extern "C" void rs_debug_set_gemm_trace(long long* buf) { g_trace = buf; }
 extern "C" void rs_debug_set_gemm_group_m(int v) { gemm_knobs_from_env(); g_group_m = v; }
 extern "C" void rs_debug_set_gemm_pairs(int v) { gemm_knobs_from_env(); g_pairs = v; }
+extern "C" void rs_debug_set_gemm_ring3(int v) { gemm_knobs_from_env(); g_ring3 = v; }
 extern "C" int rs_debug_gemm_tile_height(int M, int N, int K, int n_cus, int flags) { return pick_tile_height(M, N, K, n_cus > 0 ? n_cus : 256, flags); }
 
 static int launch_rows(rs_ctx* ctx, GemmParams& p, int bm, hipStream_t s) {
     switch (bm) {
         case 256: return launch_smf16<256>(ctx, p, s);
         case 192: return launch_smf16<192>(ctx, p, s);
-        case 128: return launch_smf16<128>(ctx, p, s);
+        case 128: return g_ring3.load() ? launch_smf16<128, true>(ctx, p, s) : launch_smf16<128>(ctx, p, s);
         case 64: return launch_smf16<64>(ctx, p, s);
         default: return rs_fail(ctx, RS_EINVAL, "gemm: tile height %d (256, 192, 128 or 64)", bm);
     }
