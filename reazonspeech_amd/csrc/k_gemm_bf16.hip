@@ -258,7 +258,7 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
 // tile (16 MFMAs each, the guide's 8-phase shape).  Per shape they are within +-4 % of this one either way — the loop is
 // paced by the LDS traffic of the 128 x 64 wave tile and the clock, not by its barrier structure — and on the whole
 // path both lose ~1 % (58.8 vs 59.5 ms / step).
-template <int BM, int OUT, bool MASK, int EPF, bool TRACE, bool R3 = false>
+template <int BM, int OUT, bool MASK, int EPF, bool TRACE>
 __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     constexpr int BN = 256, WN = 4, NWAVES = 8;
     constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -266,12 +266,14 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     constexpr int LA = BM / 8 / NWAVES, LB = BN / 8 / NWAVES;     // DMA pieces (8 rows x 128 B) per wave and K tile
     constexpr int NPH = 2;                                        // phases per K tile
     static_assert((BM == 256 || BM == 192 || BM == 128 || BM == 64) && LB == 4 && (MI % 2) == 0 && BM * 128 <= SLOT, "tile heights");
-    // R3 (128-row tiles only): the LDS is THREE whole K-tile stages of 48 KiB (A 16 KiB | B 32 KiB) instead of the five
-    // part slots: during K tile t a wave issues ALL of K tile t+2, so both operands have a whole K tile more to land
-    // (the split ring gives that to A only; its B(t+1) must arrive within the K tile it was issued in, and short tiles
-    // sit on exactly that round trip).  Waits leave K tile t+2 (LA + LB pieces) in flight.
+    // R3 (tiles of <= 128 rows): the LDS is THREE whole K-tile stages (A BM x 128 B | B 32 KiB; 48 KiB at 128 rows) instead
+    // of the five part slots: during K tile t a wave issues ALL of K tile t+2, so both operands have a whole K tile more
+    // to land (the split ring gives that to A only; its B(t+1) must arrive within the K tile it was issued in, and the
+    // short K tiles of a low tile sit on exactly that round trip: 128-row tiles ran 4 - 17 % slower on the split ring,
+    // profiles/r03j_gemm_ring3_ab.txt).  Waits leave K tile t+2 (LA + LB pieces) in flight.  Taller tiles do not fit three
+    // stages in 160 KiB.
     constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + SLOT;
-    static_assert(!R3 || 3 * STAGE <= NSLOT * SLOT, "three stages must fit the 160 KiB");
+    constexpr bool R3 = 3 * STAGE <= NSLOT * SLOT;
     long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_w0 = 0, tr_stall = 0;
     if constexpr (TRACE) { tr_t0 = __builtin_readcyclecounter(); tr_w0 = (long long)wall_clock64(); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -502,7 +504,6 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
 std::atomic<long long*> g_trace{nullptr};
 std::atomic<int> g_tile{0};        // forced tile height (RS_GEMM_TILE / rs_debug_set_gemm_tile); 0 = by shape
 std::atomic<int> g_group_m{0};     // row panels per XCD tile group; 0 = by shape
-std::atomic<int> g_ring3{0};       // RS_GEMM_RING3: 1 = 128-row tiles on the three-stage ring (R3)
 std::atomic<int> g_pairs{2};       // RS_GEMM_PAIRS: 2 = two tiles per workgroup with the LDS ring carried from the first into the second,
                                    // 1 = two tiles, the ring restarts, 0 = one tile per workgroup
 void gemm_knobs_from_env() {
@@ -512,11 +513,10 @@ void gemm_knobs_from_env() {
         env("RS_GEMM_TILE", g_tile);
         env("RS_GEMM_GROUP_M", g_group_m);
         env("RS_GEMM_PAIRS", g_pairs);
-        env("RS_GEMM_RING3", g_ring3);
     });
 }
 
-template <int BM, bool R3 = false>
+template <int BM>
 int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     constexpr int LDS = 5 * 32768;
     constexpr int EPF = 3;
@@ -543,8 +543,8 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     const bool mask = p.flags & RS_GEMM_ROWMASK;
 #define RS_SMF(O, MK, TR)                                                                                          \
     do {                                                                                                           \
-        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, MK, EPF, TR, R3>, LDS); rc != RS_OK) return rc; \
-        hipLaunchKernelGGL((gemm_smf16_kernel<BM, O, MK, EPF, TR, R3>), dim3(nwg), dim3(512), LDS, s, p);  \
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, MK, EPF, TR>, LDS); rc != RS_OK) return rc; \
+        hipLaunchKernelGGL((gemm_smf16_kernel<BM, O, MK, EPF, TR>), dim3(nwg), dim3(512), LDS, s, p);  \
     } while (0)
     if (p.trace) {
         if constexpr (BM >= 192) {
@@ -574,7 +574,8 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
 // round trip of a K tile —, fix = workgroup launch + prologue + epilogue + round imbalance.  The f32 residual epilogue
 // moves 2 x BM x 256 x 4 bytes per tile from all CUs at once: it runs at the HBM rate (13 us per round of 256 tiles).
 // At the benchmark batch this gives 256 rows to ffn_up / qkv, 192 rows to pw1 and the N = 1024 residual family; at
-// B = 32 it reproduces the measured optimum of every encoder shape.  The choice never changes a result (see the header).
+// B = 8 / 32 / 64 / 128 it reproduces the measured optimum of every encoder shape (profiles/r03k_gemm_tiles_b*.txt, taken
+// with the 128- and 64-row tiles on the three-stage ring).  The choice never changes a result (see the header).
 int pick_tile_height(int M, int N, int K, int n_cus, int flags) {
     static const int bms[4] = {256, 192, 128, 64};
     static const double kt[4] = {1.246, 1.146, 1.03, 0.96}, fix[4] = {11.5, 7.0, 5.0, 4.0};
@@ -599,14 +600,13 @@ extern "C" void rs_debug_set_gemm_tile(int bm) { gemm_knobs_from_env(); g_tile =
 extern "C" void rs_debug_set_gemm_trace(long long* buf) { g_trace = buf; }
 extern "C" void rs_debug_set_gemm_group_m(int v) { gemm_knobs_from_env(); g_group_m = v; }
 extern "C" void rs_debug_set_gemm_pairs(int v) { gemm_knobs_from_env(); g_pairs = v; }
-extern "C" void rs_debug_set_gemm_ring3(int v) { gemm_knobs_from_env(); g_ring3 = v; }
 extern "C" int rs_debug_gemm_tile_height(int M, int N, int K, int n_cus, int flags) { return pick_tile_height(M, N, K, n_cus > 0 ? n_cus : 256, flags); }
 
 static int launch_rows(rs_ctx* ctx, GemmParams& p, int bm, hipStream_t s) {
     switch (bm) {
         case 256: return launch_smf16<256>(ctx, p, s);
         case 192: return launch_smf16<192>(ctx, p, s);
-        case 128: return g_ring3.load() ? launch_smf16<128, true>(ctx, p, s) : launch_smf16<128>(ctx, p, s);
+        case 128: return launch_smf16<128>(ctx, p, s);
         case 64: return launch_smf16<64>(ctx, p, s);
         default: return rs_fail(ctx, RS_EINVAL, "gemm: tile height %d (256, 192, 128 or 64)", bm);
     }

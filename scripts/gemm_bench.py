@@ -31,12 +31,7 @@ SHAPES = [  # name, M, N, K, flags
 
 def main():
     quick = "--quick" in sys.argv
-    # TILE[pN][r]: r = 128-row tiles on the three-stage ring
-    def parse(v):
-        r3 = v.endswith("r")
-        v = v.rstrip("r")
-        return (int(v.split("p")[0]), int(v.split("p")[1]) if "p" in v else 2, int(r3))
-    variants = [parse(v) for v in sys.argv[1:] if not v.startswith("--")] or [(0, 2, 0)]
+    variants = [(int(v.split("p")[0]), int(v.split("p")[1]) if "p" in v else 2) for v in sys.argv[1:] if not v.startswith("--")] or [(0, 2)]
     groups = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--group-m=")] or [None]
     # row pitch of A / W in elements beyond K (power-of-two pitches can camp on a few L2 / HBM channels)
     pad_a = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--pad-a=")] or [0])[0]
@@ -45,9 +40,8 @@ def main():
     only = [a.split("=")[1] for a in sys.argv[1:] if a.startswith("--shape=")]
     dev = torch.device("cuda", 0)
     ctx = capi.Context(FASTCONFORMER_619M, 0)
-    sett, setp, setr, pick = (ctx.lib.rs_debug_set_gemm_tile, ctx.lib.rs_debug_set_gemm_pairs, ctx.lib.rs_debug_set_gemm_ring3,
-                              ctx.lib.rs_debug_gemm_tile_height)
-    for f in (sett, setp, setr):
+    sett, setp, pick = ctx.lib.rs_debug_set_gemm_tile, ctx.lib.rs_debug_set_gemm_pairs, ctx.lib.rs_debug_gemm_tile_height
+    for f in (sett, setp):
         f.argtypes = [ctypes.c_int]
         f.restype = None
     pick.argtypes = [ctypes.c_int] * 5
@@ -55,7 +49,6 @@ def main():
     def setv(v):
         sett(v[0])
         setp(v[1])
-        setr(v[2])
     setg = ctx.lib.rs_debug_set_gemm_group_m
     setg.argtypes = [ctypes.c_int]
     setg.restype = None
@@ -116,10 +109,10 @@ def main():
                 ts.append(e0.elapsed_time(e1) / (1 if quick else 4))
             ts.sort()
             us = ts[len(ts) // 2] * 1e3
-            v = f"{v[0] or pick(m, n, k, 256, flags)}{'*' if not v[0] else ''} p{v[1]}{' ring3' if v[2] else ''}"
+            v = f"{v[0] or pick(m, n, k, 256, flags)}{'*' if not v[0] else ''} p{v[1]}"
             print(f"{name} M{m} N{n} K{k} tile {v}{'' if gm is None else f' gm{gm}'}{f' padA{pad_a}' if pad_a else ''}{f' padW{pad_w}' if pad_w else ''}{f' padC{pad_c}' if pad_c else ''}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
         del A, W, out, res
-    setv((0, 2, 0))
+    setv((0, 2))
 
 
 if __name__ == "__main__":

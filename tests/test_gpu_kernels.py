@@ -23,23 +23,21 @@ import ctypes
 
 
 @contextlib.contextmanager
-def gemm_knobs(ctx, tile=0, pairs=2, ring3=0):
+def gemm_knobs(ctx, tile=0, pairs=2):
     """force the GEMM tile height (256 / 192 / 128 / 64; 0 = by shape) and the tiles-per-workgroup mode (2 = pairs with
     the LDS ring carried from the first tile into the second, the default; 1 = pairs, ring restarted; 0 = one tile per
     workgroup) for the calls inside"""
     lib = ctx.lib
-    for f in (lib.rs_debug_set_gemm_tile, lib.rs_debug_set_gemm_pairs, lib.rs_debug_set_gemm_ring3):
+    for f in (lib.rs_debug_set_gemm_tile, lib.rs_debug_set_gemm_pairs):
         f.argtypes = [ctypes.c_int]
         f.restype = None
     try:
         lib.rs_debug_set_gemm_tile(tile)
         lib.rs_debug_set_gemm_pairs(pairs)
-        lib.rs_debug_set_gemm_ring3(ring3)
         yield
     finally:
         lib.rs_debug_set_gemm_tile(0)
         lib.rs_debug_set_gemm_pairs(2)
-        lib.rs_debug_set_gemm_ring3(0)
 
 
 @pytest.fixture(scope="module")
@@ -176,9 +174,9 @@ def test_gemm_is_tile_and_batch_invariant(ctx, gpu_device):
     x = torch.randn((M, d), generator=g).to(gpu_device)
     lo, n = 20010, 138                       # "one utterance": 138 rows out of the middle of the batch
 
-    def run(a, res, tile, pairs=2, ring3=0):
+    def run(a, res, tile, pairs=2):
         outs = []
-        with gemm_knobs(ctx, tile=tile, pairs=pairs, ring3=ring3):
+        with gemm_knobs(ctx, tile=tile, pairs=pairs):
             o = torch.zeros((a.shape[0], d), dtype=torch.bfloat16, device=gpu_device)
             ctx.gemm(a, W[:d], o, flags=capi.GEMM_BIAS | capi.GEMM_SILU, bias=bias[:d])
             outs.append(o)
@@ -195,9 +193,9 @@ def test_gemm_is_tile_and_batch_invariant(ctx, gpu_device):
     for tile, pairs in ((256, 2), (192, 2), (128, 2), (64, 2), (0, 1), (256, 1), (192, 1), (0, 0), (256, 0), (192, 0)):
         for got, want in zip(run(A, x, tile, pairs), base):
             assert torch.equal(got, want), (tile, pairs)
-    for pairs in (2, 1, 0):                  # 128-row tiles on the three-stage ring
-        for got, want in zip(run(A, x, 128, pairs, ring3=1), base):
-            assert torch.equal(got, want), ("ring3", pairs)
+    for pairs in (1, 0):                     # 128-row tiles (three-stage ring), ring restarted / one tile per workgroup
+        for got, want in zip(run(A, x, 128, pairs), base):
+            assert torch.equal(got, want), ("three-stage ring", pairs)
     alone = run(A[lo:lo + n].contiguous(), x[lo:lo + n].contiguous(), 0)           # picks the 64-row tile on its own
     for got, want in zip(alone, base):
         assert torch.equal(got, want[lo:lo + n])
@@ -230,11 +228,12 @@ def test_gemm_pairs_cover_every_tile_once(ctx, gpu_device, tiles_m, K):
 
 @pytest.mark.parametrize("K", [64, 128, 192, 320, 1024])
 @pytest.mark.parametrize("tiles_m", [1, 2, 9, 65, 520])
-def test_gemm_three_stage_ring(ctx, gpu_device, tiles_m, K):
-    """128-row tiles on the three-stage ring (R3: all of K tile t+2 issued during K tile t): one, two, three, five and 16
-    K tiles (the stage index wraps; with pairs the ring is carried into the second tile), every run-length class of the
-    pair split; bit-equal to the five-slot ring"""
-    bm, N = 128, 512
+@pytest.mark.parametrize("bm", [128, 64])
+def test_gemm_three_stage_ring(ctx, gpu_device, bm, tiles_m, K):
+    """Tiles of 128 / 64 rows run on a three-stage LDS ring (all of K tile t+2 issued during K tile t), the taller ones on
+    the five-slot split ring: one, two, three, five and 16 K tiles (the stage index wraps; with pairs the ring is carried
+    into the second tile), every run-length class of the pair split; bit-equal to the 192-row tiles of the split ring"""
+    N = 512
     M = tiles_m * bm - 7
     g = torch.Generator().manual_seed(tiles_m + K)
     A = rb(torch.randn((M, K), generator=g))
@@ -242,12 +241,12 @@ def test_gemm_three_stage_ring(ctx, gpu_device, tiles_m, K):
     bias = torch.randn((N,), generator=g)
     ref = A @ W.t() + bias
     outs = []
-    for ring3, pairs in ((0, 2), (1, 2), (1, 1), (1, 0)):
+    for tile, pairs in ((192, 2), (bm, 2), (bm, 1), (bm, 0)):
         out = torch.full((M + 8, N), 7.0, dtype=torch.float32, device=gpu_device)
-        with gemm_knobs(ctx, tile=bm, pairs=pairs, ring3=ring3):
+        with gemm_knobs(ctx, tile=tile, pairs=pairs):
             ctx.gemm(bf(A).to(gpu_device), bf(W).to(gpu_device), out[:M], flags=capi.GEMM_BIAS | capi.GEMM_OUT_F32, bias=bias.to(gpu_device))
             sync()
-        assert (out[:M].cpu() - ref).abs().max() <= 2e-3, (ring3, pairs)
+        assert (out[:M].cpu() - ref).abs().max() <= 2e-3, (tile, pairs)
         assert (out[M:] == 7.0).all()
         outs.append(out)
     for o in outs[1:]:
