@@ -60,6 +60,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
@@ -372,6 +374,10 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < LB; ++j) dma_b(j, 1, STAGE + A_BYTES);
                 wait_vmcnt<LA + LB>();
+            } else if (wm == 1) {                                 // group 1 issues its B pieces one phase early (see the K loop)
+#pragma unroll
+                for (int j = 0; j < LB; ++j) dma_b(j, 1, 3 * SLOT);
+                wait_vmcnt<LA + LB>();
             } else {
                 wait_vmcnt<LA>();
             }
@@ -425,7 +431,15 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
             for (int jj = 0; jj < NI; ++jj) bfr[jj] = frag(bt, wn * TN + jj * 16 + frow, ks * 4 + fch);
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = frag(at, wm * TM + i * 16 + frow, ks * 4 + fch);
-            if (ks == 0 && has_b) {                               // the B pieces of K tile t+1 go out beside the fragment reads
+            // Split ring: wave group 0 issues its B pieces of K tile t+1 here, beside its fragment reads — the slot (the one
+            // A(t-1) lived in) is free from the barrier that opened this phase.  Group 1 runs one barrier behind and must
+            // have its pieces landed by the end of ITS phase-1 memory half (group 0 reads K tile t+1 right after that
+            // barrier): issued here they would have two phases to land (measured: 15 % of a 192-row K = 4096 main loop spent
+            // in that wait, profiles/r03l_gemm_trace.txt), so group 1 issues its B pieces of K tile t+2 a phase EARLIER,
+            // between the MFMAs of phase 1 of K tile t, into the slot of A(t), which nobody reads any more by then
+            // (profiles/r03m_gemm_early_b_ab.txt, r03m_gemm_trace.txt: that wait 11 -> 2 us per ffn_down tile, 192-row
+            // launches -1 .. -8 %, 256-row launches unchanged; the shader clock drops with the stall gone — power cap).
+            if (ks == 0 && has_b && (R3 || wm == 0)) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < LB; ++j) dma_b(j, t + KB, bdst);
@@ -446,6 +460,13 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
                     dma_a(i, t + 2, adst);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (!R3) {
+                    if (ks == 1 && i < LB && wm == 1 && has_a) { // group 1: its B pieces of K tile t+2 (see above)
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma_b(i, t + 2, a_cur);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             if (last && has_1 && wm == 0) timed_wait_next();      // group 0: before the barrier its reads follow
             __builtin_amdgcn_s_setprio(0);
@@ -460,11 +481,12 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
         int em0 = __builtin_amdgcn_readfirstlane(m0), en0 = __builtin_amdgcn_readfirstlane(n0);
         asm volatile("" : "+s"(em0), "+s"(en0));                  // keep the addresses out of the main loop's live ranges
         if constexpr (TRACE) tr_t2 = __builtin_readcyclecounter();
-        // Epilogue scratch: 4 KiB per wave in the slot that held this tile's LAST A part.  With the ring carried on,
-        // slots sa .. sa+2 hold the next tile's A(0), B(0), A(1) (landed or in flight); sa+3 (= last A) and sa+4 (= last
-        // B) are dead until the next tile's first K tile issues its DMAs, which happens after the barrier below.
+        // Epilogue scratch: 4 KiB per wave in the slot that held this tile's LAST B part.  With the ring carried on,
+        // slots sa .. sa+2 hold the next tile's A(0), B(0), A(1) and sa+3 (= last A) already receives group 1's pieces
+        // of the next tile's B(1); sa+4 (= last B) is dead until the next tile's first K tile issues A(2) into it, which
+        // happens after the barrier below.
         // (R3: stages sa, sa+1 hold the next tile's K tiles 0 and 1; sa+2 — the last K tile — is dead.)
-        char* scr = smem + (R3 ? (sa + 2 >= 3 ? sa - 1 : sa + 2) * STAGE : wrap(sa + 3) * SLOT) + wave * 4096;
+        char* scr = smem + (R3 ? (sa + 2 >= 3 ? sa - 1 : sa + 2) * STAGE : wrap(sa + 4) * SLOT) + wave * 4096;
         smf16_epilogue<MI, NI, OUT, MASK, EPF>(p, acc, scr, em0, en0, wm, wn, lane);
         if constexpr (TRACE) {
             // wave 0 (group 0) and wave 4 (group 1) each write a record: [0] prologue, [1] main loop, [2] epilogue
