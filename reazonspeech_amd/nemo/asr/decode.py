@@ -5,6 +5,8 @@ behaviour is fully pinned by in-tree reference code, so `tests/test_host_referen
 checks it against golden vectors produced by importing the reference file itself
 (`tests/golden/make_reference_golden.py`).
 """
+import weakref
+
 from .interface import Subword, Segment, TranscribeResult
 
 # decode.py:4-7
@@ -41,6 +43,25 @@ def find_end_of_segment(subwords, start):
     return idx
 
 
+_piece_text_cache = weakref.WeakKeyDictionary()
+
+
+def _piece_text(tokenizer):
+    """`lambda token_id: tokenizer.ids_to_text([token_id])` with the answers remembered per tokenizer: the reference asks
+    the tokenizer once per emitted token (decode.py:49), a vocabulary has ~3000 entries and a batch ~12 000 tokens."""
+    try:
+        cache = _piece_text_cache.setdefault(tokenizer, {})
+    except TypeError:                      # a tokenizer that cannot be weakly referenced: no memory across calls
+        cache = {}
+
+    def get(token_id):
+        text = cache.get(token_id)
+        if text is None:
+            text = cache[token_id] = tokenizer.ids_to_text([token_id])
+        return text
+    return get
+
+
 def decode_hypothesis(model, hyp):
     """Build a TranscribeResult from an ALSD-shaped hypothesis (decode.py:28-66).
 
@@ -49,14 +70,14 @@ def decode_hypothesis(model, hyp):
     ids = hyp.y_sequence.tolist()[1:]          # decode.py:40 — drop the leading blank
     text = model.tokenizer.ids_to_text(ids)     # decode.py:41
 
+    piece = _piece_text(model.tokenizer)
     subwords = []
     for idx, (token_id, step) in enumerate(zip(ids, hyp.timestamp)):
+        token = piece(token_id)
+        if not token:
+            continue                            # bare U+2581 pieces decode to "" and are dropped AFTER idx was assigned (decode.py:53)
         seconds = max(SECONDS_PER_STEP * (step - idx - 1) - PAD_SECONDS, 0)   # decode.py:48
-        subwords.append(Subword(seconds=seconds, token_id=token_id,
-                                token=model.tokenizer.ids_to_text([token_id])))
-
-    # bare U+2581 pieces decode to "" and are dropped AFTER idx was assigned (decode.py:53)
-    subwords = [sw for sw in subwords if sw.token]
+        subwords.append(Subword(seconds, token_id, token))
 
     segments = []
     start = 0

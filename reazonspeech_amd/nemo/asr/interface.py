@@ -70,6 +70,12 @@ class _IdSequence(list):
         return list(self)
 
 
+def _int_list(values):
+    """python ints from an integer ndarray / tensor (one C call) or any iterable"""
+    out = values.tolist() if hasattr(values, "tolist") else list(values)
+    return out if all(type(v) is int for v in out) else [int(v) for v in out]
+
+
 @dataclass
 class Hypothesis:
     """Greedy-decode result shaped like NeMo's ALSD `Hypothesis`.
@@ -88,8 +94,7 @@ class Hypothesis:
 
     @classmethod
     def from_greedy(cls, ids, frames, blank_id):
-        ids = [int(i) for i in ids]
-        frames = [int(f) for f in frames]
+        ids, frames = _int_list(ids), _int_list(frames)
         steps = [f + idx + 1 for idx, f in enumerate(frames)]
         return cls(_IdSequence([int(blank_id)] + ids), steps, frames)
 
@@ -98,7 +103,6 @@ class Hypothesis:
         """Beam-search result: `steps[idx]` is the alignment index i = frame + labels before (what rs_rnnt_alsd
         records); the timestamps handed to the reference post-processor are `i + ALSD_TIMESTAMP_OFFSET`."""
         off = ALSD_TIMESTAMP_OFFSET if offset is None else int(offset)
-        ids = [int(i) for i in ids]
-        steps = [int(s) for s in steps]
+        ids, steps = _int_list(ids), _int_list(steps)
         frames = [s - idx for idx, s in enumerate(steps)]
         return cls(_IdSequence([int(blank_id)] + ids), [s + off for s in steps], frames)

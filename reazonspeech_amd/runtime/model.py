@@ -6,6 +6,7 @@ three stage entry points of librs_asr.so on torch's current HIP stream.  It stan
 and exposes the one attribute the reference's post-processing touches: `.tokenizer`
 (pkg/nemo-asr/src/decode.py:41,47).
 """
+import gc
 import os
 import queue
 import threading
@@ -557,12 +558,19 @@ class AsrModel:
         if post_q is not None:
             post = threading.Thread(target=post_worker, daemon=True)
             post.start()
+        # The post-processing thread allocates ~10^5 small objects per batch; a generation-2 collection triggered in the
+        # middle of the pipeline holds the interpreter lock for 50-60 ms (profiles/r03n_host_timeline.txt) and every
+        # decode lane behind it: the cyclic collector is paused for the duration of the call (nothing here makes cycles).
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             self.run_pipelined(pool, len(groups), after_decode=harvest, fill=fill, dec_streams=2 if n_sets >= 3 else 1)
         finally:
             if post is not None:
                 post_q.put(None)
                 post.join()
+            if gc_was_on:
+                gc.enable()
         if post_err:
             raise post_err[0]
         return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.decoding == "alsd" else None)
