@@ -249,13 +249,17 @@ def extra_configs(model, cfg, sd, args, host_sets):
         del audio, waves
     except Exception as e:
         out["ragged_u2_10"] = {"error": repr(e)}
-    # the reference checkpoint's decode strategy (decode.py:29,38-41): ALSD, beam 4
-    for key, cfg2, what in (
-            ("alsd4", cfg.with_(decoding="alsd", beam_size=4), "ALSD beam-4 decode (max_target_len 2.0)"),
+    # the reference checkpoint's decode strategy (decode.py:29,38-41): ALSD, beam 4.  (With random-init weights the beam
+    # search spends the whole 2 x T' label budget — ~310 labels per utterance against the greedy path's 46: an untrained
+    # prediction network has states in which a label stays the most probable symbol for ever, greedy leaves them through
+    # its max-symbols-per-frame cap, ALSD has none.  Scaling the joint output layer by 8 — peaked posteriors, greedy ids
+    # unchanged — does not change that: 286 labels, profiles/r03o_bench.json.  This line is a worst case, not a trained model.)
+    for key, cfg2, what, sd2 in (
+            ("alsd4", cfg.with_(decoding="alsd", beam_size=4), "ALSD beam-4 decode (max_target_len 2.0)", sd),
             ("window_128_128_g1", cfg.with_(att_left=128, att_right=128, n_global=1),
-             "limited-context attention [128, 128] + 1 global token (SURVEY row L5), greedy decode")):
+             "limited-context attention [128, 128] + 1 global token (SURVEY row L5), greedy decode", sd)):
         try:
-            m2 = AsrModel(cfg2, sd, SyntheticTokenizer(cfg2.vocab_size), device=str(model.device))
+            m2 = AsrModel(cfg2, sd2, SyntheticTokenizer(cfg2.vocab_size), device=str(model.device))
             bufs2 = [m2.stage([a[i, :l[i]] for i in range(args.batch)], buf=m2.new_buffers(args.batch, int(args.seconds * 16000)))
                      for a, l in host_sets]
             torch.cuda.synchronize()
@@ -264,6 +268,9 @@ def extra_configs(model, cfg, sd, args, host_sets):
             out[key] = {"workload": f"{args.batch} x {args.seconds:g} s per step, {what}, HBM-resident, pipelined",
                         "value": round(sum(float(host_sets[i % n_sets][1].sum()) for i in range(steps)) / 16000.0 / dt, 1),
                         "ms_per_step": round(dt / steps * 1e3, 3)}
+            if key.startswith("alsd"):
+                n_lab = bufs2[0].n_ids.cpu().numpy()[:args.batch]
+                out[key]["mean_tokens_per_utt"] = round(float(n_lab.mean()), 1)
             if key.startswith("window"):
                 out[key]["parity"] = window_parity(m2, cfg2, sd, host_sets[0])
             del bufs2, m2
@@ -420,7 +427,7 @@ def main():
             from reazonspeech_amd.nemo.asr import transcribe_batch, audio_from_numpy, TranscribeConfig
             waves = [host_sets[k % n_sets][0][i, :host_sets[k % n_sets][1][i]] for k in range(args.api_batches) for i in range(args.batch)]
             secs = sum(len(w) for w in waves) / 16000.0
-            model.transcribe_waveforms(waves[:3 * args.batch], max_batch=args.batch)          # allocate the pool, warm up
+            model.transcribe_waveforms(waves[:4 * args.batch], max_batch=args.batch)          # allocate the pool (4 sets), warm up
             runs = []
             for _ in range(3):
                 t1 = time.perf_counter()
