@@ -508,10 +508,11 @@ def main():
         if gemm and gemm["launches"]:
             per_launch_ms = gemm["ms"] / gemm["launches"]
             achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
-            traffic = None
+            traffic = mfma_busy = pmc_clock = None
             try:   # HBM bytes per launch from the committed PMC passes (cannot be collected in-process)
                 with open(os.path.join(ROOT, "profiles", "gemm_traffic.json")) as fp:
-                    traffic = json.load(fp)["hbm_bytes_per_launch"]
+                    pmc = json.load(fp)
+                traffic, mfma_busy, pmc_clock = pmc["hbm_bytes_per_launch"], pmc.get("mfma_busy_pct"), pmc.get("clock_ghz")
             except Exception:
                 pass
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_smf16_kernel (every dense contraction of the encoder)",
@@ -521,7 +522,9 @@ def main():
                                "algorithmic_bytes_per_launch": round(gemm["bytes"] / gemm["launches"]),
                                "launches": gemm["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
                                "profiled_steps": f"{prof_state['steps']} of {args.steps} (every {PROFILE_EVERY}nd step of the timed region)",
-                               "share_of_step": round(gemm["ms"] / max(prof_state["steps"], 1) / (dt / args.steps * 1e3), 3)}
+                               "share_of_step": round(gemm["ms"] / max(prof_state["steps"], 1) / (dt / args.steps * 1e3), 3),
+                               # committed PMC passes (sequential schedule): MFMA-pipe busy cycles at the clock the chip ran at
+                               "mfma_busy_pct_pmc": mfma_busy, "clock_ghz_pmc": pmc_clock}
             if gemm_seq and gemm_seq["launches"]:
                 seq = gemm_seq["flops"] / (gemm_seq["ms"] * 1e-3) / 1e12
                 out["roofline"]["achieved_sequential_schedule"] = round(seq, 1)
