@@ -157,6 +157,10 @@ int rs_stream_destroy(void* stream);
  *                        epilogue, for EVERY batch size (one rounding point: an utterance's arithmetic does not depend on
  *                        the batch it rides in); 0 = the plain pw1 product is stored and the depthwise kernel applies the
  *                        GLU (moves one bf16 rounding; A/B and layout tests; $RS_FUSE_GLU).
+ *   "defer_out_norm"     1 (default): the float32 rows of a layer's output LayerNorm are not stored — their one reader, the
+ *                        residual operand of the next layer's first FFN, normalises the un-normed rows in its GEMM epilogue
+ *                        from per-row (mean, rstd); layers with a parity tap, and the last layer, store them.  0 = every
+ *                        output norm stores its rows.  Bit-identical results either way ($RS_DEFER_OUT_NORM).
  *   "decode_screen"      1 (default when the tensors joint.out.w16 / .wrm / .bpad / .wmax are registered): the joint's
  *                        output layer runs as a bf16 screening GEMM followed by an exact float32 evaluation of every
  *                        column that can still be the argmax (bit-identical result); 0 = every column in exact float32.

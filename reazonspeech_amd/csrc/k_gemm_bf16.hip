@@ -45,11 +45,14 @@ struct GemmParams {
     int mask_row0;     // global row index of this launch's row 0 (launches chunked over M: see rs_launch_gemm)
     int tiles_m, tiles_n;
     int group_m;       // row panels per XCD tile group
+    const float* res_ln_stats;   // OUT_RESLN: per row (mean, rstd) of the LayerNorm the residual operand still has to go through
+    const float* res_ln_g;       //            its weight / bias [N]
+    const float* res_ln_b;
     int pairs;         // > 0: a workgroup runs two consecutive tiles of its XCD's run (xcd_split); 2: the LDS ring carries over; 0: one tile
     long long* trace;  // debug: per-tile timestamps (scripts/gemm_trace.py); nullptr in production
 };
 
-enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_RES = 2, OUT_GLU = 3 };
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_RES = 2, OUT_GLU = 3, OUT_RESLN = 4 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -99,7 +102,10 @@ __host__ __device__ inline void xcd_split(int xcount, int pair_mode, int& n_pair
 template <int MI, int NI, int OUT, bool MASK, int PF>
 __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][NI], char* scr, int cm0, int cn0,
                                                int wm, int wn, int lane) {
-    constexpr bool RES = OUT == OUT_RES, out_f32 = OUT == OUT_F32 || OUT == OUT_RES, GLU = OUT == OUT_GLU, rowmask = MASK;
+    // OUT_RESLN: the residual operand is y, the previous layer's output BEFORE its output LayerNorm; that norm is applied
+    // here from per-row statistics (layernorm2_kernel writes them instead of the normalised f32 rows: one 145-MB write
+    // per layer boundary less), with the arithmetic of the norm kernel: fma((y - mean) * rstd, g, b).
+    constexpr bool RESLN = OUT == OUT_RESLN, RES = OUT == OUT_RES || RESLN, out_f32 = OUT == OUT_F32 || RES, GLU = OUT == OUT_GLU, rowmask = MASK;
     constexpr int TM = MI * 16, TN = NI * 16;
     constexpr unsigned OOB = 0xfffffff0u;                         // beyond every buffer: loads return 0, stores are dropped
     const int frow = lane & 15, fch = lane >> 4;
@@ -196,27 +202,42 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
         // lookahead every chunk paid a full HBM round trip (a dependent chain of MI latencies per wave); 3 ahead is the
         // whole-path optimum (profiles/r02u_bench_ab.txt: all of them ahead is a 24-load burst per wave).
         const int rr4 = lane >> 4, cc = lane & 15;
-        constexpr int NPF = RES ? (PF < 1 ? 1 : (PF > MI ? MI : PF)) : 1;
+        constexpr int PFE = (RESLN && MI >= 8 && PF > 1) ? PF - 1 : PF;    // 256-row tiles: one chunk less ahead instead of spilling
+        constexpr int NPF = RES ? (PFE < 1 ? 1 : (PFE > MI ? MI : PFE)) : 1;
         u32x4_t rvq[NPF][4];
-        auto load_res = [&](int i, u32x4_t (&rv)[4]) {
+        float2 stq[NPF][4];                                           // RESLN: (mean, rstd) of the rows of a chunk
+        float4 ln_g = make_float4(0.f, 0.f, 0.f, 0.f), ln_b = ln_g;
+        const auto st_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RESLN ? p.res_ln_stats : (const float*)p.out), 0,
+                                                               RESLN ? p.M * 8 : 0, 0x00020000);
+        if constexpr (RESLN) {
+            const int n = wcol0 + cc * 4;
+            if (n < p.N) {
+                ln_g = *reinterpret_cast<const float4*>(p.res_ln_g + n);
+                ln_b = *reinterpret_cast<const float4*>(p.res_ln_b + n);
+            }
+        }
+        auto load_res = [&](int i, u32x4_t (&rv)[4], float2 (&st)[4]) {
 #pragma unroll
             for (int sgm = 0; sgm < 4; ++sgm) {
                 const int m = wrow0 + i * 16 + sgm * 4 + rr4, n = wcol0 + cc * 4;
                 const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : OOB;
                 rv[sgm] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, off, 0, 0);
+                if constexpr (RESLN)
+                    st[sgm] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(st_rsrc, m < p.M ? (unsigned)m * 8u : OOB, 0, 0));
             }
         };
         if constexpr (RES) {
 #pragma unroll
-            for (int d = 0; d < NPF; ++d) load_res(d, rvq[d]);
+            for (int d = 0; d < NPF; ++d) load_res(d, rvq[d], stq[d]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             u32x4_t rv[4];
+            float2 st[4];
             if constexpr (RES) {
 #pragma unroll
-                for (int sgm = 0; sgm < 4; ++sgm) rv[sgm] = rvq[i % NPF][sgm];
+                for (int sgm = 0; sgm < 4; ++sgm) { rv[sgm] = rvq[i % NPF][sgm]; st[sgm] = stq[i % NPF][sgm]; }
             }
 #pragma unroll
             for (int jj = 0; jj < NI; ++jj) {
@@ -229,7 +250,12 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
                 const int row = sgm * 4 + rr4;
                 float4 v = *reinterpret_cast<const float4*>(scr + row * 256 + ((cc ^ row) * 16));
                 if constexpr (RES) {
-                    const float4 r = __builtin_bit_cast(float4, rv[sgm]);
+                    float4 r = __builtin_bit_cast(float4, rv[sgm]);
+                    if constexpr (RESLN) {
+                        const float mean = st[sgm].x, rstd = st[sgm].y;
+                        r.x = fmaf((r.x - mean) * rstd, ln_g.x, ln_b.x); r.y = fmaf((r.y - mean) * rstd, ln_g.y, ln_b.y);
+                        r.z = fmaf((r.z - mean) * rstd, ln_g.z, ln_b.z); r.w = fmaf((r.w - mean) * rstd, ln_g.w, ln_b.w);
+                    }
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
                 const int m = wrow0 + i * 16 + row, n = wcol0 + cc * 4;
@@ -238,7 +264,7 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), out_rsrc, off, 0, 0);
             }
             if constexpr (RES) {
-                if (i + NPF < MI) load_res(i + NPF, rvq[i % NPF]);       // refill the slot this chunk just consumed
+                if (i + NPF < MI) load_res(i + NPF, rvq[i % NPF], stq[i % NPF]);   // refill the slot this chunk just consumed
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -561,7 +587,7 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     // K = 4096 and 6 below; one-tile-wide problems (the subsampling GEMMs) 16; everything else is flat from 6 up
     p.group_m = g_group_m.load() > 0 ? g_group_m.load()
               : (p.tiles_n == 4 ? (p.K >= 4096 ? 2 : 6) : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8)));
-    const int out = (p.flags & RS_GEMM_RESIDUAL) ? OUT_RES : ((p.flags & RS_GEMM_OUT_F32) ? OUT_F32 : ((p.flags & RS_GEMM_GLU) ? OUT_GLU : OUT_BF16));
+    const int out = (p.flags & RS_GEMM_RESIDUAL) ? (p.res_ln_stats ? OUT_RESLN : OUT_RES) : ((p.flags & RS_GEMM_OUT_F32) ? OUT_F32 : ((p.flags & RS_GEMM_GLU) ? OUT_GLU : OUT_BF16));
     const bool mask = p.flags & RS_GEMM_ROWMASK;
 #define RS_SMF(O, MK, TR)                                                                                          \
     do {                                                                                                           \
@@ -579,6 +605,7 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
         }
     }
     if (out == OUT_RES && !mask) RS_SMF(OUT_RES, false, false);
+    else if (out == OUT_RESLN && !mask) RS_SMF(OUT_RESLN, false, false);
     else if (out == OUT_F32 && !mask) RS_SMF(OUT_F32, false, false);
     else if (out == OUT_BF16 && !mask) RS_SMF(OUT_BF16, false, false);
     else if (out == OUT_BF16 && mask) RS_SMF(OUT_BF16, true, false);
@@ -649,6 +676,9 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         return rs_fail(ctx, RS_EINVAL, "gemm: bias flag without a 16-byte aligned pointer");
     if ((a.flags & RS_GEMM_RESIDUAL) && (!a.residual || ((uintptr_t)a.residual & 15)))
         return rs_fail(ctx, RS_EINVAL, "gemm: residual flag without a 16-byte aligned pointer");
+    if (a.res_ln_stats && (!(a.flags & RS_GEMM_RESIDUAL) || !a.res_ln_g || !a.res_ln_b || ((uintptr_t)a.res_ln_g & 15) ||
+                           ((uintptr_t)a.res_ln_b & 15) || ((uintptr_t)a.res_ln_stats & 7)))
+        return rs_fail(ctx, RS_EINVAL, "gemm: a normalised residual needs the residual flag, row statistics and aligned weight / bias");
     if (a.flags & RS_GEMM_GLU) {
         if (a.flags & (RS_GEMM_RELU | RS_GEMM_SILU | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32 | RS_GEMM_ROWMASK))
             return rs_fail(ctx, RS_EINVAL, "gemm: GLU combines with a bias only");
@@ -681,6 +711,7 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         p.A = a.A + r0 * a.lda; p.W = a.W;
         p.out = reinterpret_cast<char*>(a.out) + r0 * out_row;
         p.bias = a.bias; p.residual = a.residual ? a.residual + r0 * a.ldc : nullptr; p.mask_lens = a.mask_lens;
+        p.res_ln_stats = a.res_ln_stats ? a.res_ln_stats + r0 * 2 : nullptr; p.res_ln_g = a.res_ln_g; p.res_ln_b = a.res_ln_b;
         p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.M = (int)rows; p.N = a.N; p.K = a.K; p.flags = a.flags;
         p.alpha = a.alpha; p.mask_rows_per_step = a.mask_rows_per_step; p.mask_steps = a.mask_steps; p.mask_row0 = (int)r0;
         p.tiles_m = p.tiles_n = 0; p.group_m = 1;

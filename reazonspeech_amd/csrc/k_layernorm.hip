@@ -5,6 +5,10 @@
 
 namespace {
 
+// the normalisation of one element, written out so that the GEMM epilogue that applies a deferred output norm
+// (k_gemm_bf16.hip, OUT_RESLN) produces the same bits from the same (mean, rstd)
+__device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float g, float b) { return fmaf((v - mean) * rstd, g, b); }
+
 // One wave per row; d = 256 * NV (NV float4 per lane).  Two-pass statistics in registers:
 // mean, then sum((x-mean)^2) — the same formulation torch.layer_norm uses in float32.
 template <int NV>
@@ -37,10 +41,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < NV; ++i) {
         const float4 gg = gr[i * 64 + lane], bb = br[i * 64 + lane];
         float4 y;
-        y.x = (v[i].x - mean) * rstd * gg.x + bb.x;
-        y.y = (v[i].y - mean) * rstd * gg.y + bb.y;
-        y.z = (v[i].z - mean) * rstd * gg.z + bb.z;
-        y.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+        y.x = ln_apply(v[i].x, mean, rstd, gg.x, bb.x);
+        y.y = ln_apply(v[i].y, mean, rstd, gg.y, bb.y);
+        y.z = ln_apply(v[i].z, mean, rstd, gg.z, bb.z);
+        y.w = ln_apply(v[i].w, mean, rstd, gg.w, bb.w);
         if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[i * 64 + lane] = y;
         if (out_bf16) {
             u16x4_t o;
@@ -58,7 +62,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, const float* __restrict__ g1,
                                                          const float* __restrict__ b1, const float* __restrict__ g2,
                                                          const float* __restrict__ b2, int M, float eps,
-                                                         float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16) {
+                                                         float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16,
+                                                         float* __restrict__ stats) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -79,16 +84,19 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
         q += (a * a + bb * bb) + (c * c + dd * dd);
     }
     float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+    // deferred output norm: y is not stored; the consumer of the residual stream (the next layer's first residual GEMM)
+    // normalises x on the fly from these two numbers
+    if (stats && lane == 0) *reinterpret_cast<float2*>(stats + (size_t)row * 2) = make_float2(mean, rstd);
     s = 0.0f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const float4 gg = reinterpret_cast<const float4*>(g1)[i * 64 + lane], bb = reinterpret_cast<const float4*>(b1)[i * 64 + lane];
         float4 y;
-        y.x = (v[i].x - mean) * rstd * gg.x + bb.x;
-        y.y = (v[i].y - mean) * rstd * gg.y + bb.y;
-        y.z = (v[i].z - mean) * rstd * gg.z + bb.z;
-        y.w = (v[i].w - mean) * rstd * gg.w + bb.w;
-        reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[i * 64 + lane] = y;
+        y.x = ln_apply(v[i].x, mean, rstd, gg.x, bb.x);
+        y.y = ln_apply(v[i].y, mean, rstd, gg.y, bb.y);
+        y.z = ln_apply(v[i].z, mean, rstd, gg.z, bb.z);
+        y.w = ln_apply(v[i].w, mean, rstd, gg.w, bb.w);
+        if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[i * 64 + lane] = y;
         v[i] = y;
         s += (y.x + y.y) + (y.z + y.w);
     }
@@ -104,10 +112,10 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
     for (int i = 0; i < NV; ++i) {
         const float4 gg = reinterpret_cast<const float4*>(g2)[i * 64 + lane], bb = reinterpret_cast<const float4*>(b2)[i * 64 + lane];
         u16x4_t o;
-        o[0] = f32_to_bf16((v[i].x - mean) * rstd * gg.x + bb.x);
-        o[1] = f32_to_bf16((v[i].y - mean) * rstd * gg.y + bb.y);
-        o[2] = f32_to_bf16((v[i].z - mean) * rstd * gg.z + bb.z);
-        o[3] = f32_to_bf16((v[i].w - mean) * rstd * gg.w + bb.w);
+        o[0] = f32_to_bf16(ln_apply(v[i].x, mean, rstd, gg.x, bb.x));
+        o[1] = f32_to_bf16(ln_apply(v[i].y, mean, rstd, gg.y, bb.y));
+        o[2] = f32_to_bf16(ln_apply(v[i].z, mean, rstd, gg.z, bb.z));
+        o[3] = f32_to_bf16(ln_apply(v[i].w, mean, rstd, gg.w, bb.w));
         reinterpret_cast<u16x4_t*>(out_bf16 + (size_t)row * D)[i * 64 + lane] = o;
     }
 }
@@ -380,13 +388,14 @@ int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float
 }
 
 int rs_launch_layernorm2(rs_ctx* ctx, const float* x, const float* g1, const float* b1, const float* g2, const float* b2,
-                         int M, int d, float eps, float* out_f32, uint16_t* out_bf16, hipStream_t s) {
+                         int M, int d, float eps, float* out_f32, uint16_t* out_bf16, float* stats, hipStream_t s) {
     if (M <= 0) return RS_OK;
     if (d % 256 || d > 2048) return rs_fail(ctx, RS_EINVAL, "layernorm: d=%d must be a multiple of 256, <= 2048", d);
     const dim3 grid((M + 3) / 4), block(256);
-    rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, 16.0 * M * d, (double)M * d * 10.0);
+    if (!out_f32 && !stats) return rs_fail(ctx, RS_EINVAL, "layernorm2: neither the first norm's rows nor its statistics requested");
+    rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, 16.0 * M * d, (double)M * d * (out_f32 ? 10.0 : 6.0));
     switch (d / 256) {
-#define LN_CASE(NV) case NV: hipLaunchKernelGGL(layernorm2_kernel<NV>, grid, block, 0, s, x, g1, b1, g2, b2, M, eps, out_f32, out_bf16); break;
+#define LN_CASE(NV) case NV: hipLaunchKernelGGL(layernorm2_kernel<NV>, grid, block, 0, s, x, g1, b1, g2, b2, M, eps, out_f32, out_bf16, stats); break;
         LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
 #undef LN_CASE
     }

@@ -222,6 +222,7 @@ int rs_finalize(rs_ctx* ctx) {
             if (const char* e = getenv("RS_DECODE_SCREEN")) ctx->decode_screen = atoi(e) != 0;     // 0 = exact evaluation of every column
             if (const char* nw = getenv("RS_DECODE_NARROW")) ctx->decode_narrow = atoi(nw) != 0;   // 0 = the wide-tile kernels of round 1
             if (const char* fg = getenv("RS_FUSE_GLU")) ctx->fuse_glu = atoi(fg) != 0;             // 0 = GLU in the conv kernel
+            if (const char* dn = getenv("RS_DEFER_OUT_NORM")) ctx->defer_out_norm = atoi(dn) != 0; // 0 = every output norm stores its f32 rows
         }
     }
     auto it = ctx->tensors.find("pos.table");
@@ -272,6 +273,7 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
         ctx->fuse_glu = value;
         return RS_OK;
     }
+    if (!strcmp(key, "defer_out_norm")) { ctx->defer_out_norm = value != 0; return RS_OK; }
     return rs_fail(ctx, RS_EINVAL, "unknown option '%s'", key);
 }
 
@@ -299,7 +301,7 @@ namespace {
 
 struct EncPlan {
     int T[5], F[5];  // per stage time / freq extents (index 0 = mel)
-    size_t off_lens, off_sa, off_sb, off_x, off_hn, off_big, off_ctx, off_posp, total;
+    size_t off_lens, off_sa, off_sb, off_x, off_hn, off_big, off_ctx, off_posp, off_stats, total;
 };
 
 EncPlan plan_encoder(const rs_ctx* ctx, int B, int t_max) {
@@ -321,6 +323,7 @@ EncPlan plan_encoder(const rs_ctx* ctx, int B, int t_max) {
     p.off_big = o; o += rs_align(M * widest * 2);
     p.off_ctx = o; o += rs_align(M * dm * 2);
     p.off_posp = o; o += rs_align((2 * Tp) * dm * 2);
+    p.off_stats = o; o += rs_align(M * 2 * 4);          // (mean, rstd) per row of a deferred output norm
     p.total = o + 256;
     return p;
 }
@@ -388,6 +391,7 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
     uint16_t* big = reinterpret_cast<uint16_t*>(ws + pl.off_big);
     uint16_t* ctxb = reinterpret_cast<uint16_t*>(ws + pl.off_ctx);
     uint16_t* posp = reinterpret_cast<uint16_t*>(ws + pl.off_posp);
+    float* ln_stats = reinterpret_cast<float*>(ws + pl.off_stats);
     const int C = d.sub_channels, dm = d.d_model, ff = d.ff_dim, S = d.sub_stages;
     const int Tp = pl.T[S], M = B * Tp;
     int rc;
@@ -426,11 +430,14 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
     const uint16_t* pos_slice = reinterpret_cast<const uint16_t*>(pt.first) + (size_t)(tcap - Tp) * dm;
     const int npos = 2 * Tp - 1;
 
+    // res_ln: the residual operand still has to go through the PREVIOUS layer's output norm (deferred, see below)
+    const rs_layer_w* res_ln = nullptr;
     auto gemm = [&](const uint16_t* A, int lda, const uint16_t* W, int K, void* out, int ldc, int Mr, int N, int flags,
                     const float* bias, float alpha, const float* res) -> int {
         rs_gemm_args g{};
         g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.out = out; g.ldc = ldc; g.M = Mr; g.N = N; g.K = K;
         g.flags = flags; g.bias = bias; g.alpha = alpha; g.residual = res;
+        if (res && res_ln) { g.res_ln_stats = ln_stats; g.res_ln_g = res_ln->ln_out_g; g.res_ln_b = res_ln->ln_out_b; res_ln = nullptr; }
         return rs_launch_gemm(ctx, g, s);
     };
     const int RES = RS_GEMM_BIAS | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32;
@@ -473,11 +480,21 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         // output norm (in place on the residual stream; the last layer also emits the bf16 copy
         // that feeds the joint's encoder projection)
         if (last) {
-            RS_TRY(rs_launch_layernorm(ctx, x, L.ln_out_g, L.ln_out_b, M, dm, d.ln_eps, hn, x, s));
+            // the f32 rows of the final norm are read by the caller's enc_out copy / a parity tap only
+            bool want_f32 = enc_out != nullptr;
+            for (size_t k = 0; k < ctx->tap_ids.size(); ++k) want_f32 = want_f32 || ctx->tap_ids[k] == i;
+            RS_TRY(rs_launch_layernorm(ctx, x, L.ln_out_g, L.ln_out_b, M, dm, d.ln_eps, hn, want_f32 ? x : nullptr, s));
         } else {
-            // output norm + the next layer's first norm on one read of the row
+            // output norm + the next layer's first norm on one read of the row.  The normalised f32 rows themselves have
+            // ONE reader, the residual operand of the next layer's first FFN: unless a parity tap wants this layer's
+            // output, they are not written (145 MB per boundary at B = 256) — the kernel leaves (mean, rstd) per row and
+            // that GEMM's epilogue normalises x on the fly, with the same arithmetic (bit-identical: tests/test_gpu_pipeline.py)
             const rs_layer_w& Ln = ctx->layers[i + 1];
-            RS_TRY(rs_launch_layernorm2(ctx, x, L.ln_out_g, L.ln_out_b, Ln.ln_ff1_g, Ln.ln_ff1_b, M, dm, d.ln_eps, x, hn, s));
+            bool tapped = ctx->defer_out_norm == 0;
+            for (size_t k = 0; k < ctx->tap_ids.size(); ++k) tapped = tapped || ctx->tap_ids[k] == i;
+            RS_TRY(rs_launch_layernorm2(ctx, x, L.ln_out_g, L.ln_out_b, Ln.ln_ff1_g, Ln.ln_ff1_b, M, dm, d.ln_eps,
+                                        tapped ? x : nullptr, hn, tapped ? nullptr : ln_stats, s));
+            if (!tapped) res_ln = &L;
         }
         for (size_t k = 0; k < ctx->tap_ids.size(); ++k)     // parity taps: x now holds this layer's output
             if (ctx->tap_ids[k] == i)

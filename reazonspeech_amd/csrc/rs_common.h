@@ -98,6 +98,7 @@ struct rs_ctx {
     // position table cache: the caller registers "pos_table.<T>" tensors (bf16 [2T-1][d])
     // options (rs_set_option)
     int n_cus = 0;                  // compute units of the device (queried on first use)
+    int defer_out_norm = 1;         // 1 = a layer's output norm is applied by the next layer's first residual GEMM (f32 rows not stored); bit-identical to 0
     int fuse_glu = 1;               // conv module: 1 = GLU in the pw1 GEMM epilogue (every batch size: one rounding point, batch-invariant);
                                     // 0 = plain pw1 product, GLU in the depthwise kernel ($RS_FUSE_GLU; A/B and layout tests)
     bool env_read = false;          // the $RS_* defaults were applied (once, by the first rs_finalize; rs_set_option wins afterwards)
@@ -150,12 +151,16 @@ struct rs_gemm_args {
     const float* bias; float alpha;
     const float* residual;
     const int32_t* mask_lens; int mask_rows_per_step; int mask_steps;
+    // residual = LayerNorm(residual operand; res_ln_g, res_ln_b) with per-row (mean, rstd) in res_ln_stats [M][2]
+    // (nullptr: the residual operand is used as it is)
+    const float* res_ln_stats; const float* res_ln_g; const float* res_ln_b;
 };
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s);
 int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float* b, int M, int d, float eps,
                         uint16_t* out_bf16, float* out_f32, hipStream_t s);
+// out_f32 == nullptr: the first norm's rows are not stored; `stats` [M][2] receives its (mean, rstd) per row instead
 int rs_launch_layernorm2(rs_ctx* ctx, const float* x, const float* g1, const float* b1, const float* g2, const float* b2,
-                         int M, int d, float eps, float* out_f32, uint16_t* out_bf16, hipStream_t s);
+                         int M, int d, float eps, float* out_f32, uint16_t* out_bf16, float* stats, hipStream_t s);
 int rs_launch_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, const float* bias_u,
                         const float* bias_v, const int32_t* lens, int B, int T, uint16_t* out, hipStream_t s);
 int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, int layout, const float* w, const float* b, const int32_t* lens,
