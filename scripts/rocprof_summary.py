@@ -32,6 +32,32 @@ def main():
         for n, g, c, a, mn, sm in cur.execute(q).fetchall():
             short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             print(f"{short[:64]:<64} {g:>7} {c:>7} {a / 1e3:>10.2f} {mn / 1e3:>9.2f} {sm / 1e6:>10.3f}")
+    gaps(cur, cols, name_col)
+
+
+def gaps(cur, cols, name_col):
+    """idle time between consecutive kernels of the stream the encoder runs on (the one with the most GEMM time)"""
+    key = next((c for c in ("stream_id", "queue_id", "stream", "queue") if c in cols), None)
+    if key is None:
+        print(f"\n# no stream / queue column in {cols}")
+        return
+    best = cur.execute(f"select {key}, sum(end - start) from kernels where {name_col} like '%gemm_smf16_kernel%' group by {key} "
+                       f"order by 2 desc limit 1").fetchone()
+    if not best:
+        return
+    rows = cur.execute(f"select start, end, {name_col} from kernels where {key} = ? order by start", (best[0],)).fetchall()
+    g = []
+    for (s0, e0, n0), (s1, e1, n1) in zip(rows, rows[1:]):
+        d = s1 - e0
+        if 0 <= d < 50_000:                 # longer pauses are step boundaries / host waits, not launch gaps
+            g.append(d)
+    if not g:
+        return
+    g.sort()
+    busy = sum(e - s for s, e, _ in rows)
+    print(f"\n# encoder stream ({key} {best[0]}): {len(rows)} kernels, {busy / 1e6:.1f} ms busy; idle between consecutive kernels "
+          f"(gaps < 50 us): n={len(g)} mean {sum(g) / len(g) / 1e3:.2f} us, median {g[len(g) // 2] / 1e3:.2f}, p90 {g[len(g) * 9 // 10] / 1e3:.2f}, "
+          f"sum {sum(g) / 1e6:.2f} ms ({sum(g) / (busy + sum(g)):.1%} of the stream's span)")
 
 
 if __name__ == "__main__":

@@ -412,34 +412,37 @@ def test_full_size_model_properties(gpu_device):
 
 
 @pytest.mark.parametrize("tile", [0, 256, 192, 128, 64])
-def test_deferred_output_norm_is_bit_identical(gpu_device, tile):
-    """`defer_out_norm` (default): a layer's output LayerNorm is applied by the next layer's first residual GEMM from
-    per-row (mean, rstd) instead of being stored.  The encoder output, the joint projection and the hypotheses are the
-    same BITS as with every output norm stored, at every GEMM tile height; a layer with a parity tap stores its rows."""
+@pytest.mark.parametrize("option", ["defer_out_norm"])
+def test_fused_epilogues_are_bit_identical(gpu_device, option, tile):
+    """A fusion that moves work into a GEMM epilogue without changing a bit of the result, checked against its unfused
+    form at every GEMM tile height on a ragged batch and on one utterance: `defer_out_norm` — a layer's output LayerNorm
+    is applied by the next layer's first residual GEMM from per-row (mean, rstd) instead of being stored.  (The same test
+    held `fuse_dwconv` — depthwise conv + SiLU in the pw1 epilogue — bit-identical too; that fusion was measured and
+    removed: profiles/r03t_*.)"""
     import ctypes
     from reazonspeech_amd.runtime.config import FASTCONFORMER_619M
     cfg = FASTCONFORMER_619M.with_(n_layers=3)
     sd = synthetic_state_dict(cfg, 5)
     model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device="cuda:0")
     audio, lens = synthetic_batch(7, 4.0, seed=99, ragged=True, min_seconds=1.0)
-    waves = [audio[b, :lens[b]] for b in range(7)]
     lib = model.ctx.lib
     lib.rs_debug_set_gemm_tile.argtypes = [ctypes.c_int]
     lib.rs_debug_set_gemm_tile.restype = None
-    outs = []
-    try:
-        lib.rs_debug_set_gemm_tile(tile)
-        for defer in (1, 0):
-            model.ctx.set_option("defer_out_norm", defer)
-            buf = model.stage(waves)
-            enc = torch.zeros((7, buf.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
-            model.run_device(buf, want_enc=enc)
-            torch.cuda.synchronize()
-            res = model.collect(buf)
-            outs.append((enc.clone(), buf.joint_enc.clone(), res.ids, res.frames))
-    finally:
-        lib.rs_debug_set_gemm_tile(0)
-        model.ctx.set_option("defer_out_norm", 1)
-    assert torch.isfinite(outs[0][0]).all() and outs[0][0].abs().max() > 0
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
+    for waves in ([audio[b, :lens[b]] for b in range(7)], [audio[2, :lens[2]]]):
+        outs = []
+        try:
+            lib.rs_debug_set_gemm_tile(tile)
+            for on in (1, 0):
+                model.ctx.set_option(option, on)
+                buf = model.stage(waves)
+                enc = torch.zeros((len(waves), buf.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
+                model.run_device(buf, want_enc=enc)
+                torch.cuda.synchronize()
+                res = model.collect(buf)
+                outs.append((enc.clone(), buf.joint_enc.clone(), res.ids, res.frames))
+        finally:
+            lib.rs_debug_set_gemm_tile(0)
+            model.ctx.set_option(option, 1)
+        assert torch.isfinite(outs[0][0]).all() and outs[0][0].abs().max() > 0
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
