@@ -434,7 +434,7 @@ def main():
                 res = model.transcribe_waveforms(waves, max_batch=args.batch)
                 runs.append(time.perf_counter() - t1)
             audios = [audio_from_numpy(w, 16000) for w in waves]
-            transcribe_batch(model, audios[:args.batch], TranscribeConfig(verbose=False))     # first call: lazy imports of the audio helpers
+            transcribe_batch(model, audios[:args.batch], TranscribeConfig(verbose=False))     # first call: fills the per-tokenizer piece-text cache
             runs_text = []
             for _ in range(3):
                 t1 = time.perf_counter()
