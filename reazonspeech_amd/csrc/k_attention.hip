@@ -55,7 +55,10 @@ __device__ __forceinline__ int vt_pos(int key) {
 // One workgroup = (batch b, head h, up to 6 query blocks of 32); one wave = one query block.
 // (Tried in round 3: delaying every second workgroup of the first dispatch round by 2k .. 14k cycles so that the Q / K / V
 // prologue bursts of the two halves of the chip stop coinciding — no effect, 154 - 156 us either way:
-// profiles/r03i_attn_skew_ab.txt.  The prologues are not what paces the launch.)
+// profiles/r03i_attn_skew_ab.txt.  Also tried: the loads issued in consumption order (Q, bias, first position rows, K by
+// global_load_lds into a swizzled 256-byte-pitch image, V) with the Q fragments and the first position block built BEFORE
+// the K / V barrier instead of after it — bit-identical, 152.4 / 153.1 vs 151.1 / 152.4 us on one box
+// (profiles/r03w_attn_prologue_ab.txt): the microsecond moved under the loads comes back as a longer load phase.)
 // WINDOW: limited-context / global-token masks compiled in (full attention otherwise: no per-score branches)
 template <bool TRACE, bool WINDOW>
 __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
