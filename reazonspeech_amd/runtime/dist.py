@@ -21,8 +21,18 @@ def init(backend: str = "nccl"):
         dist.init_process_group(backend=backend)
 
 
+_single_rank_collectives = False
+
+
+def use_collectives_with_one_rank(on: bool):
+    """Hardware check of the exchange without a second GPU: with a process group of ONE rank the gather / all_reduce of
+    this module are normally skipped; switched on, they run through the backend (RCCL on a GPU box) all the same."""
+    global _single_rank_collectives
+    _single_rank_collectives = bool(on)
+
+
 def is_on() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _single_rank_collectives)
 
 
 def world_size() -> int:
@@ -109,7 +119,7 @@ def sharded_decode(lengths: Sequence[int], run_local, counters=None):
     scores = res[3] if len(res) > 3 else None
     assert len(ids) == len(frames) == len(enc_lens) == len(shards[r]), "run_local must answer for every index it was given"
     assert scores is None or len(scores) == len(ids)
-    if W == 1:
+    if W == 1 and not _single_rank_collectives:
         out = ([None] * n, [None] * n, [None] * n, [None] * n if scores is not None else None)
         for k, i in enumerate(shards[0]):
             out[0][i], out[1][i], out[2][i] = list(ids[k]), list(frames[k]), int(enc_lens[k])

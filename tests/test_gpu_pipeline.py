@@ -446,3 +446,41 @@ def test_fused_epilogues_are_bit_identical(gpu_device, option, tile):
         assert torch.isfinite(outs[0][0]).all() and outs[0][0].abs().max() > 0
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3]
+
+
+def test_hypothesis_exchange_through_rccl_single_rank(gpu_device):
+    """The multi-GPU exchange on the hardware that is available: a `nccl` (= RCCL) process group of one rank, with the
+    collectives of runtime/dist.py forced on — the MAX all_reduce that agrees on the payload width and the one
+    all_gather_into_tensor of (count | encoder length | score bits | ids | frames) run through RCCL on device tensors and
+    give back exactly what the local decode produced, for the greedy and the beam-search payload (scores bit for bit).
+    (World sizes 2 and 8 are covered on CPU with gloo: tests/test_host_runtime.py.)"""
+    import socket
+    import torch.distributed as dist
+    from reazonspeech_amd.runtime import dist as rdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    assert not dist.is_initialized()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        rdist.use_collectives_with_one_rank(True)
+        assert rdist.is_on() and dist.get_backend() == "nccl"
+        audio, lens = synthetic_batch(9, 3.0, seed=5, ragged=True, min_seconds=0.5)
+        waves = [audio[b, :lens[b]] for b in range(9)]
+        for decoding in ("greedy_batch", "alsd"):
+            cfg = TINY.with_(decoding=decoding, beam_size=3)
+            model = AsrModel(cfg, synthetic_state_dict(cfg, 2), SyntheticTokenizer(cfg.vocab_size), device="cuda:0")
+            want = model.transcribe_waveforms(waves)
+            got = model.transcribe_waveforms_sharded(waves)
+            assert got.ids == want.ids and got.frames == want.frames and list(got.enc_lens) == list(want.enc_lens)
+            if decoding == "alsd":
+                assert np.array_equal(np.asarray(got.scores, dtype=np.float32).view(np.uint32),
+                                      np.asarray(want.scores, dtype=np.float32).view(np.uint32))
+            assert sum(len(x) for x in got.ids) > 0
+        assert rdist.max_over_ranks(1.25) == 1.25
+        rdist.barrier()
+    finally:
+        rdist.use_collectives_with_one_rank(False)
+        dist.destroy_process_group()
