@@ -102,7 +102,10 @@ class _BufView:
                 n *= d
             return t.view(-1)[:n].view(*shape)
 
-        self.audio, self.lens = base.audio, base.lens          # rows keep the full pitch (the stride is an argument)
+        # device and pinned staging re-viewed as contiguous [B][l_max] (the kernels take the row pitch as an argument):
+        # the H2D copy of a narrowed batch is then ONE contiguous asynchronous copy — a column slice of the full-pitch
+        # matrices made torch stage 164 MB through a pageable temporary, synchronously (profiles/r03x_host_timeline_ragged.txt)
+        self.audio, self.lens = cut(base.audio, B, l_max), base.lens
         self.feats = cut(base.feats, B, self.t_max, cfg.n_mels)
         self.n_frames = base.n_frames
         self.joint_enc = cut(base.joint_enc, B, self.tp_max, cfg.joint_hidden)
@@ -111,7 +114,7 @@ class _BufView:
         self.frames = cut(base.frames, B, self.u_max)
         self.n_ids, self.scores = base.n_ids, base.scores
         self.ws, self.ws_dec = base.ws, base.ws_dec
-        self.h_audio, self.h_lens = base.h_audio, base.h_lens
+        self.h_audio, self.h_lens = cut(base.h_audio, B, l_max), base.h_lens
         self.h_out = None
         self.step = -1
 
@@ -427,7 +430,7 @@ class AsrModel:
         assert view.l_max >= longest
         # one native call for the whole batch (it runs without the interpreter lock: a per-utterance numpy copy would
         # queue behind whatever Python thread holds it — the ids -> text post-processing of an earlier batch)
-        capi.host_stage_rows(buf.h_audio, view.l_max, waveforms, buf.h_lens)
+        capi.host_stage_rows(view.h_audio, view.l_max, waveforms, buf.h_lens)
         return view
 
     def stage(self, waveforms: Sequence[np.ndarray], l_max: Optional[int] = None, buf: Optional[_Buffers] = None) -> _Buffers:
@@ -480,6 +483,7 @@ class AsrModel:
         ids, frames, enc_lens, scores = rdist.sharded_decode([len(w) for w in waveforms], run_local)
         return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.decoding == "alsd" else None)
 
+    LONGEST_FIRST = True    # batch order of a long list (A/B hook of scripts/ragged_order_ab.py)
     POOL_SETS = 4       # resident batches of the host-to-host pipeline (encoder(i+2) || decode(i+1), decode(i) + one being staged)
 
     def _pool(self, B, l_max, n_sets):
@@ -520,6 +524,10 @@ class AsrModel:
         order = sorted(range(n), key=lambda i: (len(waveforms[i]), i))
         ids, frames, enc_lens, scores = [None] * n, [None] * n, [None] * n, [None] * n
         groups = [order[i:i + max_batch] for i in range(0, n, max_batch)]
+        # longest batch first: what is left after the last encoder is one decode, and the shortest batch's is the shortest
+        # (a ragged list's drain shrinks from the longest batch's decode to the shortest's)
+        if self.LONGEST_FIRST:
+            groups.reverse()
         l_max = max(len(w) for w in waveforms)
         n_sets = min(self.POOL_SETS, len(groups))
         pool = self._pool(max_batch, l_max, n_sets)

@@ -21,10 +21,15 @@ def main():
     warnings.simplefilter("ignore")
     model = load_model("cuda:0")
     rng = np.random.default_rng(0)
-    base = [(0.1 * rng.standard_normal(160000)).astype(np.float32) for _ in range(256)]
-    waves = [base[i % 256] for i in range(nb * 256)]
+    if "--ragged" in sys.argv:          # SURVEY 8(d)'s ragged set: lengths U(2 s, 10 s), seed 1235
+        from reazonspeech_amd.runtime.synth import synthetic_batch
+        audio, lens = synthetic_batch(nb * 256, 10.0, seed=1235, ragged=True, min_seconds=2.0)
+        waves = [audio[i, :lens[i]] for i in range(nb * 256)]
+    else:
+        base = [(0.1 * rng.standard_normal(160000)).astype(np.float32) for _ in range(256)]
+        waves = [base[i % 256] for i in range(nb * 256)]
     audios = [audio_from_numpy(w, 16000) for w in waves]
-    model.transcribe_waveforms(waves[:768])
+    model.transcribe_waveforms(waves[:1024])
     events = []
     t0 = [0.0]
 
