@@ -118,6 +118,9 @@ class _BufView:
         self.h_out = None
         self.step = -1
 
+    def narrow(self, l_max):
+        return self.base.narrow(l_max)
+
     @property
     def ws_alsd(self):
         return self.base.ws_alsd
@@ -221,7 +224,11 @@ class AsrModel:
         depend on the padded extent (tests: batch invariance), and consecutive transcribe() calls on clips of
         different lengths stop re-allocating pinned staging + workspace every time."""
         l_max = (max(int(l_max), 1) + self.BUCKET - 1) // self.BUCKET * self.BUCKET
-        fits = [k for k in self._bufs if k[0] == B and l_max <= k[1] <= 2 * l_max]
+        # any cached set that is long enough will do: `stage` narrows it to the batch at hand (`_Buffers.narrow`), so a
+        # longer set costs nothing per call and a folder of files of mixed lengths settles on ONE set instead of cycling
+        # through the four cached geometries (per-call latency by length: profiles/r03x_varied_lengths_latency_reuse.txt —
+        # it follows frames + emitted tokens, e.g. 7.8 ms for 2.2 s, 10 ms for 5 s, 29 ms for 29 s of noise)
+        fits = [k for k in self._bufs if k[0] == B and l_max <= k[1]]
         if fits:
             key = min(fits, key=lambda k: k[1])
             self._bufs[key] = self._bufs.pop(key)          # most recently used last
@@ -442,6 +449,7 @@ class AsrModel:
         if buf is None:
             buf = self.buffers(B, l_max)
         assert buf.B == B and buf.l_max >= longest
+        buf = buf.narrow(l_max)                  # the set itself when it has exactly this extent, else a tight view of it
         ha = buf.h_audio.numpy()
         hl = buf.h_lens.numpy()
         for b, w in enumerate(waveforms):

@@ -19,7 +19,8 @@ def main():
     dec = ([a.split("=")[1] for a in sys.argv[1:] if a.startswith("--decoding=")] or [None])[0]
     model = load_model("cuda:0", decoding=dec)
     rng = np.random.default_rng(0)
-    wave = (0.1 * rng.standard_normal(160000)).astype(np.float32)
+    secs = ([float(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--seconds=")] or [10.0])[0]
+    wave = (0.1 * rng.standard_normal(int(secs * 16000))).astype(np.float32)
     for _ in range(3):
         model.transcribe_waveforms([wave])
     lat = []
@@ -29,7 +30,7 @@ def main():
         r = model.transcribe_waveforms([wave])
         lat.append(time.perf_counter() - t0)
     lat.sort()
-    print(f"decoding={dec or 'greedy'} latency median {lat[5] * 1e3:.2f} ms min {lat[0] * 1e3:.2f} ms tokens {len(r.ids[0])}")
+    print(f"{secs:g} s decoding={dec or 'greedy'} latency median {lat[5] * 1e3:.2f} ms min {lat[0] * 1e3:.2f} ms tokens {len(r.ids[0])}")
     # stage / encoder / decode split (host clocks around synchronising calls)
     buf = model.stage([wave])
     torch.cuda.synchronize()
