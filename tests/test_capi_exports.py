@@ -84,3 +84,24 @@ def test_host_stage_rows_gathers_a_ragged_batch():
     assert (dst[3:] == 7).all()                       # rows past the batch keep their bytes; only their length is reset
     with pytest.raises(capi.RsError):
         capi.host_stage_rows(dst, 8, waves, lens)     # an utterance longer than the width
+
+
+def test_host_stage_rows_into_a_narrowed_contiguous_view():
+    """What the host pipeline does for a batch shorter than its buffer set (runtime/model.py: _BufView): the pinned
+    staging matrix is re-viewed as a contiguous [rows][l_max] block of the same memory and the batch is gathered with THAT
+    pitch, so the host-to-device copy of the batch is one contiguous range (a column slice of the full-pitch matrix was
+    copied through a synchronous temporary)."""
+    import numpy as np
+    import torch
+    base = torch.full((4, 256), 9.0)
+    view = base.view(-1)[:4 * 64].view(4, 64)              # what _BufView's `cut` builds
+    assert view.is_contiguous() and view.data_ptr() == base.data_ptr()
+    lens = torch.zeros((4,), dtype=torch.int32)
+    waves = [np.full(40, 1.0, np.float32), np.full(64, 2.0, np.float32), np.full(3, 3.0, np.float32)]
+    capi.host_stage_rows(view, 64, waves, lens)
+    flat = base.view(-1)
+    assert lens.tolist() == [40, 64, 3, 0]
+    assert (flat[0:40] == 1).all() and (flat[40:64] == 0).all()
+    assert (flat[64:128] == 2).all()
+    assert (flat[128:131] == 3).all() and (flat[131:192] == 0).all()
+    assert (flat[256:] == 9).all()                          # nothing beyond the view's rows was touched
