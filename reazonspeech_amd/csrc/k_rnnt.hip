@@ -839,7 +839,11 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     const int max_steps = tp_max + (u_max < tp_max * d.max_symbols ? u_max : tp_max * d.max_symbols) + 1;
     // (the whole loop as ONE persistent launch with agent-scope grid barriers between the phases of a step was built and
     // measured in round 2 — bit-identical, slower: five barriers per step cost more than five launch boundaries,
-    // profiles/r02p_persistent_decode_ab.txt — and removed this round; k_rnnt_persist.hip is in the history at 6afb282)
+    // profiles/r02p_persistent_decode_ab.txt — and removed this round; k_rnnt_persist.hip is in the history at 6afb282.
+    // A chunk of 16 steps captured as a hipGraph and replayed (the kernels use only the parity of the step index, so every
+    // replay has the same arguments) was tried for the launch-bound small batches: bit-identical, and slower for one 10 s
+    // utterance — decode 3.7 - 3.8 ms against 2.9 - 3.4 ms of plain launches, -1 ... -2 ms only on 20 - 30 s utterances
+    // and 40 ms for the first capture of a geometry — profiles/r03x_decode_graph_b1_ab.txt: not kept.)
     const int CHUNK = 16;
     int32_t host_counters[4] = {0, 0, 0, 0};
     int steps = 0, alive_bound = B;
