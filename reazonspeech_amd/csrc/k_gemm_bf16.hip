@@ -4,7 +4,8 @@
 //
 // This ONE kernel family carries every dense contraction of the encoder (SURVEY.md §8a rows S2-S4, L2, L3, L6
 // pw1/pw2, D1): 96.8 % of the path's FLOPs.  There is a single kernel, gemm_smf16_kernel, instantiated for four
-// tile heights (BM = 256 / 192 / 128 / 64 rows x 256 columns) and four epilogues.  Every instantiation computes an
+// tile heights (BM = 256 / 192 / 128 / 64 rows x 256 columns) and five epilogues (bf16, f32, f32 + residual, f32 +
+// LayerNorm(residual) from per-row statistics, GLU).  Every instantiation computes an
 // output element with the SAME arithmetic — v_mfma_f32_16x16x32_bf16 over ascending 32-deep k-steps into one f32
 // accumulator, then bias / activation / alpha / residual in a fixed order — so a row's result does not depend on
 // M, on the tile height the launcher picks, or on where the row sits in a tile: the encoder is batch-invariant
@@ -18,14 +19,19 @@
 //     VGPR round trip), 8 rows x 128 B per wave instruction, issued from inline asm; 16-byte chunks of an LDS row
 //     are XOR-swizzled by (row >> 1) & 7 on the per-lane SOURCE address and again on the ds_read_b128 fragment
 //     reads (conflict-free).
-//   * LDS = five 32-KiB operand-part slots ("split ring"): a K tile is two parts (A rows, weight rows), part p lives
-//     in slot p mod 5; during K tile t a wave issues first its pieces of B(t+1), then its pieces of A(t+2), which
-//     have a whole extra K tile to land.  Waits are COUNTED s_waitcnt vmcnt(n) across raw s_barriers (guide §5
+//   * LDS, tiles of 256 / 192 rows = five 32-KiB operand-part slots ("split ring"): a K tile is two parts (A rows,
+//     weight rows), part p lives in slot p mod 5; during K tile t a wave issues its pieces of A(t+2), which have a whole
+//     extra K tile to land, and its weight pieces of the NEXT K tile — wave group 0 in its phase-0 memory half, wave
+//     group 1 (one barrier behind: it would have two phases for them to land instead of three) one phase earlier,
+//     between the MFMAs of phase 1 of the K tile before.  Tiles of 128 / 64 rows = three whole K-tile stages: both
+//     operands are issued two K tiles ahead.  Waits are COUNTED s_waitcnt vmcnt(n) across raw s_barriers (guide §5
 //     T3+T4), never a drain.
+//   * two consecutive tiles per workgroup (singles in the last round), the ring carried from the first into the second:
+//     the last K tiles of tile 0 already issue tile 1's first K tiles, which land during tile 0's epilogue.
 //   * the two wave groups run half a phase apart (ping-pong): one issues its MFMAs while the other does its
 //     fragment reads and DMA issues.
 //   * XCD-aware, grouped blockIdx -> tile order (each XCD, private L2, walks a contiguous run of tiles).
-//   * epilogue through a per-wave 4-KiB LDS scratch (aliasing slot 0) so every global access is a whole 128 / 256-
+//   * epilogue through a per-wave 4-KiB LDS scratch (aliasing a dead slot / stage) so every global access is a whole 128 / 256-
 //     byte row segment: +bias, ReLU / SiLU / GLU, *alpha, +residual (f32, prefetched), per-utterance row mask.
 #include <stdlib.h>
 
