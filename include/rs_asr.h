@@ -166,7 +166,15 @@ int rs_stream_destroy(void* stream);
  *                        column that can still be the argmax (bit-identical result); 0 = every column in exact float32.
  *   "decode_narrow"      1 (default): LSTM / prediction-projection kernels with one 16-column tile per workgroup (4x the
  *                        workgroups, a quarter of the per-launch latency on an idle chip); 0 = the wide-tile kernels, which
- *                        need fewer free CUs per launch and do better next to the encoder GEMMs of the two-stage pipeline. */
+ *                        need fewer free CUs per launch and do better next to the encoder GEMMs of the two-stage pipeline.
+ *   "precision_f32"      0 (default): the throughput mode — bf16 GEMM operands and stored activations, float32 accumulation,
+ *                        float32 residual stream.  1: the PARITY mode — rs_encoder_forward runs with float32 weights,
+ *                        activations and arithmetic end to end (exact-f32 matrix-core GEMMs, IEEE exp / divide), which is what
+ *                        the reference computes (pkg/nemo-asr/src/transcribe.py:26-28, :48-53: float32, no autocast).  Needs the
+ *                        "<name>.f32" tensors: float32 copies of every bf16 GEMM weight (same layout; "L{i}.conv.pw1.w.f32" /
+ *                        ".b.f32" in NeMo's own row order, values then gates) and "pos.table.f32"; rs_workspace_bytes
+ *                        accounts for the mode once they are registered.  ~20x slower; front-end and decode are float32 in
+ *                        both modes. */
 int rs_set_option(rs_ctx* ctx, const char* key, int value);
 
 /* Parity taps (tests only; no reference counterpart — NeMo exposes intermediate activations through
@@ -247,6 +255,17 @@ int rs_gemm_bf16(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int
                  void* out, int ldc, int M, int N, int K, int flags, const float* bias, float alpha,
                  const float* residual, const int32_t* mask_lens, int mask_rows_per_step,
                  int mask_steps, void* stream);
+
+/* The float32 parity mode's operators (rs_set_option "precision_f32"), one by one: the same contracts as rs_gemm_bf16 (flags
+ * BIAS / RELU / SILU / RESIDUAL / ROWMASK; K % 32 == 0, N % 4 == 0), rs_relpos_attention (any head_dim <= 256) and
+ * rs_glu_dwconv_silu (x f32[B*T][2*d], values | gates) on float32 tensors. */
+int rs_gemm_f32(rs_ctx* ctx, const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K,
+                int flags, const float* bias, float alpha, const float* residual, const int32_t* mask_lens,
+                int mask_rows_per_step, int mask_steps, void* stream);
+int rs_relpos_attention_f32(rs_ctx* ctx, const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
+                            const int32_t* lens, int B, int T, float* ctx_out, void* stream);
+int rs_glu_dwconv_silu_f32(rs_ctx* ctx, const float* x, const float* dw_w, const float* dw_b, const int32_t* lens, int B,
+                           int T, int d, int k, float* out, void* stream);
 
 /* y = LayerNorm(x) over the last dim (d); x f32[M][d]; out_bf16 and/or out_f32 may be NULL. */
 int rs_layernorm(rs_ctx* ctx, const float* x, const float* gamma, const float* beta, int M, int d,

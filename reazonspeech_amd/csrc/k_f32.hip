@@ -1,0 +1,393 @@
+// k_f32.hip — the float32 PARITY MODE of the encoder (rs_set_option "precision_f32").
+//
+// The reference runs this model in float32 with no autocast (pkg/nemo-asr/src/transcribe.py:26-28, :48-53).  The
+// throughput mode of this library feeds bf16 operands to the matrix cores; this file is the same encoder with float32
+// weights, float32 activations and float32 arithmetic end to end, so that "greedy token ids identical to the float32
+// reference" is a statement about the whole path and not only about the decode loop:
+//
+//   gemm_f32_kernel        every dense contraction on v_mfma_f32_16x16x4_f32 (an exact f32 fma chain; 157 TF/s peak), one
+//                          fixed summation order per output element (ascending 16-blocks, inside a block k = e + 4 kk),
+//                          independent of M and of the tile position: batch-invariant like the bf16 family
+//   attention_f32_kernel   rel-pos attention, one wave per query row, float32 scores / softmax / PV
+//   glu_dwconv_silu_f32    conv-module middle with IEEE exp / divide
+//   (LayerNorm: k_layernorm.hip's kernels already compute and can store float32; subsampling: the float32 instantiations
+//    of k_subsample.hip)
+//
+// Speed is not the object (about 1 s per batch of 256 x 10 s against 55 ms in the throughput mode); the kernels are kept
+// simple enough to be read against oracle/model.py line by line.
+#include "rs_common.h"
+
+int rs_launch_sub_conv0_dw1_f32(rs_ctx* ctx, const float* feats, const int32_t* lens_stage, int B, int t_max, int T2, int F2,
+                                float* out, hipStream_t s);
+int rs_launch_sub_dw_f32(rs_ctx* ctx, const float* in, const float* w, const float* b, const int32_t* lens_out, int B, int t_in,
+                         int f_in, int t_out, int f_out, float* out, hipStream_t s);
+
+namespace {
+
+// IEEE forms (the throughput mode uses v_exp / v_rcp approximations: rs_common.h sigmoid_f)
+__device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+
+struct GemmF32 {
+    const float* A; const float* W; float* out;
+    const float* bias; const float* residual; const int32_t* mask_lens;
+    int lda, ldw, ldc, M, N, K, flags;
+    float alpha;
+    int mask_rows_per_step, mask_steps;
+};
+
+constexpr int GT = 128;   // tile rows / columns
+constexpr int GK = 32;    // K depth of a stage
+constexpr int GP = 36;    // LDS row pitch in floats (144 B: 16-byte aligned, rows 8 apart share a bank group)
+
+// out[M][N] = epilogue(A[M][K] . W[N][K]^T), all float32.  256 threads = 2 x 2 waves, a wave owns 64 x 64 outputs
+// (4 x 4 MFMA blocks).  The weight fragment is the MFMA A operand, so a lane's four accumulator registers are four
+// CONSECUTIVE columns of one output row: bias / residual / store are float4 accesses.
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
+    __shared__ __attribute__((aligned(16))) float As[GT * GP];
+    __shared__ __attribute__((aligned(16))) float Ws[GT * GP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int lr = tid >> 3, lc = tid & 7;            // staging: row lr + 32 i, 16-byte chunk lc of the 128-byte K slice
+    float4 ra[4], rw[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = m0 + lr + 32 * i, n = n0 + lr + 32 * i;
+            m = m < p.M ? m : p.M - 1;                // rows past the matrix: clamped, their products are never stored
+            n = n < p.N ? n : p.N - 1;
+            ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + k0 + 4 * lc);
+            rw[i] = *reinterpret_cast<const float4*>(p.W + (size_t)n * p.ldw + k0 + 4 * lc);
+        }
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    gload(0);
+    for (int k0 = 0; k0 < p.K; k0 += GK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(As + (lr + 32 * i) * GP + 4 * lc) = ra[i];
+            *reinterpret_cast<float4*>(Ws + (lr + 32 * i) * GP + 4 * lc) = rw[i];
+        }
+        __syncthreads();
+        if (k0 + GK < p.K) gload(k0 + GK);
+#pragma unroll
+        for (int kb = 0; kb < GK / 16; ++kb) {
+            float4 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const float4*>(As + (wm * 64 + i * 16 + fr) * GP + kb * 16 + 4 * fq);
+                wf[i] = *reinterpret_cast<const float4*>(Ws + (wn * 64 + i * 16 + fr) * GP + kb * 16 + 4 * fq);
+            }
+            // step e of a 16-block multiplies k = 16 kb + 4 kk + e for the four lane groups kk at once
+#define RS_F32_STEP(E)                                                                                          \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
+                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                               \
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni].E, af[mi].E, acc[ni][mi], 0, 0, 0);
+            RS_F32_STEP(x) RS_F32_STEP(y) RS_F32_STEP(z) RS_F32_STEP(w)
+#undef RS_F32_STEP
+        }
+        __syncthreads();
+    }
+    // epilogue, the order of k_gemm_bf16.hip: + bias, activation, * alpha, + residual, row mask
+    const bool has_bias = p.flags & RS_GEMM_BIAS, relu = p.flags & RS_GEMM_RELU, silu = p.flags & RS_GEMM_SILU;
+    const bool res = p.flags & RS_GEMM_RESIDUAL, rowmask = p.flags & RS_GEMM_ROWMASK;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + fr;
+        if (m >= p.M) continue;
+        bool keep = true;
+        if (rowmask) {
+            const int step = m / p.mask_rows_per_step;
+            const int b = step / p.mask_steps;
+            keep = step - b * p.mask_steps < p.mask_lens[b];
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + 4 * fq;
+            if (n >= p.N) continue;
+            float4 v = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+            if (has_bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (silu) { v.x = silu_exact(v.x); v.y = silu_exact(v.y); v.z = silu_exact(v.z); v.w = silu_exact(v.w); }
+            v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+            if (res) {
+                const float4 r = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldc + n);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldc + n) = v;
+        }
+    }
+}
+
+// Rel-pos attention in float32 (oracle/model.py: attention_core).  One wave per query row; a lane holds elements
+// lane, lane + 64, .. of the head dimension.  Two passes over the visible keys (maximum, then exp / sum / PV), the
+// scores are recomputed in the second pass.
+//   s[i][j] = ((q_i + u) . k_j + (q_i + v) . p[j - i + T - 1]) * scale;  masked keys weigh 0, padded queries -> 0
+template <int NV>
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ pos,
+                                                            const float* __restrict__ bias_u, const float* __restrict__ bias_v,
+                                                            const int32_t* __restrict__ lens, float* __restrict__ out, int T,
+                                                            int d, int hd, int att_left, int att_right, int n_global, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+    if (i >= T) return;
+    int len = lens[b];
+    len = len < T ? len : T;
+    float* orow = out + ((size_t)b * T + i) * d + h * hd;
+    bool ok[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ok[v] = lane + 64 * v < hd;
+    if (i >= len) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (ok[v]) orow[lane + 64 * v] = 0.0f;
+        return;
+    }
+    const size_t ld = 3 * (size_t)d;
+    const float* base = qkv + (size_t)b * T * ld + h * hd;
+    float qu[NV], qv[NV], acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int e = lane + 64 * v;
+        const float q = ok[v] ? base[(size_t)i * ld + e] : 0.0f;
+        qu[v] = ok[v] ? q + bias_u[h * hd + e] : 0.0f;
+        qv[v] = ok[v] ? q + bias_v[h * hd + e] : 0.0f;
+        acc[v] = 0.0f;
+    }
+    const bool window = att_left >= 0 || att_right >= 0;
+    const int left = att_left >= 0 ? att_left : T, right = att_right >= 0 ? att_right : T;
+    auto visible = [&](int j) -> bool {
+        if (!window) return true;
+        return ((i - j) <= left && (j - i) <= right) || i < n_global || j < n_global;
+    };
+    auto score = [&](int j) -> float {
+        const float* kr = base + (size_t)j * ld + d;
+        const float* pr = pos + (size_t)(j - i + T - 1) * d + h * hd;
+        float ac = 0.0f, bd = 0.0f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (ok[v]) {
+                ac = fmaf(qu[v], kr[lane + 64 * v], ac);
+                bd = fmaf(qv[v], pr[lane + 64 * v], bd);
+            }
+        }
+        return (wave_sum(ac) + wave_sum(bd)) * scale;
+    };
+    float mx = -INFINITY;
+    for (int j = 0; j < len; ++j)
+        if (visible(j)) mx = fmaxf(mx, score(j));
+    float den = 0.0f;
+    for (int j = 0; j < len; ++j) {
+        if (!visible(j)) continue;
+        const float e = expf(score(j) - mx);
+        den += e;
+        const float* vr = base + (size_t)j * ld + 2 * d;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (ok[v]) acc[v] = fmaf(e, vr[lane + 64 * v], acc[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        if (ok[v]) orow[lane + 64 * v] = den > 0.0f ? acc[v] / den : 0.0f;
+}
+
+// conv-module middle in float32: x [B*T][2d] (values | gates, NeMo's own order) -> GLU -> frame mask -> depthwise k
+// (BatchNorm folded) -> SiLU -> out [B*T][d].  One thread per output element, channel fastest.
+__global__ __launch_bounds__(256) void glu_dwconv_silu_f32_kernel(const float* __restrict__ x, const float* __restrict__ w /* [k][d] */,
+                                                                  const float* __restrict__ bias, const int32_t* __restrict__ lens,
+                                                                  int T, int d, int k, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y, b = blockIdx.z;
+    if (c >= d) return;
+    int len = lens[b];
+    len = len < T ? len : T;
+    const int half = (k - 1) >> 1;
+    float acc = 0.0f;                                 // F.conv1d: products first, bias last
+    for (int j = 0; j < k; ++j) {
+        const int tj = t + j - half;
+        if (tj < 0 || tj >= len) continue;
+        const float* px = x + ((size_t)b * T + tj) * 2 * d;
+        const float u = px[c] * sigmoid_exact(px[d + c]);
+        acc = fmaf(w[(size_t)j * d + c], u, acc);
+    }
+    acc += bias[c];
+    out[((size_t)b * T + t) * d + c] = silu_exact(acc);
+}
+
+struct EncPlanF32 {
+    int T[5], F[5];
+    size_t off_lens, off_sa, off_sb, off_x, off_hn, off_big, off_ctx, off_posp, total;
+};
+
+EncPlanF32 plan_f32(const rs_ctx* ctx, int B, int t_max) {
+    const rs_dims& d = ctx->d;
+    EncPlanF32 p{};
+    p.T[0] = t_max; p.F[0] = d.n_mels;
+    for (int s = 1; s <= d.sub_stages; ++s) { p.T[s] = (p.T[s - 1] + 2 - 3) / 2 + 1; p.F[s] = (p.F[s - 1] + 2 - 3) / 2 + 1; }
+    const size_t C = d.sub_channels, dm = d.d_model;
+    const size_t Tp = p.T[d.sub_stages], M = (size_t)B * Tp;
+    size_t widest = (size_t)d.ff_dim;
+    if (3 * dm > widest) widest = 3 * dm;
+    size_t o = 0;
+    p.off_lens = o; o += rs_align((size_t)4 * B * 4);
+    const size_t sub_elems = (size_t)B * p.T[2] * p.F[2] * C;
+    p.off_sa = o; o += rs_align(sub_elems * 4);
+    p.off_sb = o; o += rs_align(sub_elems * 4);
+    p.off_x = o; o += rs_align(M * dm * 4);
+    p.off_hn = o; o += rs_align(M * dm * 4);
+    p.off_big = o; o += rs_align(M * widest * 4);
+    p.off_ctx = o; o += rs_align(M * dm * 4);
+    p.off_posp = o; o += rs_align((2 * Tp) * dm * 4);
+    p.total = o + 256;
+    return p;
+}
+
+}  // namespace
+
+int rs_launch_gemm_f32(rs_ctx* ctx, const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K,
+                       int flags, const float* bias, float alpha, const float* residual, const int32_t* mask_lens,
+                       int mask_rows_per_step, int mask_steps, hipStream_t s) {
+    if (M <= 0 || N <= 0) return RS_OK;
+    if (K <= 0 || K % GK || N % 4 || (lda % 4) || (ldw % 4) || (ldc % 4))
+        return rs_fail(ctx, RS_EINVAL, "gemm_f32: K %% %d, N %% 4 and 16-byte row pitches required (M %d N %d K %d)", GK, M, N, K);
+    if (flags & ~(RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_SILU | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32 | RS_GEMM_ROWMASK))
+        return rs_fail(ctx, RS_EINVAL, "gemm_f32: unsupported flags %d", flags);
+    if ((flags & RS_GEMM_BIAS) && !bias) return rs_fail(ctx, RS_EINVAL, "gemm_f32: bias flag without a bias");
+    if ((flags & RS_GEMM_RESIDUAL) && !residual) return rs_fail(ctx, RS_EINVAL, "gemm_f32: residual flag without a residual");
+    if ((flags & RS_GEMM_ROWMASK) && (!mask_lens || mask_rows_per_step <= 0 || mask_steps <= 0))
+        return rs_fail(ctx, RS_EINVAL, "gemm_f32: row mask without lengths");
+    GemmF32 p{A, W, out, bias, residual, mask_lens, lda, ldw, ldc, M, N, K, flags, alpha, mask_rows_per_step, mask_steps};
+    const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(256);
+    rs_prof_begin(ctx, RS_PROF_GEMM, s, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, s, p);
+    rs_prof_end(ctx, RS_PROF_GEMM, s);
+    RS_CHECK_LAUNCH(ctx, "gemm_f32");
+    return RS_OK;
+}
+
+int rs_launch_attention_f32(rs_ctx* ctx, const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
+                            const int32_t* lens, int B, int T, float* out, hipStream_t s) {
+    if (B <= 0 || T <= 0) return RS_OK;
+    const rs_dims& dm = ctx->d;
+    const int hd = dm.d_model / dm.n_heads;
+    if (hd > 256) return rs_fail(ctx, RS_EINVAL, "attention_f32: head_dim %d > 256", hd);
+    const dim3 grid((T + 3) / 4, dm.n_heads, B), block(256);
+    const float scale = 1.0f / sqrtf((float)hd);
+    rs_prof_begin(ctx, RS_PROF_ATTN, s, (double)B * dm.n_heads * 3.0 * 2.0 * T * (double)T * hd, (double)B * T * dm.d_model * 4.0 * 4.0);
+#define RS_ATT_CASE(NV)                                                                                                  \
+    hipLaunchKernelGGL((attention_f32_kernel<NV>), grid, block, 0, s, qkv, pos, bias_u, bias_v, lens, out, T, dm.d_model, hd, \
+                       dm.att_left, dm.att_right, dm.n_global, scale)
+    if (hd <= 64) RS_ATT_CASE(1);
+    else if (hd <= 128) RS_ATT_CASE(2);
+    else RS_ATT_CASE(4);
+#undef RS_ATT_CASE
+    rs_prof_end(ctx, RS_PROF_ATTN, s);
+    RS_CHECK_LAUNCH(ctx, "attention_f32");
+    return RS_OK;
+}
+
+int rs_launch_glu_dwconv_f32(rs_ctx* ctx, const float* x, const float* w, const float* b, const int32_t* lens, int B, int T,
+                             int d, int k, float* out, hipStream_t s) {
+    if (B <= 0 || T <= 0) return RS_OK;
+    if (k < 1 || !(k & 1)) return rs_fail(ctx, RS_EINVAL, "glu_dwconv_f32: kernel size %d unsupported", k);
+    const dim3 grid((d + 255) / 256, T, B), block(256);
+    rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, (double)B * T * d * (2.0 * k + 12.0), (double)B * T * d * 12.0);
+    hipLaunchKernelGGL(glu_dwconv_silu_f32_kernel, grid, block, 0, s, x, w, b, lens, T, d, k, out);
+    rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
+    RS_CHECK_LAUNCH(ctx, "glu_dwconv_silu_f32");
+    return RS_OK;
+}
+
+size_t rs_encoder_f32_workspace_bytes(const rs_ctx* ctx, int B, int t_max) { return plan_f32(ctx, B, t_max).total; }
+
+// The float32 encoder: the call sequence of rs_encoder_forward (rs_api.hip) with float32 operands everywhere and no
+// fusion that moves a rounding (there is none to move: nothing is rounded below float32).
+int rs_encoder_forward_f32(rs_ctx* ctx, const float* feats, const int32_t* n_frames, int B, int t_max, float* enc_out,
+                           float* joint_enc, int32_t* enc_lens, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    const rs_dims& d = ctx->d;
+    const rs_f32_weights& w = ctx->f32;
+    const EncPlanF32 pl = plan_f32(ctx, B, t_max);
+    if (workspace_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "encoder (float32 mode): workspace %zu < %zu", workspace_bytes, pl.total);
+    char* ws = reinterpret_cast<char*>(workspace);
+    int32_t* lens_stage = reinterpret_cast<int32_t*>(ws + pl.off_lens);
+    float* sa = reinterpret_cast<float*>(ws + pl.off_sa);
+    float* sb = reinterpret_cast<float*>(ws + pl.off_sb);
+    float* x = reinterpret_cast<float*>(ws + pl.off_x);
+    float* hn = reinterpret_cast<float*>(ws + pl.off_hn);
+    float* big = reinterpret_cast<float*>(ws + pl.off_big);
+    float* ctxb = reinterpret_cast<float*>(ws + pl.off_ctx);
+    float* posp = reinterpret_cast<float*>(ws + pl.off_posp);
+    const int C = d.sub_channels, dm = d.d_model, ff = d.ff_dim, S = d.sub_stages;
+    const int Tp = pl.T[S], M = B * Tp;
+    int rc;
+#define RS_TRY(call) do { rc = (call); if (rc != RS_OK) return rc; } while (0)
+    auto gemm = [&](const float* A, int lda, const float* W, int K, float* out, int ldc, int Mr, int N, int flags, const float* bias,
+                    float alpha, const float* res) -> int {
+        return rs_launch_gemm_f32(ctx, A, lda, W, K, out, ldc, Mr, N, K, flags, bias, alpha, res, nullptr, 0, 0, s);
+    };
+    // ---- subsampling
+    RS_TRY(rs_launch_enc_lens(ctx, n_frames, B, lens_stage, s));
+    RS_TRY(rs_launch_sub_conv0_dw1_f32(ctx, feats, lens_stage, B, t_max, pl.T[2], pl.F[2], sa, s));
+    for (int st = 2; st <= S; ++st) {
+        if (st > 2)
+            RS_TRY(rs_launch_sub_dw_f32(ctx, sb, ctx->sub_dw_w[st - 2], ctx->sub_dw_b[st - 2], lens_stage + (st - 1) * B, B,
+                                        pl.T[st - 1], pl.F[st - 1], pl.T[st], pl.F[st], sa, s));
+        RS_TRY(rs_launch_gemm_f32(ctx, sa, C, w.sub_pw_w[st - 2], C, sb, C, B * pl.T[st] * pl.F[st], C, C,
+                                  RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_ROWMASK, ctx->sub_pw_b[st - 2], 1.0f, nullptr,
+                                  lens_stage + (st - 1) * B, pl.F[st], pl.T[st], s));
+    }
+    {
+        const int K = C * pl.F[S];
+        RS_TRY(gemm(sb, K, w.sub_out_w, K, x, dm, M, dm, RS_GEMM_BIAS, ctx->sub_out_b, d.xscaling ? sqrtf((float)dm) : 1.0f, nullptr));
+    }
+    const int32_t* lens = lens_stage + (S - 1) * B;
+    RS_HIP(ctx, hipMemcpyAsync(enc_lens, lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    if (ctx->tap_sub) RS_HIP(ctx, hipMemcpyAsync(ctx->tap_sub, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
+    // ---- position rows for this T'
+    const int tcap = (int)((w.pos_table_bytes / ((size_t)dm * 4) + 1) / 2);
+    if (Tp > tcap) return rs_fail(ctx, RS_EINVAL, "encoder (float32 mode): T'=%d exceeds the registered pos.table.f32 capacity %d", Tp, tcap);
+    const float* pos_slice = w.pos_table + (size_t)(tcap - Tp) * dm;
+    const int npos = 2 * Tp - 1;
+    const int RES = RS_GEMM_BIAS | RS_GEMM_RESIDUAL;
+    for (int i = 0; i < d.n_layers; ++i) {
+        const rs_layer_w& L = ctx->layers[i];
+        const rs_layer_w32& L32 = w.layers[i];
+        // 1/2 FFN
+        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_ff1_g, L.ln_ff1_b, M, dm, d.ln_eps, nullptr, hn, s));
+        RS_TRY(gemm(hn, dm, L32.ff1_w1, dm, big, ff, M, ff, RS_GEMM_BIAS | RS_GEMM_SILU, L.ff1_b1, 1.0f, nullptr));
+        RS_TRY(gemm(big, ff, L32.ff1_w2, ff, x, dm, M, dm, RES, L.ff1_b2, 0.5f, x));
+        // rel-pos MHSA
+        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_att_g, L.ln_att_b, M, dm, d.ln_eps, nullptr, hn, s));
+        RS_TRY(gemm(hn, dm, L32.qkv_w, dm, big, 3 * dm, M, 3 * dm, RS_GEMM_BIAS, L.qkv_b, 1.0f, nullptr));
+        RS_TRY(gemm(pos_slice, dm, L32.pos_w, dm, posp, dm, npos, dm, 0, nullptr, 1.0f, nullptr));
+        RS_TRY(rs_launch_attention_f32(ctx, big, posp, L.bias_u, L.bias_v, lens, B, Tp, ctxb, s));
+        RS_TRY(gemm(ctxb, dm, L32.out_w, dm, x, dm, M, dm, RES, L.out_b, 1.0f, x));
+        // conv module (pw1 in NeMo's own row order: values | gates)
+        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_conv_g, L.ln_conv_b, M, dm, d.ln_eps, nullptr, hn, s));
+        RS_TRY(gemm(hn, dm, L32.pw1_w, dm, big, 2 * dm, M, 2 * dm, RS_GEMM_BIAS, L32.pw1_b, 1.0f, nullptr));
+        RS_TRY(rs_launch_glu_dwconv_f32(ctx, big, L.dw_w, L.dw_b, lens, B, Tp, dm, d.conv_kernel, ctxb, s));
+        RS_TRY(gemm(ctxb, dm, L32.pw2_w, dm, x, dm, M, dm, RES, L.pw2_b, 1.0f, x));
+        // 1/2 FFN
+        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_ff2_g, L.ln_ff2_b, M, dm, d.ln_eps, nullptr, hn, s));
+        RS_TRY(gemm(hn, dm, L32.ff2_w1, dm, big, ff, M, ff, RS_GEMM_BIAS | RS_GEMM_SILU, L.ff2_b1, 1.0f, nullptr));
+        RS_TRY(gemm(big, ff, L32.ff2_w2, ff, x, dm, M, dm, RES, L.ff2_b2, 0.5f, x));
+        // output norm, in place (a wave holds its whole row in registers before it stores)
+        RS_TRY(rs_launch_layernorm(ctx, x, L.ln_out_g, L.ln_out_b, M, dm, d.ln_eps, nullptr, x, s));
+        for (size_t k = 0; k < ctx->tap_ids.size(); ++k)
+            if (ctx->tap_ids[k] == i)
+                RS_HIP(ctx, hipMemcpyAsync(ctx->tap_layers + k * (size_t)M * dm, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (enc_out) RS_HIP(ctx, hipMemcpyAsync(enc_out, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
+    RS_TRY(gemm(x, dm, w.jenc_w, dm, joint_enc, d.joint_hidden, M, d.joint_hidden, RS_GEMM_BIAS, ctx->jenc_b, 1.0f, nullptr));
+#undef RS_TRY
+    return RS_OK;
+}

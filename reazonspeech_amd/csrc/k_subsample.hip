@@ -26,17 +26,21 @@ __global__ void enc_lens_kernel(const int32_t* __restrict__ n_frames, int B, int
     }
 }
 
-// grid (T2, B), block C threads (thread = channel)
+__device__ __forceinline__ void put(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+__device__ __forceinline__ void put(float* p, float v) { *p = v; }
+
+// grid (T2, B), block C threads (thread = channel); OT = uint16_t (bf16, the throughput mode) or float (parity mode)
+template <typename OT>
 __global__ __launch_bounds__(256) void sub_conv0_dw1_kernel(
     const float* __restrict__ feats, const int32_t* __restrict__ lens_stage /* [stages][B] */, int B, int t_max,
     int n_mels, int T2, int F1, int F2, int C, const float* __restrict__ w0 /* [9][C] */,
     const float* __restrict__ b0, const float* __restrict__ wd /* [9][C] */, const float* __restrict__ bd,
-    uint16_t* __restrict__ out) {
+    OT* __restrict__ out) {
     const int b = blockIdx.y, t2 = blockIdx.x, c = threadIdx.x;
     const int L1 = lens_stage[0 * B + b], L2 = lens_stage[1 * B + b];
-    uint16_t* orow = out + (((size_t)b * T2 + t2) * F2) * C + c;
+    OT* orow = out + (((size_t)b * T2 + t2) * F2) * C + c;
     if (t2 >= L2) {  // masked output row
-        for (int f2 = 0; f2 < F2; ++f2) orow[(size_t)f2 * C] = 0;
+        for (int f2 = 0; f2 < F2; ++f2) put(orow + (size_t)f2 * C, 0.0f);
         return;
     }
     float k0[9], kd[9];
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void sub_conv0_dw1_kernel(
             acc = fmaf(kd[a * 3 + 1], mid[a], acc);
             acc = fmaf(kd[a * 3 + 2], right[a], acc);
         }
-        orow[(size_t)f2 * C] = f32_to_bf16(acc);
+        put(orow + (size_t)f2 * C, acc);
 #pragma unroll
         for (int a = 0; a < 3; ++a) left[a] = right[a];
     }
@@ -160,6 +164,28 @@ __global__ __launch_bounds__(256) void sub_dw_kernel(const uint16_t* __restrict_
     *reinterpret_cast<u16x8_t*>(op) = o;
 }
 
+// the same depthwise conv on float32 activations (parity mode): one thread per output element, channel fastest
+__global__ __launch_bounds__(256) void sub_dw_f32_kernel(const float* __restrict__ in, const float* __restrict__ w /* [9][C] */,
+                                                         const float* __restrict__ bias, const int32_t* __restrict__ lens_out,
+                                                         int Tin, int Fin, int Tout, int Fout, int C, float* __restrict__ out) {
+    const int c = threadIdx.x, fo = blockIdx.x, to = blockIdx.y, b = blockIdx.z;
+    float* op = out + (((size_t)b * Tout + to) * Fout + fo) * C + c;
+    if (to >= lens_out[b]) { *op = 0.0f; return; }
+    float acc = bias[c];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ti = 2 * to - 1 + i;
+        if (ti < 0 || ti >= Tin) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int fi = 2 * fo - 1 + j;
+            if (fi < 0 || fi >= Fin) continue;
+            acc = fmaf(w[(i * 3 + j) * C + c], in[(((size_t)b * Tin + ti) * Fin + fi) * C + c], acc);
+        }
+    }
+    *op = acc;
+}
+
 }  // namespace
 
 int rs_launch_enc_lens(rs_ctx* ctx, const int32_t* n_frames, int B, int32_t* lens_out, hipStream_t s) {
@@ -180,7 +206,7 @@ int rs_launch_sub_conv0_dw1(rs_ctx* ctx, const float* feats, const int32_t* lens
     const double flops = (double)B * T2 * F2 * C * 2.0 * (6 * 9 + 9);
     const double bytes = (double)B * t_max * d.n_mels * 4.0 + (double)B * T2 * F2 * C * 2.0;
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, flops, bytes);
-    hipLaunchKernelGGL(sub_conv0_dw1_kernel, dim3(T2, B), dim3(C), lds, s, feats, lens_stage, B, t_max, d.n_mels, T2,
+    hipLaunchKernelGGL(sub_conv0_dw1_kernel<uint16_t>, dim3(T2, B), dim3(C), lds, s, feats, lens_stage, B, t_max, d.n_mels, T2,
                        F1, F2, C, ctx->sub_conv0_w, ctx->sub_conv0_b, ctx->sub_dw_w[0], ctx->sub_dw_b[0], out);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
     RS_CHECK_LAUNCH(ctx, "sub_conv0_dw1");
@@ -199,5 +225,34 @@ int rs_launch_sub_dw(rs_ctx* ctx, const uint16_t* in, const float* w, const floa
     hipLaunchKernelGGL(sub_dw_kernel, grid, block, 0, s, in, w, b, lens_out, t_in, f_in, t_out, f_out, C, out);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
     RS_CHECK_LAUNCH(ctx, "sub_dw");
+    return RS_OK;
+}
+
+// ---- float32 parity mode (k_f32.hip): the same two operators storing / reading float32 activations ----------------
+int rs_launch_sub_conv0_dw1_f32(rs_ctx* ctx, const float* feats, const int32_t* lens_stage, int B, int t_max, int T2, int F2,
+                                float* out, hipStream_t s) {
+    const rs_dims& d = ctx->d;
+    const int C = d.sub_channels;
+    if (C > 256 || (C % 64)) return rs_fail(ctx, RS_EINVAL, "subsampling: channels %d unsupported (<=256, %%64)", C);
+    const int F1 = (d.n_mels + 2 - 3) / 2 + 1;
+    if (d.n_mels % 4 || 4 * F2 > d.n_mels || 2 * F2 < F1)
+        return rs_fail(ctx, RS_EINVAL, "subsampling: n_mels=%d must be a multiple of 4 with 4*F2 <= n_mels", d.n_mels);
+    rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, (double)B * T2 * F2 * C * 2.0 * (6 * 9 + 9),
+                  (double)B * t_max * d.n_mels * 4.0 + (double)B * T2 * F2 * C * 4.0);
+    hipLaunchKernelGGL(sub_conv0_dw1_kernel<float>, dim3(T2, B), dim3(C), 0, s, feats, lens_stage, B, t_max, d.n_mels, T2, F1, F2, C,
+                       ctx->sub_conv0_w, ctx->sub_conv0_b, ctx->sub_dw_w[0], ctx->sub_dw_b[0], out);
+    rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
+    RS_CHECK_LAUNCH(ctx, "sub_conv0_dw1_f32");
+    return RS_OK;
+}
+
+int rs_launch_sub_dw_f32(rs_ctx* ctx, const float* in, const float* w, const float* b, const int32_t* lens_out, int B, int t_in,
+                         int f_in, int t_out, int f_out, float* out, hipStream_t s) {
+    const int C = ctx->d.sub_channels;
+    rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, (double)B * t_out * f_out * C * 18.0,
+                  (double)B * C * 4.0 * ((double)t_in * f_in + (double)t_out * f_out));
+    hipLaunchKernelGGL(sub_dw_f32_kernel, dim3(f_out, t_out, B), dim3(C), 0, s, in, w, b, lens_out, t_in, f_in, t_out, f_out, C, out);
+    rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
+    RS_CHECK_LAUNCH(ctx, "sub_dw_f32");
     return RS_OK;
 }

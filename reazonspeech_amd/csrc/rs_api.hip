@@ -225,6 +225,36 @@ int rs_finalize(rs_ctx* ctx) {
             if (const char* dn = getenv("RS_DEFER_OUT_NORM")) ctx->defer_out_norm = atoi(dn) != 0; // 0 = every output norm stores its f32 rows
         }
     }
+    // optional: the float32 parity mode's dense weights ("<name>.f32", unrounded, the layouts of the bf16 tensors except
+    // conv.pw1, which keeps NeMo's own row order) and its position table.  All or none.
+    ctx->has_f32 = false;
+    if (ctx->tensors.count("sub.out.w.f32")) {
+        rs_f32_weights& w = ctx->f32;
+        for (int s = 1; s < d.sub_stages; ++s) r.get("sub.pw" + std::to_string(s) + ".w.f32", C * C, w.sub_pw_w[s - 1]);
+        r.get("sub.out.w.f32", dm * C * ctx->sub_freq, w.sub_out_w);
+        w.layers.assign(d.n_layers, rs_layer_w32{});
+        for (int i = 0; i < d.n_layers; ++i) {
+            rs_layer_w32& L = w.layers[i];
+            const std::string p = "L" + std::to_string(i) + ".";
+            r.get(p + "ff1.w1.f32", ff * dm, L.ff1_w1); r.get(p + "ff1.w2.f32", dm * ff, L.ff1_w2);
+            r.get(p + "ff2.w1.f32", ff * dm, L.ff2_w1); r.get(p + "ff2.w2.f32", dm * ff, L.ff2_w2);
+            r.get(p + "att.qkv.w.f32", 3 * dm * dm, L.qkv_w); r.get(p + "att.out.w.f32", dm * dm, L.out_w);
+            r.get(p + "att.pos.w.f32", dm * dm, L.pos_w);
+            r.get(p + "conv.pw1.w.f32", 2 * dm * dm, L.pw1_w); r.get(p + "conv.pw1.b.f32", 2 * dm, L.pw1_b);
+            r.get(p + "conv.pw2.w.f32", dm * dm, L.pw2_w);
+        }
+        r.get("joint.enc.w.f32", J * dm, w.jenc_w);
+        if (r.rc != RS_OK) return r.rc;
+        auto pt = ctx->tensors.find("pos.table.f32");
+        if (pt == ctx->tensors.end()) return rs_fail(ctx, RS_EMISSING, "weight tensor 'pos.table.f32' was not registered");
+        const size_t rowf = dm * sizeof(float);
+        if (pt->second.second % rowf || !((pt->second.second / rowf) & 1) || ((uintptr_t)pt->second.first & 15))
+            return rs_fail(ctx, RS_EINVAL, "pos.table.f32 must be 16-byte aligned f32 [2*Tcap-1][d_model]");
+        w.pos_table = reinterpret_cast<const float*>(pt->second.first);
+        w.pos_table_bytes = pt->second.second;
+        ctx->has_f32 = true;
+    }
+    if (ctx->precision_f32 && !ctx->has_f32) ctx->precision_f32 = 0;     // (the tensors were re-registered without the f32 set)
     auto it = ctx->tensors.find("pos.table");
     if (it == ctx->tensors.end()) return rs_fail(ctx, RS_EMISSING, "weight tensor 'pos.table' was not registered");
     const size_t rowb = dm * sizeof(uint16_t);
@@ -274,6 +304,12 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
         return RS_OK;
     }
     if (!strcmp(key, "defer_out_norm")) { ctx->defer_out_norm = value != 0; return RS_OK; }
+    if (!strcmp(key, "precision_f32")) {
+        if (value && !ctx->has_f32)
+            return rs_fail(ctx, RS_EMISSING, "precision_f32: the float32 weights (\"*.f32\" tensors) are not registered / rs_finalize has not run");
+        ctx->precision_f32 = value != 0;
+        return RS_OK;
+    }
     return rs_fail(ctx, RS_EINVAL, "unknown option '%s'", key);
 }
 
@@ -336,7 +372,11 @@ size_t rs_workspace_bytes(const rs_ctx* ctx, int B, int max_samples) {
     if (!ctx || B <= 0 || max_samples < 0) return 0;
     const int t_max = rs_mel_frames(ctx, max_samples);
     const size_t fe = rs_align((size_t)B * (t_max > 0 ? t_max : 1) * ctx->d.n_mels * 4) + 256;
-    const size_t enc = plan_encoder(ctx, B, t_max > 0 ? t_max : 1).total;
+    size_t enc = plan_encoder(ctx, B, t_max > 0 ? t_max : 1).total;
+    if (ctx->has_f32) {                      // the float32 parity mode keeps float32 activations: about twice the scratch
+        const size_t enc32 = rs_encoder_f32_workspace_bytes(ctx, B, t_max > 0 ? t_max : 1);
+        if (enc32 > enc) enc = enc32;
+    }
     const size_t dec = rs_rnnt_workspace_bytes(ctx, B);
     size_t m = fe > enc ? fe : enc;
     return m > dec ? m : dec;
@@ -380,6 +420,8 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
     if (!feats || !n_frames || !joint_enc || !enc_lens || !workspace) return rs_fail(ctx, RS_EINVAL, "encoder: null pointer");
     const rs_dims& d = ctx->d;
     hipStream_t s = (hipStream_t)stream;
+    if (ctx->precision_f32)
+        return rs_encoder_forward_f32(ctx, feats, n_frames, B, t_max, enc_out, joint_enc, enc_lens, workspace, workspace_bytes, s);
     const EncPlan pl = plan_encoder(ctx, B, t_max);
     if (workspace_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "encoder: workspace %zu < %zu", workspace_bytes, pl.total);
     char* ws = reinterpret_cast<char*>(workspace);
@@ -590,6 +632,30 @@ int rs_gemm_bf16(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int
     if (!A || !W || !out) return rs_fail(ctx, RS_EINVAL, "gemm: null pointer");
     rs_gemm_args g{A, lda, W, ldw, out, ldc, M, N, K, flags, bias, alpha, residual, mask_lens, mask_rows_per_step, mask_steps};
     return rs_launch_gemm(ctx, g, (hipStream_t)stream);
+}
+
+int rs_gemm_f32(rs_ctx* ctx, const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K, int flags,
+                const float* bias, float alpha, const float* residual, const int32_t* mask_lens, int mask_rows_per_step,
+                int mask_steps, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (M == 0 || N == 0) return RS_OK;
+    if (!A || !W || !out) return rs_fail(ctx, RS_EINVAL, "gemm_f32: null pointer");
+    return rs_launch_gemm_f32(ctx, A, lda, W, ldw, out, ldc, M, N, K, flags, bias, alpha, residual, mask_lens, mask_rows_per_step,
+                              mask_steps, (hipStream_t)stream);
+}
+
+int rs_relpos_attention_f32(rs_ctx* ctx, const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
+                            const int32_t* lens, int B, int T, float* ctx_out, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (!qkv || !pos || !bias_u || !bias_v || !lens || !ctx_out) return rs_fail(ctx, RS_EINVAL, "attention_f32: null pointer");
+    return rs_launch_attention_f32(ctx, qkv, pos, bias_u, bias_v, lens, B, T, ctx_out, (hipStream_t)stream);
+}
+
+int rs_glu_dwconv_silu_f32(rs_ctx* ctx, const float* x, const float* dw_w, const float* dw_b, const int32_t* lens, int B, int T,
+                           int d, int k, float* out, void* stream) {
+    if (!ctx) return RS_EINVAL;
+    if (!x || !dw_w || !dw_b || !lens || !out) return rs_fail(ctx, RS_EINVAL, "glu_dwconv_f32: null pointer");
+    return rs_launch_glu_dwconv_f32(ctx, x, dw_w, dw_b, lens, B, T, d, k, out, (hipStream_t)stream);
 }
 
 int rs_layernorm(rs_ctx* ctx, const float* x, const float* gamma, const float* beta, int M, int d, float eps,

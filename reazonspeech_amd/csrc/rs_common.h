@@ -68,6 +68,21 @@ struct rs_layer_w {
     const uint16_t* pos_proj;   // optional "L{i}.att.pos_proj": pos.table @ pos_w^T, bf16 [2*Tcap-1][d]; nullptr = project per call
 };
 
+// float32 parity mode (k_f32.hip): the dense weights once more, unrounded.  Norm weights, biases, depthwise taps and
+// the attention position biases are float32 in the throughput mode already and are shared.
+struct rs_layer_w32 {
+    const float *ff1_w1, *ff1_w2, *ff2_w1, *ff2_w2, *qkv_w, *out_w, *pos_w, *pw1_w, *pw2_w;
+    const float* pw1_b;         // pointwise_conv1 bias in NeMo's own row order (values | gates); the bf16 copy is interleaved
+};
+struct rs_f32_weights {
+    const float* sub_pw_w[4] = {};
+    const float* sub_out_w = nullptr;
+    std::vector<rs_layer_w32> layers;
+    const float* jenc_w = nullptr;
+    const float* pos_table = nullptr;   // "pos.table.f32": f32 [2*Tcap-1][d]
+    size_t pos_table_bytes = 0;
+};
+
 struct rs_ctx {
     int device = 0;
     rs_dims d{};
@@ -101,6 +116,9 @@ struct rs_ctx {
     int defer_out_norm = 1;         // 1 = a layer's output norm is applied by the next layer's first residual GEMM (f32 rows not stored); bit-identical to 0
     int fuse_glu = 1;               // conv module: 1 = GLU in the pw1 GEMM epilogue (every batch size: one rounding point, batch-invariant);
                                     // 0 = plain pw1 product, GLU in the depthwise kernel ($RS_FUSE_GLU; A/B and layout tests)
+    bool has_f32 = false;           // the "*.f32" tensors of the float32 parity mode are registered (all or none)
+    int precision_f32 = 0;          // rs_set_option("precision_f32"): 1 = rs_encoder_forward runs k_f32.hip's float32 encoder
+    rs_f32_weights f32;
     bool env_read = false;          // the $RS_* defaults were applied (once, by the first rs_finalize; rs_set_option wins afterwards)
     // parity taps (rs_encoder_set_taps): copies of the residual stream taken inside rs_encoder_forward
     float* tap_sub = nullptr;
@@ -172,4 +190,15 @@ int rs_launch_sub_conv0_dw1(rs_ctx* ctx, const float* feats, const int32_t* lens
                             int F2, uint16_t* out, hipStream_t s);
 int rs_launch_sub_dw(rs_ctx* ctx, const uint16_t* in, const float* w, const float* b, const int32_t* lens_out,
                      int stage, int B, int t_in, int f_in, int t_out, int f_out, uint16_t* out, hipStream_t s);
+// float32 parity mode (k_f32.hip, k_subsample.hip)
+int rs_launch_gemm_f32(rs_ctx* ctx, const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K,
+                       int flags, const float* bias, float alpha, const float* residual, const int32_t* mask_lens,
+                       int mask_rows_per_step, int mask_steps, hipStream_t s);
+int rs_launch_attention_f32(rs_ctx* ctx, const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
+                            const int32_t* lens, int B, int T, float* out, hipStream_t s);
+int rs_launch_glu_dwconv_f32(rs_ctx* ctx, const float* x, const float* w, const float* b, const int32_t* lens, int B, int T,
+                             int d, int k, float* out, hipStream_t s);
+size_t rs_encoder_f32_workspace_bytes(const rs_ctx* ctx, int B, int t_max);
+int rs_encoder_forward_f32(rs_ctx* ctx, const float* feats, const int32_t* n_frames, int B, int t_max, float* enc_out,
+                           float* joint_enc, int32_t* enc_lens, void* workspace, size_t workspace_bytes, hipStream_t s);
 int rs_launch_enc_lens(rs_ctx* ctx, const int32_t* n_frames, int B, int32_t* lens_out, hipStream_t s);

@@ -53,7 +53,8 @@ def resolve_checkpoint(checkpoint=None, allow_download=True):
     return None
 
 
-def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, decoding=None, beam_size=None):
+def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, decoding=None, beam_size=None,
+               precision="bf16"):
     """Load the ReazonSpeech FastConformer-RNNT model onto a ROCm GPU.
 
     Args:
@@ -69,6 +70,10 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
       decoding (str): override the checkpoint's decoding strategy: "greedy_batch" or "alsd" (alignment-length
         synchronous beam search, what the reference checkpoint ships with: decode.py:29,38-41).
       beam_size (int): override the beam size of "alsd" (1..8).
+      precision (str): "bf16" (default): the throughput mode — bf16 matrix-core operands, float32 accumulation, float32
+        residual stream, exact float32 decode.  "fp32": the parity mode — float32 weights, activations and arithmetic end
+        to end, i.e. what the reference computes (transcribe.py:26-28, :48-53 run NeMo in float32 without autocast; the
+        same keyword as `reazonspeech.k2.asr.load_model(precision=...)`, pkg/k2-asr/src/huggingface.py:16); ~20x slower.
       pos_cap (int): encoder frames (80 ms each) the resident relative-position tables cover at load time
         (default 1024, about 82 s); longer utterances grow the tables on first use.
 
@@ -102,7 +107,7 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
     if beam_size is not None:
         cfg = cfg.with_(beam_size=int(beam_size))
     kw = {} if pos_cap is None else {"pos_cap": int(pos_cap)}
-    return AsrModel(cfg, sd, tokenizer, device=device, pad_seconds=PAD_SECONDS, **kw)
+    return AsrModel(cfg, sd, tokenizer, device=device, pad_seconds=PAD_SECONDS, precision=precision, **kw)
 
 
 def _prepare(audio):

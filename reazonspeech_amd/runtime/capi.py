@@ -29,6 +29,7 @@ EXPORTS = [
     "rs_rnnt_greedy", "rs_profile_enable", "rs_profile_read", "rs_profile_reset", "rs_gemm_bf16",
     "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_glu_dwconv_silu_layout", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
     "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes", "rs_host_stage_rows",
+    "rs_gemm_f32", "rs_relpos_attention_f32", "rs_glu_dwconv_silu_f32",
 ]
 
 
@@ -112,6 +113,10 @@ def load():
     lib.rs_relpos_attention.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp]
     lib.rs_glu_dwconv_silu.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
     lib.rs_glu_dwconv_silu_layout.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
+    lib.rs_gemm_f32.argtypes = [vp, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp, c_float, vp, vp, c_int,
+                                c_int, vp]
+    lib.rs_relpos_attention_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp]
+    lib.rs_glu_dwconv_silu_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
     if lib.rs_abi_version() != 2:
         raise ImportError("librs_asr.so ABI version mismatch")
     _lib = lib
@@ -297,6 +302,23 @@ class Context:
         self.check(self.lib.rs_gemm_bf16(self._h, _ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(out),
                                          out.stride(0), M, N, K, flags, _ptr(bias), float(alpha), _ptr(residual),
                                          _ptr(mask_lens), mask_rows, mask_steps, c_void_p(stream)))
+
+    def gemm_f32(self, A, W, out, flags=0, bias=None, alpha=1.0, residual=None, mask_lens=None, mask_rows=0, mask_steps=0,
+                 stream=0):
+        """the float32 parity mode's GEMM: A f32 [M][K], W f32 [N][K] -> out f32 [M][N]"""
+        M, K = A.shape
+        N = W.shape[0]
+        self.check(self.lib.rs_gemm_f32(self._h, _ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(out), out.stride(0), M, N, K,
+                                        flags, _ptr(bias), float(alpha), _ptr(residual), _ptr(mask_lens), mask_rows,
+                                        mask_steps, c_void_p(stream)))
+
+    def attention_f32(self, qkv, pos, bias_u, bias_v, lens, B, T, out, stream=0):
+        self.check(self.lib.rs_relpos_attention_f32(self._h, _ptr(qkv), _ptr(pos), _ptr(bias_u), _ptr(bias_v), _ptr(lens), B, T,
+                                                    _ptr(out), c_void_p(stream)))
+
+    def glu_dwconv_f32(self, x, w, b, lens, B, T, d, k, out, stream=0):
+        self.check(self.lib.rs_glu_dwconv_silu_f32(self._h, _ptr(x), _ptr(w), _ptr(b), _ptr(lens), B, T, d, k, _ptr(out),
+                                                   c_void_p(stream)))
 
     def layernorm(self, x, gamma, beta, eps, out_bf16=None, out_f32=None, stream=0):
         M, d = x.shape

@@ -132,8 +132,14 @@ class _BufView:
 
 class AsrModel:
     def __init__(self, cfg: ModelConfig, state_dict, tokenizer, device="cuda", pos_cap: int = DEFAULT_POS_CAP,
-                 pad_seconds: float = 0.5):
+                 pad_seconds: float = 0.5, precision: str = "bf16"):
+        """precision: "bf16" = the throughput mode (bf16 GEMM operands, float32 accumulation and residual stream);
+        "fp32" = the parity mode: float32 weights, activations and arithmetic end to end, what the reference computes
+        (pkg/nemo-asr/src/transcribe.py:26-28, :48-53) — about 20x slower, 2.4 GB more weights."""
         cfg.validate()
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', not {precision!r}")
+        self.precision = precision
         if not torch.cuda.is_available():
             raise RuntimeError("reazonspeech_amd needs a ROCm GPU (MI355X / gfx950): torch.cuda.is_available() is "
                                "False and there is no CPU fallback for this path")
@@ -152,7 +158,9 @@ class AsrModel:
         self.pos_cap = 0
         with torch.cuda.device(self.device):
             self.ctx = capi.Context(cfg, index)
-            self._upload(prepare_weights(cfg, state_dict, pos_cap))
+            self._upload(prepare_weights(cfg, state_dict, pos_cap, f32=precision == "fp32"))
+            if precision == "fp32":
+                self.ctx.set_option("precision_f32", 1)
 
     # ------------------------------------------------------------------------------------------
     def _upload(self, tensors):
@@ -161,12 +169,12 @@ class AsrModel:
             dev[name] = t.to(self.device, non_blocking=False).contiguous()
             self.ctx.set_tensor(name, dev[name])
         self._pos_w = [dev[f"L{i}.att.pos.w"] for i in range(self.cfg.n_layers)]
-        self._set_pos_tables(dev["pos.table"])
+        self._set_pos_tables(dev["pos.table"], dev.get("pos.table.f32"))
 
     def _contexts(self):
         return [self.ctx] + [c for c, _ in self._dec_lanes]
 
-    def _set_pos_tables(self, table):
+    def _set_pos_tables(self, table, table_f32=None):
         """register the relative-position table (bf16 [2*cap-1][d]) and the derived per-layer tensors: the table
         projected by every layer's linear_pos, computed once with the library's own GEMM (same kernel and row
         arithmetic as the per-call projection it replaces, so results are bit-identical) — 24 x [2*cap-1][d] bf16
@@ -179,9 +187,13 @@ class AsrModel:
         torch.cuda.synchronize(self.device)
         for c in self._contexts():
             c.set_tensor("pos.table", table)
+            if table_f32 is not None:            # float32 parity mode: its layers project the rows they need per call
+                c.set_tensor("pos.table.f32", table_f32)
             for i, proj in enumerate(projs):
                 c.set_tensor(f"L{i}.att.pos_proj", proj)
             c.finalize()
+            if self.precision == "fp32":         # (rs_finalize ran again: the option survives, set it anyway for new contexts)
+                c.set_option("precision_f32", 1)
         self.pos_cap = (table.shape[0] + 1) // 2
 
     def ensure_pos_cap(self, tp: int):
@@ -194,8 +206,9 @@ class AsrModel:
         cap = 1 << (int(tp) - 1).bit_length()
         torch.cuda.synchronize(self.device)          # nothing may still read the tables being replaced
         with torch.cuda.device(self.device):
-            table = torch.from_numpy(rel_pos_table(self.cfg, cap)).to(torch.bfloat16).to(self.device).contiguous()
-            self._set_pos_tables(table)
+            host = torch.from_numpy(rel_pos_table(self.cfg, cap))
+            table = host.to(torch.bfloat16).to(self.device).contiguous()
+            self._set_pos_tables(table, host.to(self.device).contiguous() if self.precision == "fp32" else None)
 
     BUCKET = 16000      # cached buffer sets are sized in whole seconds of audio
 

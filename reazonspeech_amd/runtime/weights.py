@@ -322,7 +322,7 @@ def glu_interleave_index(d: int) -> torch.Tensor:
     return torch.cat([32 * j + r, d + 32 * j + r], dim=1).reshape(-1)
 
 
-def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int = DEFAULT_POS_CAP):
+def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int = DEFAULT_POS_CAP, f32: bool = False):
     """-> dict name -> CPU torch tensor (float32 / bfloat16 / int32) exactly as registered with
     rs_set_tensor (DESIGN.md "Weights in HBM").  Host-side transforms, all one-off:
       * GEMM weights -> bf16, [N][K] row-major (torch Linear layout already)
@@ -335,10 +335,21 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
         float32 decode matrices (LSTM, joint.pred, joint output) are stored fragment-major
         (to_fragment_major) for contiguous MFMA operand loads
       * relative position table for T' up to pos_cap, bf16 [2*cap-1][d]
+      * `f32=True` (the float32 parity mode, include/rs_asr.h "precision_f32"): every bf16 GEMM weight once more as
+        "<name>.f32", unrounded, in the same layout — except conv.pw1, which keeps NeMo's row order (values | gates:
+        the float32 conv kernel applies the GLU itself) — and the position table as "pos.table.f32"
     """
     out = {}
+    want_f32 = bool(f32)
     bf = lambda t: t.detach().to(torch.float32).to(torch.bfloat16).contiguous()   # noqa: E731
     f32 = lambda t: t.detach().to(torch.float32).contiguous()                      # noqa: E731
+
+    def dense(name, t):
+        """a GEMM weight: bf16 for the throughput mode, and unrounded for the parity mode when asked"""
+        out[name] = bf(t)
+        if want_f32:
+            out[name + ".f32"] = f32(t)
+
     C, d = cfg.sub_channels, cfg.d_model
     raw_sd, used = sd, set()
 
@@ -376,12 +387,12 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
     for s in range(1, cfg.n_sub_stages):
         out[f"sub.dw{s}.w"] = tap_major(sd[pre + f"conv.{ci}.weight"])
         out[f"sub.dw{s}.b"] = f32(sd[pre + f"conv.{ci}.bias"])
-        out[f"sub.pw{s}.w"] = bf(sd[pre + f"conv.{ci + 1}.weight"].reshape(C, C))
+        dense(f"sub.pw{s}.w", sd[pre + f"conv.{ci + 1}.weight"].reshape(C, C))
         out[f"sub.pw{s}.b"] = f32(sd[pre + f"conv.{ci + 1}.bias"])
         ci += 3
     F = cfg.sub_freq
     wo = sd[pre + "out.weight"].reshape(d, C, F).permute(0, 2, 1).reshape(d, F * C)
-    out["sub.out.w"] = bf(wo)
+    dense("sub.out.w", wo)
     out["sub.out.b"] = f32(sd[pre + "out.bias"])
 
     for i in range(cfg.n_layers):
@@ -392,18 +403,18 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
             out[p + short + ".g"] = f32(sd[L + long + ".weight"])
             out[p + short + ".b"] = f32(sd[L + long + ".bias"])
         for short, long in (("ff1", "feed_forward1"), ("ff2", "feed_forward2")):
-            out[p + short + ".w1"] = bf(sd[L + long + ".linear1.weight"])
+            dense(p + short + ".w1", sd[L + long + ".linear1.weight"])
             out[p + short + ".b1"] = f32(sd[L + long + ".linear1.bias"])
-            out[p + short + ".w2"] = bf(sd[L + long + ".linear2.weight"])
+            dense(p + short + ".w2", sd[L + long + ".linear2.weight"])
             out[p + short + ".b2"] = f32(sd[L + long + ".linear2.bias"])
         A = L + "self_attn."
-        out[p + "att.qkv.w"] = bf(torch.cat([sd[A + "linear_q.weight"], sd[A + "linear_k.weight"],
-                                             sd[A + "linear_v.weight"]], dim=0))
+        dense(p + "att.qkv.w", torch.cat([sd[A + "linear_q.weight"], sd[A + "linear_k.weight"],
+                                          sd[A + "linear_v.weight"]], dim=0))
         out[p + "att.qkv.b"] = f32(torch.cat([sd[A + "linear_q.bias"], sd[A + "linear_k.bias"],
                                               sd[A + "linear_v.bias"]], dim=0))
-        out[p + "att.out.w"] = bf(sd[A + "linear_out.weight"])
+        dense(p + "att.out.w", sd[A + "linear_out.weight"])
         out[p + "att.out.b"] = f32(sd[A + "linear_out.bias"])
-        out[p + "att.pos.w"] = bf(sd[A + "linear_pos.weight"])
+        dense(p + "att.pos.w", sd[A + "linear_pos.weight"])
         out[p + "att.bias_u"] = f32(sd[A + "pos_bias_u"].reshape(-1))
         out[p + "att.bias_v"] = f32(sd[A + "pos_bias_v"].reshape(-1))
         Cm = L + "conv."
@@ -412,6 +423,9 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
         glu_rows = glu_interleave_index(cfg.d_model)
         out[p + "conv.pw1.w"] = bf(sd[Cm + "pointwise_conv1.weight"].squeeze(-1)[glu_rows])
         out[p + "conv.pw1.b"] = f32(sd[Cm + "pointwise_conv1.bias"][glu_rows])
+        if want_f32:
+            out[p + "conv.pw1.w.f32"] = f32(sd[Cm + "pointwise_conv1.weight"].squeeze(-1))
+            out[p + "conv.pw1.b.f32"] = f32(sd[Cm + "pointwise_conv1.bias"])
         g = sd[Cm + "batch_norm.weight"].double()
         b = sd[Cm + "batch_norm.bias"].double()
         mu = sd[Cm + "batch_norm.running_mean"].double()
@@ -421,10 +435,10 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
         bdw = (sd[Cm + "depthwise_conv.bias"].double() - mu) * sc + b
         out[p + "conv.dw.w"] = f32(wdw.float().t())                                   # [k][d]
         out[p + "conv.dw.b"] = f32(bdw.float())
-        out[p + "conv.pw2.w"] = bf(sd[Cm + "pointwise_conv2.weight"].squeeze(-1))
+        dense(p + "conv.pw2.w", sd[Cm + "pointwise_conv2.weight"].squeeze(-1))
         out[p + "conv.pw2.b"] = f32(sd[Cm + "pointwise_conv2.bias"])
 
-    out["joint.enc.w"] = bf(sd["joint.enc.weight"])
+    dense("joint.enc.w", sd["joint.enc.weight"])
     out["joint.enc.b"] = f32(sd["joint.enc.bias"])
     out["pred.embed"] = f32(sd["decoder.prediction.embed.weight"])
     P = "decoder.prediction.dec_rnn.lstm."
@@ -464,6 +478,8 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
     wmax = float(wo.double().norm(dim=1).max()) * (1.0 + 2.0 ** -10)
     out["joint.out.wmax"] = torch.tensor([wmax, 0.0, 0.0, 0.0], dtype=torch.float32)
     out["pos.table"] = torch.from_numpy(rel_pos_table(cfg, pos_cap)).to(torch.bfloat16).contiguous()
+    if want_f32:
+        out["pos.table.f32"] = torch.from_numpy(rel_pos_table(cfg, pos_cap)).contiguous()
     # anything under the model's own prefixes that was NOT consumed means the checkpoint holds parameters of a
     # variant this path does not compute (e.g. self_attn.global_q/k/v, conv.layer_norm, a second joint layer):
     # refuse instead of silently ignoring them.  Other top-level modules (ctc_decoder.*, spec_augmentation.*) and

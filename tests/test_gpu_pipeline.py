@@ -149,11 +149,11 @@ def test_decode_bit_exact_many_utterances(gpu_device):
 
 
 def test_end_to_end_ids_vs_oracle(tiny, gold):
-    """whole path: ids from the HIP path vs the oracle run end to end in the same bf16 recipe (GLU in the pw1
-    epilogue).  The encoders differ by f32 accumulation order, which a bf16 rounding can amplify, so greedy ids are an
-    agreement check on top of the bit-exact / tolerance checks above: every difference must be explained by the flip
-    audit (a decision whose oracle margin is below the Lipschitz bound of the measured difference).  On this fixture
-    the ids agree exactly, with the oracle and with the HF golden."""
+    """whole path: ids and emission frames of the HIP path (throughput mode) == the oracle run end to end in the same bf16
+    recipe (GLU in the pw1 epilogue) == the HF parakeet golden, EXACTLY, on this fixture.  (The float32 parity mode makes
+    the same statement against the float32 oracle at every geometry: tests/test_gpu_fp32_mode.py.)  The flip audit runs on
+    top with an ABSOLUTE cap on the joint-projection difference it may use as an excuse (the tolerance of the encoder
+    parity test above), so an encoder regression cannot widen its own bound."""
     from oracle import audit
     model, sd = tiny
     audio, lens = gold["audio"], gold["lengths"]
@@ -162,17 +162,15 @@ def test_end_to_end_ids_vs_oracle(tiny, gold):
     f_hip = buf.joint_enc.cpu().numpy()
     f_ref, el = om.forward_to_joint(TINY, sd, torch.from_numpy(audio), torch.from_numpy(lens), "bf16-fused-glu")
     ref = og.rnnt_greedy(TINY, sd, f_ref.numpy(), el.numpy())
-    audits = [audit.flip_audit(TINY, sd, f_ref[b].numpy(), f_hip[b], int(el[b]), got.ids[b], got.frames[b]) for b in range(2)]
-    equal = [got.ids[b] == ref[b][0] for b in range(2)]
-    s = audit.summarize(audits, equal)
-    assert s["walk_reproduces_hip_path"] and s["every_id_difference_starts_at_a_flip"], s
-    for a in audits:
-        for fl in a["flips"]:
-            assert fl["margin_ref"] <= fl["bound"] * (1 + 1e-9) + 1e-12, fl
+    assert got.ids == [r[0] for r in ref] and got.frames == [r[1] for r in ref]
     hf = [[int(x) for x in gold["hf_ids"][b, :gold["hf_n_ids"][b]]] for b in range(2)]
-    if s["local_flips"] == 0:
-        assert got.ids == [r[0] for r in ref]
-    assert sum(edit_d(got.ids[b], hf[b]) for b in range(2)) <= 2, "HIP ids drifted from the HF golden"
+    assert got.ids == hf, "HIP ids drifted from the HF golden"
+    audits = [audit.flip_audit(TINY, sd, f_ref[b].numpy(), f_hip[b], int(el[b]), got.ids[b], got.frames[b]) for b in range(2)]
+    s = audit.summarize(audits, [True, True])
+    assert s["walk_reproduces_hip_path"] and s["local_flips"] == 0, s
+    for b in range(2):
+        n = int(el[b])
+        assert np.abs(f_ref[b, :n].numpy() - f_hip[b, :n]).max() <= 6e-2          # the audit's absolute cap on delta f
 
 
 def edit_d(a, b):
