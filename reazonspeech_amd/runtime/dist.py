@@ -76,6 +76,42 @@ def shard_by_length(lengths: Sequence[int], world: int) -> List[List[int]]:
     return [order[slice(*shard_bounds(len(order), world, r))] for r in range(world)]
 
 
+def shard_balanced(lengths: Sequence[int], world: int, max_batch: int = 256) -> Tuple[List[List[int]], int]:
+    """Ragged input: deal length-sorted CHUNKS to ranks in snake order (0 .. W-1, W-1 .. 0, ...), an even number of chunks
+    per rank, so that every rank pairs short chunks with long ones: per-rank audio seconds AND per-rank padded work come
+    out equal (contiguous runs of the sorted order give the last rank ~3x the first rank's audio on U(2 s, 10 s)), while a
+    chunk — one batch on its rank — is still a run of neighbours in the sorted order, i.e. tightly padded.
+    -> (indices per rank, chunk size = the batch size each rank should cut its shard into)."""
+    n = len(lengths)
+    order = sorted(range(n), key=lambda i: (lengths[i], i))
+    if n == 0 or world <= 1:
+        return [order] + [[] for _ in range(max(world, 1) - 1)], max_batch
+    per_rank = -(-n // world)
+    k = max(2, -(-per_rank // max_batch))
+    k += k & 1                                                   # even: the snake pairs chunk c with chunk 2W-1-c
+    chunk = max(1, -(-n // (world * k)))
+    shards: List[List[int]] = [[] for _ in range(world)]
+    for c in range(world * k):                                   # exactly W * k chunks whose sizes differ by at most one
+        rnd, pos = divmod(c, world)
+        lo, hi = shard_bounds(n, world * k, c)
+        shards[pos if rnd % 2 == 0 else world - 1 - pos].extend(order[lo:hi])
+    return shards, chunk
+
+
+def shard_plan(lengths: Sequence[int], world: int, max_batch: int = 256, mode: str = "auto") -> Tuple[List[List[int]], int]:
+    """How `sharded_decode` deals utterances: "contiguous" = runs of the length-sorted order (right for
+    equal-length input such as BASELINE configs[2], where any dealing is balanced and whole batches of `max_batch` are the
+    most efficient), "balanced" = `shard_balanced`, "auto" = contiguous when every rank's padded work would be within 5 % of
+    the others' anyway (longest utterance <= 1.05 x the shortest), balanced otherwise."""
+    if mode not in ("auto", "contiguous", "balanced"):
+        raise ValueError(f"shard mode {mode!r}")
+    if mode == "auto":
+        mode = "contiguous" if (len(lengths) == 0 or max(lengths) <= 1.05 * max(min(lengths), 1)) else "balanced"
+    if mode == "contiguous":
+        return shard_by_length(lengths, world), max_batch
+    return shard_balanced(lengths, world, max_batch)
+
+
 def gather_hypotheses(ids: torch.Tensor, frames: torch.Tensor, n_ids: torch.Tensor):
     """all_gather of one rank's padded hypotheses -> ([W*B, U], [W*B, U], [W*B]) on every rank.
     One fused payload (ids | frames | n) per rank so the exchange is a single collective."""
@@ -99,13 +135,15 @@ def _collective_device() -> torch.device:
     return torch.device("cpu")
 
 
-def sharded_decode(lengths: Sequence[int], run_local, counters=None):
+def sharded_decode(lengths: Sequence[int], run_local, counters=None, max_batch: int = 256, mode: str = "auto"):
     """The multi-GPU entry point of the path (BASELINE.json configs[2]: 2048 utterances over 8 GPUs; reference
     mechanism: one process per GPU, pkg/evaluation/src/base.py:194-212, examples/rs-nemo/eval.py:24-28).
 
     Every rank calls this with the SAME `lengths` (samples per utterance, caller order).  The utterances are dealt
-    to ranks by `shard_by_length`, rank r decodes its shard with `run_local(indices) -> (ids, frames, enc_lens[, scores])`
-    (lists in shard order; `scores` = hypothesis log-probabilities of the beam search, or None), and ONE all_gather of
+    to ranks by `shard_plan` (equal lengths: contiguous runs; ragged: length-sorted chunks in snake order, balanced audio
+    seconds per rank), rank r decodes its shard with `run_local(indices[, batch]) -> (ids, frames, enc_lens[, scores])`
+    (lists in shard order; `batch` = the batch size the plan was made for, passed when `run_local` takes two arguments;
+    `scores` = hypothesis log-probabilities of the beam search, or None), and ONE all_gather of
     the padded hypotheses (count | encoder length | score bits | ids | frames fused into one int32 payload per rank)
     returns every utterance's result to every rank, restored to caller order.  There is no other collective besides a
     MAX all_reduce that agrees on the payload width.
@@ -113,8 +151,13 @@ def sharded_decode(lengths: Sequence[int], run_local, counters=None):
     -> (ids, frames, enc_lens, scores): lists of length len(lengths) in caller order (`scores` None when no rank had any)."""
     n = len(lengths)
     W, r = world_size(), rank()
-    shards = shard_by_length(lengths, W)
-    res = run_local(list(shards[r]))
+    shards, batch = shard_plan(lengths, W, max_batch, mode)
+    import inspect
+    try:
+        two = len(inspect.signature(run_local).parameters) >= 2
+    except (TypeError, ValueError):
+        two = False
+    res = run_local(list(shards[r]), batch) if two else run_local(list(shards[r]))
     ids, frames, enc_lens = res[0], res[1], res[2]
     scores = res[3] if len(res) > 3 else None
     assert len(ids) == len(frames) == len(enc_lens) == len(shards[r]), "run_local must answer for every index it was given"

@@ -497,11 +497,13 @@ class AsrModel:
         collective (runtime/dist.py: sharded_decode).  With a single process it is `transcribe_waveforms`."""
         from . import dist as rdist
 
-        def run_local(indices):
-            res = self.transcribe_waveforms([waveforms[i] for i in indices], max_batch=max_batch)
+        def run_local(indices, batch):
+            # `batch`: the chunk size of the dealing plan (ragged input is dealt as length-sorted chunks, balanced over the
+            # ranks: runtime/dist.py shard_balanced) — this rank's batches are exactly its chunks
+            res = self.transcribe_waveforms([waveforms[i] for i in indices], max_batch=min(max_batch, batch))
             return res.ids, res.frames, res.enc_lens, res.scores
 
-        ids, frames, enc_lens, scores = rdist.sharded_decode([len(w) for w in waveforms], run_local)
+        ids, frames, enc_lens, scores = rdist.sharded_decode([len(w) for w in waveforms], run_local, max_batch=max_batch)
         return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.decoding == "alsd" else None)
 
     LONGEST_FIRST = True    # batch order of a long list (A/B hook of scripts/ragged_order_ab.py)

@@ -155,6 +155,16 @@ def test_shard_helpers():
     assert [len(s) for s in shards] == [3, 2, 2]
     assert max(lens[i] for i in shards[0]) <= min(lens[i] for i in shards[1])
     assert rdist.shard_by_length([], 2) == [[], []]
+    # plans: equal lengths -> contiguous whole batches; ragged -> snake-dealt chunks, an even number per rank
+    sh, batch = rdist.shard_plan([160000] * 2048, 8, 256)
+    assert batch == 256 and [len(x) for x in sh] == [256] * 8 and sh[0] == list(range(256))
+    sh, batch = rdist.shard_plan(list(range(1000, 1000 + 4096)), 4, 256)
+    assert batch == 256 and [len(x) for x in sh] == [1024] * 4 and sh[0][:256] == list(range(256)) and sh[0][256:512] == list(range(7 * 256, 8 * 256))
+    sh, batch = rdist.shard_plan([5, 1, 9, 3, 7], 2, 256)
+    assert sorted(sum(sh, [])) == list(range(5)) and batch == 2 and sh == [[1, 3, 2], [0, 4]]
+    assert rdist.shard_plan([], 3)[0] == [[], [], []]
+    with pytest.raises(ValueError):
+        rdist.shard_plan([1], 1, mode="nope")
     assert rdist.world_size() == 1 and rdist.rank() == 0 and rdist.max_over_ranks(1.5) == 1.5
 
 
@@ -211,7 +221,7 @@ def _sharded_worker(rank, world, port, out_dir):
         return _fake_decode(lengths)(indices)
 
     counters = {}
-    out = rdist.sharded_decode(lengths, run_local, counters)
+    out = rdist.sharded_decode(lengths, run_local, counters, mode="contiguous")
     empty = rdist.sharded_decode([], lambda idx: ([], [], []))
     torch.save((out, calls, counters, empty), os.path.join(out_dir, f"s{rank}.pt"))
     rdist.shutdown()
@@ -255,8 +265,17 @@ def _sharded8_worker(rank, world, port, out_dir):
     rng = np.random.default_rng(1235)
     lengths = rng.integers(2 * 16000, 10 * 16000 + 1, size=2048).tolist()      # BASELINE configs[2]: 2048 = 8 x 256, ragged
     counters = {}
-    out = rdist.sharded_decode(lengths, _fake_beam_decode(lengths), counters)
+    out = rdist.sharded_decode(lengths, _fake_beam_decode(lengths), counters, mode="contiguous")
     few = rdist.sharded_decode(lengths[:5], _fake_beam_decode(lengths[:5]))      # 5 utterances on 8 ranks: three empty shards
+    # the default plan for ragged input: balanced chunks; run_local learns the chunk size and which utterances it got
+    mine = {}
+
+    def run_local(indices, batch):
+        mine["indices"], mine["batch"] = list(indices), batch
+        return _fake_beam_decode(lengths)(indices)
+
+    bal = rdist.sharded_decode(lengths, run_local)
+    torch.save((mine, bal[0] == out[0] and bal[1] == out[1] and bal[2] == out[2]), os.path.join(out_dir, f"b{rank}.pt"))
     if rank in (0, world - 1):
         torch.save((out, counters, few), os.path.join(out_dir, f"w{rank}.pt"))
     rdist.shutdown()
@@ -282,6 +301,24 @@ def test_sharded_decode_gloo_world8_2048_ragged(tmp_path):
         assert np.array_equal(np.asarray(out[3], np.float32).view(np.int32), np.asarray(want[3], np.float32).view(np.int32))
         assert counters["collectives"] == 1
         assert few[:3] == want_few[:3] and few[3] == want_few[3]
+    # the balanced plan (default for ragged input): same answers, every utterance dealt once, per-rank audio seconds AND
+    # per-rank padded work (batch size x longest utterance of each batch) within 5 % of the mean, batches tightly padded
+    secs, padded, seen = [], [], []
+    for r in range(world):
+        mine, same = torch.load(os.path.join(str(tmp_path), f"b{r}.pt"))
+        assert same and mine["batch"] == 128
+        idx = sorted(mine["indices"], key=lambda i: (lengths[i], i))
+        seen += idx
+        secs.append(sum(lengths[i] for i in idx) / 16000.0)
+        groups = [idx[k:k + mine["batch"]] for k in range(0, len(idx), mine["batch"])]
+        padded.append(sum(len(g) * max(lengths[i] for i in g) for g in groups) / 16000.0)
+        for g in groups:                                  # a batch spans at most ~1/16 of the length range (+ sampling noise)
+            assert max(lengths[i] for i in g) - min(lengths[i] for i in g) <= 0.08 * (10 - 2) * 16000
+    assert sorted(seen) == list(range(2048))
+    assert max(secs) <= 1.05 * (sum(secs) / world) and min(secs) >= 0.95 * (sum(secs) / world), secs
+    assert max(padded) <= 1.05 * (sum(padded) / world), padded
+    contiguous = [sum(lengths[i] for i in s) / 16000.0 for s in shards]
+    assert max(contiguous) > 2.5 * min(contiguous)         # what the balanced plan replaces
 
 
 # ---- .nemo archives shaped like NeMo writes them (not produced by this repo's write_nemo) -------------------------
