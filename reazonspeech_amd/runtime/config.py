@@ -182,6 +182,57 @@ def resolve_interpolations(cfg: dict) -> dict:
     return walk(cfg)
 
 
+# Every key of the four model sections that this loader either interprets ("used") or knows to have no effect on
+# inference ("inert": training / logging / memory knobs).  [UPSTREAM] NeMo >= 2.6:
+# examples/asr/conf/fastconformer/fast-conformer_transducer_bpe.yaml, ConformerEncoder / RNNTDecoder / RNNTJoint /
+# AudioToMelSpectrogramPreprocessor constructor arguments.  In strict mode a key outside these tables raises: a setting
+# nobody mapped is a setting that may change what the checkpoint computes.
+KNOWN_KEYS = {
+    "preprocessor": {
+        "used": {"sample_rate", "n_fft", "window_size", "window_stride", "features", "preemph", "log_zero_guard_value",
+                 "normalize", "window", "frame_splicing", "log", "log_zero_guard_type", "mag_power", "n_window_size",
+                 "n_window_stride", "exact_pad", "highfreq", "lowfreq", "mel_norm"},
+        "inert": {"_target_", "dither", "pad_to", "nb_augmentation_prob", "pad_value", "use_torchaudio", "rng", "nb_max_freq", "stft_exact_pad",
+                  "stft_conv", "use_grads"},
+    },
+    "encoder": {
+        "used": {"feat_in", "n_layers", "d_model", "use_bias", "subsampling", "subsampling_factor", "subsampling_conv_channels",
+                 "causal_downsampling", "reduction", "reduction_position", "reduction_factor", "ff_expansion_factor",
+                 "self_attention_model", "n_heads", "att_context_size", "att_context_style", "att_context_probs", "xscaling",
+                 "untie_biases", "conv_kernel_size", "conv_norm_type", "conv_context_size", "global_tokens",
+                 "global_tokens_spacing", "global_attn_separate", "feat_out", "subsampling_conv_chunking_factor",
+                 "use_pytorch_sdpa", "use_pytorch_sdpa_backends", "sync_max_audio_length"},
+        "inert": {"_target_", "pos_emb_max_len", "dropout", "dropout_pre_encoder", "dropout_emb", "dropout_att",
+                  "stochastic_depth_drop_prob", "stochastic_depth_mode", "stochastic_depth_start_layer"},
+    },
+    "decoder": {
+        "used": {"vocab_size", "prednet", "blank_as_pad", "normalization_mode"},
+        "inert": {"_target_", "random_state_sampling"},
+    },
+    "decoder.prednet": {
+        "used": {"pred_hidden", "pred_rnn_layers", "rnn_type", "rnn_hidden_size"},
+        "inert": {"t_max", "dropout", "forget_gate_bias", "weights_init_scale", "hidden_hidden_bias_scale"},
+    },
+    "joint": {
+        "used": {"num_classes", "vocabulary", "jointnet", "num_extra_outputs"},
+        "inert": {"_target_", "log_softmax", "preserve_memory", "fuse_loss_wer", "fused_batch_size", "masking_prob"},
+    },
+    "joint.jointnet": {
+        "used": {"joint_hidden", "activation", "encoder_hidden", "pred_hidden"},
+        "inert": {"dropout"},
+    },
+}
+
+
+def _check_known(section: str, node: dict):
+    known = KNOWN_KEYS[section]["used"] | KNOWN_KEYS[section]["inert"]
+    unknown = sorted(k for k in node if k not in known)
+    if unknown:
+        raise UnsupportedCheckpoint(f"model_config.yaml: unknown setting(s) {section}.{{{', '.join(unknown)}}} — not mapped by "
+                                    f"this loader, so their effect on the computation is unknown (strict mode; "
+                                    f"from_nemo_yaml(..., strict=False) ignores them)")
+
+
 def from_nemo_yaml(cfg: dict, strict: bool = True) -> ModelConfig:
     """Map a NeMo `model_config.yaml` (already parsed to a dict) onto ModelConfig.
     [UPSTREAM] key names follow NeMo >= 2.6 `EncDecRNNTBPEModel` configs
@@ -221,7 +272,25 @@ def from_nemo_yaml(cfg: dict, strict: bool = True) -> ModelConfig:
         def need(cond, what):
             if not cond:
                 raise UnsupportedCheckpoint(f"model_config.yaml: {what} is not implemented by the gfx950 kernels")
+        for section, node in (("preprocessor", pre), ("encoder", enc), ("decoder", dec), ("decoder.prednet", prednet),
+                              ("joint", joint), ("joint.jointnet", jn)):
+            _check_known(section, node)
         need(str(enc.get("subsampling", "dw_striding")) == "dw_striding", f"encoder.subsampling={enc.get('subsampling')!r}")
+        need(bool(enc.get("untie_biases", True)), "encoder.untie_biases=false (position biases shared by all layers)")
+        need(int(enc.get("feat_out", -1) or -1) in (-1, int(enc.get("d_model", 1024))), "encoder.feat_out (an output projection)")
+        need(not enc.get("global_tokens_spacing") or int(enc.get("global_tokens_spacing")) == 1, "encoder.global_tokens_spacing != 1")
+        need(dec.get("normalization_mode") in (None, "null"), f"decoder.normalization_mode={dec.get('normalization_mode')!r}")
+        need(int(joint.get("num_extra_outputs", 0) or 0) == 0, "joint.num_extra_outputs (TDT durations)")
+        need(pre.get("highfreq") in (None, "null") or float(pre.get("highfreq")) == sr / 2.0, f"preprocessor.highfreq={pre.get('highfreq')!r}")
+        need(float(pre.get("lowfreq", 0) or 0) == 0.0, f"preprocessor.lowfreq={pre.get('lowfreq')!r}")
+        need(str(pre.get("mel_norm", "slaney")) == "slaney", f"preprocessor.mel_norm={pre.get('mel_norm')!r}")
+        need(not pre.get("exact_pad", False), "preprocessor.exact_pad")
+        need(prednet.get("rnn_hidden_size") in (None, "null") or int(prednet.get("rnn_hidden_size")) == int(prednet.get("pred_hidden", 640)),
+             "decoder.prednet.rnn_hidden_size != pred_hidden (projected LSTM)")
+        need(jn.get("encoder_hidden") in (None, "null") or int(jn.get("encoder_hidden")) == int(enc.get("d_model", 1024)),
+             "joint.jointnet.encoder_hidden != encoder.d_model")
+        need(jn.get("pred_hidden") in (None, "null") or int(jn.get("pred_hidden")) == int(prednet.get("pred_hidden", 640)),
+             "joint.jointnet.pred_hidden != decoder.prednet.pred_hidden")
         need(not enc.get("causal_downsampling", False), "encoder.causal_downsampling")
         need(att_model in ("rel_pos", "rel_pos_local_attn"), f"encoder.self_attention_model={att_model!r}")
         need(str(enc.get("conv_norm_type", "batch_norm")) == "batch_norm", f"encoder.conv_norm_type={enc.get('conv_norm_type')!r}")
@@ -259,8 +328,9 @@ def from_nemo_yaml(cfg: dict, strict: bool = True) -> ModelConfig:
     return ModelConfig(
         sample_rate=sr,
         n_fft=int(pre.get("n_fft", 512) or 512),
-        win_length=int(round(float(pre.get("window_size", 0.025)) * sr)),
-        hop_length=int(round(float(pre.get("window_stride", 0.01)) * sr)),
+        # (n_window_size / n_window_stride give the same two numbers in samples)
+        win_length=int(pre["n_window_size"]) if pre.get("n_window_size") else int(round(float(pre.get("window_size") or 0.025) * sr)),
+        hop_length=int(pre["n_window_stride"]) if pre.get("n_window_stride") else int(round(float(pre.get("window_stride") or 0.01) * sr)),
         n_mels=int(pre.get("features", 80)),
         preemph=float(pre.get("preemph", 0.97) or 0.0),
         log_guard=float(guard),

@@ -531,3 +531,44 @@ def test_gemm_tile_height_rule():
         for name, bm in table.items():
             N, K, flags = shapes[name]
             assert pick(B * 138, N, K, 256, flags) == bm, (B, name)
+
+
+# ---- A5: the loader against NeMo's PUBLISHED FastConformer-Transducer configuration (not this repo's writer) ---------
+def test_strict_loader_on_nemo_published_fastconformer_xl_config():
+    """tests/golden/nemo_fastconformer_xl_transducer_bpe.yaml follows NeMo's own
+    examples/asr/conf/fastconformer/fast-conformer_transducer_bpe.yaml key for key (XL sizes): strict mode maps it onto the
+    619M architecture, ignores the training-only sections, resolves the interpolations — and refuses ANY setting it has no
+    mapping for, and every known variant the kernels do not compute"""
+    import copy
+    import yaml
+    from reazonspeech_amd.runtime.config import from_nemo_yaml, FASTCONFORMER_619M, UnsupportedCheckpoint
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nemo_fastconformer_xl_transducer_bpe.yaml")
+    with open(path) as fp:
+        doc = yaml.safe_load(fp)
+    cfg = from_nemo_yaml(copy.deepcopy(doc))
+    assert cfg == FASTCONFORMER_619M.with_(decoding="alsd", beam_size=4)
+    assert cfg.n_params() == 619223481                                  # README.rst:34-35: "619M"
+    assert from_nemo_yaml({"model": copy.deepcopy(doc)}) == cfg         # training-style nesting
+
+    def broken(section, key, value, sub=None):
+        d = copy.deepcopy(doc)
+        node = d[section] if sub is None else d[section][sub]
+        node[key] = value
+        return d
+
+    for args in (("encoder", "mystery_knob", 3), ("preprocessor", "new_flag", True), ("decoder", "extra", 1),
+                 ("joint", "whatever", 0), ("decoder", "unknown_prednet_knob", 1, "prednet"), ("joint", "gate", 1, "jointnet"),
+                 # known settings whose non-default value changes the computation
+                 ("encoder", "untie_biases", False), ("encoder", "subsampling", "striding"), ("encoder", "conv_norm_type", "layer_norm"),
+                 ("encoder", "feat_out", 512), ("encoder", "causal_downsampling", True), ("decoder", "normalization_mode", "layer"),
+                 ("joint", "num_extra_outputs", 5), ("preprocessor", "normalize", "all_features"), ("preprocessor", "highfreq", 7600),
+                 ("preprocessor", "mel_norm", None), ("joint", "activation", "tanh", "jointnet"),
+                 ("decoder", "rnn_hidden_size", 1024, "prednet")):
+        with pytest.raises(UnsupportedCheckpoint):
+            from_nemo_yaml(broken(*args))
+    # the same unknown key is ignored when the caller opts out of strictness
+    assert from_nemo_yaml(broken("encoder", "mystery_knob", 3), strict=False).d_model == 1024
+    # window given in samples
+    d = copy.deepcopy(doc)
+    d["preprocessor"].pop("window_size"); d["preprocessor"]["n_window_size"] = 400
+    assert from_nemo_yaml(d).win_length == 400
