@@ -238,6 +238,10 @@ int rs_profile_enable(rs_ctx* ctx, int class_mask);
 int rs_profile_read(rs_ctx* ctx, int klass, double* ms, int64_t* launches, double* flops,
                     double* bytes);
 int rs_profile_reset(rs_ctx* ctx);
+/* Per-launch detail of a class since the last reset, in launch order: shapes[4 * i ..] = (M, N, K, flags) for GEMM launches
+ * (zeros for other classes), flops[i], ms[i].  Up to `cap` records are copied (arrays may be NULL); *n_out = how many exist.
+ * bench.py groups them into `roofline.per_shape`. */
+int rs_profile_read_launches(rs_ctx* ctx, int klass, int32_t* shapes, double* flops, float* ms, int cap, int* n_out);
 
 /* ---- single-operator entry points (parity tests call these one by one) -------------------*/
 

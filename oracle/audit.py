@@ -114,3 +114,102 @@ def summarize(audits, ids_equal):
         out["flip_margin_over_bound_max"] = float(max(f["margin_ref"] / max(f["bound"], 1e-30) for f in flips))
         out["flip_margin_percentile_of_all_margins_max"] = float((margins < fm.max()).mean() * 100.0)
     return out
+
+
+def flip_audit_batch(cfg, sd, f_ref, f_hip, enc_lens, hyp_ids, hyp_frames, device="cpu"):
+    """`flip_audit` for a whole batch at once, in torch float64 on `device` (a GPU box audits all 256 rows of the benchmark
+    batch in a second or two; the per-row numpy walk above takes about half a second per row).  Rows advance in lockstep
+    over their own decision lists; the arithmetic per row is the same as in `flip_audit`.
+
+      f_ref, f_hip   [B, T, J] tensors (any float dtype / device): reference and audited joint-encoder projections
+      enc_lens       B ints;  hyp_ids / hyp_frames: the AUDITED side's hypotheses (lists of lists)
+    -> list of per-row dicts with the keys of `flip_audit` (margins as numpy float64 arrays)."""
+    import torch
+    dev = torch.device(device)
+    f64 = lambda t: t.detach().to(device=dev, dtype=torch.float64)  # noqa: E731
+    B = len(enc_lens)
+    blank, H, L = cfg.blank_id, cfg.pred_hidden, cfg.pred_layers
+    P = "decoder.prediction.dec_rnn.lstm."
+    emb = f64(sd["decoder.prediction.embed.weight"])
+    w = [torch.cat([f64(sd[P + f"weight_ih_l{l}"]), f64(sd[P + f"weight_hh_l{l}"])], dim=1) for l in range(L)]
+    bsum = [f64(sd[P + f"bias_ih_l{l}"]) + f64(sd[P + f"bias_hh_l{l}"]) for l in range(L)]
+    wp, bp = f64(sd["joint.pred.weight"]), f64(sd["joint.pred.bias"])
+    wo, bo = f64(sd["joint.joint_net.2.weight"]), f64(sd["joint.joint_net.2.bias"])
+    wnorm = wo.norm(dim=1)
+    fr, fh = f64(f_ref), f64(f_hip)
+    # decision lists: at frame t the tokens emitted there, then the blank that advanced the frame
+    dec_t, dec_k = [], []
+    for b in range(B):
+        by_frame = {}
+        for k, t in zip(hyp_ids[b], hyp_frames[b]):
+            by_frame.setdefault(int(t), []).append(int(k))
+        ts, ks = [], []
+        for t in range(int(enc_lens[b])):
+            toks = by_frame.get(t, [])
+            for k in toks + ([blank] if len(toks) < cfg.max_symbols else []):
+                ts.append(t); ks.append(k)
+        dec_t.append(ts); dec_k.append(ks)
+    D = max((len(x) for x in dec_t), default=0)
+    T = torch.zeros((B, max(D, 1)), dtype=torch.long)
+    K = torch.full((B, max(D, 1)), blank, dtype=torch.long)
+    V = torch.zeros((B, max(D, 1)), dtype=torch.bool)
+    for b in range(B):
+        n = len(dec_t[b])
+        T[b, :n] = torch.tensor(dec_t[b], dtype=torch.long)
+        K[b, :n] = torch.tensor(dec_k[b], dtype=torch.long)
+        V[b, :n] = True
+    T, K, V = T.to(dev), K.to(dev), V.to(dev)
+    h = [torch.zeros((B, H), dtype=torch.float64, device=dev) for _ in range(L)]
+    c = [torch.zeros((B, H), dtype=torch.float64, device=dev) for _ in range(L)]
+
+    def pred_step(tokens, rows):
+        """advance the prediction network of `rows` (bool [B]) with `tokens` [B]; -> g [B, J] for those rows"""
+        x = emb[tokens]
+        for l in range(L):
+            z = torch.cat([x, h[l]], dim=1) @ w[l].t() + bsum[l]
+            i, f, g_, o = torch.sigmoid(z[:, :H]), torch.sigmoid(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), torch.sigmoid(z[:, 3 * H:])
+            cn = f * c[l] + i * g_
+            hn = o * torch.tanh(cn)
+            c[l] = torch.where(rows[:, None], cn, c[l])
+            h[l] = torch.where(rows[:, None], hn, h[l])
+            x = h[l]
+        return x @ wp.t() + bp
+
+    every = torch.ones((B,), dtype=torch.bool, device=dev)
+    g = pred_step(torch.full((B,), blank, dtype=torch.long, device=dev), every)
+    rows_idx = torch.arange(B, device=dev)
+    margins = torch.zeros((B, max(D, 1)), dtype=torch.float64, device=dev)
+    k_ref_all = torch.zeros((B, max(D, 1)), dtype=torch.long, device=dev)
+    m_flip = torch.zeros((B, max(D, 1)), dtype=torch.float64, device=dev)
+    df_all = torch.zeros((B, max(D, 1)), dtype=torch.float64, device=dev)
+    path_bad = torch.zeros((B,), dtype=torch.bool, device=dev)
+    for d in range(D):
+        t, k, v = T[:, d], K[:, d], V[:, d]
+        fr_t, fh_t = fr[rows_idx, t], fh[rows_idx, t]
+        z_ref = torch.relu(fr_t + g) @ wo.t() + bo
+        z_hip = torch.relu(fh_t + g) @ wo.t() + bo
+        top2 = z_ref.topk(2, dim=1).values
+        margins[:, d] = top2[:, 0] - top2[:, 1]
+        k_ref = z_ref.argmax(dim=1)
+        k_ref_all[:, d] = k_ref
+        m_flip[:, d] = z_ref[rows_idx, k_ref] - z_ref[rows_idx, k]
+        df_all[:, d] = (fr_t - fh_t).norm(dim=1)
+        path_bad |= v & ((z_hip.max(dim=1).values - z_hip[rows_idx, k]) > 1e-3)
+        emit = v & (k != blank)
+        if bool(emit.any()):
+            g_new = pred_step(k, emit)
+            g = torch.where(emit[:, None], g_new, g)
+    margins, k_ref_all, m_flip, df_all = margins.cpu().numpy(), k_ref_all.cpu().numpy(), m_flip.cpu().numpy(), df_all.cpu().numpy()
+    wn = wnorm.cpu().numpy()
+    path_bad = path_bad.cpu().numpy()
+    out = []
+    for b in range(B):
+        n = len(dec_t[b])
+        flips = []
+        for d in range(n):
+            if int(k_ref_all[b, d]) != dec_k[b][d]:
+                kr, kh = int(k_ref_all[b, d]), dec_k[b][d]
+                flips.append({"frame": dec_t[b][d], "k_ref": kr, "k_hip": kh, "margin_ref": float(m_flip[b, d]),
+                              "bound": float((wn[kr] + wn[kh]) * df_all[b, d]), "delta_f": float(df_all[b, d])})
+        out.append({"decisions": n, "flips": flips, "margins": margins[b, :n].astype(np.float64), "path_ok": not bool(path_bad[b])})
+    return out

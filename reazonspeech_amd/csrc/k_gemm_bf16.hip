@@ -709,6 +709,7 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     const double bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K) +
                          (double)a.M * a.N * ((a.flags & RS_GEMM_OUT_F32) ? 4 : ((a.flags & RS_GEMM_GLU) ? 1 : 2)) +
                          ((a.flags & RS_GEMM_RESIDUAL) ? (double)a.M * a.N * 4 : 0.0);   // residual is read once
+    ctx->prof_tag[0] = a.M; ctx->prof_tag[1] = a.N; ctx->prof_tag[2] = a.K; ctx->prof_tag[3] = a.flags;
     rs_prof_begin(ctx, RS_PROF_GEMM, s, flops, bytes);
     int rc = RS_OK;
     for (size_t r0 = 0; r0 < (size_t)a.M && rc == RS_OK; r0 += max_rows) {

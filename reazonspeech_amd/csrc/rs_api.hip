@@ -66,6 +66,8 @@ void rs_prof_begin(rs_ctx* ctx, int klass, hipStream_t s, double flops, double b
     p.flops += flops;
     p.bytes += bytes;
     p.launches += 1;
+    if (p.detail.size() < (1u << 20)) p.detail.push_back(rs_prof_launch{ctx->prof_tag[0], ctx->prof_tag[1], ctx->prof_tag[2], ctx->prof_tag[3], flops, -1.0f});
+    ctx->prof_tag[0] = ctx->prof_tag[1] = ctx->prof_tag[2] = ctx->prof_tag[3] = 0;
 }
 void rs_prof_end(rs_ctx* ctx, int klass, hipStream_t s) {
     if (!(ctx->prof_mask & klass)) return;
@@ -601,7 +603,7 @@ int rs_profile_enable(rs_ctx* ctx, int class_mask) {
 }
 int rs_profile_reset(rs_ctx* ctx) {
     if (!ctx) return RS_EINVAL;
-    for (auto& p : ctx->prof) { p.used = 0; p.flops = p.bytes = p.ms_acc = 0; p.launches = 0; }
+    for (auto& p : ctx->prof) { p.used = 0; p.flops = p.bytes = p.ms_acc = 0; p.launches = 0; p.detail.clear(); p.read = 0; }
     return RS_OK;
 }
 int rs_profile_read(rs_ctx* ctx, int klass, double* ms, int64_t* launches, double* flops, double* bytes) {
@@ -613,6 +615,7 @@ int rs_profile_read(rs_ctx* ctx, int klass, double* ms, int64_t* launches, doubl
         float t = 0;
         RS_HIP(ctx, hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]));
         total += t;
+        if (p.read < p.detail.size()) p.detail[p.read++].ms = t;      // launches are bracketed and read in the same order
     }
     p.ms_acc = total;
     p.used = 0;
@@ -620,6 +623,21 @@ int rs_profile_read(rs_ctx* ctx, int klass, double* ms, int64_t* launches, doubl
     if (launches) *launches = p.launches;
     if (flops) *flops = p.flops;
     if (bytes) *bytes = p.bytes;
+    return RS_OK;
+}
+
+int rs_profile_read_launches(rs_ctx* ctx, int klass, int32_t* shapes, double* flops, float* ms, int cap, int* n_out) {
+    if (!ctx || klass <= 0 || cap < 0 || !n_out) return RS_EINVAL;
+    if (int rc = rs_profile_read(ctx, klass, nullptr, nullptr, nullptr, nullptr); rc != RS_OK) return rc;   // folds pending events in
+    const rs_prof_slot& p = ctx->prof[rs_prof_class_index(klass)];
+    const int n = (int)p.read < cap ? (int)p.read : cap;
+    for (int i = 0; i < n; ++i) {
+        const rs_prof_launch& l = p.detail[i];
+        if (shapes) { shapes[4 * i] = l.M; shapes[4 * i + 1] = l.N; shapes[4 * i + 2] = l.K; shapes[4 * i + 3] = l.flags; }
+        if (flops) flops[i] = l.flops;
+        if (ms) ms[i] = l.ms;
+    }
+    *n_out = (int)p.read;
     return RS_OK;
 }
 

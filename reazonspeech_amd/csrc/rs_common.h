@@ -51,8 +51,11 @@ __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // ----------------------------------------------------------------------------------------
 // host side: context
 // ----------------------------------------------------------------------------------------
+struct rs_prof_launch { int32_t M, N, K, flags; double flops; float ms; };
 struct rs_prof_slot {
     std::vector<hipEvent_t> ev;  // pairs (start, stop)
+    std::vector<rs_prof_launch> detail;   // one record per bracketed launch since the last reset (shape tag + its time once read)
+    size_t read = 0;             // records of `detail` whose events were already folded into ms_acc
     size_t used = 0;
     double flops = 0, bytes = 0;
     double ms_acc = 0;
@@ -127,6 +130,7 @@ struct rs_ctx {
     // profiling
     int prof_mask = 0;
     rs_prof_slot prof[8];
+    int32_t prof_tag[4] = {0, 0, 0, 0};   // (M, N, K, flags) of the launch about to be bracketed (set by the GEMM launcher)
 };
 
 // Opt-in for more than 64 KiB of dynamic LDS, once per (device, kernel): the attribute is per device and the

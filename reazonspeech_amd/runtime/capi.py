@@ -29,7 +29,7 @@ EXPORTS = [
     "rs_rnnt_greedy", "rs_profile_enable", "rs_profile_read", "rs_profile_reset", "rs_gemm_bf16",
     "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_glu_dwconv_silu_layout", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
     "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes", "rs_host_stage_rows",
-    "rs_gemm_f32", "rs_relpos_attention_f32", "rs_glu_dwconv_silu_f32",
+    "rs_gemm_f32", "rs_relpos_attention_f32", "rs_glu_dwconv_silu_f32", "rs_profile_read_launches",
 ]
 
 
@@ -113,6 +113,7 @@ def load():
     lib.rs_relpos_attention.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp]
     lib.rs_glu_dwconv_silu.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
     lib.rs_glu_dwconv_silu_layout.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
+    lib.rs_profile_read_launches.argtypes = [vp, c_int, vp, vp, vp, c_int, POINTER(c_int)]
     lib.rs_gemm_f32.argtypes = [vp, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp, c_float, vp, vp, c_int,
                                 c_int, vp]
     lib.rs_relpos_attention_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp]
@@ -293,6 +294,18 @@ class Context:
         ms, n, fl, by = c_double(), c_int64(), c_double(), c_double()
         self.check(self.lib.rs_profile_read(self._h, int(klass), byref(ms), byref(n), byref(fl), byref(by)))
         return dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+
+    def profile_launches(self, klass):
+        """per-launch records of a profiled class since the last reset: list of (M, N, K, flags, flops, ms)"""
+        import numpy as np
+        n = c_int(0)
+        self.check(self.lib.rs_profile_read_launches(self._h, int(klass), None, None, None, 0, byref(n)))
+        cap = max(n.value, 1)
+        shapes, fl, ms = np.zeros((cap, 4), np.int32), np.zeros((cap,), np.float64), np.zeros((cap,), np.float32)
+        self.check(self.lib.rs_profile_read_launches(self._h, int(klass), c_void_p(shapes.ctypes.data), c_void_p(fl.ctypes.data),
+                                                     c_void_p(ms.ctypes.data), cap, byref(n)))
+        k = min(n.value, cap)
+        return [(int(shapes[i, 0]), int(shapes[i, 1]), int(shapes[i, 2]), int(shapes[i, 3]), float(fl[i]), float(ms[i])) for i in range(k)]
 
     # ---- single operators (used by the parity tests) ----
     def gemm(self, A, W, out, flags=0, bias=None, alpha=1.0, residual=None, mask_lens=None, mask_rows=0,

@@ -7,7 +7,9 @@ ParakeetForRNNT.generate).  NeMo itself is not installable here
 is the strongest anchor available; the fixture stores the *inputs* and the HF outputs so
 the comparison can be re-run anywhere without transformers.
 
-    python tests/golden/make_parakeet_golden.py
+    python tests/golden/make_parakeet_golden.py            # toy geometry
+    python tests/golden/make_parakeet_golden.py --wide     # the 619M layer geometry, 2 layers, 3 seeds
+    python tests/golden/make_parakeet_golden.py --full     # the 619M model itself: 24 layers, the benchmark's weights
 """
 import importlib.machinery
 import os
@@ -241,8 +243,52 @@ def main_wide():
     print("wrote", out, os.path.getsize(out), "bytes")
 
 
+# ---- the FULL benchmark model: 24 layers, 619M parameters, the synthetic weights bench.py runs (seed 0) ----
+FULL_ROWS = 2
+
+
+def full_audio():
+    """rows 0 and 1 of the benchmark batch (256 x 10 s, seed 1234) with the reference's 0.5 s padding
+    (pkg/nemo-asr/src/audio.py:70-83) — the same rows tests/golden/bench_fp32.npz keeps the oracle's joint projection of"""
+    from reazonspeech_amd.runtime.synth import synthetic_batch
+    audio, lens = synthetic_batch(256, 10.0, seed=1234)
+    padded = np.zeros((FULL_ROWS, audio.shape[1] + 16000), np.float32)
+    for b in range(FULL_ROWS):
+        padded[b, 8000:8000 + int(lens[b])] = audio[b, :int(lens[b])]
+    return padded, (lens[:FULL_ROWS] + 16000).astype(np.int64)
+
+
+def main_full():
+    """tests/golden/parakeet_full.npz: transformers' ParakeetForRNNT with ALL 24 layers at the 619M geometry, the
+    benchmark's weights and two benchmark utterances — anchors the oracle path that checks the benchmark itself
+    (the toy and two-layer fixtures cannot see an error that only accumulates over depth)"""
+    import hashlib
+    from reazonspeech_amd.runtime.config import FASTCONFORMER_619M
+    _install_librosa_stub()
+    cfg = FASTCONFORMER_619M
+    sd = synthetic_state_dict(cfg, seed=0)
+    audio, lens = full_audio()
+    feats, enc_out, enc_lens, ids, frames = hf_outputs(cfg, sd, audio, lens)
+    umax = max(1, max(len(x) for x in ids))
+    ids_arr = np.full((FULL_ROWS, umax), -1, np.int32)
+    frm_arr = np.full((FULL_ROWS, umax), -1, np.int32)
+    for b in range(FULL_ROWS):
+        ids_arr[b, :len(ids[b])] = ids[b]
+        frm_arr[b, :len(frames[b])] = frames[b]
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "parakeet_full.npz")
+    np.savez_compressed(
+        out, weights_seed=np.int64(0), audio_sha256=np.frombuffer(hashlib.sha256(audio.tobytes()).digest(), np.uint8),
+        lengths=lens, hf_n_frames=feats["attention_mask"].sum(-1).numpy().astype(np.int64),
+        hf_enc=enc_out.last_hidden_state.numpy().astype(np.float32),
+        hf_joint_enc=enc_out.pooler_output.numpy().astype(np.float32), hf_enc_lens=enc_lens.astype(np.int64),
+        hf_ids=ids_arr, hf_frames=frm_arr, hf_n_ids=np.array([len(x) for x in ids], np.int32))
+    print("wrote", out, os.path.getsize(out), "bytes; tokens per utt:", [len(x) for x in ids], "enc lens", enc_lens)
+
+
 if __name__ == "__main__":
-    if "--wide" in sys.argv:
+    if "--full" in sys.argv:
+        main_full()
+    elif "--wide" in sys.argv:
         main_wide()
     else:
         main()

@@ -58,3 +58,19 @@ def test_flip_audit_sees_flips_under_large_noise_and_none_without():
     assert s["local_flips"] > 0 and not all(eq)
     assert s["every_id_difference_starts_at_a_flip"]
     assert s["flip_margin_over_bound_max"] <= 1.0 + 1e-9
+
+
+def test_batched_audit_equals_the_per_row_walk():
+    """oracle/audit.py: flip_audit_batch (torch float64, rows in lockstep — what the GPU tests and bench.py run over all 256
+    rows of the benchmark batch) reports what the per-row numpy walk reports: decisions, margins, flips, bounds"""
+    cfg, sd, f_ref, f_hip, el = _case(noise=0.05)
+    ref, hip, audits = _audit_all(cfg, sd, f_ref, f_hip, el)
+    batch = audit.flip_audit_batch(cfg, sd, torch.from_numpy(f_ref), torch.from_numpy(f_hip), el.tolist(),
+                                   [h[0] for h in hip], [h[1] for h in hip])
+    assert sum(len(a["flips"]) for a in audits) > 0
+    for a, b in zip(audits, batch):
+        assert a["decisions"] == b["decisions"] and a["path_ok"] == b["path_ok"]
+        assert np.allclose(a["margins"], b["margins"], rtol=1e-9, atol=1e-12)
+        assert [(x["frame"], x["k_ref"], x["k_hip"]) for x in a["flips"]] == [(x["frame"], x["k_ref"], x["k_hip"]) for x in b["flips"]]
+        for x, y in zip(a["flips"], b["flips"]):
+            assert abs(x["margin_ref"] - y["margin_ref"]) < 1e-9 and abs(x["bound"] - y["bound"]) < 1e-9
