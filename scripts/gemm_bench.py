@@ -111,6 +111,25 @@ def main():
             us = ts[len(ts) // 2] * 1e3
             v = f"{v[0] or pick(m, n, k, 256, flags)}{'*' if not v[0] else ''} p{v[1]}"
             print(f"{name} M{m} N{n} K{k} tile {v}{'' if gm is None else f' gm{gm}'}{f' padA{pad_a}' if pad_a else ''}{f' padW{pad_w}' if pad_w else ''}{f' padC{pad_c}' if pad_c else ''}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
+        if "--yardstick" in sys.argv:
+            # the vendor library on the same operands, same box, same process: torch.mm -> hipBLASLt / rocBLAS, plain bf16
+            # product without any epilogue (so it does less work than the fused launches it stands next to)
+            Wt = W.t()
+            y = torch.mm(A, Wt)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(7):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(4):
+                    torch.mm(A, Wt, out=y)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / 4)
+            ts.sort()
+            us = ts[len(ts) // 2] * 1e3
+            print(f"{name} M{m} N{n} K{k} yardstick torch.mm (hipBLASLt, no epilogue): {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
+            del y
         del A, W, out, res
     setv((0, 2))
 

@@ -386,7 +386,6 @@ def test_619m_limited_context_attention_vs_oracle(full):
 # ---- ALL 256 rows: the float32 parity mode against the committed float32-oracle golden, and the throughput mode audited
 # ---- against the parity mode on every row ----------------------------------------------------------
 BENCH_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_fp32.npz")
-FULL_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parakeet_full.npz")
 TOL_F32 = 1e-4                       # encoder / joint projection of the parity mode vs the float32 oracle (measured ~2e-5)
 SETS = {"equal": dict(seed=1234), "ragged": dict(seed=1235, ragged=True, min_seconds=2.0)}
 
@@ -514,19 +513,3 @@ def test_619m_throughput_mode_flip_audit_over_all_256_rows(full, bench_batch, fp
     assert s["walk_reproduces_hip_path"] and s["every_id_difference_starts_at_a_flip"], s
     if s["local_flips"]:
         assert s["flip_margin_percentile_of_all_margins_max"] <= 50.0, s
-
-
-def test_619m_oracle_rows_match_hf_parakeet_24_layers():
-    """(runs anywhere; kept beside its consumers) the float32 oracle's joint projection of benchmark rows 0 and 1 stored in
-    bench_fp32.npz against transformers' ParakeetForRNNT with all 24 layers and the benchmark's weights
-    (tests/golden/parakeet_full.npz): the oracle path that checks the benchmark is itself anchored at full depth"""
-    if not os.path.exists(FULL_GOLD):
-        pytest.skip("parakeet_full.npz not generated")
-    gold, hf = np.load(BENCH_GOLD), np.load(FULL_GOLD)
-    g_ids, g_frames = golden_rows(gold, "equal")
-    for b in range(2):
-        n = int(hf["hf_enc_lens"][b])
-        assert n == int(gold["equal_enc_lens"][b])
-        assert np.abs(gold["equal_f_rows"][b, :n] - hf["hf_joint_enc"][b, :n]).max() <= 2e-4
-        k = int(hf["hf_n_ids"][b])
-        assert g_ids[b] == hf["hf_ids"][b, :k].tolist() and g_frames[b] == hf["hf_frames"][b, :k].tolist()

@@ -149,3 +149,46 @@ def test_wide_geometry_vs_hf(seed):
         n = int(gold[k + "hf_n_ids"][b])
         assert out[b][0] == gold[k + "hf_ids"][b, :n].tolist()
         assert out[b][1] == gold[k + "hf_frames"][b, :n].tolist()
+
+
+# ---- the 619M model itself: 24 layers, the benchmark's weights, benchmark utterances --------------------------------
+def test_full_depth_oracle_vs_hf_parakeet_24_layers():
+    """The oracle path that checks the BENCHMARK (tests/golden/bench_fp32.npz: the float32 oracle end to end on all 256 rows
+    of the benchmark batch, 619M geometry, seed-0 weights) against transformers' ParakeetForRNNT with all 24 layers and the
+    same weights on benchmark rows 0 and 1 (tests/golden/parakeet_full.npz, make_parakeet_golden.py --full): joint
+    projection within 2e-4 over the whole utterance, greedy ids and emission frames identical.  The toy and two-layer
+    fixtures above cannot see an error that only accumulates over depth; this one can."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = np.load(os.path.join(here, "golden", "bench_fp32.npz"))
+    hf = np.load(os.path.join(here, "golden", "parakeet_full.npz"))
+    off = gold["equal_offsets"]
+    worst = 0.0
+    for b in range(2):
+        n = int(hf["hf_enc_lens"][b])
+        assert n == int(gold["equal_enc_lens"][b]) == 138
+        worst = max(worst, float(np.abs(gold["equal_f_rows"][b, :n] - hf["hf_joint_enc"][b, :n]).max()))
+        k = int(hf["hf_n_ids"][b])
+        assert gold["equal_ids"][off[b]:off[b + 1]].tolist() == hf["hf_ids"][b, :k].tolist()
+        assert gold["equal_frames"][off[b]:off[b + 1]].tolist() == hf["hf_frames"][b, :k].tolist()
+    assert worst <= 2e-4, worst
+    assert int(hf["hf_n_ids"].sum()) > 100
+
+
+def test_full_depth_oracle_reproduces_its_own_golden_row():
+    """the committed golden is what the oracle computes today: row 1 of the benchmark batch re-run here (one utterance, ~3 s
+    of CPU) — joint projection bit-for-bit up to float32 reassociation across thread counts (1e-5), ids and frames identical"""
+    from reazonspeech_amd.runtime.config import FASTCONFORMER_619M
+    from reazonspeech_amd.runtime.synth import synthetic_batch
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = np.load(os.path.join(here, "golden", "bench_fp32.npz"))
+    cfg = FASTCONFORMER_619M
+    sd = synthetic_state_dict(cfg, seed=0)
+    audio, lens = synthetic_batch(256, 10.0, seed=1234)
+    b = 1
+    wav = np.pad(audio[b, :int(lens[b])], 8000)
+    f, el = om.forward_to_joint(cfg, sd, torch.from_numpy(wav)[None], torch.tensor([len(wav)]), "fp32")
+    n = int(el[0])
+    assert np.abs(f[0, :n].numpy() - gold["equal_f_rows"][b, :n]).max() <= 1e-5
+    hyp = og.rnnt_greedy(cfg, sd, f.numpy(), el.numpy())[0]
+    off = gold["equal_offsets"]
+    assert hyp[0] == gold["equal_ids"][off[b]:off[b + 1]].tolist() and hyp[1] == gold["equal_frames"][off[b]:off[b + 1]].tolist()
