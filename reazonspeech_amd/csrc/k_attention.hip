@@ -25,13 +25,24 @@
 
 namespace {
 
-constexpr int HD = 128;             // head dim (fixed)
-constexpr int KROW = 272;           // bytes per K / P row in LDS (256 + 16 pad: conflict-free b128 reads)
 constexpr int VROW = 80;            // bytes per V^T row in LDS (64 + 16 pad)
-constexpr int K_BYTES = 32 * KROW;  // 8704
-constexpr int VT_BYTES = HD * VROW; // 10240
-constexpr int SCR_BYTES = 32 * KROW;   // per-wave scratch: 32 staged P rows, later the [32 queries][68] f32 skew tile
-constexpr int SKEW_LD = 68;            // floats per query row of the skew tile (64 used): 32 * 68 * 4 = SCR_BYTES
+constexpr int SKEW_LD = 68;            // floats per query row of the skew tile (64 used)
+// Geometry per head dimension HD (128: FastConformer-XL, the shape the kernel was tuned on; 64: the ESPnet Conformer's
+// 512 / 8).  A K / P row is HD bf16 = NCH 16-byte chunks.
+template <int HD>
+struct AttnGeom {
+    static_assert(HD == 128 || HD == 64, "head_dim 128 or 64");
+    static constexpr int NCH = HD / 8;             // 16-byte chunks per row
+    static constexpr int KS = HD / 16;             // 16-deep k-steps of the S^T / BD^T products
+    static constexpr int DB = HD / 32;             // 32-row blocks of O^T
+    static constexpr int KROW = 2 * HD + 16;       // bytes per K / P row in LDS (+16 pad: conflict-free b128 reads)
+    static constexpr int K_BYTES = 32 * KROW;
+    static constexpr int VT_BYTES = HD * VROW;
+    // per-wave scratch: 32 staged P rows, later the [32 queries][68] f32 skew tile
+    static constexpr int SCR_BYTES = 32 * KROW > 32 * SKEW_LD * 4 ? 32 * KROW : 32 * SKEW_LD * 4;
+    static constexpr int RPP = 64 / NCH;           // rows one 64-lane pass of 16-byte pieces covers
+    static constexpr int VH = NCH / 8;             // wave-wide V staging items per key block
+};
 constexpr int KB_CHUNK = 5;            // key blocks staged per workgroup barrier (160 keys: all of T' = 138)
 constexpr float NEG = -1.0e30f;
 
@@ -60,8 +71,11 @@ __device__ __forceinline__ int vt_pos(int key) {
 // the K / V barrier instead of after it — bit-identical, 152.4 / 153.1 vs 151.1 / 152.4 us on one box
 // (profiles/r03w_attn_prologue_ab.txt): the microsecond moved under the loads comes back as a longer load phase.)
 // WINDOW: limited-context / global-token masks compiled in (full attention otherwise: no per-score branches)
-template <bool TRACE, bool WINDOW>
+template <int HD, bool TRACE, bool WINDOW>
 __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
+    using G = AttnGeom<HD>;
+    constexpr int NCH = G::NCH, KS = G::KS, DB = G::DB, KROW = G::KROW, K_BYTES = G::K_BYTES, VT_BYTES = G::VT_BYTES;
+    constexpr int SCR_BYTES = G::SCR_BYTES, RPP = G::RPP, VH = G::VH;
     long long ts[40];
     int nts = 0;
     // TRACE: drain the memory counters, make the newest MFMA result architecturally visible, then stamp
@@ -104,11 +118,11 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     auto stage_kv = [&](int jc, int nb) {
         // nb * 512 K items <= 8 * blockDim for every launch shape.  Named scalars, unconditional (clamped)
         // loads: an indexed array or a predicated definition is demoted to scratch memory by the compiler.
-        const int items = nb * 512;
+        const int items = nb * 32 * NCH;
         auto k_src = [&](int it) -> const uint4* {
             int idx = tid + it * (int)blockDim.x;
             idx = idx < items ? idx : items - 1;
-            const int slot = idx >> 9, key = (idx >> 4) & 31, ch = idx & 15;
+            const int slot = idx / (32 * NCH), key = (idx / NCH) & 31, ch = idx % NCH;
             int krow = (jc + slot) * 32 + key;
             krow = krow < T ? krow : T - 1;
             return reinterpret_cast<const uint4*>(base + (size_t)krow * ld + d + h * HD + ch * 8);
@@ -117,14 +131,14 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
         const uint4 kr4 = *k_src(4), kr5 = *k_src(5), kr6 = *k_src(6), kr7 = *k_src(7);
         // V work items are wave-wide: (slot, half of the 16 chunks); lane = (key group g, chunk c_lo);
         // a 16-lane store group is 8 key groups x 2 chunks (2-way bank conflict at worst)
-        constexpr int MAXV = 2;               // 2 * nb wave items over nw waves
+        constexpr int MAXV = 2;               // VH * nb wave items over nw waves
         const int g = lane & 7, c_lo = (lane >> 3) & 7;
         uint4 vreg[MAXV][4];
 #pragma unroll
         for (int it = 0; it < MAXV; ++it) {
             int wi = wave + it * nw;
-            wi = wi < 2 * nb ? wi : 2 * nb - 1;
-            const int slot = wi >> 1, ch = (wi & 1) * 8 + c_lo;
+            wi = wi < VH * nb ? wi : VH * nb - 1;
+            const int slot = wi / VH, ch = (wi % VH) * 8 + c_lo;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 int krow = (jc + slot) * 32 + 4 * g + a;
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
         auto k_put = [&](int it, const uint4& v) {
             const int idx = tid + it * (int)blockDim.x;
             if (idx < items) {
-                const int slot = idx >> 9, key = (idx >> 4) & 31, ch = idx & 15;
+                const int slot = idx / (32 * NCH), key = (idx / NCH) & 31, ch = idx % NCH;
                 *reinterpret_cast<uint4*>(Ks + slot * K_BYTES + key * KROW + ch * 16) = v;
             }
         };
@@ -144,8 +158,8 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
 #pragma unroll
         for (int it = 0; it < MAXV; ++it) {
             const int wi = wave + it * nw;
-            if (wi < 2 * nb) {
-                const int slot = wi >> 1, ch = (wi & 1) * 8 + c_lo;
+            if (wi < VH * nb) {
+                const int slot = wi / VH, ch = (wi % VH) * 8 + c_lo;
                 const int pos0 = vt_pos(4 * g);           // keys 4g .. 4g+3 sit at positions pos0 .. pos0+3
                 char* dst = Vts + slot * VT_BYTES + (ch * 8) * VROW + ((((pos0 >> 3) ^ (ch & 3)) << 4) + (pos0 & 7) * 2);
                 const unsigned k0[4] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w};
@@ -170,21 +184,21 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     // per lane, identical across the wave, and held the prologue for ~3 us.
     const int qrow = qi < T ? qi : T - 1;
     const uint16_t* qp = base + (size_t)qrow * ld + h * HD;
-    u16x8_t raw[8];
+    u16x8_t raw[KS];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) raw[ks] = *reinterpret_cast<const u16x8_t*>(qp + 8 * (2 * ks + hh));
-    if (wave == 0)
+    for (int ks = 0; ks < KS; ++ks) raw[ks] = *reinterpret_cast<const u16x8_t*>(qp + 8 * (2 * ks + hh));
+    if (wave == 0 && 4 * lane < 2 * HD)                  // bias_s = [u(HD) | v(HD)]
         *reinterpret_cast<float4*>(bias_s + 4 * lane) =
-            *reinterpret_cast<const float4*>((lane < 32 ? p.bias_u : p.bias_v - HD) + h * HD + 4 * lane);
+            *reinterpret_cast<const float4*>((4 * lane < HD ? p.bias_u : p.bias_v - HD) + h * HD + 4 * lane);
     stage_kv(0, n_kblocks < KB_CHUNK ? n_kblocks : KB_CHUNK);
     stamp(0.0f);                                   // [1] own K/V stores issued and landed
     __syncthreads();
     stamp(0.0f);                                   // [2] workgroup barrier passed
 
     // ---- Q fragments (+u, +v), rounded to bf16: B operand, lane = (query il, k-chunk hh)
-    bf16x8_t qu[8], qv[8];
+    bf16x8_t qu[KS], qv[KS];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         const int c = 8 * (2 * ks + hh);
         float bu[8], bvv[8];
         *reinterpret_cast<float4*>(&bu[0]) = *reinterpret_cast<const float4*>(bias_s + c);
@@ -202,9 +216,9 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
         qv[ks] = __builtin_bit_cast(bf16x8_t, bq);
     }
 
-    f32x16_t o[4];
+    f32x16_t o[DB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[i][e] = 0.0f;
     float m_run = NEG, l_run = 0.0f;
@@ -217,19 +231,25 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     //      (coalesced 256-byte row reads from L2 -> LDS rows of 272 B -> conflict-free fragment reads)
     auto bd_block = [&](int nrow0) -> f32x16_t {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {   // two passes of 4 rows-of-4: 16 staging VGPRs, not 32
+        for (int half = 0; half < 2; ++half) {   // two passes of 16 rows (HD 128: 4 rows-of-4, 16 staging VGPRs, not 32)
             // (named scalars: a uint4 array here is demoted to scratch memory, with dead stores in the loop)
             auto p_src = [&](int q) -> const uint4* {
-                int n = nrow0 + 4 * (4 * half + q) + (lane >> 4);
+                int n = nrow0 + 16 * half + RPP * q + lane / NCH;
                 n = n < 0 ? 0 : (n >= n_pos ? n_pos - 1 : n);
-                return reinterpret_cast<const uint4*>(pos_h + (size_t)n * d + (lane & 15) * 8);
+                return reinterpret_cast<const uint4*>(pos_h + (size_t)n * d + (lane % NCH) * 8);
             };
-            const uint4 p0 = *p_src(0), p1 = *p_src(1), p2 = *p_src(2), p3 = *p_src(3);
-            char* dst = scr + (16 * half + (lane >> 4)) * KROW + (lane & 15) * 16;
-            *reinterpret_cast<uint4*>(dst) = p0;
-            *reinterpret_cast<uint4*>(dst + 4 * KROW) = p1;
-            *reinterpret_cast<uint4*>(dst + 8 * KROW) = p2;
-            *reinterpret_cast<uint4*>(dst + 12 * KROW) = p3;
+            char* dst = scr + (16 * half + lane / NCH) * KROW + (lane % NCH) * 16;
+            if constexpr (RPP == 4) {
+                const uint4 p0 = *p_src(0), p1 = *p_src(1), p2 = *p_src(2), p3 = *p_src(3);
+                *reinterpret_cast<uint4*>(dst) = p0;
+                *reinterpret_cast<uint4*>(dst + 4 * KROW) = p1;
+                *reinterpret_cast<uint4*>(dst + 8 * KROW) = p2;
+                *reinterpret_cast<uint4*>(dst + 12 * KROW) = p3;
+            } else {
+                const uint4 p0 = *p_src(0), p1 = *p_src(1);
+                *reinterpret_cast<uint4*>(dst) = p0;
+                *reinterpret_cast<uint4*>(dst + 8 * KROW) = p1;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(scr + il * KROW + (2 * ks + hh) * 16);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qv[ks], acc, 0, 0, 0);
         }
@@ -285,8 +305,8 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
             __syncthreads();                  // previous chunk fully consumed
             // later chunks (T' > 160 only) restage with everything live: one item at a time, 8 staging VGPRs
 #pragma unroll 1
-            for (int idx = tid; idx < nb * 512; idx += blockDim.x) {
-                const int slot = idx >> 9, key = (idx >> 4) & 31, ch = idx & 15;
+            for (int idx = tid; idx < nb * 32 * NCH; idx += blockDim.x) {
+                const int slot = idx / (32 * NCH), key = (idx / NCH) & 31, ch = idx % NCH;
                 int krow = (jc + slot) * 32 + key;
                 krow = krow < T ? krow : T - 1;
                 const uint16_t* kp = base + (size_t)krow * ld + d + h * HD + ch * 8;
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = 0.0f;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks_t + il * KROW + (2 * ks + hh) * 16);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[ks], s, 0, 0, 0);
             }
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < DB; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
             stamp(o[0][0]);                        // [8+5k] softmax update
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
                 pf[sidx] = __builtin_bit_cast(bf16x8_t, t);
             }
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
+            for (int db = 0; db < DB; ++db) {
                 const int drow = db * 32 + il;
 #pragma unroll
                 for (int sidx = 0; sidx < 2; ++sidx) {
@@ -416,7 +436,7 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     {
         const float inv = (q_valid && l_run > 0.0f) ? 1.0f / l_run : 0.0f;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<u16x4_t*>(scr + il * KROW + (db * 32 + 8 * g + 4 * hh) * 2) =
@@ -424,11 +444,11 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int row = 4 * q + (lane >> 4);
-            const uint4 v = *reinterpret_cast<const uint4*>(scr + row * KROW + (lane & 15) * 16);
+        for (int q = 0; q < 32 / RPP; ++q) {
+            const int row = RPP * q + lane / NCH;
+            const uint4 v = *reinterpret_cast<const uint4*>(scr + row * KROW + (lane % NCH) * 16);
             if (i0 + row < T)
-                *reinterpret_cast<uint4*>(p.out + ((size_t)b * T + i0 + row) * d + h * HD + (lane & 15) * 8) = v;
+                *reinterpret_cast<uint4*>(p.out + ((size_t)b * T + i0 + row) * d + h * HD + (lane % NCH) * 8) = v;
         }
     }
     if constexpr (TRACE) {
@@ -447,37 +467,52 @@ long long* g_attn_trace = nullptr;
 // debug hook (scripts/attn_trace.py): buffer of 40 int64 per workgroup, or nullptr to switch tracing off
 extern "C" void rs_debug_set_attn_trace(long long* buf) { g_attn_trace = buf; }
 
+namespace {
+
+template <int HD>
+int launch_attention_hd(rs_ctx* ctx, AttnParams& p, int B, int T, hipStream_t s) {
+    using G = AttnGeom<HD>;
+    const rs_dims& dm = ctx->d;
+    p.scale = 1.0f / sqrtf((float)HD);
+    const int qblocks = (T + 31) / 32;
+    // at most 6 query blocks per workgroup (HD 128: 5 * (8704 + 10240) + 6 * 8704 = 147 KB of the 160 KB LDS)
+    const int nw = qblocks < 6 ? qblocks : 6;
+    const dim3 grid((qblocks + nw - 1) / nw, dm.n_heads, B), block(64 * nw);
+    const size_t lds = (size_t)KB_CHUNK * (G::K_BYTES + G::VT_BYTES) + (size_t)nw * G::SCR_BYTES + 2 * HD * sizeof(float);
+    {
+        constexpr int MAX_LDS = KB_CHUNK * (G::K_BYTES + G::VT_BYTES) + 6 * G::SCR_BYTES + 2 * HD * (int)sizeof(float);
+        int rc = rs_ensure_dynamic_lds(ctx, (const void*)relpos_attention_kernel<HD, false, false>, MAX_LDS);
+        if (rc == RS_OK) rc = rs_ensure_dynamic_lds(ctx, (const void*)relpos_attention_kernel<HD, false, true>, MAX_LDS);
+        if constexpr (HD == 128)
+            if (rc == RS_OK) rc = rs_ensure_dynamic_lds(ctx, (const void*)relpos_attention_kernel<HD, true, false>, MAX_LDS);
+        if (rc != RS_OK) return rc;
+    }
+    // algorithmic: ac + bd + pv = 3 * 2*T*T*HD per (b,h)
+    const double flops = (double)B * dm.n_heads * 3.0 * 2.0 * T * (double)T * HD;
+    const double bytes = (double)B * T * dm.d_model * 2.0 * 4.0;
+    rs_prof_begin(ctx, RS_PROF_ATTN, s, flops, bytes);
+    p.trace = HD == 128 ? g_attn_trace : nullptr;
+    const bool window = p.att_left >= 0 || p.att_right >= 0;
+    if (window) hipLaunchKernelGGL((relpos_attention_kernel<HD, false, true>), grid, block, lds, s, p);
+    else if (p.trace) {
+        if constexpr (HD == 128) hipLaunchKernelGGL((relpos_attention_kernel<HD, true, false>), grid, block, lds, s, p);
+    } else hipLaunchKernelGGL((relpos_attention_kernel<HD, false, false>), grid, block, lds, s, p);
+    rs_prof_end(ctx, RS_PROF_ATTN, s);
+    RS_CHECK_LAUNCH(ctx, "relpos_attention");
+    return RS_OK;
+}
+
+}  // namespace
+
 int rs_launch_attention(rs_ctx* ctx, const uint16_t* qkv, const uint16_t* pos, const float* bias_u,
                         const float* bias_v, const int32_t* lens, int B, int T, uint16_t* out, hipStream_t s) {
     if (B <= 0 || T <= 0) return RS_OK;
     const rs_dims& dm = ctx->d;
-    if (dm.d_model / dm.n_heads != HD) return rs_fail(ctx, RS_EINVAL, "attention: head_dim must be %d", HD);
+    const int hd = dm.n_heads > 0 ? dm.d_model / dm.n_heads : 0;
     AttnParams p;
     p.qkv = qkv; p.pos = pos; p.bias_u = bias_u; p.bias_v = bias_v; p.lens = lens; p.out = out;
     p.T = T; p.d_model = dm.d_model; p.att_left = dm.att_left; p.att_right = dm.att_right; p.n_global = dm.n_global;
-    p.scale = 1.0f / sqrtf((float)HD);
-    const int qblocks = (T + 31) / 32;
-    // at most 6 query blocks per workgroup: 5 * (8704 + 10240) + 6 * 8704 = 147 KB of the 160 KB LDS
-    const int nw = qblocks < 6 ? qblocks : 6;
-    const dim3 grid((qblocks + nw - 1) / nw, dm.n_heads, B), block(64 * nw);
-    const size_t lds = (size_t)KB_CHUNK * (K_BYTES + VT_BYTES) + (size_t)nw * SCR_BYTES + 2 * HD * sizeof(float);
-    {
-        constexpr int MAX_LDS = KB_CHUNK * (K_BYTES + VT_BYTES) + 6 * SCR_BYTES + 2 * HD * (int)sizeof(float);
-        int rc = rs_ensure_dynamic_lds(ctx, (const void*)relpos_attention_kernel<false, false>, MAX_LDS);
-        if (rc == RS_OK) rc = rs_ensure_dynamic_lds(ctx, (const void*)relpos_attention_kernel<false, true>, MAX_LDS);
-        if (rc == RS_OK) rc = rs_ensure_dynamic_lds(ctx, (const void*)relpos_attention_kernel<true, false>, MAX_LDS);
-        if (rc != RS_OK) return rc;
-    }
-    // algorithmic: ac + bd + pv = 3 * 2*T*T*128 per (b,h)
-    const double flops = (double)B * dm.n_heads * 3.0 * 2.0 * T * (double)T * HD;
-    const double bytes = (double)B * T * dm.d_model * 2.0 * 4.0;
-    rs_prof_begin(ctx, RS_PROF_ATTN, s, flops, bytes);
-    p.trace = g_attn_trace;
-    const bool window = p.att_left >= 0 || p.att_right >= 0;
-    if (window) hipLaunchKernelGGL((relpos_attention_kernel<false, true>), grid, block, lds, s, p);
-    else if (p.trace) hipLaunchKernelGGL((relpos_attention_kernel<true, false>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((relpos_attention_kernel<false, false>), grid, block, lds, s, p);
-    rs_prof_end(ctx, RS_PROF_ATTN, s);
-    RS_CHECK_LAUNCH(ctx, "relpos_attention");
-    return RS_OK;
+    if (hd == 128) return launch_attention_hd<128>(ctx, p, B, T, s);
+    if (hd == 64) return launch_attention_hd<64>(ctx, p, B, T, s);
+    return rs_fail(ctx, RS_EINVAL, "attention: head_dim %d (128 or 64 are built)", hd);
 }

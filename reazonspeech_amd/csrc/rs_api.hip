@@ -89,14 +89,14 @@ int rs_create(rs_ctx** out, int device, const rs_dims* dims) {
     ctx->d = *dims;
     const rs_dims& d = ctx->d;
     int rc = RS_OK;
-    if (d.n_heads <= 0 || d.d_model % d.n_heads || d.d_model / d.n_heads != 128)
-        rc = rs_fail(ctx, RS_EINVAL, "head_dim must be 128 (d_model %d, heads %d)", d.d_model, d.n_heads);
+    if (d.n_heads <= 0 || d.d_model % d.n_heads || (d.d_model / d.n_heads != 128 && d.d_model / d.n_heads != 64))
+        rc = rs_fail(ctx, RS_EINVAL, "head_dim must be 128 or 64 (d_model %d, heads %d)", d.d_model, d.n_heads);
     else if (d.d_model % 256 || d.ff_dim % 64) rc = rs_fail(ctx, RS_EINVAL, "d_model %% 256, ff_dim %% 64 required");
     else if (d.sub_stages < 2 || d.sub_stages > 4) rc = rs_fail(ctx, RS_EINVAL, "2..4 subsampling stages supported");
     else if (d.n_layers < 1) rc = rs_fail(ctx, RS_EINVAL, "n_layers");
     else if (d.pred_layers < 1 || d.pred_layers > 4) rc = rs_fail(ctx, RS_EINVAL, "pred_layers");
     if (rc != RS_OK) { *out = ctx; return rc; }  // caller can read rs_last_error, then rs_destroy
-    ctx->head_dim = 128;
+    ctx->head_dim = d.d_model / d.n_heads;
     int f = d.n_mels;
     for (int s = 0; s < d.sub_stages; ++s) f = (f + 2 - 3) / 2 + 1;
     ctx->sub_freq = f;

@@ -113,7 +113,7 @@ class ModelConfig:
         return replace(self, **kw)
 
     def validate(self):
-        assert self.head_dim == 128, "attention kernel is built for head_dim 128"
+        assert self.head_dim in (128, 64), "the attention kernel is built for head_dim 128 and 64"
         assert self.d_model % 64 == 0 and self.ff_dim % 64 == 0
         assert self.sub_channels % 64 == 0
         assert self.pred_hidden % 128 == 0 and self.joint_hidden % 128 == 0   # K slices of k_rnnt.hip

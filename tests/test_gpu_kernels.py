@@ -410,8 +410,13 @@ def test_glu_dwconv_silu(ctx, gpu_device, T, lens):
                                            # and without global tokens, asymmetric windows, a window wider than a chunk
                                            (1400, [1400, 777], (128, 128, 1)), (1000, [1000, 333], (40, 200, 0)),
                                            (900, [900, 650], (0, 0, 3)), (700, [700, 512], (300, 17, 0))])
-def test_relpos_attention(gpu_device, T, lens, window):
-    cfg = TINY if window is None else TINY.with_(att_left=window[0], att_right=window[1], n_global=window[2])
+@pytest.mark.parametrize("heads", [2, 4])
+def test_relpos_attention(gpu_device, T, lens, window, heads):
+    """heads = 2: head_dim 128 (FastConformer-XL), heads = 4: head_dim 64 (the ESPnet Conformer's 512 / 8) — one kernel
+    template, two geometries"""
+    cfg = TINY.with_(n_heads=heads)
+    if window is not None:
+        cfg = cfg.with_(att_left=window[0], att_right=window[1], n_global=window[2])
     c = capi.Context(cfg, 0)
     g = torch.Generator().manual_seed(T + len(lens))
     B, H, dh, d = len(lens), cfg.n_heads, cfg.head_dim, cfg.d_model
@@ -437,4 +442,4 @@ def test_relpos_attention(gpu_device, T, lens, window):
 
 def test_rejects_wrong_head_dim(gpu_device):
     with pytest.raises(capi.RsError):
-        capi.Context(TINY.with_(n_heads=4), 0)
+        capi.Context(TINY.with_(n_heads=8), 0)            # head_dim 32: 128 and 64 are built
