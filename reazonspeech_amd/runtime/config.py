@@ -48,6 +48,13 @@ class ModelConfig:
     beam_size: int = 4                   # decoding.beam.beam_size (1..8 on the device)
     alsd_max_target_len: float = 2.0     # decoding.beam.alsd_max_target_len: float = multiple of T', int = absolute label budget
     beam_score_norm: bool = True         # decoding.beam.score_norm: rank finished hypotheses by score / len(y_sequence)
+    # --- model family: "nemo" = FastConformer-RNNT (everything above as NeMo defines it); "espnet" = the ESPnet2
+    #     Conformer-Transducer of reazonspeech.espnet.asr (pkg/espnet-asr/src/transcribe.py:12-32).  [UPSTREAM] ESPnet differences,
+    #     each a switch of the same kernels: DefaultFrontend (periodic Hann over win_length, reflect edge padding, 1 + L // hop
+    #     frames, log(max(x, 1e-10)), global mean / variance normalisation), Conv2dSubsampling x4 (two dense 3x3 stride-2 convs
+    #     without padding, d_model channels), LayerNorm eps 1e-12, a LayerNorm after the last block, tanh joint without a
+    #     decoder-side bias, blank = token 0 (vocab_size counts every token), one symbol per frame in greedy search, a CTC head.
+    family: str = "nemo"
 
     # ---- derived ----
     @property
@@ -55,12 +62,16 @@ class ModelConfig:
         return self.d_model // self.n_heads
 
     @property
+    def espnet(self) -> bool:
+        return self.family == "espnet"
+
+    @property
     def blank_id(self) -> int:
-        return self.vocab_size
+        return 0 if self.espnet else self.vocab_size
 
     @property
     def n_logits(self) -> int:
-        return self.vocab_size + 1
+        return self.vocab_size if self.espnet else self.vocab_size + 1
 
     @property
     def n_sub_stages(self) -> int:
@@ -68,24 +79,27 @@ class ModelConfig:
 
     @property
     def sub_freq(self) -> int:
-        """mel bins left after the strided convs (80 -> 40 -> 20 -> 10)."""
+        """mel bins left after the strided convs (NeMo: 80 -> 40 -> 20 -> 10; ESPnet: 80 -> 39 -> 19)."""
         f = self.n_mels
         for _ in range(self.n_sub_stages):
-            f = (f + 2 - 3) // 2 + 1
+            f = self.conv_out_len(f)
         return f
 
     def mel_frames(self, n_samples: int) -> int:
         """valid log-mel frames for `n_samples` samples: floor(L / hop)
-        ([UPSTREAM] FilterbankFeatures.get_seq_len with center=True)."""
+        ([UPSTREAM] FilterbankFeatures.get_seq_len with center=True); ESPnet's Stft keeps all 1 + floor(L / hop) frames."""
+        if self.espnet:
+            return 1 + n_samples // self.hop_length
         return (n_samples + (self.n_fft // 2) * 2 - self.n_fft) // self.hop_length
 
     def stft_frames(self, n_samples: int) -> int:
         """frames torch.stft(center=True) produces: 1 + floor(L / hop)."""
         return 1 + n_samples // self.hop_length
 
-    @staticmethod
-    def conv_out_len(n: int) -> int:
-        """k=3, s=2, p=1 output length."""
+    def conv_out_len(self, n: int) -> int:
+        """output length of one subsampling conv: k=3, s=2 with p=1 (NeMo dw_striding) or p=0 (ESPnet Conv2dSubsampling)."""
+        if self.espnet:
+            return (n - 3) // 2 + 1 if n >= 3 else 0
         return (n + 2 - 3) // 2 + 1
 
     def enc_frames(self, n_mel_frames: int) -> int:
@@ -95,6 +109,8 @@ class ModelConfig:
         return n
 
     def n_params(self) -> int:
+        if self.espnet:
+            return self._n_params_espnet()
         d, f, c = self.d_model, self.ff_dim, self.sub_channels
         sub = (c * 9 + c) + (self.n_sub_stages - 1) * ((c * 9 + c) + (c * c + c)) \
             + (c * self.sub_freq * d + d)
@@ -105,6 +121,16 @@ class ModelConfig:
         joint = (h * self.joint_hidden + self.joint_hidden) + (d * self.joint_hidden + self.joint_hidden) \
             + (self.joint_hidden * self.n_logits + self.n_logits)
         return sub + self.n_layers * layer + pred + joint
+
+    def _n_params_espnet(self) -> int:
+        """[UPSTREAM] ESPnet2 ESPnetASRModel with a ConformerEncoder (Conv2dSubsampling), CTC, TransducerDecoder, JointNetwork"""
+        d, f, k, V, H, J = self.d_model, self.ff_dim, self.conv_kernel, self.vocab_size, self.pred_hidden, self.joint_hidden
+        embed = (d * 9 + d) + (d * d * 9 + d) + (d * self.sub_freq * d + d)
+        layer = 2 * (d * f + f + f * d + d) + 4 * (d * d + d) + d * d + 2 * d \
+            + (2 * d * d + 2 * d) + (d * k + d) + 2 * d + (d * d + d) + 5 * 2 * d
+        dec = V * H + self.pred_layers * (4 * H * H * 2 + 8 * H)
+        joint = (d * J + J) + H * J + (J * V + V)
+        return embed + self.n_layers * layer + 2 * d + (d * V + V) + dec + joint
 
     def to_dict(self):
         return asdict(self)
@@ -118,6 +144,10 @@ class ModelConfig:
         assert self.sub_channels % 64 == 0
         assert self.pred_hidden % 128 == 0 and self.joint_hidden % 128 == 0   # K slices of k_rnnt.hip
         assert self.pred_hidden == self.joint_hidden or True
+        assert self.family in ("nemo", "espnet"), f"model family {self.family!r}"
+        if self.espnet:
+            assert self.sub_factor == 4 and self.sub_channels == self.d_model, "ESPnet Conv2dSubsampling: x4, d_model channels"
+            assert self.decoding in ("greedy", "greedy_batch"), "the ESPnet path decodes greedily on the device"
         assert self.conv_kernel % 2 == 1 and self.conv_kernel <= 31
         assert self.n_fft == 512 and self.win_length <= 512
         assert self.decoding in ("greedy", "greedy_batch", "alsd"), f"decoding strategy {self.decoding!r}"
@@ -138,6 +168,21 @@ TINY = ModelConfig(d_model=256, n_heads=2, ff_dim=512, n_layers=2, sub_channels=
 # layers: every kernel instantiation and tile path of the benchmark configuration at a size the CPU oracle
 # and the HF golden generator finish in seconds (tests/golden/parakeet_wide.npz)
 WIDE2 = ModelConfig(n_layers=2)
+
+# reazonspeech.espnet.asr: "Conformer-Transducer ... 120M parameters" (README.rst:37-40).  The architecture itself lives in
+# the config.yaml of an unreachable Hugging Face repository (pkg/espnet-asr/src/transcribe.py:27-31): [UPSTREAM] this is the
+# ESPnet2 conformer recipe shape (512 / 8 heads / 2048 / kernel 31, DefaultFrontend 512 / 128) with the depth and
+# vocabulary that give 120M parameters; every number is a field a real config overrides.
+ESPNET_CONFORMER_120M = ModelConfig(
+    family="espnet", win_length=512, hop_length=128, preemph=0.0, log_guard=1e-10, norm_eps=1e-20,
+    d_model=512, n_heads=8, ff_dim=2048, n_layers=17, conv_kernel=31, sub_channels=512, sub_factor=4, xscaling=True,
+    ln_eps=1e-12, vocab_size=2600, pred_hidden=512, pred_layers=1, joint_hidden=640, max_symbols=1)
+
+# its toy shape for CPU oracle runs
+ESPNET_TINY = ModelConfig(
+    family="espnet", win_length=512, hop_length=128, preemph=0.0, log_guard=1e-10, norm_eps=1e-20,
+    d_model=256, n_heads=4, ff_dim=512, n_layers=2, conv_kernel=15, sub_channels=256, sub_factor=4, xscaling=True,
+    ln_eps=1e-12, vocab_size=96, pred_hidden=128, pred_layers=1, joint_hidden=128, max_symbols=1)
 
 
 class UnsupportedCheckpoint(ValueError):

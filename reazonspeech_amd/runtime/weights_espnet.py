@@ -1,0 +1,207 @@
+"""Weights of the ESPnet2 Conformer-Transducer (`reazonspeech.espnet.asr`): seeded synthetic generator with ESPnet's
+state-dict key names, and the host-side re-layout into what librs_asr.so consumes.
+
+The reference loads `Speech2Text.from_pretrained("https://huggingface.co/reazon-research/reazonspeech-espnet-v2", lm_weight=0)`
+(pkg/espnet-asr/src/transcribe.py:26-32): an ESPnet2 `ESPnetASRModel` (config.yaml + a .pth state dict).  Neither ESPnet nor
+the checkpoint is reachable here, so every key name below is [UPSTREAM] ESPnet2 (espnet2/asr/encoder/conformer_encoder.py,
+espnet/nets/pytorch_backend/conformer/{encoder_layer,convolution}.py, .../transformer/{subsampling,attention,embedding}.py,
+espnet2/asr/decoder/transducer_decoder.py, espnet2/asr/transducer/joint_network.py, espnet2/asr/ctc.py,
+espnet2/layers/{stft,log_mel,global_mvn}.py) as of ESPnet 202x; `prepare_weights_espnet` refuses a state dict with leftovers.
+"""
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+
+from .config import ModelConfig, UnsupportedCheckpoint
+from .weights import (BRANCH_GAIN, _randn, _seed_for, banded_filterbank, fft_twiddles, glu_interleave_index, rel_pos_table,
+                      slaney_mel_filterbank, to_fragment_major, DEFAULT_POS_CAP)
+
+
+def synthetic_state_dict_espnet(cfg: ModelConfig, seed: int = 0, blank_bias: float = None) -> Dict[str, torch.Tensor]:
+    """Seeded random weights under ESPnet2's keys and shapes (the recipe of `synthetic_state_dict`: 1/sqrt(fan_in) linears,
+    small residual-branch gains, a blank-logit offset so greedy emits a realistic number of tokens)."""
+    assert cfg.espnet
+    cfg.validate()
+    sd: Dict[str, torch.Tensor] = {}
+    d, f, H, J, V, k = cfg.d_model, cfg.ff_dim, cfg.pred_hidden, cfg.joint_hidden, cfg.vocab_size, cfg.conv_kernel
+
+    def lin(name, out_f, in_f, bias=True, gain=1.0):
+        sd[name + ".weight"] = _randn(name + ".weight", seed, (out_f, in_f), gain / math.sqrt(in_f))
+        if bias:
+            sd[name + ".bias"] = _randn(name + ".bias", seed, (out_f,), 0.05)
+
+    def norm(name, n):
+        sd[name + ".weight"] = 1.0 + _randn(name + ".weight", seed, (n,), 0.05)
+        sd[name + ".bias"] = _randn(name + ".bias", seed, (n,), 0.05)
+
+    # front-end buffers: LogMel.melmat [n_freq, n_mels] (librosa Slaney filters, transposed), GlobalMVN mean / std
+    sd["frontend.logmel.melmat"] = torch.from_numpy(slaney_mel_filterbank(cfg)).t().contiguous()
+    sd["normalize.mean"] = -9.0 + _randn("normalize.mean", seed, (cfg.n_mels,), 1.0)       # log-mel of speech sits around -9
+    sd["normalize.std"] = 3.0 + _randn("normalize.std", seed, (cfg.n_mels,), 0.2).abs()
+
+    E = "encoder.embed."
+    sd[E + "conv.0.weight"] = _randn(E + "conv.0.weight", seed, (d, 1, 3, 3), 1.0 / 3.0)
+    sd[E + "conv.0.bias"] = _randn(E + "conv.0.bias", seed, (d,), 0.05)
+    sd[E + "conv.2.weight"] = _randn(E + "conv.2.weight", seed, (d, d, 3, 3), 1.4 / math.sqrt(9 * d))
+    sd[E + "conv.2.bias"] = _randn(E + "conv.2.bias", seed, (d,), 0.05)
+    lin(E + "out.0", d, d * cfg.sub_freq)
+
+    for i in range(cfg.n_layers):
+        L = f"encoder.encoders.{i}."
+        for ff in ("feed_forward_macaron", "feed_forward"):
+            lin(L + ff + ".w_1", f, d)
+            lin(L + ff + ".w_2", d, f, gain=BRANCH_GAIN)
+        for nm in ("norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff", "norm_final"):
+            norm(L + nm, d)
+        for nm in ("linear_q", "linear_k", "linear_v", "linear_out"):
+            lin(L + "self_attn." + nm, d, d, gain=(2.0 if nm in ("linear_q", "linear_k") else BRANCH_GAIN if nm == "linear_out" else 1.0))
+        lin(L + "self_attn.linear_pos", d, d, bias=False)
+        sd[L + "self_attn.pos_bias_u"] = _randn(L + "pos_bias_u", seed, (cfg.n_heads, cfg.head_dim), 0.1)
+        sd[L + "self_attn.pos_bias_v"] = _randn(L + "pos_bias_v", seed, (cfg.n_heads, cfg.head_dim), 0.1)
+        C = L + "conv_module."
+        sd[C + "pointwise_conv1.weight"] = _randn(C + "pw1.w", seed, (2 * d, d, 1), 1.0 / math.sqrt(d))
+        sd[C + "pointwise_conv1.bias"] = _randn(C + "pw1.b", seed, (2 * d,), 0.05)
+        sd[C + "depthwise_conv.weight"] = _randn(C + "dw.w", seed, (d, 1, k), 1.0 / math.sqrt(k))
+        sd[C + "depthwise_conv.bias"] = _randn(C + "dw.b", seed, (d,), 0.05)
+        sd[C + "norm.weight"] = 1.0 + _randn(C + "bn.w", seed, (d,), 0.05)
+        sd[C + "norm.bias"] = _randn(C + "bn.b", seed, (d,), 0.05)
+        sd[C + "norm.running_mean"] = _randn(C + "bn.m", seed, (d,), 0.05)
+        sd[C + "norm.running_var"] = 1.0 + 0.1 * torch.rand((d,), generator=torch.Generator().manual_seed(_seed_for(C + "bn.v", seed)))
+        sd[C + "norm.num_batches_tracked"] = torch.tensor(1, dtype=torch.int64)
+        sd[C + "pointwise_conv2.weight"] = _randn(C + "pw2.w", seed, (d, d, 1), BRANCH_GAIN / math.sqrt(d))
+        sd[C + "pointwise_conv2.bias"] = _randn(C + "pw2.b", seed, (d,), 0.05)
+    norm("encoder.after_norm", d)
+    lin("ctc.ctc_lo", V, d, gain=2.0)
+    emb = _randn("decoder.embed.weight", seed, (V, H), 1.0)
+    emb[cfg.blank_id].zero_()                                     # Embedding(padding_idx=blank)
+    sd["decoder.embed.weight"] = emb
+    for l in range(cfg.pred_layers):
+        P = f"decoder.decoder.{l}."
+        sd[P + "weight_ih_l0"] = _randn(P + "weight_ih_l0", seed, (4 * H, H), 1.0 / math.sqrt(H))
+        sd[P + "weight_hh_l0"] = _randn(P + "weight_hh_l0", seed, (4 * H, H), 1.0 / math.sqrt(H))
+        sd[P + "bias_ih_l0"] = _randn(P + "bias_ih_l0", seed, (4 * H,), 0.05)
+        sd[P + "bias_hh_l0"] = _randn(P + "bias_hh_l0", seed, (4 * H,), 0.05)
+    lin("joint_network.lin_enc", J, d)
+    lin("joint_network.lin_dec", J, H, bias=False)
+    lin("joint_network.lin_out", V, J, gain=6.0)                  # tanh keeps |a| <= 1: a larger output gain spreads the logits
+    if blank_bias is None:
+        # scanned with the CPU oracle (oracle/espnet.py greedy): ~70 tokens per 10 s utterance (358 frames) at the 120M shape
+        blank_bias = {(512, 17, 2600): 15.5, (256, 2, 96): 9.0}.get((cfg.d_model, cfg.n_layers, cfg.vocab_size), 10.0)
+    sd["joint_network.lin_out.bias"][cfg.blank_id] += float(blank_bias)
+    # a CTC head whose blank posterior exceeds find_blank's 0.98 threshold (pkg/espnet-asr/src/ctc.py:29) on roughly half
+    # of the frames, so that the 20 s windowing has gaps to cut at
+    sd["ctc.ctc_lo.bias"][cfg.blank_id] += {(512, 17, 2600): 13.0, (256, 2, 96): 8.5}.get((cfg.d_model, cfg.n_layers, cfg.vocab_size), 10.0)
+    return sd
+
+
+def hann_periodic(n: int) -> np.ndarray:
+    """torch.hann_window(n) (periodic=True), what ESPnet's Stft builds for window='hann'"""
+    return torch.hann_window(n, periodic=True, dtype=torch.float32).numpy()
+
+
+def prepare_weights_espnet(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int = DEFAULT_POS_CAP, f32: bool = False):
+    """-> dict name -> CPU tensor as registered with rs_set_tensor for an `family="espnet"` context.  The conformer blocks
+    take the names and layouts of the NeMo path (`prepare_weights`): ESPnet's block is the same arithmetic with
+    feed_forward_macaron / feed_forward for feed_forward1 / feed_forward2.  What is new:
+      * "sub.conv0.*": Conv2d(1, C, 3, 2) tap-major; "sub.conv1.w": Conv2d(C, C, 3, 2) as the bf16 [C][9*C] matrix of the
+        implicit GEMM, K ordered (kernel row, kernel column, input channel) like the channels-last patches the gather kernel
+        lays out; "sub.out.w" columns permuted from (c, f) to (f, c);
+      * "fe.mvn_mean" / "fe.mvn_istd": GlobalMVN; "fe.window": periodic Hann over win_length;
+      * "final_norm.*" (encoder.after_norm), "ctc.w" / "ctc.b" (ctc.ctc_lo);
+      * joint: lin_enc -> "joint.enc.*", lin_dec (no bias) -> "joint.pred.*" with a zero bias, lin_out -> "joint.out.*".
+    """
+    if f32:
+        raise UnsupportedCheckpoint("the float32 parity mode is built for the NeMo family only")
+    assert cfg.espnet
+    out = {}
+    used = set()
+    bf = lambda t: t.detach().to(torch.float32).to(torch.bfloat16).contiguous()   # noqa: E731
+    f32t = lambda t: t.detach().to(torch.float32).contiguous()                     # noqa: E731
+
+    def get(key):
+        if key not in sd:
+            raise UnsupportedCheckpoint(f"checkpoint has no tensor {key!r} (architecture differs from the configuration?)")
+        used.add(key)
+        return sd[key]
+
+    d, C = cfg.d_model, cfg.sub_channels
+    fb = get("frontend.logmel.melmat").to(torch.float32).t().contiguous().numpy()          # [n_mels][n_freq]
+    if fb.shape != (cfg.n_mels, cfg.n_fft // 2 + 1):
+        raise UnsupportedCheckpoint(f"frontend.logmel.melmat has shape {tuple(fb.shape[::-1])}")
+    idx, w = banded_filterbank(fb)
+    out["fe.window"] = torch.from_numpy(hann_periodic(cfg.win_length))
+    out["fe.twiddle"] = torch.from_numpy(fft_twiddles(cfg.n_fft))
+    out["fe.fb_idx"] = torch.from_numpy(idx)
+    out["fe.fb_w"] = torch.from_numpy(w)
+    std = get("normalize.std").to(torch.float64).clamp_min(cfg.norm_eps)
+    out["fe.mvn_mean"] = f32t(get("normalize.mean"))
+    out["fe.mvn_istd"] = (1.0 / std).to(torch.float32).contiguous()
+
+    E = "encoder.embed."
+    out["sub.conv0.w"] = f32t(get(E + "conv.0.weight").reshape(C, 9).t())
+    out["sub.conv0.b"] = f32t(get(E + "conv.0.bias"))
+    out["sub.conv1.w"] = bf(get(E + "conv.2.weight").permute(0, 2, 3, 1).reshape(C, 9 * C))
+    out["sub.conv1.b"] = f32t(get(E + "conv.2.bias"))
+    F = cfg.sub_freq
+    out["sub.out.w"] = bf(get(E + "out.0.weight").reshape(d, C, F).permute(0, 2, 1).reshape(d, F * C))
+    out["sub.out.b"] = f32t(get(E + "out.0.bias"))
+
+    for i in range(cfg.n_layers):
+        L = f"encoder.encoders.{i}."
+        p = f"L{i}."
+        for short, long in (("ln_ff1", "norm_ff_macaron"), ("ln_att", "norm_mha"), ("ln_conv", "norm_conv"),
+                            ("ln_ff2", "norm_ff"), ("ln_out", "norm_final")):
+            out[p + short + ".g"] = f32t(get(L + long + ".weight"))
+            out[p + short + ".b"] = f32t(get(L + long + ".bias"))
+        for short, long in (("ff1", "feed_forward_macaron"), ("ff2", "feed_forward")):
+            out[p + short + ".w1"] = bf(get(L + long + ".w_1.weight"))
+            out[p + short + ".b1"] = f32t(get(L + long + ".w_1.bias"))
+            out[p + short + ".w2"] = bf(get(L + long + ".w_2.weight"))
+            out[p + short + ".b2"] = f32t(get(L + long + ".w_2.bias"))
+        A = L + "self_attn."
+        out[p + "att.qkv.w"] = bf(torch.cat([get(A + "linear_q.weight"), get(A + "linear_k.weight"), get(A + "linear_v.weight")], dim=0))
+        out[p + "att.qkv.b"] = f32t(torch.cat([get(A + "linear_q.bias"), get(A + "linear_k.bias"), get(A + "linear_v.bias")], dim=0))
+        out[p + "att.out.w"] = bf(get(A + "linear_out.weight"))
+        out[p + "att.out.b"] = f32t(get(A + "linear_out.bias"))
+        out[p + "att.pos.w"] = bf(get(A + "linear_pos.weight"))
+        out[p + "att.bias_u"] = f32t(get(A + "pos_bias_u").reshape(-1))
+        out[p + "att.bias_v"] = f32t(get(A + "pos_bias_v").reshape(-1))
+        Cm = L + "conv_module."
+        rows = glu_interleave_index(d)
+        out[p + "conv.pw1.w"] = bf(get(Cm + "pointwise_conv1.weight").squeeze(-1)[rows])
+        out[p + "conv.pw1.b"] = f32t(get(Cm + "pointwise_conv1.bias")[rows])
+        g, b = get(Cm + "norm.weight").double(), get(Cm + "norm.bias").double()
+        mu, var = get(Cm + "norm.running_mean").double(), get(Cm + "norm.running_var").double()
+        sc = g / torch.sqrt(var + cfg.bn_eps)
+        out[p + "conv.dw.w"] = f32t((get(Cm + "depthwise_conv.weight").double().squeeze(1) * sc[:, None]).float().t())
+        out[p + "conv.dw.b"] = f32t(((get(Cm + "depthwise_conv.bias").double() - mu) * sc + b).float())
+        out[p + "conv.pw2.w"] = bf(get(Cm + "pointwise_conv2.weight").squeeze(-1))
+        out[p + "conv.pw2.b"] = f32t(get(Cm + "pointwise_conv2.bias"))
+    out["final_norm.g"] = f32t(get("encoder.after_norm.weight"))
+    out["final_norm.b"] = f32t(get("encoder.after_norm.bias"))
+    out["ctc.w"] = bf(get("ctc.ctc_lo.weight"))
+    out["ctc.b"] = f32t(get("ctc.ctc_lo.bias"))
+    out["joint.enc.w"] = bf(get("joint_network.lin_enc.weight"))
+    out["joint.enc.b"] = f32t(get("joint_network.lin_enc.bias"))
+    out["pred.embed"] = f32t(get("decoder.embed.weight"))
+    H = cfg.pred_hidden
+    for l in range(cfg.pred_layers):
+        P = f"decoder.decoder.{l}."
+        wl = torch.cat([get(P + "weight_ih_l0"), get(P + "weight_hh_l0")], dim=1)
+        out[f"pred.lstm{l}.w"] = to_fragment_major(wl)
+        perm = torch.arange(4 * H).view(4, H // 4, 4).permute(1, 0, 2).reshape(-1)
+        out[f"pred.lstm{l}.w4"] = to_fragment_major(wl.to(torch.float32)[perm])
+        out[f"pred.lstm{l}.b"] = f32t(get(P + "bias_ih_l0").float() + get(P + "bias_hh_l0").float())
+    out["joint.pred.w"] = to_fragment_major(get("joint_network.lin_dec.weight"))
+    out["joint.pred.b"] = torch.zeros((cfg.joint_hidden,), dtype=torch.float32)           # lin_dec has no bias
+    out["joint.out.w"] = to_fragment_major(get("joint_network.lin_out.weight"))
+    out["joint.out.b"] = f32t(get("joint_network.lin_out.bias"))
+    out["pos.table"] = torch.from_numpy(rel_pos_table(cfg, pos_cap)).to(torch.bfloat16).contiguous()
+    benign = ("num_batches_tracked",)
+    left = [k for k in sd if k not in used and not k.endswith(benign)]
+    if left:
+        raise UnsupportedCheckpoint(f"{len(left)} checkpoint tensor(s) have no counterpart in this implementation: "
+                                    + ", ".join(left[:8]) + (" ..." if len(left) > 8 else ""))
+    return out
