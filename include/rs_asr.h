@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 2
+#define RS_ABI_VERSION 3
 
 enum {
     RS_OK = 0,
@@ -72,6 +72,19 @@ typedef struct rs_dims {
     int32_t pred_layers;   /* 2 */
     int32_t joint_hidden;  /* 640 */
     int32_t max_symbols;   /* 10 */
+    /* ---- model family switches (ABI 3).  All zero = NeMo FastConformer-RNNT, the path everything above describes.  The
+     * ESPnet2 Conformer-Transducer of reazonspeech.espnet.asr (pkg/espnet-asr/src/transcribe.py:26-32) sets all five. ---- */
+    int32_t frontend_kind; /* 0: NeMo AudioToMelSpectrogramPreprocessor.  1: ESPnet DefaultFrontend + GlobalMVN — reflect edge
+                              padding, 1 + L / hop frames, log(max(x, log_guard)), (x - "fe.mvn_mean") * "fe.mvn_istd"; preemph
+                              must be 0 */
+    int32_t sub_kind;      /* 0: dw_striding x 2^sub_stages.  1: ESPnet Conv2dSubsampling x4 — Conv2d(1, C, 3, 2) ReLU
+                              Conv2d(C, C, 3, 2) ReLU without padding ("sub.conv0.*" f32 tap-major, "sub.conv1.w" bf16 [C][9C] with K
+                              ordered (kernel row, kernel column, channel)), Linear(C * F2, d_model); sub_stages must be 2 */
+    int32_t final_norm;    /* 1: a LayerNorm after the last block ("final_norm.g" / ".b"; ESPnet encoder.after_norm) */
+    int32_t joint_act;     /* joint activation: 0 = ReLU (NeMo), 1 = tanh (ESPnet JointNetwork); tanh decodes with the exact
+                              (un-screened) joint kernels */
+    int32_t ctc_vocab;     /* > 0: a CTC head Linear(d_model, ctc_vocab) is registered ("ctc.w" bf16 [ctc_vocab][d_model], "ctc.b");
+                              see rs_encoder_set_ctc_out.  ctc_vocab % 4 == 0 */
 } rs_dims;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -183,6 +196,12 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value);
  * conformer layer (layer_out[k] for layer_ids[k]; rows L1-L7).  NULL / 0 disables.  layer_ids is a host array. */
 int rs_encoder_set_taps(rs_ctx* ctx, float* sub_out, float* layer_out, const int32_t* layer_ids,
                         int n_layer_ids);
+
+/* CTC posteriors (ESPnet family; replaces model.asr_model.ctc.softmax(model.asr_model.encode(...)), pkg/espnet-asr/src/ctc.py:12-27):
+ * when set, the next rs_encoder_forward calls also write softmax(ctc_lo(encoder output)) — probabilities, not logarithms, as the
+ * reference's blank finder (ctc.py:29-58) and its ctc_segmentation call (ctc.py:60-75) consume them — to probs f32
+ * [B*tp_max][ctc_vocab] and / or only the blank column to blank_prob f32 [B*tp_max].  Either may be NULL; both NULL disables. */
+int rs_encoder_set_ctc_out(rs_ctx* ctx, float* probs, float* blank_prob);
 
 /* ---- stage 3: RNN-T greedy decode -------------------------------------------------------
  * Replaces: decoding.rnnt_decoder_predictions_tensor inside model.transcribe

@@ -42,6 +42,8 @@ def _ip(a):
 def decoder_arrays(cfg, sd):
     """float32 numpy arrays in the layout rnnt_greedy.c expects (the same host-side prep the
     device path applies: W = [W_ih | W_hh], bias = b_ih + b_hh in float32)."""
+    if getattr(cfg, "espnet", False):
+        return decoder_arrays_espnet(cfg, sd)
     P = "decoder.prediction.dec_rnn.lstm."
     ws, bs = [], []
     for l in range(cfg.pred_layers):
@@ -55,9 +57,24 @@ def decoder_arrays(cfg, sd):
                 Wo=c("joint.joint_net.2.weight"), bo=c("joint.joint_net.2.bias"))
 
 
+def decoder_arrays_espnet(cfg, sd):
+    """the same arrays from an ESPnet2 state dict ([UPSTREAM] TransducerDecoder: one LSTM module per layer; JointNetwork:
+    lin_dec has no bias, lin_enc is hoisted into `f` by the caller)"""
+    ws, bs = [], []
+    for l in range(cfg.pred_layers):
+        P = f"decoder.decoder.{l}."
+        ws.append(np.ascontiguousarray(np.concatenate([sd[P + "weight_ih_l0"].numpy(), sd[P + "weight_hh_l0"].numpy()], axis=1), dtype=np.float32))
+        bs.append((sd[P + "bias_ih_l0"].numpy().astype(np.float32) + sd[P + "bias_hh_l0"].numpy().astype(np.float32)).astype(np.float32))
+    c = lambda k: np.ascontiguousarray(sd[k].numpy(), dtype=np.float32)  # noqa: E731
+    return dict(embed=c("decoder.embed.weight"), lstm_w=ws, lstm_b=bs, Wp=c("joint_network.lin_dec.weight"),
+                bp=np.zeros((cfg.joint_hidden,), np.float32), Wo=c("joint_network.lin_out.weight"), bo=c("joint_network.lin_out.bias"))
+
+
 def rnnt_greedy(cfg, sd, f, enc_lens, u_max=None):
-    """f float32 [B, Tp, J] (numpy), enc_lens int[B] -> list of (ids, frames) per utterance."""
+    """f float32 [B, Tp, J] (numpy), enc_lens int[B] -> list of (ids, frames) per utterance.  The joint activation follows
+    the model family (ReLU for NeMo, tanh for ESPnet); ESPnet's greedy search is max_symbols = 1."""
     L = lib()
+    L.rs_oracle_set_joint_act(1 if getattr(cfg, "espnet", False) else 0)
     arr = decoder_arrays(cfg, sd)
     f = np.ascontiguousarray(f, dtype=np.float32)
     B, Tp, J = f.shape

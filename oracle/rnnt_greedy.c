@@ -66,11 +66,17 @@ void rs_oracle_lstm_step(const float* x, const float* h, const float* c, const f
     }
 }
 
-/* logits[V] = Wo . relu(f + g) + bo ; returns argmax (lowest index on ties) */
+/* joint activation: 0 = ReLU ([UPSTREAM] NeMo RNNTJoint), 1 = tanh ([UPSTREAM] ESPnet2 JointNetwork, the model family of
+ * reazonspeech.espnet.asr: pkg/espnet-asr/src/transcribe.py:26-32) with the shared polynomial of rnnt_math.h, which the HIP
+ * tile kernel evaluates operation for operation (k_rnnt.hip: DecodeState.joint_act). */
+static int g_joint_act = 0;
+void rs_oracle_set_joint_act(int act) { g_joint_act = act; }
+
+/* logits[V] = Wo . act(f + g) + bo ; returns argmax (lowest index on ties) */
 int rs_oracle_joint_argmax(const float* f, const float* g, const float* Wo, const float* bo, int J, int V,
                            float* logits_out /* may be NULL */) {
     float* a = (float*)malloc(sizeof(float) * J);
-    for (int k = 0; k < J; ++k) a[k] = fmaxf(f[k] + g[k], 0.0f);
+    for (int k = 0; k < J; ++k) a[k] = g_joint_act ? rs_tanhf(f[k] + g[k]) : fmaxf(f[k] + g[k], 0.0f);
     int best = 0;
     float bestv = -INFINITY;
     for (int v = 0; v < V; ++v) {

@@ -32,6 +32,8 @@ struct FrontParams {
     const float* fb_w;     // [n_mels][FB_MAXW]
     int audio_stride, pad_left, pad_right, t_max, n_mels, win_length, hop;
     float preemph, log_guard;
+    int kind;              // 0: NeMo (zero edge padding, floor(L / hop) frames, log(x + guard)); 1: ESPnet DefaultFrontend
+                           // (reflect edge padding, 1 + floor(L / hop) frames, log(max(x, guard)); normalised by feat_mvn_kernel)
 };
 
 __device__ __forceinline__ float fetch_sample(const float* __restrict__ a, int i, int pad_left, int len) {
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
     const int b = blockIdx.y;
     const int len = p.lens[b];
     const int Lp = len + p.pad_left + p.pad_right;       // padded length (reference: after pad_audio)
-    const int n_valid = Lp / p.hop;                       // floor((Lp + 2*(n_fft/2) - n_fft) / hop)
+    const int n_valid = Lp / p.hop + (p.kind == 1 ? 1 : 0);   // NeMo: floor((Lp + 2*(n_fft/2) - n_fft) / hop); ESPnet Stft keeps the last frame
     if (blockIdx.x == 0 && threadIdx.x == 0) p.n_frames[b] = n_valid;
     const float* a = p.audio + (size_t)b * p.audio_stride;
     if ((int)blockIdx.x * WAVES * FRAMES_PER_WAVE >= min(n_valid, p.t_max)) return;  // block-uniform
@@ -105,8 +107,13 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
     const int i_base = f0 * p.hop - NFFT / 2 + centre_off;
     const int span = (WAVES * FRAMES_PER_WAVE - 1) * p.hop + NFFT;
     for (int idx = threadIdx.x; idx < span; idx += blockDim.x) {
-        const int i = i_base + idx;
+        int i = i_base + idx;
         float y = 0.0f;
+        if (p.kind == 1 && Lp > 1) {                      // torch.stft(pad_mode="reflect"): x[-k] = x[k], x[L-1+k] = x[L-1-k]
+            i = i < 0 ? -i : i;
+            i = i >= Lp ? 2 * (Lp - 1) - i : i;
+            i = i < 0 ? 0 : i;                            // (an utterance shorter than n_fft / 2: torch refuses it, clamp)
+        }
         if (i >= 0 && i < Lp) {
             const float x0 = fetch_sample(a, i, p.pad_left, len);
             y = i >= 1 ? x0 - p.preemph * fetch_sample(a, i - 1, p.pad_left, len) : x0;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
                 const float* w = p.fb_w + m * FB_MAXW;
                 float acc = 0.0f;
                 for (int j = 0; j < cnt; ++j) acc = fmaf(w[j], pw[wave][f][k0 + j], acc);
-                p.raw[((size_t)b * p.t_max + t + f) * p.n_mels + m] = logf(acc + p.log_guard);
+                p.raw[((size_t)b * p.t_max + t + f) * p.n_mels + m] = p.kind == 1 ? logf(fmaxf(acc, p.log_guard)) : logf(acc + p.log_guard);
             }
         }
         wave_sync();
@@ -264,6 +271,18 @@ __global__ __launch_bounds__(1024) void feat_normalize_kernel(const float* __res
         }
 }
 
+// ESPnet GlobalMVN: (x - mean[m]) * istd[m] on the valid frames, zeros beyond.  grid (ceil(t_max * n_mels / 256), B)
+__global__ __launch_bounds__(256) void feat_mvn_kernel(const float* __restrict__ raw, const int32_t* __restrict__ n_frames, int t_max,
+                                                       int n_mels, const float* __restrict__ mean, const float* __restrict__ istd,
+                                                       float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t_max * n_mels) return;
+    const int t = i / n_mels, m = i - t * n_mels;
+    const size_t at = (size_t)b * t_max * n_mels + i;
+    out[at] = t < n_frames[b] ? (raw[at] - mean[m]) * istd[m] : 0.0f;
+}
+
 }  // namespace
 
 int rs_launch_frontend(rs_ctx* ctx, const float* audio, const int32_t* lens, int B, int audio_stride,
@@ -280,13 +299,18 @@ int rs_launch_frontend(rs_ctx* ctx, const float* audio, const int32_t* lens, int
     p.audio_stride = audio_stride; p.pad_left = pad_left; p.pad_right = pad_right; p.t_max = t_max;
     p.n_mels = d.n_mels; p.win_length = d.win_length; p.hop = d.hop_length;
     p.preemph = d.preemph; p.log_guard = d.log_guard;
+    p.kind = d.frontend_kind;
     const int fpb = WAVES * FRAMES_PER_WAVE;
     const dim3 grid((t_max + fpb - 1) / fpb, B), block(64 * WAVES);
     const double bytes = (double)B * ((double)t_max * d.hop_length * 4.0 + (double)t_max * d.n_mels * 4.0 * 3.0);
     rs_prof_begin(ctx, RS_PROF_FRONTEND, s, (double)B * t_max * (5.0 * 512 * 9 + 3 * 257 + 2 * 600), bytes);
     hipLaunchKernelGGL(logmel_kernel, grid, block, 0, s, p);
-    hipLaunchKernelGGL(feat_normalize_kernel, dim3(B), dim3(1024), 0, s, raw, n_frames, t_max, d.n_mels, d.norm_eps,
-                       feats);
+    if (d.frontend_kind == 1)
+        hipLaunchKernelGGL(feat_mvn_kernel, dim3((t_max * d.n_mels + 255) / 256, B), dim3(256), 0, s, raw, n_frames, t_max, d.n_mels,
+                           ctx->fe_mvn_mean, ctx->fe_mvn_istd, feats);
+    else
+        hipLaunchKernelGGL(feat_normalize_kernel, dim3(B), dim3(1024), 0, s, raw, n_frames, t_max, d.n_mels, d.norm_eps,
+                           feats);
     rs_prof_end(ctx, RS_PROF_FRONTEND, s);
     RS_CHECK_LAUNCH(ctx, "frontend");
     return RS_OK;

@@ -228,9 +228,14 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri) {
             a[ri] = fr.a[ri];
-            if (MODE >= 1) {   // relu(f + g) is elementwise: apply it before the lane permutation
-                a[ri].x = fmaxf(a[ri].x + fr.g[ri].x, 0.0f); a[ri].y = fmaxf(a[ri].y + fr.g[ri].y, 0.0f);
-                a[ri].z = fmaxf(a[ri].z + fr.g[ri].z, 0.0f); a[ri].w = fmaxf(a[ri].w + fr.g[ri].w, 0.0f);
+            if (MODE >= 1) {   // the joint activation of (f + g) is elementwise: apply it before the lane permutation
+                if (st.joint_act) {            // ESPnet JointNetwork: tanh (the shared polynomial: bit-exact with the C oracle)
+                    a[ri].x = rs_tanhf(a[ri].x + fr.g[ri].x); a[ri].y = rs_tanhf(a[ri].y + fr.g[ri].y);
+                    a[ri].z = rs_tanhf(a[ri].z + fr.g[ri].z); a[ri].w = rs_tanhf(a[ri].w + fr.g[ri].w);
+                } else {
+                    a[ri].x = fmaxf(a[ri].x + fr.g[ri].x, 0.0f); a[ri].y = fmaxf(a[ri].y + fr.g[ri].y, 0.0f);
+                    a[ri].z = fmaxf(a[ri].z + fr.g[ri].z, 0.0f); a[ri].w = fmaxf(a[ri].w + fr.g[ri].w, 0.0f);
+                }
             }
             a[ri] = to_mfma_a_layout(a[ri], perm);
         }
@@ -809,6 +814,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     char* w = reinterpret_cast<char*>(workspace);
     auto take = [&](size_t bytes) { char* p = w; w += rs_align(bytes); return p; };
     DecodeState st;
+    st.joint_act = d.joint_act;
     const size_t state_bytes = (size_t)L * B * H * 4;
     st.h = (float*)take(state_bytes); st.c = (float*)take(state_bytes);
     st.h_tmp = (float*)take(state_bytes); st.c_tmp = (float*)take(state_bytes);
@@ -822,7 +828,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     st.a16 = (uint16_t*)take((size_t)B * J * 2); st.anorm = (float*)take((size_t)B * 4);
     st.zapprox = (float*)take((size_t)B * Vpad * 4);
     // the screened joint keeps a row's logits (<= 48 x 64) and a K slice (<= 8 blocks of 16) in registers, J / 32 <= 20 weight fragments
-    const bool screen = ctx->decode_screen && ctx->jout_w16 && ctx->jout_wrm && ctx->jout_bpad && ctx->jout_wmax && V <= 48 * 64 &&
+    const bool screen = d.joint_act == 0 && ctx->decode_screen && ctx->jout_w16 && ctx->jout_wrm && ctx->jout_bpad && ctx->jout_wmax && V <= 48 * 64 &&
                         J / SPLITK_TILE / 16 <= 8 && J / 32 <= 20;
 
     if (int rc = ensure_decode_lds(ctx); rc != RS_OK) return rc;

@@ -61,6 +61,7 @@ struct DecodeState {
     uint16_t* a16;   // [B][J] bf16 relu(f + g) of alive slot i
     float* anorm;    // [B]    ||relu(f + g)||_2 of alive slot i (rounded up)
     float* zapprox;  // [B][Vpad] approximate logits of alive slot i (bf16 MFMA GEMM, f32 accumulate, + bias)
+    int joint_act;   // 0: relu(f + g) (NeMo RNNTJoint); 1: tanh(f + g) (ESPnet JointNetwork) — exact-tile kernels only
 };
 
 }  // namespace

@@ -14,14 +14,12 @@
 
 namespace {
 
-__device__ __forceinline__ int conv_len(int n) { return (n + 2 - 3) / 2 + 1; }
-
-__global__ void enc_lens_kernel(const int32_t* __restrict__ n_frames, int B, int stages, int32_t* __restrict__ out) {
+__global__ void enc_lens_kernel(const int32_t* __restrict__ n_frames, int B, int stages, int sub_kind, int32_t* __restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     int n = n_frames[b];
     for (int s = 0; s < stages; ++s) {
-        n = n > 0 ? conv_len(n) : 0;
+        n = n > 0 ? (sub_kind ? (n >= 3 ? (n - 3) / 2 + 1 : 0) : (n + 2 - 3) / 2 + 1) : 0;      // rs_conv_len
         out[s * B + b] = n;
     }
 }
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(256) void sub_dw_f32_kernel(const float* __restrict
 }  // namespace
 
 int rs_launch_enc_lens(rs_ctx* ctx, const int32_t* n_frames, int B, int32_t* lens_out, hipStream_t s) {
-    hipLaunchKernelGGL(enc_lens_kernel, dim3((B + 127) / 128), dim3(128), 0, s, n_frames, B, ctx->d.sub_stages, lens_out);
+    hipLaunchKernelGGL(enc_lens_kernel, dim3((B + 127) / 128), dim3(128), 0, s, n_frames, B, ctx->d.sub_stages, ctx->d.sub_kind, lens_out);
     RS_CHECK_LAUNCH(ctx, "enc_lens");
     return RS_OK;
 }

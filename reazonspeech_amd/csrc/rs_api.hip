@@ -95,10 +95,15 @@ int rs_create(rs_ctx** out, int device, const rs_dims* dims) {
     else if (d.sub_stages < 2 || d.sub_stages > 4) rc = rs_fail(ctx, RS_EINVAL, "2..4 subsampling stages supported");
     else if (d.n_layers < 1) rc = rs_fail(ctx, RS_EINVAL, "n_layers");
     else if (d.pred_layers < 1 || d.pred_layers > 4) rc = rs_fail(ctx, RS_EINVAL, "pred_layers");
+    else if ((unsigned)d.frontend_kind > 1u || (unsigned)d.sub_kind > 1u || (unsigned)d.final_norm > 1u || (unsigned)d.joint_act > 1u)
+        rc = rs_fail(ctx, RS_EINVAL, "model family switches must be 0 or 1");
+    else if (d.sub_kind == 1 && (d.sub_stages != 2 || d.sub_channels % 64)) rc = rs_fail(ctx, RS_EINVAL, "Conv2dSubsampling: x4 (two stages), channels %% 64");
+    else if (d.frontend_kind == 1 && d.preemph != 0.0f) rc = rs_fail(ctx, RS_EINVAL, "the ESPnet front-end has no pre-emphasis");
+    else if (d.ctc_vocab < 0 || d.ctc_vocab % 4) rc = rs_fail(ctx, RS_EINVAL, "ctc_vocab %% 4");
     if (rc != RS_OK) { *out = ctx; return rc; }  // caller can read rs_last_error, then rs_destroy
     ctx->head_dim = d.d_model / d.n_heads;
     int f = d.n_mels;
-    for (int s = 0; s < d.sub_stages; ++s) f = (f + 2 - 3) / 2 + 1;
+    for (int s = 0; s < d.sub_stages; ++s) f = rs_conv_len(f, d.sub_kind);
     ctx->sub_freq = f;
     if (hipSetDevice(device) != hipSuccess) { *out = ctx; return rs_fail(ctx, RS_EHIP, "hipSetDevice(%d) failed", device); }
     *out = ctx;
@@ -158,7 +163,11 @@ int rs_finalize(rs_ctx* ctx) {
     r.get("fe.fb_w", (size_t)d.n_mels * 32, ctx->fe_fb_w);
     r.get("sub.conv0.w", 9 * C, ctx->sub_conv0_w);
     r.get("sub.conv0.b", C, ctx->sub_conv0_b);
-    for (int s = 1; s < d.sub_stages; ++s) {
+    if (d.frontend_kind == 1) { r.get("fe.mvn_mean", (size_t)d.n_mels, ctx->fe_mvn_mean); r.get("fe.mvn_istd", (size_t)d.n_mels, ctx->fe_mvn_istd); }
+    if (d.sub_kind == 1) { r.get("sub.conv1.w", C * 9 * C, ctx->sub_conv1_w); r.get("sub.conv1.b", C, ctx->sub_conv1_b); }
+    if (d.final_norm) { r.get("final_norm.g", dm, ctx->final_norm_g); r.get("final_norm.b", dm, ctx->final_norm_b); }
+    if (d.ctc_vocab > 0) { r.get("ctc.w", (size_t)d.ctc_vocab * dm, ctx->ctc_w); r.get("ctc.b", (size_t)d.ctc_vocab, ctx->ctc_b); }
+    for (int s = 1; s < d.sub_stages && d.sub_kind == 0; ++s) {
         const std::string p = "sub.dw" + std::to_string(s), q = "sub.pw" + std::to_string(s);
         r.get(p + ".w", 9 * C, ctx->sub_dw_w[s - 1]);
         r.get(p + ".b", C, ctx->sub_dw_b[s - 1]);
@@ -326,11 +335,19 @@ int rs_encoder_set_taps(rs_ctx* ctx, float* sub_out, float* layer_out, const int
     return RS_OK;
 }
 
-int rs_mel_frames(const rs_ctx* ctx, int n_samples) { return n_samples / ctx->d.hop_length; }
+int rs_mel_frames(const rs_ctx* ctx, int n_samples) { return n_samples / ctx->d.hop_length + (ctx->d.frontend_kind == 1 ? 1 : 0); }
 
 int rs_enc_frames(const rs_ctx* ctx, int n) {
-    for (int s = 0; s < ctx->d.sub_stages; ++s) n = n > 0 ? (n + 2 - 3) / 2 + 1 : 0;
+    for (int s = 0; s < ctx->d.sub_stages; ++s) n = rs_conv_len(n, ctx->d.sub_kind);
     return n;
+}
+
+int rs_encoder_set_ctc_out(rs_ctx* ctx, float* probs, float* blank_prob) {
+    if (!ctx) return RS_EINVAL;
+    if ((probs || blank_prob) && ctx->d.ctc_vocab <= 0) return rs_fail(ctx, RS_EINVAL, "this model has no CTC head (rs_dims.ctc_vocab)");
+    ctx->ctc_probs = probs;
+    ctx->ctc_blank = blank_prob;
+    return RS_OK;
 }
 
 }  // extern "C"
@@ -339,29 +356,48 @@ namespace {
 
 struct EncPlan {
     int T[5], F[5];  // per stage time / freq extents (index 0 = mel)
-    size_t off_lens, off_sa, off_sb, off_x, off_hn, off_big, off_ctx, off_posp, off_stats, total;
+    size_t off_lens, off_sa, off_sb, off_x, off_hn, off_big, off_ctx, off_posp, off_stats, off_col, off_ctc, total;
+    int chunk;       // Conv2dSubsampling: utterances per pass of conv0 / patch gather / dense-conv GEMM
 };
 
 EncPlan plan_encoder(const rs_ctx* ctx, int B, int t_max) {
     const rs_dims& d = ctx->d;
     EncPlan p{};
     p.T[0] = t_max; p.F[0] = d.n_mels;
-    for (int s = 1; s <= d.sub_stages; ++s) { p.T[s] = (p.T[s - 1] + 2 - 3) / 2 + 1; p.F[s] = (p.F[s - 1] + 2 - 3) / 2 + 1; }
+    for (int s = 1; s <= d.sub_stages; ++s) { p.T[s] = rs_conv_len(p.T[s - 1], d.sub_kind); p.F[s] = rs_conv_len(p.F[s - 1], d.sub_kind); }
     const size_t C = d.sub_channels, dm = d.d_model;
-    const size_t Tp = p.T[d.sub_stages], M = (size_t)B * Tp;
+    const size_t Tp = p.T[d.sub_stages] > 0 ? p.T[d.sub_stages] : 1, M = (size_t)B * Tp;
     size_t widest = (size_t)d.ff_dim;
     if (3 * dm > widest) widest = 3 * dm;
     size_t o = 0;
     p.off_lens = o; o += rs_align((size_t)4 * B * 4);
-    const size_t sub_elems = (size_t)B * p.T[2] * p.F[2] * C;  // stage-2 extent is the largest stored one
-    p.off_sa = o; o += rs_align(sub_elems * 2);
-    p.off_sb = o; o += rs_align(sub_elems * 2);
+    p.chunk = B;
+    p.off_col = 0;
+    if (d.sub_kind == 1) {
+        // sa = conv0 output of ONE chunk of utterances [chunk][T1][F1][C]; col = its 3x3 patches [chunk*T2*F2][9C];
+        // sb = the dense conv's output of the WHOLE batch [B][T2][F2][C].  The chunk keeps the patch matrix near 1 GiB.
+        const size_t per_utt_col = (size_t)(p.T[2] > 0 ? p.T[2] : 1) * p.F[2] * 9 * C * 2;
+        size_t chunk = ((size_t)1 << 30) / per_utt_col;
+        if (chunk < 1) chunk = 1;
+        if (chunk > (size_t)B) chunk = (size_t)B;
+        while (chunk > 1 && chunk * (size_t)p.T[2] > 65535) --chunk;            // grid limit of the gather kernel
+        p.chunk = (int)chunk;
+        p.off_sa = o; o += rs_align(chunk * (size_t)(p.T[1] > 0 ? p.T[1] : 1) * p.F[1] * C * 2);
+        p.off_col = o; o += rs_align(chunk * per_utt_col);
+        p.off_sb = o; o += rs_align((size_t)B * (p.T[2] > 0 ? p.T[2] : 1) * p.F[2] * C * 2);
+    } else {
+        const size_t sub_elems = (size_t)B * p.T[2] * p.F[2] * C;  // stage-2 extent is the largest stored one
+        p.off_sa = o; o += rs_align(sub_elems * 2);
+        p.off_sb = o; o += rs_align(sub_elems * 2);
+    }
     p.off_x = o; o += rs_align(M * dm * 4);
     p.off_hn = o; o += rs_align(M * dm * 2);
     p.off_big = o; o += rs_align(M * widest * 2);
     p.off_ctx = o; o += rs_align(M * dm * 2);
     p.off_posp = o; o += rs_align((2 * Tp) * dm * 2);
     p.off_stats = o; o += rs_align(M * 2 * 4);          // (mean, rstd) per row of a deferred output norm
+    p.off_ctc = o;
+    if (d.ctc_vocab > 0) o += rs_align(M * (size_t)d.ctc_vocab * 4);   // CTC logits when only the blank column is wanted
     p.total = o + 256;
     return p;
 }
@@ -443,8 +479,26 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
 
     // ---- subsampling -------------------------------------------------------------------------
     RS_TRY(rs_launch_enc_lens(ctx, n_frames, B, lens_stage, s));
+    if (Tp <= 0) return rs_fail(ctx, RS_EINVAL, "encoder: %d feature frames are too few for the subsampling", t_max);
+    if (d.sub_kind == 1) {
+        // ESPnet Conv2dSubsampling: conv0 (VALU) -> 3x3 patches -> dense conv as one GEMM per chunk of utterances (bias, ReLU,
+        // rows past an utterance's T2 zeroed), into sb [B][T2][F2][C]
+        uint16_t* col = reinterpret_cast<uint16_t*>(ws + pl.off_col);
+        const int T1 = pl.T[1], F1 = pl.F[1], T2 = pl.T[2], F2 = pl.F[2];
+        for (int b0 = 0; b0 < B; b0 += pl.chunk) {
+            const int bc = B - b0 < pl.chunk ? B - b0 : pl.chunk;
+            RS_TRY(rs_launch_sub2d_conv0(ctx, feats, lens_stage, b0, bc, t_max, T1, F1, sa, s));
+            RS_TRY(rs_launch_im2col3x3s2(ctx, sa, bc, T1, F1, T2, F2, col, s));
+            rs_gemm_args g{};
+            g.A = col; g.lda = 9 * C; g.W = ctx->sub_conv1_w; g.ldw = 9 * C; g.out = sb + (size_t)b0 * T2 * F2 * C; g.ldc = C;
+            g.M = bc * T2 * F2; g.N = C; g.K = 9 * C;
+            g.flags = RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_ROWMASK; g.bias = ctx->sub_conv1_b; g.alpha = 1.0f;
+            g.mask_lens = lens_stage + B + b0; g.mask_rows_per_step = F2; g.mask_steps = T2;
+            RS_TRY(rs_launch_gemm(ctx, g, s));
+        }
+    } else
     RS_TRY(rs_launch_sub_conv0_dw1(ctx, feats, lens_stage, B, t_max, pl.T[2], pl.F[2], sa, s));
-    for (int st = 2; st <= S; ++st) {
+    for (int st = 2; st <= S && d.sub_kind == 0; ++st) {
         if (st > 2)
             RS_TRY(rs_launch_sub_dw(ctx, sb, ctx->sub_dw_w[st - 2], ctx->sub_dw_b[st - 2], lens_stage + (st - 1) * B, st, B,
                                     pl.T[st - 1], pl.F[st - 1], pl.T[st], pl.F[st], sa, s));
@@ -523,7 +577,10 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         RS_TRY(gemm(big, ff, L.ff2_w2, ff, x, dm, M, dm, RES, L.ff2_b2, 0.5f, x));
         // output norm (in place on the residual stream; the last layer also emits the bf16 copy
         // that feeds the joint's encoder projection)
-        if (last) {
+        if (last && d.final_norm) {
+            // ESPnet: the block's norm_final, then the encoder's after_norm; hn = bf16 of the latter feeds the joint / CTC heads
+            RS_TRY(rs_launch_layernorm(ctx, x, L.ln_out_g, L.ln_out_b, M, dm, d.ln_eps, nullptr, x, s));
+        } else if (last) {
             // the f32 rows of the final norm are read by the caller's enc_out copy / a parity tap only
             bool want_f32 = enc_out != nullptr;
             for (size_t k = 0; k < ctx->tap_ids.size(); ++k) want_f32 = want_f32 || ctx->tap_ids[k] == i;
@@ -544,9 +601,16 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
             if (ctx->tap_ids[k] == i)
                 RS_HIP(ctx, hipMemcpyAsync(ctx->tap_layers + k * (size_t)M * dm, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
     }
+    if (d.final_norm) RS_TRY(rs_launch_layernorm(ctx, x, ctx->final_norm_g, ctx->final_norm_b, M, dm, d.ln_eps, hn, enc_out ? x : nullptr, s));
     if (enc_out) RS_HIP(ctx, hipMemcpyAsync(enc_out, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
     RS_TRY(gemm(hn, dm, ctx->jenc_w, dm, joint_enc, d.joint_hidden, M, d.joint_hidden, RS_GEMM_BIAS | RS_GEMM_OUT_F32,
                 ctx->jenc_b, 1.0f, nullptr));
+    if (d.ctc_vocab > 0 && (ctx->ctc_probs || ctx->ctc_blank)) {
+        // CTC posteriors of every frame: logits by the same GEMM family, softmax in place
+        float* z = ctx->ctc_probs ? ctx->ctc_probs : reinterpret_cast<float*>(ws + pl.off_ctc);
+        RS_TRY(gemm(hn, dm, ctx->ctc_w, dm, z, d.ctc_vocab, M, d.ctc_vocab, RS_GEMM_BIAS | RS_GEMM_OUT_F32, ctx->ctc_b, 1.0f, nullptr));
+        RS_TRY(rs_launch_ctc_softmax(ctx, z, M, d.ctc_vocab, d.ctc_vocab, d.blank_id, ctx->ctc_blank, s));
+    }
 #undef RS_TRY
     return RS_OK;
 }

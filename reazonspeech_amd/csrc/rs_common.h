@@ -103,6 +103,14 @@ struct rs_ctx {
     const uint16_t* sub_out_w = nullptr;
     const float* sub_out_b = nullptr;
     std::vector<rs_layer_w> layers;
+    // ESPnet family (rs_dims.frontend_kind / sub_kind / final_norm / ctc_vocab)
+    const float *fe_mvn_mean = nullptr, *fe_mvn_istd = nullptr;
+    const uint16_t* sub_conv1_w = nullptr;
+    const float* sub_conv1_b = nullptr;
+    const float *final_norm_g = nullptr, *final_norm_b = nullptr;
+    const uint16_t* ctc_w = nullptr;
+    const float* ctc_b = nullptr;
+    float *ctc_probs = nullptr, *ctc_blank = nullptr;     // rs_encoder_set_ctc_out
     const uint16_t* jenc_w = nullptr;
     const float* jenc_b = nullptr;
     const float* lstm_w4[8] = {};   // optional "pred.lstm{l}.w4": fragment-major with rows permuted to (unit group, gate, unit)
@@ -206,3 +214,10 @@ size_t rs_encoder_f32_workspace_bytes(const rs_ctx* ctx, int B, int t_max);
 int rs_encoder_forward_f32(rs_ctx* ctx, const float* feats, const int32_t* n_frames, int B, int t_max, float* enc_out,
                            float* joint_enc, int32_t* enc_lens, void* workspace, size_t workspace_bytes, hipStream_t s);
 int rs_launch_enc_lens(rs_ctx* ctx, const int32_t* n_frames, int B, int32_t* lens_out, hipStream_t s);
+// ESPnet family (k_espnet.hip)
+int rs_launch_sub2d_conv0(rs_ctx* ctx, const float* feats, const int32_t* lens1, int b0, int Bc, int t_max, int T1, int F1,
+                          uint16_t* out, hipStream_t s);
+int rs_launch_im2col3x3s2(rs_ctx* ctx, const uint16_t* in, int Bc, int T1, int F1, int T2, int F2, uint16_t* out, hipStream_t s);
+int rs_launch_ctc_softmax(rs_ctx* ctx, float* logits, int M, int V, int ld, int blank, float* blank_out, hipStream_t s);
+// output length of one subsampling conv (k 3, s 2): padding 1 (NeMo dw_striding) or none (ESPnet Conv2dSubsampling)
+static inline int rs_conv_len(int n, int sub_kind) { return sub_kind ? (n >= 3 ? (n - 3) / 2 + 1 : 0) : (n > 0 ? (n + 2 - 3) / 2 + 1 : 0); }

@@ -1,0 +1,105 @@
+"""`load_model()` / `transcribe()` of `reazonspeech.espnet.asr` (pkg/espnet-asr/src/transcribe.py:12-82).
+
+The control flow is the reference's: audio longer than WINDOW_SECONDS is cut at the midpoint of the longest non-speech
+stretch the CTC head finds in the next 20 s (:59-67), each piece is recognised with (16000, 8000) samples of zero padding
+(:69) and split into time-stamped segments by CTC segmentation (:72-77).  Underneath, `Speech2Text` is replaced by
+`EspnetModel` (model.py): HIP front-end, Conv2dSubsampling, conformer blocks, CTC head and transducer greedy search."""
+import sys
+
+import numpy as np
+import torch
+
+from .audio import norm_audio
+from .interface import TranscribeConfig, TranscribeResult, Segment
+from .ctc import split_text, find_blank
+
+# Hyper parameters (transcribe.py:9-10)
+WINDOW_SECONDS = 20
+PADDING = (16000, 8000)
+
+
+def load_model(device=None, config=None, seed=0):
+    """Load the ReazonSpeech ESPnet model onto a ROCm GPU (transcribe.py:12-32).
+
+    Args:
+      device (str): "cuda" / "cuda:N"; None picks "cuda" when available like the reference (:20-24).  There is no CPU path
+        in this package: "cpu" raises.
+      config (ModelConfig): architecture (family "espnet"); default: the 120M Conformer-Transducer shape.
+      seed (int): seed of the synthetic weights.
+
+    The reference downloads `reazon-research/reazonspeech-espnet-v2` through espnet_model_zoo (:27-31); neither ESPnet nor
+    the archive is reachable here, and no reader for ESPnet's packed archives is built: this loads SEEDED SYNTHETIC weights of
+    the architecture (timings are valid, transcripts are meaningless) and says so."""
+    from ...runtime.config import ESPNET_CONFORMER_120M
+    from ...runtime.weights_espnet import synthetic_state_dict_espnet
+    from .model import EspnetModel, synthetic_token_list
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    if str(device).startswith("cpu"):
+        raise RuntimeError("reazonspeech_amd runs on MI355X (gfx950) only; no CPU path exists (use the reference package for CPU inference)")
+    cfg = config or ESPNET_CONFORMER_120M
+    if config is None:
+        print("[reazonspeech_amd] WARNING: reazonspeech.espnet.asr has no checkpoint reader in this build — loading SEEDED SYNTHETIC "
+              "weights of the 120M Conformer-Transducer architecture: timings are valid, transcripts are meaningless.",
+              file=sys.stderr, flush=True)
+    return EspnetModel(cfg, synthetic_state_dict_espnet(cfg, seed), synthetic_token_list(cfg.vocab_size, seed), device=device)
+
+
+def transcribe(model, audio, config=None):
+    """Interface function to transcribe audio data (transcribe.py:34-82).
+
+    Args:
+      model (EspnetModel): what `load_model()` returned
+      audio (AudioData): Audio to transcribe
+      config (TranscribeConfig): Additional settings
+
+    Returns:
+      TranscribeResult
+    """
+    if config is None:
+        config = TranscribeConfig()
+    audio = norm_audio(audio)
+    pos = 0
+    fulltext = ""
+    segments = []
+    window = int(WINDOW_SECONDS * audio.samplerate)
+    total = len(audio.waveform)
+    while pos < total:
+        samples = audio.waveform[pos:]
+        # If the audio data is very long, find out the longest non-speech region and perform decoding up to that point.
+        if len(samples) > window:
+            blank = find_blank(model, samples[:window])
+            mid = int((blank.start + blank.end) / 2)
+            samples = samples[:mid]
+        asr = model(np.pad(samples, PADDING, mode="constant"))[0][0]
+        fulltext += asr
+        for start, end, text in split_text(model, samples, asr):
+            segments.append(Segment(
+                start_seconds=((pos + start) / audio.samplerate),
+                end_seconds=((pos + end) / audio.samplerate),
+                text=text,
+            ))
+        pos += len(samples)
+        if config.verbose:       # the reference draws a tqdm bar (transcribe.py:55-56,79-80)
+            print(f"\rTranscribe: {pos}/{total}", end="" if pos < total else "\n", file=sys.stderr, flush=True)
+    return TranscribeResult(fulltext, segments)
+
+
+def transcribe_batch(model, audios, config=None):
+    """Additive: many SHORT utterances (each at most one 20 s window) recognised as one batch on the device, then segmented
+    one by one on the host.  An utterance longer than a window goes through `transcribe` on its own."""
+    if config is None:
+        config = TranscribeConfig(verbose=False)
+    norm = [norm_audio(a) for a in audios]
+    window = int(WINDOW_SECONDS * 16000)
+    short = [i for i, a in enumerate(norm) if len(a.waveform) <= window]
+    out = [None] * len(norm)
+    texts = model.recognize_batch([norm[i].waveform for i in short]) if short else []
+    for i, asr in zip(short, texts):
+        samples = norm[i].waveform
+        segs = [Segment(start / 16000, end / 16000, text) for start, end, text in split_text(model, samples, asr)]
+        out[i] = TranscribeResult(asr, segs)
+    for i, a in enumerate(norm):
+        if out[i] is None:
+            out[i] = transcribe(model, a, TranscribeConfig(verbose=False))
+    return out

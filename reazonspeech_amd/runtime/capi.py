@@ -29,7 +29,7 @@ EXPORTS = [
     "rs_rnnt_greedy", "rs_profile_enable", "rs_profile_read", "rs_profile_reset", "rs_gemm_bf16",
     "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_glu_dwconv_silu_layout", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
     "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes", "rs_host_stage_rows",
-    "rs_gemm_f32", "rs_relpos_attention_f32", "rs_glu_dwconv_silu_f32", "rs_profile_read_launches",
+    "rs_gemm_f32", "rs_relpos_attention_f32", "rs_glu_dwconv_silu_f32", "rs_profile_read_launches", "rs_encoder_set_ctc_out",
 ]
 
 
@@ -43,6 +43,7 @@ class RsDims(Structure):
         ("ln_eps", c_float), ("att_left", c_int32), ("att_right", c_int32), ("n_global", c_int32),
         ("n_logits", c_int32), ("blank_id", c_int32), ("pred_hidden", c_int32), ("pred_layers", c_int32),
         ("joint_hidden", c_int32), ("max_symbols", c_int32),
+        ("frontend_kind", c_int32), ("sub_kind", c_int32), ("final_norm", c_int32), ("joint_act", c_int32), ("ctc_vocab", c_int32),
     ]
 
     @classmethod
@@ -51,7 +52,8 @@ class RsDims(Structure):
                    cfg.norm_eps, cfg.d_model, cfg.n_heads, cfg.ff_dim, cfg.n_layers, cfg.conv_kernel,
                    cfg.sub_channels, cfg.n_sub_stages, int(cfg.xscaling), cfg.ln_eps, cfg.att_left,
                    cfg.att_right, cfg.n_global, cfg.n_logits, cfg.blank_id, cfg.pred_hidden, cfg.pred_layers,
-                   cfg.joint_hidden, cfg.max_symbols)
+                   cfg.joint_hidden, cfg.max_symbols,
+                   *((1, 1, 1, 1, cfg.n_logits) if getattr(cfg, "espnet", False) else (0, 0, 0, 0, 0)))
 
 
 class RsError(RuntimeError):
@@ -118,7 +120,8 @@ def load():
                                 c_int, vp]
     lib.rs_relpos_attention_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp]
     lib.rs_glu_dwconv_silu_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
-    if lib.rs_abi_version() != 2:
+    lib.rs_encoder_set_ctc_out.argtypes = [vp, vp, vp]
+    if lib.rs_abi_version() != 3:
         raise ImportError("librs_asr.so ABI version mismatch")
     _lib = lib
     return lib
@@ -254,6 +257,12 @@ class Context:
         ids = (c_int32 * len(layer_ids))(*layer_ids)
         self._taps = (sub_out, layer_out)          # keep the buffers alive while registered
         self.check(self.lib.rs_encoder_set_taps(self._h, _ptr(sub_out), _ptr(layer_out), ids, len(layer_ids)))
+
+    def set_ctc_out(self, probs=None, blank_prob=None):
+        """CTC posteriors of the next encoder calls (ESPnet family): f32 [B*tp_max][vocab] and / or the blank column
+        f32 [B*tp_max]; no arguments = off"""
+        self._ctc = (probs, blank_prob)            # keep the buffers alive while registered
+        self.check(self.lib.rs_encoder_set_ctc_out(self._h, _ptr(probs), _ptr(blank_prob)))
 
     def rnnt_greedy(self, joint_enc, enc_lens, B, tp_max, u_max, ids, frames, n_ids, ws, stream):
         self.check(self.lib.rs_rnnt_greedy(self._h, _ptr(joint_enc), _ptr(enc_lens), B, tp_max, u_max, _ptr(ids),

@@ -132,7 +132,7 @@ class _BufView:
 
 class AsrModel:
     def __init__(self, cfg: ModelConfig, state_dict, tokenizer, device="cuda", pos_cap: int = DEFAULT_POS_CAP,
-                 pad_seconds: float = 0.5, precision: str = "bf16"):
+                 pad_seconds: float = 0.5, precision: str = "bf16", pad_samples=None):
         """precision: "bf16" = the throughput mode (bf16 GEMM operands, float32 accumulation and residual stream);
         "fp32" = the parity mode: float32 weights, activations and arithmetic end to end, what the reference computes
         (pkg/nemo-asr/src/transcribe.py:26-28, :48-53) — about 20x slower, 2.4 GB more weights."""
@@ -151,6 +151,8 @@ class AsrModel:
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", index)
         self.pad_left = self.pad_right = int(pad_seconds * cfg.sample_rate)   # audio.py:80-82 via decode.py:4
+        if pad_samples is not None:          # asymmetric padding in samples (espnet: PADDING = (16000, 8000), transcribe.py:10,69)
+            self.pad_left, self.pad_right = int(pad_samples[0]), int(pad_samples[1])
         self._bufs = {}
         self._dec_lanes = []            # [(context, stream)] of the decode lanes beyond what was needed so far
         self._streams = None
@@ -158,7 +160,11 @@ class AsrModel:
         self.pos_cap = 0
         with torch.cuda.device(self.device):
             self.ctx = capi.Context(cfg, index)
-            self._upload(prepare_weights(cfg, state_dict, pos_cap, f32=precision == "fp32"))
+            if cfg.espnet:
+                from .weights_espnet import prepare_weights_espnet
+                self._upload(prepare_weights_espnet(cfg, state_dict, pos_cap, f32=precision == "fp32"))
+            else:
+                self._upload(prepare_weights(cfg, state_dict, pos_cap, f32=precision == "fp32"))
             if precision == "fp32":
                 self.ctx.set_option("precision_f32", 1)
 
@@ -225,6 +231,10 @@ class AsrModel:
           * big batches on an otherwise idle chip (sequential schedule): screened joint + narrow tiles (79.9 vs 84.7 ms).
         $RS_DECODE_SCREEN / $RS_DECODE_NARROW override (A/B runs)."""
         if "RS_DECODE_SCREEN" in os.environ or "RS_DECODE_NARROW" in os.environ:
+            return
+        if self is not None and self.cfg.espnet:   # tanh joint: the exact kernels (the screened joint's bound is derived for ReLU)
+            ctx.set_option("decode_screen", 0)
+            ctx.set_option("decode_narrow", 0 if (pipelined and lanes == 1 and B >= 128) else 1)
             return
         big = B >= 128
         critical = pipelined and lanes == 1
