@@ -371,7 +371,64 @@ def extra_configs(model, cfg, sd, args, host_sets):
             torch.cuda.empty_cache()
         except Exception as e:
             out[key] = {"error": repr(e)}
+    # BASELINE configs[0]'s model on the GPU: reazonspeech.espnet.asr Conformer-Transducer 120M — the same
+    # kernels behind another front-end / subsampling / joint, one 20 s window's worth of work per utterance
+    try:
+        out["espnet_120m"] = espnet_config(model.device, args)
+    except Exception as e:
+        out["espnet_120m"] = {"error": repr(e)}
     return out
+
+
+def espnet_config(device, args):
+    """`reazonspeech.espnet.asr` (pkg/espnet-asr/src/transcribe.py): 256 x 10 s utterances with the reference's (16000, 8000)
+    padding through front-end + Conv2dSubsampling + 17 conformer blocks + transducer greedy search, HBM-resident and pipelined
+    like the headline loop; parity of two utterances against the CPU oracle of that model (oracle/espnet.py)."""
+    from reazonspeech_amd.runtime.config import ESPNET_CONFORMER_120M
+    from reazonspeech_amd.runtime.weights_espnet import synthetic_state_dict_espnet
+    from reazonspeech_amd.espnet.asr.model import EspnetModel, synthetic_token_list, PADDING
+    cfg = ESPNET_CONFORMER_120M
+    sd = synthetic_state_dict_espnet(cfg, 0)
+    em = EspnetModel(cfg, sd, synthetic_token_list(cfg.vocab_size, 0), device=str(device))
+    am = em.am
+    n_sets = max(1 + args.dec_streams, 3)
+    bufs, secs = [], []
+    for k in range(n_sets):
+        audio, lens = synthetic_batch(args.batch, args.seconds, seed=4242 + 1000 * k)
+        waves = [np.pad(audio[i, :lens[i]], PADDING) for i in range(args.batch)]
+        bufs.append(am.stage(waves, buf=am.new_buffers(args.batch, len(waves[0]))))
+        secs.append(float(lens.sum()) / 16000.0)
+        if k == 0:
+            first = (audio, lens)
+    torch.cuda.synchronize()
+    steps = 10
+    dt = timed_pipeline(am, bufs, steps, 3, args.dec_streams)
+    n_tok = bufs[0].n_ids.cpu().numpy()
+    res = {"workload": f"{args.batch} x {args.seconds:g} s per step (+ (16000, 8000) samples of padding each), ESPnet Conformer-Transducer "
+                       f"{cfg.n_params() / 1e6:.0f}M, transducer greedy search (one symbol per frame), HBM-resident, pipelined",
+           "value": round(sum(secs[i % n_sets] for i in range(steps)) / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+           "enc_frames": bufs[0].tp_max, "mean_tokens_per_utt": round(float(n_tok.mean()), 1)}
+    try:
+        from oracle import espnet as oe, greedy as og
+        audio, lens = first
+        k = 2
+        padded = np.stack([np.pad(audio[i, :lens[i]], PADDING) for i in range(k)])
+        small = am.stage([padded[i] for i in range(k)])
+        enc = torch.zeros((k, small.tp_max, cfg.d_model), dtype=torch.float32, device=am.device)
+        am.run_device(small, want_enc=enc)
+        torch.cuda.synchronize()
+        got = am.collect(small)
+        ref = oe.forward(cfg, sd, torch.from_numpy(padded), torch.tensor([padded.shape[1]] * k), "fp32")
+        n = int(ref["enc_lens"][0])
+        same = og.rnnt_greedy(cfg, sd, small.joint_enc.cpu().numpy(), np.asarray(got.enc_lens, np.int32))
+        res["parity"] = {"utterances": k, "checker": "oracle/espnet.py (fp32 CPU restatement of the ESPnet2 model; unpinned against ESPnet itself)",
+                         "encoder_max_err": round(float((enc.cpu()[:, :n] - ref["enc"][:, :n]).abs().max()), 4),
+                         "decode_bit_exact_given_same_joint_enc": got.ids == [r[0] for r in same] and got.frames == [r[1] for r in same]}
+    except Exception as e:
+        res["parity"] = {"error": repr(e)}
+    del bufs, em
+    torch.cuda.empty_cache()
+    return res
 
 
 def window_parity(model, cfg, sd, host_set, k=2):
