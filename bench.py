@@ -432,24 +432,44 @@ def espnet_config(device, args):
 
 
 def window_parity(model, cfg, sd, host_set, k=2):
-    """limited-context attention at the benchmark geometry: k utterances of the resident batch against the fp32 oracle
-    run with the same attention predicate (oracle/model.py: attention_allowed)"""
-    from oracle import model as om
+    """limited-context attention at the benchmark geometry, ALL rows of a resident batch: the float32 parity mode with the same
+    attention predicate is the reference (itself checked against the fp32 CPU oracle on `k` utterances: oracle/model.py
+    attention_allowed), the throughput mode is compared with it row by row — joint-projection difference, ids identity
+    count, flip audit (oracle/audit.py)."""
+    from oracle import model as om, audit
     audio, lens = host_set
-    buf = model.stage([audio[b, :int(lens[b])] for b in range(k)])
-    enc = torch.zeros((k, buf.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
-    model.run_device(buf, want_enc=enc)
+    B = audio.shape[0]
+    waves = [audio[b, :int(lens[b])] for b in range(B)]
+    buf = model.stage(waves, buf=model.new_buffers(B, audio.shape[1]))
+    model.run_device(buf)
     torch.cuda.synchronize()
-    e_max = e_sum = cnt = 0.0
+    got = model.collect(buf)
+    m32 = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device=str(model.device), precision="fp32")
+    b32 = m32.stage(waves, buf=m32.new_buffers(B, audio.shape[1]))
+    enc32 = torch.zeros((B, b32.tp_max, cfg.d_model), dtype=torch.float32, device=model.device)
+    m32.run_device(b32, want_enc=enc32)
+    torch.cuda.synchronize()
+    got32 = m32.collect(b32)
+    e_max = 0.0
     for b in range(k):
         wav = np.pad(audio[b, :int(lens[b])], 8000)
         taps = {}
         f, el = om.forward_to_joint(cfg, sd, torch.from_numpy(wav)[None], torch.tensor([len(wav)]), "fp32", taps)
         n = int(el[0])
-        d = (enc[b, :n].cpu() - taps["enc"][0, :n]).abs()
-        e_max, e_sum, cnt = max(e_max, d.max().item()), e_sum + d.sum().item(), cnt + d.numel()
-    return {"utterances": k, "checker": "fp32 CPU oracle with the same attention predicate",
-            "encoder_max_err": round(e_max, 4), "encoder_mean_err": round(e_sum / cnt, 5)}
+        e_max = max(e_max, float((enc32[b, :n].cpu() - taps["enc"][0, :n]).abs().max()))
+    dj = max(float((buf.joint_enc[b, :got.enc_lens[b]] - b32.joint_enc[b, :got.enc_lens[b]]).abs().max()) for b in range(B))
+    audits = audit.flip_audit_batch(cfg, sd, b32.joint_enc, buf.joint_enc, got.enc_lens, got.ids, got.frames, device=model.device)
+    equal = [got.ids[b] == got32.ids[b] and got.frames[b] == got32.frames[b] for b in range(B)]
+    s = audit.summarize(audits, equal)
+    out = {"rows": B, "reference": "float32 parity mode with the same attention predicate, same rows",
+           "fp32_mode_encoder_max_err_vs_cpu_oracle": round(e_max, 7), "fp32_mode_rows_checked_against_cpu_oracle": k,
+           "joint_enc_max_diff_vs_fp32_mode": round(dj, 4), "ids_exact_vs_fp32_mode": f"{sum(equal)}/{B}",
+           "local_flips": s["local_flips"], "every_id_difference_starts_at_a_flip": s["every_id_difference_starts_at_a_flip"],
+           "every_flip_obeys_the_lipschitz_bound": all(fl["margin_ref"] <= fl["bound"] * (1 + 1e-9) + 1e-12 for a in audits for fl in a["flips"]),
+           "flip_margin_max": s.get("flip_margin_max")}
+    del m32, b32, enc32
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
