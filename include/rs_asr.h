@@ -180,11 +180,6 @@ int rs_stream_destroy(void* stream);
  *   "decode_narrow"      1 (default): LSTM / prediction-projection kernels with one 16-column tile per workgroup (4x the
  *                        workgroups, a quarter of the per-launch latency on an idle chip); 0 = the wide-tile kernels, which
  *                        need fewer free CUs per launch and do better next to the encoder GEMMs of the two-stage pipeline.
- *   "fold_ln"            1 (default when the "L{i}.att.qkv.wf / .cs / .bf", "L{i}.conv.pw1.wf / .cs / .bf", "L{i}.ff2.w1f / .cs1 / .bf1"
- *                        tensors are registered): the self-attention, conv-module and second-FFN LayerNorms of a block are not
- *                        passes of their own — the residual GEMM in front of each also leaves the raw bf16 rows and their row
- *                        statistics, the GEMM behind it normalises in its epilogue (rs_gemm_bf16_ln).  0 = every LayerNorm is
- *                        a kernel ($RS_FOLD_LN).  Moves one bf16 rounding from the normalised to the raw row.
  *   "precision_f32"      0 (default): the throughput mode — bf16 GEMM operands and stored activations, float32 accumulation,
  *                        float32 residual stream.  1: the PARITY mode — rs_encoder_forward runs with float32 weights,
  *                        activations and arithmetic end to end (exact-f32 matrix-core GEMMs, IEEE exp / divide), which is what
@@ -283,19 +278,6 @@ int rs_gemm_bf16(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int
                  void* out, int ldc, int M, int N, int K, int flags, const float* bias, float alpha,
                  const float* residual, const int32_t* mask_lens, int mask_rows_per_step,
                  int mask_steps, void* stream);
-
-/* The two GEMM forms of a FOLDED LayerNorm (rs_set_option "fold_ln"; no reference counterpart: NeMo runs the norm as its own
- * module).  Linear(LayerNorm(x)) = rstd * (x . W'^T - mean * colsum(W')) + (W . beta + bias) with W' = gamma o W:
- *   producer  rs_gemm_bf16 with a residual output (flags must hold RS_GEMM_RESIDUAL, N % 256 == 0) that ALSO writes
- *             emit_xb bf16 [M][ldc] = the rows it stored, rounded, and emit_part f32 [M][N / 64][2] = (sum, sum of squares) of
- *             every 64-column slice of each row; rs_ln_stats adds the slices up in order: stats f32 [M][2] = (mean, rstd);
- *   consumer  a bf16 / GLU output whose A operand is emit_xb, W the gamma-scaled weight (bf16), bias = W . beta + bias,
- *             ln_colsum f32 [N] = column sums of the ROUNDED scaled weight, ln_stats = the producer's row statistics.
- * Pass NULL for the pair that does not apply.  Results do not depend on M or on the tile height. */
-int rs_gemm_bf16_ln(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int ldw, void* out, int ldc, int M, int N,
-                    int K, int flags, const float* bias, float alpha, const float* residual, uint16_t* emit_xb,
-                    float* emit_part, const float* ln_stats, const float* ln_colsum, void* stream);
-int rs_ln_stats(rs_ctx* ctx, const float* part, int M, int slots, int n_cols, float eps, float* stats, void* stream);
 
 /* The float32 parity mode's operators (rs_set_option "precision_f32"), one by one: the same contracts as rs_gemm_bf16 (flags
  * BIAS / RELU / SILU / RESIDUAL / ROWMASK; K % 32 == 0, N % 4 == 0), rs_relpos_attention (any head_dim <= 256) and

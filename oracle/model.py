@@ -14,10 +14,6 @@ against (HF = transformers/models/parakeet/...).
           chip-fulls of tiles): the conv module's GLU is applied to the float32 accumulators in the pw1 GEMM
           epilogue and ITS output is what gets stored as bf16 (the plain "bf16" recipe rounds the pw1 output and
           applies the GLU in float32 inside the depthwise kernel).
-  "bf16-lnfold"  the product default since round 4 (rs_set_option "fold_ln"): "bf16-fused-glu" with the self-attention,
-          conv-module and second-FFN LayerNorms FOLDED into the GEMMs behind them — the A operand is the RAW residual row
-          rounded to bf16, the weight is gamma o W rounded to bf16, and the epilogue applies
-          rstd * (acc - mean * colsum(W')) + (W . beta + bias) with float32 row statistics (`_linear_lnfold`).
 """
 import math
 from typing import Dict, Optional
@@ -28,7 +24,7 @@ import torch.nn.functional as F
 
 def _rb(x: torch.Tensor, recipe: str) -> torch.Tensor:
     """round to bf16 and back (identity in the fp32 recipe)"""
-    if recipe in ("bf16", "bf16-fused-glu", "bf16-lnfold"):
+    if recipe in ("bf16", "bf16-fused-glu"):
         return x.to(torch.bfloat16).to(torch.float32)
     return x
 
@@ -139,23 +135,9 @@ def _linear(x, sd, name, recipe, bias=True):
     return y + sd[name + ".bias"] if bias else y
 
 
-def _linear_lnfold(cfg, x, w, bias, gamma, beta):
-    """Linear(LayerNorm(x)) the way the folded GEMM computes it (csrc/k_gemm_bf16.hip FOLD epilogue, weights.py
-    fold_layernorm): bf16(x) . bf16(gamma o W)^T with float32 accumulation, then rstd * (acc - mean * cs) + (W . beta + bias);
-    mean / rstd from the float32 row (E[x^2] - mean^2 on the device: the same number to float32 rounding)."""
-    wf = (w * gamma[None, :]).to(torch.bfloat16).to(torch.float32)
-    cs = wf.double().sum(dim=1).float()
-    bf_ = (w.double() @ beta.double() + bias.double()).float()
-    mean = x.mean(dim=-1, keepdim=True)
-    rstd = 1.0 / torch.sqrt(x.var(dim=-1, unbiased=False, keepdim=True) + cfg.ln_eps)
-    acc = x.to(torch.bfloat16).to(torch.float32) @ wf.t()
-    return rstd * (acc - mean * cs) + bf_
-
-
-def feed_forward(cfg, sd, prefix, h, recipe, pre=None):
-    """[UPSTREAM] ConformerFeedForward: Linear -> SiLU -> Linear (HF:109-121).  `pre`: linear1's output when the caller
-    computed it with the LayerNorm folded in."""
-    u = _rb(F.silu(_linear(h, sd, prefix + ".linear1", recipe) if pre is None else pre), recipe)
+def feed_forward(cfg, sd, prefix, h, recipe):
+    """[UPSTREAM] ConformerFeedForward: Linear -> SiLU -> Linear (HF:109-121)."""
+    u = _rb(F.silu(_linear(h, sd, prefix + ".linear1", recipe)), recipe)
     return _linear(u, sd, prefix + ".linear2", recipe)
 
 
@@ -206,39 +188,36 @@ def attention_core(cfg, q, k, v, p, bias_u, bias_v, lens, recipe):
     return _rb(ctx.transpose(1, 2).reshape(B, T, H * dh), recipe)
 
 
-def rel_pos_attention(cfg, sd, prefix, h, pos_tab, lens, recipe, pre=None):
+def rel_pos_attention(cfg, sd, prefix, h, pos_tab, lens, recipe):
     """[UPSTREAM] RelPositionMultiHeadAttention (HF:299-362): q,k,v,pos projections,
     attention_core, linear_out.
 
     bf16 recipe: q,k,v,p stored bf16; (q+u),(q+v) rounded to bf16 (MFMA operands);
     probabilities rounded to bf16 for the PV product while the normaliser sums the
     unrounded values; context stored bf16."""
-    B, T, d = (h if h is not None else pre[0]).shape
+    B, T, d = h.shape
     H, dh = cfg.n_heads, cfg.head_dim
-    if pre is None:
-        pre = [_linear(h, sd, prefix + nm, recipe) for nm in (".linear_q", ".linear_k", ".linear_v")]
-    q, k, v = (_rb(t, recipe).view(B, T, H, dh) for t in pre)
+    q = _rb(_linear(h, sd, prefix + ".linear_q", recipe), recipe).view(B, T, H, dh)
+    k = _rb(_linear(h, sd, prefix + ".linear_k", recipe), recipe).view(B, T, H, dh)
+    v = _rb(_linear(h, sd, prefix + ".linear_v", recipe), recipe).view(B, T, H, dh)
     p = _rb(_linear(_rb(pos_tab, recipe), sd, prefix + ".linear_pos", recipe, bias=False), recipe)
     p = p.view(2 * T - 1, H, dh)
     ctx = attention_core(cfg, q, k, v, p, sd[prefix + ".pos_bias_u"], sd[prefix + ".pos_bias_v"], lens, recipe)
     return _linear(ctx, sd, prefix + ".linear_out", recipe)
 
 
-def conv_module(cfg, sd, prefix, h, lens, recipe, pre=None):
+def conv_module(cfg, sd, prefix, h, lens, recipe):
     """[UPSTREAM] ConformerConvolution (HF:159-193): pw1 -> GLU -> zero padded frames ->
     depthwise k -> BatchNorm (eval) -> SiLU -> pw2.  BatchNorm is folded into the
     depthwise weights exactly like the device weight prep does."""
-    B, T, d = h.shape if h is not None else (pre.shape[0], pre.shape[1], pre.shape[2] // 2)
-    if pre is None:
-        w1 = _rb(sd[prefix + ".pointwise_conv1.weight"].squeeze(-1), recipe)
-        y = h @ w1.t() + sd[prefix + ".pointwise_conv1.bias"]  # [B,T,2d]
-    else:
-        y = pre                              # pw1's output with norm_conv folded in
-    if recipe not in ("bf16-fused-glu", "bf16-lnfold"):
+    B, T, d = h.shape
+    w1 = _rb(sd[prefix + ".pointwise_conv1.weight"].squeeze(-1), recipe)
+    y = h @ w1.t() + sd[prefix + ".pointwise_conv1.bias"]  # [B,T,2d]
+    if recipe != "bf16-fused-glu":
         y = _rb(y, recipe)                   # pw1 output stored bf16, GLU inside the conv kernel (f32, not rounded)
     a, g = y[..., :d], y[..., d:]
     u = a * torch.sigmoid(g)
-    if recipe in ("bf16-fused-glu", "bf16-lnfold"):
+    if recipe == "bf16-fused-glu":
         u = _rb(u, recipe)                   # GLU in the pw1 GEMM epilogue (f32 accumulators), its output stored bf16
     u = u * _len_mask(lens, T)[:, :, None]
     wdw, bdw = fold_batchnorm(cfg, sd, prefix)
@@ -271,15 +250,6 @@ def conformer_layer(cfg, sd, i, x, pos_tab, lens, recipe):
         return _rb(_ln(t, sd[L + name + ".weight"], sd[L + name + ".bias"], eps), recipe)
 
     x = x + 0.5 * feed_forward(cfg, sd, L + "feed_forward1", ln("norm_feed_forward1", x), recipe)
-    if recipe == "bf16-lnfold":
-        def fold(lin, norm, t):
-            w = sd[L + lin + ".weight"]
-            return _linear_lnfold(cfg, t, w.squeeze(-1) if w.dim() == 3 else w, sd[L + lin + ".bias"], sd[L + norm + ".weight"], sd[L + norm + ".bias"])
-        qkv = [fold("self_attn." + nm, "norm_self_att", x) for nm in ("linear_q", "linear_k", "linear_v")]
-        x = x + rel_pos_attention(cfg, sd, L + "self_attn", None, pos_tab, lens, recipe, pre=qkv)
-        x = x + conv_module(cfg, sd, L + "conv", None, lens, recipe, pre=fold("conv.pointwise_conv1", "norm_conv", x))
-        x = x + 0.5 * feed_forward(cfg, sd, L + "feed_forward2", None, recipe, pre=fold("feed_forward2.linear1", "norm_feed_forward2", x))
-        return _ln(x, sd[L + "norm_out.weight"], sd[L + "norm_out.bias"], eps)
     x = x + rel_pos_attention(cfg, sd, L + "self_attn", ln("norm_self_att", x), pos_tab, lens, recipe)
     x = x + conv_module(cfg, sd, L + "conv", ln("norm_conv", x), lens, recipe)
     x = x + 0.5 * feed_forward(cfg, sd, L + "feed_forward2", ln("norm_feed_forward2", x), recipe)

@@ -54,18 +54,11 @@ struct GemmParams {
     const float* res_ln_stats;   // OUT_RESLN: per row (mean, rstd) of the LayerNorm the residual operand still has to go through
     const float* res_ln_g;       //            its weight / bias [N]
     const float* res_ln_b;
-    // LayerNorm folded across a residual GEMM -> norm -> GEMM chain (rs_gemm_args.emit_xb / ln_stats; the header of rs_api.hip):
-    uint16_t* emit_xb;           // EMIT (producer, residual outputs): bf16 copy of the rows this launch writes, [M][ldc]
-    float* emit_part;            //       per row and 64-column wave slice (sum, sum of squares) of those rows: [M][N / 64][2]
-    const float* ln_stats;       // FOLD (consumer, bf16 / GLU outputs): per row (mean, rstd) of the norm between A and this product
-    const float* ln_cs;          //       [N] column sums of the gamma-scaled weight; p.bias then holds W . beta + bias
     int pairs;         // > 0: a workgroup runs two consecutive tiles of its XCD's run (xcd_split); 2: the LDS ring carries over; 0: one tile
     long long* trace;  // debug: per-tile timestamps (scripts/gemm_trace.py); nullptr in production
 };
 
-enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_RES = 2, OUT_GLU = 3, OUT_RESLN = 4,
-       OUT_BF16_FOLD = 5, OUT_GLU_FOLD = 6,         // consumer of a folded LayerNorm: out = rstd * (acc - mean * colsum) + (W . beta + bias)
-       OUT_RES_EMIT = 7, OUT_RESLN_EMIT = 8 };      // producer: also writes the bf16 copy and the per-row partial statistics
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_RES = 2, OUT_GLU = 3, OUT_RESLN = 4 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -90,7 +83,6 @@ __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigne
 }
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 
@@ -119,9 +111,7 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
     // OUT_RESLN: the residual operand is y, the previous layer's output BEFORE its output LayerNorm; that norm is applied
     // here from per-row statistics (layernorm2_kernel writes them instead of the normalised f32 rows: one 145-MB write
     // per layer boundary less), with the arithmetic of the norm kernel: fma((y - mean) * rstd, g, b).
-    constexpr bool EMIT = OUT == OUT_RES_EMIT || OUT == OUT_RESLN_EMIT, FOLD = OUT == OUT_BF16_FOLD || OUT == OUT_GLU_FOLD;
-    constexpr bool RESLN = OUT == OUT_RESLN || OUT == OUT_RESLN_EMIT, RES = OUT == OUT_RES || OUT == OUT_RES_EMIT || RESLN,
-                   out_f32 = OUT == OUT_F32 || RES, GLU = OUT == OUT_GLU || OUT == OUT_GLU_FOLD, rowmask = MASK;
+    constexpr bool RESLN = OUT == OUT_RESLN, RES = OUT == OUT_RES || RESLN, out_f32 = OUT == OUT_F32 || RES, GLU = OUT == OUT_GLU, rowmask = MASK;
     constexpr int TM = MI * 16, TN = NI * 16;
     constexpr unsigned OOB = 0xfffffff0u;                         // beyond every buffer: loads return 0, stores are dropped
     const int frow = lane & 15, fch = lane >> 4;
@@ -138,37 +128,15 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
                                                              has_bias ? p.N * 4 : 0, 0x00020000);
     const int wrow0 = cm0 + wm * TM, wcol0 = cn0 + wn * TN;
     float4 bias_r[NI];
-    float4 cs_r[FOLD ? NI : 1];
-    const auto cs_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FOLD ? p.ln_cs : (const float*)p.out), 0, FOLD ? p.N * 4 : 0, 0x00020000);
-    const auto lst_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FOLD ? p.ln_stats : (const float*)p.out), 0, FOLD ? p.M * 8 : 0, 0x00020000);
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) {
         const int n = wcol0 + jj * 16 + 4 * fch;
         const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(bias_rsrc, (unsigned)n * 4u, 0, 0);   // no bias / n >= N: zeros
         bias_r[jj] = __builtin_bit_cast(float4, b);
-        if constexpr (FOLD) cs_r[jj] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cs_rsrc, (unsigned)n * 4u, 0, 0));
-    }
-    // FOLD: (mean, rstd) of the rows of accumulator block i (row wrow0 + i * 16 + frow); rows past M read zeros (never stored)
-    float2 lst[FOLD ? MI : 1];
-    if constexpr (FOLD) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = wrow0 + i * 16 + frow;
-            lst[i] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(lst_rsrc, m < p.M ? (unsigned)m * 8u : OOB, 0, 0));
-        }
     }
     auto finish = [&](int i, int jj) -> float4 {
-        float4 v;
-        if constexpr (FOLD) {
-            // LayerNorm(x) . W^T + b  =  rstd * (x . W'^T - mean * colsum(W')) + (W . beta + b),  W' = gamma o W: the raw bf16 rows of the
-            // residual stream are the A operand, the normalisation is two fmas here
-            const float nm = -lst[i].x, rs = lst[i].y;
-            v = make_float4(fmaf(rs, fmaf(nm, cs_r[jj].x, acc[i][jj][0]), bias_r[jj].x), fmaf(rs, fmaf(nm, cs_r[jj].y, acc[i][jj][1]), bias_r[jj].y),
-                            fmaf(rs, fmaf(nm, cs_r[jj].z, acc[i][jj][2]), bias_r[jj].z), fmaf(rs, fmaf(nm, cs_r[jj].w, acc[i][jj][3]), bias_r[jj].w));
-        } else {
-            v = make_float4(acc[i][jj][0] + bias_r[jj].x, acc[i][jj][1] + bias_r[jj].y, acc[i][jj][2] + bias_r[jj].z,
-                            acc[i][jj][3] + bias_r[jj].w);
-        }
+        float4 v = make_float4(acc[i][jj][0] + bias_r[jj].x, acc[i][jj][1] + bias_r[jj].y, acc[i][jj][2] + bias_r[jj].z,
+                               acc[i][jj][3] + bias_r[jj].w);
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
         v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
@@ -247,8 +215,6 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
         float4 ln_g = make_float4(0.f, 0.f, 0.f, 0.f), ln_b = ln_g;
         const auto st_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RESLN ? p.res_ln_stats : (const float*)p.out), 0,
                                                                RESLN ? p.M * 8 : 0, 0x00020000);
-        const auto xb_rsrc = __builtin_amdgcn_make_buffer_rsrc(EMIT ? (void*)p.emit_xb : p.out, 0, EMIT ? (int)(out_bytes >> 1) : 0, 0x00020000);
-        const auto part_rsrc = __builtin_amdgcn_make_buffer_rsrc(EMIT ? (void*)p.emit_part : p.out, 0, EMIT ? p.M * (p.N >> 6) * 8 : 0, 0x00020000);
         if constexpr (RESLN) {
             const int n = wcol0 + cc * 4;
             if (n < p.N) {
@@ -302,18 +268,6 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
                 if (!row_keep(m)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), out_rsrc, off, 0, 0);
-                if constexpr (EMIT) {
-                    // the next GEMM's A operand: the same rows rounded to bf16, and what its folded LayerNorm needs of them —
-                    // (sum, sum of squares) of this wave's 64 columns per row, reduced over the 16 lanes that hold the row in a
-                    // fixed order (the slices are added up, in order, by ln_stats_kernel): independent of M and of the tile height
-                    const u16x4_t hb = pack_bf16x4(v.x, v.y, v.z, v.w);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, hb), xb_rsrc, off == OOB ? OOB : off >> 1, 0, 0);
-                    float s1 = (v.x + v.y) + (v.z + v.w), s2 = fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                    const unsigned offp = (cc == 0 && m < p.M && n < p.N) ? ((unsigned)m * (unsigned)(p.N >> 6) + (unsigned)(wcol0 >> 6)) * 8u : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){__float_as_uint(s1), __float_as_uint(s2)}, part_rsrc, offp, 0, 0);
-                }
             }
             if constexpr (RES) {
                 if (i + NPF < MI) load_res(i + NPF, rvq[i % NPF], stq[i % NPF]);   // refill the slot this chunk just consumed
@@ -639,9 +593,7 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     // K = 4096 and 6 below; one-tile-wide problems (the subsampling GEMMs) 16; everything else is flat from 6 up
     p.group_m = g_group_m.load() > 0 ? g_group_m.load()
               : (p.tiles_n == 4 ? (p.K >= 4096 ? 2 : 6) : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8)));
-    int out = (p.flags & RS_GEMM_RESIDUAL) ? (p.res_ln_stats ? OUT_RESLN : OUT_RES) : ((p.flags & RS_GEMM_OUT_F32) ? OUT_F32 : ((p.flags & RS_GEMM_GLU) ? OUT_GLU : OUT_BF16));
-    if (p.emit_xb) out = out == OUT_RESLN ? OUT_RESLN_EMIT : OUT_RES_EMIT;
-    if (p.ln_stats) out = out == OUT_GLU ? OUT_GLU_FOLD : OUT_BF16_FOLD;
+    const int out = (p.flags & RS_GEMM_RESIDUAL) ? (p.res_ln_stats ? OUT_RESLN : OUT_RES) : ((p.flags & RS_GEMM_OUT_F32) ? OUT_F32 : ((p.flags & RS_GEMM_GLU) ? OUT_GLU : OUT_BF16));
     const bool mask = p.flags & RS_GEMM_ROWMASK;
 #define RS_SMF(O, MK, TR)                                                                                          \
     do {                                                                                                           \
@@ -664,11 +616,7 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     else if (out == OUT_BF16 && !mask) RS_SMF(OUT_BF16, false, false);
     else if (out == OUT_BF16 && mask) RS_SMF(OUT_BF16, true, false);
     else if (out == OUT_GLU && !mask) RS_SMF(OUT_GLU, false, false);
-    else if (out == OUT_BF16_FOLD && !mask) RS_SMF(OUT_BF16_FOLD, false, false);
-    else if (out == OUT_GLU_FOLD && !mask) RS_SMF(OUT_GLU_FOLD, false, false);
-    else if (out == OUT_RES_EMIT && !mask) RS_SMF(OUT_RES_EMIT, false, false);
-    else if (out == OUT_RESLN_EMIT && !mask) RS_SMF(OUT_RESLN_EMIT, false, false);
-    else return rs_fail(ctx, RS_EINVAL, "gemm: the row mask combines with plain bf16 output only");
+    else return rs_fail(ctx, RS_EINVAL, "gemm: the row mask combines with bf16 output only");
 #undef RS_SMF
     return RS_OK;
 }
@@ -742,15 +690,6 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
             return rs_fail(ctx, RS_EINVAL, "gemm: GLU combines with a bias only");
         if ((a.N % 64) || a.alpha != 1.0f) return rs_fail(ctx, RS_EINVAL, "gemm: GLU needs N %% 64 == 0 and alpha == 1 (N=%d)", a.N);
     }
-    if (a.emit_xb || a.emit_part) {
-        if (!a.emit_xb || !a.emit_part || !(a.flags & RS_GEMM_RESIDUAL) || (a.N % 256) || ((uintptr_t)a.emit_xb & 15) || ((uintptr_t)a.emit_part & 7))
-            return rs_fail(ctx, RS_EINVAL, "gemm: the LayerNorm-fold producer needs a residual output, N %% 256 == 0, both emit buffers, aligned");
-    }
-    if (a.ln_stats || a.ln_cs) {
-        if (!a.ln_stats || !a.ln_cs || !(a.flags & RS_GEMM_BIAS) || f32 || (a.flags & (RS_GEMM_ROWMASK | RS_GEMM_RELU)) || ((uintptr_t)a.ln_stats & 7) ||
-            ((uintptr_t)a.ln_cs & 15))
-            return rs_fail(ctx, RS_EINVAL, "gemm: the LayerNorm-fold consumer is a bf16 / GLU output with the folded bias and column sums, aligned");
-    }
     if ((size_t)a.N * a.ldw * 2 >= (1ull << 32)) return rs_fail(ctx, RS_EINVAL, "gemm: weight matrix beyond 4 GiB");
     gemm_knobs_from_env();
     if (ctx->n_cus <= 0) {
@@ -780,9 +719,6 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         p.out = reinterpret_cast<char*>(a.out) + r0 * out_row;
         p.bias = a.bias; p.residual = a.residual ? a.residual + r0 * a.ldc : nullptr; p.mask_lens = a.mask_lens;
         p.res_ln_stats = a.res_ln_stats ? a.res_ln_stats + r0 * 2 : nullptr; p.res_ln_g = a.res_ln_g; p.res_ln_b = a.res_ln_b;
-        p.emit_xb = a.emit_xb ? a.emit_xb + r0 * a.ldc : nullptr;
-        p.emit_part = a.emit_part ? a.emit_part + r0 * (size_t)(a.N >> 6) * 2 : nullptr;
-        p.ln_stats = a.ln_stats ? a.ln_stats + r0 * 2 : nullptr; p.ln_cs = a.ln_cs;
         p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.M = (int)rows; p.N = a.N; p.K = a.K; p.flags = a.flags;
         p.alpha = a.alpha; p.mask_rows_per_step = a.mask_rows_per_step; p.mask_steps = a.mask_steps; p.mask_row0 = (int)r0;
         p.tiles_m = p.tiles_n = 0; p.group_m = 1;

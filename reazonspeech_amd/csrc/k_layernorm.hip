@@ -362,20 +362,6 @@ __global__ __launch_bounds__(256) void dwconv_silu_dma_kernel(const uint16_t* __
     }
 }
 
-// folded LayerNorm (k_gemm_bf16.hip EMIT / FOLD): per-row (sum, sum of squares) over `slots` 64-column slices, added up in
-// slice order -> (mean, rstd).  var = E[x^2] - mean^2 in float32 (|mean| << std on the residual stream), clamped at 0.
-__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ part, int M, int slots, float inv_n, float eps,
-                                                       float* __restrict__ stats) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
-    const float2* p = reinterpret_cast<const float2*>(part) + (size_t)m * slots;
-    float s1 = 0.0f, s2 = 0.0f;
-    for (int k = 0; k < slots; ++k) { const float2 v = p[k]; s1 += v.x; s2 += v.y; }
-    const float mean = s1 * inv_n;
-    const float var = fmaxf(fmaf(-mean, mean, s2 * inv_n), 0.0f);
-    *reinterpret_cast<float2*>(stats + (size_t)m * 2) = make_float2(mean, 1.0f / sqrtf(var + eps));
-}
-
 int g_glu_generic = 0;
 
 }  // namespace
@@ -448,15 +434,5 @@ int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, int layout, const float
     }
     rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
     RS_CHECK_LAUNCH(ctx, "glu_dwconv_silu");
-    return RS_OK;
-}
-
-int rs_launch_ln_stats(rs_ctx* ctx, const float* part, int M, int slots, int n_cols, float eps, float* stats, hipStream_t s) {
-    if (M <= 0) return RS_OK;
-    if (slots <= 0 || n_cols <= 0) return rs_fail(ctx, RS_EINVAL, "ln_stats: empty row");
-    rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, 2.0 * M * slots, (double)M * (slots * 8.0 + 8.0));
-    hipLaunchKernelGGL(ln_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, s, part, M, slots, 1.0f / (float)n_cols, eps, stats);
-    rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
-    RS_CHECK_LAUNCH(ctx, "ln_stats");
     return RS_OK;
 }

@@ -234,21 +234,7 @@ int rs_finalize(rs_ctx* ctx) {
             if (const char* nw = getenv("RS_DECODE_NARROW")) ctx->decode_narrow = atoi(nw) != 0;   // 0 = the wide-tile kernels of round 1
             if (const char* fg = getenv("RS_FUSE_GLU")) ctx->fuse_glu = atoi(fg) != 0;             // 0 = GLU in the conv kernel
             if (const char* dn = getenv("RS_DEFER_OUT_NORM")) ctx->defer_out_norm = atoi(dn) != 0; // 0 = every output norm stores its f32 rows
-            if (const char* fl = getenv("RS_FOLD_LN")) ctx->fold_ln = atoi(fl) != 0;               // 0 = every LayerNorm is its own pass
         }
-    }
-    // optional: the LayerNorm-fold tensors of every layer (weights.py fold_layernorm).  All or none.
-    ctx->has_fold = false;
-    if (ctx->tensors.count("L0.att.qkv.wf")) {
-        for (int i = 0; i < d.n_layers; ++i) {
-            rs_layer_w& L = ctx->layers[i];
-            const std::string p = "L" + std::to_string(i) + ".";
-            r.get(p + "att.qkv.wf", 3 * dm * dm, L.qkv_wf); r.get(p + "att.qkv.cs", 3 * dm, L.qkv_cs); r.get(p + "att.qkv.bf", 3 * dm, L.qkv_bf);
-            r.get(p + "conv.pw1.wf", 2 * dm * dm, L.pw1_wf); r.get(p + "conv.pw1.cs", 2 * dm, L.pw1_cs); r.get(p + "conv.pw1.bf", 2 * dm, L.pw1_bf);
-            r.get(p + "ff2.w1f", ff * dm, L.ff2_w1f); r.get(p + "ff2.cs1", ff, L.ff2_cs1); r.get(p + "ff2.bf1", ff, L.ff2_bf1);
-        }
-        if (r.rc != RS_OK) return r.rc;
-        ctx->has_fold = (dm % 256) == 0;
     }
     // optional: the float32 parity mode's dense weights ("<name>.f32", unrounded, the layouts of the bf16 tensors except
     // conv.pw1, which keeps NeMo's own row order) and its position table.  All or none.
@@ -329,7 +315,6 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
         return RS_OK;
     }
     if (!strcmp(key, "defer_out_norm")) { ctx->defer_out_norm = value != 0; return RS_OK; }
-    if (!strcmp(key, "fold_ln")) { ctx->fold_ln = value != 0; return RS_OK; }
     if (!strcmp(key, "precision_f32")) {
         if (value && !ctx->has_f32)
             return rs_fail(ctx, RS_EMISSING, "precision_f32: the float32 weights (\"*.f32\" tensors) are not registered / rs_finalize has not run");
@@ -371,7 +356,7 @@ namespace {
 
 struct EncPlan {
     int T[5], F[5];  // per stage time / freq extents (index 0 = mel)
-    size_t off_lens, off_sa, off_sb, off_x, off_hn, off_big, off_ctx, off_posp, off_stats, off_col, off_ctc, off_fstats, off_fpart, total;
+    size_t off_lens, off_sa, off_sb, off_x, off_hn, off_big, off_ctx, off_posp, off_stats, off_col, off_ctc, total;
     int chunk;       // Conv2dSubsampling: utterances per pass of conv0 / patch gather / dense-conv GEMM
 };
 
@@ -413,8 +398,6 @@ EncPlan plan_encoder(const rs_ctx* ctx, int B, int t_max) {
     p.off_stats = o; o += rs_align(M * 2 * 4);          // (mean, rstd) per row of a deferred output norm
     p.off_ctc = o;
     if (d.ctc_vocab > 0) o += rs_align(M * (size_t)d.ctc_vocab * 4);   // CTC logits when only the blank column is wanted
-    p.off_fstats = o; o += rs_align(M * 2 * 4);                          // fold_ln: (mean, rstd) per row of the norm being folded
-    p.off_fpart = o; o += rs_align(M * (dm / 64 + 1) * 2 * 4);           //          (sum, sum of squares) per row and 64-column slice
     p.total = o + 256;
     return p;
 }
@@ -555,35 +538,10 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         if (res && res_ln) { g.res_ln_stats = ln_stats; g.res_ln_g = res_ln->ln_out_g; g.res_ln_b = res_ln->ln_out_b; res_ln = nullptr; }
         return rs_launch_gemm(ctx, g, s);
     };
+    const int RES = RS_GEMM_BIAS | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32;
     // fuse_glu (default 1): the GLU is applied to the float32 pw1 accumulators in the GEMM epilogue for EVERY batch
     // size — one rounding point, so an utterance's arithmetic does not depend on the batch it rides in
     const bool glu_fused = ctx->fuse_glu != 0 && (dm % 32) == 0;
-    const int RES = RS_GEMM_BIAS | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32;
-    // fold_ln: the three inner LayerNorms of a block are not passes of their own.  The residual GEMM in front of each (the
-    // producer) also writes the bf16 copy of the rows it updates into `hn` and, per row and 64-column slice, their (sum, sum
-    // of squares); ln_stats_kernel turns those into (mean, rstd); the GEMM behind the norm (the consumer) multiplies the RAW
-    // bf16 rows by the gamma-scaled weight and normalises in its epilogue:
-    //     Linear(LayerNorm(x)) = rstd * (x . W'^T - mean * colsum(W')) + (W . beta + bias)
-    // One 145-MB read of x per folded norm less (the LayerNorm kernels run at the HBM roofline: removing a pass is the only
-    // lever left on them).  The rounding point moves from the normalised row to the raw row: oracle recipe "bf16-lnfold".
-    const bool fold = ctx->fold_ln != 0 && ctx->has_fold && glu_fused;
-    float* fstats = reinterpret_cast<float*>(ws + pl.off_fstats);
-    float* fpart = reinterpret_cast<float*>(ws + pl.off_fpart);
-    auto gemm_emit = [&](const uint16_t* A, int lda, const uint16_t* W, int K, const float* bias, float alpha) -> int {   // x += alpha * (A . W^T + bias)
-        rs_gemm_args g{};
-        g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.out = x; g.ldc = dm; g.M = M; g.N = dm; g.K = K;
-        g.flags = RES; g.bias = bias; g.alpha = alpha; g.residual = x;
-        if (res_ln) { g.res_ln_stats = ln_stats; g.res_ln_g = res_ln->ln_out_g; g.res_ln_b = res_ln->ln_out_b; res_ln = nullptr; }
-        g.emit_xb = hn; g.emit_part = fpart;
-        if (int rc2 = rs_launch_gemm(ctx, g, s); rc2 != RS_OK) return rc2;
-        return rs_launch_ln_stats(ctx, fpart, M, dm / 64, dm, d.ln_eps, fstats, s);
-    };
-    auto gemm_fold = [&](const uint16_t* Wf, const float* cs, const float* bfold, void* out, int ldc, int N, int flags) -> int {
-        rs_gemm_args g{};
-        g.A = hn; g.lda = dm; g.W = Wf; g.ldw = dm; g.out = out; g.ldc = ldc; g.M = M; g.N = N; g.K = dm;
-        g.flags = flags | RS_GEMM_BIAS; g.bias = bfold; g.alpha = 1.0f; g.ln_stats = fstats; g.ln_cs = cs;
-        return rs_launch_gemm(ctx, g, s);
-    };
 
     for (int i = 0; i < d.n_layers; ++i) {
         const rs_layer_w& L = ctx->layers[i];
@@ -591,26 +549,14 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         // 1/2 FFN  (layers > 0: hn was produced by the previous layer's fused output-norm kernel)
         if (i == 0) RS_TRY(rs_launch_layernorm(ctx, x, L.ln_ff1_g, L.ln_ff1_b, M, dm, d.ln_eps, hn, nullptr, s));
         RS_TRY(gemm(hn, dm, L.ff1_w1, dm, big, ff, M, ff, RS_GEMM_BIAS | RS_GEMM_SILU, L.ff1_b1, 1.0f, nullptr));
-        if (fold) {
-            RS_TRY(gemm_emit(big, ff, L.ff1_w2, ff, L.ff1_b2, 0.5f));
-            RS_TRY(gemm_fold(L.qkv_wf, L.qkv_cs, L.qkv_bf, big, 3 * dm, 3 * dm, 0));
-        } else {
         RS_TRY(gemm(big, ff, L.ff1_w2, ff, x, dm, M, dm, RES, L.ff1_b2, 0.5f, x));
         // rel-pos MHSA
         RS_TRY(rs_launch_layernorm(ctx, x, L.ln_att_g, L.ln_att_b, M, dm, d.ln_eps, hn, nullptr, s));
         RS_TRY(gemm(hn, dm, L.qkv_w, dm, big, 3 * dm, M, 3 * dm, RS_GEMM_BIAS, L.qkv_b, 1.0f, nullptr));
-        }
         const uint16_t* pproj = posp;
         if (L.pos_proj) pproj = L.pos_proj + (size_t)(tcap - Tp) * dm;      // rows of the pre-projected table
         else RS_TRY(gemm(pos_slice, dm, L.pos_w, dm, posp, dm, npos, dm, 0, nullptr, 1.0f, nullptr));
         RS_TRY(rs_launch_attention(ctx, big, pproj, L.bias_u, L.bias_v, lens, B, Tp, ctxb, s));
-        if (fold) {
-            RS_TRY(gemm_emit(ctxb, dm, L.out_w, dm, L.out_b, 1.0f));
-            RS_TRY(gemm_fold(L.pw1_wf, L.pw1_cs, L.pw1_bf, big, dm, 2 * dm, RS_GEMM_GLU));
-            RS_TRY(rs_launch_glu_dwconv(ctx, big, RS_GLU_APPLIED, L.dw_w, L.dw_b, lens, B, Tp, dm, d.conv_kernel, ctxb, s));
-            RS_TRY(gemm_emit(ctxb, dm, L.pw2_w, dm, L.pw2_b, 1.0f));
-            RS_TRY(gemm_fold(L.ff2_w1f, L.ff2_cs1, L.ff2_bf1, big, ff, ff, RS_GEMM_SILU));
-        } else {
         RS_TRY(gemm(ctxb, dm, L.out_w, dm, x, dm, M, dm, RES, L.out_b, 1.0f, x));
         // conv module
         RS_TRY(rs_launch_layernorm(ctx, x, L.ln_conv_g, L.ln_conv_b, M, dm, d.ln_eps, hn, nullptr, s));
@@ -628,7 +574,6 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         // 1/2 FFN
         RS_TRY(rs_launch_layernorm(ctx, x, L.ln_ff2_g, L.ln_ff2_b, M, dm, d.ln_eps, hn, nullptr, s));
         RS_TRY(gemm(hn, dm, L.ff2_w1, dm, big, ff, M, ff, RS_GEMM_BIAS | RS_GEMM_SILU, L.ff2_b1, 1.0f, nullptr));
-        }
         RS_TRY(gemm(big, ff, L.ff2_w2, ff, x, dm, M, dm, RES, L.ff2_b2, 0.5f, x));
         // output norm (in place on the residual stream; the last layer also emits the bf16 copy
         // that feeds the joint's encoder projection)
@@ -769,23 +714,6 @@ int rs_gemm_bf16(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int
     if (!A || !W || !out) return rs_fail(ctx, RS_EINVAL, "gemm: null pointer");
     rs_gemm_args g{A, lda, W, ldw, out, ldc, M, N, K, flags, bias, alpha, residual, mask_lens, mask_rows_per_step, mask_steps};
     return rs_launch_gemm(ctx, g, (hipStream_t)stream);
-}
-
-int rs_gemm_bf16_ln(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int ldw, void* out, int ldc, int M, int N, int K,
-                    int flags, const float* bias, float alpha, const float* residual, uint16_t* emit_xb, float* emit_part,
-                    const float* ln_stats, const float* ln_colsum, void* stream) {
-    if (!ctx) return RS_EINVAL;
-    if (M == 0 || N == 0) return RS_OK;
-    if (!A || !W || !out) return rs_fail(ctx, RS_EINVAL, "gemm: null pointer");
-    rs_gemm_args g{A, lda, W, ldw, out, ldc, M, N, K, flags, bias, alpha, residual, nullptr, 0, 0};
-    g.emit_xb = emit_xb; g.emit_part = emit_part; g.ln_stats = ln_stats; g.ln_cs = ln_colsum;
-    return rs_launch_gemm(ctx, g, (hipStream_t)stream);
-}
-
-int rs_ln_stats(rs_ctx* ctx, const float* part, int M, int slots, int n_cols, float eps, float* stats, void* stream) {
-    if (!ctx) return RS_EINVAL;
-    if (!part || !stats) return rs_fail(ctx, RS_EINVAL, "ln_stats: null pointer");
-    return rs_launch_ln_stats(ctx, part, M, slots, n_cols, eps, stats, (hipStream_t)stream);
 }
 
 int rs_gemm_f32(rs_ctx* ctx, const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K, int flags,

@@ -68,9 +68,6 @@ struct rs_layer_w {
     const uint16_t *ff1_w1, *ff1_w2, *ff2_w1, *ff2_w2, *qkv_w, *out_w, *pos_w, *pw1_w, *pw2_w;
     const float *ff1_b1, *ff1_b2, *ff2_b1, *ff2_b2, *qkv_b, *out_b, *bias_u, *bias_v, *pw1_b, *pw2_b;
     const float *dw_w, *dw_b;
-    // optional "fold_ln" tensors: gamma-scaled weights, their column sums, W . beta + bias (weights.py fold_layernorm); all or none
-    const uint16_t *qkv_wf = nullptr, *pw1_wf = nullptr, *ff2_w1f = nullptr;
-    const float *qkv_cs = nullptr, *qkv_bf = nullptr, *pw1_cs = nullptr, *pw1_bf = nullptr, *ff2_cs1 = nullptr, *ff2_bf1 = nullptr;
     const uint16_t* pos_proj;   // optional "L{i}.att.pos_proj": pos.table @ pos_w^T, bf16 [2*Tcap-1][d]; nullptr = project per call
 };
 
@@ -130,8 +127,6 @@ struct rs_ctx {
     int defer_out_norm = 1;         // 1 = a layer's output norm is applied by the next layer's first residual GEMM (f32 rows not stored); bit-identical to 0
     int fuse_glu = 1;               // conv module: 1 = GLU in the pw1 GEMM epilogue (every batch size: one rounding point, batch-invariant);
                                     // 0 = plain pw1 product, GLU in the depthwise kernel ($RS_FUSE_GLU; A/B and layout tests)
-    bool has_fold = false;          // the "fold_ln" tensors are registered (all layers)
-    int fold_ln = 1;                // 1 (default, when has_fold): the self-attention / conv / second-FFN LayerNorms are folded into the GEMMs around them
     bool has_f32 = false;           // the "*.f32" tensors of the float32 parity mode are registered (all or none)
     int precision_f32 = 0;          // rs_set_option("precision_f32"): 1 = rs_encoder_forward runs k_f32.hip's float32 encoder
     rs_f32_weights f32;
@@ -189,15 +184,7 @@ struct rs_gemm_args {
     // residual = LayerNorm(residual operand; res_ln_g, res_ln_b) with per-row (mean, rstd) in res_ln_stats [M][2]
     // (nullptr: the residual operand is used as it is)
     const float* res_ln_stats; const float* res_ln_g; const float* res_ln_b;
-    // LayerNorm folded across "residual GEMM -> LayerNorm -> GEMM" (fold_ln, rs_api.hip):
-    //   producer (a residual output, N % 256 == 0): emit_xb [M][ldc] receives the bf16 copy of the rows written, emit_part
-    //   [M][N / 64][2] the per-row (sum, sum of squares) of each 64-column slice; rs_launch_ln_stats turns them into (mean, rstd)
-    uint16_t* emit_xb; float* emit_part;
-    //   consumer (bf16 / GLU output): A = those raw bf16 rows, W = gamma-scaled weight, bias = W . beta + bias, ln_cs = column sums
-    //   of the scaled weight, ln_stats [M][2] = (mean, rstd): out = act(rstd * (acc - mean * cs) + bias)
-    const float* ln_stats; const float* ln_cs;
 };
-int rs_launch_ln_stats(rs_ctx* ctx, const float* part, int M, int slots, int n_cols, float eps, float* stats, hipStream_t s);
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s);
 int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float* b, int M, int d, float eps,
                         uint16_t* out_bf16, float* out_f32, hipStream_t s);

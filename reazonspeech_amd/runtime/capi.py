@@ -30,7 +30,6 @@ EXPORTS = [
     "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_glu_dwconv_silu_layout", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
     "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes", "rs_host_stage_rows",
     "rs_gemm_f32", "rs_relpos_attention_f32", "rs_glu_dwconv_silu_f32", "rs_profile_read_launches", "rs_encoder_set_ctc_out",
-    "rs_gemm_bf16_ln", "rs_ln_stats",
 ]
 
 
@@ -122,8 +121,6 @@ def load():
     lib.rs_relpos_attention_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp]
     lib.rs_glu_dwconv_silu_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
     lib.rs_encoder_set_ctc_out.argtypes = [vp, vp, vp]
-    lib.rs_gemm_bf16_ln.argtypes = [vp, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp, c_float, vp, vp, vp, vp, vp, vp]
-    lib.rs_ln_stats.argtypes = [vp, vp, c_int, c_int, c_int, c_float, vp, vp]
     if lib.rs_abi_version() != 3:
         raise ImportError("librs_asr.so ABI version mismatch")
     _lib = lib
@@ -327,19 +324,6 @@ class Context:
         self.check(self.lib.rs_gemm_bf16(self._h, _ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(out),
                                          out.stride(0), M, N, K, flags, _ptr(bias), float(alpha), _ptr(residual),
                                          _ptr(mask_lens), mask_rows, mask_steps, c_void_p(stream)))
-
-    def gemm_ln(self, A, W, out, flags=0, bias=None, alpha=1.0, residual=None, emit_xb=None, emit_part=None, ln_stats=None,
-                ln_colsum=None, stream=0):
-        """the producer / consumer GEMM forms of a folded LayerNorm (include/rs_asr.h: rs_gemm_bf16_ln)"""
-        M, K = A.shape
-        N = W.shape[0]
-        self.check(self.lib.rs_gemm_bf16_ln(self._h, _ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(out), out.stride(0), M, N, K,
-                                            flags, _ptr(bias), float(alpha), _ptr(residual), _ptr(emit_xb), _ptr(emit_part),
-                                            _ptr(ln_stats), _ptr(ln_colsum), c_void_p(stream)))
-
-    def ln_stats(self, part, n_cols, eps, stats, stream=0):
-        M, slots = part.shape[0], part.shape[1]
-        self.check(self.lib.rs_ln_stats(self._h, _ptr(part), M, slots, int(n_cols), float(eps), _ptr(stats), c_void_p(stream)))
 
     def gemm_f32(self, A, W, out, flags=0, bias=None, alpha=1.0, residual=None, mask_lens=None, mask_rows=0, mask_steps=0,
                  stream=0):

@@ -322,17 +322,6 @@ def glu_interleave_index(d: int) -> torch.Tensor:
     return torch.cat([32 * j + r, d + 32 * j + r], dim=1).reshape(-1)
 
 
-def fold_layernorm(w: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
-    """LayerNorm folded into the Linear that consumes it (rs_set_option "fold_ln"; k_gemm_bf16.hip FOLD epilogue):
-        Linear(LayerNorm(x)) = rstd * (x . W'^T - mean * colsum(W')) + (W . beta + bias),   W' = gamma o W
-    -> (W' as bf16 [N][K], colsum of the ROUNDED W' float32 [N] — it must cancel the mean of exactly the products the
-    matrix cores form —, folded bias float32 [N] from the unrounded W in float64)."""
-    wf = (w.detach().to(torch.float32) * gamma.detach().to(torch.float32)[None, :]).to(torch.bfloat16).contiguous()
-    cs = wf.to(torch.float64).sum(dim=1).to(torch.float32).contiguous()
-    bf_ = (w.detach().to(torch.float64) @ beta.detach().to(torch.float64) + bias.detach().to(torch.float64)).to(torch.float32).contiguous()
-    return wf, cs, bf_
-
-
 def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int = DEFAULT_POS_CAP, f32: bool = False):
     """-> dict name -> CPU torch tensor (float32 / bfloat16 / int32) exactly as registered with
     rs_set_tensor (DESIGN.md "Weights in HBM").  Host-side transforms, all one-off:
@@ -424,15 +413,6 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
         out[p + "att.qkv.b"] = f32(torch.cat([sd[A + "linear_q.bias"], sd[A + "linear_k.bias"],
                                               sd[A + "linear_v.bias"]], dim=0))
         dense(p + "att.out.w", sd[A + "linear_out.weight"])
-        # the three inner norms of a block (self-attention, conv module, second FFN) folded into the GEMMs that consume them
-        # ("fold_ln": the producing residual GEMM leaves the raw bf16 rows and their statistics, no LayerNorm pass in between)
-        qkv_w = torch.cat([sd[A + "linear_q.weight"], sd[A + "linear_k.weight"], sd[A + "linear_v.weight"]], dim=0)
-        qkv_b = torch.cat([sd[A + "linear_q.bias"], sd[A + "linear_k.bias"], sd[A + "linear_v.bias"]], dim=0)
-        out[p + "att.qkv.wf"], out[p + "att.qkv.cs"], out[p + "att.qkv.bf"] = fold_layernorm(
-            qkv_w, qkv_b, sd[L + "norm_self_att.weight"], sd[L + "norm_self_att.bias"])
-        out[p + "ff2.w1f"], out[p + "ff2.cs1"], out[p + "ff2.bf1"] = fold_layernorm(
-            sd[L + "feed_forward2.linear1.weight"], sd[L + "feed_forward2.linear1.bias"], sd[L + "norm_feed_forward2.weight"],
-            sd[L + "norm_feed_forward2.bias"])
         out[p + "att.out.b"] = f32(sd[A + "linear_out.bias"])
         dense(p + "att.pos.w", sd[A + "linear_pos.weight"])
         out[p + "att.bias_u"] = f32(sd[A + "pos_bias_u"].reshape(-1))
@@ -443,9 +423,6 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
         glu_rows = glu_interleave_index(cfg.d_model)
         out[p + "conv.pw1.w"] = bf(sd[Cm + "pointwise_conv1.weight"].squeeze(-1)[glu_rows])
         out[p + "conv.pw1.b"] = f32(sd[Cm + "pointwise_conv1.bias"][glu_rows])
-        wf, cs, bfold = fold_layernorm(sd[Cm + "pointwise_conv1.weight"].squeeze(-1), sd[Cm + "pointwise_conv1.bias"],
-                                       sd[L + "norm_conv.weight"], sd[L + "norm_conv.bias"])
-        out[p + "conv.pw1.wf"], out[p + "conv.pw1.cs"], out[p + "conv.pw1.bf"] = wf[glu_rows].contiguous(), cs[glu_rows].contiguous(), bfold[glu_rows].contiguous()
         if want_f32:
             out[p + "conv.pw1.w.f32"] = f32(sd[Cm + "pointwise_conv1.weight"].squeeze(-1))
             out[p + "conv.pw1.b.f32"] = f32(sd[Cm + "pointwise_conv1.bias"])

@@ -102,34 +102,6 @@ def test_bf16_recipe_stays_close_to_fp32(gold, sd):
         assert 0 < (f16[b, :n] - f16g[b, :n]).abs().max() <= 0.05
 
 
-def test_lnfold_recipe_is_the_same_model():
-    """the "bf16-lnfold" recipe (the inner LayerNorms folded into the GEMMs behind them: oracle/model.py _linear_lnfold,
-    weights.py fold_layernorm) is algebraically the same network: in float64 the folded form equals Linear(LayerNorm(x)), and
-    as a bf16 recipe it sits as close to the fp32 oracle as the un-folded recipe does"""
-    g = torch.Generator().manual_seed(4)
-    x = 30.0 * torch.randn((7, 256), generator=g, dtype=torch.float64) + 3.0
-    w = torch.randn((64, 256), generator=g, dtype=torch.float64) / 16
-    b, gamma, beta = torch.randn((64,), generator=g, dtype=torch.float64), 1 + 0.1 * torch.randn((256,), generator=g, dtype=torch.float64), \
-        0.1 * torch.randn((256,), generator=g, dtype=torch.float64)
-    ref = torch.nn.functional.layer_norm(x, (256,), gamma, beta, TINY.ln_eps) @ w.t() + b
-    wf = w * gamma[None, :]
-    mean, rstd = x.mean(-1, keepdim=True), 1 / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + TINY.ln_eps)
-    assert (rstd * (x @ wf.t() - mean * wf.sum(1)) + (w @ beta + b) - ref).abs().max() < 1e-10
-    from reazonspeech_amd.runtime.weights import fold_layernorm
-    wf16, cs, bfold = fold_layernorm(w.float(), b.float(), gamma.float(), beta.float())
-    assert (cs.double() - wf16.double().sum(1)).abs().max() < 1e-5 and (bfold.double() - (w @ beta + b)).abs().max() < 1e-5
-    gold = np.load(GOLD)
-    sd = synthetic_state_dict(TINY, int(gold["seed"]), blank_bias=float(gold["blank_bias"]))
-    a, l = torch.from_numpy(gold["audio"]), torch.from_numpy(gold["lengths"])
-    f32, el = om.forward_to_joint(TINY, sd, a, l, "fp32")
-    fold, _ = om.forward_to_joint(TINY, sd, a, l, "bf16-lnfold")
-    plain, _ = om.forward_to_joint(TINY, sd, a, l, "bf16-fused-glu")
-    for b_ in range(2):
-        n = int(el[b_])
-        assert (f32[b_, :n] - fold[b_, :n]).abs().max() <= 0.1
-        assert 0 < (fold[b_, :n] - plain[b_, :n]).abs().max() <= 0.05
-
-
 def test_attention_window_predicate():
     cfg = TINY.with_(att_left=2, att_right=1, n_global=1)
     allowed = om.attention_allowed(cfg, 6, torch.tensor([6, 4]))
