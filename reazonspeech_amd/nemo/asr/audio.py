@@ -43,8 +43,13 @@ def audio_from_path(path):
     data = None
     try:
         import soundfile  # optional, not in this image
-        data, samplerate = soundfile.read(path, dtype="float32", always_2d=True)
-        data = data.T  # [channels, L]
+        try:
+            data, samplerate = soundfile.read(path, dtype="float32", always_2d=True)
+            data = data.T  # [channels, L]
+        except (RuntimeError, OSError):
+            # libsndfile cannot decode this container (mp3 / m4a ...): librosa.load catches that and retries with
+            # audioread — so does this
+            data = None
     except ImportError:
         pass
     if data is None:

@@ -45,7 +45,8 @@ def resolve_checkpoint(checkpoint=None, allow_download=True):
             break
         try:
             root = snapshot_download(HF_REPO, local_files_only=local_only, allow_patterns=["*.nemo"], etag_timeout=5)
-        except Exception:
+        except Exception as e:             # not cached / no network / authentication / disk: remembered for the caller's warning
+            resolve_checkpoint.last_error = f"{'cache lookup' if local_only else 'download'}: {type(e).__name__}: {e}"
             continue
         found = sorted(glob.glob(os.path.join(root, "**", "*.nemo"), recursive=True))
         if found:
@@ -90,6 +91,11 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
     if str(device).startswith("cpu"):
         raise RuntimeError("reazonspeech_amd runs on MI355X (gfx950) only; no CPU path exists "
                            "(use the reference package for CPU inference)")
+    if config is not None and checkpoint is None:
+        if os.environ.get(CHECKPOINT_ENV):
+            print(f"[reazonspeech_amd] WARNING: ${CHECKPOINT_ENV} is set but ignored because an explicit `config` was passed "
+                  f"(synthetic weights of that architecture are generated); pass `checkpoint=` to load the archive.", file=sys.stderr, flush=True)
+    resolve_checkpoint.last_error = None
     checkpoint = None if config is not None and checkpoint is None else resolve_checkpoint(checkpoint)
     if checkpoint:
         cfg, sd, tok_bytes = W.read_nemo(checkpoint)
@@ -98,7 +104,9 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
         if config is None:
             print(f"[reazonspeech_amd] WARNING: no checkpoint — neither ${CHECKPOINT_ENV} nor a cached / downloadable copy "
                   f"of '{HF_REPO}' was found.  Loading SEEDED SYNTHETIC weights of the 619M architecture: timings are "
-                  f"valid, transcripts are meaningless.", file=sys.stderr, flush=True)
+                  f"valid, transcripts are meaningless."
+                  + (f"  (last lookup failure — {resolve_checkpoint.last_error})" if getattr(resolve_checkpoint, "last_error", None) else ""),
+                  file=sys.stderr, flush=True)
         cfg = config or FASTCONFORMER_619M
         sd = W.synthetic_state_dict(cfg, seed)
         tokenizer = SyntheticTokenizer(cfg.vocab_size, seed)

@@ -412,33 +412,37 @@ class AsrModel:
                 threads.append(threading.Thread(target=stager, daemon=True))
             for th in threads:
                 th.start()
-            for i in range(steps):
-                if fill is not None:
-                    staged[i].wait()
-                    if errors:
-                        break
-                    buf = views[i]
-                else:
-                    buf = bufs[i % nb]
-                    if i >= nb:
-                        done[i - nb].wait()           # this buffer set's previous decode must be finished
-                buf.step = i
-                if before_encoder is not None:
-                    before_encoder(i)
-                if from_host:
-                    with torch.cuda.stream(enc_stream):          # only the columns this batch's geometry reads
-                        w = buf.l_max
-                        buf.audio[:, :w].copy_(buf.h_audio[:, :w], non_blocking=True)
-                        buf.lens.copy_(buf.h_lens, non_blocking=True)
-                self.run_encoder(buf, enc_stream.cuda_stream)
-                ev = torch.cuda.Event()
-                ev.record(enc_stream)
-                queues[i % len(queues)].put((i, buf, ev))          # batch i goes to decode lane i mod lanes
-            stop.set()                  # (an error may have ended the loop early: release the stager)
-            for q in queues:
-                q.put(None)
-            for th in threads:
-                th.join()
+            # whatever happens while batches are being enqueued (an RsError from the encoder, an allocation failure, an exception
+            # of the caller's before_encoder hook), the workers and the stager are always released and joined before it propagates
+            try:
+                for i in range(steps):
+                    if fill is not None:
+                        staged[i].wait()
+                        if errors:
+                            break
+                        buf = views[i]
+                    else:
+                        buf = bufs[i % nb]
+                        if i >= nb:
+                            done[i - nb].wait()           # this buffer set's previous decode must be finished
+                    buf.step = i
+                    if before_encoder is not None:
+                        before_encoder(i)
+                    if from_host:
+                        with torch.cuda.stream(enc_stream):          # only the columns this batch's geometry reads
+                            w = buf.l_max
+                            buf.audio[:, :w].copy_(buf.h_audio[:, :w], non_blocking=True)
+                            buf.lens.copy_(buf.h_lens, non_blocking=True)
+                    self.run_encoder(buf, enc_stream.cuda_stream)
+                    ev = torch.cuda.Event()
+                    ev.record(enc_stream)
+                    queues[i % len(queues)].put((i, buf, ev))          # batch i goes to decode lane i mod lanes
+            finally:
+                stop.set()              # releases the stager
+                for q in queues:
+                    q.put(None)
+                for th in threads:
+                    th.join()
             torch.cuda.current_stream().wait_stream(enc_stream)
             for _, ds in dec_lanes:
                 torch.cuda.current_stream().wait_stream(ds)
@@ -602,8 +606,11 @@ class AsrModel:
         # The post-processing thread allocates ~10^5 small objects per batch; a generation-2 collection triggered in the
         # middle of the pipeline holds the interpreter lock for 50-60 ms (profiles/r03n_host_timeline.txt) and every
         # decode lane behind it: the cyclic collector is paused for the duration of the call (nothing here makes cycles).
-        gc_was_on = gc.isenabled()
-        gc.disable()
+        # (process-global, so only for the duration of the call, and only the automatic trigger: gc.collect() still works for
+        # a host application's other threads; `pause_gc=False` on the model opts out)
+        gc_was_on = gc.isenabled() and getattr(self, "pause_gc", True)
+        if gc_was_on:
+            gc.disable()
         try:
             self.run_pipelined(pool, len(groups), after_decode=harvest, fill=fill, dec_streams=2 if n_sets >= 3 else 1)
         finally:
