@@ -18,18 +18,23 @@ WINDOW_SECONDS = 20
 PADDING = (16000, 8000)
 
 
-def load_model(device=None, config=None, seed=0):
+CHECKPOINT_ENV = "REAZONSPEECH_ESPNET_CHECKPOINT"
+
+
+def load_model(device=None, checkpoint=None, config=None, seed=0):
     """Load the ReazonSpeech ESPnet model onto a ROCm GPU (transcribe.py:12-32).
 
     Args:
       device (str): "cuda" / "cuda:N"; None picks "cuda" when available like the reference (:20-24).  There is no CPU path
         in this package: "cpu" raises.
-      config (ModelConfig): architecture (family "espnet"); default: the 120M Conformer-Transducer shape.
+      checkpoint (str): an ESPnet2 model directory or model-zoo `.zip` (training `config.yaml`, `*.pth`, `feats_stats.npz`);
+        defaults to $REAZONSPEECH_ESPNET_CHECKPOINT.  Read without ESPnet (runtime/weights_espnet.py: read_espnet), strictly.
+      config (ModelConfig): architecture (family "espnet") for synthetic weights; default: the 120M Conformer-Transducer shape.
       seed (int): seed of the synthetic weights.
 
-    The reference downloads `reazon-research/reazonspeech-espnet-v2` through espnet_model_zoo (:27-31); neither ESPnet nor
-    the archive is reachable here, and no reader for ESPnet's packed archives is built: this loads SEEDED SYNTHETIC weights of
-    the architecture (timings are valid, transcripts are meaningless) and says so."""
+    The reference downloads `reazon-research/reazonspeech-espnet-v2` through espnet_model_zoo (:27-31), which an offline box
+    cannot do; without a checkpoint this loads SEEDED SYNTHETIC weights of the architecture (timings are valid, transcripts
+    are meaningless) and says so."""
     from ...runtime.config import ESPNET_CONFORMER_120M
     from ...runtime.weights_espnet import synthetic_state_dict_espnet
     from .model import EspnetModel, synthetic_token_list
@@ -37,6 +42,14 @@ def load_model(device=None, config=None, seed=0):
         device = "cuda" if torch.cuda.is_available() else "cpu"
     if str(device).startswith("cpu"):
         raise RuntimeError("reazonspeech_amd runs on MI355X (gfx950) only; no CPU path exists (use the reference package for CPU inference)")
+    import os
+    from ...runtime.weights_espnet import read_espnet
+    checkpoint = checkpoint or (os.environ.get(CHECKPOINT_ENV) if config is None else None)
+    if checkpoint:
+        if not os.path.exists(checkpoint):
+            raise FileNotFoundError(f"checkpoint {checkpoint!r} does not exist")
+        cfg, sd, tokens = read_espnet(checkpoint)
+        return EspnetModel(cfg, sd, tokens, device=device)
     cfg = config or ESPNET_CONFORMER_120M
     if config is None:
         print("[reazonspeech_amd] WARNING: reazonspeech.espnet.asr has no checkpoint reader in this build — loading SEEDED SYNTHETIC "

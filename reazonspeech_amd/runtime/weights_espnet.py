@@ -205,3 +205,129 @@ def prepare_weights_espnet(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_ca
         raise UnsupportedCheckpoint(f"{len(left)} checkpoint tensor(s) have no counterpart in this implementation: "
                                     + ", ".join(left[:8]) + (" ..." if len(left) > 8 else ""))
     return out
+
+
+# ------------------------------------------------------------------------------------
+# ESPnet2 model directories / model-zoo archives
+# ------------------------------------------------------------------------------------
+
+def config_from_espnet_yaml(doc: dict) -> ModelConfig:
+    """Map an ESPnet2 ASR training `config.yaml` (parsed) onto ModelConfig(family="espnet").  [UPSTREAM] key names follow
+    espnet2/tasks/asr.py (`frontend_conf`, `normalize`, `encoder` / `encoder_conf`, `decoder` / `decoder_conf`,
+    `joint_net_conf`, `token_list`) and the constructor arguments of the classes cited in this module's header.  Strict: a
+    variant the kernels do not compute raises UnsupportedCheckpoint instead of loading silently."""
+    def need(cond, what):
+        if not cond:
+            raise UnsupportedCheckpoint(f"config.yaml: {what} is not implemented by the gfx950 kernels")
+
+    fe = doc.get("frontend_conf") or {}
+    enc = doc.get("encoder_conf") or {}
+    dec = doc.get("decoder_conf") or {}
+    jn = doc.get("joint_net_conf") or {}
+    tokens = doc.get("token_list")
+    need(str(doc.get("frontend", "default")) == "default", f"frontend={doc.get('frontend')!r}")
+    need(str(doc.get("normalize", "global_mvn")) == "global_mvn", f"normalize={doc.get('normalize')!r} (GlobalMVN only)")
+    need(str(doc.get("encoder", "conformer")) == "conformer", f"encoder={doc.get('encoder')!r}")
+    need(str(doc.get("decoder", "transducer")) == "transducer", f"decoder={doc.get('decoder')!r} (a transducer model is expected)")
+    need(doc.get("preencoder") in (None, "null") and doc.get("postencoder") in (None, "null"), "pre / post encoders")
+    need(isinstance(tokens, (list, tuple)) and len(tokens) > 2, "a token_list")
+    need(str(enc.get("input_layer", "conv2d")) == "conv2d", f"encoder_conf.input_layer={enc.get('input_layer')!r}")
+    need(str(enc.get("pos_enc_layer_type", "rel_pos")) == "rel_pos" and str(enc.get("selfattention_layer_type", "rel_selfattn")) == "rel_selfattn"
+         and str(enc.get("rel_pos_type", "latest")) == "latest", "anything but the latest rel_pos / rel_selfattn attention")
+    need(bool(enc.get("macaron_style", True)) and bool(enc.get("use_cnn_module", True)), "a conformer without macaron FFN / conv module")
+    need(bool(enc.get("normalize_before", True)) and not enc.get("concat_after", False), "post-norm / concat_after blocks")
+    need(str(enc.get("activation_type", "swish")) == "swish", f"encoder_conf.activation_type={enc.get('activation_type')!r}")
+    need(str(enc.get("positionwise_layer_type", "linear")) == "linear", "non-linear position-wise layers")
+    need(not enc.get("interctc_layer_idx") and not enc.get("stochastic_depth_rate"), "intermediate CTC / stochastic depth at inference")
+    need(str(dec.get("rnn_type", "lstm")) == "lstm", f"decoder_conf.rnn_type={dec.get('rnn_type')!r}")
+    need(str(jn.get("joint_activation_type", "tanh")) == "tanh", f"joint_net_conf.joint_activation_type={jn.get('joint_activation_type')!r}")
+    fs_raw = str(fe.get("fs", 16000))                    # ESPnet accepts "16k" (humanfriendly) as well as 16000
+    fs = int(float(fs_raw[:-1]) * 1000) if fs_raw.lower().endswith("k") else int(fs_raw)
+    n_fft = int(fe.get("n_fft", 512))
+    hidden = int(dec.get("hidden_size", 256))
+    need(int(dec.get("embed_size", hidden)) == hidden or "embed_size" not in dec, "decoder embed_size != hidden_size")
+    need(not fe.get("htk", False) and int(fe.get("fmin") or 0) == 0 and fe.get("fmax") in (None, "null", fs // 2),
+         "a mel filterbank other than Slaney 0 .. fs/2")
+    d = int(enc.get("output_size", 256))
+    return ModelConfig(
+        family="espnet", sample_rate=fs, n_fft=n_fft, win_length=int(fe.get("win_length") or n_fft), hop_length=int(fe.get("hop_length", 128)), n_mels=int(fe.get("n_mels", 80)),
+        preemph=0.0, log_guard=1e-10, norm_eps=1e-20,
+        d_model=d, n_heads=int(enc.get("attention_heads", 4)), ff_dim=int(enc.get("linear_units", 2048)), n_layers=int(enc.get("num_blocks", 6)),
+        conv_kernel=int(enc.get("cnn_module_kernel", 31)), sub_channels=d, sub_factor=4, xscaling=True, ln_eps=1e-12,
+        vocab_size=len(tokens), pred_hidden=hidden, pred_layers=int(dec.get("num_layers", 1)),
+        joint_hidden=int(jn.get("joint_space_size", 256)), max_symbols=1).validate()
+
+
+def read_espnet(path: str):
+    """Read an ESPnet2 ASR model — a directory or a model-zoo `.zip` holding the training `config.yaml`, the `*.pth` state
+    dict and the GlobalMVN statistics (`feats_stats.npz`, named by `normalize_conf.stats_file`) — without ESPnet.
+    -> (ModelConfig, state dict with "normalize.mean" / "normalize.std" added, token list).
+    [UPSTREAM] layout of espnet_model_zoo archives (what `Speech2Text.from_pretrained` unpacks: pkg/espnet-asr/src/transcribe.py:26-32)."""
+    import io
+    import os
+    import zipfile
+
+    import yaml
+    files = {}
+    if os.path.isdir(path):
+        for root, _, names in os.walk(path):
+            for n in names:
+                files[os.path.relpath(os.path.join(root, n), path)] = os.path.join(root, n)
+        read = lambda k: open(files[k], "rb").read()          # noqa: E731
+    else:
+        zf = zipfile.ZipFile(path)
+        files = {n: n for n in zf.namelist()}
+        read = lambda k: zf.read(k)                           # noqa: E731
+    cfg_key = next((k for k in sorted(files) if os.path.basename(k) == "config.yaml"), None)
+    pth_key = next((k for k in sorted(files) if k.endswith(".pth")), None)
+    if cfg_key is None or pth_key is None:
+        raise ValueError(f"{path}: not an ESPnet2 model (config.yaml / *.pth missing)")
+    doc = yaml.safe_load(read(cfg_key))
+    cfg = config_from_espnet_yaml(doc)
+    sd = torch.load(io.BytesIO(read(pth_key)), map_location="cpu", weights_only=True)
+    stats_name = os.path.basename(str((doc.get("normalize_conf") or {}).get("stats_file", "feats_stats.npz")))
+    st_key = next((k for k in sorted(files) if os.path.basename(k) == stats_name), None)
+    if st_key is None:
+        raise UnsupportedCheckpoint(f"{path}: GlobalMVN statistics {stats_name!r} not found")
+    st = np.load(io.BytesIO(read(st_key)))
+    count = float(st["count"])                        # [UPSTREAM] espnet2/layers/global_mvn.py: mean = sum / count, var = sum_sq / count - mean^2
+    mean = st["sum"].astype(np.float64) / count
+    var = st["sum_square"].astype(np.float64) / count - mean * mean
+    sd = dict(sd)
+    sd["normalize.mean"] = torch.from_numpy(mean.astype(np.float32))
+    sd["normalize.std"] = torch.from_numpy(np.sqrt(np.maximum(var, 1e-20)).astype(np.float32))
+    return cfg, sd, list(doc["token_list"])
+
+
+def write_espnet(path: str, cfg: ModelConfig, sd, token_list):
+    """Write a model directory in the layout `read_espnet` reads (tests round-trip a synthetic model through it)."""
+    import os
+
+    import yaml
+    os.makedirs(os.path.join(path, "exp", "asr_stats", "train"), exist_ok=True)
+    os.makedirs(os.path.join(path, "exp", "asr_train"), exist_ok=True)
+    mean, std = sd["normalize.mean"].double().numpy(), sd["normalize.std"].double().numpy()
+    count = 1000.0
+    np.savez(os.path.join(path, "exp", "asr_stats", "train", "feats_stats.npz"), count=np.array(count), sum=mean * count,
+             sum_square=(std * std + mean * mean) * count)
+    doc = {
+        "frontend": "default", "frontend_conf": {"fs": "16k", "n_fft": cfg.n_fft, "win_length": cfg.win_length, "hop_length": cfg.hop_length,
+                                                   "n_mels": cfg.n_mels},
+        "normalize": "global_mvn", "normalize_conf": {"stats_file": "exp/asr_stats/train/feats_stats.npz"},
+        "specaug": None, "preencoder": None, "postencoder": None,
+        "encoder": "conformer",
+        "encoder_conf": {"output_size": cfg.d_model, "attention_heads": cfg.n_heads, "linear_units": cfg.ff_dim, "num_blocks": cfg.n_layers,
+                         "dropout_rate": 0.1, "positional_dropout_rate": 0.1, "attention_dropout_rate": 0.1, "input_layer": "conv2d",
+                         "normalize_before": True, "macaron_style": True, "rel_pos_type": "latest", "pos_enc_layer_type": "rel_pos",
+                         "selfattention_layer_type": "rel_selfattn", "activation_type": "swish", "use_cnn_module": True,
+                         "cnn_module_kernel": cfg.conv_kernel},
+        "decoder": "transducer",
+        "decoder_conf": {"rnn_type": "lstm", "num_layers": cfg.pred_layers, "hidden_size": cfg.pred_hidden, "dropout": 0.1, "dropout_embed": 0.2},
+        "joint_net_conf": {"joint_space_size": cfg.joint_hidden},
+        "model_conf": {"ctc_weight": 0.3, "report_cer": False, "report_wer": False},
+        "token_list": list(token_list), "token_type": "char", "init": None,
+    }
+    with open(os.path.join(path, "exp", "asr_train", "config.yaml"), "w") as fp:
+        yaml.safe_dump(doc, fp, allow_unicode=True)
+    keep = {k: v for k, v in sd.items() if not k.startswith("normalize.")}
+    torch.save(keep, os.path.join(path, "exp", "asr_train", "valid.loss.ave.pth"))

@@ -117,3 +117,49 @@ def test_ctc_segmentation_is_a_max_plus_path():
         if score > best:
             best, best_times = score, times
     assert [int(x) for x in timings[1:]] == list(best_times)
+
+
+# ---- weights: ESPnet2 keys, the model directory reader, the prepared tensors -------------------------------------------
+def test_espnet_model_directory_round_trip_and_strict_config(tmp_path):
+    """an ESPnet2 model directory (training config.yaml, *.pth, feats_stats.npz) written in the zoo's layout is read back
+    without ESPnet: same configuration, same tensors, GlobalMVN statistics rebuilt from (count, sum, sum_square); a
+    configuration the kernels do not compute is refused"""
+    import copy
+    import torch
+    import yaml
+    from reazonspeech_amd.runtime.config import ESPNET_TINY, ESPNET_CONFORMER_120M, UnsupportedCheckpoint
+    from reazonspeech_amd.runtime import weights_espnet as we
+    cfg = ESPNET_TINY
+    sd = we.synthetic_state_dict_espnet(cfg, 3)
+    toks = synthetic_token_list(cfg.vocab_size, 3)
+    we.write_espnet(str(tmp_path), cfg, sd, toks)
+    cfg2, sd2, toks2 = we.read_espnet(str(tmp_path))
+    assert cfg2 == cfg and toks2 == toks
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd if not k.startswith("normalize."))
+    assert (sd["normalize.mean"] - sd2["normalize.mean"]).abs().max() < 1e-5 and (sd["normalize.std"] - sd2["normalize.std"]).abs().max() < 1e-5
+    prepared = we.prepare_weights_espnet(cfg2, sd2)
+    assert prepared["sub.conv1.w"].shape == (cfg.d_model, 9 * cfg.d_model) and prepared["sub.conv1.w"].dtype == torch.bfloat16
+    assert prepared["ctc.w"].shape == (cfg.vocab_size, cfg.d_model) and prepared["joint.pred.b"].abs().max() == 0
+    # the dense conv's K order is (kernel row, kernel column, input channel)
+    w = sd["encoder.embed.conv.2.weight"]
+    assert torch.equal(prepared["sub.conv1.w"][5, (1 * 3 + 2) * cfg.d_model + 7], w[5, 7, 1, 2].to(torch.bfloat16))
+    # a leftover tensor or a missing one is an error, not a silent skip
+    with pytest.raises(UnsupportedCheckpoint):
+        we.prepare_weights_espnet(cfg, {**sd, "encoder.encoders.0.extra.weight": torch.zeros(1)})
+    with pytest.raises(UnsupportedCheckpoint):
+        we.prepare_weights_espnet(cfg, {k: v for k, v in sd.items() if k != "ctc.ctc_lo.bias"})
+    doc = yaml.safe_load(open(os.path.join(str(tmp_path), "exp", "asr_train", "config.yaml")))
+    for section, key, value in (("encoder_conf", "input_layer", "conv2d6"), ("encoder_conf", "rel_pos_type", "legacy"),
+                                ("encoder_conf", "activation_type", "relu"), ("joint_net_conf", "joint_activation_type", "relu"),
+                                ("decoder_conf", "rnn_type", "gru"), ("frontend_conf", "htk", True)):
+        bad = copy.deepcopy(doc)
+        bad[section][key] = value
+        with pytest.raises(UnsupportedCheckpoint):
+            we.config_from_espnet_yaml(bad)
+    bad = copy.deepcopy(doc)
+    bad["normalize"] = "utterance_mvn"
+    with pytest.raises(UnsupportedCheckpoint):
+        we.config_from_espnet_yaml(bad)
+    assert abs(ESPNET_CONFORMER_120M.n_params() - 120e6) < 3e6                              # README.rst:39-40: "120M"
+    sd120 = None
+    assert ESPNET_CONFORMER_120M.enc_frames(ESPNET_CONFORMER_120M.mel_frames(160000 + 24000)) == 358
