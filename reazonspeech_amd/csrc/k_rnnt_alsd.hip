@@ -132,8 +132,35 @@ __global__ __launch_bounds__(64 * MAX_BEAM) void alsd_select_kernel(
         if (i < n_steps && wave < n_cur) live = (i - as.len[p][row]) <= T - 1;
         if (live) {
             const float* zr = zbuf + (size_t)row * zstride;
+            // ONE scan finds the row maximum AND each lane's own W best non-blank logits (sorted by (logit desc, index asc): a lane
+            // meets its columns in ascending order, so a later equal logit never displaces an earlier one); the W best of the
+            // row are then popped from the 64 sorted lists in W register rounds.  (The row used to be scanned once for the
+            // maximum and once more per beam slot: 2 + W passes over 3001 logits, W of them only to find what this scan
+            // already held in registers.)  The selection is the same total order as before: identical candidates.
             float m = -INFINITY;
-            for (int v = lane; v < V; v += 64) { const float zv = zr[v]; if (zv > m) m = zv; }
+            float tz[MAX_BEAM];
+            int tv[MAX_BEAM];
+#pragma unroll
+            for (int k = 0; k < MAX_BEAM; ++k) { tz[k] = -INFINITY; tv[k] = -1; }
+            for (int v = lane; v < V; v += 64) {
+                const float zv = zr[v];
+                if (zv > m) m = zv;
+                if (v != blank) {
+                    float cz = zv;
+                    int cv = v;
+                    bool ins = false;                                       // once placed, everything behind shifts down one slot
+#pragma unroll
+                    for (int k = 0; k < MAX_BEAM; ++k) {
+                        if (k < W && (ins || tv[k] < 0 || cz > tz[k])) {   // an empty slot takes anything (also a -inf logit)
+                            const float sz = tz[k]; const int sv = tv[k];
+                            tz[k] = cz; tv[k] = cv;
+                            cz = sz; cv = sv;
+                            ins = true;
+                            if (cv < 0) break;
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off, 64); if (o > m) m = o; }
             float sum = 0.0f;
@@ -145,17 +172,9 @@ __global__ __launch_bounds__(64 * MAX_BEAM) void alsd_select_kernel(
             const float hs = as.score[p][row];
             const int base = wave * (W + 1);
             if (lane == 0) { c_score[base] = hs + (zr[blank] - lse); c_tok[base] = -1; c_ok[base] = 1; s_live = 1; }
-            float pz = INFINITY;
-            int pv = -1;
             for (int j = 0; j < W; ++j) {
-                float bz = -INFINITY;
-                int bv = -1;
-                for (int v = lane; v < V; v += 64) {
-                    if (v == blank) continue;
-                    const float zv = zr[v];
-                    if (!(zv < pz || (zv == pz && v > pv))) continue;
-                    if (bv < 0 || zv > bz) { bz = zv; bv = v; }
-                }
+                float bz = tz[0];
+                int bv = tv[0];
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
                     const float oz = __shfl_xor(bz, off, 64);
@@ -164,7 +183,11 @@ __global__ __launch_bounds__(64 * MAX_BEAM) void alsd_select_kernel(
                 }
                 if (bv < 0) break;
                 if (lane == 0) { c_score[base + 1 + j] = hs + (bz - lse); c_tok[base + 1 + j] = bv; c_ok[base + 1 + j] = 1; }
-                pz = bz; pv = bv;
+                if (tv[0] == bv) {                                           // the owner pops its head
+#pragma unroll
+                    for (int k = 0; k + 1 < MAX_BEAM; ++k) { tz[k] = tz[k + 1]; tv[k] = tv[k + 1]; }
+                    tz[MAX_BEAM - 1] = -INFINITY; tv[MAX_BEAM - 1] = -1;
+                }
             }
         }
     }
