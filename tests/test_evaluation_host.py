@@ -142,3 +142,18 @@ def test_hooks_plug_into_reference_base_evaluator(tmp_path, capsys):
     finally:
         for k in ("_ref_eval", "_ref_eval.utils", "_ref_eval.base"):
             sys.modules.pop(k, None)
+
+
+def test_espnet_evaluator_hooks_use_the_espnet_package():
+    """`RSEspnetAmdEvaluator` (examples/rs-espnet/eval.py:16-33): the single hook goes through the windowing `transcribe`, the
+    batch hook through `transcribe_batch`, both of `reazonspeech.espnet.asr` — driven here with the deterministic fake model"""
+    import espnet_fake as fk
+    ev = E.RSEspnetAmdEvaluator(model=fk.FakeEspnetModel(), batch_size=2)
+    # the fake has no recognize_batch: give it the one the batch hook needs
+    ev.model.recognize_batch = lambda waves: [fk.text_of(w) for w in waves]
+    rows = [{"audio": {"array": fk.long_audio(3.0, s), "sampling_rate": 16000}, "text": "あいう"} for s in (1, 2, 3)]
+    single = [ev._evaluate(r)["prediction"] for r in rows]
+    batch = ev._evaluate_batch({"audio": [r["audio"] for r in rows]})["predictions"]
+    assert single == batch == [fk.text_of(r["audio"]["array"]) for r in rows]
+    out = ev.evaluate(rows, batch_size=2)
+    assert [r["prediction"] for r in out] == single and all("distance" in r for r in out)
