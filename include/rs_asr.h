@@ -247,6 +247,28 @@ int rs_rnnt_alsd(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, i
                  int32_t* steps, int32_t* n_ids, float* scores, void* workspace, size_t workspace_bytes,
                  void* stream);
 
+/* ---- the "default" transducer beam search ---------------------------------------------------------
+ * replaces: espnet2 BeamSearchTransducer.default_beam_search + sort_nbest behind Speech2Text.__call__, which the reference
+ * builds with ESPnet's defaults (beam_size 20, search_type "default", score_norm, nbest 1, lm_weight 0:
+ * pkg/espnet-asr/src/transcribe.py:27-31) and calls once per window (transcribe.py:68).  Graves' search: per frame, pop the
+ * best open hypothesis, keep its blank extension, open its `beam` best label extensions, until `beam` kept hypotheses beat
+ * everything still open.  The evaluation order is documented in oracle/espnet_beam.c and the results are bit-identical to it.
+ *
+ *   beam       beam_size (>= 1; clamped to the vocabulary)
+ *   flags      RS_BEAM_SCORE_NORM: the winner is the best score / len(yseq) (yseq counts the leading blank), else the best score
+ *   max_pops   prediction-network evaluations allowed per frame (0 = 16 * beam).  Upstream has no bound; a trained model needs
+ *              about `beam` to 2 * beam.  The workspace grows with it.
+ *   ids    i32[B][out_cap]  labels of the best hypothesis (no leading blank),  n_ids i32[B],  scores f32[B] (log-probability)
+ *   pops   i32[B]           prediction-network evaluations spent on utterance b
+ * Workspace: rs_rnnt_beam_workspace_bytes(ctx, B, beam, tp_max, max_pops), separate from rs_workspace_bytes.
+ * Synchronises the stream internally.  RS_EOVERFLOW if a frame needed more than max_pops pops or a result has more than out_cap
+ * labels (the affected rows return n_ids = 0). */
+enum { RS_BEAM_SCORE_NORM = 1 };
+size_t rs_rnnt_beam_workspace_bytes(const rs_ctx* ctx, int B, int beam, int tp_max, int max_pops);
+int rs_rnnt_beam(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int beam, int flags,
+                 int max_pops, int out_cap, int32_t* ids, int32_t* n_ids, float* scores, int32_t* pops, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
 /* ---- profiling hooks for bench.py (roofline.achieved) ------------------------------------
  * When enabled, the launcher brackets every launch of the selected kernel class with HIP
  * events on the launch stream.  rs_profile_read synchronises those events and returns the

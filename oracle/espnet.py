@@ -153,3 +153,81 @@ def greedy_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor):
                     g = step(k)
             out.append((ids, frames))
     return out
+
+
+def default_beam_search_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor, beam_size=20, score_norm=True):
+    """[UPSTREAM] espnet2 BeamSearchTransducer.default_beam_search + sort_nbest (espnet 202308, no LM) — the decode
+    reazonspeech.espnet.asr runs, since the reference builds Speech2Text with its defaults (beam_size 20, search_type
+    "default", score_norm True, nbest 1: pkg/espnet-asr/src/transcribe.py:27-31).  Restated statement for statement:
+
+        kept_hyps = [Hypothesis(0.0, [blank], init_state)]
+        for enc_out_t in enc_out:
+            hyps, kept_hyps = kept_hyps, []
+            while True:
+                max_hyp = max(hyps, key=score); hyps.remove(max_hyp)
+                dec_out, state = decoder.score(max_hyp)          # LSTM on yseq[-1] from max_hyp.dec_state
+                logp = log_softmax(joint(enc_out_t, dec_out))
+                top_k = logp[1:].topk(beam_k)
+                kept_hyps.append(Hypothesis(max_hyp.score + float(logp[0]), max_hyp.yseq, max_hyp.dec_state))
+                for logp_k, k in zip(*top_k):
+                    hyps.append(Hypothesis(max_hyp.score + float(logp_k), max_hyp.yseq + [k + 1], state))
+                hyps_max = max(hyps, key=score).score
+                kept_most_prob = sorted([h for h in kept_hyps if h.score > hyps_max], key=score)
+                if len(kept_most_prob) >= beam: kept_hyps = kept_most_prob; break
+        return sorted(kept_hyps, key=score / len(yseq), reverse=True)[0]
+
+    Scores are Python floats (float64 sums of float32 log-probabilities) as upstream; decoder.score's cache only saves work
+    (the state is a function of the label sequence).  -> [(ids, score, pops)] per utterance.  The bit-exact checker of the HIP
+    search is oracle/espnet_beam.c (float32 sums, fixed order); tests/test_oracle_espnet_beam.py compares the two."""
+    H, V, blank = cfg.pred_hidden, cfg.n_logits, cfg.blank_id
+    assert blank == 0
+    lstms = []
+    for l in range(cfg.pred_layers):
+        m = torch.nn.LSTM(H, H, 1, batch_first=True)
+        with torch.no_grad():
+            for nm in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+                getattr(m, nm).copy_(sd[f"decoder.decoder.{l}." + nm])
+        lstms.append(m)
+    emb = sd["decoder.embed.weight"]
+    wd = sd["joint_network.lin_dec.weight"]
+    wo, bo = sd["joint_network.lin_out.weight"], sd["joint_network.lin_out.bias"]
+    beam = min(beam_size, V)
+    beam_k = min(beam, V - 1)
+
+    def score_fn(hyp):
+        x = emb[hyp["yseq"][-1]].view(1, 1, H)
+        new = []
+        for l, m in enumerate(lstms):
+            x, st = m(x, hyp["state"][l])
+            new.append(st)
+        return x[0, 0] @ wd.t(), new
+
+    out = []
+    with torch.no_grad():
+        for b in range(f.shape[0]):
+            init = [(torch.zeros(1, 1, H), torch.zeros(1, 1, H)) for _ in lstms]
+            kept = [dict(score=0.0, yseq=[blank], state=init)]
+            pops = 0
+            for t in range(int(lens[b])):
+                hyps, kept = kept, []
+                while True:
+                    max_hyp = max(hyps, key=lambda h: h["score"])
+                    hyps.remove(max_hyp)
+                    pops += 1
+                    dec_out, state = score_fn(max_hyp)
+                    logp = torch.log_softmax(torch.tanh(f[b, t] + dec_out) @ wo.t() + bo, dim=-1)
+                    top = logp[1:].topk(beam_k)
+                    kept.append(dict(score=max_hyp["score"] + float(logp[0]), yseq=max_hyp["yseq"][:], state=max_hyp["state"]))
+                    for lp, k in zip(*top):
+                        hyps.append(dict(score=max_hyp["score"] + float(lp), yseq=max_hyp["yseq"][:] + [int(k) + 1], state=state))
+                    hyps_max = float(max(hyps, key=lambda h: h["score"])["score"])
+                    most = sorted([h for h in kept if h["score"] > hyps_max], key=lambda h: h["score"])
+                    if len(most) >= beam:
+                        kept = most
+                        break
+            if score_norm:
+                kept = sorted(kept, key=lambda h: h["score"] / len(h["yseq"]), reverse=True)
+            else:
+                kept = sorted(kept, key=lambda h: h["score"], reverse=True)
+            out.append((kept[0]["yseq"][1:], kept[0]["score"], pops))
+    return out

@@ -7,9 +7,10 @@ and answers the calls the reference makes on it:
     model.asr_model.encode(speech, length)[0], model.asr_model.ctc.softmax(enc)      (ctc.py:24-26)
     model.dtype, model.device                                                        (ctc.py:19-21)
 so that the reference's own ctc.py runs against it unmodified (tests/test_espnet_host.py does exactly that); the package's
-own code uses the direct forms `recognize` / `ctc_posteriors`.  Decoding on the device is transducer GREEDY search (ESPnet's
-`beam_size=1` path: one symbol per frame); the reference's default — `Speech2Text` beam search, beam 20 — is not restated
-(DESIGN.md §8)."""
+own code uses the direct forms `recognize` / `ctc_posteriors`.  Decoding on the device follows `beam_size` the way
+[UPSTREAM] BeamSearchTransducer does: beam_size <= 1 is greedy_search (one symbol per frame), anything larger the "default"
+beam search with score normalisation (k_rnnt_beam.hip) — the reference's setting is Speech2Text's default, beam_size 20
+(transcribe.py:27-31 overrides only lm_weight)."""
 import numpy as np
 import torch
 
@@ -47,8 +48,11 @@ class _AsrModelView:
 
 
 class EspnetModel:
-    def __init__(self, cfg, state_dict, token_list, device="cuda"):
+    def __init__(self, cfg, state_dict, token_list, device="cuda", beam_size=1, max_pops=0):
         assert cfg.espnet and len(token_list) == cfg.vocab_size
+        if beam_size is not None and int(beam_size) > 1:
+            cfg = cfg.with_(decoding="beam", beam_size=int(beam_size), beam_score_norm=True, beam_max_pops=int(max_pops))
+        self.beam_size = cfg.beam_size if cfg.decoding == "beam" else 1
         self.cfg = cfg
         self.token_list = list(token_list)
         self.am = AsrModel(cfg, state_dict, None, device=device, pad_seconds=0.0)
@@ -59,7 +63,7 @@ class EspnetModel:
 
     # ---- the reference's call forms -------------------------------------------------------------------------------
     def __call__(self, speech):
-        """Speech2Text.__call__: n-best list of (text, tokens, token ids, hypothesis); here the one greedy hypothesis"""
+        """Speech2Text.__call__: n-best list of (text, tokens, token ids, hypothesis); here nbest = 1 (upstream's default)"""
         wav = np.asarray(speech.detach().cpu().numpy() if isinstance(speech, torch.Tensor) else speech, dtype=np.float32).reshape(-1)
         res = self.am.transcribe_waveforms([wav])
         ids = res.ids[0]

@@ -21,7 +21,7 @@ PADDING = (16000, 8000)
 CHECKPOINT_ENV = "REAZONSPEECH_ESPNET_CHECKPOINT"
 
 
-def load_model(device=None, checkpoint=None, config=None, seed=0):
+def load_model(device=None, checkpoint=None, config=None, seed=0, beam_size=None, max_pops=0):
     """Load the ReazonSpeech ESPnet model onto a ROCm GPU (transcribe.py:12-32).
 
     Args:
@@ -31,6 +31,11 @@ def load_model(device=None, checkpoint=None, config=None, seed=0):
         defaults to $REAZONSPEECH_ESPNET_CHECKPOINT.  Read without ESPnet (runtime/weights_espnet.py: read_espnet), strictly.
       config (ModelConfig): architecture (family "espnet") for synthetic weights; default: the 120M Conformer-Transducer shape.
       seed (int): seed of the synthetic weights.
+      beam_size (int): transducer search width, as Speech2Text's `beam_size`: <= 1 greedy search, larger the default beam
+        search.  None = 20 for a checkpoint (Speech2Text's default, which the reference keeps: :27-31) and 1 for synthetic
+        weights (an untrained joint can make the default search extend one frame without end; see `max_pops`).
+      max_pops (int): prediction-network evaluations the beam search may spend per frame (0 = 16 * beam_size); upstream has
+        no bound.  Exceeding it raises (RS_EOVERFLOW) rather than truncating.
 
     The reference downloads `reazon-research/reazonspeech-espnet-v2` through espnet_model_zoo (:27-31), which an offline box
     cannot do; without a checkpoint this loads SEEDED SYNTHETIC weights of the architecture (timings are valid, transcripts
@@ -49,13 +54,14 @@ def load_model(device=None, checkpoint=None, config=None, seed=0):
         if not os.path.exists(checkpoint):
             raise FileNotFoundError(f"checkpoint {checkpoint!r} does not exist")
         cfg, sd, tokens = read_espnet(checkpoint)
-        return EspnetModel(cfg, sd, tokens, device=device)
+        return EspnetModel(cfg, sd, tokens, device=device, beam_size=20 if beam_size is None else beam_size, max_pops=max_pops)
     cfg = config or ESPNET_CONFORMER_120M
     if config is None:
         print("[reazonspeech_amd] WARNING: reazonspeech.espnet.asr has no checkpoint reader in this build — loading SEEDED SYNTHETIC "
               "weights of the 120M Conformer-Transducer architecture: timings are valid, transcripts are meaningless.",
               file=sys.stderr, flush=True)
-    return EspnetModel(cfg, synthetic_state_dict_espnet(cfg, seed), synthetic_token_list(cfg.vocab_size, seed), device=device)
+    return EspnetModel(cfg, synthetic_state_dict_espnet(cfg, seed), synthetic_token_list(cfg.vocab_size, seed), device=device,
+                       beam_size=1 if beam_size is None else beam_size, max_pops=max_pops)
 
 
 def transcribe(model, audio, config=None):

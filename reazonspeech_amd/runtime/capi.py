@@ -28,7 +28,7 @@ EXPORTS = [
     "rs_workspace_bytes", "rs_mel_frames", "rs_enc_frames", "rs_frontend_logmel", "rs_encoder_forward",
     "rs_rnnt_greedy", "rs_profile_enable", "rs_profile_read", "rs_profile_reset", "rs_gemm_bf16",
     "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_glu_dwconv_silu_layout", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
-    "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes", "rs_host_stage_rows",
+    "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes", "rs_rnnt_beam", "rs_rnnt_beam_workspace_bytes", "rs_host_stage_rows",
     "rs_gemm_f32", "rs_relpos_attention_f32", "rs_glu_dwconv_silu_f32", "rs_profile_read_launches", "rs_encoder_set_ctc_out",
 ]
 
@@ -101,6 +101,10 @@ def load():
     lib.rs_stream_destroy.argtypes = [vp]
     lib.rs_encoder_set_taps.argtypes = [vp, vp, vp, POINTER(c_int32), c_int]
     lib.rs_rnnt_greedy.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
+    lib.rs_rnnt_beam_workspace_bytes.argtypes = [vp, c_int, c_int, c_int, c_int]
+    lib.rs_rnnt_beam_workspace_bytes.restype = c_size_t
+    lib.rs_rnnt_beam.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, vp, c_size_t, vp]
+    lib.rs_rnnt_beam.restype = c_int
     lib.rs_rnnt_alsd_workspace_bytes.argtypes = [vp, c_int, c_int, c_int, c_double, c_int]
     lib.rs_rnnt_alsd_workspace_bytes.restype = c_size_t
     lib.rs_rnnt_alsd.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_double, c_int, c_int, c_int, vp, vp, vp, vp, vp,
@@ -290,6 +294,18 @@ class Context:
         flags = (ALSD_SCORE_NORM if score_norm else 0) | (ALSD_MERGE if merge else 0)
         self.check(self.lib.rs_rnnt_alsd(self._h, _ptr(joint_enc), _ptr(enc_lens), B, tp_max, beam, ratio, abs_len, flags,
                                          ids.shape[1], _ptr(ids), _ptr(steps), _ptr(n_ids), _ptr(scores), _ptr(ws),
+                                         ws.numel() * ws.element_size(), c_void_p(stream)))
+
+    def beam_workspace_bytes(self, B, beam, tp_max, max_pops=0):
+        n = self.lib.rs_rnnt_beam_workspace_bytes(self._h, B, beam, tp_max, max_pops)
+        if n == 0:
+            raise RuntimeError("rs_rnnt_beam_workspace_bytes: invalid arguments")
+        return n
+
+    def rnnt_beam(self, joint_enc, enc_lens, B, tp_max, beam, score_norm, max_pops, ids, n_ids, scores, pops, ws, stream):
+        """ESPnet's default transducer beam search: ids int32 [B][out_cap], n_ids / pops int32 [B], scores float32 [B]"""
+        self.check(self.lib.rs_rnnt_beam(self._h, _ptr(joint_enc), _ptr(enc_lens), B, tp_max, beam, 1 if score_norm else 0,
+                                         int(max_pops), ids.shape[1], _ptr(ids), _ptr(n_ids), _ptr(scores), _ptr(pops), _ptr(ws),
                                          ws.numel() * ws.element_size(), c_void_p(stream)))
 
     # ---- profiling ----

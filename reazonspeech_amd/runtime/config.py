@@ -44,8 +44,10 @@ class ModelConfig:
     joint_hidden: int = 640
     max_symbols: int = 10
     # --- decoding strategy (checkpoint cfg `decoding.*`; [UPSTREAM] RNNTDecodingConfig / BeamRNNTInferConfig) ---
-    decoding: str = "greedy_batch"       # "greedy" / "greedy_batch": batched greedy; "alsd": alignment-length synchronous beam search
-    beam_size: int = 4                   # decoding.beam.beam_size (1..8 on the device)
+    decoding: str = "greedy_batch"       # "greedy" / "greedy_batch": batched greedy; "alsd": alignment-length synchronous beam search;
+                                         # "beam": the default (Graves) beam search as ESPnet2 implements it (k_rnnt_beam.hip)
+    beam_size: int = 4                   # decoding.beam.beam_size (alsd: 1..8 on the device; beam: 1..64)
+    beam_max_pops: int = 0               # "beam": prediction-network evaluations allowed per frame (0 = 16 * beam_size)
     alsd_max_target_len: float = 2.0     # decoding.beam.alsd_max_target_len: float = multiple of T', int = absolute label budget
     beam_score_norm: bool = True         # decoding.beam.score_norm: rank finished hypotheses by score / len(y_sequence)
     # --- model family: "nemo" = FastConformer-RNNT (everything above as NeMo defines it); "espnet" = the ESPnet2
@@ -138,6 +140,20 @@ class ModelConfig:
     def with_(self, **kw):
         return replace(self, **kw)
 
+    @property
+    def has_scores(self):
+        """the decoding strategy returns a log-probability per hypothesis (the beam searches)"""
+        return self.decoding in ("alsd", "beam")
+
+    def label_cap(self, tp_max: int) -> int:
+        """labels a hypothesis of a tp_max-frame utterance can hold in the output buffers"""
+        if self.decoding == "alsd":       # a hypothesis has at most one label per alignment step
+            budget = int(self.alsd_max_target_len * tp_max) if isinstance(self.alsd_max_target_len, float) else int(self.alsd_max_target_len)
+            return max(1, tp_max + budget)
+        if self.decoding == "beam":       # no per-frame limit upstream; a result longer than this is reported (RS_EOVERFLOW)
+            return 2 * tp_max + 16
+        return tp_max * self.max_symbols
+
     def validate(self):
         assert self.head_dim in (128, 64), "the attention kernel is built for head_dim 128 and 64"
         assert self.d_model % 64 == 0 and self.ff_dim % 64 == 0
@@ -147,11 +163,12 @@ class ModelConfig:
         assert self.family in ("nemo", "espnet"), f"model family {self.family!r}"
         if self.espnet:
             assert self.sub_factor == 4 and self.sub_channels == self.d_model, "ESPnet Conv2dSubsampling: x4, d_model channels"
-            assert self.decoding in ("greedy", "greedy_batch"), "the ESPnet path decodes greedily on the device"
+            assert self.decoding in ("greedy", "greedy_batch", "beam"), "the ESPnet path decodes greedily or with the default beam search"
         assert self.conv_kernel % 2 == 1 and self.conv_kernel <= 31
         assert self.n_fft == 512 and self.win_length <= 512
-        assert self.decoding in ("greedy", "greedy_batch", "alsd"), f"decoding strategy {self.decoding!r}"
-        assert 1 <= self.beam_size <= 8, "beam_size 1..8"
+        assert self.decoding in ("greedy", "greedy_batch", "alsd", "beam"), f"decoding strategy {self.decoding!r}"
+        assert 1 <= self.beam_size <= (64 if self.decoding == "beam" else 8), "beam_size 1..8 (alsd) / 1..64 (beam)"
+        assert self.beam_max_pops == 0 or self.beam_max_pops >= self.beam_size
         assert self.alsd_max_target_len >= 0
         return self
 

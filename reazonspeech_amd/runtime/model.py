@@ -46,9 +46,7 @@ class _Buffers:
         self.t_max = max(ctx.mel_frames(self.l_pad), 1)
         self.tp_max = max(ctx.enc_frames(self.t_max), 1)
         model.ensure_pos_cap(self.tp_max)
-        self.u_max = self.tp_max * cfg.max_symbols
-        if cfg.decoding == "alsd":       # a hypothesis has at most one label per alignment step
-            self.u_max = max(1, self.tp_max + alsd_label_budget(self.tp_max, cfg.alsd_max_target_len))
+        self.u_max = cfg.label_cap(self.tp_max)
         i32, f32 = torch.int32, torch.float32
         self.audio = torch.zeros((B, l_max), dtype=f32, device=dev)
         self.lens = torch.zeros((B,), dtype=i32, device=dev)
@@ -60,6 +58,7 @@ class _Buffers:
         self.frames = torch.zeros((B, self.u_max), dtype=i32, device=dev)
         self.n_ids = torch.zeros((B,), dtype=i32, device=dev)
         self.scores = torch.zeros((B,), dtype=f32, device=dev)
+        self.pops = torch.zeros((B,), dtype=i32, device=dev)     # "beam": prediction-network evaluations per utterance
         self.ws_alsd = None              # beam-search scratch (grows with beam and alignment length): on first use
         self.ws = torch.empty((ctx.workspace_bytes(B, self.l_pad),), dtype=torch.uint8, device=dev)
         # the decoder of batch i overlaps the encoder of batch i+1 in the pipelined path: own scratch
@@ -91,9 +90,7 @@ class _BufView:
         self.l_pad = l_max + model.pad_left + model.pad_right
         self.t_max = max(ctx.mel_frames(self.l_pad), 1)
         self.tp_max = max(ctx.enc_frames(self.t_max), 1)
-        self.u_max = self.tp_max * cfg.max_symbols
-        if cfg.decoding == "alsd":
-            self.u_max = max(1, self.tp_max + alsd_label_budget(self.tp_max, cfg.alsd_max_target_len))
+        self.u_max = cfg.label_cap(self.tp_max)
         B = self.B
 
         def cut(t, *shape):
@@ -112,7 +109,7 @@ class _BufView:
         self.enc_lens = base.enc_lens
         self.ids = cut(base.ids, B, self.u_max)
         self.frames = cut(base.frames, B, self.u_max)
-        self.n_ids, self.scores = base.n_ids, base.scores
+        self.n_ids, self.scores, self.pops = base.n_ids, base.scores, base.pops
         self.ws, self.ws_dec = base.ws, base.ws_dec
         self.h_audio, self.h_lens = cut(base.h_audio, B, l_max), base.h_lens
         self.h_out = None
@@ -285,6 +282,14 @@ class AsrModel:
         (emission frames); ALSD fills buf.ids / buf.frames (alignment steps i = frame + labels before) / buf.scores.
         Both synchronise the stream."""
         cfg = self.cfg
+        if cfg.decoding == "beam":
+            n = ctx.beam_workspace_bytes(buf.B, cfg.beam_size, buf.tp_max, cfg.beam_max_pops)
+            if buf.ws_alsd is None or buf.ws_alsd.numel() < n:
+                buf.ws_alsd = torch.empty((n,), dtype=torch.uint8, device=self.device)
+            # (no emission frames in this search: buf.frames stays as allocated, zeros)
+            ctx.rnnt_beam(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, cfg.beam_size, cfg.beam_score_norm, cfg.beam_max_pops,
+                          buf.ids, buf.n_ids, buf.scores, buf.pops, buf.ws_alsd, stream)
+            return
         if cfg.decoding != "alsd":
             ctx.rnnt_greedy(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, buf.u_max, buf.ids, buf.frames, buf.n_ids,
                             ws, stream)
@@ -380,7 +385,7 @@ class AsrModel:
                             if from_host:
                                 with torch.cuda.stream(stream):
                                     buf.h_out = (buf.n_ids.cpu(), buf.ids.cpu(), buf.frames.cpu(), buf.enc_lens.cpu(),
-                                                 buf.scores.cpu() if self.cfg.decoding == "alsd" else None)
+                                                 buf.scores.cpu() if self.cfg.has_scores else None)
                             if after_decode is not None:
                                 if i > 0:
                                     hooked[i - 1].wait()
@@ -494,10 +499,12 @@ class AsrModel:
         pipeline worker already copied back (buf.h_out), otherwise they are fetched here"""
         if host is None:
             host = (buf.n_ids.cpu(), buf.ids.cpu(), buf.frames.cpu(), buf.enc_lens.cpu(),
-                    buf.scores.cpu() if self.cfg.decoding == "alsd" else None)
+                    buf.scores.cpu() if self.cfg.has_scores else None)
         n, ids, frames, el = (t.numpy() for t in host[:4])
         if self.cfg.decoding == "alsd":      # alignment step i = frame + labels emitted before
             frames = frames - np.arange(frames.shape[1], dtype=frames.dtype)[None, :]
+            scores = host[4].numpy().tolist()
+        elif self.cfg.decoding == "beam":    # the default search keeps no emission frames (upstream Hypothesis has none)
             scores = host[4].numpy().tolist()
         else:
             scores = None
@@ -518,7 +525,7 @@ class AsrModel:
             return res.ids, res.frames, res.enc_lens, res.scores
 
         ids, frames, enc_lens, scores = rdist.sharded_decode([len(w) for w in waveforms], run_local, max_batch=max_batch)
-        return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.decoding == "alsd" else None)
+        return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.has_scores else None)
 
     LONGEST_FIRST = True    # batch order of a long list (A/B hook of scripts/ragged_order_ab.py)
     POOL_SETS = 4       # resident batches of the host-to-host pipeline (encoder(i+2) || decode(i+1), decode(i) + one being staged)
@@ -621,4 +628,4 @@ class AsrModel:
                 gc.enable()
         if post_err:
             raise post_err[0]
-        return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.decoding == "alsd" else None)
+        return DecodedBatch(ids, frames, enc_lens, scores if self.cfg.has_scores else None)

@@ -19,7 +19,7 @@ from .weights import (BRANCH_GAIN, _randn, _seed_for, banded_filterbank, fft_twi
                       slaney_mel_filterbank, to_fragment_major, DEFAULT_POS_CAP)
 
 
-def synthetic_state_dict_espnet(cfg: ModelConfig, seed: int = 0, blank_bias: float = None) -> Dict[str, torch.Tensor]:
+def synthetic_state_dict_espnet(cfg: ModelConfig, seed: int = 0, blank_bias: float = None, dec_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Seeded random weights under ESPnet2's keys and shapes (the recipe of `synthetic_state_dict`: 1/sqrt(fan_in) linears,
     small residual-branch gains, a blank-logit offset so greedy emits a realistic number of tokens)."""
     assert cfg.espnet
@@ -84,7 +84,7 @@ def synthetic_state_dict_espnet(cfg: ModelConfig, seed: int = 0, blank_bias: flo
         sd[P + "bias_ih_l0"] = _randn(P + "bias_ih_l0", seed, (4 * H,), 0.05)
         sd[P + "bias_hh_l0"] = _randn(P + "bias_hh_l0", seed, (4 * H,), 0.05)
     lin("joint_network.lin_enc", J, d)
-    lin("joint_network.lin_dec", J, H, bias=False)
+    lin("joint_network.lin_dec", J, H, bias=False, gain=dec_gain)
     lin("joint_network.lin_out", V, J, gain=6.0)                  # tanh keeps |a| <= 1: a larger output gain spreads the logits
     if blank_bias is None:
         # scanned with the CPU oracle (oracle/espnet.py greedy): ~70 tokens per 10 s utterance (358 frames) at the 120M shape

@@ -1,0 +1,142 @@
+"""-m gpu: the default transducer beam search (reazonspeech_amd/csrc/k_rnnt_beam.hip — what Speech2Text runs for
+reazonspeech.espnet.asr: beam_size 20, score_norm) through the C ABI against oracle/espnet_beam.c on the same joint-encoder
+projection: labels, scores (float32, BIT-EXACT) and the number of prediction-network evaluations per utterance.
+oracle/espnet_beam.c itself follows the torch restatement of ESPnet's algorithm (tests/test_oracle_espnet_beam.py).
+
+The synthetic checkpoints here use dec_gain = 8 and their own blank offset (see tests/test_oracle_espnet_beam.py for why)."""
+import numpy as np
+import pytest
+import torch
+
+from reazonspeech_amd.runtime.config import ESPNET_TINY, ESPNET_CONFORMER_120M
+from reazonspeech_amd.runtime.synth import synthetic_batch
+from reazonspeech_amd.runtime.weights_espnet import synthetic_state_dict_espnet
+from reazonspeech_amd.espnet.asr.model import EspnetModel, synthetic_token_list
+from oracle import greedy as og
+
+pytestmark = pytest.mark.gpu
+
+
+def build(cfg, seed, bias, beam_size=1, max_pops=0):
+    sd = synthetic_state_dict_espnet(cfg, seed, blank_bias=bias, dec_gain=8.0)
+    return EspnetModel(cfg, sd, synthetic_token_list(cfg.vocab_size, seed), device="cuda:0", beam_size=beam_size, max_pops=max_pops), sd
+
+
+def encode(model, audio, lens):
+    """front-end + encoder on the device -> the staged buffers (joint_enc, enc_lens in HBM)"""
+    am = model.am
+    buf = am.stage([audio[b, :int(lens[b])] for b in range(audio.shape[0])])
+    with torch.cuda.device(am.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        am.ctx.frontend(buf.audio, buf.lens, 0, 0, buf.t_max, buf.feats, buf.n_frames, buf.ws, stream)
+        am.ctx.encoder(buf.feats, buf.n_frames, buf.B, buf.t_max, None, buf.joint_enc, buf.enc_lens, buf.ws, stream)
+        torch.cuda.synchronize()
+    return buf
+
+
+def device_beam(model, buf, beam, score_norm=True, max_pops=0, enc_lens=None, out_cap=None):
+    am = model.am
+    B = buf.B
+    dev = am.device
+    el = buf.enc_lens if enc_lens is None else torch.as_tensor(enc_lens, dtype=torch.int32, device=dev)
+    cap = out_cap or (2 * buf.tp_max + 16)
+    ids = torch.full((B, cap), -7, dtype=torch.int32, device=dev)
+    n_ids = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    scores = torch.full((B,), 123.0, dtype=torch.float32, device=dev)
+    pops = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    ws = torch.empty((am.ctx.beam_workspace_bytes(B, beam, buf.tp_max, max_pops),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        am.ctx.rnnt_beam(buf.joint_enc, el, B, buf.tp_max, beam, score_norm, max_pops, ids, n_ids, scores, pops, ws,
+                         torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    n = n_ids.cpu().numpy()
+    return [(ids[b, :n[b]].cpu().tolist(), float(scores[b]), int(pops[b])) for b in range(B)]
+
+
+@pytest.fixture(scope="module")
+def tiny(gpu_device):
+    model, sd = build(ESPNET_TINY, 11, 12.0)
+    audio, lens = synthetic_batch(6, 2.0, seed=21)
+    lens = lens.copy()
+    lens[1] = lens[1] // 2
+    lens[4] = 3000
+    buf = encode(model, audio, lens)
+    buf.sample_lens = lens
+    return model, sd, buf
+
+
+@pytest.mark.parametrize("beam", [1, 2, 4, 20])
+def test_tiny_bit_exact(tiny, beam):
+    model, sd, buf = tiny
+    f = buf.joint_enc.cpu().numpy()
+    el = buf.enc_lens.cpu().numpy()
+    want = og.espnet_beam(model.cfg, sd, f, el, beam=beam, max_pops=16 * beam, out_cap=2 * buf.tp_max + 16)
+    got = device_beam(model, buf, beam)
+    assert [g[0] for g in got] == [w[0] for w in want]
+    assert [g[2] for g in got] == [w[2] for w in want]
+    assert [np.float32(g[1]) for g in got] == [np.float32(w[1]) for w in want]
+    assert sum(len(g[0]) for g in got) > 0
+
+
+def test_tiny_score_norm_off_and_empty_rows(tiny):
+    model, sd, buf = tiny
+    f = buf.joint_enc.cpu().numpy()
+    el = buf.enc_lens.cpu().numpy().copy()
+    el[2] = 0
+    el[5] = 1
+    want = og.espnet_beam(model.cfg, sd, f, el, beam=5, score_norm=False, max_pops=80, out_cap=2 * buf.tp_max + 16)
+    got = device_beam(model, buf, 5, score_norm=False, enc_lens=el)
+    assert got == [(w[0], float(np.float32(w[1])), w[2]) for w in want]
+    assert got[2] == ([], 0.0, 0)
+
+
+def test_results_do_not_depend_on_the_batch(tiny):
+    """an utterance searched alone gives what it gives inside the batch (rows are independent state machines)"""
+    model, sd, buf = tiny
+    full = device_beam(model, buf, 8)
+    am = model.am
+    for b in (0, 3):
+        T = int(buf.enc_lens[b])
+        one = am.stage([np.zeros(int(buf.sample_lens[b]), np.float32)])   # a 1-row buffer set; its joint_enc is overwritten below
+        assert one.tp_max >= T
+        one.joint_enc.zero_()
+        one.joint_enc[0, :T] = buf.joint_enc[b, :T]
+        got = device_beam(model, one, 8, enc_lens=[T])
+        assert got[0] == full[b]
+
+
+def test_overflow_is_reported_not_truncated(tiny):
+    model, sd, buf = tiny
+    with pytest.raises(RuntimeError, match="max_pops"):
+        device_beam(model, buf, 8, max_pops=9)
+    with pytest.raises(RuntimeError, match="out_cap"):
+        device_beam(model, buf, 4, out_cap=1)
+    # and the context is usable afterwards
+    assert device_beam(model, buf, 2)
+
+
+def test_model_call_uses_the_beam_search(gpu_device):
+    model, sd = build(ESPNET_TINY, 11, 12.0, beam_size=6)
+    audio, lens = synthetic_batch(2, 1.5, seed=4)
+    wav = audio[0, :int(lens[0])]
+    text, tokens, ids, _ = model(wav)[0]
+    buf = encode(model, wav[None, :], np.asarray([len(wav)], np.int32))
+    want = og.espnet_beam(model.cfg, sd, buf.joint_enc.cpu().numpy(), buf.enc_lens.cpu().numpy(), beam=6, max_pops=96,
+                          out_cap=2 * buf.tp_max + 16)
+    assert ids == want[0][0] and text == "".join(model.token_list[i] for i in ids)
+    res = model.am.transcribe_waveforms([audio[b, :int(lens[b])] for b in range(2)])
+    assert res.ids[0] == ids and res.scores is not None and len(res.scores) == 2
+    assert all(f == 0 for f in res.frames[0])
+
+
+def test_120m_one_utterance_bit_exact(gpu_device):
+    """the published shape (V = 2600, joint 640, prediction net 512), beam 20, 4 s of audio"""
+    cfg = ESPNET_CONFORMER_120M
+    model, sd = build(cfg, 5, 17.0)
+    audio, lens = synthetic_batch(2, 4.0, seed=8)
+    buf = encode(model, audio, lens)
+    got = device_beam(model, buf, 20, max_pops=640)
+    want = og.espnet_beam(cfg, sd, buf.joint_enc.cpu().numpy(), buf.enc_lens.cpu().numpy(), beam=20, max_pops=640,
+                          out_cap=2 * buf.tp_max + 16)
+    assert got == [(w[0], float(np.float32(w[1])), w[2]) for w in want]
+    print("120M beam-20 pops per frame:", [g[2] / max(1, int(t)) for g, t in zip(got, buf.enc_lens.cpu())], "labels", [len(g[0]) for g in got])
