@@ -3,22 +3,25 @@
 // Speech2Text with its defaults — beam_size 20, search_type "default", score_norm, nbest 1, no LM
 // (pkg/espnet-asr/src/transcribe.py:27-31).
 //
-// The search is frame-synchronous per utterance but the number of prediction-network evaluations ("pops") a frame takes is
-// data dependent, so utterances are NOT kept in frame lockstep: every utterance is its own state machine and one device
-// iteration performs ONE pop for every utterance that is still searching, whatever frame it is at:
+// The search is frame-synchronous per utterance but the number of pops a frame takes is data dependent, so utterances are NOT
+// kept in frame lockstep: every utterance is its own state machine and one device iteration performs ONE pop for every
+// utterance that is still searching, whatever frame it is at.  One iteration = 3 + L launches:
 //
-//   beam_pop_kernel      (one wave per utterance) first maximum of the open list `hyps`; the popped hypothesis' sequence enters
-//                        the label trie; its stored prediction-net state (the state BEFORE its last label) and that label are
-//                        placed in row b of the decode state; the utterance joins this iteration's work lists
-//   LSTM x L + joint.pred, joint logits of frame t_b   the exact-f32 kernels of the greedy path (k_rnnt.hip) over those rows
-//   beam_expand_kernel   (one workgroup per utterance) log-softmax, the blank extension -> `kept`, the beam_k best labels ->
-//                        `hyps` (with the state AFTER the popped hypothesis' last label, parked in a state-pool slot), the
-//                        end-of-frame test (>= beam entries of kept above max(hyps)), and at the end of a frame: survivors sorted
-//                        ascending, their states compacted into the other pool, t += 1; at the last frame the winner by
-//                        score / len(yseq) is read back through the trie
+//   LSTM x L + joint.pred   over the utterances whose popped sequence has not been evaluated yet (k_rnnt.hip, exact f32)
+//   joint logits            of every searching utterance at its frame t_b (rnnt_tile_kernel<2>)
+//   beam_expand_kernel      (one workgroup per utterance) log-softmax, the blank extension -> `kept`, the beam_k best labels ->
+//                           the open list, the end-of-frame test (>= beam entries of kept above the maximum of the open list) and,
+//                           at the end of a frame: survivors sorted ascending, their slots compacted into the other pool, t += 1;
+//                           at the last frame the winner by score / len(yseq) is read back through the label trie.  Then the NEXT
+//                           pop of the utterance (the first maximum of the open list, which the end-of-frame test just found):
+//                           a sequence seen for the first time enters the trie and the LSTM work list with the state it starts
+//                           from; one evaluated before only hands its cached joint.pred output to the joint
 //
 // Evaluation order (float32 sums, log-sum-exp tree, tie rules) is documented in oracle/espnet_beam.c and the results are
 // bit-identical to it: labels, scores and the pop count.  Compiled with -ffp-contract=off.
+#include <cstdio>
+#include <cstdlib>
+
 #include "k_rnnt_common.h"
 
 int rs_rnnt_launch_lstm_pred(rs_ctx* ctx, const void* st_ptr, int rows, hipStream_t s);
@@ -58,32 +61,39 @@ struct BeamState {
     int32_t* nh;         // entries of hyps (dead ones included)
     int32_t* nk;         // entries of kept
     int32_t* npop;       // pops of the current frame
-    int32_t* ninit;      // hypotheses the current frame started with (state slots [0, ninit) of the current pool)
-    int32_t* pool;       // current state pool (0 / 1)
+    int32_t* nfree;      // free slots (entries of freelist)
     int32_t* nnode;      // trie nodes in use
     int32_t* pops;       // pops over the whole utterance (the work measure, returned)
-    // the hypothesis popped in this iteration [B]
+    // the hypothesis popped for this iteration [B]
     float* cur_score;
     int32_t* cur_node;
-    int32_t* cur_state;
+    int32_t* cur_slot;   // its own slot when cur_new == 0
     int32_t* cur_len;
+    int32_t* cur_new;    // 1: its prediction-network output is being computed in this iteration (row b of the decode state)
     // open list [B][max_h]
     float* h_score;
     int32_t* h_node;     // trie node of the sequence when h_tok < 0, of the sequence without its last label otherwise
-    int32_t* h_tok;
-    int32_t* h_state;    // pool slot of the state BEFORE the last label
+    int32_t* h_tok;      // last label of a sequence that has not been evaluated yet, or -1
+    int32_t* h_slot;     // h_tok >= 0: slot of the sequence without its last label (the state to start from); else its own slot
     int32_t* h_len;      // len(yseq): labels + the leading blank
     int32_t* h_alive;
     // blank extensions of this frame [B][max_pops]
     float* k_score;
     int32_t* k_node;
-    int32_t* k_state;
+    int32_t* k_slot;     // own slot
     int32_t* k_len;
     int2* nodes;         // [B][max_nodes] (parent, label)
-    float* states;       // [2][B][slots][2 * L * H]  (h then c)
+    float* slots;        // [B][n_slots][slot_floats]: per evaluated sequence  h [L][H], c [L][H] after its last label, g [J]
+    int32_t* freelist;   // [B][n_slots] free slot ids; a frame's end returns every slot no survivor owns
     int32_t* flags;      // [0] utterances done, [1] overflow
-    int max_h, max_pops, max_nodes, slots;
+    unsigned long long* trace;   // $RS_BEAM_TRACE: cycles per phase of the expand kernel, summed over workgroups (else null)
+    int max_h, max_pops, max_nodes, n_slots, slot_floats;
 };
+
+// [UPSTREAM] decoder.score(hyp, cache) caches the prediction-network output by label sequence; so does the slot pool: a
+// sequence is evaluated ONCE (when a label extension is popped for the first time) and the ~beam survivors that open every
+// frame are popped again without touching the LSTM — only the joint depends on the frame.  The cached values are the ones
+// the oracle recomputes (same kernels, same inputs), so this changes no bit of the result.
 
 __device__ __forceinline__ void beam_fail(const BeamState& bs, int b) {   // one thread
     bs.done[b] = 1;
@@ -97,11 +107,13 @@ __global__ __launch_bounds__(256) void beam_init_kernel(BeamState bs, DecodeStat
                                                         int32_t* __restrict__ pops) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    bs.t[b] = 0; bs.nk[b] = 0; bs.npop[b] = 0; bs.ninit[b] = 1; bs.pool[b] = 0; bs.pops[b] = 0;
-    bs.nodes[(size_t)b * bs.max_nodes] = make_int2(-1, blank);
-    bs.nnode[b] = 1;
+    bs.t[b] = 0; bs.nk[b] = 0; bs.npop[b] = 0; bs.pops[b] = 0;
+    bs.nnode[b] = 0;
+    for (int i = 1; i < bs.n_slots; ++i) bs.freelist[(size_t)b * bs.n_slots + i - 1] = i;
+    bs.nfree[b] = bs.n_slots - 1;
+    // the start: [blank] is a sequence that has not been evaluated; it starts from slot 0 (never handed out), the zero state
     const size_t h0 = (size_t)b * bs.max_h;
-    bs.h_score[h0] = 0.0f; bs.h_node[h0] = 0; bs.h_tok[h0] = -1; bs.h_state[h0] = 0; bs.h_len[h0] = 1; bs.h_alive[h0] = 1;
+    bs.h_score[h0] = 0.0f; bs.h_node[h0] = -1; bs.h_tok[h0] = blank; bs.h_slot[h0] = 0; bs.h_len[h0] = 1; bs.h_alive[h0] = 1;
     bs.nh[b] = 1;
     st.token[b] = blank; st.tcur[b] = 0;
     n_ids[b] = 0; scores[b] = 0.0f; pops[b] = 0;
@@ -110,131 +122,255 @@ __global__ __launch_bounds__(256) void beam_init_kernel(BeamState bs, DecodeStat
     if (fin) atomicAdd(&bs.flags[0], 1);
 }
 
-// grid B, block 64
-__global__ __launch_bounds__(64) void beam_pop_kernel(BeamState bs, DecodeState st, int B, int L, int H) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (bs.done[b]) return;
-    const int n = bs.nh[b];
-    const size_t hb = (size_t)b * bs.max_h;
-    float best = -INFINITY;
-    int bi = -1;
-    for (int i = lane; i < n; i += 64)
+// ---- wave-wide first maximum by (value desc, index asc) on the DPP path: row_shr 1/2/4/8 fold each row of 16 lanes into
+// its lane 15, row_bcast:15 / row_bcast:31 fold the rows into lane 63 (full-rate VALU moves, no LDS crossbar: a ds_bpermute
+// butterfly is 12 dependent ~100-cycle hops, and the search pays one such reduction per label of every expansion).  The order
+// is total, so the fold order does not matter.  Entries with index < 0 are "nothing".  Every lane returns the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_fold(float& z, int& v) {
+    const float oz = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(z), CTRL, ROW_MASK, 0xf, false));
+    const int ov = __builtin_amdgcn_update_dpp(-1, v, CTRL, ROW_MASK, 0xf, false);
+    if (ov >= 0 && (v < 0 || oz > z || (oz == z && ov < v))) { z = oz; v = ov; }
+}
+__device__ __forceinline__ void wave_argmax(float& z, int& v) {
+    dpp_fold<0x111, 0xf>(z, v);   // row_shr:1
+    dpp_fold<0x112, 0xf>(z, v);   // row_shr:2
+    dpp_fold<0x114, 0xf>(z, v);   // row_shr:4
+    dpp_fold<0x118, 0xf>(z, v);   // row_shr:8
+    dpp_fold<0x142, 0xa>(z, v);   // row_bcast:15 into rows 1 and 3
+    dpp_fold<0x143, 0xc>(z, v);   // row_bcast:31 into rows 2 and 3
+    z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), 63));
+    v = __builtin_amdgcn_readlane(v, 63);
+}
+
+// ---- block-wide (256 threads) first maximum of the alive entries of the open list: (score desc, index asc) ----
+__device__ __forceinline__ void beam_argmax(const BeamState& bs, size_t hb, int n, float* w_f, int* w_i, float& best, int& bi) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    best = -INFINITY; bi = -1;
+    for (int i = tid; i < n; i += 256)
         if (bs.h_alive[hb + i]) {
             const float s = bs.h_score[hb + i];
-            if (bi < 0 || s > best) { best = s; bi = i; }          // a lane meets its entries in ascending order
+            if (bi < 0 || s > best) { best = s; bi = i; }          // a thread meets its entries in ascending order
         }
+    wave_argmax(best, bi);
+    __syncthreads();                                               // w_f / w_i may still be read from an earlier use
+    if (lane == 0) { w_f[wave] = best; w_i[wave] = bi; }
+    __syncthreads();
+    best = w_f[0]; bi = w_i[0];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float os = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
+    for (int w = 1; w < 4; ++w) {
+        const float os = w_f[w];
+        const int oi = w_i[w];
         if (oi >= 0 && (bi < 0 || os > best || (os == best && oi < bi))) { best = os; bi = oi; }
     }
+}
+
+// ---- pop entry `bi` of the open list for the next iteration (block-wide; every thread passes the same bi) ----
+// list = the joint work list the next iteration reads
+__device__ __forceinline__ void beam_pop(const BeamState& bs, const DecodeState& st, int b, int B, int L, int H, int J, int bi,
+                                         float score, int list) {
+    const int tid = threadIdx.x;
+    const size_t hb = (size_t)b * bs.max_h;
+    const bool none = bi < 0;                                      // cannot happen (a pop always opens beam_k >= 1 extensions)
+    if (none) bi = 0;
+    const int tok = bs.h_tok[hb + bi], slot = bs.h_slot[hb + bi];
     int node = bs.h_node[hb + bi];
-    const int tok = bs.h_tok[hb + bi];
-    const int state = bs.h_state[hb + bi];
-    int ok = 1;
-    if (lane == 0) {
-        if (bs.npop[b] >= bs.max_pops || (tok >= 0 && bs.nnode[b] >= bs.max_nodes)) { beam_fail(bs, b); ok = 0; }
-    }
-    ok = __shfl(ok, 0, 64);
-    if (!ok) return;
-    int last = tok;
-    if (lane == 0) {
+    const bool bad = none || bs.npop[b] >= bs.max_pops || (tok >= 0 && bs.nnode[b] >= bs.max_nodes);
+    __syncthreads();                                               // every thread has read the entry and the counters
+    if (bad) { if (tid == 0) beam_fail(bs, b); return; }
+    const int LH = L * H;
+    const float* src = bs.slots + ((size_t)b * bs.n_slots + slot) * (size_t)bs.slot_floats;
+    if (tid == 0) {
         bs.h_alive[hb + bi] = 0;
-        if (tok >= 0) {                                            // the sequence enters the trie now
+        if (tok >= 0) {                                            // the sequence enters the trie, and the LSTM work list
             const int nn = bs.nnode[b];
             bs.nodes[(size_t)b * bs.max_nodes + nn] = make_int2(node, tok);
             node = nn;
             bs.nnode[b] = nn + 1;
-        } else {
-            last = bs.nodes[(size_t)b * bs.max_nodes + node].y;
+            st.token[b] = tok;
+            st.act[atomicAdd(&st.counters[0], 1)] = b;
         }
-        bs.cur_score[b] = best; bs.cur_node[b] = node; bs.cur_state[b] = state; bs.cur_len[b] = bs.h_len[hb + bi];
-        st.token[b] = last;
+        bs.cur_score[b] = score; bs.cur_node[b] = node; bs.cur_slot[b] = slot; bs.cur_len[b] = bs.h_len[hb + bi];
+        bs.cur_new[b] = tok >= 0;
         st.tcur[b] = bs.t[b];
-        st.act[atomicAdd(&st.counters[0], 1)] = b;                 // LSTM / joint.pred work list
-        st.alive[atomicAdd(&st.counters[2], 1)] = b;               // joint-logits work list (list 0: the joint runs with step 0)
+        st.alive[(size_t)list * B + atomicAdd(&st.counters[2 + list], 1)] = b;
     }
-    const int LH = L * H;
-    const float* src = bs.states + (((size_t)bs.pool[b] * B + b) * bs.slots + state) * (2 * (size_t)LH);
-    for (int i = lane; i < LH; i += 64) {
-        const int l = i / H, u = i - l * H;
-        st.h[((size_t)l * B + b) * H + u] = src[i];
-        st.c[((size_t)l * B + b) * H + u] = src[LH + i];
+    if (tok >= 0) {                                                // start state of the evaluation
+        for (int i = tid; i < LH; i += 256) {
+            const int l = i / H, u = i - l * H;
+            st.h[((size_t)l * B + b) * H + u] = src[i];
+            st.c[((size_t)l * B + b) * H + u] = src[LH + i];
+        }
+    } else {                                                       // evaluated before: only the joint needs it
+        for (int i = tid; i < J; i += 256) st.g[(size_t)b * J + i] = src[2 * LH + i];
     }
 }
 
-// grid B, block 256, dynamic LDS: z row [V] + kept scores [max_pops] + survivor slots [max_pops]
+// the first pop of every utterance; grid B, block 256
+__global__ __launch_bounds__(256) void beam_first_pop_kernel(BeamState bs, DecodeState st, int B, int L, int H, int J) {
+    const int b = blockIdx.x;
+    if (bs.done[b]) return;
+    beam_pop(bs, st, b, B, L, H, J, 0, 0.0f, 0);
+}
+
+#define BEAM_MARK(phase)                                                                       \
+    if (bs.trace && tid == 0) {                                                                \
+        const unsigned long long now = wall_clock64();                                         \
+        atomicAdd(&bs.trace[2 * (phase)], now - t_mark);                                       \
+        atomicAdd(&bs.trace[2 * (phase) + 1], 1ull);                                           \
+        t_mark = now;                                                                          \
+    }
+
+// grid B, block 256, dynamic LDS: z row [zstride] + exp terms [zstride] + kept scores [max_pops] + slot marks [n_slots]
+// EPT = logits per thread (V <= 256 * EPT): a thread keeps its logits v = tid + 256 e in registers for the label rounds
+template <int EPT>
 __global__ __launch_bounds__(256) void beam_expand_kernel(BeamState bs, DecodeState st, const float* __restrict__ zbuf, int zstride,
-                                                          const int32_t* __restrict__ enc_lens, int B, int L, int H, int V, int blank,
-                                                          int beam, int beam_k, int score_norm, int out_cap,
+                                                          const int32_t* __restrict__ enc_lens, int B, int L, int H, int J, int V,
+                                                          int blank, int beam, int beam_k, int score_norm, int out_cap, int iter,
                                                           int32_t* __restrict__ ids, int32_t* __restrict__ n_ids,
                                                           float* __restrict__ scores, int32_t* __restrict__ pops) {
     extern __shared__ __attribute__((aligned(16))) char beam_smem[];
     float* zs = reinterpret_cast<float*>(beam_smem);
-    float* ks = zs + zstride;                                        // kept scores
-    int* kslot = reinterpret_cast<int*>(ks + bs.max_pops);           // rank -> source pool slot
+    float* es = zs + zstride;                                        // exp(z - max)
+    float* ks = es + zstride;                                        // kept scores
+    int* used = reinterpret_cast<int*>(ks + bs.max_pops);            // slot -> owned by a survivor
     __shared__ float w_f[2][4];
     __shared__ int w_i[2][4];
-    __shared__ float s_lse, s_hmax;
-    __shared__ int s_good, s_best;
+    __shared__ float s_lse;
+    __shared__ int s_good, s_best, s_nfree;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (b == 0 && tid == 0) st.counters[2] = 0;                      // the next pop rebuilds list 0 (counters[0] was zeroed by the joint)
     if (bs.done[b]) return;
-    const int LH = L * H;
-    const int pool = bs.pool[b];
-    float* pool_cur = bs.states + (((size_t)pool * B + b) * bs.slots) * (2 * (size_t)LH);
-    float* pool_nxt = bs.states + (((size_t)(pool ^ 1) * B + b) * bs.slots) * (2 * (size_t)LH);
-    const int npop = bs.npop[b], ninit = bs.ninit[b], nk = bs.nk[b], nh0 = bs.nh[b];
-    const int after = ninit + npop;                                  // < slots: ninit <= max_pops, npop < max_pops
-    // park the state after the popped hypothesis' last label; stage the logits
-    for (int i = tid; i < LH; i += 256) {
-        const int l = i / H, u = i - l * H;
-        pool_cur[(size_t)after * 2 * LH + i] = st.h[((size_t)l * B + b) * H + u];
-        pool_cur[(size_t)after * 2 * LH + LH + i] = st.c[((size_t)l * B + b) * H + u];
+    unsigned long long t_mark = bs.trace ? wall_clock64() : 0ull;
+    const int LH = L * H, SS = bs.slot_floats;
+    float* pool = bs.slots + ((size_t)b * bs.n_slots) * (size_t)SS;
+    int32_t* fl = bs.freelist + (size_t)b * bs.n_slots;
+    const int npop = bs.npop[b], nfree = bs.nfree[b], nk = bs.nk[b], nh0 = bs.nh[b];
+    const int is_new = bs.cur_new[b];
+    // the popped hypothesis' own slot: a fresh one when it was evaluated in this iteration (never short: n_slots - 1 =
+    // 2 * max_pops >= survivors of the last frame + evaluations of this one)
+    const int own = is_new ? fl[nfree - 1] : bs.cur_slot[b];
+    if (is_new) {
+        float* dst = pool + (size_t)own * SS;
+        for (int i = tid; i < LH; i += 256) {
+            const int l = i / H, u = i - l * H;
+            dst[i] = st.h[((size_t)l * B + b) * H + u];
+            dst[LH + i] = st.c[((size_t)l * B + b) * H + u];
+        }
+        for (int i = tid; i < J; i += 256) dst[2 * LH + i] = st.g[(size_t)b * J + i];
     }
     const float* zr = zbuf + (size_t)b * zstride;
-    for (int v = tid; v < V; v += 256) zs[v] = zr[v];
-    __syncthreads();
-    if (wave == 0) {                                                 // log-sum-exp in the documented order
-        float m = -INFINITY;
-        for (int v = lane; v < V; v += 64) { const float zv = zs[v]; if (zv > m) m = zv; }
+    float zreg[EPT];
+    unsigned gone = 0;                                               // bit e: logit e of this thread is not a candidate (any more)
+    float m = -INFINITY;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off, 64); if (o > m) m = o; }
+    for (int e = 0; e < EPT; ++e) {
+        const int v = tid + 256 * e;
+        const bool in = v < V;
+        zreg[e] = in ? zr[v] : -INFINITY;
+        if (in) zs[v] = zreg[e];
+        m = fmaxf(m, zreg[e]);
+        gone |= (unsigned)(!in || v == blank) << e;
+    }
+    m = wave_max(m);
+    if (lane == 0) w_f[0][wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(w_f[0][0], w_f[0][1]), fmaxf(w_f[0][2], w_f[0][3]));
+    BEAM_MARK(0)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {                                  // the terms of the sum; added below in the documented order
+        const int v = tid + 256 * e;
+        if (v < V) es[v] = rs_expf(zreg[e] - m);
+    }
+    __syncthreads();
+    if (wave == 0) {
         float sum = 0.0f;
-        for (int v = lane; v < V; v += 64) sum = sum + rs_expf(zs[v] - m);
+        for (int v = lane; v < V; v += 64) sum = sum + es[v];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off, 64);
         if (lane == 0) s_lse = m + rs_logf(sum);
     }
     __syncthreads();
+    BEAM_MARK(1)
     const float lse = s_lse;
+    const float zblank = zs[blank];
     const float hs = bs.cur_score[b];
     const int cnode = bs.cur_node[b], clen = bs.cur_len[b];
     const size_t hb = (size_t)b * bs.max_h, kb = (size_t)b * bs.max_pops;
-    if (tid == 0) {
-        bs.k_score[kb + nk] = hs + (zs[blank] - lse);
-        bs.k_node[kb + nk] = cnode; bs.k_state[kb + nk] = bs.cur_state[b]; bs.k_len[kb + nk] = clen;
+    // ---- the beam_k best labels by (logit desc, index asc) ----
+    // Fast path: a threshold that at least beam_k candidates reach, the (few) logits at or above it gathered in LDS, each ranked
+    // by counting.  theta = the smallest, over the four waves, of a wave's q-th largest per-thread maximum with q =
+    // ceil(beam_k / 4): every wave then holds q threads whose maximum is >= theta, so at least beam_k logits qualify, and the
+    // beam_k best overall are among them.  (Picking them one at a time costs a block-wide reduction per label.)
+    float my_z = 0.0f;
+    int n_child = 0, my_v = -1;
+    bool ranked = false;
+    if (beam_k <= 128) {
+        float tmax = -INFINITY;                                      // this thread's best candidate
+        int targ = -1;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const bool take = !((gone >> e) & 1u) & ((targ < 0) | (zreg[e] > tmax));
+            tmax = take ? zreg[e] : tmax;
+            targ = take ? tid + 256 * e : targ;
+        }
+        const int q = (beam_k + 3) / 4;
+        float cz = tmax, theta_w = INFINITY;
+        int cv = targ;
+        for (int r = 0; r < q; ++r) {                                // the wave's q-th largest thread maximum (wave-local rounds: no barrier)
+            float bz = cz;
+            int bv = cv;
+            wave_argmax(bz, bv);
+            theta_w = bv < 0 ? -INFINITY : bz;
+            if (bv < 0) break;
+            if (cv == bv) cv = -1;                                   // its owner steps aside
+        }
+        if (lane == 0) w_f[1][wave] = theta_w;
+        if (tid == 0) s_good = 0;                                    // candidate counter
+        __syncthreads();
+        const float theta = fminf(fminf(w_f[1][0], w_f[1][1]), fminf(w_f[1][2], w_f[1][3]));
+        // gather (logit, label) of every candidate >= theta into es[] / zs[] (both free from here: zs[blank] was read above)
+        int* cand_v = reinterpret_cast<int*>(zs);
+        float* cand_z = es;
+        const int cap = V < 256 ? V : 256;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (!((gone >> e) & 1u) && zreg[e] >= theta) {
+                const int slot = atomicAdd(&s_good, 1);
+                if (slot < cap) { cand_z[slot] = zreg[e]; cand_v[slot] = tid + 256 * e; }
+            }
+        __syncthreads();
+        const int n_c = s_good;
+        if (n_c <= cap) {                                            // (else: a plateau of equal logits; the rounds below handle it)
+            ranked = true;
+            n_child = n_c < beam_k ? n_c : beam_k;
+            if (tid < n_c) {
+                const float zi = cand_z[tid];
+                const int vi = cand_v[tid];
+                int rank = 0;
+                for (int o = 0; o < n_c; ++o) {
+                    const float zo = cand_z[o];
+                    const int vo = cand_v[o];
+                    rank += (zo > zi) | ((zo == zi) & (vo < vi));
+                }
+                if (rank < n_child) {                                // pick `rank`: the open list takes it in that position
+                    const size_t o = hb + nh0 + rank;
+                    bs.h_score[o] = hs + (zi - lse);
+                    bs.h_node[o] = cnode; bs.h_tok[o] = vi; bs.h_slot[o] = own; bs.h_len[o] = clen + 1; bs.h_alive[o] = 1;
+                }
+            }
+        }
     }
-    // the beam_k best labels by (logit desc, index asc), one per round: every round takes the best entry that comes strictly
-    // after the previous pick in that order
-    float pz = INFINITY;
-    int pv = -1, n_child = 0;
-    for (int j = 0; j < beam_k; ++j) {
+    // General path, one label per round: the first maximum of what has not been taken yet
+    for (int j = 0; !ranked && j < beam_k; ++j) {
         float bz = -INFINITY;
         int bv = -1;
-        for (int v = tid; v < V; v += 256) {
-            if (v == blank) continue;
-            const float zv = zs[v];
-            if (!(zv < pz || (zv == pz && v > pv))) continue;
-            if (bv < 0 || zv > bz) { bz = zv; bv = v; }
-        }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float oz = __shfl_xor(bz, off, 64);
-            const int ov = __shfl_xor(bv, off, 64);
-            if (ov >= 0 && (bv < 0 || oz > bz || (oz == bz && ov < bv))) { bz = oz; bv = ov; }
+        for (int e = 0; e < EPT; ++e) {                              // ascending v: a later equal logit does not displace
+            const bool take = !((gone >> e) & 1u) & ((bv < 0) | (zreg[e] > bz));
+            bz = take ? zreg[e] : bz;
+            bv = take ? tid + 256 * e : bv;
         }
+        wave_argmax(bz, bv);
         if (lane == 0) { w_f[j & 1][wave] = bz; w_i[j & 1][wave] = bv; }
         __syncthreads();
         bz = w_f[j & 1][0]; bv = w_i[j & 1][0];
@@ -245,38 +381,49 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamState bs, DecodeSt
             if (ov >= 0 && (bv < 0 || oz > bz || (oz == bz && ov < bv))) { bz = oz; bv = ov; }
         }
         if (bv < 0) break;
-        if (tid == 0) {
-            const size_t o = hb + nh0 + j;
-            bs.h_score[o] = hs + (bz - lse);
-            bs.h_node[o] = cnode; bs.h_tok[o] = bv; bs.h_state[o] = after; bs.h_len[o] = clen + 1; bs.h_alive[o] = 1;
-        }
-        pz = bz; pv = bv;
-        ++n_child;
+        if ((bv & 255) == tid) gone |= 1u << (bv >> 8);              // its owner retires it
+        if (tid == j) { my_z = bz; my_v = bv; }                       // thread j keeps pick j (a global store here would put its
+        ++n_child;                                                   // round trip into every round's barrier)
+    }
+    if (tid == 255) {                                                // the blank extension
+        bs.k_score[kb + nk] = hs + (zblank - lse);
+        bs.k_node[kb + nk] = cnode; bs.k_slot[kb + nk] = own; bs.k_len[kb + nk] = clen;
+    }
+    if (!ranked && tid < n_child) {
+        const size_t o = hb + nh0 + tid;
+        bs.h_score[o] = hs + (my_z - lse);
+        bs.h_node[o] = cnode; bs.h_tok[o] = my_v; bs.h_slot[o] = own; bs.h_len[o] = clen + 1; bs.h_alive[o] = 1;
     }
     const int nh = nh0 + n_child, nkk = nk + 1;
-    __syncthreads();                                                 // thread 0's entries are visible to the block below
-    // end-of-frame test: at least `beam` kept entries strictly above the maximum of the open list
-    float hm = -INFINITY;
-    for (int i = tid; i < nh; i += 256)
-        if (bs.h_alive[hb + i]) { const float s = bs.h_score[hb + i]; if (s > hm) hm = s; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(hm, off, 64); if (o > hm) hm = o; }
-    if (lane == 0) w_f[0][wave] = hm;
+    __syncthreads();                                                 // the new entries are visible to the block below
+    BEAM_MARK(2)
+    // end-of-frame test: at least `beam` kept entries strictly above the maximum of the open list — whose first maximum is
+    // also the next hypothesis to pop if the frame goes on
+    float hm;
+    int bi;
+    beam_argmax(bs, hb, nh, w_f[0], w_i[0], hm, bi);
     for (int i = tid; i < nkk; i += 256) ks[i] = bs.k_score[kb + i];
-    __syncthreads();
-    hm = fmaxf(fmaxf(w_f[0][0], w_f[0][1]), fmaxf(w_f[0][2], w_f[0][3]));
-    if (tid == 0) { s_good = 0; s_hmax = hm; }
+    if (tid == 0) s_good = 0;
     __syncthreads();
     int good = 0;
     for (int i = tid; i < nkk; i += 256) good += ks[i] > hm;
     if (good) atomicAdd(&s_good, good);
     __syncthreads();
     const int n_good = s_good;
+    const int list = (iter + 1) & 1;
+    BEAM_MARK(3)
     if (n_good < beam) {                                             // the frame goes on
-        if (tid == 0) { bs.nh[b] = nh; bs.nk[b] = nkk; bs.npop[b] = npop + 1; bs.pops[b] += 1; }
+        if (tid == 0) { bs.nh[b] = nh; bs.nk[b] = nkk; bs.npop[b] = npop + 1; bs.nfree[b] = nfree - is_new; bs.pops[b] += 1; }
+        __syncthreads();
+        beam_pop(bs, st, b, B, L, H, J, bi, hm, list);
+        BEAM_MARK(4)
         return;
     }
-    // ---- end of frame: survivors ascending by score (ties in kept order) become the next frame's open list ----
+    // ---- end of frame: survivors ascending by score (ties in kept order) become the next frame's open list; every slot that
+    // no survivor owns goes back to the free list (in any order: slot ids never reach a result) ----
+    for (int sl = tid; sl < bs.n_slots; sl += 256) used[sl] = sl == 0;
+    if (tid == 0) s_nfree = 0;
+    __syncthreads();
     for (int i = tid; i < nkk; i += 256) {
         const float si = ks[i];
         if (!(si > hm)) continue;
@@ -285,24 +432,29 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamState bs, DecodeSt
             const float so = ks[o];
             if (so > hm && (so < si || (so == si && o < i))) ++rank;
         }
+        const int slot = bs.k_slot[kb + i];
         bs.h_score[hb + rank] = si;
-        bs.h_node[hb + rank] = bs.k_node[kb + i]; bs.h_tok[hb + rank] = -1; bs.h_state[hb + rank] = rank;
+        bs.h_node[hb + rank] = bs.k_node[kb + i]; bs.h_tok[hb + rank] = -1; bs.h_slot[hb + rank] = slot;
         bs.h_len[hb + rank] = bs.k_len[kb + i]; bs.h_alive[hb + rank] = 1;
-        kslot[rank] = bs.k_state[kb + i];
+        used[slot] = 1;
     }
     __syncthreads();
+    BEAM_MARK(5)
     const int t_next = bs.t[b] + 1;
     const bool last = t_next >= enc_lens[b];
     if (!last) {
-        for (int r = 0; r < n_good; ++r) {
-            const float* src = pool_cur + (size_t)kslot[r] * 2 * LH;
-            float* dst = pool_nxt + (size_t)r * 2 * LH;
-            for (int i = tid; i < 2 * LH; i += 256) dst[i] = src[i];
-        }
+        for (int sl = tid; sl < bs.n_slots; sl += 256)
+            if (!used[sl]) fl[atomicAdd(&s_nfree, 1)] = sl;
+        __syncthreads();
+        BEAM_MARK(6)
         if (tid == 0) {
-            bs.nh[b] = n_good; bs.nk[b] = 0; bs.npop[b] = 0; bs.ninit[b] = n_good; bs.pool[b] = pool ^ 1; bs.t[b] = t_next;
+            bs.nh[b] = n_good; bs.nk[b] = 0; bs.npop[b] = 0; bs.nfree[b] = s_nfree; bs.t[b] = t_next;
             bs.pops[b] += 1;
         }
+        __syncthreads();                                             // the new list and the counters are in place
+        beam_argmax(bs, hb, n_good, w_f[1], w_i[1], hm, bi);
+        beam_pop(bs, st, b, B, L, H, J, bi, hm, list);
+        BEAM_MARK(7)
         return;
     }
     // ---- last frame: the first maximum of score / len(yseq) (or of score) over the survivors in their order ----
@@ -314,12 +466,7 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamState bs, DecodeSt
             const float norm = score_norm ? sc / (float)bs.h_len[hb + r] : sc;
             if (br < 0 || norm > bn) { bn = norm; br = r; }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float on = __shfl_xor(bn, off, 64);
-            const int orr = __shfl_xor(br, off, 64);
-            if (orr >= 0 && (br < 0 || on > bn || (on == bn && orr < br))) { bn = on; br = orr; }
-        }
+        wave_argmax(bn, br);
         if (lane == 0) s_best = br;
     }
     __syncthreads();
@@ -341,11 +488,12 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamState bs, DecodeSt
         }
         atomicAdd(&bs.flags[0], 1);
     }
+    BEAM_MARK(8)
 }
 
 struct BeamPlan {
-    size_t b4, h4, k4, nodes, states, state1, g, rows4, z, total;
-    int max_h, max_nodes, slots, zstride;
+    size_t b4, h4, k4, nodes, slots, freelist, state1, g, rows4, z, total;
+    int max_h, max_nodes, n_slots, slot_floats, zstride;
 };
 
 BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam_k, int tp_max, int max_pops) {
@@ -353,18 +501,20 @@ BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam_k, int tp_max, int max_pop
     BeamPlan p;
     p.max_h = max_pops * (beam_k + 1) + 1;
     p.max_nodes = (tp_max > 0 ? tp_max : 1) * max_pops + 1;        // a pop adds at most one node
-    p.slots = 2 * max_pops;
+    p.n_slots = 2 * max_pops + 1;                                    // zero state + survivors (<= max_pops) + evaluations of a frame (<= max_pops)
+    p.slot_floats = 2 * d.pred_layers * d.pred_hidden + d.joint_hidden;
     p.zstride = (d.n_logits + 63) / 64 * 64;
     p.b4 = rs_align((size_t)B * 4);
     p.h4 = rs_align((size_t)B * p.max_h * 4);
     p.k4 = rs_align((size_t)B * max_pops * 4);
     p.nodes = rs_align((size_t)B * p.max_nodes * 8);
     p.state1 = rs_align((size_t)d.pred_layers * B * d.pred_hidden * 4);
-    p.states = rs_align((size_t)2 * B * p.slots * 2 * d.pred_layers * d.pred_hidden * 4);
+    p.slots = rs_align((size_t)B * p.n_slots * p.slot_floats * 4);
+    p.freelist = rs_align((size_t)B * p.n_slots * 4);
     p.g = rs_align((size_t)B * d.joint_hidden * 4);
     p.rows4 = rs_align((size_t)B * 4);
     p.z = rs_align((size_t)B * p.zstride * 4);
-    p.total = 13 * p.b4 + 6 * p.h4 + 4 * p.k4 + p.nodes + p.states + 4 * p.state1 + p.g + 6 * p.rows4 + 2 * rs_align(64) + p.z + 1024;
+    p.total = 13 * p.b4 + 6 * p.h4 + 4 * p.k4 + p.nodes + p.slots + p.freelist + 4 * p.state1 + p.g + 6 * p.rows4 + 2 * rs_align(64) + rs_align(256) + p.z + 1024;
     return p;
 }
 
@@ -388,10 +538,11 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     if (V < 2) return rs_fail(ctx, RS_EINVAL, "beam search: vocabulary of %d", V);
     const int bm = beam < V ? beam : V, beam_k = bm < V - 1 ? bm : V - 1;
     const int mp = clamp_pops(bm, max_pops);
+    if (bm > 128) return rs_fail(ctx, RS_EINVAL, "beam search: beam size must be 1..128");
     if (mp < bm) return rs_fail(ctx, RS_EINVAL, "beam search: max_pops %d < beam %d (a frame needs at least `beam` pops)", mp, bm);
     const BeamPlan pl = beam_plan(ctx, B, beam_k, tp_max, mp);
     if (workspace_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "beam search: workspace %zu < %zu", workspace_bytes, pl.total);
-    const size_t lds = (size_t)pl.zstride * 4 + (size_t)mp * 8;
+    const size_t lds = (size_t)pl.zstride * 8 + (size_t)mp * 4 + (size_t)pl.n_slots * 4;
     if (lds > 60 * 1024) return rs_fail(ctx, RS_EINVAL, "beam search: vocabulary %d / max_pops %d exceed the expand kernel's LDS", V, mp);
     char* w = reinterpret_cast<char*>(workspace);
     auto take = [&](size_t bytes) { char* q = w; w += bytes; return q; };
@@ -400,20 +551,23 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     // every int32 / float bookkeeping array first (one memset), then the big buffers
     char* zero_from = w;
     bs.t = (int32_t*)take(pl.b4); bs.done = (int32_t*)take(pl.b4); bs.nh = (int32_t*)take(pl.b4); bs.nk = (int32_t*)take(pl.b4);
-    bs.npop = (int32_t*)take(pl.b4); bs.ninit = (int32_t*)take(pl.b4); bs.pool = (int32_t*)take(pl.b4);
+    bs.npop = (int32_t*)take(pl.b4); bs.nfree = (int32_t*)take(pl.b4);
     bs.nnode = (int32_t*)take(pl.b4); bs.pops = (int32_t*)take(pl.b4);
-    bs.cur_score = (float*)take(pl.b4); bs.cur_node = (int32_t*)take(pl.b4); bs.cur_state = (int32_t*)take(pl.b4);
-    bs.cur_len = (int32_t*)take(pl.b4);
+    bs.cur_score = (float*)take(pl.b4); bs.cur_node = (int32_t*)take(pl.b4); bs.cur_slot = (int32_t*)take(pl.b4);
+    bs.cur_len = (int32_t*)take(pl.b4); bs.cur_new = (int32_t*)take(pl.b4);
     bs.flags = (int32_t*)take(rs_align(64));
     int32_t* counters = (int32_t*)take(rs_align(64));
+    unsigned long long* trace = (unsigned long long*)take(rs_align(256));
+    bs.trace = getenv("RS_BEAM_TRACE") ? trace : nullptr;
     const size_t zero_bytes = (size_t)(w - zero_from);
     bs.h_score = (float*)take(pl.h4); bs.h_node = (int32_t*)take(pl.h4); bs.h_tok = (int32_t*)take(pl.h4);
-    bs.h_state = (int32_t*)take(pl.h4); bs.h_len = (int32_t*)take(pl.h4); bs.h_alive = (int32_t*)take(pl.h4);
-    bs.k_score = (float*)take(pl.k4); bs.k_node = (int32_t*)take(pl.k4); bs.k_state = (int32_t*)take(pl.k4);
+    bs.h_slot = (int32_t*)take(pl.h4); bs.h_len = (int32_t*)take(pl.h4); bs.h_alive = (int32_t*)take(pl.h4);
+    bs.k_score = (float*)take(pl.k4); bs.k_node = (int32_t*)take(pl.k4); bs.k_slot = (int32_t*)take(pl.k4);
     bs.k_len = (int32_t*)take(pl.k4);
     bs.nodes = (int2*)take(pl.nodes);
-    bs.states = (float*)take(pl.states);
-    bs.max_h = pl.max_h; bs.max_pops = mp; bs.max_nodes = pl.max_nodes; bs.slots = pl.slots;
+    bs.slots = (float*)take(pl.slots);
+    bs.freelist = (int32_t*)take(pl.freelist);
+    bs.max_h = pl.max_h; bs.max_pops = mp; bs.max_nodes = pl.max_nodes; bs.n_slots = pl.n_slots; bs.slot_floats = pl.slot_floats;
     st.h = (float*)take(pl.state1); st.c = (float*)take(pl.state1);
     st.h_tmp = (float*)take(pl.state1); st.c_tmp = (float*)take(pl.state1);
     st.g = (float*)take(pl.g);
@@ -425,12 +579,15 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     st.zapprox = (float*)take(pl.z);
     st.joint_act = d.joint_act;
 
-    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)beam_expand_kernel, (int)lds); rc != RS_OK) return rc;
+    auto expand = V <= 256 * 4 ? beam_expand_kernel<4> : V <= 256 * 12 ? beam_expand_kernel<12> : V <= 256 * 20 ? beam_expand_kernel<20> : beam_expand_kernel<32>;
+    if (V > 256 * 32) return rs_fail(ctx, RS_EINVAL, "beam search: vocabulary %d > 8192", V);
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)expand, (int)lds); rc != RS_OK) return rc;
     rs_prof_begin(ctx, RS_PROF_DECODE, s, 0.0, 0.0);
     RS_HIP(ctx, hipMemsetAsync(zero_from, 0, zero_bytes, s));
-    // slot 0 of pool 0 of every utterance: the zero state the search starts from
-    RS_HIP(ctx, hipMemset2DAsync(bs.states, (size_t)pl.slots * 2 * L * H * 4, 0, (size_t)2 * L * H * 4, B, s));
+    // slot 0 of every utterance: the zero state the search starts from
+    RS_HIP(ctx, hipMemset2DAsync(bs.slots, (size_t)pl.n_slots * pl.slot_floats * 4, 0, (size_t)pl.slot_floats * 4, B, s));
     hipLaunchKernelGGL(beam_init_kernel, dim3((B + 255) / 256), dim3(256), 0, s, bs, st, enc_lens, B, d.blank_id, n_ids, scores, pops);
+    hipLaunchKernelGGL(beam_first_pop_kernel, dim3(B), dim3(256), 0, s, bs, st, B, L, H, J);
     RS_CHECK_LAUNCH(ctx, "beam init");
 
     const int CHUNK = 32;
@@ -440,11 +597,10 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     bool finished = false;
     while (!finished && it < max_iters) {
         for (int c = 0; c < CHUNK; ++c, ++it) {
-            hipLaunchKernelGGL(beam_pop_kernel, dim3(B), dim3(64), 0, s, bs, st, B, L, H);
             if (int rc = rs_rnnt_launch_lstm_pred(ctx, &st, B, s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
-            if (int rc = rs_rnnt_launch_joint_logits(ctx, &st, joint_enc, B, tp_max, 1, 0, s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
-            hipLaunchKernelGGL(beam_expand_kernel, dim3(B), dim3(256), lds, s, bs, st, st.zapprox, pl.zstride, enc_lens, B, L, H, V,
-                               d.blank_id, bm, beam_k, score_norm, out_cap, ids, n_ids, scores, pops);
+            if (int rc = rs_rnnt_launch_joint_logits(ctx, &st, joint_enc, B, tp_max, 1, (int)(it & 1), s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
+            hipLaunchKernelGGL(expand, dim3(B), dim3(256), lds, s, bs, st, st.zapprox, pl.zstride, enc_lens, B, L, H, J, V,
+                               d.blank_id, bm, beam_k, score_norm, out_cap, (int)(it & 1), ids, n_ids, scores, pops);
         }
         RS_CHECK_LAUNCH(ctx, "beam step");
         RS_HIP(ctx, hipMemcpyAsync(hf, bs.flags, sizeof hf, hipMemcpyDeviceToHost, s));
@@ -452,6 +608,15 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
         finished = hf[0] >= B;
     }
     rs_prof_end(ctx, RS_PROF_DECODE, s);
+    if (bs.trace) {                                                  // diagnostic: where the expand kernel's workgroups spend their time
+        unsigned long long tr[18];
+        RS_HIP(ctx, hipMemcpy(tr, trace, sizeof tr, hipMemcpyDeviceToHost));
+        static const char* names[9] = {"park+stage+max", "exp+lse", "label rounds", "argmax+count", "pop (frame goes on)", "rank survivors",
+                                       "free slots", "argmax+pop (new frame)", "read back"};
+        for (int i = 0; i < 9; ++i)
+            fprintf(stderr, "[beam trace] %-24s %10llu passes  %8.2f us each (100 MHz wall clock)\n", names[i], tr[2 * i + 1],
+                    tr[2 * i + 1] ? (double)tr[2 * i] / (double)tr[2 * i + 1] / 100.0 : 0.0);
+    }
     if (!finished) return rs_fail(ctx, RS_ESTATE, "beam search: %d of %d utterances unfinished after %lld iterations", B - hf[0], B, it);
     if (hf[1]) return rs_fail(ctx, RS_EOVERFLOW, "beam search: a frame needed more than max_pops=%d prediction-network evaluations, or a result has more than out_cap=%d labels", mp, out_cap);
     return RS_OK;
