@@ -377,6 +377,10 @@ def extra_configs(model, cfg, sd, args, host_sets):
         out["espnet_120m"] = espnet_config(model.device, args)
     except Exception as e:
         out["espnet_120m"] = {"error": repr(e)}
+    try:
+        out["espnet_120m_beam20"] = espnet_beam_config(model.device, args)
+    except Exception as e:
+        out["espnet_120m_beam20"] = {"error": repr(e)}
     return out
 
 
@@ -424,6 +428,69 @@ def espnet_config(device, args):
         res["parity"] = {"utterances": k, "checker": "oracle/espnet.py (fp32 CPU restatement of the ESPnet2 model; unpinned against ESPnet itself)",
                          "encoder_max_err": round(float((enc.cpu()[:, :n] - ref["enc"][:, :n]).abs().max()), 4),
                          "decode_bit_exact_given_same_joint_enc": got.ids == [r[0] for r in same] and got.frames == [r[1] for r in same]}
+    except Exception as e:
+        res["parity"] = {"error": repr(e)}
+    del bufs, em
+    torch.cuda.empty_cache()
+    return res
+
+
+def espnet_beam_config(device, args, beam=20, max_pops=640):
+    """`reazonspeech.espnet.asr` with the decode the reference actually runs: Speech2Text's default transducer beam search
+    (beam_size 20, score_norm; pkg/espnet-asr/src/transcribe.py:27-31) on the device (k_rnnt_beam.hip), pipelined behind the
+    encoder like every other configuration.  The synthetic checkpoint is the one the beam-search tests use (dec_gain 8: an
+    untrained joint in which the encoder dominates makes the default search extend a frame without end).  Parity: two
+    utterances, first 64 frames, against oracle/espnet_beam.c on the same joint-encoder projection — labels, scores, pop counts."""
+    from reazonspeech_amd.runtime.config import ESPNET_CONFORMER_120M
+    from reazonspeech_amd.runtime.weights_espnet import synthetic_state_dict_espnet
+    from reazonspeech_amd.espnet.asr.model import EspnetModel, synthetic_token_list, PADDING
+    cfg = ESPNET_CONFORMER_120M
+    sd = synthetic_state_dict_espnet(cfg, 0, blank_bias=16.0, dec_gain=8.0)
+    em = EspnetModel(cfg, sd, synthetic_token_list(cfg.vocab_size, 0), device=str(device), beam_size=beam, max_pops=max_pops)
+    am = em.am
+    n_sets = max(1 + args.dec_streams, 3)
+    bufs, secs = [], []
+    for k in range(n_sets):
+        audio, lens = synthetic_batch(args.batch, args.seconds, seed=4242 + 1000 * k)
+        waves = [np.pad(audio[i, :lens[i]], PADDING) for i in range(args.batch)]
+        bufs.append(am.stage(waves, buf=am.new_buffers(args.batch, len(waves[0]))))
+        secs.append(float(lens.sum()) / 16000.0)
+    torch.cuda.synchronize()
+    steps = 4
+    dt = timed_pipeline(am, bufs, steps, 2, args.dec_streams)
+    pops = bufs[0].pops.cpu().numpy().astype(np.float64)
+    frames = float(bufs[0].enc_lens.sum())
+    res = {"workload": f"{args.batch} x {args.seconds:g} s per step (+ (16000, 8000) samples of padding each), ESPnet Conformer-Transducer "
+                       f"{cfg.n_params() / 1e6:.0f}M, default transducer beam search, beam {beam}, score_norm (Speech2Text's defaults), "
+                       f"HBM-resident, pipelined, {args.dec_streams} decode lane(s)",
+           "value": round(sum(secs[i % n_sets] for i in range(steps)) / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+           "enc_frames": bufs[0].tp_max, "mean_tokens_per_utt": round(float(bufs[0].n_ids.cpu().numpy().mean()), 1),
+           "pops_per_frame": round(float(pops.sum() / max(frames, 1.0)), 2), "max_pops_per_utterance": int(pops.max())}
+    try:
+        from oracle import greedy as og
+        b0 = bufs[0]
+        k, T = 2, 64
+        el = np.minimum(b0.enc_lens.cpu().numpy()[:k], T).astype(np.int32)
+        f = b0.joint_enc[:k].cpu().numpy()
+        want = og.espnet_beam(cfg, sd, f, el, beam=beam, max_pops=max_pops, out_cap=b0.u_max)
+        dev = am.device
+        sub = am.stage([np.zeros(16, np.float32)] * k)          # a k-row buffer set for the outputs
+        je = torch.zeros((k, b0.tp_max, cfg.joint_hidden), dtype=torch.float32, device=dev)
+        je.copy_(b0.joint_enc[:k])
+        ids = torch.zeros((k, b0.u_max), dtype=torch.int32, device=dev)
+        n_ids = torch.zeros((k,), dtype=torch.int32, device=dev)
+        sc = torch.zeros((k,), dtype=torch.float32, device=dev)
+        pp = torch.zeros((k,), dtype=torch.int32, device=dev)
+        ws = torch.empty((am.ctx.beam_workspace_bytes(k, beam, b0.tp_max, max_pops),), dtype=torch.uint8, device=dev)
+        am.ctx.rnnt_beam(je, torch.from_numpy(el).to(dev), k, b0.tp_max, beam, True, max_pops, ids, n_ids, sc, pp, ws,
+                         torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        n = n_ids.cpu().numpy()
+        got = [(ids[i, :n[i]].cpu().tolist(), float(sc[i]), int(pp[i])) for i in range(k)]
+        res["parity"] = {"utterances": k, "frames": T, "checker": "oracle/espnet_beam.c (float32, fixed order; follows the torch restatement of "
+                         "ESPnet's default_beam_search — unpinned against ESPnet itself)",
+                         "labels_scores_pops_bit_exact": got == [(w[0], float(np.float32(w[1])), w[2]) for w in want]}
+        del sub
     except Exception as e:
         res["parity"] = {"error": repr(e)}
     del bufs, em

@@ -18,6 +18,8 @@
 // Work lists keep the step cost proportional to the rows that still need it: the joint runs over
 // the rows still decoding (`alive`), the LSTM over the rows that just emitted a non-blank (`act`).
 // Tiles are [32 rows] x [64 columns] so that operands fetched from L2 are reused 2-4x in registers.
+#include <cstdlib>
+
 #include "k_rnnt_common.h"
 
 namespace {
@@ -153,6 +155,8 @@ __global__ __launch_bounds__(1024) void rnnt_lstm_kernel(DecodeState st, int lay
 // ---- [32 rows] x [64 cols] tile of  out = W . a + bias  with the 8 K slices on the 8 waves --------------
 // MODE 0: prediction projection g = W_p . h_top + b_p over the `act` rows (+ LSTM state commit)
 // MODE 1: joint logits  W_o . relu(f[b][t_b] + g[b]) + b_o over the `alive` rows, per-tile argmax
+// MODE 3: MODE 2 with row r's prediction vector at st.g + st.g_off[r] (the default beam search, k_rnnt_beam.hip: the vectors
+//         stay where they are cached)
 // MODE 2: the same logits written out in full (beam search, k_rnnt_alsd.hip): rows are hypotheses, `rows_per_utt`
 //         consecutive rows share an utterance's encoder frames; logits go to st.zapprox with row stride 64 * n_ctiles
 template <int MODE>
@@ -171,6 +175,11 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
         st.counters[0] = 0;
         st.counters[2 + ((step + 1) & 1)] = 0;
     }
+    // MODE >= 1 is launched with gridDim.x rounded up to a multiple of 8 (joint_grid_x): workgroups go to the 8 XCDs round-robin
+    // by linear id = ct + gridDim.x * rt, so with a multiple of 8 a column tile lands on XCD ct % 8 in EVERY row tile and each
+    // XCD's L2 keeps its eighth of W_o (0.8 of 6.6 MB at V = 2600) across row tiles and across steps; with gridDim.x = 41 every
+    // XCD pulled all of W_o through the fabric once per launch.
+    if (MODE >= 1 && ct >= n_ctiles) return;
     if (rt * 32 >= n_rows) return;
     if (tid < 32) {
         const int i = rt * 32 + tid;
@@ -191,9 +200,9 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
         } else {
             int t = st.tcur[row];
             t = t < Tp ? t : Tp - 1;
-            const int utt = MODE == 2 ? row / rows_per_utt : row;
+            const int utt = MODE >= 2 ? row / rows_per_utt : row;
             asrc[ri] = f + ((size_t)utt * Tp + t) * K;
-            gsrc[ri] = st.g + (size_t)row * K;
+            gsrc[ri] = MODE == 3 ? st.g + st.g_off[row] : st.g + (size_t)row * K;
         }
     }
     // fragment-major weights ([ceil(N/16)][K/16][lane][4], rows past N are zero)
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
         if (v < N) {
             s = s + bias[v];
             if (MODE == 0) { if (row_ok) st.g[(size_t)brow * N + v] = s; }
-            else if (MODE == 2) { if (row_ok) st.zapprox[(size_t)brow * (64 * n_ctiles) + v] = s; }
+            else if (MODE >= 2) { if (row_ok) st.zapprox[(size_t)brow * (64 * n_ctiles) + v] = s; }
             else if (s > best) { best = s; best_idx = v; }
         }
     }
@@ -757,11 +766,18 @@ void launch_lstm_pred(rs_ctx* ctx, const DecodeState& st, int B, int rows_bound,
                        0, L, H, H, J, ctx->jpred_w, ctx->jpred_b, 0, 0, 1);
 }
 
+// column-tile extent of a joint launch: a multiple of 8 when there is more than one row tile (see rnnt_tile_kernel)
+int joint_grid_x(int nct, int rts) {
+    static const bool off = getenv("RS_DECODE_NO_XCD") != nullptr;     // A/B hook
+    return rts > 1 && !off ? (nct + 7) / 8 * 8 : nct;
+}
+
 int ensure_decode_lds(rs_ctx* ctx) {
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_lstm_kernel, LSTM_LDS); rc != RS_OK) return rc;
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<0>, TILE_LDS); rc != RS_OK) return rc;
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<1>, TILE_LDS); rc != RS_OK) return rc;
-    return rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<2>, TILE_LDS);
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<2>, TILE_LDS); rc != RS_OK) return rc;
+    return rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<3>, TILE_LDS);
 }
 
 }  // namespace
@@ -779,7 +795,20 @@ int rs_rnnt_launch_joint_logits(rs_ctx* ctx, const void* st_ptr, const float* jo
     if (int rc = ensure_decode_lds(ctx); rc != RS_OK) return rc;
     const rs_dims& d = ctx->d;
     const int nct = (d.n_logits + 63) / 64;
-    hipLaunchKernelGGL(rnnt_tile_kernel<2>, dim3(nct, (rows + 31) / 32), dim3(512), TILE_LDS, s,
+    hipLaunchKernelGGL(rnnt_tile_kernel<2>, dim3(joint_grid_x(nct, (rows + 31) / 32), (rows + 31) / 32), dim3(512), TILE_LDS, s,
+                       *reinterpret_cast<const DecodeState*>(st_ptr), joint_enc, rows, tp_max, d.pred_layers, d.pred_hidden,
+                       d.joint_hidden, d.n_logits, ctx->jout_w, ctx->jout_b, nct, step, rows_per_utt);
+    return RS_OK;
+}
+
+// the same with indirect prediction vectors (st.g_off); `rows` = extent of the row space (the alive lists have that stride)
+int rs_rnnt_launch_joint_logits_indirect(rs_ctx* ctx, const void* st_ptr, const float* joint_enc, int rows, int rows_bound, int tp_max,
+                                         int rows_per_utt, int step, hipStream_t s) {
+    if (int rc = ensure_decode_lds(ctx); rc != RS_OK) return rc;
+    const rs_dims& d = ctx->d;
+    const int nct = (d.n_logits + 63) / 64;
+    const int rts = (rows_bound + 31) / 32 > 0 ? (rows_bound + 31) / 32 : 1;
+    hipLaunchKernelGGL(rnnt_tile_kernel<3>, dim3(joint_grid_x(nct, rts), rts), dim3(512), TILE_LDS, s,
                        *reinterpret_cast<const DecodeState*>(st_ptr), joint_enc, rows, tp_max, d.pred_layers, d.pred_hidden,
                        d.joint_hidden, d.n_logits, ctx->jout_w, ctx->jout_b, nct, step, rows_per_utt);
     return RS_OK;
@@ -814,6 +843,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     char* w = reinterpret_cast<char*>(workspace);
     auto take = [&](size_t bytes) { char* p = w; w += rs_align(bytes); return p; };
     DecodeState st;
+    st.g_off = nullptr;
     st.joint_act = d.joint_act;
     const size_t state_bytes = (size_t)L * B * H * 4;
     st.h = (float*)take(state_bytes); st.c = (float*)take(state_bytes);
@@ -875,7 +905,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
                 // both kernels walk the compacted alive list: only the row tiles / slots the bound covers are launched
                 // (next to the encoder every workgroup, even one that exits at once, has to wait for a free CU)
                 const int rts = (rows + 31) / 32 > 0 ? (rows + 31) / 32 : 1;
-                hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(nct, rts), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H, J,
+                hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(joint_grid_x(nct, rts), rts), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H, J,
                                    V, ctx->jout_w, ctx->jout_b, nct, steps, 1);
                 hipLaunchKernelGGL(rnnt_finalize_kernel, dim3((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1), dim3(256), 0, s, st, enc_lens, B, nct,
                                    d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);

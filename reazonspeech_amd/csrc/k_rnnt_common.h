@@ -61,6 +61,7 @@ struct DecodeState {
     uint16_t* a16;   // [B][J] bf16 relu(f + g) of alive slot i
     float* anorm;    // [B]    ||relu(f + g)||_2 of alive slot i (rounded up)
     float* zapprox;  // [B][Vpad] approximate logits of alive slot i (bf16 MFMA GEMM, f32 accumulate, + bias)
+    const long long* g_off;   // rnnt_tile_kernel<3> only: [rows] offset (floats, from `g`) of row r's joint.pred vector
     int joint_act;   // 0: relu(f + g) (NeMo RNNTJoint); 1: tanh(f + g) (ESPnet JointNetwork) — exact-tile kernels only
 };
 
