@@ -167,7 +167,8 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
     extern __shared__ __attribute__((aligned(16))) char tile_smem[];
     float (*part)[32][65] = reinterpret_cast<float (*)[32][65]>(tile_smem);   // [SPLITK_TILE][32][65]
     int* rows_s = reinterpret_cast<int*>(tile_smem + SPLITK_TILE * 32 * 65 * 4);
-    const int rt = blockIdx.y, ct = blockIdx.x;
+    int rt = blockIdx.y;
+    const int ct = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t* list = MODE == 0 ? st.act : st.alive + (size_t)(step & 1) * B;
     const int n_rows = MODE == 0 ? st.counters[0] : st.counters[2 + (step & 1)];
@@ -180,6 +181,9 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
     // XCD's L2 keeps its eighth of W_o (0.8 of 6.6 MB at V = 2600) across row tiles and across steps; with gridDim.x = 41 every
     // XCD pulled all of W_o through the fabric once per launch.
     if (MODE >= 1 && ct >= n_ctiles) return;
+    // MODE 3 walks the row tiles with stride gridDim.y (its list can be anything from a handful of rows to rows_per_utt per
+    // utterance, and the launch cannot know): every other mode has one row tile per workgroup and leaves after the first pass
+    for (;; rt += gridDim.y) {
     if (rt * 32 >= n_rows) return;
     if (tid < 32) {
         const int i = rt * 32 + tid;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
             for (int r = 0; r < 4; ++r) part[wave][ri * 16 + 4 * kk + r][cj * 16 + li] = acc[ri][cj][r];
     __syncthreads();
     // thread = (row i, 8 consecutive columns); waves 4..7 are done
-    if (tid >= 256) return;
+    if (tid >= 256) { if (MODE == 3) { __syncthreads(); continue; } return; }
     const int i = tid >> 3, c0 = (tid & 7) * 8;
     const bool row_ok = rt * 32 + i < n_rows;
     const int brow = rows_s[i];
@@ -318,6 +322,9 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
                     st.h[o] = st.h_tmp[o];
                     st.c[o] = st.c_tmp[o];
                 }
+    }
+    if (MODE != 3) return;
+    __syncthreads();                                     // `part` / `rows_s` are rewritten by the next row tile
     }
 }
 

@@ -3,19 +3,30 @@
 // Speech2Text with its defaults — beam_size 20, search_type "default", score_norm, nbest 1, no LM
 // (pkg/espnet-asr/src/transcribe.py:27-31).
 //
-// The search is frame-synchronous per utterance but the number of pops a frame takes is data dependent, so utterances are NOT
-// kept in frame lockstep: every utterance is its own state machine and one device iteration performs ONE pop for every
-// utterance that is still searching, whatever frame it is at.  One iteration = 3 + L launches:
+// Per frame the search pops the best open hypothesis, keeps its blank extension, opens its `beam` best label extensions, and
+// repeats until `beam` kept hypotheses beat everything still open.  What a pop needs is the log-softmax of ONE joint row
+// (hypothesis, frame); which hypotheses get popped is only known as the search goes.  Two facts shape the device version:
 //
-//   LSTM x L + joint.pred   over the utterances whose popped sequence has not been evaluated yet (k_rnnt.hip, exact f32)
-//   joint logits            of every searching utterance at its frame t_b (rnnt_tile_kernel<2>)
-//   beam_expand_kernel      (one workgroup per utterance) log-softmax, the blank extension -> `kept`, the beam_k best labels ->
-//                           the open list, the end-of-frame test (>= beam entries of kept above the maximum of the open list) and,
-//                           at the end of a frame: survivors sorted ascending, their slots compacted into the other pool, t += 1;
-//                           at the last frame the winner by score / len(yseq) is read back through the label trie.  Then the NEXT
-//                           pop of the utterance (the first maximum of the open list, which the end-of-frame test just found):
-//                           a sequence seen for the first time enters the trie and the LSTM work list with the state it starts
-//                           from; one evaluated before only hands its cached joint.pred output to the joint
+//   * the hypotheses that open a frame are the survivors of the previous one (>= beam of them) and nearly all of them are
+//     popped again — so their joint rows at the new frame are computed TOGETHER when the frame starts (up to R of them, best
+//     first), as one tall launch instead of ~beam launches of one row per utterance; a row that turns out not to be needed
+//     costs a few MFLOP and changes nothing;
+//   * the prediction network only depends on the label sequence ([UPSTREAM] decoder.score caches by sequence): a sequence is
+//     evaluated once, when one of its label extensions is popped for the first time, and the result (LSTM state + joint.pred
+//     vector) stays in a slot that its extensions and its own later pops refer to.
+//
+// Utterances are independent state machines (the pop count of a frame is data dependent, so they are NOT kept in frame
+// lockstep).  One device iteration = 4 + L launches:
+//
+//   LSTM x L + joint.pred   over the utterances waiting for a new sequence's evaluation (k_rnnt.hip, exact f32)
+//   joint logits            rnnt_tile_kernel<3> over this iteration's rows: the batch rows of utterances that just entered a
+//                           frame, the single row of those waiting for one evaluation
+//   beam_record_kernel      one wave per row: log-softmax, log p(blank), the beam_k best labels with their log-probabilities
+//   beam_step_kernel        one workgroup per utterance, open-list scores in LDS: applies the finished evaluation(s), then keeps
+//                           popping for as long as the best open hypothesis already has its record; ends the frame when the
+//                           test says so (survivors sorted, slots of everything else freed, t += 1, next batch scheduled, or the
+//                           winner read back through the label trie after the last frame); stops at the first pop that needs an
+//                           evaluation and schedules it
 //
 // Evaluation order (float32 sums, log-sum-exp tree, tie rules) is documented in oracle/espnet_beam.c and the results are
 // bit-identical to it: labels, scores and the pop count.  Compiled with -ffp-contract=off.
@@ -25,8 +36,8 @@
 #include "k_rnnt_common.h"
 
 int rs_rnnt_launch_lstm_pred(rs_ctx* ctx, const void* st_ptr, int rows, hipStream_t s);
-int rs_rnnt_launch_joint_logits(rs_ctx* ctx, const void* st_ptr, const float* joint_enc, int rows, int tp_max, int rows_per_utt,
-                                int step, hipStream_t s);
+int rs_rnnt_launch_joint_logits_indirect(rs_ctx* ctx, const void* st_ptr, const float* joint_enc, int rows, int rows_bound, int tp_max,
+                                         int rows_per_utt, int step, hipStream_t s);
 
 namespace {
 
@@ -58,13 +69,16 @@ struct BeamState {
     // per utterance [B]
     int32_t* t;          // frame being searched
     int32_t* done;
-    int32_t* nh;         // entries of hyps (dead ones included)
+    int32_t* nh;         // entries of the open list (dead ones included)
     int32_t* nk;         // entries of kept
     int32_t* npop;       // pops of the current frame
     int32_t* nfree;      // free slots (entries of freelist)
+    int32_t* ninit;      // hypotheses the current frame started with = entries [0, ninit) of the open list
     int32_t* nnode;      // trie nodes in use
     int32_t* pops;       // pops over the whole utterance (the work measure, returned)
-    // the hypothesis popped for this iteration [B]
+    int32_t* mode;       // what this iteration evaluates: 0 = the one popped hypothesis (row R), 1 = the frame's batch (rows [0, nb))
+    int32_t* nb;
+    // the hypothesis popped for a single evaluation [B]
     float* cur_score;
     int32_t* cur_node;
     int32_t* cur_slot;   // its own slot when cur_new == 0
@@ -77,6 +91,7 @@ struct BeamState {
     int32_t* h_slot;     // h_tok >= 0: slot of the sequence without its last label (the state to start from); else its own slot
     int32_t* h_len;      // len(yseq): labels + the leading blank
     int32_t* h_alive;
+    int32_t* h_rec;      // [B][max_pops] entry i < ninit: batch row that holds its record at the current frame, or -1
     // blank extensions of this frame [B][max_pops]
     float* k_score;
     int32_t* k_node;
@@ -85,15 +100,13 @@ struct BeamState {
     int2* nodes;         // [B][max_nodes] (parent, label)
     float* slots;        // [B][n_slots][slot_floats]: per evaluated sequence  h [L][H], c [L][H] after its last label, g [J]
     int32_t* freelist;   // [B][n_slots] free slot ids; a frame's end returns every slot no survivor owns
+    float* rec;          // [B][R + 1][rec_floats]: log p(blank), label count, log p(label j) x beam_k, label j x beam_k
+    long long* g_off;    // [B][R + 1] where row r's joint.pred vector is, in floats from DecodeState.g
+    long long slots_off; // slots - DecodeState.g
     int32_t* flags;      // [0] utterances done, [1] overflow
-    unsigned long long* trace;   // $RS_BEAM_TRACE: cycles per phase of the expand kernel, summed over workgroups (else null)
-    int max_h, max_pops, max_nodes, n_slots, slot_floats;
+    unsigned long long* trace;   // $RS_BEAM_TRACE: cycles per phase of the step kernel, summed over workgroups (else null)
+    int max_h, max_pops, max_nodes, n_slots, slot_floats, R, rec_floats, beam_k;
 };
-
-// [UPSTREAM] decoder.score(hyp, cache) caches the prediction-network output by label sequence; so does the slot pool: a
-// sequence is evaluated ONCE (when a label extension is popped for the first time) and the ~beam survivors that open every
-// frame are popped again without touching the LSTM — only the joint depends on the frame.  The cached values are the ones
-// the oracle recomputes (same kernels, same inputs), so this changes no bit of the result.
 
 __device__ __forceinline__ void beam_fail(const BeamState& bs, int b) {   // one thread
     bs.done[b] = 1;
@@ -101,13 +114,17 @@ __device__ __forceinline__ void beam_fail(const BeamState& bs, int b) {   // one
     atomicAdd(&bs.flags[0], 1);
 }
 
+// LDS-only barrier: waits for this wave's LDS traffic, not for its global stores (a __syncthreads() also drains vmcnt, which
+// would put the round trip of every fire-and-forget store of the pop loop into the loop)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // grid ceil(B / 256)
-__global__ __launch_bounds__(256) void beam_init_kernel(BeamState bs, DecodeState st, const int32_t* __restrict__ enc_lens, int B,
-                                                        int blank, int32_t* __restrict__ n_ids, float* __restrict__ scores,
+__global__ __launch_bounds__(256) void beam_init_kernel(BeamState bs, const int32_t* __restrict__ enc_lens, int B, int blank,
+                                                        int32_t* __restrict__ n_ids, float* __restrict__ scores,
                                                         int32_t* __restrict__ pops) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    bs.t[b] = 0; bs.nk[b] = 0; bs.npop[b] = 0; bs.pops[b] = 0;
+    bs.t[b] = 0; bs.nk[b] = 0; bs.npop[b] = 0; bs.pops[b] = 0; bs.ninit[b] = 0; bs.mode[b] = 0; bs.nb[b] = 0;
     bs.nnode[b] = 0;
     for (int i = 1; i < bs.n_slots; ++i) bs.freelist[(size_t)b * bs.n_slots + i - 1] = i;
     bs.nfree[b] = bs.n_slots - 1;
@@ -115,7 +132,6 @@ __global__ __launch_bounds__(256) void beam_init_kernel(BeamState bs, DecodeStat
     const size_t h0 = (size_t)b * bs.max_h;
     bs.h_score[h0] = 0.0f; bs.h_node[h0] = -1; bs.h_tok[h0] = blank; bs.h_slot[h0] = 0; bs.h_len[h0] = 1; bs.h_alive[h0] = 1;
     bs.nh[b] = 1;
-    st.token[b] = blank; st.tcur[b] = 0;
     n_ids[b] = 0; scores[b] = 0.0f; pops[b] = 0;
     const int fin = enc_lens[b] <= 0;            // nothing to search: the empty hypothesis, score 0
     bs.done[b] = fin;
@@ -124,8 +140,8 @@ __global__ __launch_bounds__(256) void beam_init_kernel(BeamState bs, DecodeStat
 
 // ---- wave-wide first maximum by (value desc, index asc) on the DPP path: row_shr 1/2/4/8 fold each row of 16 lanes into
 // its lane 15, row_bcast:15 / row_bcast:31 fold the rows into lane 63 (full-rate VALU moves, no LDS crossbar: a ds_bpermute
-// butterfly is 12 dependent ~100-cycle hops, and the search pays one such reduction per label of every expansion).  The order
-// is total, so the fold order does not matter.  Entries with index < 0 are "nothing".  Every lane returns the result.
+// butterfly is 12 dependent ~100-cycle hops).  The order is total, so the fold order does not matter.  Entries with index < 0
+// are "nothing".  Every lane returns the result.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void dpp_fold(float& z, int& v) {
     const float oz = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(z), CTRL, ROW_MASK, 0xf, false));
@@ -143,19 +159,123 @@ __device__ __forceinline__ void wave_argmax(float& z, int& v) {
     v = __builtin_amdgcn_readlane(v, 63);
 }
 
-// ---- block-wide (256 threads) first maximum of the alive entries of the open list: (score desc, index asc) ----
-__device__ __forceinline__ void beam_argmax(const BeamState& bs, size_t hb, int n, float* w_f, int* w_i, float& best, int& bi) {
+// ---- records: one wave per row of this iteration's joint list ----------------------------------------------------------
+// rec[row] = { log p(blank), n (int bits), log p(label_j) for j < beam_k, label_j (int bits) for j < beam_k }, labels by
+// (logit desc, index asc).  log-sum-exp in the documented order: lane l adds exp(z[v] - max) for v = l, l + 64, ..., then the
+// tree p[l] += p[l + off].  Selection: theta = the beam_k-th largest per-lane maximum — at least beam_k logits reach it — the few
+// logits >= theta are gathered in LDS and ranked by counting (a plateau of more than 128 equal logits falls back to one
+// wave-wide maximum per label).
+// grid: any (workgroups stride over the list), block 256, dynamic LDS 4 x (zstride + 256) floats
+__global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeState st, const float* __restrict__ zbuf, int zstride,
+                                                          int rows, int V, int blank, int list) {
+    extern __shared__ __attribute__((aligned(16))) char rec_smem[];
+    __shared__ int s_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* zs = reinterpret_cast<float*>(rec_smem) + (size_t)wave * (zstride + 256);
+    float* cz = zs + zstride;
+    int* cv = reinterpret_cast<int*>(cz + 128);
+    const int n = st.counters[2 + list];
+    const int beam_k = bs.beam_k;
+    for (int idx = blockIdx.x * 4 + wave; idx < n; idx += gridDim.x * 4) {
+        const int row = st.alive[(size_t)list * rows + idx];
+        const float* zr = zbuf + (size_t)row * zstride;
+        float m = -INFINITY, tmax = -INFINITY;
+        int targ = -1;
+        for (int v = lane; v < V; v += 64) {
+            const float zv = zr[v];
+            zs[v] = zv;
+            m = fmaxf(m, zv);
+            const bool take = (v != blank) & ((targ < 0) | (zv > tmax));
+            tmax = take ? zv : tmax;
+            targ = take ? v : targ;
+        }
+        m = wave_max(m);
+        float sum = 0.0f;
+        for (int v = lane; v < V; v += 64) sum = sum + rs_expf(zs[v] - m);     // a lane re-reads what it wrote
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off, 64);
+        sum = __shfl(sum, 0, 64);
+        const float lse = m + rs_logf(sum);
+        float theta = -INFINITY;
+        {
+            float cz_l = tmax;
+            int cv_l = targ;
+            for (int r = 0; r < beam_k; ++r) {
+                float bz = cz_l;
+                int bv = cv_l;
+                wave_argmax(bz, bv);
+                theta = bv < 0 ? -INFINITY : bz;
+                if (bv < 0) break;
+                if (cv_l == bv) cv_l = -1;
+            }
+        }
+        if (lane == 0) s_cnt[wave] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // (a wave's LDS operations execute in order)
+        for (int v = lane; v < V; v += 64) {
+            const float zv = zs[v];
+            if (v != blank && zv >= theta) {
+                const int slot = atomicAdd(&s_cnt[wave], 1);
+                if (slot < 128) { cz[slot] = zv; cv[slot] = v; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int n_c = s_cnt[wave];
+        float* out = bs.rec + (size_t)row * bs.rec_floats;
+        int n_lab = 0;
+        if (n_c <= 128) {
+            n_lab = n_c < beam_k ? n_c : beam_k;
+            for (int c = lane; c < n_c; c += 64) {
+                const float zi = cz[c];
+                const int vi = cv[c];
+                int rank = 0;
+                for (int o = 0; o < n_c; ++o) {
+                    const float zo = cz[o];
+                    const int vo = cv[o];
+                    rank += (zo > zi) | ((zo == zi) & (vo < vi));
+                }
+                if (rank < n_lab) { out[2 + rank] = zi - lse; out[2 + beam_k + rank] = __int_as_float(vi); }
+            }
+        } else {
+            float pz = INFINITY;
+            int pv = -1;
+            for (int j = 0; j < beam_k; ++j) {
+                float bz = -INFINITY;
+                int bv = -1;
+                for (int v = lane; v < V; v += 64) {
+                    const float zv = zs[v];
+                    const bool after = (v != blank) & ((zv < pz) | ((zv == pz) & (v > pv)));
+                    const bool take = after & ((bv < 0) | (zv > bz));
+                    bz = take ? zv : bz;
+                    bv = take ? v : bv;
+                }
+                wave_argmax(bz, bv);
+                if (bv < 0) break;
+                if (lane == 0) { out[2 + j] = bz - lse; out[2 + beam_k + j] = __int_as_float(bv); }
+                pz = bz; pv = bv;
+                ++n_lab;
+            }
+        }
+        if (lane == 0) { out[0] = zs[blank] - lse; out[1] = __int_as_float(n_lab); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // zs / cz are rewritten by this wave's next row
+    }
+}
+
+// ---- block-wide (256 threads) first maximum of the live entries of the LDS score list (dead = NaN) + the number of kept
+// scores strictly above it ----
+__device__ __forceinline__ void list_argmax_count(const float* lsc, int n, const float* ks, int nk, float* w_f, int* w_i, int* s_good,
+                                                  float& best, int& bi, int& n_good) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     best = -INFINITY; bi = -1;
-    for (int i = tid; i < n; i += 256)
-        if (bs.h_alive[hb + i]) {
-            const float s = bs.h_score[hb + i];
-            if (bi < 0 || s > best) { best = s; bi = i; }          // a thread meets its entries in ascending order
-        }
+    for (int i = tid; i < n; i += 256) {
+        const float s = lsc[i];
+        const bool take = (s == s) & ((bi < 0) | (s > best));      // a thread meets its entries in ascending order
+        best = take ? s : best;
+        bi = take ? i : bi;
+    }
     wave_argmax(best, bi);
-    __syncthreads();                                               // w_f / w_i may still be read from an earlier use
     if (lane == 0) { w_f[wave] = best; w_i[wave] = bi; }
-    __syncthreads();
+    if (tid == 0) *s_good = 0;
+    lds_barrier();
     best = w_f[0]; bi = w_i[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
@@ -163,54 +283,60 @@ __device__ __forceinline__ void beam_argmax(const BeamState& bs, size_t hb, int 
         const int oi = w_i[w];
         if (oi >= 0 && (bi < 0 || os > best || (os == best && oi < bi))) { best = os; bi = oi; }
     }
+    int good = 0;
+    for (int i = tid; i < nk; i += 256) good += ks[i] > best;
+    if (good) atomicAdd(s_good, good);
+    lds_barrier();
+    n_good = *s_good;
+    lds_barrier();                                                 // w_f / w_i / s_good are free again
 }
 
-// ---- pop entry `bi` of the open list for the next iteration (block-wide; every thread passes the same bi) ----
-// list = the joint work list the next iteration reads
-__device__ __forceinline__ void beam_pop(const BeamState& bs, const DecodeState& st, int b, int B, int L, int H, int J, int bi,
-                                         float score, int list) {
+// ---- hand entry `bi` of the open list to the next iteration as a single evaluation (block-wide; the caller has made this
+// launch's global stores visible).  list = the joint work list the next iteration reads ----
+__device__ __forceinline__ void schedule_single(const BeamState& bs, const DecodeState& st, int b, int B, int L, int H, int J, int bi,
+                                                float score, int t, int list) {
     const int tid = threadIdx.x;
     const size_t hb = (size_t)b * bs.max_h;
-    const bool none = bi < 0;                                      // cannot happen (a pop always opens beam_k >= 1 extensions)
-    if (none) bi = 0;
     const int tok = bs.h_tok[hb + bi], slot = bs.h_slot[hb + bi];
     int node = bs.h_node[hb + bi];
-    const bool bad = none || bs.npop[b] >= bs.max_pops || (tok >= 0 && bs.nnode[b] >= bs.max_nodes);
-    __syncthreads();                                               // every thread has read the entry and the counters
-    if (bad) { if (tid == 0) beam_fail(bs, b); return; }
-    const int LH = L * H;
-    const float* src = bs.slots + ((size_t)b * bs.n_slots + slot) * (size_t)bs.slot_floats;
+    const int nn = bs.nnode[b];
+    if (tok >= 0 && nn >= bs.max_nodes) { if (tid == 0) beam_fail(bs, b); return; }
+    const int LH = L * H, rows = B * (bs.R + 1), row = b * (bs.R + 1) + bs.R;
+    const size_t slot_off = ((size_t)b * bs.n_slots + slot) * (size_t)bs.slot_floats;
+    __syncthreads();                                               // every thread has read the entry and the node count
     if (tid == 0) {
         bs.h_alive[hb + bi] = 0;
         if (tok >= 0) {                                            // the sequence enters the trie, and the LSTM work list
-            const int nn = bs.nnode[b];
             bs.nodes[(size_t)b * bs.max_nodes + nn] = make_int2(node, tok);
             node = nn;
             bs.nnode[b] = nn + 1;
             st.token[b] = tok;
             st.act[atomicAdd(&st.counters[0], 1)] = b;
+            bs.g_off[row] = (long long)b * J;                      // joint.pred writes row b of the decode state
+        } else {
+            bs.g_off[row] = bs.slots_off + (long long)slot_off + 2 * LH;   // evaluated before: the cached vector
         }
         bs.cur_score[b] = score; bs.cur_node[b] = node; bs.cur_slot[b] = slot; bs.cur_len[b] = bs.h_len[hb + bi];
         bs.cur_new[b] = tok >= 0;
-        st.tcur[b] = bs.t[b];
-        st.alive[(size_t)list * B + atomicAdd(&st.counters[2 + list], 1)] = b;
+        bs.mode[b] = 0;
+        st.tcur[row] = t;
+        st.alive[(size_t)list * rows + atomicAdd(&st.counters[2 + list], 1)] = row;
     }
     if (tok >= 0) {                                                // start state of the evaluation
+        const float* src = bs.slots + slot_off;
         for (int i = tid; i < LH; i += 256) {
             const int l = i / H, u = i - l * H;
             st.h[((size_t)l * B + b) * H + u] = src[i];
             st.c[((size_t)l * B + b) * H + u] = src[LH + i];
         }
-    } else {                                                       // evaluated before: only the joint needs it
-        for (int i = tid; i < J; i += 256) st.g[(size_t)b * J + i] = src[2 * LH + i];
     }
 }
 
-// the first pop of every utterance; grid B, block 256
-__global__ __launch_bounds__(256) void beam_first_pop_kernel(BeamState bs, DecodeState st, int B, int L, int H, int J) {
+// the first pop of every utterance: the start hypothesis; grid B, block 256
+__global__ __launch_bounds__(256) void beam_first_kernel(BeamState bs, DecodeState st, int B, int L, int H, int J) {
     const int b = blockIdx.x;
     if (bs.done[b]) return;
-    beam_pop(bs, st, b, B, L, H, J, 0, 0.0f, 0);
+    schedule_single(bs, st, b, B, L, H, J, 0, 0.0f, 0, 0);
 }
 
 #define BEAM_MARK(phase)                                                                       \
@@ -221,264 +347,175 @@ __global__ __launch_bounds__(256) void beam_first_pop_kernel(BeamState bs, Decod
         t_mark = now;                                                                          \
     }
 
-// grid B, block 256, dynamic LDS: z row [zstride] + exp terms [zstride] + kept scores [max_pops] + slot marks [n_slots]
-// EPT = logits per thread (V <= 256 * EPT): a thread keeps its logits v = tid + 256 e in registers for the label rounds
-template <int EPT>
-__global__ __launch_bounds__(256) void beam_expand_kernel(BeamState bs, DecodeState st, const float* __restrict__ zbuf, int zstride,
-                                                          const int32_t* __restrict__ enc_lens, int B, int L, int H, int J, int V,
-                                                          int blank, int beam, int beam_k, int score_norm, int out_cap, int iter,
-                                                          int32_t* __restrict__ ids, int32_t* __restrict__ n_ids,
-                                                          float* __restrict__ scores, int32_t* __restrict__ pops) {
+// grid B, block 256.  Dynamic LDS (floats / ints): open-list scores [max_h], kept score / node / slot / len [max_pops] each,
+// frame-start hypotheses' node / slot / len / record row [max_pops] each, slot marks [n_slots], records [(R + 1) * rec_floats]
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeState st, const int32_t* __restrict__ enc_lens, int B,
+                                                        int L, int H, int J, int beam, int score_norm, int out_cap, int iter,
+                                                        int32_t* __restrict__ ids, int32_t* __restrict__ n_ids,
+                                                        float* __restrict__ scores, int32_t* __restrict__ pops) {
     extern __shared__ __attribute__((aligned(16))) char beam_smem[];
-    float* zs = reinterpret_cast<float*>(beam_smem);
-    float* es = zs + zstride;                                        // exp(z - max)
-    float* ks = es + zstride;                                        // kept scores
-    int* used = reinterpret_cast<int*>(ks + bs.max_pops);            // slot -> owned by a survivor
-    __shared__ float w_f[2][4];
-    __shared__ int w_i[2][4];
-    __shared__ float s_lse;
-    __shared__ int s_good, s_best, s_nfree;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int MP = bs.max_pops, R = bs.R, RF = bs.rec_floats, K = bs.beam_k;
+    float* lsc = reinterpret_cast<float*>(beam_smem);
+    float* ks = lsc + bs.max_h;
+    int* kn = reinterpret_cast<int*>(ks + MP);
+    int* ksl = kn + MP;
+    int* kl = ksl + MP;
+    int* sn = kl + MP;
+    int* ssl = sn + MP;
+    int* sl = ssl + MP;
+    int* sr = sl + MP;
+    int* used = sr + MP;
+    float* recs = reinterpret_cast<float*>(used + bs.n_slots);
+    __shared__ float w_f[4];
+    __shared__ int w_i[4];
+    __shared__ int s_good, s_nfree;
+    const int b = blockIdx.x, tid = threadIdx.x;
     if (bs.done[b]) return;
     unsigned long long t_mark = bs.trace ? wall_clock64() : 0ull;
     const int LH = L * H, SS = bs.slot_floats;
+    const size_t hb = (size_t)b * bs.max_h, kb = (size_t)b * MP;
     float* pool = bs.slots + ((size_t)b * bs.n_slots) * (size_t)SS;
     int32_t* fl = bs.freelist + (size_t)b * bs.n_slots;
-    const int npop = bs.npop[b], nfree = bs.nfree[b], nk = bs.nk[b], nh0 = bs.nh[b];
-    const int is_new = bs.cur_new[b];
-    // the popped hypothesis' own slot: a fresh one when it was evaluated in this iteration (never short: n_slots - 1 =
-    // 2 * max_pops >= survivors of the last frame + evaluations of this one)
-    const int own = is_new ? fl[nfree - 1] : bs.cur_slot[b];
-    if (is_new) {
-        float* dst = pool + (size_t)own * SS;
-        for (int i = tid; i < LH; i += 256) {
-            const int l = i / H, u = i - l * H;
-            dst[i] = st.h[((size_t)l * B + b) * H + u];
-            dst[LH + i] = st.c[((size_t)l * B + b) * H + u];
-        }
-        for (int i = tid; i < J; i += 256) dst[2 * LH + i] = st.g[(size_t)b * J + i];
-    }
-    const float* zr = zbuf + (size_t)b * zstride;
-    float zreg[EPT];
-    unsigned gone = 0;                                               // bit e: logit e of this thread is not a candidate (any more)
-    float m = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int v = tid + 256 * e;
-        const bool in = v < V;
-        zreg[e] = in ? zr[v] : -INFINITY;
-        if (in) zs[v] = zreg[e];
-        m = fmaxf(m, zreg[e]);
-        gone |= (unsigned)(!in || v == blank) << e;
-    }
-    m = wave_max(m);
-    if (lane == 0) w_f[0][wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(w_f[0][0], w_f[0][1]), fmaxf(w_f[0][2], w_f[0][3]));
-    BEAM_MARK(0)
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {                                  // the terms of the sum; added below in the documented order
-        const int v = tid + 256 * e;
-        if (v < V) es[v] = rs_expf(zreg[e] - m);
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float sum = 0.0f;
-        for (int v = lane; v < V; v += 64) sum = sum + es[v];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off, 64);
-        if (lane == 0) s_lse = m + rs_logf(sum);
-    }
-    __syncthreads();
-    BEAM_MARK(1)
-    const float lse = s_lse;
-    const float zblank = zs[blank];
-    const float hs = bs.cur_score[b];
-    const int cnode = bs.cur_node[b], clen = bs.cur_len[b];
-    const size_t hb = (size_t)b * bs.max_h, kb = (size_t)b * bs.max_pops;
-    // ---- the beam_k best labels by (logit desc, index asc) ----
-    // Fast path: a threshold that at least beam_k candidates reach, the (few) logits at or above it gathered in LDS, each ranked
-    // by counting.  theta = the smallest, over the four waves, of a wave's q-th largest per-thread maximum with q =
-    // ceil(beam_k / 4): every wave then holds q threads whose maximum is >= theta, so at least beam_k logits qualify, and the
-    // beam_k best overall are among them.  (Picking them one at a time costs a block-wide reduction per label.)
-    float my_z = 0.0f;
-    int n_child = 0, my_v = -1;
-    bool ranked = false;
-    if (beam_k <= 128) {
-        float tmax = -INFINITY;                                      // this thread's best candidate
-        int targ = -1;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const bool take = !((gone >> e) & 1u) & ((targ < 0) | (zreg[e] > tmax));
-            tmax = take ? zreg[e] : tmax;
-            targ = take ? tid + 256 * e : targ;
-        }
-        const int q = (beam_k + 3) / 4;
-        float cz = tmax, theta_w = INFINITY;
-        int cv = targ;
-        for (int r = 0; r < q; ++r) {                                // the wave's q-th largest thread maximum (wave-local rounds: no barrier)
-            float bz = cz;
-            int bv = cv;
-            wave_argmax(bz, bv);
-            theta_w = bv < 0 ? -INFINITY : bz;
-            if (bv < 0) break;
-            if (cv == bv) cv = -1;                                   // its owner steps aside
-        }
-        if (lane == 0) w_f[1][wave] = theta_w;
-        if (tid == 0) s_good = 0;                                    // candidate counter
-        __syncthreads();
-        const float theta = fminf(fminf(w_f[1][0], w_f[1][1]), fminf(w_f[1][2], w_f[1][3]));
-        // gather (logit, label) of every candidate >= theta into es[] / zs[] (both free from here: zs[blank] was read above)
-        int* cand_v = reinterpret_cast<int*>(zs);
-        float* cand_z = es;
-        const int cap = V < 256 ? V : 256;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e)
-            if (!((gone >> e) & 1u) && zreg[e] >= theta) {
-                const int slot = atomicAdd(&s_good, 1);
-                if (slot < cap) { cand_z[slot] = zreg[e]; cand_v[slot] = tid + 256 * e; }
-            }
-        __syncthreads();
-        const int n_c = s_good;
-        if (n_c <= cap) {                                            // (else: a plateau of equal logits; the rounds below handle it)
-            ranked = true;
-            n_child = n_c < beam_k ? n_c : beam_k;
-            if (tid < n_c) {
-                const float zi = cand_z[tid];
-                const int vi = cand_v[tid];
-                int rank = 0;
-                for (int o = 0; o < n_c; ++o) {
-                    const float zo = cand_z[o];
-                    const int vo = cand_v[o];
-                    rank += (zo > zi) | ((zo == zi) & (vo < vi));
-                }
-                if (rank < n_child) {                                // pick `rank`: the open list takes it in that position
-                    const size_t o = hb + nh0 + rank;
-                    bs.h_score[o] = hs + (zi - lse);
-                    bs.h_node[o] = cnode; bs.h_tok[o] = vi; bs.h_slot[o] = own; bs.h_len[o] = clen + 1; bs.h_alive[o] = 1;
-                }
-            }
-        }
-    }
-    // General path, one label per round: the first maximum of what has not been taken yet
-    for (int j = 0; !ranked && j < beam_k; ++j) {
-        float bz = -INFINITY;
-        int bv = -1;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {                              // ascending v: a later equal logit does not displace
-            const bool take = !((gone >> e) & 1u) & ((bv < 0) | (zreg[e] > bz));
-            bz = take ? zreg[e] : bz;
-            bv = take ? tid + 256 * e : bv;
-        }
-        wave_argmax(bz, bv);
-        if (lane == 0) { w_f[j & 1][wave] = bz; w_i[j & 1][wave] = bv; }
-        __syncthreads();
-        bz = w_f[j & 1][0]; bv = w_i[j & 1][0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float oz = w_f[j & 1][w];
-            const int ov = w_i[j & 1][w];
-            if (ov >= 0 && (bv < 0 || oz > bz || (oz == bz && ov < bv))) { bz = oz; bv = ov; }
-        }
-        if (bv < 0) break;
-        if ((bv & 255) == tid) gone |= 1u << (bv >> 8);              // its owner retires it
-        if (tid == j) { my_z = bz; my_v = bv; }                       // thread j keeps pick j (a global store here would put its
-        ++n_child;                                                   // round trip into every round's barrier)
-    }
-    if (tid == 255) {                                                // the blank extension
-        bs.k_score[kb + nk] = hs + (zblank - lse);
-        bs.k_node[kb + nk] = cnode; bs.k_slot[kb + nk] = own; bs.k_len[kb + nk] = clen;
-    }
-    if (!ranked && tid < n_child) {
-        const size_t o = hb + nh0 + tid;
-        bs.h_score[o] = hs + (my_z - lse);
-        bs.h_node[o] = cnode; bs.h_tok[o] = my_v; bs.h_slot[o] = own; bs.h_len[o] = clen + 1; bs.h_alive[o] = 1;
-    }
-    const int nh = nh0 + n_child, nkk = nk + 1;
-    __syncthreads();                                                 // the new entries are visible to the block below
-    BEAM_MARK(2)
-    // end-of-frame test: at least `beam` kept entries strictly above the maximum of the open list — whose first maximum is
-    // also the next hypothesis to pop if the frame goes on
-    float hm;
-    int bi;
-    beam_argmax(bs, hb, nh, w_f[0], w_i[0], hm, bi);
-    for (int i = tid; i < nkk; i += 256) ks[i] = bs.k_score[kb + i];
-    if (tid == 0) s_good = 0;
-    __syncthreads();
-    int good = 0;
-    for (int i = tid; i < nkk; i += 256) good += ks[i] > hm;
-    if (good) atomicAdd(&s_good, good);
-    __syncthreads();
-    const int n_good = s_good;
+    const int t = bs.t[b], ninit = bs.ninit[b], mode = bs.mode[b], nbatch = bs.nb[b];
+    int nh = bs.nh[b], nk = bs.nk[b], npop = bs.npop[b], nfree = bs.nfree[b], pops_add = 0;
     const int list = (iter + 1) & 1;
-    BEAM_MARK(3)
-    if (n_good < beam) {                                             // the frame goes on
-        if (tid == 0) { bs.nh[b] = nh; bs.nk[b] = nkk; bs.npop[b] = npop + 1; bs.nfree[b] = nfree - is_new; bs.pops[b] += 1; }
-        __syncthreads();
-        beam_pop(bs, st, b, B, L, H, J, bi, hm, list);
-        BEAM_MARK(4)
+
+    // ---- this launch's view of the utterance, in LDS ----
+    for (int i = tid; i < nh; i += 256) lsc[i] = bs.h_alive[hb + i] ? bs.h_score[hb + i] : __int_as_float(0x7fc00000);
+    for (int i = tid; i < nk; i += 256) { ks[i] = bs.k_score[kb + i]; kn[i] = bs.k_node[kb + i]; ksl[i] = bs.k_slot[kb + i]; kl[i] = bs.k_len[kb + i]; }
+    for (int i = tid; i < ninit; i += 256) { sn[i] = bs.h_node[hb + i]; ssl[i] = bs.h_slot[hb + i]; sl[i] = bs.h_len[hb + i]; sr[i] = bs.h_rec[kb + i]; }
+    {   // the records of this frame's batch (they stay valid until the frame ends) and, in mode 0, of the single evaluation
+        const float* src = bs.rec + ((size_t)b * (R + 1)) * RF;
+        for (int i = tid; i < nbatch * RF; i += 256) recs[i] = src[i];
+        if (mode == 0) for (int i = tid; i < RF; i += 256) recs[R * RF + i] = src[R * RF + i];
+    }
+    // the expansion to apply first: the single evaluation that just finished (mode 0); a batch has none pending
+    bool have = mode == 0;
+    float e_score = 0.0f;
+    int e_node = 0, e_len = 0, e_own = 0, e_row = R;
+    if (mode == 0) {
+        const int is_new = bs.cur_new[b];
+        // its own slot: a fresh one when it was evaluated in this iteration (never short: n_slots - 1 = 2 * max_pops >= survivors
+        // of the last frame + evaluations of this one)
+        e_own = is_new ? fl[nfree - 1] : bs.cur_slot[b];
+        if (is_new) {
+            float* dst = pool + (size_t)e_own * SS;
+            for (int i = tid; i < LH; i += 256) {
+                const int l = i / H, u = i - l * H;
+                dst[i] = st.h[((size_t)l * B + b) * H + u];
+                dst[LH + i] = st.c[((size_t)l * B + b) * H + u];
+            }
+            for (int i = tid; i < J; i += 256) dst[2 * LH + i] = st.g[(size_t)b * J + i];
+        }
+        nfree -= is_new;
+        e_score = bs.cur_score[b]; e_node = bs.cur_node[b]; e_len = bs.cur_len[b];
+    }
+    __syncthreads();
+    BEAM_MARK(0)
+
+    float hm;
+    int bi, n_good;
+    for (;;) {
+        if (have) {                                                  // ---- apply one pop: blank extension + label extensions ----
+            const float* rc = recs + (size_t)e_row * RF;
+            const int n_lab = __float_as_int(rc[1]);
+            if (tid == 255) {
+                const float sc = e_score + rc[0];
+                ks[nk] = sc; kn[nk] = e_node; ksl[nk] = e_own; kl[nk] = e_len;
+                bs.k_score[kb + nk] = sc; bs.k_node[kb + nk] = e_node; bs.k_slot[kb + nk] = e_own; bs.k_len[kb + nk] = e_len;
+            }
+            if (tid < n_lab) {
+                const float sc = e_score + rc[2 + tid];
+                const size_t o = hb + nh + tid;
+                lsc[nh + tid] = sc;
+                bs.h_score[o] = sc; bs.h_node[o] = e_node; bs.h_tok[o] = __float_as_int(rc[2 + K + tid]); bs.h_slot[o] = e_own;
+                bs.h_len[o] = e_len + 1; bs.h_alive[o] = 1;
+            }
+            nh += n_lab; nk += 1; npop += 1; pops_add += 1;
+            lds_barrier();
+        }
+        // end-of-frame test: at least `beam` kept entries strictly above the maximum of the open list — whose first maximum is
+        // also the next hypothesis to pop if the frame goes on
+        list_argmax_count(lsc, nh, ks, nk, w_f, w_i, &s_good, hm, bi, n_good);
+        if (n_good >= beam) break;
+        if (bi < 0 || npop >= MP) { if (tid == 0) beam_fail(bs, b); return; }
+        if (bi < ninit && sr[bi] >= 0) {                             // its record at this frame is here already: pop it now
+            if (tid == 0) { lsc[bi] = __int_as_float(0x7fc00000); bs.h_alive[hb + bi] = 0; }
+            e_score = hm; e_node = sn[bi]; e_len = sl[bi]; e_own = ssl[bi]; e_row = sr[bi];
+            have = true;
+            continue;
+        }
+        // ---- it needs an evaluation: hand it to the next iteration ----
+        if (tid == 0) { bs.nh[b] = nh; bs.nk[b] = nk; bs.npop[b] = npop; bs.nfree[b] = nfree; bs.pops[b] += pops_add; }
+        __syncthreads();                                             // entries appended in this launch are read back from global
+        BEAM_MARK(1)
+        schedule_single(bs, st, b, B, L, H, J, bi, hm, t, list);
+        BEAM_MARK(2)
         return;
     }
+    BEAM_MARK(3)
     // ---- end of frame: survivors ascending by score (ties in kept order) become the next frame's open list; every slot that
-    // no survivor owns goes back to the free list (in any order: slot ids never reach a result) ----
-    for (int sl = tid; sl < bs.n_slots; sl += 256) used[sl] = sl == 0;
+    // no survivor owns goes back to the free list (in any order: slot ids never reach a result).  The survivors are popped
+    // best first (ties: lowest position): the first R in that order get the rows of the next frame's batch. ----
+    for (int s = tid; s < bs.n_slots; s += 256) used[s] = s == 0;
     if (tid == 0) s_nfree = 0;
-    __syncthreads();
-    for (int i = tid; i < nkk; i += 256) {
+    lds_barrier();
+    const int t_next = t + 1;
+    const bool last = t_next >= enc_lens[b];
+    const int rows = B * (R + 1);
+    for (int i = tid; i < nk; i += 256) {
         const float si = ks[i];
         if (!(si > hm)) continue;
-        int rank = 0;
-        for (int o = 0; o < nkk; ++o) {
+        int rank = 0, desc = 0;
+        for (int o = 0; o < nk; ++o) {
             const float so = ks[o];
-            if (so > hm && (so < si || (so == si && o < i))) ++rank;
+            if (!(so > hm)) continue;
+            rank += (so < si) | ((so == si) & (o < i));
+            desc += (so > si) | ((so == si) & (o < i));
         }
-        const int slot = bs.k_slot[kb + i];
-        bs.h_score[hb + rank] = si;
-        bs.h_node[hb + rank] = bs.k_node[kb + i]; bs.h_tok[hb + rank] = -1; bs.h_slot[hb + rank] = slot;
-        bs.h_len[hb + rank] = bs.k_len[kb + i]; bs.h_alive[hb + rank] = 1;
+        const int slot = ksl[i];
         used[slot] = 1;
-    }
-    __syncthreads();
-    BEAM_MARK(5)
-    const int t_next = bs.t[b] + 1;
-    const bool last = t_next >= enc_lens[b];
-    if (!last) {
-        for (int sl = tid; sl < bs.n_slots; sl += 256)
-            if (!used[sl]) fl[atomicAdd(&s_nfree, 1)] = sl;
-        __syncthreads();
-        BEAM_MARK(6)
-        if (tid == 0) {
-            bs.nh[b] = n_good; bs.nk[b] = 0; bs.npop[b] = 0; bs.nfree[b] = s_nfree; bs.t[b] = t_next;
-            bs.pops[b] += 1;
+        if (last) {                                                  // by position: what the read-back below needs
+            lsc[rank] = score_norm ? si / (float)kl[i] : si;
+            sn[rank] = kn[i]; sl[rank] = kl[i]; ssl[rank] = __float_as_int(si);
+        } else {
+            bs.h_score[hb + rank] = si;
+            bs.h_node[hb + rank] = kn[i]; bs.h_tok[hb + rank] = -1; bs.h_slot[hb + rank] = slot;
+            bs.h_len[hb + rank] = kl[i]; bs.h_alive[hb + rank] = 1;
+            bs.h_rec[kb + rank] = desc < R ? desc : -1;
+            if (desc < R) {
+                const int row = b * (R + 1) + desc;
+                bs.g_off[row] = bs.slots_off + (long long)(((size_t)b * bs.n_slots + slot) * (size_t)SS) + 2 * LH;
+                st.tcur[row] = t_next;
+                st.alive[(size_t)list * rows + atomicAdd(&st.counters[2 + list], 1)] = row;
+            }
         }
-        __syncthreads();                                             // the new list and the counters are in place
-        beam_argmax(bs, hb, n_good, w_f[1], w_i[1], hm, bi);
-        beam_pop(bs, st, b, B, L, H, J, bi, hm, list);
-        BEAM_MARK(7)
+    }
+    lds_barrier();
+    BEAM_MARK(4)
+    if (!last) {
+        for (int s = tid; s < bs.n_slots; s += 256)
+            if (!used[s]) fl[atomicAdd(&s_nfree, 1)] = s;
+        lds_barrier();
+        if (tid == 0) {
+            bs.nh[b] = n_good; bs.nk[b] = 0; bs.npop[b] = 0; bs.nfree[b] = s_nfree; bs.ninit[b] = n_good; bs.t[b] = t_next;
+            bs.pops[b] += pops_add;
+            bs.mode[b] = 1; bs.nb[b] = n_good < R ? n_good : R;
+        }
+        BEAM_MARK(5)
         return;
     }
     // ---- last frame: the first maximum of score / len(yseq) (or of score) over the survivors in their order ----
-    if (wave == 0) {
-        float bn = -INFINITY;
-        int br = -1;
-        for (int r = lane; r < n_good; r += 64) {
-            const float sc = bs.h_score[hb + r];
-            const float norm = score_norm ? sc / (float)bs.h_len[hb + r] : sc;
-            if (br < 0 || norm > bn) { bn = norm; br = r; }
-        }
-        wave_argmax(bn, br);
-        if (lane == 0) s_best = br;
-    }
-    __syncthreads();
+    int dummy;
+    list_argmax_count(lsc, n_good, ks, 0, w_f, w_i, &s_good, hm, bi, dummy);
     if (tid == 0) {
-        const int br = s_best;
-        const int n = bs.h_len[hb + br] - 1;
-        scores[b] = bs.h_score[hb + br];
-        pops[b] = bs.pops[b] + 1;
+        const int n = sl[bi] - 1;
+        scores[b] = __int_as_float(ssl[bi]);
+        pops[b] = bs.pops[b] + pops_add;
         bs.done[b] = 1;
         if (n > out_cap) { n_ids[b] = 0; bs.flags[1] = 1; }
         else {
-            int node = bs.h_node[hb + br];
+            int node = sn[bi];
             for (int q = n - 1; q >= 0; --q) {
                 const int2 nd = bs.nodes[(size_t)b * bs.max_nodes + node];
                 ids[(size_t)b * out_cap + q] = nd.y;
@@ -488,15 +525,15 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamState bs, DecodeSt
         }
         atomicAdd(&bs.flags[0], 1);
     }
-    BEAM_MARK(8)
+    BEAM_MARK(6)
 }
 
 struct BeamPlan {
-    size_t b4, h4, k4, nodes, slots, freelist, state1, g, rows4, z, total;
-    int max_h, max_nodes, n_slots, slot_floats, zstride;
+    size_t b4, h4, k4, nodes, slots, freelist, rec, goff, state1, g, rows4, z, total, step_lds, rec_lds;
+    int max_h, max_nodes, n_slots, slot_floats, zstride, R, rec_floats, rows;
 };
 
-BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam_k, int tp_max, int max_pops) {
+BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam, int beam_k, int tp_max, int max_pops) {
     const rs_dims& d = ctx->d;
     BeamPlan p;
     p.max_h = max_pops * (beam_k + 1) + 1;
@@ -504,6 +541,12 @@ BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam_k, int tp_max, int max_pop
     p.n_slots = 2 * max_pops + 1;                                    // zero state + survivors (<= max_pops) + evaluations of a frame (<= max_pops)
     p.slot_floats = 2 * d.pred_layers * d.pred_hidden + d.joint_hidden;
     p.zstride = (d.n_logits + 63) / 64 * 64;
+    int R = (beam + 12 + 3) / 4 * 4;                                 // a frame opens with >= beam survivors, usually a few more
+    if (R > 64) R = 64;
+    if (R > max_pops) R = max_pops;
+    p.R = R;
+    p.rec_floats = 2 + 2 * beam_k;
+    p.rows = B * (R + 1);
     p.b4 = rs_align((size_t)B * 4);
     p.h4 = rs_align((size_t)B * p.max_h * 4);
     p.k4 = rs_align((size_t)B * max_pops * 4);
@@ -511,10 +554,15 @@ BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam_k, int tp_max, int max_pop
     p.state1 = rs_align((size_t)d.pred_layers * B * d.pred_hidden * 4);
     p.slots = rs_align((size_t)B * p.n_slots * p.slot_floats * 4);
     p.freelist = rs_align((size_t)B * p.n_slots * 4);
+    p.rec = rs_align((size_t)p.rows * p.rec_floats * 4);
+    p.goff = rs_align((size_t)p.rows * 8);
     p.g = rs_align((size_t)B * d.joint_hidden * 4);
-    p.rows4 = rs_align((size_t)B * 4);
-    p.z = rs_align((size_t)B * p.zstride * 4);
-    p.total = 13 * p.b4 + 6 * p.h4 + 4 * p.k4 + p.nodes + p.slots + p.freelist + 4 * p.state1 + p.g + 6 * p.rows4 + 2 * rs_align(64) + rs_align(256) + p.z + 1024;
+    p.rows4 = rs_align((size_t)p.rows * 4);
+    p.z = rs_align((size_t)p.rows * p.zstride * 4);
+    p.total = 18 * p.b4 + 6 * p.h4 + 5 * p.k4 + p.nodes + p.slots + p.freelist + p.rec + p.goff + 4 * p.state1 + p.g +
+              3 * p.rows4 + 2 * rs_align(64) + rs_align(256) + p.z + 1024;
+    p.step_lds = (size_t)p.max_h * 4 + (size_t)max_pops * 4 * 8 + (size_t)p.n_slots * 4 + (size_t)(R + 1) * p.rec_floats * 4;
+    p.rec_lds = (size_t)4 * (p.zstride + 256) * 4;
     return p;
 }
 
@@ -525,7 +573,7 @@ int clamp_pops(int beam, int max_pops) { return max_pops > 0 ? max_pops : 16 * b
 size_t rs_rnnt_beam_workspace_bytes_impl(const rs_ctx* ctx, int B, int beam, int tp_max, int max_pops) {
     const int V = ctx->d.n_logits;
     const int bm = beam < V ? beam : V, beam_k = bm < V - 1 ? bm : V - 1;
-    return beam_plan(ctx, B, beam_k, tp_max, clamp_pops(bm, max_pops)).total;
+    return beam_plan(ctx, B, bm, beam_k, tp_max, clamp_pops(bm, max_pops)).total;
 }
 
 int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int beam, int score_norm,
@@ -540,10 +588,10 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     const int mp = clamp_pops(bm, max_pops);
     if (bm > 128) return rs_fail(ctx, RS_EINVAL, "beam search: beam size must be 1..128");
     if (mp < bm) return rs_fail(ctx, RS_EINVAL, "beam search: max_pops %d < beam %d (a frame needs at least `beam` pops)", mp, bm);
-    const BeamPlan pl = beam_plan(ctx, B, beam_k, tp_max, mp);
+    const BeamPlan pl = beam_plan(ctx, B, bm, beam_k, tp_max, mp);
     if (workspace_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "beam search: workspace %zu < %zu", workspace_bytes, pl.total);
-    const size_t lds = (size_t)pl.zstride * 8 + (size_t)mp * 4 + (size_t)pl.n_slots * 4;
-    if (lds > 60 * 1024) return rs_fail(ctx, RS_EINVAL, "beam search: vocabulary %d / max_pops %d exceed the expand kernel's LDS", V, mp);
+    if (pl.step_lds > 150 * 1024) return rs_fail(ctx, RS_EINVAL, "beam search: beam %d x max_pops %d needs %zu bytes of LDS (> 150 KB): lower max_pops", bm, mp, pl.step_lds);
+    if (pl.rec_lds > 150 * 1024) return rs_fail(ctx, RS_EINVAL, "beam search: vocabulary %d exceeds the record kernel's LDS", V);
     char* w = reinterpret_cast<char*>(workspace);
     auto take = [&](size_t bytes) { char* q = w; w += bytes; return q; };
     BeamState bs;
@@ -551,8 +599,8 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     // every int32 / float bookkeeping array first (one memset), then the big buffers
     char* zero_from = w;
     bs.t = (int32_t*)take(pl.b4); bs.done = (int32_t*)take(pl.b4); bs.nh = (int32_t*)take(pl.b4); bs.nk = (int32_t*)take(pl.b4);
-    bs.npop = (int32_t*)take(pl.b4); bs.nfree = (int32_t*)take(pl.b4);
-    bs.nnode = (int32_t*)take(pl.b4); bs.pops = (int32_t*)take(pl.b4);
+    bs.npop = (int32_t*)take(pl.b4); bs.nfree = (int32_t*)take(pl.b4); bs.ninit = (int32_t*)take(pl.b4);
+    bs.nnode = (int32_t*)take(pl.b4); bs.pops = (int32_t*)take(pl.b4); bs.mode = (int32_t*)take(pl.b4); bs.nb = (int32_t*)take(pl.b4);
     bs.cur_score = (float*)take(pl.b4); bs.cur_node = (int32_t*)take(pl.b4); bs.cur_slot = (int32_t*)take(pl.b4);
     bs.cur_len = (int32_t*)take(pl.b4); bs.cur_new = (int32_t*)take(pl.b4);
     bs.flags = (int32_t*)take(rs_align(64));
@@ -562,45 +610,61 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     const size_t zero_bytes = (size_t)(w - zero_from);
     bs.h_score = (float*)take(pl.h4); bs.h_node = (int32_t*)take(pl.h4); bs.h_tok = (int32_t*)take(pl.h4);
     bs.h_slot = (int32_t*)take(pl.h4); bs.h_len = (int32_t*)take(pl.h4); bs.h_alive = (int32_t*)take(pl.h4);
+    bs.h_rec = (int32_t*)take(pl.k4);
     bs.k_score = (float*)take(pl.k4); bs.k_node = (int32_t*)take(pl.k4); bs.k_slot = (int32_t*)take(pl.k4);
     bs.k_len = (int32_t*)take(pl.k4);
     bs.nodes = (int2*)take(pl.nodes);
-    bs.slots = (float*)take(pl.slots);
     bs.freelist = (int32_t*)take(pl.freelist);
+    bs.rec = (float*)take(pl.rec);
+    bs.g_off = (long long*)take(pl.goff);
+    st.g = (float*)take(pl.g);                                      // joint.pred rows of the LSTM launch; the slots follow in the same
+    bs.slots = (float*)take(pl.slots);                               // allocation, so one base + offset addresses both
+    bs.slots_off = (long long)(bs.slots - st.g);
     bs.max_h = pl.max_h; bs.max_pops = mp; bs.max_nodes = pl.max_nodes; bs.n_slots = pl.n_slots; bs.slot_floats = pl.slot_floats;
+    bs.R = pl.R; bs.rec_floats = pl.rec_floats; bs.beam_k = beam_k;
     st.h = (float*)take(pl.state1); st.c = (float*)take(pl.state1);
     st.h_tmp = (float*)take(pl.state1); st.c_tmp = (float*)take(pl.state1);
-    st.g = (float*)take(pl.g);
-    st.tcur = (int32_t*)take(pl.rows4); st.sym = (int32_t*)take(pl.rows4); st.token = (int32_t*)take(pl.rows4);
-    st.act = (int32_t*)take(pl.rows4);
+    st.tcur = (int32_t*)take(pl.rows4);                              // per joint row
+    st.sym = nullptr;
+    st.token = (int32_t*)take(pl.b4); st.act = (int32_t*)take(pl.b4);   // per LSTM row (= utterance)
     st.alive = (int32_t*)take(2 * pl.rows4);
     st.counters = counters;
     st.pmax = nullptr; st.pidx = nullptr; st.a16 = nullptr; st.anorm = nullptr;
     st.zapprox = (float*)take(pl.z);
+    st.g_off = bs.g_off;
     st.joint_act = d.joint_act;
 
-    auto expand = V <= 256 * 4 ? beam_expand_kernel<4> : V <= 256 * 12 ? beam_expand_kernel<12> : V <= 256 * 20 ? beam_expand_kernel<20> : beam_expand_kernel<32>;
-    if (V > 256 * 32) return rs_fail(ctx, RS_EINVAL, "beam search: vocabulary %d > 8192", V);
-    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)expand, (int)lds); rc != RS_OK) return rc;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)beam_step_kernel, (int)pl.step_lds); rc != RS_OK) return rc;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)beam_record_kernel, (int)pl.rec_lds); rc != RS_OK) return rc;
     rs_prof_begin(ctx, RS_PROF_DECODE, s, 0.0, 0.0);
     RS_HIP(ctx, hipMemsetAsync(zero_from, 0, zero_bytes, s));
     // slot 0 of every utterance: the zero state the search starts from
     RS_HIP(ctx, hipMemset2DAsync(bs.slots, (size_t)pl.n_slots * pl.slot_floats * 4, 0, (size_t)pl.slot_floats * 4, B, s));
-    hipLaunchKernelGGL(beam_init_kernel, dim3((B + 255) / 256), dim3(256), 0, s, bs, st, enc_lens, B, d.blank_id, n_ids, scores, pops);
-    hipLaunchKernelGGL(beam_first_pop_kernel, dim3(B), dim3(256), 0, s, bs, st, B, L, H, J);
+    hipLaunchKernelGGL(beam_init_kernel, dim3((B + 255) / 256), dim3(256), 0, s, bs, enc_lens, B, d.blank_id, n_ids, scores, pops);
+    hipLaunchKernelGGL(beam_first_kernel, dim3(B), dim3(256), 0, s, bs, st, B, L, H, J);
     RS_CHECK_LAUNCH(ctx, "beam init");
 
     const int CHUNK = 32;
-    const long long max_iters = (long long)(tp_max > 0 ? tp_max : 1) * mp + 1;
+    const long long max_iters = (long long)(tp_max > 0 ? tp_max : 1) * (mp + 1) + 1;
+    // the joint walks its list with a fixed number of row tiles (the list holds between B and B * R rows); the record kernel
+    // strides over it the same way
+    const int joint_rts = pl.rows / 32 < 96 ? (pl.rows + 31) / 32 : 96;
+    const int rec_blocks = pl.rows / 4 < 1024 ? (pl.rows + 3) / 4 : 1024;
     int32_t hf[2] = {0, 0};
     long long it = 0;
     bool finished = false;
     while (!finished && it < max_iters) {
         for (int c = 0; c < CHUNK; ++c, ++it) {
+            const int step = (int)(it & 1);
             if (int rc = rs_rnnt_launch_lstm_pred(ctx, &st, B, s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
-            if (int rc = rs_rnnt_launch_joint_logits(ctx, &st, joint_enc, B, tp_max, 1, (int)(it & 1), s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
-            hipLaunchKernelGGL(expand, dim3(B), dim3(256), lds, s, bs, st, st.zapprox, pl.zstride, enc_lens, B, L, H, J, V,
-                               d.blank_id, bm, beam_k, score_norm, out_cap, (int)(it & 1), ids, n_ids, scores, pops);
+            if (int rc = rs_rnnt_launch_joint_logits_indirect(ctx, &st, joint_enc, pl.rows, joint_rts * 32, tp_max, pl.R + 1, step, s); rc != RS_OK) {
+                rs_prof_end(ctx, RS_PROF_DECODE, s);
+                return rc;
+            }
+            hipLaunchKernelGGL(beam_record_kernel, dim3(rec_blocks), dim3(256), pl.rec_lds, s, bs, st, st.zapprox, pl.zstride, pl.rows, V,
+                               d.blank_id, step);
+            hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), pl.step_lds, s, bs, st, enc_lens, B, L, H, J, bm, score_norm, out_cap,
+                               step, ids, n_ids, scores, pops);
         }
         RS_CHECK_LAUNCH(ctx, "beam step");
         RS_HIP(ctx, hipMemcpyAsync(hf, bs.flags, sizeof hf, hipMemcpyDeviceToHost, s));
@@ -608,14 +672,15 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
         finished = hf[0] >= B;
     }
     rs_prof_end(ctx, RS_PROF_DECODE, s);
-    if (bs.trace) {                                                  // diagnostic: where the expand kernel's workgroups spend their time
-        unsigned long long tr[18];
+    if (bs.trace) {                                                  // diagnostic: where the step kernel's workgroups spend their time
+        unsigned long long tr[14];
         RS_HIP(ctx, hipMemcpy(tr, trace, sizeof tr, hipMemcpyDeviceToHost));
-        static const char* names[9] = {"park+stage+max", "exp+lse", "label rounds", "argmax+count", "pop (frame goes on)", "rank survivors",
-                                       "free slots", "argmax+pop (new frame)", "read back"};
-        for (int i = 0; i < 9; ++i)
-            fprintf(stderr, "[beam trace] %-24s %10llu passes  %8.2f us each (100 MHz wall clock)\n", names[i], tr[2 * i + 1],
+        static const char* names[7] = {"load state", "pops until an evaluation", "schedule it", "pops until frame end", "rank survivors",
+                                       "free slots", "read back"};
+        for (int i = 0; i < 7; ++i)
+            fprintf(stderr, "[beam trace] %-26s %10llu passes  %8.2f us each (100 MHz wall clock)\n", names[i], tr[2 * i + 1],
                     tr[2 * i + 1] ? (double)tr[2 * i] / (double)tr[2 * i + 1] / 100.0 : 0.0);
+        fprintf(stderr, "[beam trace] %lld iterations\n", it);
     }
     if (!finished) return rs_fail(ctx, RS_ESTATE, "beam search: %d of %d utterances unfinished after %lld iterations", B - hf[0], B, it);
     if (hf[1]) return rs_fail(ctx, RS_EOVERFLOW, "beam search: a frame needed more than max_pops=%d prediction-network evaluations, or a result has more than out_cap=%d labels", mp, out_cap);
