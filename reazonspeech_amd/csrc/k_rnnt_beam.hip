@@ -179,11 +179,25 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
     for (int idx = blockIdx.x * 4 + wave; idx < n; idx += gridDim.x * 4) {
         const int row = st.alive[(size_t)list * rows + idx];
         const float* zr = zbuf + (size_t)row * zstride;
+        // the row comes in as 16-byte loads, eight in flight per lane (one load per loop trip would serialise ~40 HBM/L2 round
+        // trips per row), and is re-read from LDS in the lane-strided order the sums are defined in
+        {
+            const float4* zr4 = reinterpret_cast<const float4*>(zr);          // rows are zstride (multiple of 64) floats apart
+            float4* zs4 = reinterpret_cast<float4*>(zs);
+            const int n4 = zstride / 4;
+            for (int q0 = lane; q0 < n4; q0 += 64 * 8) {
+                float4 buf[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int q = q0 + 64 * u; buf[u] = q < n4 ? zr4[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int q = q0 + 64 * u; if (q < n4) zs4[q] = buf[u]; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float m = -INFINITY, tmax = -INFINITY;
         int targ = -1;
         for (int v = lane; v < V; v += 64) {
-            const float zv = zr[v];
-            zs[v] = zv;
+            const float zv = zs[v];
             m = fmaxf(m, zv);
             const bool take = (v != blank) & ((targ < 0) | (zv > tmax));
             tmax = take ? zv : tmax;
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
         }
         m = wave_max(m);
         float sum = 0.0f;
-        for (int v = lane; v < V; v += 64) sum = sum + rs_expf(zs[v] - m);     // a lane re-reads what it wrote
+        for (int v = lane; v < V; v += 64) sum = sum + rs_expf(zs[v] - m);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off, 64);
         sum = __shfl(sum, 0, 64);
@@ -261,8 +275,10 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
 }
 
 // ---- block-wide (256 threads) first maximum of the live entries of the LDS score list (dead = NaN) + the number of kept
-// scores strictly above it ----
-__device__ __forceinline__ void list_argmax_count(const float* lsc, int n, const float* ks, int nk, float* w_f, int* w_i, int* s_good,
+// scores strictly above it (only counted when there are at least `beam` of them: the end-of-frame test cannot pass before).
+// w_f / w_i / s_cnt are double-buffered by the parity of the call, so one barrier separates a call from the next. ----
+struct ArgmaxScratch { float w_f[2][4]; int w_i[2][4]; int cnt[2]; };
+__device__ __forceinline__ void list_argmax_count(const float* lsc, int n, const float* ks, int nk, int beam, ArgmaxScratch* sc, int par,
                                                   float& best, int& bi, int& n_good) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     best = -INFINITY; bi = -1;
@@ -273,22 +289,23 @@ __device__ __forceinline__ void list_argmax_count(const float* lsc, int n, const
         bi = take ? i : bi;
     }
     wave_argmax(best, bi);
-    if (lane == 0) { w_f[wave] = best; w_i[wave] = bi; }
-    if (tid == 0) *s_good = 0;
+    if (lane == 0) { sc->w_f[par][wave] = best; sc->w_i[par][wave] = bi; }
     lds_barrier();
-    best = w_f[0]; bi = w_i[0];
+    best = sc->w_f[par][0]; bi = sc->w_i[par][0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-        const float os = w_f[w];
-        const int oi = w_i[w];
+        const float os = sc->w_f[par][w];
+        const int oi = sc->w_i[par][w];
         if (oi >= 0 && (bi < 0 || os > best || (os == best && oi < bi))) { best = os; bi = oi; }
     }
+    if (tid == 0) sc->cnt[par ^ 1] = 0;                           // the next call's counter (its last readers are past the barrier above)
+    n_good = 0;
+    if (nk < beam) return;
     int good = 0;
     for (int i = tid; i < nk; i += 256) good += ks[i] > best;
-    if (good) atomicAdd(s_good, good);
+    if (good) atomicAdd(&sc->cnt[par], good);
     lds_barrier();
-    n_good = *s_good;
-    lds_barrier();                                                 // w_f / w_i / s_good are free again
+    n_good = sc->cnt[par];
 }
 
 // ---- hand entry `bi` of the open list to the next iteration as a single evaluation (block-wide; the caller has made this
@@ -366,9 +383,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
     int* sr = sl + MP;
     int* used = sr + MP;
     float* recs = reinterpret_cast<float*>(used + bs.n_slots);
-    __shared__ float w_f[4];
-    __shared__ int w_i[4];
-    __shared__ int s_good, s_nfree;
+    __shared__ ArgmaxScratch sc;
+    __shared__ int s_nfree;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (bs.done[b]) return;
     unsigned long long t_mark = bs.trace ? wall_clock64() : 0ull;
@@ -414,8 +430,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
     BEAM_MARK(0)
 
     float hm;
-    int bi, n_good;
-    for (;;) {
+    int bi, n_good, par = 0;
+    if (tid == 0) { sc.cnt[0] = 0; sc.cnt[1] = 0; }
+    lds_barrier();
+    for (;; par ^= 1) {
         if (have) {                                                  // ---- apply one pop: blank extension + label extensions ----
             const float* rc = recs + (size_t)e_row * RF;
             const int n_lab = __float_as_int(rc[1]);
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
         }
         // end-of-frame test: at least `beam` kept entries strictly above the maximum of the open list — whose first maximum is
         // also the next hypothesis to pop if the frame goes on
-        list_argmax_count(lsc, nh, ks, nk, w_f, w_i, &s_good, hm, bi, n_good);
+        list_argmax_count(lsc, nh, ks, nk, beam, &sc, par, hm, bi, n_good);
         if (n_good >= beam) break;
         if (bi < 0 || npop >= MP) { if (tid == 0) beam_fail(bs, b); return; }
         if (bi < ninit && sr[bi] >= 0) {                             // its record at this frame is here already: pop it now
@@ -507,7 +525,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
     }
     // ---- last frame: the first maximum of score / len(yseq) (or of score) over the survivors in their order ----
     int dummy;
-    list_argmax_count(lsc, n_good, ks, 0, w_f, w_i, &s_good, hm, bi, dummy);
+    list_argmax_count(lsc, n_good, ks, 0, 1, &sc, par ^ 1, hm, bi, dummy);
     if (tid == 0) {
         const int n = sl[bi] - 1;
         scores[b] = __int_as_float(ssl[bi]);
@@ -648,7 +666,7 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     const long long max_iters = (long long)(tp_max > 0 ? tp_max : 1) * (mp + 1) + 1;
     // the joint walks its list with a fixed number of row tiles (the list holds between B and B * R rows); the record kernel
     // strides over it the same way
-    const int joint_rts = pl.rows / 32 < 96 ? (pl.rows + 31) / 32 : 96;
+    const int joint_rts = pl.rows / 32 < 64 ? (pl.rows + 31) / 32 : 64;
     const int rec_blocks = pl.rows / 4 < 1024 ? (pl.rows + 3) / 4 : 1024;
     int32_t hf[2] = {0, 0};
     long long it = 0;
