@@ -157,6 +157,8 @@ __global__ __launch_bounds__(1024) void rnnt_lstm_kernel(DecodeState st, int lay
 // MODE 1: joint logits  W_o . relu(f[b][t_b] + g[b]) + b_o over the `alive` rows, per-tile argmax
 // MODE 3: MODE 2 with row r's prediction vector at st.g + st.g_off[r] (the default beam search, k_rnnt_beam.hip: the vectors
 //         stay where they are cached)
+// MODE 4: MODE 3 with the activated rows act(f + g) precomputed in st.a_pre [row][K] (with a tanh joint every one of the
+//         ceil(V / 64) column tiles recomputed the same 32 x K tanh values, about as many VALU cycles as the tile's MFMA cycles)
 // MODE 2: the same logits written out in full (beam search, k_rnnt_alsd.hip): rows are hypotheses, `rows_per_utt`
 //         consecutive rows share an utterance's encoder frames; logits go to st.zapprox with row stride 64 * n_ctiles
 template <int MODE>
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
     // XCD's L2 keeps its eighth of W_o (0.8 of 6.6 MB at V = 2600) across row tiles and across steps; with gridDim.x = 41 every
     // XCD pulled all of W_o through the fabric once per launch.
     if (MODE >= 1 && ct >= n_ctiles) return;
-    // MODE 3 walks the row tiles with stride gridDim.y (its list can be anything from a handful of rows to rows_per_utt per
+    // MODE 3 / 4 walk the row tiles with stride gridDim.y (its list can be anything from a handful of rows to rows_per_utt per
     // utterance, and the launch cannot know): every other mode has one row tile per workgroup and leaves after the first pass
     for (;; rt += gridDim.y) {
     if (rt * 32 >= n_rows) return;
@@ -202,11 +204,16 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
             asrc[ri] = st.h_tmp + ((size_t)(L - 1) * B + row) * H;
             gsrc[ri] = nullptr;
         } else {
-            int t = st.tcur[row];
-            t = t < Tp ? t : Tp - 1;
-            const int utt = MODE >= 2 ? row / rows_per_utt : row;
-            asrc[ri] = f + ((size_t)utt * Tp + t) * K;
-            gsrc[ri] = MODE == 3 ? st.g + st.g_off[row] : st.g + (size_t)row * K;
+            if (MODE == 4) {
+                asrc[ri] = st.a_pre + (size_t)row * K;
+                gsrc[ri] = nullptr;
+            } else {
+                int t = st.tcur[row];
+                t = t < Tp ? t : Tp - 1;
+                const int utt = MODE >= 2 ? row / rows_per_utt : row;
+                asrc[ri] = f + ((size_t)utt * Tp + t) * K;
+                gsrc[ri] = MODE == 3 ? st.g + st.g_off[row] : st.g + (size_t)row * K;
+            }
         }
     }
     // fragment-major weights ([ceil(N/16)][K/16][lane][4], rows past N are zero)
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
     for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) acc[ri][cj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    constexpr bool HAS_G = MODE >= 1 && MODE <= 3;          // MODE 4 reads rows that are already act(f + g)
     struct Frag { float4 a[2], g[2], w[4]; };
     auto load = [&](int k0) {
         Frag fr;
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri) {
             fr.a[ri] = *reinterpret_cast<const float4*>(asrc[ri] + k);
-            if (MODE >= 1) fr.g[ri] = *reinterpret_cast<const float4*>(gsrc[ri] + k);
+            if (HAS_G) fr.g[ri] = *reinterpret_cast<const float4*>(gsrc[ri] + k);
         }
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) fr.w[cj] = *reinterpret_cast<const float4*>(wfrag[cj] + (size_t)(k0 >> 4) * 256);
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri) {
             a[ri] = fr.a[ri];
-            if (MODE >= 1) {   // the joint activation of (f + g) is elementwise: apply it before the lane permutation
+            if (HAS_G) {       // the joint activation of (f + g) is elementwise: apply it before the lane permutation
                 if (st.joint_act) {            // ESPnet JointNetwork: tanh (the shared polynomial: bit-exact with the C oracle)
                     a[ri].x = rs_tanhf(a[ri].x + fr.g[ri].x); a[ri].y = rs_tanhf(a[ri].y + fr.g[ri].y);
                     a[ri].z = rs_tanhf(a[ri].z + fr.g[ri].z); a[ri].w = rs_tanhf(a[ri].w + fr.g[ri].w);
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
             for (int r = 0; r < 4; ++r) part[wave][ri * 16 + 4 * kk + r][cj * 16 + li] = acc[ri][cj][r];
     __syncthreads();
     // thread = (row i, 8 consecutive columns); waves 4..7 are done
-    if (tid >= 256) { if (MODE == 3) { __syncthreads(); continue; } return; }
+    if (tid >= 256) { if (MODE >= 3) { __syncthreads(); continue; } return; }
     const int i = tid >> 3, c0 = (tid & 7) * 8;
     const bool row_ok = rt * 32 + i < n_rows;
     const int brow = rows_s[i];
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
                     st.c[o] = st.c_tmp[o];
                 }
     }
-    if (MODE != 3) return;
+    if (MODE < 3) return;
     __syncthreads();                                     // `part` / `rows_s` are rewritten by the next row tile
     }
 }
@@ -784,7 +792,8 @@ int ensure_decode_lds(rs_ctx* ctx) {
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<0>, TILE_LDS); rc != RS_OK) return rc;
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<1>, TILE_LDS); rc != RS_OK) return rc;
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<2>, TILE_LDS); rc != RS_OK) return rc;
-    return rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<3>, TILE_LDS);
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<3>, TILE_LDS); rc != RS_OK) return rc;
+    return rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<4>, TILE_LDS);
 }
 
 }  // namespace
@@ -815,9 +824,13 @@ int rs_rnnt_launch_joint_logits_indirect(rs_ctx* ctx, const void* st_ptr, const 
     const rs_dims& d = ctx->d;
     const int nct = (d.n_logits + 63) / 64;
     const int rts = (rows_bound + 31) / 32 > 0 ? (rows_bound + 31) / 32 : 1;
-    hipLaunchKernelGGL(rnnt_tile_kernel<3>, dim3(joint_grid_x(nct, rts), rts), dim3(512), TILE_LDS, s,
-                       *reinterpret_cast<const DecodeState*>(st_ptr), joint_enc, rows, tp_max, d.pred_layers, d.pred_hidden,
-                       d.joint_hidden, d.n_logits, ctx->jout_w, ctx->jout_b, nct, step, rows_per_utt);
+    const DecodeState& st = *reinterpret_cast<const DecodeState*>(st_ptr);
+    if (st.a_pre)
+        hipLaunchKernelGGL(rnnt_tile_kernel<4>, dim3(joint_grid_x(nct, rts), rts), dim3(512), TILE_LDS, s, st, joint_enc, rows, tp_max,
+                           d.pred_layers, d.pred_hidden, d.joint_hidden, d.n_logits, ctx->jout_w, ctx->jout_b, nct, step, rows_per_utt);
+    else
+        hipLaunchKernelGGL(rnnt_tile_kernel<3>, dim3(joint_grid_x(nct, rts), rts), dim3(512), TILE_LDS, s, st, joint_enc, rows, tp_max,
+                           d.pred_layers, d.pred_hidden, d.joint_hidden, d.n_logits, ctx->jout_w, ctx->jout_b, nct, step, rows_per_utt);
     return RS_OK;
 }
 
@@ -850,7 +863,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     char* w = reinterpret_cast<char*>(workspace);
     auto take = [&](size_t bytes) { char* p = w; w += rs_align(bytes); return p; };
     DecodeState st;
-    st.g_off = nullptr;
+    st.g_off = nullptr; st.a_pre = nullptr;
     st.joint_act = d.joint_act;
     const size_t state_bytes = (size_t)L * B * H * 4;
     st.h = (float*)take(state_bytes); st.c = (float*)take(state_bytes);

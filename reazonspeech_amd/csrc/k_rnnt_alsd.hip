@@ -432,7 +432,7 @@ int rs_rnnt_alsd_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
         q.h = hset[k]; q.c = cset[k]; q.h_tmp = h_tmp; q.c_tmp = c_tmp; q.g = gset[k];
         q.tcur = tcur; q.sym = sym; q.token = token; q.act = act; q.alive = alive; q.counters = counters;
         q.pmax = nullptr; q.pidx = nullptr; q.a16 = nullptr; q.anorm = nullptr; q.zapprox = zbuf;
-        q.g_off = nullptr;
+        q.g_off = nullptr; q.a_pre = nullptr;
         q.joint_act = d.joint_act;
     }
     const int zstride = (V + 63) / 64 * 64;

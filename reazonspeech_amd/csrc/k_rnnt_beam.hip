@@ -16,11 +16,12 @@
 //     vector) stays in a slot that its extensions and its own later pops refer to.
 //
 // Utterances are independent state machines (the pop count of a frame is data dependent, so they are NOT kept in frame
-// lockstep).  One device iteration = 4 + L launches:
+// lockstep).  One device iteration = 5 + L launches:
 //
 //   LSTM x L + joint.pred   over the utterances waiting for a new sequence's evaluation (k_rnnt.hip, exact f32)
-//   joint logits            rnnt_tile_kernel<3> over this iteration's rows: the batch rows of utterances that just entered a
-//                           frame, the single row of those waiting for one evaluation
+//   beam_act_kernel         act(f + g) of this iteration's rows: the batch rows of utterances that just entered a frame, the single
+//                           row of those waiting for one evaluation
+//   joint logits            rnnt_tile_kernel<4> over those rows
 //   beam_record_kernel      one wave per row: log-softmax, log p(blank), the beam_k best labels with their log-probabilities
 //   beam_step_kernel        one workgroup per utterance, open-list scores in LDS: applies the finished evaluation(s), then keeps
 //                           popping for as long as the best open hypothesis already has its record; ends the frame when the
@@ -159,6 +160,26 @@ __device__ __forceinline__ void wave_argmax(float& z, int& v) {
     v = __builtin_amdgcn_readlane(v, 63);
 }
 
+// ---- a_pre[row] = act(f[utt][t] + g[row]) for the rows of this iteration's joint list (the joint's column tiles then read it
+// instead of each recomputing it); one thread per 4 elements, workgroups stride over the list ----
+__global__ __launch_bounds__(256) void beam_act_kernel(DecodeState st, const float* __restrict__ f, float* __restrict__ a_pre, int rows,
+                                                       int Tp, int J, int rows_per_utt, int list) {
+    const int n = st.counters[2 + list];
+    const int q4 = J / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)n * q4; i += (long long)gridDim.x * 256) {
+        const int idx = (int)(i / q4), q = (int)(i - (long long)idx * q4);
+        const int row = st.alive[(size_t)list * rows + idx];
+        int t = st.tcur[row];
+        t = t < Tp ? t : Tp - 1;
+        const float4 a = reinterpret_cast<const float4*>(f + ((size_t)(row / rows_per_utt) * Tp + t) * J)[q];
+        const float4 g = reinterpret_cast<const float4*>(st.g + st.g_off[row])[q];
+        float4 r;
+        if (st.joint_act) { r.x = rs_tanhf(a.x + g.x); r.y = rs_tanhf(a.y + g.y); r.z = rs_tanhf(a.z + g.z); r.w = rs_tanhf(a.w + g.w); }
+        else { r.x = fmaxf(a.x + g.x, 0.0f); r.y = fmaxf(a.y + g.y, 0.0f); r.z = fmaxf(a.z + g.z, 0.0f); r.w = fmaxf(a.w + g.w, 0.0f); }
+        reinterpret_cast<float4*>(a_pre + (size_t)row * J)[q] = r;
+    }
+}
+
 // ---- records: one wave per row of this iteration's joint list ----------------------------------------------------------
 // rec[row] = { log p(blank), n (int bits), log p(label_j) for j < beam_k, label_j (int bits) for j < beam_k }, labels by
 // (logit desc, index asc).  log-sum-exp in the documented order: lane l adds exp(z[v] - max) for v = l, l + 64, ..., then the
@@ -169,7 +190,6 @@ __device__ __forceinline__ void wave_argmax(float& z, int& v) {
 __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeState st, const float* __restrict__ zbuf, int zstride,
                                                           int rows, int V, int blank, int list) {
     extern __shared__ __attribute__((aligned(16))) char rec_smem[];
-    __shared__ int s_cnt[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* zs = reinterpret_cast<float*>(rec_smem) + (size_t)wave * (zstride + 256);
     float* cz = zs + zstride;
@@ -210,33 +230,45 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
         for (int off = 32; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off, 64);
         sum = __shfl(sum, 0, 64);
         const float lse = m + rs_logf(sum);
-        float theta = -INFINITY;
+        // theta = the beam_k-th largest lane maximum: every lane ranks its own against the other 63 (readlane broadcasts)
+        float theta;
         {
-            float cz_l = tmax;
-            int cv_l = targ;
-            for (int r = 0; r < beam_k; ++r) {
-                float bz = cz_l;
-                int bv = cv_l;
-                wave_argmax(bz, bv);
-                theta = bv < 0 ? -INFINITY : bz;
-                if (bv < 0) break;
-                if (cv_l == bv) cv_l = -1;
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tmax), j));
+                const int ov = __builtin_amdgcn_readlane(targ, j);
+                rank += (ov >= 0) & ((targ < 0) | (oz > tmax) | ((oz == tmax) & (ov < targ)));
             }
+            theta = wave_max((rank == beam_k - 1 && targ >= 0) ? tmax : -INFINITY);   // no such lane: fewer than beam_k candidates
         }
-        if (lane == 0) s_cnt[wave] = 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // (a wave's LDS operations execute in order)
-        for (int v = lane; v < V; v += 64) {
-            const float zv = zs[v];
-            if (v != blank && zv >= theta) {
-                const int slot = atomicAdd(&s_cnt[wave], 1);
-                if (slot < 128) { cz[slot] = zv; cv[slot] = v; }
-            }
+        // gather the logits >= theta: ballot compaction (positions by lane order within a pass; any order would do)
+        int n_c = 0;
+        for (int v0 = 0; v0 < V; v0 += 64) {
+            const int v = v0 + lane;
+            const float zv = v < V ? zs[v] : -INFINITY;
+            const bool in = (v < V) & (v != blank) & (zv >= theta);
+            const unsigned long long mask = __ballot(in);
+            const int pos = n_c + __popcll(mask & ((1ull << lane) - 1ull));
+            if (in && pos < 128) { cz[pos] = zv; cv[pos] = v; }
+            n_c += __popcll(mask);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int n_c = s_cnt[wave];
         float* out = bs.rec + (size_t)row * bs.rec_floats;
         int n_lab = 0;
-        if (n_c <= 128) {
+        if (n_c <= 64) {                                             // the usual case: one candidate per lane, ranked in registers
+            n_lab = n_c < beam_k ? n_c : beam_k;
+            const float zi = lane < n_c ? cz[lane] : -INFINITY;
+            const int vi = lane < n_c ? cv[lane] : -1;
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const float zo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zi), j));
+                const int vo = __builtin_amdgcn_readlane(vi, j);
+                rank += (vo >= 0) & ((zo > zi) | ((zo == zi) & (vo < vi)));
+            }
+            if (vi >= 0 && rank < n_lab) { out[2 + rank] = zi - lse; out[2 + beam_k + rank] = __int_as_float(vi); }
+        } else if (n_c <= 128) {
             n_lab = n_c < beam_k ? n_c : beam_k;
             for (int c = lane; c < n_c; c += 64) {
                 const float zi = cz[c];
@@ -547,7 +579,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
 }
 
 struct BeamPlan {
-    size_t b4, h4, k4, nodes, slots, freelist, rec, goff, state1, g, rows4, z, total, step_lds, rec_lds;
+    size_t b4, h4, k4, nodes, slots, freelist, rec, goff, state1, g, rows4, z, apre, total, step_lds, rec_lds;
     int max_h, max_nodes, n_slots, slot_floats, zstride, R, rec_floats, rows;
 };
 
@@ -577,7 +609,8 @@ BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam, int beam_k, int tp_max, i
     p.g = rs_align((size_t)B * d.joint_hidden * 4);
     p.rows4 = rs_align((size_t)p.rows * 4);
     p.z = rs_align((size_t)p.rows * p.zstride * 4);
-    p.total = 18 * p.b4 + 6 * p.h4 + 5 * p.k4 + p.nodes + p.slots + p.freelist + p.rec + p.goff + 4 * p.state1 + p.g +
+    p.apre = rs_align((size_t)p.rows * d.joint_hidden * 4);
+    p.total = p.apre + 18 * p.b4 + 6 * p.h4 + 5 * p.k4 + p.nodes + p.slots + p.freelist + p.rec + p.goff + 4 * p.state1 + p.g +
               3 * p.rows4 + 2 * rs_align(64) + rs_align(256) + p.z + 1024;
     p.step_lds = (size_t)p.max_h * 4 + (size_t)max_pops * 4 * 8 + (size_t)p.n_slots * 4 + (size_t)(R + 1) * p.rec_floats * 4;
     p.rec_lds = (size_t)4 * (p.zstride + 256) * 4;
@@ -650,6 +683,8 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     st.pmax = nullptr; st.pidx = nullptr; st.a16 = nullptr; st.anorm = nullptr;
     st.zapprox = (float*)take(pl.z);
     st.g_off = bs.g_off;
+    float* a_pre = (float*)take(pl.apre);
+    st.a_pre = a_pre;
     st.joint_act = d.joint_act;
 
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)beam_step_kernel, (int)pl.step_lds); rc != RS_OK) return rc;
@@ -667,6 +702,7 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     // the joint walks its list with a fixed number of row tiles (the list holds between B and B * R rows); the record kernel
     // strides over it the same way
     const int joint_rts = pl.rows / 32 < 64 ? (pl.rows + 31) / 32 : 64;
+    const int act_blocks = 512;
     const int rec_blocks = pl.rows / 4 < 1024 ? (pl.rows + 3) / 4 : 1024;
     int32_t hf[2] = {0, 0};
     long long it = 0;
@@ -675,6 +711,7 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
         for (int c = 0; c < CHUNK; ++c, ++it) {
             const int step = (int)(it & 1);
             if (int rc = rs_rnnt_launch_lstm_pred(ctx, &st, B, s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
+            hipLaunchKernelGGL(beam_act_kernel, dim3(act_blocks), dim3(256), 0, s, st, joint_enc, a_pre, pl.rows, tp_max, J, pl.R + 1, step);
             if (int rc = rs_rnnt_launch_joint_logits_indirect(ctx, &st, joint_enc, pl.rows, joint_rts * 32, tp_max, pl.R + 1, step, s); rc != RS_OK) {
                 rs_prof_end(ctx, RS_PROF_DECODE, s);
                 return rc;

@@ -62,6 +62,7 @@ struct DecodeState {
     float* anorm;    // [B]    ||relu(f + g)||_2 of alive slot i (rounded up)
     float* zapprox;  // [B][Vpad] approximate logits of alive slot i (bf16 MFMA GEMM, f32 accumulate, + bias)
     const long long* g_off;   // rnnt_tile_kernel<3> only: [rows] offset (floats, from `g`) of row r's joint.pred vector
+    const float* a_pre;       // rnnt_tile_kernel<4> only: [rows][J] act(f + g) of row r
     int joint_act;   // 0: relu(f + g) (NeMo RNNTJoint); 1: tanh(f + g) (ESPnet JointNetwork) — exact-tile kernels only
 };
 
