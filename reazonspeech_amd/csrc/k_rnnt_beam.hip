@@ -186,7 +186,10 @@ __global__ __launch_bounds__(256) void beam_act_kernel(DecodeState st, const flo
 // tree p[l] += p[l + off].  Selection: theta = the beam_k-th largest per-lane maximum — at least beam_k logits reach it — the few
 // logits >= theta are gathered in LDS and ranked by counting (a plateau of more than 128 equal logits falls back to one
 // wave-wide maximum per label).
+// EPT > 0: V <= 64 * EPT and a lane keeps its logits v = lane + 64 e in registers (a wave-wide load of 64 consecutive floats
+// is one coalesced request; EPT of them are in flight); EPT = 0: any V, the row is staged in LDS and re-read from there.
 // grid: any (workgroups stride over the list), block 256, dynamic LDS 4 x (zstride + 256) floats
+template <int EPT>
 __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeState st, const float* __restrict__ zbuf, int zstride,
                                                           int rows, int V, int blank, int list) {
     extern __shared__ __attribute__((aligned(16))) char rec_smem[];
@@ -196,12 +199,15 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
     int* cv = reinterpret_cast<int*>(cz + 128);
     const int n = st.counters[2 + list];
     const int beam_k = bs.beam_k;
+    const int ne = EPT > 0 ? EPT : (V + 63) / 64;
     for (int idx = blockIdx.x * 4 + wave; idx < n; idx += gridDim.x * 4) {
         const int row = st.alive[(size_t)list * rows + idx];
         const float* zr = zbuf + (size_t)row * zstride;
-        // the row comes in as 16-byte loads, eight in flight per lane (one load per loop trip would serialise ~40 HBM/L2 round
-        // trips per row), and is re-read from LDS in the lane-strided order the sums are defined in
-        {
+        float zreg[EPT > 0 ? EPT : 1];
+        if (EPT > 0) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) { const int v = lane + 64 * e; zreg[e] = v < V ? zr[v] : -INFINITY; }
+        } else {
             const float4* zr4 = reinterpret_cast<const float4*>(zr);          // rows are zstride (multiple of 64) floats apart
             float4* zs4 = reinterpret_cast<float4*>(zs);
             const int n4 = zstride / 4;
@@ -212,20 +218,27 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const int q = q0 + 64 * u; if (q < n4) zs4[q] = buf[u]; }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float m = -INFINITY, tmax = -INFINITY;
+#define ZAT(e) (EPT > 0 ? zreg[EPT > 0 ? (e) : 0] : (lane + 64 * (e) < V ? zs[lane + 64 * (e)] : -INFINITY))
+        float m = -INFINITY, tmax = -INFINITY, zb = -INFINITY;
         int targ = -1;
-        for (int v = lane; v < V; v += 64) {
-            const float zv = zs[v];
+#pragma unroll
+        for (int e = 0; e < ne; ++e) {
+            const int v = lane + 64 * e;
+            const float zv = ZAT(e);
             m = fmaxf(m, zv);
-            const bool take = (v != blank) & ((targ < 0) | (zv > tmax));
+            zb = v == blank ? zv : zb;
+            const bool take = (v < V) & (v != blank) & ((targ < 0) | (zv > tmax));
             tmax = take ? zv : tmax;
             targ = take ? v : targ;
         }
         m = wave_max(m);
+        zb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zb), blank & 63));
         float sum = 0.0f;
-        for (int v = lane; v < V; v += 64) sum = sum + rs_expf(zs[v] - m);
+#pragma unroll
+        for (int e = 0; e < ne; ++e)
+            if (lane + 64 * e < V) sum = sum + rs_expf(ZAT(e) - m);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off, 64);
         sum = __shfl(sum, 0, 64);
@@ -244,9 +257,10 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
         }
         // gather the logits >= theta: ballot compaction (positions by lane order within a pass; any order would do)
         int n_c = 0;
-        for (int v0 = 0; v0 < V; v0 += 64) {
-            const int v = v0 + lane;
-            const float zv = v < V ? zs[v] : -INFINITY;
+#pragma unroll
+        for (int e = 0; e < ne; ++e) {
+            const int v = lane + 64 * e;
+            const float zv = ZAT(e);
             const bool in = (v < V) & (v != blank) & (zv >= theta);
             const unsigned long long mask = __ballot(in);
             const int pos = n_c + __popcll(mask & ((1ull << lane) - 1ull));
@@ -281,7 +295,12 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
                 }
                 if (rank < n_lab) { out[2 + rank] = zi - lse; out[2 + beam_k + rank] = __int_as_float(vi); }
             }
-        } else {
+        } else {                                                     // a plateau: one wave-wide maximum per label
+            if (EPT > 0) {
+#pragma unroll
+                for (int e = 0; e < ne; ++e) if (lane + 64 * e < V) zs[lane + 64 * e] = ZAT(e);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             float pz = INFINITY;
             int pv = -1;
             for (int j = 0; j < beam_k; ++j) {
@@ -301,7 +320,8 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
                 ++n_lab;
             }
         }
-        if (lane == 0) { out[0] = zs[blank] - lse; out[1] = __int_as_float(n_lab); }
+#undef ZAT
+        if (lane == 0) { out[0] = zb - lse; out[1] = __int_as_float(n_lab); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // zs / cz are rewritten by this wave's next row
     }
 }
@@ -688,7 +708,9 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     st.joint_act = d.joint_act;
 
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)beam_step_kernel, (int)pl.step_lds); rc != RS_OK) return rc;
-    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)beam_record_kernel, (int)pl.rec_lds); rc != RS_OK) return rc;
+    const bool rec_lds = getenv("RS_BEAM_RECORD_LDS") != nullptr;   // test hook: the any-vocabulary variant on a small one
+    auto record = rec_lds ? beam_record_kernel<0> : V <= 64 * 16 ? beam_record_kernel<16> : V <= 64 * 48 ? beam_record_kernel<48> : beam_record_kernel<0>;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)record, (int)pl.rec_lds); rc != RS_OK) return rc;
     rs_prof_begin(ctx, RS_PROF_DECODE, s, 0.0, 0.0);
     RS_HIP(ctx, hipMemsetAsync(zero_from, 0, zero_bytes, s));
     // slot 0 of every utterance: the zero state the search starts from
@@ -716,7 +738,7 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
                 rs_prof_end(ctx, RS_PROF_DECODE, s);
                 return rc;
             }
-            hipLaunchKernelGGL(beam_record_kernel, dim3(rec_blocks), dim3(256), pl.rec_lds, s, bs, st, st.zapprox, pl.zstride, pl.rows, V,
+            hipLaunchKernelGGL(record, dim3(rec_blocks), dim3(256), pl.rec_lds, s, bs, st, st.zapprox, pl.zstride, pl.rows, V,
                                d.blank_id, step);
             hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), pl.step_lds, s, bs, st, enc_lens, B, L, H, J, bm, score_norm, out_cap,
                                step, ids, n_ids, scores, pops);

@@ -78,6 +78,14 @@ def test_tiny_bit_exact(tiny, beam):
     assert sum(len(g[0]) for g in got) > 0
 
 
+def test_record_kernel_lds_variant(tiny, monkeypatch):
+    """vocabularies past 3072 entries take the record kernel that re-reads the row from LDS; forced here on the small one"""
+    model, sd, buf = tiny
+    want = device_beam(model, buf, 6)
+    monkeypatch.setenv("RS_BEAM_RECORD_LDS", "1")
+    assert device_beam(model, buf, 6) == want
+
+
 def test_tiny_score_norm_off_and_empty_rows(tiny):
     model, sd, buf = tiny
     f = buf.joint_enc.cpu().numpy()
