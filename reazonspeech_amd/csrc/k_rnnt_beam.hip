@@ -23,11 +23,11 @@
 //                           row of those waiting for one evaluation
 //   joint logits            rnnt_tile_kernel<4> over those rows
 //   beam_record_kernel      one wave per row: log-softmax, log p(blank), the beam_k best labels with their log-probabilities
-//   beam_step_kernel        one workgroup per utterance, open-list scores in LDS: applies the finished evaluation(s), then keeps
-//                           popping for as long as the best open hypothesis already has its record; ends the frame when the
-//                           test says so (survivors sorted, slots of everything else freed, t += 1, next batch scheduled, or the
-//                           winner read back through the label trie after the last frame); stops at the first pop that needs an
-//                           evaluation and schedules it
+//   beam_step_kernel        one workgroup per utterance, open-list scores in LDS: pops for as long as the best open hypothesis has
+//                           its record at this frame; ends the frame when the test says so (survivors sorted, slots of
+//                           everything else freed, t += 1, next batch scheduled, or the winner read back through the label trie
+//                           after the last frame); at the first pop that has no record it asks for the expansions of the best
+//                           KS record-less hypotheses (the first is needed, the others are guesses that usually come true)
 //
 // Evaluation order (float32 sums, log-sum-exp tree, tie rules) is documented in oracle/espnet_beam.c and the results are
 // bit-identical to it: labels, scores and the pop count.  Compiled with -ffp-contract=off.
@@ -77,22 +77,18 @@ struct BeamState {
     int32_t* ninit;      // hypotheses the current frame started with = entries [0, ninit) of the open list
     int32_t* nnode;      // trie nodes in use
     int32_t* pops;       // pops over the whole utterance (the work measure, returned)
-    int32_t* mode;       // what this iteration evaluates: 0 = the one popped hypothesis (row R), 1 = the frame's batch (rows [0, nb))
-    int32_t* nb;
-    // the hypothesis popped for a single evaluation [B]
-    float* cur_score;
-    int32_t* cur_node;
-    int32_t* cur_slot;   // its own slot when cur_new == 0
-    int32_t* cur_len;
-    int32_t* cur_new;    // 1: its prediction-network output is being computed in this iteration (row b of the decode state)
+    int32_t* nb;         // records [0, nb): the frame's batch
+    int32_t* nrec;       // records [R, nrec): evaluations asked for one iteration at a time
+    int32_t* npark;      // prediction-network rows of the last iteration whose results still sit in the decode state
+    int32_t* park_slot;  // [B][KS] the slot each of them goes to
     // open list [B][max_h]
     float* h_score;
     int32_t* h_node;     // trie node of the sequence when h_tok < 0, of the sequence without its last label otherwise
-    int32_t* h_tok;      // last label of a sequence that has not been evaluated yet, or -1
+    int32_t* h_tok;      // last label of a sequence that is not in the trie yet, or -1
     int32_t* h_slot;     // h_tok >= 0: slot of the sequence without its last label (the state to start from); else its own slot
     int32_t* h_len;      // len(yseq): labels + the leading blank
     int32_t* h_alive;
-    int32_t* h_rec;      // [B][max_pops] entry i < ninit: batch row that holds its record at the current frame, or -1
+    int32_t* h_rec;      // record that holds its expansion at the current frame, or -1
     // blank extensions of this frame [B][max_pops]
     float* k_score;
     int32_t* k_node;
@@ -101,12 +97,14 @@ struct BeamState {
     int2* nodes;         // [B][max_nodes] (parent, label)
     float* slots;        // [B][n_slots][slot_floats]: per evaluated sequence  h [L][H], c [L][H] after its last label, g [J]
     int32_t* freelist;   // [B][n_slots] free slot ids; a frame's end returns every slot no survivor owns
-    float* rec;          // [B][R + 1][rec_floats]: log p(blank), label count, log p(label j) x beam_k, label j x beam_k
-    long long* g_off;    // [B][R + 1] where row r's joint.pred vector is, in floats from DecodeState.g
+    float* rec;          // [B][RP][rec_floats]: log p(blank), label count, log p(label j) x beam_k, label j x beam_k
+    int32_t* rec_slot;   // [B][RP] own slot of the hypothesis a record belongs to
+    int32_t* row_rec;    // [B][R + KS] record a joint row of this iteration fills
+    long long* g_off;    // [B][R + KS] where a joint row's joint.pred vector is, in floats from DecodeState.g
     long long slots_off; // slots - DecodeState.g
     int32_t* flags;      // [0] utterances done, [1] overflow
     unsigned long long* trace;   // $RS_BEAM_TRACE: cycles per phase of the step kernel, summed over workgroups (else null)
-    int max_h, max_pops, max_nodes, n_slots, slot_floats, R, rec_floats, beam_k;
+    int max_h, max_pops, max_nodes, n_slots, slot_floats, R, KS, RP, rec_floats, beam_k;
 };
 
 __device__ __forceinline__ void beam_fail(const BeamState& bs, int b) {   // one thread
@@ -125,13 +123,14 @@ __global__ __launch_bounds__(256) void beam_init_kernel(BeamState bs, const int3
                                                         int32_t* __restrict__ pops) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    bs.t[b] = 0; bs.nk[b] = 0; bs.npop[b] = 0; bs.pops[b] = 0; bs.ninit[b] = 0; bs.mode[b] = 0; bs.nb[b] = 0;
+    bs.t[b] = 0; bs.nk[b] = 0; bs.npop[b] = 0; bs.pops[b] = 0; bs.ninit[b] = 0; bs.nb[b] = 0; bs.nrec[b] = bs.R; bs.npark[b] = 0;
     bs.nnode[b] = 0;
     for (int i = 1; i < bs.n_slots; ++i) bs.freelist[(size_t)b * bs.n_slots + i - 1] = i;
     bs.nfree[b] = bs.n_slots - 1;
     // the start: [blank] is a sequence that has not been evaluated; it starts from slot 0 (never handed out), the zero state
     const size_t h0 = (size_t)b * bs.max_h;
     bs.h_score[h0] = 0.0f; bs.h_node[h0] = -1; bs.h_tok[h0] = blank; bs.h_slot[h0] = 0; bs.h_len[h0] = 1; bs.h_alive[h0] = 1;
+    bs.h_rec[h0] = -1;
     bs.nh[b] = 1;
     n_ids[b] = 0; scores[b] = 0.0f; pops[b] = 0;
     const int fin = enc_lens[b] <= 0;            // nothing to search: the empty hypothesis, score 0
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(256) void beam_act_kernel(DecodeState st, const flo
 // grid: any (workgroups stride over the list), block 256, dynamic LDS 4 x (zstride + 256) floats
 template <int EPT>
 __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeState st, const float* __restrict__ zbuf, int zstride,
-                                                          int rows, int V, int blank, int list) {
+                                                          int rows, int rows_per_utt, int V, int blank, int list) {
     extern __shared__ __attribute__((aligned(16))) char rec_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* zs = reinterpret_cast<float*>(rec_smem) + (size_t)wave * (zstride + 256);
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
             n_c += __popcll(mask);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float* out = bs.rec + (size_t)row * bs.rec_floats;
+        float* out = bs.rec + ((size_t)(row / rows_per_utt) * bs.RP + bs.row_rec[row]) * bs.rec_floats;
         int n_lab = 0;
         if (n_c <= 64) {                                             // the usual case: one candidate per lane, ranked in registers
             n_lab = n_c < beam_k ? n_c : beam_k;
@@ -328,15 +327,18 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
 
 // ---- block-wide (256 threads) first maximum of the live entries of the LDS score list (dead = NaN) + the number of kept
 // scores strictly above it (only counted when there are at least `beam` of them: the end-of-frame test cannot pass before).
-// w_f / w_i / s_cnt are double-buffered by the parity of the call, so one barrier separates a call from the next. ----
+// NEED_NO_REC: only entries without a record (lrec < 0) compete.  w_f / w_i / cnt are double-buffered by the parity of the
+// call, so one barrier separates a call from the next. ----
 struct ArgmaxScratch { float w_f[2][4]; int w_i[2][4]; int cnt[2]; };
-__device__ __forceinline__ void list_argmax_count(const float* lsc, int n, const float* ks, int nk, int beam, ArgmaxScratch* sc, int par,
-                                                  float& best, int& bi, int& n_good) {
+template <bool NEED_NO_REC>
+__device__ __forceinline__ void list_argmax_count(const float* lsc, const short* lrec, int n, const float* ks, int nk, int beam,
+                                                  ArgmaxScratch* sc, int par, float& best, int& bi, int& n_good) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     best = -INFINITY; bi = -1;
     for (int i = tid; i < n; i += 256) {
         const float s = lsc[i];
-        const bool take = (s == s) & ((bi < 0) | (s > best));      // a thread meets its entries in ascending order
+        bool take = (s == s) & ((bi < 0) | (s > best));            // a thread meets its entries in ascending order
+        if (NEED_NO_REC) take = take & (lrec[i] < 0);
         best = take ? s : best;
         bi = take ? i : bi;
     }
@@ -360,52 +362,77 @@ __device__ __forceinline__ void list_argmax_count(const float* lsc, int n, const
     n_good = sc->cnt[par];
 }
 
-// ---- hand entry `bi` of the open list to the next iteration as a single evaluation (block-wide; the caller has made this
-// launch's global stores visible).  list = the joint work list the next iteration reads ----
-__device__ __forceinline__ void schedule_single(const BeamState& bs, const DecodeState& st, int b, int B, int L, int H, int J, int bi,
-                                                float score, int t, int list) {
+// ---- ask for the expansions the search will want next: the best KS open hypotheses that have no record at this frame, best
+// first.  The first one is the hypothesis the pop loop stopped at; the others are a guess (their turn comes unless the frame ends
+// first or new extensions overtake them — then their records simply wait or are dropped with the frame: asking changes no
+// result).  A hypothesis that is not in the label trie yet gets its prediction-network evaluation (a slot for the result is taken
+// now; the trie node is made when it is popped); one that is has its joint.pred vector cached.
+// Block-wide; the caller has made this launch's global stores visible.  list = the joint work list the next iteration reads ----
+__device__ __forceinline__ void schedule_evals(const BeamState& bs, const DecodeState& st, int b, int B, int L, int H, int J, const float* lsc,
+                                               short* lrec, int nh, int t, int npop, int nfree, int nrec, ArgmaxScratch* sc, int par,
+                                               int list) {
     const int tid = threadIdx.x;
     const size_t hb = (size_t)b * bs.max_h;
-    const int tok = bs.h_tok[hb + bi], slot = bs.h_slot[hb + bi];
-    int node = bs.h_node[hb + bi];
-    const int nn = bs.nnode[b];
-    if (tok >= 0 && nn >= bs.max_nodes) { if (tid == 0) beam_fail(bs, b); return; }
-    const int LH = L * H, rows = B * (bs.R + 1), row = b * (bs.R + 1) + bs.R;
-    const size_t slot_off = ((size_t)b * bs.n_slots + slot) * (size_t)bs.slot_floats;
-    __syncthreads();                                               // every thread has read the entry and the node count
-    if (tid == 0) {
-        bs.h_alive[hb + bi] = 0;
-        if (tok >= 0) {                                            // the sequence enters the trie, and the LSTM work list
-            bs.nodes[(size_t)b * bs.max_nodes + nn] = make_int2(node, tok);
-            node = nn;
-            bs.nnode[b] = nn + 1;
-            st.token[b] = tok;
-            st.act[atomicAdd(&st.counters[0], 1)] = b;
-            bs.g_off[row] = (long long)b * J;                      // joint.pred writes row b of the decode state
-        } else {
-            bs.g_off[row] = bs.slots_off + (long long)slot_off + 2 * LH;   // evaluated before: the cached vector
+    const int LH = L * H, KS = bs.KS, rpu = bs.R + KS, rows = B * rpu;
+    int32_t* fl = bs.freelist + (size_t)b * bs.n_slots;
+    int n_lstm = 0;
+    for (int k = 0; k < KS; ++k, par ^= 1) {
+        float sc_k;
+        int bi, dummy;
+        list_argmax_count<true>(lsc, lrec, nh, nullptr, 0, 1, sc, par, sc_k, bi, dummy);
+        if (bi < 0 || (k > 0 && nrec >= bs.RP - 1)) break;
+        const int tok = bs.h_tok[hb + bi], slot = bs.h_slot[hb + bi];
+        // guesses leave the slots alone that the frame's remaining pops may still need (the needed one always finds a slot:
+        // free slots >= pops the frame may still make, an invariant every branch here keeps)
+        if (tok >= 0 && k > 0 && nfree - 1 < bs.max_pops - npop) break;
+        const int rp = k == 0 ? bs.RP - 1 : nrec++;                 // the needed one is consumed by the next launch: one record serves
+        const int row = b * rpu + bs.R + k;
+        int own = slot;
+        if (tok >= 0) own = fl[--nfree];
+        const size_t src_off = ((size_t)b * bs.n_slots + slot) * (size_t)bs.slot_floats;
+        const int lrow = b * KS + n_lstm;                          // prediction-network row
+        if (tid == 0) {
+            lrec[bi] = (short)rp;
+            bs.h_rec[hb + bi] = rp;
+            bs.rec_slot[(size_t)b * bs.RP + rp] = own;
+            bs.row_rec[row] = rp;
+            st.tcur[row] = t;
+            st.alive[(size_t)list * rows + atomicAdd(&st.counters[2 + list], 1)] = row;
+            if (tok >= 0) {
+                st.token[lrow] = tok;
+                st.act[atomicAdd(&st.counters[0], 1)] = lrow;
+                bs.g_off[row] = (long long)lrow * J;               // joint.pred writes that row of the decode state
+                bs.park_slot[(size_t)b * KS + n_lstm] = own;
+            } else {
+                bs.g_off[row] = bs.slots_off + (long long)src_off + 2 * LH;   // evaluated before: the cached vector
+            }
         }
-        bs.cur_score[b] = score; bs.cur_node[b] = node; bs.cur_slot[b] = slot; bs.cur_len[b] = bs.h_len[hb + bi];
-        bs.cur_new[b] = tok >= 0;
-        bs.mode[b] = 0;
-        st.tcur[row] = t;
-        st.alive[(size_t)list * rows + atomicAdd(&st.counters[2 + list], 1)] = row;
-    }
-    if (tok >= 0) {                                                // start state of the evaluation
-        const float* src = bs.slots + slot_off;
-        for (int i = tid; i < LH; i += 256) {
-            const int l = i / H, u = i - l * H;
-            st.h[((size_t)l * B + b) * H + u] = src[i];
-            st.c[((size_t)l * B + b) * H + u] = src[LH + i];
+        if (tok >= 0) {                                            // start state of the evaluation
+            const float* src = bs.slots + src_off;
+            const int n_rows = B * KS;
+            for (int i = tid; i < LH; i += 256) {
+                const int l = i / H, u = i - l * H;
+                st.h[((size_t)l * n_rows + lrow) * H + u] = src[i];
+                st.c[((size_t)l * n_rows + lrow) * H + u] = src[LH + i];
+            }
+            ++n_lstm;
         }
+        lds_barrier();                                             // lrec[bi] is set before the next round looks
     }
+    if (tid == 0) { bs.nrec[b] = nrec; bs.nfree[b] = nfree; bs.npark[b] = n_lstm; }
 }
 
-// the first pop of every utterance: the start hypothesis; grid B, block 256
+// the first iteration's request: the start hypothesis; grid B, block 256, dynamic LDS like beam_step_kernel
 __global__ __launch_bounds__(256) void beam_first_kernel(BeamState bs, DecodeState st, int B, int L, int H, int J) {
+    extern __shared__ __attribute__((aligned(16))) char beam_smem[];
+    float* lsc = reinterpret_cast<float*>(beam_smem);
+    short* lrec = reinterpret_cast<short*>(lsc + bs.max_h);
+    __shared__ ArgmaxScratch sc;
     const int b = blockIdx.x;
     if (bs.done[b]) return;
-    schedule_single(bs, st, b, B, L, H, J, 0, 0.0f, 0, 0);
+    if (threadIdx.x == 0) { lsc[0] = 0.0f; lrec[0] = -1; sc.cnt[0] = 0; sc.cnt[1] = 0; }
+    __syncthreads();
+    schedule_evals(bs, st, b, B, L, H, J, lsc, lrec, 1, 0, 0, bs.nfree[b], bs.nrec[b], &sc, 0, 0);
 }
 
 #define BEAM_MARK(phase)                                                                       \
@@ -416,25 +443,26 @@ __global__ __launch_bounds__(256) void beam_first_kernel(BeamState bs, DecodeSta
         t_mark = now;                                                                          \
     }
 
-// grid B, block 256.  Dynamic LDS (floats / ints): open-list scores [max_h], kept score / node / slot / len [max_pops] each,
-// frame-start hypotheses' node / slot / len / record row [max_pops] each, slot marks [n_slots], records [(R + 1) * rec_floats]
+// grid B, block 256.  Dynamic LDS: open-list scores [max_h] f32 + records [max_h] i16, kept score / node / slot / len
+// [max_pops] each, frame-start hypotheses' node / len [max_pops] each, slot marks [n_slots], records [RP * rec_floats], their
+// slots [RP]
 __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeState st, const int32_t* __restrict__ enc_lens, int B,
                                                         int L, int H, int J, int beam, int score_norm, int out_cap, int iter,
                                                         int32_t* __restrict__ ids, int32_t* __restrict__ n_ids,
                                                         float* __restrict__ scores, int32_t* __restrict__ pops) {
     extern __shared__ __attribute__((aligned(16))) char beam_smem[];
-    const int MP = bs.max_pops, R = bs.R, RF = bs.rec_floats, K = bs.beam_k;
+    const int MP = bs.max_pops, R = bs.R, KS = bs.KS, RP = bs.RP, RF = bs.rec_floats, K = bs.beam_k;
     float* lsc = reinterpret_cast<float*>(beam_smem);
-    float* ks = lsc + bs.max_h;
+    short* lrec = reinterpret_cast<short*>(lsc + bs.max_h);
+    float* ks = reinterpret_cast<float*>(lrec + (bs.max_h + 1) / 2 * 2);
     int* kn = reinterpret_cast<int*>(ks + MP);
     int* ksl = kn + MP;
     int* kl = ksl + MP;
     int* sn = kl + MP;
-    int* ssl = sn + MP;
-    int* sl = ssl + MP;
-    int* sr = sl + MP;
-    int* used = sr + MP;
+    int* sl = sn + MP;
+    int* used = sl + MP;
     float* recs = reinterpret_cast<float*>(used + bs.n_slots);
+    int* rslot = reinterpret_cast<int*>(recs + (size_t)RP * RF);
     __shared__ ArgmaxScratch sc;
     __shared__ int s_nfree;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -444,82 +472,88 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
     const size_t hb = (size_t)b * bs.max_h, kb = (size_t)b * MP;
     float* pool = bs.slots + ((size_t)b * bs.n_slots) * (size_t)SS;
     int32_t* fl = bs.freelist + (size_t)b * bs.n_slots;
-    const int t = bs.t[b], ninit = bs.ninit[b], mode = bs.mode[b], nbatch = bs.nb[b];
-    int nh = bs.nh[b], nk = bs.nk[b], npop = bs.npop[b], nfree = bs.nfree[b], pops_add = 0;
+    const int t = bs.t[b], ninit = bs.ninit[b], nbatch = bs.nb[b], nrec = bs.nrec[b], npark = bs.npark[b];
+    int nh = bs.nh[b], nk = bs.nk[b], npop = bs.npop[b], nnode = bs.nnode[b], pops_add = 0;
+    const int nfree = bs.nfree[b];
     const int list = (iter + 1) & 1;
 
     // ---- this launch's view of the utterance, in LDS ----
-    for (int i = tid; i < nh; i += 256) lsc[i] = bs.h_alive[hb + i] ? bs.h_score[hb + i] : __int_as_float(0x7fc00000);
+    for (int i = tid; i < nh; i += 256) {
+        lsc[i] = bs.h_alive[hb + i] ? bs.h_score[hb + i] : __int_as_float(0x7fc00000);
+        lrec[i] = (short)bs.h_rec[hb + i];
+    }
     for (int i = tid; i < nk; i += 256) { ks[i] = bs.k_score[kb + i]; kn[i] = bs.k_node[kb + i]; ksl[i] = bs.k_slot[kb + i]; kl[i] = bs.k_len[kb + i]; }
-    for (int i = tid; i < ninit; i += 256) { sn[i] = bs.h_node[hb + i]; ssl[i] = bs.h_slot[hb + i]; sl[i] = bs.h_len[hb + i]; sr[i] = bs.h_rec[kb + i]; }
-    {   // the records of this frame's batch (they stay valid until the frame ends) and, in mode 0, of the single evaluation
-        const float* src = bs.rec + ((size_t)b * (R + 1)) * RF;
+    for (int i = tid; i < ninit; i += 256) { sn[i] = bs.h_node[hb + i]; sl[i] = bs.h_len[hb + i]; }
+    {   // the records of this frame: the batch [0, nbatch) and what was asked for since [R, nrec)
+        const float* src = bs.rec + ((size_t)b * RP) * RF;
         for (int i = tid; i < nbatch * RF; i += 256) recs[i] = src[i];
-        if (mode == 0) for (int i = tid; i < RF; i += 256) recs[R * RF + i] = src[R * RF + i];
+        for (int i = R * RF + tid; i < nrec * RF; i += 256) recs[i] = src[i];
+        for (int i = (RP - 1) * RF + tid; i < RP * RF; i += 256) recs[i] = src[i];
+        for (int i = tid; i < RP; i += 256) rslot[i] = bs.rec_slot[(size_t)b * RP + i];
     }
-    // the expansion to apply first: the single evaluation that just finished (mode 0); a batch has none pending
-    bool have = mode == 0;
-    float e_score = 0.0f;
-    int e_node = 0, e_len = 0, e_own = 0, e_row = R;
-    if (mode == 0) {
-        const int is_new = bs.cur_new[b];
-        // its own slot: a fresh one when it was evaluated in this iteration (never short: n_slots - 1 = 2 * max_pops >= survivors
-        // of the last frame + evaluations of this one)
-        e_own = is_new ? fl[nfree - 1] : bs.cur_slot[b];
-        if (is_new) {
-            float* dst = pool + (size_t)e_own * SS;
-            for (int i = tid; i < LH; i += 256) {
-                const int l = i / H, u = i - l * H;
-                dst[i] = st.h[((size_t)l * B + b) * H + u];
-                dst[LH + i] = st.c[((size_t)l * B + b) * H + u];
-            }
-            for (int i = tid; i < J; i += 256) dst[2 * LH + i] = st.g[(size_t)b * J + i];
+    // the prediction-network results of the last iteration go to the slots taken for them
+    for (int k = 0; k < npark; ++k) {
+        float* dst = pool + (size_t)bs.park_slot[(size_t)b * KS + k] * SS;
+        const int lrow = b * KS + k, n_rows = B * KS;
+        for (int i = tid; i < LH; i += 256) {
+            const int l = i / H, u = i - l * H;
+            dst[i] = st.h[((size_t)l * n_rows + lrow) * H + u];
+            dst[LH + i] = st.c[((size_t)l * n_rows + lrow) * H + u];
         }
-        nfree -= is_new;
-        e_score = bs.cur_score[b]; e_node = bs.cur_node[b]; e_len = bs.cur_len[b];
+        for (int i = tid; i < J; i += 256) dst[2 * LH + i] = st.g[(size_t)lrow * J + i];
     }
+    if (tid == 0) { sc.cnt[0] = 0; sc.cnt[1] = 0; }
     __syncthreads();
     BEAM_MARK(0)
 
-    float hm;
-    int bi, n_good, par = 0;
-    if (tid == 0) { sc.cnt[0] = 0; sc.cnt[1] = 0; }
-    lds_barrier();
+    bool have = false;
+    float e_score = 0.0f, hm;
+    int e_node = 0, e_len = 0, e_own = 0, e_row = 0, bi, n_good, par = 0;
     for (;; par ^= 1) {
         if (have) {                                                  // ---- apply one pop: blank extension + label extensions ----
             const float* rc = recs + (size_t)e_row * RF;
             const int n_lab = __float_as_int(rc[1]);
             if (tid == 255) {
-                const float sc = e_score + rc[0];
-                ks[nk] = sc; kn[nk] = e_node; ksl[nk] = e_own; kl[nk] = e_len;
-                bs.k_score[kb + nk] = sc; bs.k_node[kb + nk] = e_node; bs.k_slot[kb + nk] = e_own; bs.k_len[kb + nk] = e_len;
+                const float sc_b = e_score + rc[0];
+                ks[nk] = sc_b; kn[nk] = e_node; ksl[nk] = e_own; kl[nk] = e_len;
+                bs.k_score[kb + nk] = sc_b; bs.k_node[kb + nk] = e_node; bs.k_slot[kb + nk] = e_own; bs.k_len[kb + nk] = e_len;
             }
             if (tid < n_lab) {
-                const float sc = e_score + rc[2 + tid];
+                const float sc_c = e_score + rc[2 + tid];
                 const size_t o = hb + nh + tid;
-                lsc[nh + tid] = sc;
-                bs.h_score[o] = sc; bs.h_node[o] = e_node; bs.h_tok[o] = __float_as_int(rc[2 + K + tid]); bs.h_slot[o] = e_own;
-                bs.h_len[o] = e_len + 1; bs.h_alive[o] = 1;
+                lsc[nh + tid] = sc_c; lrec[nh + tid] = -1;
+                bs.h_score[o] = sc_c; bs.h_node[o] = e_node; bs.h_tok[o] = __float_as_int(rc[2 + K + tid]); bs.h_slot[o] = e_own;
+                bs.h_len[o] = e_len + 1; bs.h_alive[o] = 1; bs.h_rec[o] = -1;
             }
             nh += n_lab; nk += 1; npop += 1; pops_add += 1;
             lds_barrier();
         }
         // end-of-frame test: at least `beam` kept entries strictly above the maximum of the open list — whose first maximum is
         // also the next hypothesis to pop if the frame goes on
-        list_argmax_count(lsc, nh, ks, nk, beam, &sc, par, hm, bi, n_good);
+        list_argmax_count<false>(lsc, lrec, nh, ks, nk, beam, &sc, par, hm, bi, n_good);
         if (n_good >= beam) break;
         if (bi < 0 || npop >= MP) { if (tid == 0) beam_fail(bs, b); return; }
-        if (bi < ninit && sr[bi] >= 0) {                             // its record at this frame is here already: pop it now
-            if (tid == 0) { lsc[bi] = __int_as_float(0x7fc00000); bs.h_alive[hb + bi] = 0; }
-            e_score = hm; e_node = sn[bi]; e_len = sl[bi]; e_own = ssl[bi]; e_row = sr[bi];
-            have = true;
-            continue;
+        const int rp = lrec[bi];
+        if (rp < 0) break;                                           // it needs an evaluation
+        // ---- its record at this frame is here: pop it now ----
+        if (bi < ninit) { e_node = sn[bi]; e_len = sl[bi]; }
+        else {                                                       // a label extension (opened in an earlier launch): it enters the trie
+            const int tok = bs.h_tok[hb + bi], parent = bs.h_node[hb + bi];
+            e_len = bs.h_len[hb + bi];
+            if (nnode >= bs.max_nodes) { if (tid == 0) beam_fail(bs, b); return; }
+            if (tid == 0) bs.nodes[(size_t)b * bs.max_nodes + nnode] = make_int2(parent, tok);
+            e_node = nnode++;
         }
-        // ---- it needs an evaluation: hand it to the next iteration ----
-        if (tid == 0) { bs.nh[b] = nh; bs.nk[b] = nk; bs.npop[b] = npop; bs.nfree[b] = nfree; bs.pops[b] += pops_add; }
+        if (tid == 0) { lsc[bi] = __int_as_float(0x7fc00000); bs.h_alive[hb + bi] = 0; }
+        e_score = hm; e_own = rslot[rp]; e_row = rp;
+        have = true;
+    }
+    if (n_good < beam) {
+        // ---- hand the hypotheses the search wants next to the next iteration ----
+        if (tid == 0) { bs.nh[b] = nh; bs.nk[b] = nk; bs.npop[b] = npop; bs.nnode[b] = nnode; bs.pops[b] += pops_add; }
         __syncthreads();                                             // entries appended in this launch are read back from global
         BEAM_MARK(1)
-        schedule_single(bs, st, b, B, L, H, J, bi, hm, t, list);
+        schedule_evals(bs, st, b, B, L, H, J, lsc, lrec, nh, t, npop, nfree, nrec, &sc, par ^ 1, list);
         BEAM_MARK(2)
         return;
     }
@@ -532,7 +566,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
     lds_barrier();
     const int t_next = t + 1;
     const bool last = t_next >= enc_lens[b];
-    const int rows = B * (R + 1);
+    const int rpu = R + KS, rows = B * rpu;
     for (int i = tid; i < nk; i += 256) {
         const float si = ks[i];
         if (!(si > hm)) continue;
@@ -544,17 +578,19 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
             desc += (so > si) | ((so == si) & (o < i));
         }
         const int slot = ksl[i];
-        used[slot] = 1;
         if (last) {                                                  // by position: what the read-back below needs
             lsc[rank] = score_norm ? si / (float)kl[i] : si;
-            sn[rank] = kn[i]; sl[rank] = kl[i]; ssl[rank] = __float_as_int(si);
+            sn[rank] = kn[i]; sl[rank] = kl[i]; used[rank] = __float_as_int(si);
         } else {
+            used[slot] = 1;
             bs.h_score[hb + rank] = si;
             bs.h_node[hb + rank] = kn[i]; bs.h_tok[hb + rank] = -1; bs.h_slot[hb + rank] = slot;
             bs.h_len[hb + rank] = kl[i]; bs.h_alive[hb + rank] = 1;
-            bs.h_rec[kb + rank] = desc < R ? desc : -1;
+            bs.h_rec[hb + rank] = desc < R ? desc : -1;
             if (desc < R) {
-                const int row = b * (R + 1) + desc;
+                const int row = b * rpu + desc;
+                bs.rec_slot[(size_t)b * RP + desc] = slot;
+                bs.row_rec[row] = desc;
                 bs.g_off[row] = bs.slots_off + (long long)(((size_t)b * bs.n_slots + slot) * (size_t)SS) + 2 * LH;
                 st.tcur[row] = t_next;
                 st.alive[(size_t)list * rows + atomicAdd(&st.counters[2 + list], 1)] = row;
@@ -569,18 +605,18 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
         lds_barrier();
         if (tid == 0) {
             bs.nh[b] = n_good; bs.nk[b] = 0; bs.npop[b] = 0; bs.nfree[b] = s_nfree; bs.ninit[b] = n_good; bs.t[b] = t_next;
-            bs.pops[b] += pops_add;
-            bs.mode[b] = 1; bs.nb[b] = n_good < R ? n_good : R;
+            bs.nnode[b] = nnode; bs.pops[b] += pops_add;
+            bs.nb[b] = n_good < R ? n_good : R; bs.nrec[b] = R; bs.npark[b] = 0;
         }
         BEAM_MARK(5)
         return;
     }
     // ---- last frame: the first maximum of score / len(yseq) (or of score) over the survivors in their order ----
     int dummy;
-    list_argmax_count(lsc, n_good, ks, 0, 1, &sc, par ^ 1, hm, bi, dummy);
+    list_argmax_count<false>(lsc, lrec, n_good, ks, 0, 1, &sc, par ^ 1, hm, bi, dummy);
     if (tid == 0) {
         const int n = sl[bi] - 1;
-        scores[b] = __int_as_float(ssl[bi]);
+        scores[b] = __int_as_float(used[bi]);
         pops[b] = bs.pops[b] + pops_add;
         bs.done[b] = 1;
         if (n > out_cap) { n_ids[b] = 0; bs.flags[1] = 1; }
@@ -599,8 +635,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
 }
 
 struct BeamPlan {
-    size_t b4, h4, k4, nodes, slots, freelist, rec, goff, state1, g, rows4, z, apre, total, step_lds, rec_lds;
-    int max_h, max_nodes, n_slots, slot_floats, zstride, R, rec_floats, rows;
+    size_t b4, bk4, h4, k4, nodes, slots, freelist, rec, rp4, goff, state1, g, rows4, z, apre, total, step_lds, rec_lds;
+    int max_h, max_nodes, n_slots, slot_floats, zstride, R, KS, RP, rec_floats, rows;
 };
 
 BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam, int beam_k, int tp_max, int max_pops) {
@@ -615,24 +651,31 @@ BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam, int beam_k, int tp_max, i
     if (R > 64) R = 64;
     if (R > max_pops) R = max_pops;
     p.R = R;
+    int KS = 4;                                                      // evaluations asked for per iteration (the first is needed, the rest are guesses)
+    if (const char* e = getenv("RS_BEAM_SPEC")) KS = atoi(e);
+    p.KS = KS < 1 ? 1 : KS > 8 ? 8 : KS;
+    p.RP = R + 32 + 1;                                               // batch + guesses of a frame + the needed one
     p.rec_floats = 2 + 2 * beam_k;
-    p.rows = B * (R + 1);
+    p.rows = B * (R + p.KS);
     p.b4 = rs_align((size_t)B * 4);
+    p.bk4 = rs_align((size_t)B * p.KS * 4);
     p.h4 = rs_align((size_t)B * p.max_h * 4);
     p.k4 = rs_align((size_t)B * max_pops * 4);
     p.nodes = rs_align((size_t)B * p.max_nodes * 8);
-    p.state1 = rs_align((size_t)d.pred_layers * B * d.pred_hidden * 4);
+    p.state1 = rs_align((size_t)d.pred_layers * B * p.KS * d.pred_hidden * 4);
     p.slots = rs_align((size_t)B * p.n_slots * p.slot_floats * 4);
     p.freelist = rs_align((size_t)B * p.n_slots * 4);
-    p.rec = rs_align((size_t)p.rows * p.rec_floats * 4);
+    p.rec = rs_align((size_t)B * p.RP * p.rec_floats * 4);
+    p.rp4 = rs_align((size_t)B * p.RP * 4);
     p.goff = rs_align((size_t)p.rows * 8);
-    p.g = rs_align((size_t)B * d.joint_hidden * 4);
+    p.g = rs_align((size_t)B * p.KS * d.joint_hidden * 4);
     p.rows4 = rs_align((size_t)p.rows * 4);
     p.z = rs_align((size_t)p.rows * p.zstride * 4);
     p.apre = rs_align((size_t)p.rows * d.joint_hidden * 4);
-    p.total = p.apre + 18 * p.b4 + 6 * p.h4 + 5 * p.k4 + p.nodes + p.slots + p.freelist + p.rec + p.goff + 4 * p.state1 + p.g +
-              3 * p.rows4 + 2 * rs_align(64) + rs_align(256) + p.z + 1024;
-    p.step_lds = (size_t)p.max_h * 4 + (size_t)max_pops * 4 * 8 + (size_t)p.n_slots * 4 + (size_t)(R + 1) * p.rec_floats * 4;
+    p.total = 12 * p.b4 + 3 * p.bk4 + 7 * p.h4 + 4 * p.k4 + p.nodes + p.slots + p.freelist + p.rec + p.rp4 + p.goff + 4 * p.state1 + p.g +
+              4 * p.rows4 + 2 * rs_align(64) + rs_align(256) + p.z + p.apre + 1024;
+    p.step_lds = (size_t)p.max_h * 4 + (size_t)(p.max_h + 1) / 2 * 4 + (size_t)max_pops * 4 * 6 + (size_t)p.n_slots * 4 +
+                 (size_t)p.RP * p.rec_floats * 4 + (size_t)p.RP * 4;
     p.rec_lds = (size_t)4 * (p.zstride + 256) * 4;
     return p;
 }
@@ -671,9 +714,9 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     char* zero_from = w;
     bs.t = (int32_t*)take(pl.b4); bs.done = (int32_t*)take(pl.b4); bs.nh = (int32_t*)take(pl.b4); bs.nk = (int32_t*)take(pl.b4);
     bs.npop = (int32_t*)take(pl.b4); bs.nfree = (int32_t*)take(pl.b4); bs.ninit = (int32_t*)take(pl.b4);
-    bs.nnode = (int32_t*)take(pl.b4); bs.pops = (int32_t*)take(pl.b4); bs.mode = (int32_t*)take(pl.b4); bs.nb = (int32_t*)take(pl.b4);
-    bs.cur_score = (float*)take(pl.b4); bs.cur_node = (int32_t*)take(pl.b4); bs.cur_slot = (int32_t*)take(pl.b4);
-    bs.cur_len = (int32_t*)take(pl.b4); bs.cur_new = (int32_t*)take(pl.b4);
+    bs.nnode = (int32_t*)take(pl.b4); bs.pops = (int32_t*)take(pl.b4); bs.nb = (int32_t*)take(pl.b4);
+    bs.nrec = (int32_t*)take(pl.b4); bs.npark = (int32_t*)take(pl.b4);
+    bs.park_slot = (int32_t*)take(pl.bk4);
     bs.flags = (int32_t*)take(rs_align(64));
     int32_t* counters = (int32_t*)take(rs_align(64));
     unsigned long long* trace = (unsigned long long*)take(rs_align(256));
@@ -681,23 +724,25 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     const size_t zero_bytes = (size_t)(w - zero_from);
     bs.h_score = (float*)take(pl.h4); bs.h_node = (int32_t*)take(pl.h4); bs.h_tok = (int32_t*)take(pl.h4);
     bs.h_slot = (int32_t*)take(pl.h4); bs.h_len = (int32_t*)take(pl.h4); bs.h_alive = (int32_t*)take(pl.h4);
-    bs.h_rec = (int32_t*)take(pl.k4);
+    bs.h_rec = (int32_t*)take(pl.h4);
     bs.k_score = (float*)take(pl.k4); bs.k_node = (int32_t*)take(pl.k4); bs.k_slot = (int32_t*)take(pl.k4);
     bs.k_len = (int32_t*)take(pl.k4);
     bs.nodes = (int2*)take(pl.nodes);
     bs.freelist = (int32_t*)take(pl.freelist);
     bs.rec = (float*)take(pl.rec);
+    bs.rec_slot = (int32_t*)take(pl.rp4);
+    bs.row_rec = (int32_t*)take(pl.rows4);
     bs.g_off = (long long*)take(pl.goff);
     st.g = (float*)take(pl.g);                                      // joint.pred rows of the LSTM launch; the slots follow in the same
     bs.slots = (float*)take(pl.slots);                               // allocation, so one base + offset addresses both
     bs.slots_off = (long long)(bs.slots - st.g);
     bs.max_h = pl.max_h; bs.max_pops = mp; bs.max_nodes = pl.max_nodes; bs.n_slots = pl.n_slots; bs.slot_floats = pl.slot_floats;
-    bs.R = pl.R; bs.rec_floats = pl.rec_floats; bs.beam_k = beam_k;
+    bs.R = pl.R; bs.KS = pl.KS; bs.RP = pl.RP; bs.rec_floats = pl.rec_floats; bs.beam_k = beam_k;
     st.h = (float*)take(pl.state1); st.c = (float*)take(pl.state1);
     st.h_tmp = (float*)take(pl.state1); st.c_tmp = (float*)take(pl.state1);
     st.tcur = (int32_t*)take(pl.rows4);                              // per joint row
     st.sym = nullptr;
-    st.token = (int32_t*)take(pl.b4); st.act = (int32_t*)take(pl.b4);   // per LSTM row (= utterance)
+    st.token = (int32_t*)take(pl.bk4); st.act = (int32_t*)take(pl.bk4);   // per prediction-network row
     st.alive = (int32_t*)take(2 * pl.rows4);
     st.counters = counters;
     st.pmax = nullptr; st.pidx = nullptr; st.a16 = nullptr; st.anorm = nullptr;
@@ -707,39 +752,41 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     st.a_pre = a_pre;
     st.joint_act = d.joint_act;
 
-    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)beam_step_kernel, (int)pl.step_lds); rc != RS_OK) return rc;
     const bool rec_lds = getenv("RS_BEAM_RECORD_LDS") != nullptr;   // test hook: the any-vocabulary variant on a small one
     auto record = rec_lds ? beam_record_kernel<0> : V <= 64 * 16 ? beam_record_kernel<16> : V <= 64 * 48 ? beam_record_kernel<48> : beam_record_kernel<0>;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)beam_step_kernel, (int)pl.step_lds); rc != RS_OK) return rc;
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)beam_first_kernel, (int)pl.step_lds); rc != RS_OK) return rc;
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)record, (int)pl.rec_lds); rc != RS_OK) return rc;
     rs_prof_begin(ctx, RS_PROF_DECODE, s, 0.0, 0.0);
     RS_HIP(ctx, hipMemsetAsync(zero_from, 0, zero_bytes, s));
     // slot 0 of every utterance: the zero state the search starts from
     RS_HIP(ctx, hipMemset2DAsync(bs.slots, (size_t)pl.n_slots * pl.slot_floats * 4, 0, (size_t)pl.slot_floats * 4, B, s));
     hipLaunchKernelGGL(beam_init_kernel, dim3((B + 255) / 256), dim3(256), 0, s, bs, enc_lens, B, d.blank_id, n_ids, scores, pops);
-    hipLaunchKernelGGL(beam_first_kernel, dim3(B), dim3(256), 0, s, bs, st, B, L, H, J);
+    hipLaunchKernelGGL(beam_first_kernel, dim3(B), dim3(256), pl.step_lds, s, bs, st, B, L, H, J);
     RS_CHECK_LAUNCH(ctx, "beam init");
 
     const int CHUNK = 32;
     const long long max_iters = (long long)(tp_max > 0 ? tp_max : 1) * (mp + 1) + 1;
-    // the joint walks its list with a fixed number of row tiles (the list holds between B and B * R rows); the record kernel
-    // strides over it the same way
+    // the joint walks its list with a fixed number of row tiles (the list holds between B and B * R rows); the act and record
+    // kernels stride over it the same way
     const int joint_rts = pl.rows / 32 < 64 ? (pl.rows + 31) / 32 : 64;
     const int act_blocks = 512;
     const int rec_blocks = pl.rows / 4 < 1024 ? (pl.rows + 3) / 4 : 1024;
+    const int rpu = pl.R + pl.KS;
     int32_t hf[2] = {0, 0};
     long long it = 0;
     bool finished = false;
     while (!finished && it < max_iters) {
         for (int c = 0; c < CHUNK; ++c, ++it) {
             const int step = (int)(it & 1);
-            if (int rc = rs_rnnt_launch_lstm_pred(ctx, &st, B, s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
-            hipLaunchKernelGGL(beam_act_kernel, dim3(act_blocks), dim3(256), 0, s, st, joint_enc, a_pre, pl.rows, tp_max, J, pl.R + 1, step);
-            if (int rc = rs_rnnt_launch_joint_logits_indirect(ctx, &st, joint_enc, pl.rows, joint_rts * 32, tp_max, pl.R + 1, step, s); rc != RS_OK) {
+            if (int rc = rs_rnnt_launch_lstm_pred(ctx, &st, B * pl.KS, s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
+            hipLaunchKernelGGL(beam_act_kernel, dim3(act_blocks), dim3(256), 0, s, st, joint_enc, a_pre, pl.rows, tp_max, J, rpu, step);
+            if (int rc = rs_rnnt_launch_joint_logits_indirect(ctx, &st, joint_enc, pl.rows, joint_rts * 32, tp_max, rpu, step, s); rc != RS_OK) {
                 rs_prof_end(ctx, RS_PROF_DECODE, s);
                 return rc;
             }
-            hipLaunchKernelGGL(record, dim3(rec_blocks), dim3(256), pl.rec_lds, s, bs, st, st.zapprox, pl.zstride, pl.rows, V,
-                               d.blank_id, step);
+            hipLaunchKernelGGL(record, dim3(rec_blocks), dim3(256), pl.rec_lds, s, bs, st, st.zapprox, pl.zstride, pl.rows, rpu, V, d.blank_id,
+                               step);
             hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), pl.step_lds, s, bs, st, enc_lens, B, L, H, J, bm, score_norm, out_cap,
                                step, ids, n_ids, scores, pops);
         }
@@ -752,7 +799,7 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     if (bs.trace) {                                                  // diagnostic: where the step kernel's workgroups spend their time
         unsigned long long tr[14];
         RS_HIP(ctx, hipMemcpy(tr, trace, sizeof tr, hipMemcpyDeviceToHost));
-        static const char* names[7] = {"load state", "pops until an evaluation", "schedule it", "pops until frame end", "rank survivors",
+        static const char* names[7] = {"load state", "pops until an evaluation", "ask for evaluations", "pops until frame end", "rank survivors",
                                        "free slots", "read back"};
         for (int i = 0; i < 7; ++i)
             fprintf(stderr, "[beam trace] %-26s %10llu passes  %8.2f us each (100 MHz wall clock)\n", names[i], tr[2 * i + 1],

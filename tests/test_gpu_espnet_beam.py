@@ -78,6 +78,15 @@ def test_tiny_bit_exact(tiny, beam):
     assert sum(len(g[0]) for g in got) > 0
 
 
+@pytest.mark.parametrize("ks", ["1", "2", "8"])
+def test_guesses_do_not_change_results(tiny, monkeypatch, ks):
+    """how many expansions are asked for ahead of need per iteration ($RS_BEAM_SPEC, default 4) is a scheduling matter"""
+    model, sd, buf = tiny
+    want = device_beam(model, buf, 10)
+    monkeypatch.setenv("RS_BEAM_SPEC", ks)
+    assert device_beam(model, buf, 10) == want
+
+
 def test_record_kernel_lds_variant(tiny, monkeypatch):
     """vocabularies past 3072 entries take the record kernel that re-reads the row from LDS; forced here on the small one"""
     model, sd, buf = tiny
