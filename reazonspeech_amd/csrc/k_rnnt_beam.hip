@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void beam_record_kernel(BeamState bs, DecodeSt
 
 // ---- block-wide (256 threads) first maximum of the live entries of the LDS score list (dead = NaN) + the number of kept
 // scores strictly above it (only counted when there are at least `beam` of them: the end-of-frame test cannot pass before).
-// NEED_NO_REC: only entries without a record (lrec < 0) compete.  w_f / w_i / cnt are double-buffered by the parity of the
+// NEED_NO_REC: only entries without a record (lrec == -1) compete.  w_f / w_i / cnt are double-buffered by the parity of the
 // call, so one barrier separates a call from the next. ----
 struct ArgmaxScratch { float w_f[2][4]; int w_i[2][4]; int cnt[2]; };
 template <bool NEED_NO_REC>
@@ -338,7 +338,7 @@ __device__ __forceinline__ void list_argmax_count(const float* lsc, const short*
     for (int i = tid; i < n; i += 256) {
         const float s = lsc[i];
         bool take = (s == s) & ((bi < 0) | (s > best));            // a thread meets its entries in ascending order
-        if (NEED_NO_REC) take = take & (lrec[i] < 0);
+        if (NEED_NO_REC) take = take & (lrec[i] == -1);
         best = take ? s : best;
         bi = take ? i : bi;
     }
@@ -371,55 +371,72 @@ __device__ __forceinline__ void list_argmax_count(const float* lsc, const short*
 __device__ __forceinline__ void schedule_evals(const BeamState& bs, const DecodeState& st, int b, int B, int L, int H, int J, const float* lsc,
                                                short* lrec, int nh, int t, int npop, int nfree, int nrec, ArgmaxScratch* sc, int par,
                                                int list) {
+    __shared__ int c_bi[8], c_tok[8], c_slot[8];
     const int tid = threadIdx.x;
     const size_t hb = (size_t)b * bs.max_h;
     const int LH = L * H, KS = bs.KS, rpu = bs.R + KS, rows = B * rpu;
     int32_t* fl = bs.freelist + (size_t)b * bs.n_slots;
-    int n_lstm = 0;
+    // the candidates, best first (LDS only); a chosen one is marked so that the next round skips it
+    int n_cand = 0;
     for (int k = 0; k < KS; ++k, par ^= 1) {
         float sc_k;
         int bi, dummy;
         list_argmax_count<true>(lsc, lrec, nh, nullptr, 0, 1, sc, par, sc_k, bi, dummy);
-        if (bi < 0 || (k > 0 && nrec >= bs.RP - 1)) break;
-        const int tok = bs.h_tok[hb + bi], slot = bs.h_slot[hb + bi];
-        // guesses leave the slots alone that the frame's remaining pops may still need (the needed one always finds a slot:
-        // free slots >= pops the frame may still make, an invariant every branch here keeps)
-        if (tok >= 0 && k > 0 && nfree - 1 < bs.max_pops - npop) break;
+        if (bi < 0) break;
+        if (tid == 0) { c_bi[k] = bi; lrec[bi] = -2; }
+        ++n_cand;
+        lds_barrier();
+    }
+    if (tid < n_cand) { c_tok[tid] = bs.h_tok[hb + c_bi[tid]]; c_slot[tid] = bs.h_slot[hb + c_bi[tid]]; }
+    __syncthreads();
+    // which of them are asked for: the first always; a guess only while records are left, and — if it needs a slot — while the
+    // frame's remaining pops keep theirs (free slots >= pops the frame may still make: an invariant every branch here keeps,
+    // which is also why the needed one always finds a slot)
+    int n_acc = 0, n_lstm = 0;
+    for (int k = 0; k < n_cand; ++k) {
+        const bool is_new = c_tok[k] >= 0;
+        if (k > 0 && (nrec >= bs.RP - 1 || (is_new && nfree - 1 < bs.max_pops - npop))) break;
         const int rp = k == 0 ? bs.RP - 1 : nrec++;                 // the needed one is consumed by the next launch: one record serves
-        const int row = b * rpu + bs.R + k;
-        int own = slot;
-        if (tok >= 0) own = fl[--nfree];
-        const size_t src_off = ((size_t)b * bs.n_slots + slot) * (size_t)bs.slot_floats;
-        const int lrow = b * KS + n_lstm;                          // prediction-network row
+        const int own = is_new ? fl[--nfree] : c_slot[k];
         if (tid == 0) {
+            const int bi = c_bi[k], row = b * rpu + bs.R + k, lrow = b * KS + n_lstm;
+            const size_t src_off = ((size_t)b * bs.n_slots + c_slot[k]) * (size_t)bs.slot_floats;
             lrec[bi] = (short)rp;
             bs.h_rec[hb + bi] = rp;
             bs.rec_slot[(size_t)b * bs.RP + rp] = own;
             bs.row_rec[row] = rp;
             st.tcur[row] = t;
             st.alive[(size_t)list * rows + atomicAdd(&st.counters[2 + list], 1)] = row;
-            if (tok >= 0) {
-                st.token[lrow] = tok;
+            if (is_new) {
+                st.token[lrow] = c_tok[k];
                 st.act[atomicAdd(&st.counters[0], 1)] = lrow;
                 bs.g_off[row] = (long long)lrow * J;               // joint.pred writes that row of the decode state
                 bs.park_slot[(size_t)b * KS + n_lstm] = own;
+                c_bi[k] = n_lstm;                                  // (reused below: the prediction-network row of candidate k)
             } else {
                 bs.g_off[row] = bs.slots_off + (long long)src_off + 2 * LH;   // evaluated before: the cached vector
             }
         }
-        if (tok >= 0) {                                            // start state of the evaluation
-            const float* src = bs.slots + src_off;
-            const int n_rows = B * KS;
-            for (int i = tid; i < LH; i += 256) {
-                const int l = i / H, u = i - l * H;
-                st.h[((size_t)l * n_rows + lrow) * H + u] = src[i];
-                st.c[((size_t)l * n_rows + lrow) * H + u] = src[LH + i];
-            }
-            ++n_lstm;
-        }
-        lds_barrier();                                             // lrec[bi] is set before the next round looks
+        n_lstm += is_new;
+        ++n_acc;
     }
-    if (tid == 0) { bs.nrec[b] = nrec; bs.nfree[b] = nfree; bs.npark[b] = n_lstm; }
+    if (tid == 0) {
+        for (int k = n_acc; k < n_cand; ++k) lrec[c_bi[k]] = -1;     // not asked for after all
+        bs.nrec[b] = nrec; bs.nfree[b] = nfree; bs.npark[b] = n_lstm;
+    }
+    lds_barrier();
+    // start states of the new evaluations
+    const int n_rows = B * KS;
+    for (int k = 0; k < n_acc; ++k) {
+        if (c_tok[k] < 0) continue;
+        const float* src = bs.slots + ((size_t)b * bs.n_slots + c_slot[k]) * (size_t)bs.slot_floats;
+        const int lrow = b * KS + c_bi[k];
+        for (int i = tid; i < LH; i += 256) {
+            const int l = i / H, u = i - l * H;
+            st.h[((size_t)l * n_rows + lrow) * H + u] = src[i];
+            st.c[((size_t)l * n_rows + lrow) * H + u] = src[LH + i];
+        }
+    }
 }
 
 // the first iteration's request: the start hypothesis; grid B, block 256, dynamic LDS like beam_step_kernel
@@ -492,15 +509,20 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
         for (int i = tid; i < RP; i += 256) rslot[i] = bs.rec_slot[(size_t)b * RP + i];
     }
     // the prediction-network results of the last iteration go to the slots taken for them
-    for (int k = 0; k < npark; ++k) {
-        float* dst = pool + (size_t)bs.park_slot[(size_t)b * KS + k] * SS;
-        const int lrow = b * KS + k, n_rows = B * KS;
-        for (int i = tid; i < LH; i += 256) {
-            const int l = i / H, u = i - l * H;
-            dst[i] = st.h[((size_t)l * n_rows + lrow) * H + u];
-            dst[LH + i] = st.c[((size_t)l * n_rows + lrow) * H + u];
+    {
+        const int n_rows = B * KS, per = 2 * LH + J;
+        for (int i = tid; i < npark * per; i += 256) {
+            const int k = i / per, e = i - k * per;
+            const int lrow = b * KS + k;
+            float v;
+            if (e < 2 * LH) {
+                const int which = e >= LH, q = e - which * LH, l = q / H, u = q - l * H;
+                v = (which ? st.c : st.h)[((size_t)l * n_rows + lrow) * H + u];
+            } else {
+                v = st.g[(size_t)lrow * J + (e - 2 * LH)];
+            }
+            pool[(size_t)bs.park_slot[(size_t)b * KS + k] * SS + e] = v;
         }
-        for (int i = tid; i < J; i += 256) dst[2 * LH + i] = st.g[(size_t)lrow * J + i];
     }
     if (tid == 0) { sc.cnt[0] = 0; sc.cnt[1] = 0; }
     __syncthreads();
@@ -651,7 +673,7 @@ BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam, int beam_k, int tp_max, i
     if (R > 64) R = 64;
     if (R > max_pops) R = max_pops;
     p.R = R;
-    int KS = 4;                                                      // evaluations asked for per iteration (the first is needed, the rest are guesses)
+    int KS = 3;                                                      // evaluations asked for per iteration (the first is needed, the rest are guesses)
     if (const char* e = getenv("RS_BEAM_SPEC")) KS = atoi(e);
     p.KS = KS < 1 ? 1 : KS > 8 ? 8 : KS;
     p.RP = R + 32 + 1;                                               // batch + guesses of a frame + the needed one

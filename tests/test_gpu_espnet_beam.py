@@ -80,7 +80,7 @@ def test_tiny_bit_exact(tiny, beam):
 
 @pytest.mark.parametrize("ks", ["1", "2", "8"])
 def test_guesses_do_not_change_results(tiny, monkeypatch, ks):
-    """how many expansions are asked for ahead of need per iteration ($RS_BEAM_SPEC, default 4) is a scheduling matter"""
+    """how many expansions are asked for ahead of need per iteration ($RS_BEAM_SPEC, default 3) is a scheduling matter"""
     model, sd, buf = tiny
     want = device_beam(model, buf, 10)
     monkeypatch.setenv("RS_BEAM_SPEC", ks)
