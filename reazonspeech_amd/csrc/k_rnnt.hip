@@ -157,6 +157,8 @@ __global__ __launch_bounds__(1024) void rnnt_lstm_kernel(DecodeState st, int lay
 // MODE 1: joint logits  W_o . relu(f[b][t_b] + g[b]) + b_o over the `alive` rows, per-tile argmax
 // MODE 3: MODE 2 with row r's prediction vector at st.g + st.g_off[r] (the default beam search, k_rnnt_beam.hip: the vectors
 //         stay where they are cached)
+// MODE 5: MODE 1 with look-ahead (greedy search on small batches): an alive utterance brings rows_per_utt rows, its frames
+//         t .. t + rows_per_utt - 1 under the prediction vector it has now; pmax / pidx rows are utterance * rows_per_utt + j
 // MODE 4: MODE 3 with the activated rows act(f + g) precomputed in st.a_pre [row][K] (with a tanh joint every one of the
 //         ceil(V / 64) column tiles recomputed the same 32 x K tanh values, about as many VALU cycles as the tile's MFMA cycles)
 // MODE 2: the same logits written out in full (beam search, k_rnnt_alsd.hip): rows are hypotheses, `rows_per_utt`
@@ -172,8 +174,12 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
     int rt = blockIdx.y;
     const int ct = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr bool WALK = MODE == 3 || MODE == 4;       // strides over the row tiles
+    constexpr bool ARGMAX = MODE == 1 || MODE == 5;     // per-tile argmax instead of logits
     const int32_t* list = MODE == 0 ? st.act : st.alive + (size_t)(step & 1) * B;
-    const int n_rows = MODE == 0 ? st.counters[0] : st.counters[2 + (step & 1)];
+    // MODE 5: every alive utterance contributes `rows_per_utt` rows, its next frames t, t + 1, ... under the SAME prediction vector
+    const int la = MODE == 5 ? rows_per_utt : 1;
+    const int n_rows = MODE == 0 ? st.counters[0] : st.counters[2 + (step & 1)] * la;
     if (MODE >= 1 && rt == 0 && ct == 0 && tid == 0) {   // lists that this step's finalize will build
         st.counters[0] = 0;
         st.counters[2 + ((step + 1) & 1)] = 0;
@@ -188,8 +194,9 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
     for (;; rt += gridDim.y) {
     if (rt * 32 >= n_rows) return;
     if (tid < 32) {
-        const int i = rt * 32 + tid;
-        rows_s[tid] = list[i < n_rows ? i : n_rows - 1];
+        int i = rt * 32 + tid;
+        i = i < n_rows ? i : n_rows - 1;
+        rows_s[tid] = MODE == 5 ? list[i / la] * la + i % la : list[i];
     }
     __syncthreads();
     const int li = lane & 15, kk = lane >> 4;
@@ -207,6 +214,12 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
             if (MODE == 4) {
                 asrc[ri] = st.a_pre + (size_t)row * K;
                 gsrc[ri] = nullptr;
+            } else if (MODE == 5) {
+                const int utt = row / la;
+                int t = st.tcur[utt] + row % la;                 // (frames past the utterance's end are computed and ignored)
+                t = t < Tp ? t : Tp - 1;
+                asrc[ri] = f + ((size_t)utt * Tp + t) * K;
+                gsrc[ri] = st.g + (size_t)utt * K;
             } else {
                 int t = st.tcur[row];
                 t = t < Tp ? t : Tp - 1;
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
     for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) acc[ri][cj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    constexpr bool HAS_G = MODE >= 1 && MODE <= 3;          // MODE 4 reads rows that are already act(f + g)
+    constexpr bool HAS_G = (MODE >= 1 && MODE <= 3) || MODE == 5;          // MODE 4 reads rows that are already act(f + g)
     struct Frag { float4 a[2], g[2], w[4]; };
     auto load = [&](int k0) {
         Frag fr;
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
             for (int r = 0; r < 4; ++r) part[wave][ri * 16 + 4 * kk + r][cj * 16 + li] = acc[ri][cj][r];
     __syncthreads();
     // thread = (row i, 8 consecutive columns); waves 4..7 are done
-    if (tid >= 256) { if (MODE >= 3) { __syncthreads(); continue; } return; }
+    if (tid >= 256) { if (WALK) { __syncthreads(); continue; } return; }
     const int i = tid >> 3, c0 = (tid & 7) * 8;
     const bool row_ok = rt * 32 + i < n_rows;
     const int brow = rows_s[i];
@@ -303,11 +316,11 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
         if (v < N) {
             s = s + bias[v];
             if (MODE == 0) { if (row_ok) st.g[(size_t)brow * N + v] = s; }
-            else if (MODE >= 2) { if (row_ok) st.zapprox[(size_t)brow * (64 * n_ctiles) + v] = s; }
+            else if (!ARGMAX) { if (row_ok) st.zapprox[(size_t)brow * (64 * n_ctiles) + v] = s; }
             else if (s > best) { best = s; best_idx = v; }
         }
     }
-    if (MODE == 1) {
+    if (ARGMAX) {
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {   // the 8 lanes of a row are adjacent
             const float ov = __shfl_xor(best, off, 64);
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(512) void rnnt_tile_kernel(DecodeState st, const fl
                     st.c[o] = st.c_tmp[o];
                 }
     }
-    if (MODE < 3) return;
+    if (!WALK) return;
     __syncthreads();                                     // `part` / `rows_s` are rewritten by the next row tile
     }
 }
@@ -382,6 +395,58 @@ __global__ __launch_bounds__(256) void rnnt_finalize_kernel(DecodeState st, cons
 }
 
 
+
+// ---- finalize with look-ahead (rnnt_tile_kernel<5>): frames t, t + 1, ... of an utterance were scored under the prediction
+// vector it has now.  Blank at a frame means the vector is unchanged at the next one, so its row is exactly what the frame-by-
+// frame loop would have computed: the rows are consumed in order up to and including the first label (whose successors are
+// discarded: the vector changes).  Same ids and frames as one frame per step, in up to `la` times fewer steps. ----
+__global__ __launch_bounds__(256) void rnnt_finalize_la_kernel(DecodeState st, const int32_t* __restrict__ enc_lens, int B, int n_ctiles,
+                                                               int blank, int max_symbols, int u_max, int step, int la,
+                                                               int32_t* __restrict__ ids, int32_t* __restrict__ frames,
+                                                               int32_t* __restrict__ n_ids) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_alive = st.counters[2 + (step & 1)];
+    if (slot >= n_alive) return;
+    const int b = st.alive[(size_t)(step & 1) * B + slot];
+    const int T = enc_lens[b];
+    int t = st.tcur[b], sy = st.sym[b];
+    bool emitted = false;
+    for (int j = 0; j < la && t < T; ++j) {
+        float val = -INFINITY;
+        int idx = 0x7fffffff;
+        const size_t row = (size_t)b * la + j;
+        for (int ctile = lane; ctile < n_ctiles; ctile += 64) {
+            const float ov = st.pmax[row * n_ctiles + ctile];
+            const int oi = st.pidx[row * n_ctiles + ctile];
+            if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(val, off, 64);
+            const int oi = __shfl_xor(idx, off, 64);
+            if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+        }
+        if (idx == blank || idx == 0x7fffffff) { t += 1; sy = 0; continue; }
+        if (lane == 0) {
+            const int n = n_ids[b];
+            if (n < u_max) { ids[(size_t)b * u_max + n] = idx; frames[(size_t)b * u_max + n] = t; n_ids[b] = n + 1; }
+            else st.counters[1] = 1;
+            st.token[b] = idx;
+        }
+        emitted = true;
+        sy += 1;
+        if (sy >= max_symbols) { t += 1; sy = 0; }
+        break;
+    }
+    if (lane != 0) return;
+    st.tcur[b] = t; st.sym[b] = sy;
+    if (t < T) {
+        const int pos = atomicAdd(&st.counters[2 + ((step + 1) & 1)], 1);
+        st.alive[(size_t)((step + 1) & 1) * B + pos] = b;
+        if (emitted) { const int pa = atomicAdd(&st.counters[0], 1); st.act[pa] = b; }
+    }
+}
 
 // ---- narrow-tile variants (the default) -----------------------------------------------------------------------
 // A decode step's LSTM / projection work is tiny (~0.2 GFLOP per layer at 32 emitting rows); what a batch pays is
@@ -793,7 +858,8 @@ int ensure_decode_lds(rs_ctx* ctx) {
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<1>, TILE_LDS); rc != RS_OK) return rc;
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<2>, TILE_LDS); rc != RS_OK) return rc;
     if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<3>, TILE_LDS); rc != RS_OK) return rc;
-    return rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<4>, TILE_LDS);
+    if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<4>, TILE_LDS); rc != RS_OK) return rc;
+    return rs_ensure_dynamic_lds(ctx, (const void*)rnnt_tile_kernel<5>, TILE_LDS);
 }
 
 }  // namespace
@@ -835,6 +901,9 @@ int rs_rnnt_launch_joint_logits_indirect(rs_ctx* ctx, const void* st_ptr, const 
 }
 
 // --------------------------------------------------------------------------------------------------
+// frames an utterance may look ahead per greedy step (rnnt_tile_kernel<5>): the pmax / pidx scratch is sized for it
+constexpr int LOOKAHEAD_MAX = 8;
+
 size_t rs_rnnt_workspace_bytes(const rs_ctx* ctx, int B) {
     const rs_dims& d = ctx->d;
     const int L = d.pred_layers, H = d.pred_hidden, J = d.joint_hidden;
@@ -844,7 +913,7 @@ size_t rs_rnnt_workspace_bytes(const rs_ctx* ctx, int B) {
     n += rs_align((size_t)B * J * 4);
     n += 6 * rs_align((size_t)B * 4);
     n += rs_align(64);
-    n += 2 * rs_align((size_t)B * nct * 4);
+    n += 2 * rs_align((size_t)B * LOOKAHEAD_MAX * nct * 4);
     const size_t vpad = (size_t)(d.n_logits + 15) / 16 * 16;
     n += rs_align((size_t)B * J * 2) + rs_align((size_t)B * 4) + rs_align((size_t)B * vpad * 4);   // screened joint
     return n + 1024;
@@ -873,7 +942,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     st.token = (int32_t*)take((size_t)B * 4); st.act = (int32_t*)take((size_t)B * 4);
     st.alive = (int32_t*)take((size_t)2 * B * 4);
     st.counters = (int32_t*)take(64);
-    st.pmax = (float*)take((size_t)B * nct * 4); st.pidx = (int32_t*)take((size_t)B * nct * 4);
+    st.pmax = (float*)take((size_t)B * LOOKAHEAD_MAX * nct * 4); st.pidx = (int32_t*)take((size_t)B * LOOKAHEAD_MAX * nct * 4);
     const int Vpad = (V + 15) / 16 * 16;
     st.a16 = (uint16_t*)take((size_t)B * J * 2); st.anorm = (float*)take((size_t)B * 4);
     st.zapprox = (float*)take((size_t)B * Vpad * 4);
@@ -901,6 +970,8 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     // utterance — decode 3.7 - 3.8 ms against 2.9 - 3.4 ms of plain launches, -1 ... -2 ms only on 20 - 30 s utterances
     // and 40 ms for the first capture of a geometry — profiles/r03x_decode_graph_b1_ab.txt: not kept.)
     const int CHUNK = 16;
+    static const bool no_lookahead = getenv("RS_DECODE_NO_LOOKAHEAD") != nullptr;   // A/B hook
+    const bool lookahead = !no_lookahead;
     int32_t host_counters[4] = {0, 0, 0, 0};
     int steps = 0, alive_bound = B;
     bool finished = false;
@@ -924,11 +995,24 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
             } else {
                 // both kernels walk the compacted alive list: only the row tiles / slots the bound covers are launched
                 // (next to the encoder every workgroup, even one that exits at once, has to wait for a free CU)
-                const int rts = (rows + 31) / 32 > 0 ? (rows + 31) / 32 : 1;
-                hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(joint_grid_x(nct, rts), rts), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H, J,
-                                   V, ctx->jout_w, ctx->jout_b, nct, steps, 1);
-                hipLaunchKernelGGL(rnnt_finalize_kernel, dim3((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1), dim3(256), 0, s, st, enc_lens, B, nct,
-                                   d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
+                // few rows leave the chip idle: each utterance then scores its next `la` frames in the same launch (look-ahead:
+                // blank keeps the prediction vector, so those rows are what the next steps would compute) and a step consumes
+                // them up to the first label — up to la times fewer steps, same output.  la x rows stays within 256 joint rows.
+                int la = 1;
+                if (lookahead) while (la < LOOKAHEAD_MAX && 2 * la * (rows > 0 ? rows : 1) <= 256) la *= 2;
+                if (la > 1) {
+                    const int rts = (rows * la + 31) / 32 > 0 ? (rows * la + 31) / 32 : 1;
+                    hipLaunchKernelGGL(rnnt_tile_kernel<5>, dim3(joint_grid_x(nct, rts), rts), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H,
+                                       J, V, ctx->jout_w, ctx->jout_b, nct, steps, la);
+                    hipLaunchKernelGGL(rnnt_finalize_la_kernel, dim3((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1), dim3(256), 0, s, st, enc_lens, B, nct,
+                                       d.blank_id, d.max_symbols, u_max, steps, la, ids, frames, n_ids);
+                } else {
+                    const int rts = (rows + 31) / 32 > 0 ? (rows + 31) / 32 : 1;
+                    hipLaunchKernelGGL(rnnt_tile_kernel<1>, dim3(joint_grid_x(nct, rts), rts), dim3(512), TILE_LDS, s, st, joint_enc, B, tp_max, L, H,
+                                       J, V, ctx->jout_w, ctx->jout_b, nct, steps, 1);
+                    hipLaunchKernelGGL(rnnt_finalize_kernel, dim3((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1), dim3(256), 0, s, st, enc_lens, B, nct,
+                                       d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
+                }
             }
             lstm_and_pred(rows);
         }
