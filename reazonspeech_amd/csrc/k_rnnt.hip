@@ -18,6 +18,7 @@
 // Work lists keep the step cost proportional to the rows that still need it: the joint runs over
 // the rows still decoding (`alive`), the LSTM over the rows that just emitted a non-blank (`act`).
 // Tiles are [32 rows] x [64 columns] so that operands fetched from L2 are reused 2-4x in registers.
+#include <cstdio>
 #include <cstdlib>
 
 #include "k_rnnt_common.h"
@@ -970,8 +971,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     // utterance — decode 3.7 - 3.8 ms against 2.9 - 3.4 ms of plain launches, -1 ... -2 ms only on 20 - 30 s utterances
     // and 40 ms for the first capture of a geometry — profiles/r03x_decode_graph_b1_ab.txt: not kept.)
     const int CHUNK = 16;
-    static const bool no_lookahead = getenv("RS_DECODE_NO_LOOKAHEAD") != nullptr;   // A/B hook
-    const bool lookahead = !no_lookahead;
+    const bool lookahead = getenv("RS_DECODE_NO_LOOKAHEAD") == nullptr;   // A/B and test hook
     int32_t host_counters[4] = {0, 0, 0, 0};
     int steps = 0, alive_bound = B;
     bool finished = false;
@@ -1023,6 +1023,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
         alive_bound = host_counters[2 + (steps & 1)];
     }
     rs_prof_end(ctx, RS_PROF_DECODE, s);
+    if (getenv("RS_DECODE_TRACE")) fprintf(stderr, "[decode trace] B=%d T'=%d: %d steps (screen %d, narrow %d, lookahead %d)\n", B, tp_max, steps, (int)screen, (int)narrow, (int)lookahead);
     if (host_counters[1]) return rs_fail(ctx, RS_EOVERFLOW, "rnnt: an utterance emitted more than u_max=%d tokens", u_max);
     if (!finished) return rs_fail(ctx, RS_ESTATE, "rnnt: decode did not finish in %d steps", max_steps);
     return RS_OK;

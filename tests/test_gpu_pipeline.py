@@ -119,18 +119,22 @@ def test_decode_bit_exact_given_same_encoder_output(tiny, gold):
     assert got.frames == [r[1] for r in ref]
 
 
-def test_decode_bit_exact_many_utterances(gpu_device):
+@pytest.mark.parametrize("lookahead,B", [(True, 37), (False, 37), (True, 3), (True, 150)])
+def test_decode_bit_exact_many_utterances(gpu_device, monkeypatch, lookahead, B):
     """synthetic joint-encoder tensors straight into rs_rnnt_greedy: ragged lengths, an empty
-    utterance, a batch that is not a multiple of the 16-row tile"""
+    utterance, a batch that is not a multiple of the 16-row tile.  Small batches score several frames per utterance and step
+    (look-ahead: 37 rows -> 4 frames, 3 rows -> 8, 150 rows -> 1 until the tail); $RS_DECODE_NO_LOOKAHEAD is the plain loop."""
+    if not lookahead:
+        monkeypatch.setenv("RS_DECODE_NO_LOOKAHEAD", "1")
     cfg = TINY
     sd = synthetic_state_dict(cfg, 11, blank_bias=4.0)
     model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device="cuda:0")
     g = torch.Generator().manual_seed(2)
-    B, Tp = 37, 45
+    Tp = 45
     f = torch.randn((B, Tp, cfg.joint_hidden), generator=g) * 1.5
     lens = torch.randint(1, Tp + 1, (B,), generator=g, dtype=torch.int32)
-    lens[3] = 0
-    lens[5] = Tp
+    lens[B // 2] = 0
+    lens[B - 1] = Tp
     u_max = Tp * cfg.max_symbols
     dev = model.device
     ids = torch.zeros((B, u_max), dtype=torch.int32, device=dev)
@@ -142,7 +146,7 @@ def test_decode_bit_exact_many_utterances(gpu_device):
     torch.cuda.synchronize()
     ref = og.rnnt_greedy(cfg, sd, f.numpy(), lens.numpy())
     n = n_ids.cpu().numpy()
-    assert sum(len(r[0]) for r in ref) > 50, "test inputs should emit tokens"
+    assert sum(len(r[0]) for r in ref) > B, "test inputs should emit tokens"
     for b in range(B):
         assert ids[b, :n[b]].cpu().tolist() == ref[b][0], b
         assert frames[b, :n[b]].cpu().tolist() == ref[b][1], b
