@@ -373,14 +373,17 @@ def from_nemo_yaml(cfg: dict, strict: bool = True) -> ModelConfig:
         need(str(prednet.get("rnn_type", "lstm") or "lstm").lower() == "lstm" if "rnn_type" in prednet else True, "a non-LSTM prediction network")
     strategy = str(decoding.get("strategy", "greedy_batch"))
     beam = decoding.get("beam", {}) or {}
-    if strategy not in ("greedy", "greedy_batch", "alsd"):
-        warnings.warn(f"checkpoint decoding.strategy={strategy!r}: only greedy and alsd are implemented; decoding greedily "
+    if strategy not in ("greedy", "greedy_batch", "alsd", "beam"):
+        warnings.warn(f"checkpoint decoding.strategy={strategy!r}: only greedy, alsd and beam (the default beam search) are implemented; decoding greedily "
                       "(batched greedy RNN-T), transcripts can differ from the reference's beam search", RuntimeWarning,
                       stacklevel=2)
         strategy = "greedy_batch"
     beam_size = int(beam.get("beam_size", 4) or 4)
     if strategy == "alsd" and not 1 <= beam_size <= 8:
         raise UnsupportedCheckpoint(f"decoding.beam.beam_size={beam_size}: the device beam search keeps 1..8 hypotheses")
+    if strategy == "beam" and not 1 <= beam_size <= 64:
+        # [UPSTREAM] BeamRNNTInfer.default_beam_search is the same Graves search ESPnet implements (k_rnnt_beam.hip)
+        raise UnsupportedCheckpoint(f"decoding.beam.beam_size={beam_size}: the device default beam search keeps 1..64 hypotheses")
     max_target = beam.get("alsd_max_target_len", 2.0)
     max_target = 2.0 if max_target is None else (int(max_target) if isinstance(max_target, int) else float(max_target))
     guard = pre.get("log_zero_guard_value", 2.0 ** -24)
@@ -414,7 +417,7 @@ def from_nemo_yaml(cfg: dict, strict: bool = True) -> ModelConfig:
         joint_hidden=int(jn.get("joint_hidden", 640)),
         max_symbols=int(greedy.get("max_symbols", greedy.get("max_symbols_per_step", 10)) or 10),
         decoding=strategy,
-        beam_size=min(max(beam_size, 1), 8),
+        beam_size=min(max(beam_size, 1), 64 if strategy == "beam" else 8),
         alsd_max_target_len=max_target,
         beam_score_norm=bool(beam.get("score_norm", True)),
     ).validate()

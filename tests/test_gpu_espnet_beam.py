@@ -157,3 +157,39 @@ def test_120m_one_utterance_bit_exact(gpu_device):
                           out_cap=2 * buf.tp_max + 16)
     assert got == [(w[0], float(np.float32(w[1])), w[2]) for w in want]
     print("120M beam-20 pops per frame:", [g[2] / max(1, int(t)) for g, t in zip(got, buf.enc_lens.cpu())], "labels", [len(g[0]) for g in got])
+
+
+def test_nemo_family_two_lstm_layers_blank_last(gpu_device):
+    """the same search over the NeMo-shaped decoder (`decoding.strategy: beam` is NeMo's default_beam_search, the same Graves
+    algorithm): ReLU joint with a prediction bias, TWO LSTM layers, blank as the LAST index — against oracle/espnet_beam.c"""
+    from reazonspeech_amd.runtime.config import TINY
+    from reazonspeech_amd.runtime.weights import synthetic_state_dict
+    from reazonspeech_amd.runtime.tokenizer import SyntheticTokenizer
+    from reazonspeech_amd.runtime.model import AsrModel
+    cfg = TINY.with_(decoding="beam", beam_size=6)
+    sd = synthetic_state_dict(cfg, 11, blank_bias=6.0)
+    model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device="cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, Tp = 5, 30
+    f = torch.randn((B, Tp, cfg.joint_hidden), generator=g) * 1.2
+    lens = np.asarray([30, 17, 1, 0, 25], np.int32)
+    dev = model.device
+    cap = 2 * Tp + 16
+    ids = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    n_ids = torch.zeros((B,), dtype=torch.int32, device=dev)
+    scores = torch.zeros((B,), dtype=torch.float32, device=dev)
+    pops = torch.zeros((B,), dtype=torch.int32, device=dev)
+    ws = torch.empty((model.ctx.beam_workspace_bytes(B, 6, Tp, 600),), dtype=torch.uint8, device=dev)
+    try:
+        model.ctx.rnnt_beam(f.to(dev), torch.from_numpy(lens).to(dev), B, Tp, 6, True, 600, ids, n_ids, scores, pops, ws,
+                            torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = [(ids[b, :int(n_ids[b])].cpu().tolist(), float(scores[b]), int(pops[b])) for b in range(B)]
+        want = og.espnet_beam(cfg, sd, f.numpy(), lens, beam=6, max_pops=600, out_cap=cap)
+    except RuntimeError as e:            # an untrained joint that never settles: the overflow must be the oracle's too
+        assert "max_pops" in str(e)
+        with pytest.raises(RuntimeError):
+            og.espnet_beam(cfg, sd, f.numpy(), lens, beam=6, max_pops=600, out_cap=cap)
+        pytest.skip("this synthetic decoder does not settle within max_pops (both sides agree)")
+    assert got == [(w[0], float(np.float32(w[1])), w[2]) for w in want]
+    assert sum(len(g_[0]) for g_ in got) > 0

@@ -572,3 +572,18 @@ def test_strict_loader_on_nemo_published_fastconformer_xl_config():
     d = copy.deepcopy(doc)
     d["preprocessor"].pop("window_size"); d["preprocessor"]["n_window_size"] = 400
     assert from_nemo_yaml(d).win_length == 400
+
+
+def test_beam_decoding_config():
+    """decoding = "beam" (the default transducer beam search): allowed for both families, beam 1..64, label cap, scores"""
+    from reazonspeech_amd.runtime.config import ESPNET_TINY, TINY
+    c = ESPNET_TINY.with_(decoding="beam", beam_size=20).validate()
+    assert c.has_scores and c.label_cap(100) == 216
+    assert TINY.with_(decoding="beam", beam_size=64).validate().has_scores
+    assert not TINY.validate().has_scores and TINY.label_cap(100) == 100 * TINY.max_symbols
+    with pytest.raises(AssertionError):
+        TINY.with_(decoding="beam", beam_size=65).validate()
+    with pytest.raises(AssertionError):
+        ESPNET_TINY.with_(decoding="alsd").validate()
+    with pytest.raises(AssertionError):
+        TINY.with_(decoding="beam", beam_size=8, beam_max_pops=4).validate()
