@@ -7,7 +7,7 @@
 //                        log-mel map -> bf16 channels-last [Bc][T1][F1][C]  (f32 VALU, 9 taps per output)
 //   im2col3x3s2_kernel   the patches of Conv2d(C, C, 3, 2) gathered row-major [Bc*T2*F2][9*C], K ordered (kernel row, kernel
 //                        column, channel): the dense conv then is ONE k_gemm_bf16 launch (M x C x 9C, bias + ReLU + row
-//                        mask in its epilogue).  Pure 16-byte copies, HBM-bound.  The encoder runs the two kernels and
+//                        mask in its epilogue).  Pure 16-byte copies, HBM-bound, one workgroup per output position.  The encoder runs the two kernels and
 //                        the GEMM over chunks of utterances so that the patch matrix stays around 1 GB.
 //   ctc_softmax_kernel   [UPSTREAM] CTC.softmax: row softmax of the ctc_lo logits in place (probabilities, not logs: what the
 //                        reference hands to its blank finder and to ctc_segmentation), plus the blank column on its own
@@ -49,16 +49,22 @@ __global__ __launch_bounds__(256) void sub2d_conv0_kernel(const float* __restric
     }
 }
 
-// one wave per (output position, kernel tap): copies C bf16 channels (16 bytes per lane, C / 8 lanes busy per pass)
-// grid (9, F2, Bc * T2), block 64
-__global__ __launch_bounds__(64) void im2col3x3s2_kernel(const uint16_t* __restrict__ in /* [Bc][T1][F1][C] */, int T1, int F1,
-                                                         int T2, int F2, int C, uint16_t* __restrict__ out /* [Bc*T2*F2][9*C] */) {
-    const int tap = blockIdx.x, f2 = blockIdx.y, bt = blockIdx.z;
+// one workgroup per output position (t2, f2): the 9 taps x C channels of its patch are 9 contiguous runs of C bf16 in the input
+// and ONE contiguous run of 9 C in the output; a thread moves 16 bytes at a time (9 C / 8 = 576 moves at C = 512).
+// (One 64-thread workgroup per tap — 1 KB each, 766k workgroups per chunk — was dispatch-bound: 417 us per chunk for 1.2 GB.)
+// grid (F2, Bc * T2), block 256
+__global__ __launch_bounds__(256) void im2col3x3s2_kernel(const uint16_t* __restrict__ in /* [Bc][T1][F1][C] */, int T1, int F1,
+                                                          int T2, int F2, int C, uint16_t* __restrict__ out /* [Bc*T2*F2][9*C] */) {
+    const int f2 = blockIdx.x, bt = blockIdx.y;
     const int bl = bt / T2, t2 = bt - bl * T2;
-    const int i = tap / 3, j = tap - 3 * i;
-    const uint4* src = reinterpret_cast<const uint4*>(in + (((size_t)bl * T1 + 2 * t2 + i) * F1 + 2 * f2 + j) * C);
-    uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)bt * F2 + f2) * 9 * C + (size_t)tap * C);
-    for (int q = threadIdx.x; q < C / 8; q += 64) dst[q] = src[q];
+    const int c8 = C / 8;
+    uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)bt * F2 + f2) * 9 * C);
+    const uint16_t* base = in + (((size_t)bl * T1 + 2 * t2) * F1 + 2 * f2) * C;
+    for (int q = threadIdx.x; q < 9 * c8; q += 256) {
+        const int tap = q / c8, c = q - tap * c8;
+        const int i = tap / 3, j = tap - 3 * i;
+        dst[q] = reinterpret_cast<const uint4*>(base + ((size_t)i * F1 + j) * C)[c];
+    }
 }
 
 // row softmax in place, one wave per row; blank_out[row] = p[row][blank] (may be null)
@@ -99,9 +105,9 @@ int rs_launch_sub2d_conv0(rs_ctx* ctx, const float* feats, const int32_t* lens1,
 int rs_launch_im2col3x3s2(rs_ctx* ctx, const uint16_t* in, int Bc, int T1, int F1, int T2, int F2, uint16_t* out, hipStream_t s) {
     const int C = ctx->d.sub_channels;
     if (C % 8) return rs_fail(ctx, RS_EINVAL, "im2col: channels %d must be a multiple of 8", C);
-    if ((long long)Bc * T2 > 65535LL || F2 > 65535) return rs_fail(ctx, RS_EINVAL, "im2col: chunk of %d x %d rows exceeds the grid", Bc, T2);
+    if ((long long)Bc * T2 > 65535LL) return rs_fail(ctx, RS_EINVAL, "im2col: chunk of %d x %d rows exceeds the grid", Bc, T2);
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, (double)Bc * T2 * F2 * 9.0 * C * 2.0 * 2.0);
-    hipLaunchKernelGGL(im2col3x3s2_kernel, dim3(9, F2, Bc * T2), dim3(64), 0, s, in, T1, F1, T2, F2, C, out);
+    hipLaunchKernelGGL(im2col3x3s2_kernel, dim3(F2, Bc * T2), dim3(256), 0, s, in, T1, F1, T2, F2, C, out);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
     RS_CHECK_LAUNCH(ctx, "im2col3x3s2");
     return RS_OK;
