@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 3
+#define RS_ABI_VERSION 4
 
 enum {
     RS_OK = 0,

@@ -125,7 +125,7 @@ def load():
     lib.rs_relpos_attention_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp]
     lib.rs_glu_dwconv_silu_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
     lib.rs_encoder_set_ctc_out.argtypes = [vp, vp, vp]
-    if lib.rs_abi_version() != 3:
+    if lib.rs_abi_version() != 4:
         raise ImportError("librs_asr.so ABI version mismatch")
     _lib = lib
     return lib
