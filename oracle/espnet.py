@@ -180,17 +180,28 @@ def default_beam_search_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor, beam
     (the state is a function of the label sequence).  -> [(ids, score, pops)] per utterance.  The bit-exact checker of the HIP
     search is oracle/espnet_beam.c (float32 sums, fixed order); tests/test_oracle_espnet_beam.py compares the two."""
     H, V, blank = cfg.pred_hidden, cfg.n_logits, cfg.blank_id
-    assert blank == 0
+    nemo = not getattr(cfg, "espnet", False)
+    # the same search over a NeMo-shaped decoder ([UPSTREAM] BeamRNNTInfer.default_beam_search, `decoding.strategy: beam`): blank
+    # is the LAST index there (top-k over logp[ids], ids = every index but blank), the joint is ReLU with a prediction bias
     lstms = []
     for l in range(cfg.pred_layers):
         m = torch.nn.LSTM(H, H, 1, batch_first=True)
         with torch.no_grad():
-            for nm in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
-                getattr(m, nm).copy_(sd[f"decoder.decoder.{l}." + nm])
+            for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                src = sd[f"decoder.prediction.dec_rnn.lstm.{nm}_l{l}"] if nemo else sd[f"decoder.decoder.{l}.{nm}_l0"]
+                getattr(m, nm + "_l0").copy_(src)
         lstms.append(m)
-    emb = sd["decoder.embed.weight"]
-    wd = sd["joint_network.lin_dec.weight"]
-    wo, bo = sd["joint_network.lin_out.weight"], sd["joint_network.lin_out.bias"]
+    if nemo:
+        emb = sd["decoder.prediction.embed.weight"]
+        wd, bd = sd["joint.pred.weight"], sd["joint.pred.bias"]
+        wo, bo = sd["joint.joint_net.2.weight"], sd["joint.joint_net.2.bias"]
+        act = torch.relu
+    else:
+        emb = sd["decoder.embed.weight"]
+        wd, bd = sd["joint_network.lin_dec.weight"], 0.0
+        wo, bo = sd["joint_network.lin_out.weight"], sd["joint_network.lin_out.bias"]
+        act = torch.tanh
+    labels = torch.tensor([v for v in range(V) if v != blank])
     beam = min(beam_size, V)
     beam_k = min(beam, V - 1)
 
@@ -200,7 +211,7 @@ def default_beam_search_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor, beam
         for l, m in enumerate(lstms):
             x, st = m(x, hyp["state"][l])
             new.append(st)
-        return x[0, 0] @ wd.t(), new
+        return x[0, 0] @ wd.t() + bd, new
 
     out = []
     with torch.no_grad():
@@ -215,11 +226,11 @@ def default_beam_search_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor, beam
                     hyps.remove(max_hyp)
                     pops += 1
                     dec_out, state = score_fn(max_hyp)
-                    logp = torch.log_softmax(torch.tanh(f[b, t] + dec_out) @ wo.t() + bo, dim=-1)
-                    top = logp[1:].topk(beam_k)
-                    kept.append(dict(score=max_hyp["score"] + float(logp[0]), yseq=max_hyp["yseq"][:], state=max_hyp["state"]))
+                    logp = torch.log_softmax(act(f[b, t] + dec_out) @ wo.t() + bo, dim=-1)
+                    top = logp[labels].topk(beam_k)                  # (upstream: logp[1:] with blank = 0)
+                    kept.append(dict(score=max_hyp["score"] + float(logp[blank]), yseq=max_hyp["yseq"][:], state=max_hyp["state"]))
                     for lp, k in zip(*top):
-                        hyps.append(dict(score=max_hyp["score"] + float(lp), yseq=max_hyp["yseq"][:] + [int(k) + 1], state=state))
+                        hyps.append(dict(score=max_hyp["score"] + float(lp), yseq=max_hyp["yseq"][:] + [int(labels[k])], state=state))
                     hyps_max = float(max(hyps, key=lambda h: h["score"])["score"])
                     most = sorted([h for h in kept if h["score"] > hyps_max], key=lambda h: h["score"])
                     if len(most) >= beam:

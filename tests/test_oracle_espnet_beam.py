@@ -61,3 +61,21 @@ def test_beam_one_is_not_greedy_but_close():
     b1 = og.espnet_beam(cfg, sd, f.numpy(), lens.numpy(), beam=1)
     gr = og.rnnt_greedy(cfg, sd, f.numpy(), lens.numpy())
     assert [x[0] for x in b1] == [x[0] for x in gr]
+
+
+def test_c_follows_torch_restatement_nemo_decoder():
+    """the NeMo-shaped decoder (`decoding.strategy: beam`): two LSTM layers, blank as the last index, ReLU joint with a
+    prediction bias — the C checker against the torch restatement on random joint-encoder projections"""
+    from reazonspeech_amd.runtime.config import TINY
+    from reazonspeech_amd.runtime.weights import synthetic_state_dict
+    cfg = TINY
+    sd = synthetic_state_dict(cfg, 11, blank_bias=6.0)
+    g = torch.Generator().manual_seed(3)
+    f = torch.randn((3, 14, cfg.joint_hidden), generator=g) * 1.2
+    lens = torch.tensor([14, 9, 0], dtype=torch.int32)
+    ref = oe.default_beam_search_torch(cfg, sd, f, lens, beam_size=5)
+    got = og.espnet_beam(cfg, sd, f.numpy(), lens.numpy(), beam=5, max_pops=400)
+    for (rid, rs, rp), (gid, gs, gp) in zip(ref, got):
+        assert gid == rid and gp == rp
+        assert abs(gs - rs) <= 1e-4 * max(1.0, abs(rs))
+    assert all(cfg.blank_id not in r[0] for r in ref)
