@@ -11,7 +11,7 @@
 #   pmc          four --pmc passes (sequential schedule)  -> <tag>_pmc_per_kernel.txt (scripts/pmc_to_traffic.py turns it into profiles/gemm_traffic.json)
 #   gemm=ARGS    scripts/gemm_bench.py ARGS (commas = spaces; e.g. gemm=0,--yardstick) -> <tag>_gemm.txt
 #   espnet=B     scripts/espnet_bench.py --batch=B        -> <tag>_espnet_bench.txt
-#   beam[=ARGS]  scripts/espnet_beam_bench.py ARGS (commas = spaces; default --bias=16,--beam=5,20) -> <tag>_beam_bench.txt;
+#   beam[=ARGS]  scripts/espnet_beam_bench.py ARGS ('+' = space; default --bias=16+--beam=5,20) -> <tag>_beam_bench.txt;
 #                with RS_BEAM_TRACE=1 in the environment the step kernel's phase times are appended
 #   ab:VAR=a,b   the bench with environment VAR set to a, then b (same box, interleaved twice) -> <tag>_ab_VAR.txt
 TAG=${1:?tag}; shift
@@ -48,8 +48,8 @@ for WHAT in "$@"; do
       B=${WHAT#espnet=}; [ "$B" == "espnet" ] && B=256
       timeout 600 python scripts/espnet_bench.py --batch=$B > gpurun_out/${TAG}_espnet_bench.txt 2>&1; cat gpurun_out/${TAG}_espnet_bench.txt ;;
     beam|beam=*)
-      A=${WHAT#beam=}; [ "$A" == "beam" ] && A="--bias=16,--beam=5,20"
-      timeout 600 python scripts/espnet_beam_bench.py ${A//,/ } > gpurun_out/${TAG}_beam_bench.txt 2>&1; grep -v amdgpu.ids gpurun_out/${TAG}_beam_bench.txt ;;
+      A=${WHAT#beam=}; [ "$A" == "beam" ] && A="--bias=16+--beam=5,20"
+      timeout 600 python scripts/espnet_beam_bench.py ${A//+/ } > gpurun_out/${TAG}_beam_bench.txt 2>&1; grep -v amdgpu.ids gpurun_out/${TAG}_beam_bench.txt ;;
     ab:*)
       SPEC=${WHAT#ab:}; VAR=${SPEC%%=*}; REST=${SPEC#*=}; VALS=${REST%%:*}; N=20; [[ "$REST" == *:* ]] && N=${REST##*:}
       : > gpurun_out/${TAG}_ab_${VAR}.txt
