@@ -259,6 +259,8 @@ int rs_rnnt_alsd(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, i
  *   max_pops   prediction-network evaluations allowed per frame (0 = 16 * beam).  Upstream has no bound; a trained model needs
  *              about `beam` to 2 * beam.  The workspace grows with it.
  *   ids    i32[B][out_cap]  labels of the best hypothesis (no leading blank),  n_ids i32[B],  scores f32[B] (log-probability)
+ *   frames i32[B][out_cap]  the encoder frame each label was appended at, or NULL ([UPSTREAM] NeMo keeps them as
+ *                           Hypothesis.timestep; ESPnet's hypotheses carry none — the espnet package times its segments by CTC)
  *   pops   i32[B]           prediction-network evaluations spent on utterance b
  * Workspace: rs_rnnt_beam_workspace_bytes(ctx, B, beam, tp_max, max_pops), separate from rs_workspace_bytes.
  * Synchronises the stream internally.  RS_EOVERFLOW if a frame needed more than max_pops pops or a result has more than out_cap
@@ -266,8 +268,8 @@ int rs_rnnt_alsd(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, i
 enum { RS_BEAM_SCORE_NORM = 1 };
 size_t rs_rnnt_beam_workspace_bytes(const rs_ctx* ctx, int B, int beam, int tp_max, int max_pops);
 int rs_rnnt_beam(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int beam, int flags,
-                 int max_pops, int out_cap, int32_t* ids, int32_t* n_ids, float* scores, int32_t* pops, void* workspace,
-                 size_t workspace_bytes, void* stream);
+                 int max_pops, int out_cap, int32_t* ids, int32_t* frames, int32_t* n_ids, float* scores, int32_t* pops,
+                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- profiling hooks for bench.py (roofline.achieved) ------------------------------------
  * When enabled, the launcher brackets every launch of the selected kernel class with HIP

@@ -155,7 +155,7 @@ def greedy_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor):
     return out
 
 
-def default_beam_search_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor, beam_size=20, score_norm=True):
+def default_beam_search_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor, beam_size=20, score_norm=True, with_frames=False):
     """[UPSTREAM] espnet2 BeamSearchTransducer.default_beam_search + sort_nbest (espnet 202308, no LM) — the decode
     reazonspeech.espnet.asr runs, since the reference builds Speech2Text with its defaults (beam_size 20, search_type
     "default", score_norm True, nbest 1: pkg/espnet-asr/src/transcribe.py:27-31).  Restated statement for statement:
@@ -217,7 +217,7 @@ def default_beam_search_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor, beam
     with torch.no_grad():
         for b in range(f.shape[0]):
             init = [(torch.zeros(1, 1, H), torch.zeros(1, 1, H)) for _ in lstms]
-            kept = [dict(score=0.0, yseq=[blank], state=init)]
+            kept = [dict(score=0.0, yseq=[blank], state=init, frames=[])]   # frames: [UPSTREAM] NeMo Hypothesis.timestep (ESPnet keeps none)
             pops = 0
             for t in range(int(lens[b])):
                 hyps, kept = kept, []
@@ -228,9 +228,9 @@ def default_beam_search_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor, beam
                     dec_out, state = score_fn(max_hyp)
                     logp = torch.log_softmax(act(f[b, t] + dec_out) @ wo.t() + bo, dim=-1)
                     top = logp[labels].topk(beam_k)                  # (upstream: logp[1:] with blank = 0)
-                    kept.append(dict(score=max_hyp["score"] + float(logp[blank]), yseq=max_hyp["yseq"][:], state=max_hyp["state"]))
+                    kept.append(dict(score=max_hyp["score"] + float(logp[blank]), yseq=max_hyp["yseq"][:], state=max_hyp["state"], frames=max_hyp["frames"]))
                     for lp, k in zip(*top):
-                        hyps.append(dict(score=max_hyp["score"] + float(lp), yseq=max_hyp["yseq"][:] + [int(labels[k])], state=state))
+                        hyps.append(dict(score=max_hyp["score"] + float(lp), yseq=max_hyp["yseq"][:] + [int(labels[k])], state=state, frames=max_hyp["frames"] + [t]))
                     hyps_max = float(max(hyps, key=lambda h: h["score"])["score"])
                     most = sorted([h for h in kept if h["score"] > hyps_max], key=lambda h: h["score"])
                     if len(most) >= beam:
@@ -240,5 +240,5 @@ def default_beam_search_torch(cfg, sd, f: torch.Tensor, lens: torch.Tensor, beam
                 kept = sorted(kept, key=lambda h: h["score"] / len(h["yseq"]), reverse=True)
             else:
                 kept = sorted(kept, key=lambda h: h["score"], reverse=True)
-            out.append((kept[0]["yseq"][1:], kept[0]["score"], pops))
+            out.append((kept[0]["yseq"][1:], kept[0]["frames"], kept[0]["score"], pops) if with_frames else (kept[0]["yseq"][1:], kept[0]["score"], pops))
     return out

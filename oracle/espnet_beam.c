@@ -3,7 +3,7 @@
  * the decode that reazonspeech.espnet.asr actually runs: the reference builds Speech2Text with its defaults
  * (pkg/espnet-asr/src/transcribe.py:27-31: only lm_weight=0 is overridden), i.e. beam_size 20, search_type "default",
  * score_norm True, nbest 1, no LM.  TEST INFRASTRUCTURE (see oracle/__init__.py): only tests/ use it, as the checker of
- * the HIP search (reazonspeech_amd/csrc/k_espnet_beam.hip).
+ * the HIP search (reazonspeech_amd/csrc/k_rnnt_beam.hip).
  *
  * PARITY UNPINNED against upstream: espnet2/asr/transducer/beam_search_transducer.py (BeamSearchTransducer.
  * default_beam_search, sort_nbest) is a third-party dependency that is absent here (pkg/espnet-asr/pyproject.toml:
@@ -52,7 +52,7 @@ typedef struct {
     int alive;
 } bhyp_t;
 
-typedef struct { int parent, tok; } node_t;
+typedef struct { int parent, tok, t; } node_t;   /* t: the frame at which the label was appended (its hypothesis was opened AND popped there) */
 
 typedef struct { float* v; int n, cap, width; } pool_t;     /* states: h [L][H] then c [L][H] */
 
@@ -67,12 +67,13 @@ static int pool_push(pool_t* p, const float* h, const float* c, int LH) {
 }
 
 /* f [B][Tp][J] (joint.enc output).  Outputs the best hypothesis per utterance: ids [B][out_cap] (without the leading
- * blank), n_ids [B], scores [B], and pops [B] = prediction-net evaluations spent (the work measure of the search).
- * Returns 0, or -5 on overflow (max_pops per frame / out_cap). */
+ * blank), frames [B][out_cap] (may be NULL: the frame each label was appended at — upstream ESPnet keeps none, [UPSTREAM] NeMo's
+ * default_beam_search keeps them as Hypothesis.timestep), n_ids [B], scores [B], and pops [B] = prediction-net evaluations spent
+ * (the work measure of the search).  Returns 0, or -5 on overflow (max_pops per frame / out_cap). */
 int rs_oracle_espnet_beam(const float* f, const int32_t* enc_lens, int B, int Tp, int J, int H, int L, int V, int blank,
                           const float* embed, const float* const* lstm_w, const float* const* lstm_b, const float* Wp,
                           const float* bp, const float* Wo, const float* bo, int beam, int score_norm, int max_pops,
-                          int out_cap, int32_t* ids, int32_t* n_ids, float* scores, int32_t* pops) {
+                          int out_cap, int32_t* ids, int32_t* frames, int32_t* n_ids, float* scores, int32_t* pops) {
     int overflow = 0;
     if (beam > V) beam = V;
     const int beam_k = beam < V - 1 ? beam : V - 1;
@@ -85,7 +86,7 @@ int rs_oracle_espnet_beam(const float* f, const int32_t* enc_lens, int B, int Tp
         const int T = enc_lens[b];
         int n_nodes = 1, cap_nodes = 1024;
         node_t* nodes = (node_t*)malloc(sizeof(node_t) * cap_nodes);
-        nodes[0].parent = -1; nodes[0].tok = blank;
+        nodes[0].parent = -1; nodes[0].tok = blank; nodes[0].t = -1;
         pool_t pool[2] = {{NULL, 0, 0, 2 * LH}, {NULL, 0, 0, 2 * LH}};
         int cur = 0;
         memset(hn, 0, sizeof(float) * LH); memset(cn, 0, sizeof(float) * LH);
@@ -110,7 +111,7 @@ int rs_oracle_espnet_beam(const float* f, const int32_t* enc_lens, int B, int Tp
                 ++n_pop; ++n_pops_total;
                 if (mh.tok >= 0) {                                     /* its sequence enters the trie now */
                     if (n_nodes == cap_nodes) { cap_nodes *= 2; nodes = (node_t*)realloc(nodes, sizeof(node_t) * cap_nodes); }
-                    nodes[n_nodes].parent = mh.node; nodes[n_nodes].tok = mh.tok;
+                    nodes[n_nodes].parent = mh.node; nodes[n_nodes].tok = mh.tok; nodes[n_nodes].t = t;
                     mh.node = n_nodes++; mh.tok = -1;
                 }
                 const float* sv = pool[cur].v + (size_t)mh.state * 2 * LH;
@@ -183,7 +184,11 @@ int rs_oracle_espnet_beam(const float* f, const int32_t* enc_lens, int B, int Tp
             if (n > out_cap) { overflow = 1; n_ids[b] = 0; }
             else {
                 int node = kept[best].node;                          /* survivors are always in the trie */
-                for (int q = n - 1; q >= 0; --q) { ids[(size_t)b * out_cap + q] = nodes[node].tok; node = nodes[node].parent; }
+                for (int q = n - 1; q >= 0; --q) {
+                    ids[(size_t)b * out_cap + q] = nodes[node].tok;
+                    if (frames) frames[(size_t)b * out_cap + q] = nodes[node].t;
+                    node = nodes[node].parent;
+                }
                 n_ids[b] = n;
             }
         }

@@ -130,9 +130,10 @@ def rnnt_alsd(cfg, sd, f, enc_lens, beam=4, max_target_len=2.0, score_norm=True,
     return [(ids[b, :n_ids[b]].tolist(), steps[b, :n_ids[b]].tolist(), float(scores[b])) for b in range(B)]
 
 
-def espnet_beam(cfg, sd, f, enc_lens, beam=20, score_norm=True, max_pops=None, out_cap=None):
+def espnet_beam(cfg, sd, f, enc_lens, beam=20, score_norm=True, max_pops=None, out_cap=None, with_frames=False):
     """f float32 [B, Tp, J] (numpy), enc_lens int[B] -> list of (ids, score, pops) of the best hypothesis per utterance
-    under ESPnet's default transducer beam search, in the fixed float32 evaluation order of espnet_beam.c."""
+    under ESPnet's default transducer beam search, in the fixed float32 evaluation order of espnet_beam.c.
+    with_frames: (ids, frames, score, pops) — frames = the frame each label was appended at."""
     L = lib()
     L.rs_oracle_set_joint_act(1 if getattr(cfg, "espnet", False) else 0)
     arr = decoder_arrays(cfg, sd)
@@ -144,6 +145,7 @@ def espnet_beam(cfg, sd, f, enc_lens, beam=20, score_norm=True, max_pops=None, o
     if out_cap is None:
         out_cap = max(1, Tp * 4)
     ids = np.zeros((B, out_cap), np.int32)
+    frames = np.zeros((B, out_cap), np.int32)
     n_ids = np.zeros((B,), np.int32)
     scores = np.zeros((B,), np.float32)
     pops = np.zeros((B,), np.int32)
@@ -154,7 +156,9 @@ def espnet_beam(cfg, sd, f, enc_lens, beam=20, score_norm=True, max_pops=None, o
     rc = L.rs_oracle_espnet_beam(_fp(f), _ip(enc_lens), B, Tp, J, cfg.pred_hidden, cfg.pred_layers, cfg.n_logits,
                                  cfg.blank_id, _fp(arr["embed"]), wl, bl, _fp(arr["Wp"]), _fp(arr["bp"]), _fp(arr["Wo"]),
                                  _fp(arr["bo"]), int(beam), int(bool(score_norm)), int(max_pops), int(out_cap), _ip(ids),
-                                 _ip(n_ids), _fp(scores), _ip(pops))
+                                 _ip(frames), _ip(n_ids), _fp(scores), _ip(pops))
     if rc != 0:
         raise RuntimeError(f"oracle espnet beam search overflowed (max_pops={max_pops}, out_cap={out_cap})")
+    if with_frames:
+        return [(ids[b, :n_ids[b]].tolist(), frames[b, :n_ids[b]].tolist(), float(scores[b]), int(pops[b])) for b in range(B)]
     return [(ids[b, :n_ids[b]].tolist(), float(scores[b]), int(pops[b])) for b in range(B)]

@@ -95,6 +95,7 @@ struct BeamState {
     int32_t* k_slot;     // own slot
     int32_t* k_len;
     int2* nodes;         // [B][max_nodes] (parent, label)
+    int32_t* node_frame; // [B][max_nodes] the frame the label was appended at
     float* slots;        // [B][n_slots][slot_floats]: per evaluated sequence  h [L][H], c [L][H] after its last label, g [J]
     int32_t* freelist;   // [B][n_slots] free slot ids; a frame's end returns every slot no survivor owns
     float* rec;          // [B][RP][rec_floats]: log p(blank), label count, log p(label j) x beam_k, label j x beam_k
@@ -465,8 +466,9 @@ __global__ __launch_bounds__(256) void beam_first_kernel(BeamState bs, DecodeSta
 // slots [RP]
 __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeState st, const int32_t* __restrict__ enc_lens, int B,
                                                         int L, int H, int J, int beam, int score_norm, int out_cap, int iter,
-                                                        int32_t* __restrict__ ids, int32_t* __restrict__ n_ids,
-                                                        float* __restrict__ scores, int32_t* __restrict__ pops) {
+                                                        int32_t* __restrict__ ids, int32_t* __restrict__ frames,
+                                                        int32_t* __restrict__ n_ids, float* __restrict__ scores,
+                                                        int32_t* __restrict__ pops) {
     extern __shared__ __attribute__((aligned(16))) char beam_smem[];
     const int MP = bs.max_pops, R = bs.R, KS = bs.KS, RP = bs.RP, RF = bs.rec_floats, K = bs.beam_k;
     float* lsc = reinterpret_cast<float*>(beam_smem);
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
             const int tok = bs.h_tok[hb + bi], parent = bs.h_node[hb + bi];
             e_len = bs.h_len[hb + bi];
             if (nnode >= bs.max_nodes) { if (tid == 0) beam_fail(bs, b); return; }
-            if (tid == 0) bs.nodes[(size_t)b * bs.max_nodes + nnode] = make_int2(parent, tok);
+            if (tid == 0) { bs.nodes[(size_t)b * bs.max_nodes + nnode] = make_int2(parent, tok); bs.node_frame[(size_t)b * bs.max_nodes + nnode] = t; }
             e_node = nnode++;
         }
         if (tid == 0) { lsc[bi] = __int_as_float(0x7fc00000); bs.h_alive[hb + bi] = 0; }
@@ -647,6 +649,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
             for (int q = n - 1; q >= 0; --q) {
                 const int2 nd = bs.nodes[(size_t)b * bs.max_nodes + node];
                 ids[(size_t)b * out_cap + q] = nd.y;
+                if (frames) frames[(size_t)b * out_cap + q] = bs.node_frame[(size_t)b * bs.max_nodes + node];
                 node = nd.x;
             }
             n_ids[b] = n;
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState bs, DecodeStat
 }
 
 struct BeamPlan {
-    size_t b4, bk4, h4, k4, nodes, slots, freelist, rec, rp4, goff, state1, g, rows4, z, apre, total, step_lds, rec_lds;
+    size_t b4, bk4, h4, k4, nodes, nodes4, slots, freelist, rec, rp4, goff, state1, g, rows4, z, apre, total, step_lds, rec_lds;
     int max_h, max_nodes, n_slots, slot_floats, zstride, R, KS, RP, rec_floats, rows;
 };
 
@@ -684,6 +687,7 @@ BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam, int beam_k, int tp_max, i
     p.h4 = rs_align((size_t)B * p.max_h * 4);
     p.k4 = rs_align((size_t)B * max_pops * 4);
     p.nodes = rs_align((size_t)B * p.max_nodes * 8);
+    p.nodes4 = rs_align((size_t)B * p.max_nodes * 4);
     p.state1 = rs_align((size_t)d.pred_layers * B * p.KS * d.pred_hidden * 4);
     p.slots = rs_align((size_t)B * p.n_slots * p.slot_floats * 4);
     p.freelist = rs_align((size_t)B * p.n_slots * 4);
@@ -694,7 +698,7 @@ BeamPlan beam_plan(const rs_ctx* ctx, int B, int beam, int beam_k, int tp_max, i
     p.rows4 = rs_align((size_t)p.rows * 4);
     p.z = rs_align((size_t)p.rows * p.zstride * 4);
     p.apre = rs_align((size_t)p.rows * d.joint_hidden * 4);
-    p.total = 12 * p.b4 + 3 * p.bk4 + 7 * p.h4 + 4 * p.k4 + p.nodes + p.slots + p.freelist + p.rec + p.rp4 + p.goff + 4 * p.state1 + p.g +
+    p.total = 12 * p.b4 + 3 * p.bk4 + 7 * p.h4 + 4 * p.k4 + p.nodes + p.nodes4 + p.slots + p.freelist + p.rec + p.rp4 + p.goff + 4 * p.state1 + p.g +
               4 * p.rows4 + 2 * rs_align(64) + rs_align(256) + p.z + p.apre + 1024;
     p.step_lds = (size_t)p.max_h * 4 + (size_t)(p.max_h + 1) / 2 * 4 + (size_t)max_pops * 4 * 6 + (size_t)p.n_slots * 4 +
                  (size_t)p.RP * p.rec_floats * 4 + (size_t)p.RP * 4;
@@ -713,8 +717,8 @@ size_t rs_rnnt_beam_workspace_bytes_impl(const rs_ctx* ctx, int B, int beam, int
 }
 
 int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int beam, int score_norm,
-                      int max_pops, int out_cap, int32_t* ids, int32_t* n_ids, float* scores, int32_t* pops, void* workspace,
-                      size_t workspace_bytes, hipStream_t s) {
+                      int max_pops, int out_cap, int32_t* ids, int32_t* frames, int32_t* n_ids, float* scores, int32_t* pops,
+                      void* workspace, size_t workspace_bytes, hipStream_t s) {
     const rs_dims& d = ctx->d;
     const int L = d.pred_layers, H = d.pred_hidden, J = d.joint_hidden, V = d.n_logits;
     if (H % 128 || J % 128) return rs_fail(ctx, RS_EINVAL, "beam search: pred_hidden/joint_hidden must be multiples of 128");
@@ -750,6 +754,7 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
     bs.k_score = (float*)take(pl.k4); bs.k_node = (int32_t*)take(pl.k4); bs.k_slot = (int32_t*)take(pl.k4);
     bs.k_len = (int32_t*)take(pl.k4);
     bs.nodes = (int2*)take(pl.nodes);
+    bs.node_frame = (int32_t*)take(pl.nodes4);
     bs.freelist = (int32_t*)take(pl.freelist);
     bs.rec = (float*)take(pl.rec);
     bs.rec_slot = (int32_t*)take(pl.rp4);
@@ -810,7 +815,7 @@ int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
             hipLaunchKernelGGL(record, dim3(rec_blocks), dim3(256), pl.rec_lds, s, bs, st, st.zapprox, pl.zstride, pl.rows, rpu, V, d.blank_id,
                                step);
             hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), pl.step_lds, s, bs, st, enc_lens, B, L, H, J, bm, score_norm, out_cap,
-                               step, ids, n_ids, scores, pops);
+                               step, ids, frames, n_ids, scores, pops);
         }
         RS_CHECK_LAUNCH(ctx, "beam step");
         RS_HIP(ctx, hipMemcpyAsync(hf, bs.flags, sizeof hf, hipMemcpyDeviceToHost, s));

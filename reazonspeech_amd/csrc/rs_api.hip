@@ -14,8 +14,8 @@ size_t rs_rnnt_workspace_bytes(const rs_ctx* ctx, int B);
 size_t rs_rnnt_alsd_workspace_bytes_impl(const rs_ctx* ctx, int B, int beam, int cap);
 size_t rs_rnnt_beam_workspace_bytes_impl(const rs_ctx* ctx, int B, int beam, int tp_max, int max_pops);
 int rs_rnnt_beam_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int beam, int score_norm,
-                      int max_pops, int out_cap, int32_t* ids, int32_t* n_ids, float* scores, int32_t* pops, void* workspace,
-                      size_t workspace_bytes, hipStream_t s);
+                      int max_pops, int out_cap, int32_t* ids, int32_t* frames, int32_t* n_ids, float* scores, int32_t* pops,
+                      void* workspace, size_t workspace_bytes, hipStream_t s);
 int rs_rnnt_alsd_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int beam, double ratio,
                       int abs_len, int score_norm, int merge, int out_cap, int32_t* ids, int32_t* steps, int32_t* n_ids,
                       float* scores, void* workspace, size_t workspace_bytes, hipStream_t s);
@@ -669,8 +669,8 @@ size_t rs_rnnt_beam_workspace_bytes(const rs_ctx* ctx, int B, int beam, int tp_m
 }
 
 int rs_rnnt_beam(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, int B, int tp_max, int beam, int flags, int max_pops,
-                 int out_cap, int32_t* ids, int32_t* n_ids, float* scores, int32_t* pops, void* workspace, size_t workspace_bytes,
-                 void* stream) {
+                 int out_cap, int32_t* ids, int32_t* frames, int32_t* n_ids, float* scores, int32_t* pops, void* workspace,
+                 size_t workspace_bytes, void* stream) {
     if (!ctx) return RS_EINVAL;
     if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_rnnt_beam");
     if (B < 0 || tp_max < 0 || out_cap < 0 || max_pops < 0) return rs_fail(ctx, RS_EINVAL, "beam search: negative size");
@@ -684,7 +684,7 @@ int rs_rnnt_beam(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, i
         return RS_OK;
     }
     return rs_rnnt_beam_impl(ctx, joint_enc, enc_lens, B, tp_max, beam, (flags & RS_BEAM_SCORE_NORM) != 0, max_pops, out_cap, ids,
-                             n_ids, scores, pops, workspace, workspace_bytes, (hipStream_t)stream);
+                             frames, n_ids, scores, pops, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // ---- profiling -------------------------------------------------------------------------------------

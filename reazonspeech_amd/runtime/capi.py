@@ -103,7 +103,7 @@ def load():
     lib.rs_rnnt_greedy.argtypes = [vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
     lib.rs_rnnt_beam_workspace_bytes.argtypes = [vp, c_int, c_int, c_int, c_int]
     lib.rs_rnnt_beam_workspace_bytes.restype = c_size_t
-    lib.rs_rnnt_beam.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, vp, c_size_t, vp]
+    lib.rs_rnnt_beam.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, vp, vp, c_size_t, vp]
     lib.rs_rnnt_beam.restype = c_int
     lib.rs_rnnt_alsd_workspace_bytes.argtypes = [vp, c_int, c_int, c_int, c_double, c_int]
     lib.rs_rnnt_alsd_workspace_bytes.restype = c_size_t
@@ -302,10 +302,12 @@ class Context:
             raise RuntimeError("rs_rnnt_beam_workspace_bytes: invalid arguments")
         return n
 
-    def rnnt_beam(self, joint_enc, enc_lens, B, tp_max, beam, score_norm, max_pops, ids, n_ids, scores, pops, ws, stream):
-        """ESPnet's default transducer beam search: ids int32 [B][out_cap], n_ids / pops int32 [B], scores float32 [B]"""
+    def rnnt_beam(self, joint_enc, enc_lens, B, tp_max, beam, score_norm, max_pops, ids, n_ids, scores, pops, ws, stream, frames=None):
+        """ESPnet's default transducer beam search: ids (and frames, optional) int32 [B][out_cap], n_ids / pops int32 [B],
+        scores float32 [B]"""
+        assert frames is None or frames.shape == ids.shape
         self.check(self.lib.rs_rnnt_beam(self._h, _ptr(joint_enc), _ptr(enc_lens), B, tp_max, beam, 1 if score_norm else 0,
-                                         int(max_pops), ids.shape[1], _ptr(ids), _ptr(n_ids), _ptr(scores), _ptr(pops), _ptr(ws),
+                                         int(max_pops), ids.shape[1], _ptr(ids), _ptr(frames) if frames is not None else None, _ptr(n_ids), _ptr(scores), _ptr(pops), _ptr(ws),
                                          ws.numel() * ws.element_size(), c_void_p(stream)))
 
     # ---- profiling ----

@@ -286,9 +286,8 @@ class AsrModel:
             n = ctx.beam_workspace_bytes(buf.B, cfg.beam_size, buf.tp_max, cfg.beam_max_pops)
             if buf.ws_alsd is None or buf.ws_alsd.numel() < n:
                 buf.ws_alsd = torch.empty((n,), dtype=torch.uint8, device=self.device)
-            # (no emission frames in this search: buf.frames stays as allocated, zeros)
             ctx.rnnt_beam(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, cfg.beam_size, cfg.beam_score_norm, cfg.beam_max_pops,
-                          buf.ids, buf.n_ids, buf.scores, buf.pops, buf.ws_alsd, stream)
+                          buf.ids, buf.n_ids, buf.scores, buf.pops, buf.ws_alsd, stream, frames=buf.frames)
             return
         if cfg.decoding != "alsd":
             ctx.rnnt_greedy(buf.joint_enc, buf.enc_lens, buf.B, buf.tp_max, buf.u_max, buf.ids, buf.frames, buf.n_ids,
@@ -504,7 +503,7 @@ class AsrModel:
         if self.cfg.decoding == "alsd":      # alignment step i = frame + labels emitted before
             frames = frames - np.arange(frames.shape[1], dtype=frames.dtype)[None, :]
             scores = host[4].numpy().tolist()
-        elif self.cfg.decoding == "beam":    # the default search keeps no emission frames (upstream Hypothesis has none)
+        elif self.cfg.decoding == "beam":    # frames = the frame each label was appended at ([UPSTREAM] NeMo Hypothesis.timestep)
             scores = host[4].numpy().tolist()
         else:
             scores = None

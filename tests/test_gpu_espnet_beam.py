@@ -34,22 +34,25 @@ def encode(model, audio, lens):
     return buf
 
 
-def device_beam(model, buf, beam, score_norm=True, max_pops=0, enc_lens=None, out_cap=None):
+def device_beam(model, buf, beam, score_norm=True, max_pops=0, enc_lens=None, out_cap=None, with_frames=False):
     am = model.am
     B = buf.B
     dev = am.device
     el = buf.enc_lens if enc_lens is None else torch.as_tensor(enc_lens, dtype=torch.int32, device=dev)
     cap = out_cap or (2 * buf.tp_max + 16)
     ids = torch.full((B, cap), -7, dtype=torch.int32, device=dev)
+    frames = torch.full((B, cap), -7, dtype=torch.int32, device=dev) if with_frames else None
     n_ids = torch.full((B,), -7, dtype=torch.int32, device=dev)
     scores = torch.full((B,), 123.0, dtype=torch.float32, device=dev)
     pops = torch.full((B,), -7, dtype=torch.int32, device=dev)
     ws = torch.empty((am.ctx.beam_workspace_bytes(B, beam, buf.tp_max, max_pops),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         am.ctx.rnnt_beam(buf.joint_enc, el, B, buf.tp_max, beam, score_norm, max_pops, ids, n_ids, scores, pops, ws,
-                         torch.cuda.current_stream().cuda_stream)
+                         torch.cuda.current_stream().cuda_stream, frames=frames)
         torch.cuda.synchronize()
     n = n_ids.cpu().numpy()
+    if with_frames:
+        return [(ids[b, :n[b]].cpu().tolist(), frames[b, :n[b]].cpu().tolist(), float(scores[b]), int(pops[b])) for b in range(B)]
     return [(ids[b, :n[b]].cpu().tolist(), float(scores[b]), int(pops[b])) for b in range(B)]
 
 
@@ -70,11 +73,12 @@ def test_tiny_bit_exact(tiny, beam):
     model, sd, buf = tiny
     f = buf.joint_enc.cpu().numpy()
     el = buf.enc_lens.cpu().numpy()
-    want = og.espnet_beam(model.cfg, sd, f, el, beam=beam, max_pops=16 * beam, out_cap=2 * buf.tp_max + 16)
-    got = device_beam(model, buf, beam)
+    want = og.espnet_beam(model.cfg, sd, f, el, beam=beam, max_pops=16 * beam, out_cap=2 * buf.tp_max + 16, with_frames=True)
+    got = device_beam(model, buf, beam, with_frames=True)
     assert [g[0] for g in got] == [w[0] for w in want]
-    assert [g[2] for g in got] == [w[2] for w in want]
-    assert [np.float32(g[1]) for g in got] == [np.float32(w[1]) for w in want]
+    assert [g[1] for g in got] == [w[1] for w in want]            # the frame each label was appended at
+    assert [g[3] for g in got] == [w[3] for w in want]
+    assert [np.float32(g[2]) for g in got] == [np.float32(w[2]) for w in want]
     assert sum(len(g[0]) for g in got) > 0
 
 
@@ -139,11 +143,11 @@ def test_model_call_uses_the_beam_search(gpu_device):
     text, tokens, ids, _ = model(wav)[0]
     buf = encode(model, wav[None, :], np.asarray([len(wav)], np.int32))
     want = og.espnet_beam(model.cfg, sd, buf.joint_enc.cpu().numpy(), buf.enc_lens.cpu().numpy(), beam=6, max_pops=96,
-                          out_cap=2 * buf.tp_max + 16)
+                          out_cap=2 * buf.tp_max + 16, with_frames=True)
     assert ids == want[0][0] and text == "".join(model.token_list[i] for i in ids)
     res = model.am.transcribe_waveforms([audio[b, :int(lens[b])] for b in range(2)])
     assert res.ids[0] == ids and res.scores is not None and len(res.scores) == 2
-    assert all(f == 0 for f in res.frames[0])
+    assert res.frames[0] == want[0][1]
 
 
 def test_120m_one_utterance_bit_exact(gpu_device):
@@ -176,20 +180,22 @@ def test_nemo_family_two_lstm_layers_blank_last(gpu_device):
     dev = model.device
     cap = 2 * Tp + 16
     ids = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    frames = torch.full((B, cap), -7, dtype=torch.int32, device=dev)
     n_ids = torch.zeros((B,), dtype=torch.int32, device=dev)
     scores = torch.zeros((B,), dtype=torch.float32, device=dev)
     pops = torch.zeros((B,), dtype=torch.int32, device=dev)
     ws = torch.empty((model.ctx.beam_workspace_bytes(B, 6, Tp, 600),), dtype=torch.uint8, device=dev)
     try:
         model.ctx.rnnt_beam(f.to(dev), torch.from_numpy(lens).to(dev), B, Tp, 6, True, 600, ids, n_ids, scores, pops, ws,
-                            torch.cuda.current_stream().cuda_stream)
+                            torch.cuda.current_stream().cuda_stream, frames=frames)
         torch.cuda.synchronize()
-        got = [(ids[b, :int(n_ids[b])].cpu().tolist(), float(scores[b]), int(pops[b])) for b in range(B)]
-        want = og.espnet_beam(cfg, sd, f.numpy(), lens, beam=6, max_pops=600, out_cap=cap)
+        got = [(ids[b, :int(n_ids[b])].cpu().tolist(), frames[b, :int(n_ids[b])].cpu().tolist(), float(scores[b]), int(pops[b]))
+               for b in range(B)]
+        want = og.espnet_beam(cfg, sd, f.numpy(), lens, beam=6, max_pops=600, out_cap=cap, with_frames=True)
     except RuntimeError as e:            # an untrained joint that never settles: the overflow must be the oracle's too
         assert "max_pops" in str(e)
         with pytest.raises(RuntimeError):
             og.espnet_beam(cfg, sd, f.numpy(), lens, beam=6, max_pops=600, out_cap=cap)
         pytest.skip("this synthetic decoder does not settle within max_pops (both sides agree)")
-    assert got == [(w[0], float(np.float32(w[1])), w[2]) for w in want]
+    assert got == [(w[0], w[1], float(np.float32(w[2])), w[3]) for w in want]
     assert sum(len(g_[0]) for g_ in got) > 0

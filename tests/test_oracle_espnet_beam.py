@@ -73,9 +73,10 @@ def test_c_follows_torch_restatement_nemo_decoder():
     g = torch.Generator().manual_seed(3)
     f = torch.randn((3, 14, cfg.joint_hidden), generator=g) * 1.2
     lens = torch.tensor([14, 9, 0], dtype=torch.int32)
-    ref = oe.default_beam_search_torch(cfg, sd, f, lens, beam_size=5)
-    got = og.espnet_beam(cfg, sd, f.numpy(), lens.numpy(), beam=5, max_pops=400)
-    for (rid, rs, rp), (gid, gs, gp) in zip(ref, got):
+    ref = oe.default_beam_search_torch(cfg, sd, f, lens, beam_size=5, with_frames=True)
+    got = og.espnet_beam(cfg, sd, f.numpy(), lens.numpy(), beam=5, max_pops=400, with_frames=True)
+    for (rid, rfr, rs, rp), (gid, gfr, gs, gp) in zip(ref, got):
         assert gid == rid and gp == rp
+        assert gfr == rfr and all(a <= b_ for a, b_ in zip(gfr, gfr[1:]))      # the frame each label was appended at
         assert abs(gs - rs) <= 1e-4 * max(1.0, abs(rs))
-    assert all(cfg.blank_id not in r[0] for r in ref)
+    assert all(cfg.blank_id not in r[0] for r in ref) and any(r[1] for r in ref)
