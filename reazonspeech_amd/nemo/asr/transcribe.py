@@ -68,9 +68,10 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
         transcripts are then meaningless).
       config (ModelConfig): architecture for synthetic weights (no checkpoint lookup is made when it is given).
       seed (int): seed of the synthetic weights.
-      decoding (str): override the checkpoint's decoding strategy: "greedy_batch" or "alsd" (alignment-length
-        synchronous beam search, what the reference checkpoint ships with: decode.py:29,38-41).
-      beam_size (int): override the beam size of "alsd" (1..8).
+      decoding (str): override the checkpoint's decoding strategy: "greedy_batch", "alsd" (alignment-length
+        synchronous beam search, what the reference checkpoint ships with: decode.py:29,38-41) or "beam" ([UPSTREAM] NeMo's
+        `strategy: beam`, the default Graves beam search — the one ESPnet runs, csrc/k_rnnt_beam.hip).
+      beam_size (int): override the beam size ("alsd": 1..8, "beam": 1..64).
       precision (str): "bf16" (default): the throughput mode — bf16 matrix-core operands, float32 accumulation, float32
         residual stream, exact float32 decode.  "fp32": the parity mode — float32 weights, activations and arithmetic end
         to end, i.e. what the reference computes (transcribe.py:26-28, :48-53 run NeMo in float32 without autocast; the
@@ -114,6 +115,7 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
         cfg = cfg.with_(decoding=str(decoding))
     if beam_size is not None:
         cfg = cfg.with_(beam_size=int(beam_size))
+    cfg.validate()
     kw = {} if pos_cap is None else {"pos_cap": int(pos_cap)}
     return AsrModel(cfg, sd, tokenizer, device=device, pad_seconds=PAD_SECONDS, precision=precision, **kw)
 
