@@ -104,7 +104,8 @@ def _randn(name, seed, shape, std):
     return (torch.randn(shape, generator=g, dtype=torch.float32) * std)
 
 
-def synthetic_state_dict(cfg: ModelConfig, seed: int = 0, blank_bias: float = None) -> Dict[str, torch.Tensor]:
+def synthetic_state_dict(cfg: ModelConfig, seed: int = 0, blank_bias: float = None, dec_gain: float = 1.0,
+                         out_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Seeded random weights with NeMo's state-dict keys and shapes.
 
     Every tensor draws from its own generator (seed x hash(name)), so the values do not
@@ -183,9 +184,9 @@ def synthetic_state_dict(cfg: ModelConfig, seed: int = 0, blank_bias: float = No
         sd[P + f"weight_hh_l{l}"] = _randn(P + f"weight_hh_l{l}", seed, (4 * H, H), 1.0 / math.sqrt(H))
         sd[P + f"bias_ih_l{l}"] = _randn(P + f"bias_ih_l{l}", seed, (4 * H,), 0.05)
         sd[P + f"bias_hh_l{l}"] = _randn(P + f"bias_hh_l{l}", seed, (4 * H,), 0.05)
-    lin("joint.pred", J, H)
+    lin("joint.pred", J, H, gain=dec_gain)   # dec_gain > 1: the prediction network weighs in the joint like a trained one's (beam-search recipes)
     lin("joint.enc", J, d)
-    lin("joint.joint_net.2", cfg.n_logits, J, gain=2.0)
+    lin("joint.joint_net.2", cfg.n_logits, J, gain=2.0 * out_gain)   # out_gain > 1: peaked posteriors (beam-search recipes)
     if blank_bias is None:
         blank_bias = default_blank_bias(cfg)
     sd["joint.joint_net.2.bias"][cfg.blank_id] += float(blank_bias)
