@@ -384,6 +384,68 @@ def extra_configs(model, cfg, sd, args, host_sets):
     return out
 
 
+def espnet_parity(am, cfg, sd, buf256, first):
+    """End-to-end id parity of the ESPnet family (pkg/espnet-asr/src/transcribe.py:69: `model(np.pad(samples, PADDING))[0][0]`)
+    on ALL 256 rows of the timed batch against the committed float32-oracle golden (tests/golden/bench_espnet_fp32.npz:
+    oracle/espnet.py run end to end on every row, one utterance per call): the float32 parity mode must reproduce ids and
+    frames, the bf16 throughput mode is flip-audited against the parity mode's projection (oracle/audit.py)."""
+    import hashlib
+    from oracle import audit, greedy as og
+    from reazonspeech_amd.espnet.asr.model import EspnetModel, synthetic_token_list, PADDING
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "bench_espnet_fp32.npz"))
+    audio, lens = first
+    if hashlib.sha256(audio.tobytes()).digest() != bytes(gold["audio_sha256"].tolist()):
+        return {"error": "the resident batch is not the golden's batch (seed / rank / --seconds differ)"}
+    rows = int(gold["rows"])
+    off = gold["ids_offsets"]
+    g_ids = [gold["ids"][off[b]:off[b + 1]].tolist() for b in range(rows)]
+    g_frames = [gold["frames"][off[b]:off[b + 1]].tolist() for b in range(rows)]
+    waves = [np.pad(audio[i, :lens[i]], PADDING) for i in range(audio.shape[0])]
+    t0 = time.perf_counter()
+    m32 = EspnetModel(cfg, sd, synthetic_token_list(cfg.vocab_size, 0), device=str(am.device), precision="fp32").am
+    b32 = m32.stage(waves, buf=m32.new_buffers(len(waves), len(waves[0])))
+    m32.run_device(b32)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    m32.run_device(b32)
+    torch.cuda.synchronize()
+    ms32 = (time.perf_counter() - t1) * 1e3
+    got32 = m32.collect(b32)
+    g = torch.Generator().manual_seed(int(gold["proj_seed"]))
+    R = (torch.randn((cfg.joint_hidden, 8), generator=g, dtype=torch.float32) / cfg.joint_hidden ** 0.5).to(am.device)
+    proj = (b32.joint_enc @ R).cpu().numpy()
+    perr = max(float(np.abs(proj[b, :got32.enc_lens[b]] - gold["proj"][b, :got32.enc_lens[b]]).max()) for b in range(rows))
+    exact = [got32.ids[b] == g_ids[b] and got32.frames[b] == g_frames[b] for b in range(rows)]
+    out = {"checker": "tests/golden/bench_espnet_fp32.npz: oracle/espnet.py (float32 CPU restatement of the ESPnet2 model; unpinned against "
+                      "ESPnet itself) end to end on every row; generator tests/golden/make_espnet_golden.py",
+           "fp32_mode": {"rows": rows, "ids_exact": f"{sum(exact)}/{rows}", "enc_lens_equal": got32.enc_lens[:rows] == gold["enc_lens"].tolist(),
+                         "joint_proj_fingerprint_max_err_all_rows": round(perr, 7), "rows_differing": [b for b in range(rows) if not exact[b]],
+                         "golden_rows_with_a_margin_below_1e-3": int((gold["min_margin"] < float(gold["near_tie"])).sum()),
+                         "decisions": int(gold["n_decisions"].sum()), "ms_per_batch_of_256": round(ms32, 1),
+                         "rtfx": round(float(lens.sum()) / 16000.0 / (ms32 * 1e-3), 1), "load_and_first_run_s": round(t1 - t0, 1)}}
+    # the bf16 throughput mode (the timed kernels) on the same rows, audited against the parity mode's projection
+    am.run_device(buf256)
+    torch.cuda.synchronize()
+    got16 = am.collect(buf256)
+    f16 = buf256.joint_enc
+    dj = max(float((f16[b, :got16.enc_lens[b]] - b32.joint_enc[b, :got16.enc_lens[b]]).abs().max()) for b in range(rows))
+    audits = audit.flip_audit_batch(cfg, sd, b32.joint_enc[:rows], f16[:rows], got16.enc_lens[:rows], got16.ids[:rows], got16.frames[:rows],
+                                    device=am.device)
+    equal = [got16.ids[b] == g_ids[b] and got16.frames[b] == g_frames[b] for b in range(rows)]
+    s = audit.summarize(audits, equal)
+    ref_tokens = sum(len(x) for x in g_ids)
+    dist = sum(edit_distance(got16.ids[b], g_ids[b]) for b in range(rows) if not equal[b])
+    same = og.rnnt_greedy(cfg, sd, f16[:8].cpu().numpy(), np.asarray(got16.enc_lens[:8], np.int32))
+    s.update(rows=rows, ids_exact_vs_fp32_oracle=f"{sum(equal)}/{rows}", token_agreement=round(1.0 - dist / max(ref_tokens, 1), 4),
+             joint_enc_max_diff_vs_fp32_mode=round(dj, 4),
+             every_flip_obeys_the_lipschitz_bound=all(fl["margin_ref"] <= fl["bound"] * (1 + 1e-9) + 1e-12 for a in audits for fl in a["flips"]),
+             decode_bit_exact_given_same_joint_enc_rows_0_7=got16.ids[:8] == [r[0] for r in same] and got16.frames[:8] == [r[1] for r in same])
+    out["bf16_audit_all_rows"] = s
+    del m32, b32
+    torch.cuda.empty_cache()
+    return out
+
+
 def espnet_config(device, args):
     """`reazonspeech.espnet.asr` (pkg/espnet-asr/src/transcribe.py): 256 x 10 s utterances with the reference's (16000, 8000)
     padding through front-end + Conv2dSubsampling + 17 conformer blocks + transducer greedy search, HBM-resident and pipelined
@@ -413,21 +475,7 @@ def espnet_config(device, args):
            "value": round(sum(secs[i % n_sets] for i in range(steps)) / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
            "enc_frames": bufs[0].tp_max, "mean_tokens_per_utt": round(float(n_tok.mean()), 1)}
     try:
-        from oracle import espnet as oe, greedy as og
-        audio, lens = first
-        k = 2
-        padded = np.stack([np.pad(audio[i, :lens[i]], PADDING) for i in range(k)])
-        small = am.stage([padded[i] for i in range(k)])
-        enc = torch.zeros((k, small.tp_max, cfg.d_model), dtype=torch.float32, device=am.device)
-        am.run_device(small, want_enc=enc)
-        torch.cuda.synchronize()
-        got = am.collect(small)
-        ref = oe.forward(cfg, sd, torch.from_numpy(padded), torch.tensor([padded.shape[1]] * k), "fp32")
-        n = int(ref["enc_lens"][0])
-        same = og.rnnt_greedy(cfg, sd, small.joint_enc.cpu().numpy(), np.asarray(got.enc_lens, np.int32))
-        res["parity"] = {"utterances": k, "checker": "oracle/espnet.py (fp32 CPU restatement of the ESPnet2 model; unpinned against ESPnet itself)",
-                         "encoder_max_err": round(float((enc.cpu()[:, :n] - ref["enc"][:, :n]).abs().max()), 4),
-                         "decode_bit_exact_given_same_joint_enc": got.ids == [r[0] for r in same] and got.frames == [r[1] for r in same]}
+        res["parity"] = espnet_parity(am, cfg, sd, bufs[0], first)
     except Exception as e:
         res["parity"] = {"error": repr(e)}
     del bufs, em

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 4
+#define RS_ABI_VERSION 5
 
 enum {
     RS_OK = 0,
@@ -83,15 +83,56 @@ typedef struct rs_dims {
     int32_t final_norm;    /* 1: a LayerNorm after the last block ("final_norm.g" / ".b"; ESPnet encoder.after_norm) */
     int32_t joint_act;     /* joint activation: 0 = ReLU (NeMo), 1 = tanh (ESPnet JointNetwork); tanh decodes with the exact
                               (un-screened) joint kernels */
-    int32_t ctc_vocab;     /* > 0: a CTC head Linear(d_model, ctc_vocab) is registered ("ctc.w" bf16 [ctc_vocab][d_model], "ctc.b");
-                              see rs_encoder_set_ctc_out.  ctc_vocab % 4 == 0 */
+    int32_t ctc_vocab;     /* > 0: a CTC head Linear(d_model, ctc_vocab) is registered with its rows padded to Vp = the next
+                              multiple of 4 ("ctc.w" bf16 [Vp][d_model], "ctc.b" f32 [Vp]; the padding rows are never read back:
+                              the softmax runs over ctc_vocab columns and writes 0 to the rest); see rs_encoder_set_ctc_out */
 } rs_dims;
+
+/* Dimensions of the Zipformer2 transducer of reazonspeech.k2.asr: what sherpa-onnx reads out of the three ONNX files the
+ * reference hands it (pkg/k2-asr/src/huggingface.py:73-83; [UPSTREAM] icefall zipformer recipe: --num-encoder-layers,
+ * --feedforward-dim, --num-heads, --encoder-dim, --cnn-module-kernel, --downsampling-factor, --query-head-dim, ...). */
+typedef struct rs_k2_dims {
+    int32_t n_mels;            /* 80 (feature_dim, huggingface.py:80) */
+    int32_t frame_length;      /* 400 samples */
+    int32_t frame_shift;       /* 160 samples */
+    float preemph;             /* 0.97 (kaldi-native-fbank default) */
+    int32_t embed_c1, embed_c2, embed_c3;   /* encoder_embed conv channels: 8, 32, 128 */
+    int32_t n_stacks;          /* 6 */
+    int32_t encoder_dim[8];    /* 192,256,512,768,512,256 */
+    int32_t num_layers[8];     /* 2,2,4,5,4,2 */
+    int32_t ff_dim[8];         /* 512,768,1536,2048,1536,768 */
+    int32_t num_heads[8];      /* 4,4,4,8,4,4 */
+    int32_t cnn_kernel[8];     /* 31,31,15,15,15,31 (7, 15 and 31 are built) */
+    int32_t downsampling[8];   /* 1,2,4,8,4,2 */
+    int32_t query_head_dim;    /* 32 */
+    int32_t value_head_dim;    /* 12 */
+    int32_t pos_head_dim;      /* 4 */
+    int32_t pos_dim;           /* 48 (host side only: the position tables arrive projected) */
+    int32_t vocab_size;        /* lines of tokens.txt */
+    int32_t decoder_dim;       /* 512 */
+    int32_t joiner_dim;        /* 512 */
+    int32_t context_size;      /* 2 */
+    int32_t blank_id;          /* 0 */
+    int32_t unk_id;            /* id of "<unk>", -1 = none: sherpa-onnx's greedy search does not emit it */
+} rs_k2_dims;
 
 /* ---- context ------------------------------------------------------------------------- */
 
 /* Replaces: model object construction inside EncDecRNNTBPEModel.from_pretrained
  * (pkg/nemo-asr/src/transcribe.py:26-28).  `device` is the HIP device ordinal. */
 int rs_create(rs_ctx** out, int device, const rs_dims* dims);
+/* The same for reazonspeech.k2.asr — replaces: sherpa_onnx.OfflineRecognizer.from_transducer(encoder, decoder, joiner, ...)
+ * (pkg/k2-asr/src/huggingface.py:73-83).  The context answers the SAME stage entry points: rs_set_tensor / rs_finalize,
+ * rs_workspace_bytes, rs_mel_frames ((n + shift / 2) / shift kaldi-style frames), rs_enc_frames (((T - 7) / 2 + 1) / 2),
+ * rs_frontend_logmel (kaldi-native-fbank features: snip_edges false with reflected edges, per-frame DC removal and
+ * pre-emphasis, povey window, log(max(mel energy, FLT_EPSILON)), no normalisation), rs_encoder_forward (encoder_embed +
+ * Zipformer2 stacks + joiner.encoder_proj, csrc/k_zipformer.hip) and rs_rnnt_greedy (stateless decoder + tanh joiner, one
+ * symbol per frame, `<unk>` treated as blank: sherpa-onnx OfflineTransducerGreedySearchDecoder).  Tensor names: DESIGN.md
+ * "reazonspeech.k2.asr". */
+int rs_k2_create(rs_ctx** out, int device, const rs_k2_dims* dims);
+/* Parity taps of a Zipformer context (tests only): embed_out f32 [B*T3][encoder_dim[0]] (encoder_embed's output) and stack_out,
+ * the stacks' outputs f32 [B*T3][encoder_dim[s]] one after the other; NULL disables. */
+int rs_k2_encoder_set_taps(rs_ctx* ctx, float* embed_out, float* stack_out);
 void rs_destroy(rs_ctx* ctx);
 const char* rs_last_error(const rs_ctx* ctx);
 int rs_abi_version(void);
@@ -200,7 +241,8 @@ int rs_encoder_set_taps(rs_ctx* ctx, float* sub_out, float* layer_out, const int
 /* CTC posteriors (ESPnet family; replaces model.asr_model.ctc.softmax(model.asr_model.encode(...)), pkg/espnet-asr/src/ctc.py:12-27):
  * when set, the next rs_encoder_forward calls also write softmax(ctc_lo(encoder output)) — probabilities, not logarithms, as the
  * reference's blank finder (ctc.py:29-58) and its ctc_segmentation call (ctc.py:60-75) consume them — to probs f32
- * [B*tp_max][ctc_vocab] and / or only the blank column to blank_prob f32 [B*tp_max].  Either may be NULL; both NULL disables. */
+ * [B*tp_max][Vp] (Vp = ctc_vocab rounded up to a multiple of 4: the row pitch; columns >= ctc_vocab are 0) and / or only the
+ * blank column to blank_prob f32 [B*tp_max].  Either may be NULL; both NULL disables. */
 int rs_encoder_set_ctc_out(rs_ctx* ctx, float* probs, float* blank_prob);
 
 /* ---- stage 3: RNN-T greedy decode -------------------------------------------------------
@@ -297,7 +339,9 @@ enum { RS_GEMM_BIAS = 1, RS_GEMM_RELU = 2, RS_GEMM_SILU = 4, RS_GEMM_RESIDUAL = 
        /* out bf16[M][N/2] = (a + bias_a) * sigmoid(g + bias_g): columns 64j .. 64j+31 of the product are values,
         * 64j+32 .. 64j+63 their gates (weight rows interleaved in blocks of 32, see rs_set_tensor); bias only,
         * N % 64 == 0 */
-       RS_GEMM_GLU = 64 };
+       RS_GEMM_GLU = 64,
+       /* icefall's SwooshL / SwooshR activations (the Zipformer family; plain bf16 or f32 output only) */
+       RS_GEMM_SWOOSHL = 128, RS_GEMM_SWOOSHR = 256 };
 int rs_gemm_bf16(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                  void* out, int ldc, int M, int N, int K, int flags, const float* bias, float alpha,
                  const float* residual, const int32_t* mask_lens, int mask_rows_per_step,

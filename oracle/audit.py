@@ -18,6 +18,25 @@ whose top two logits are closer than that noise can move them may flip.  This mo
 import numpy as np
 
 
+def _decoder_view(cfg, sd):
+    """the decoder / joint tensors under the NeMo key names this module reads, whatever the model family: an ESPnet2 state
+    dict ([UPSTREAM] TransducerDecoder: one LSTM module per layer, JointNetwork: lin_dec without a bias, tanh) is re-keyed.
+    The walk itself is family-independent — tanh is 1-Lipschitz like ReLU, so the flip bound is the same, and ESPnet's
+    greedy_search (one symbol per frame) is the max_symbols = 1 case of the decision lists."""
+    if not getattr(cfg, "espnet", False):
+        return sd
+    import torch
+    out = {"decoder.prediction.embed.weight": sd["decoder.embed.weight"],
+           "joint.pred.weight": sd["joint_network.lin_dec.weight"],
+           "joint.pred.bias": torch.zeros((cfg.joint_hidden,), dtype=torch.float32),
+           "joint.joint_net.2.weight": sd["joint_network.lin_out.weight"],
+           "joint.joint_net.2.bias": sd["joint_network.lin_out.bias"]}
+    for l in range(cfg.pred_layers):
+        for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            out[f"decoder.prediction.dec_rnn.lstm.{nm}_l{l}"] = sd[f"decoder.decoder.{l}.{nm}_l0"]
+    return out
+
+
 def _sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
@@ -58,6 +77,8 @@ def flip_audit(cfg, sd, f_ref, f_hip, enc_len, hip_ids, hip_frames):
       path_ok        the float64 argmax on the HIP rows reproduces the HIP hypothesis at every point whose float64
                      top-2 margin exceeds 1e-3 (sanity of the walk itself; the bit-exact statement is the C oracle's)
     """
+    sd = _decoder_view(cfg, sd)
+    act = np.tanh if getattr(cfg, "espnet", False) else (lambda a: np.maximum(a, 0.0))
     f_ref = np.asarray(f_ref, np.float64)
     f_hip = np.asarray(f_hip, np.float64)
     wo = sd["joint.joint_net.2.weight"].detach().cpu().numpy().astype(np.float64)
@@ -75,8 +96,8 @@ def flip_audit(cfg, sd, f_ref, f_hip, enc_len, hip_ids, hip_frames):
         toks = by_frame.get(t, [])
         path = toks + ([blank] if len(toks) < cfg.max_symbols else [])
         for k in path:
-            z_ref = wo @ np.maximum(f_ref[t] + g, 0.0) + bo
-            z_hip = wo @ np.maximum(f_hip[t] + g, 0.0) + bo
+            z_ref = wo @ act(f_ref[t] + g) + bo
+            z_hip = wo @ act(f_hip[t] + g) + bo
             n_dec += 1
             top = np.argpartition(z_ref, -2)[-2:]
             margins.append(float(abs(z_ref[top[1]] - z_ref[top[0]])))
@@ -125,6 +146,8 @@ def flip_audit_batch(cfg, sd, f_ref, f_hip, enc_lens, hyp_ids, hyp_frames, devic
       enc_lens       B ints;  hyp_ids / hyp_frames: the AUDITED side's hypotheses (lists of lists)
     -> list of per-row dicts with the keys of `flip_audit` (margins as numpy float64 arrays)."""
     import torch
+    sd = _decoder_view(cfg, sd)
+    act = torch.tanh if getattr(cfg, "espnet", False) else torch.relu
     dev = torch.device(device)
     f64 = lambda t: t.detach().to(device=dev, dtype=torch.float64)  # noqa: E731
     B = len(enc_lens)
@@ -186,8 +209,8 @@ def flip_audit_batch(cfg, sd, f_ref, f_hip, enc_lens, hyp_ids, hyp_frames, devic
     for d in range(D):
         t, k, v = T[:, d], K[:, d], V[:, d]
         fr_t, fh_t = fr[rows_idx, t], fh[rows_idx, t]
-        z_ref = torch.relu(fr_t + g) @ wo.t() + bo
-        z_hip = torch.relu(fh_t + g) @ wo.t() + bo
+        z_ref = act(fr_t + g) @ wo.t() + bo
+        z_hip = act(fh_t + g) @ wo.t() + bo
         top2 = z_ref.topk(2, dim=1).values
         margins[:, d] = top2[:, 0] - top2[:, 1]
         k_ref = z_ref.argmax(dim=1)

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = [os.path.join(HERE, n) for n in ("rnnt_greedy.c", "rnnt_alsd.c", "espnet_beam.c")]
+SOURCES = [os.path.join(HERE, n) for n in ("rnnt_greedy.c", "rnnt_alsd.c", "espnet_beam.c", "k2_greedy.c")]
 DEPENDS = SOURCES + [os.path.join(HERE, "rnnt_math.h")]
 OUT = os.path.join(HERE, "librs_oracle.so")
 

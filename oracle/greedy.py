@@ -162,3 +162,27 @@ def espnet_beam(cfg, sd, f, enc_lens, beam=20, score_norm=True, max_pops=None, o
     if with_frames:
         return [(ids[b, :n_ids[b]].tolist(), frames[b, :n_ids[b]].tolist(), float(scores[b]), int(pops[b])) for b in range(B)]
     return [(ids[b, :n_ids[b]].tolist(), float(scores[b]), int(pops[b])) for b in range(B)]
+
+
+def k2_greedy(cfg, sd, f, enc_lens, u_max=None):
+    """Zipformer family (oracle/k2_greedy.c): f float32 [B, Tp, J] = joiner.encoder_proj(encoder output), enc_lens int[B]
+    -> list of (ids, frames) per utterance under sherpa-onnx's offline greedy search with icefall's stateless decoder."""
+    L = lib()
+    L.rs_oracle_k2_greedy.restype = ctypes.c_int
+    c = lambda k: np.ascontiguousarray(sd[k].numpy(), dtype=np.float32)  # noqa: E731
+    f = np.ascontiguousarray(f, dtype=np.float32)
+    B, Tp, J = f.shape
+    enc_lens = np.ascontiguousarray(enc_lens, dtype=np.int32)
+    if u_max is None:
+        u_max = max(Tp, 1)
+    ids = np.zeros((B, u_max), np.int32)
+    frames = np.zeros((B, u_max), np.int32)
+    n_ids = np.zeros((B,), np.int32)
+    embed, conv_w = c("decoder.embedding.weight"), c("decoder.conv.weight")
+    wp, bp = c("joiner.decoder_proj.weight"), c("joiner.decoder_proj.bias")
+    wo, bo = c("joiner.output_linear.weight"), c("joiner.output_linear.bias")
+    rc = L.rs_oracle_k2_greedy(_fp(f), _ip(enc_lens), B, Tp, J, cfg.decoder_dim, cfg.vocab_size, cfg.blank_id, cfg.unk_id, _fp(embed),
+                               _fp(conv_w), _fp(wp), _fp(bp), _fp(wo), _fp(bo), u_max, _ip(ids), _ip(frames), _ip(n_ids))
+    if rc != 0:
+        raise RuntimeError(f"oracle k2 greedy overflowed u_max={u_max}")
+    return [(ids[b, :n_ids[b]].tolist(), frames[b, :n_ids[b]].tolist()) for b in range(B)]

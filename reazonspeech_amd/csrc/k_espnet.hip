@@ -15,14 +15,19 @@
 
 namespace {
 
+__device__ __forceinline__ void store_act(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+__device__ __forceinline__ void store_act(float* p, float v) { *p = v; }
+
 // grid (T1, Bc), block 256: a thread owns channels c = tid, tid + 256, ...; the three mel rows of this output row sit in LDS
+// (OutT = uint16_t: bf16 for the throughput mode; float: the float32 parity mode)
+template <typename OutT>
 __global__ __launch_bounds__(256) void sub2d_conv0_kernel(const float* __restrict__ feats, const int32_t* __restrict__ lens1 /* [B] valid T1 rows */,
                                                           int b0, int t_max, int n_mels, int T1, int F1, int C,
                                                           const float* __restrict__ w0 /* [9][C] */, const float* __restrict__ bias,
-                                                          uint16_t* __restrict__ out) {
+                                                          OutT* __restrict__ out) {
     __shared__ float rows[3][132];
     const int t1 = blockIdx.x, bl = blockIdx.y, b = b0 + bl;
-    uint16_t* orow = out + (((size_t)bl * T1 + t1) * F1) * C;
+    OutT* orow = out + (((size_t)bl * T1 + t1) * F1) * C;
     if (t1 >= lens1[b]) {                           // rows past the utterance: zeros (never read by a valid output row)
         for (int i = threadIdx.x; i < F1 * C; i += 256) orow[i] = 0;
         return;
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(256) void sub2d_conv0_kernel(const float* __restric
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc = fmaf(k[i * 3 + j], rows[i][2 * f1 + j], acc);
-            orow[(size_t)f1 * C + c] = f32_to_bf16(fmaxf(acc, 0.0f));
+            store_act(orow + (size_t)f1 * C + c, fmaxf(acc, 0.0f));
         }
     }
 }
@@ -53,17 +58,17 @@ __global__ __launch_bounds__(256) void sub2d_conv0_kernel(const float* __restric
 // and ONE contiguous run of 9 C in the output; a thread moves 16 bytes at a time (9 C / 8 = 576 moves at C = 512).
 // (One 64-thread workgroup per tap — 1 KB each, 766k workgroups per chunk — was dispatch-bound: 417 us per chunk for 1.2 GB.)
 // grid (F2, Bc * T2), block 256
-__global__ __launch_bounds__(256) void im2col3x3s2_kernel(const uint16_t* __restrict__ in /* [Bc][T1][F1][C] */, int T1, int F1,
-                                                          int T2, int F2, int C, uint16_t* __restrict__ out /* [Bc*T2*F2][9*C] */) {
+// (element-size generic: `c8` = 16-byte pieces per C channels — C / 8 for bf16, C / 4 for the float32 parity mode)
+__global__ __launch_bounds__(256) void im2col3x3s2_kernel(const uint4* __restrict__ in /* [Bc][T1][F1][c8] */, int T1, int F1,
+                                                          int T2, int F2, int c8, uint4* __restrict__ out /* [Bc*T2*F2][9*c8] */) {
     const int f2 = blockIdx.x, bt = blockIdx.y;
     const int bl = bt / T2, t2 = bt - bl * T2;
-    const int c8 = C / 8;
-    uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)bt * F2 + f2) * 9 * C);
-    const uint16_t* base = in + (((size_t)bl * T1 + 2 * t2) * F1 + 2 * f2) * C;
+    uint4* dst = out + ((size_t)bt * F2 + f2) * 9 * c8;
+    const uint4* base = in + (((size_t)bl * T1 + 2 * t2) * F1 + 2 * f2) * c8;
     for (int q = threadIdx.x; q < 9 * c8; q += 256) {
         const int tap = q / c8, c = q - tap * c8;
         const int i = tap / 3, j = tap - 3 * i;
-        dst[q] = reinterpret_cast<const uint4*>(base + ((size_t)i * F1 + j) * C)[c];
+        dst[q] = base[((size_t)i * F1 + j) * c8 + c];
     }
 }
 
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(256) void ctc_softmax_kernel(float* __restrict__ z,
         p[v] = q;
         if (v == blank && blank_out) blank_out[row] = q;
     }
+    for (int v = V + lane; v < ld; v += 64) p[v] = 0.0f;       // the columns that pad the vocabulary to a multiple of 4
 }
 
 }  // namespace
@@ -95,10 +101,23 @@ int rs_launch_sub2d_conv0(rs_ctx* ctx, const float* feats, const int32_t* lens1,
     const int C = d.sub_channels;
     if (d.n_mels > 128 || 2 * (F1 - 1) + 2 >= d.n_mels + 1) return rs_fail(ctx, RS_EINVAL, "conv2d subsampling: n_mels %d / F1 %d", d.n_mels, F1);
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, (double)Bc * T1 * F1 * C * 18.0, (double)Bc * (t_max * d.n_mels * 4.0 + (double)T1 * F1 * C * 2.0));
-    hipLaunchKernelGGL(sub2d_conv0_kernel, dim3(T1, Bc), dim3(256), 0, s, feats, lens1, b0, t_max, d.n_mels, T1, F1, C,
+    hipLaunchKernelGGL(sub2d_conv0_kernel<uint16_t>, dim3(T1, Bc), dim3(256), 0, s, feats, lens1, b0, t_max, d.n_mels, T1, F1, C,
                        ctx->sub_conv0_w, ctx->sub_conv0_b, out);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
     RS_CHECK_LAUNCH(ctx, "sub2d_conv0");
+    return RS_OK;
+}
+
+int rs_launch_sub2d_conv0_f32(rs_ctx* ctx, const float* feats, const int32_t* lens1, int b0, int Bc, int t_max, int T1, int F1,
+                              float* out, hipStream_t s) {
+    const rs_dims& d = ctx->d;
+    const int C = d.sub_channels;
+    if (d.n_mels > 128 || 2 * (F1 - 1) + 2 >= d.n_mels + 1) return rs_fail(ctx, RS_EINVAL, "conv2d subsampling: n_mels %d / F1 %d", d.n_mels, F1);
+    rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, (double)Bc * T1 * F1 * C * 18.0, (double)Bc * (t_max * d.n_mels * 4.0 + (double)T1 * F1 * C * 4.0));
+    hipLaunchKernelGGL(sub2d_conv0_kernel<float>, dim3(T1, Bc), dim3(256), 0, s, feats, lens1, b0, t_max, d.n_mels, T1, F1, C,
+                       ctx->sub_conv0_w, ctx->sub_conv0_b, out);
+    rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
+    RS_CHECK_LAUNCH(ctx, "sub2d_conv0_f32");
     return RS_OK;
 }
 
@@ -107,9 +126,22 @@ int rs_launch_im2col3x3s2(rs_ctx* ctx, const uint16_t* in, int Bc, int T1, int F
     if (C % 8) return rs_fail(ctx, RS_EINVAL, "im2col: channels %d must be a multiple of 8", C);
     if ((long long)Bc * T2 > 65535LL) return rs_fail(ctx, RS_EINVAL, "im2col: chunk of %d x %d rows exceeds the grid", Bc, T2);
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, (double)Bc * T2 * F2 * 9.0 * C * 2.0 * 2.0);
-    hipLaunchKernelGGL(im2col3x3s2_kernel, dim3(F2, Bc * T2), dim3(256), 0, s, in, T1, F1, T2, F2, C, out);
+    hipLaunchKernelGGL(im2col3x3s2_kernel, dim3(F2, Bc * T2), dim3(256), 0, s, reinterpret_cast<const uint4*>(in), T1, F1, T2, F2, C / 8,
+                       reinterpret_cast<uint4*>(out));
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
     RS_CHECK_LAUNCH(ctx, "im2col3x3s2");
+    return RS_OK;
+}
+
+int rs_launch_im2col3x3s2_f32(rs_ctx* ctx, const float* in, int Bc, int T1, int F1, int T2, int F2, float* out, hipStream_t s) {
+    const int C = ctx->d.sub_channels;
+    if (C % 4) return rs_fail(ctx, RS_EINVAL, "im2col: channels %d must be a multiple of 4", C);
+    if ((long long)Bc * T2 > 65535LL) return rs_fail(ctx, RS_EINVAL, "im2col: chunk of %d x %d rows exceeds the grid", Bc, T2);
+    rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, (double)Bc * T2 * F2 * 9.0 * C * 4.0 * 2.0);
+    hipLaunchKernelGGL(im2col3x3s2_kernel, dim3(F2, Bc * T2), dim3(256), 0, s, reinterpret_cast<const uint4*>(in), T1, F1, T2, F2, C / 4,
+                       reinterpret_cast<uint4*>(out));
+    rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
+    RS_CHECK_LAUNCH(ctx, "im2col3x3s2_f32");
     return RS_OK;
 }
 

@@ -225,28 +225,48 @@ __global__ __launch_bounds__(256) void glu_dwconv_silu_f32_kernel(const float* _
 
 struct EncPlanF32 {
     int T[5], F[5];
-    size_t off_lens, off_sa, off_sb, off_x, off_hn, off_big, off_ctx, off_posp, total;
+    size_t off_lens, off_sa, off_sb, off_col, off_x, off_hn, off_big, off_ctx, off_posp, off_ctc, total;
+    int chunk;       // Conv2dSubsampling: utterances per pass of conv0 / patch gather / dense-conv GEMM
 };
 
 EncPlanF32 plan_f32(const rs_ctx* ctx, int B, int t_max) {
     const rs_dims& d = ctx->d;
     EncPlanF32 p{};
     p.T[0] = t_max; p.F[0] = d.n_mels;
-    for (int s = 1; s <= d.sub_stages; ++s) { p.T[s] = (p.T[s - 1] + 2 - 3) / 2 + 1; p.F[s] = (p.F[s - 1] + 2 - 3) / 2 + 1; }
+    for (int s = 1; s <= d.sub_stages; ++s) { p.T[s] = rs_conv_len(p.T[s - 1], d.sub_kind); p.F[s] = rs_conv_len(p.F[s - 1], d.sub_kind); }
     const size_t C = d.sub_channels, dm = d.d_model;
-    const size_t Tp = p.T[d.sub_stages], M = (size_t)B * Tp;
+    const size_t Tp = p.T[d.sub_stages] > 0 ? p.T[d.sub_stages] : 1, M = (size_t)B * Tp;
     size_t widest = (size_t)d.ff_dim;
     if (3 * dm > widest) widest = 3 * dm;
     size_t o = 0;
     p.off_lens = o; o += rs_align((size_t)4 * B * 4);
-    const size_t sub_elems = (size_t)B * p.T[2] * p.F[2] * C;
-    p.off_sa = o; o += rs_align(sub_elems * 4);
-    p.off_sb = o; o += rs_align(sub_elems * 4);
+    p.chunk = B;
+    p.off_col = 0;
+    if (d.sub_kind == 1) {
+        // the layout of rs_api.hip's plan_encoder with float32 elements: conv0 output and 3x3 patches of ONE chunk of
+        // utterances (patch matrix near 1 GiB), the dense conv's output of the whole batch
+        const size_t T2 = p.T[2] > 0 ? p.T[2] : 1;
+        const size_t per_utt_col = T2 * p.F[2] * 9 * C * 4;
+        size_t chunk = ((size_t)1 << 30) / per_utt_col;
+        if (chunk < 1) chunk = 1;
+        if (chunk > (size_t)B) chunk = (size_t)B;
+        while (chunk > 1 && chunk * T2 > 65535) --chunk;
+        p.chunk = (int)chunk;
+        p.off_sa = o; o += rs_align(chunk * (size_t)(p.T[1] > 0 ? p.T[1] : 1) * p.F[1] * C * 4);
+        p.off_col = o; o += rs_align(chunk * per_utt_col);
+        p.off_sb = o; o += rs_align((size_t)B * T2 * p.F[2] * C * 4);
+    } else {
+        const size_t sub_elems = (size_t)B * p.T[2] * p.F[2] * C;
+        p.off_sa = o; o += rs_align(sub_elems * 4);
+        p.off_sb = o; o += rs_align(sub_elems * 4);
+    }
     p.off_x = o; o += rs_align(M * dm * 4);
     p.off_hn = o; o += rs_align(M * dm * 4);
     p.off_big = o; o += rs_align(M * widest * 4);
     p.off_ctx = o; o += rs_align(M * dm * 4);
     p.off_posp = o; o += rs_align((2 * Tp) * dm * 4);
+    p.off_ctc = o;
+    if (d.ctc_vocab > 0) o += rs_align(M * (size_t)rs_ctc_pad(d.ctc_vocab) * 4);
     p.total = o + 256;
     return p;
 }
@@ -336,8 +356,22 @@ int rs_encoder_forward_f32(rs_ctx* ctx, const float* feats, const int32_t* n_fra
     };
     // ---- subsampling
     RS_TRY(rs_launch_enc_lens(ctx, n_frames, B, lens_stage, s));
+    if (Tp <= 0) return rs_fail(ctx, RS_EINVAL, "encoder (float32 mode): %d feature frames are too few for the subsampling", t_max);
+    if (d.sub_kind == 1) {
+        // ESPnet Conv2dSubsampling in float32: conv0 -> 3x3 patches -> the dense conv as one exact-f32 GEMM per chunk of utterances
+        float* col = reinterpret_cast<float*>(ws + pl.off_col);
+        const int T1 = pl.T[1], F1 = pl.F[1], T2 = pl.T[2], F2 = pl.F[2];
+        for (int b0 = 0; b0 < B; b0 += pl.chunk) {
+            const int bc = B - b0 < pl.chunk ? B - b0 : pl.chunk;
+            RS_TRY(rs_launch_sub2d_conv0_f32(ctx, feats, lens_stage, b0, bc, t_max, T1, F1, sa, s));
+            RS_TRY(rs_launch_im2col3x3s2_f32(ctx, sa, bc, T1, F1, T2, F2, col, s));
+            RS_TRY(rs_launch_gemm_f32(ctx, col, 9 * C, w.sub_conv1_w, 9 * C, sb + (size_t)b0 * T2 * F2 * C, C, bc * T2 * F2, C, 9 * C,
+                                      RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_ROWMASK, ctx->sub_conv1_b, 1.0f, nullptr,
+                                      lens_stage + B + b0, F2, T2, s));
+        }
+    } else
     RS_TRY(rs_launch_sub_conv0_dw1_f32(ctx, feats, lens_stage, B, t_max, pl.T[2], pl.F[2], sa, s));
-    for (int st = 2; st <= S; ++st) {
+    for (int st = 2; st <= S && d.sub_kind == 0; ++st) {
         if (st > 2)
             RS_TRY(rs_launch_sub_dw_f32(ctx, sb, ctx->sub_dw_w[st - 2], ctx->sub_dw_b[st - 2], lens_stage + (st - 1) * B, B,
                                         pl.T[st - 1], pl.F[st - 1], pl.T[st], pl.F[st], sa, s));
@@ -386,8 +420,16 @@ int rs_encoder_forward_f32(rs_ctx* ctx, const float* feats, const int32_t* n_fra
             if (ctx->tap_ids[k] == i)
                 RS_HIP(ctx, hipMemcpyAsync(ctx->tap_layers + k * (size_t)M * dm, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
     }
+    // ESPnet: the encoder's after_norm on top of the last block's norm_final
+    if (d.final_norm) RS_TRY(rs_launch_layernorm(ctx, x, ctx->final_norm_g, ctx->final_norm_b, M, dm, d.ln_eps, nullptr, x, s));
     if (enc_out) RS_HIP(ctx, hipMemcpyAsync(enc_out, x, (size_t)M * dm * 4, hipMemcpyDeviceToDevice, s));
     RS_TRY(gemm(x, dm, w.jenc_w, dm, joint_enc, d.joint_hidden, M, d.joint_hidden, RS_GEMM_BIAS, ctx->jenc_b, 1.0f, nullptr));
+    if (d.ctc_vocab > 0 && (ctx->ctc_probs || ctx->ctc_blank)) {
+        const int Vp = rs_ctc_pad(d.ctc_vocab);
+        float* z = ctx->ctc_probs ? ctx->ctc_probs : reinterpret_cast<float*>(ws + pl.off_ctc);
+        RS_TRY(gemm(x, dm, w.ctc_w, dm, z, Vp, M, Vp, RS_GEMM_BIAS, ctx->ctc_b, 1.0f, nullptr));
+        RS_TRY(rs_launch_ctc_softmax(ctx, z, M, d.ctc_vocab, Vp, d.blank_id, ctx->ctc_blank, s));
+    }
 #undef RS_TRY
     return RS_OK;
 }

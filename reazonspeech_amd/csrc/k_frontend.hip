@@ -33,7 +33,11 @@ struct FrontParams {
     int audio_stride, pad_left, pad_right, t_max, n_mels, win_length, hop;
     float preemph, log_guard;
     int kind;              // 0: NeMo (zero edge padding, floor(L / hop) frames, log(x + guard)); 1: ESPnet DefaultFrontend
-                           // (reflect edge padding, 1 + floor(L / hop) frames, log(max(x, guard)); normalised by feat_mvn_kernel)
+                           // (reflect edge padding, 1 + floor(L / hop) frames, log(max(x, guard)); normalised by feat_mvn_kernel);
+                           // 2: kaldi-native-fbank as sherpa-onnx configures it (reazonspeech.k2.asr): snip_edges = false — frame f
+                           // covers samples [hop f + hop / 2 - win / 2, .. + win), edges REFLECTED (-1 -> 0, L -> L - 1) —, per frame:
+                           // subtract the mean, x[i] -= preemph x[i - 1] (x[0] -= preemph x[0]), window, log(max(x, guard)); the
+                           // features are written as they are (no normalisation)
 };
 
 __device__ __forceinline__ float fetch_sample(const float* __restrict__ a, int i, int pad_left, int len) {
@@ -93,7 +97,8 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
     const int b = blockIdx.y;
     const int len = p.lens[b];
     const int Lp = len + p.pad_left + p.pad_right;       // padded length (reference: after pad_audio)
-    const int n_valid = Lp / p.hop + (p.kind == 1 ? 1 : 0);   // NeMo: floor((Lp + 2*(n_fft/2) - n_fft) / hop); ESPnet Stft keeps the last frame
+    const int n_valid = p.kind == 2 ? (Lp + p.hop / 2) / p.hop
+                                    : Lp / p.hop + (p.kind == 1 ? 1 : 0);   // NeMo: floor((Lp + 2*(n_fft/2) - n_fft) / hop); ESPnet Stft keeps the last frame
     if (blockIdx.x == 0 && threadIdx.x == 0) p.n_frames[b] = n_valid;
     const float* a = p.audio + (size_t)b * p.audio_stride;
     if ((int)blockIdx.x * WAVES * FRAMES_PER_WAVE >= min(n_valid, p.t_max)) return;  // block-uniform
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
     // outside [0, Lp) is zero, and y[0] = x[0] has no predecessor.
     const int centre_off = (NFFT - p.win_length) / 2;     // 56: window centred in the 512 frame
     const int f0 = blockIdx.x * WAVES * FRAMES_PER_WAVE;
-    const int i_base = f0 * p.hop - NFFT / 2 + centre_off;
+    const int i_base = p.kind == 2 ? f0 * p.hop + p.hop / 2 - p.win_length / 2 : f0 * p.hop - NFFT / 2 + centre_off;
     const int span = (WAVES * FRAMES_PER_WAVE - 1) * p.hop + NFFT;
     for (int idx = threadIdx.x; idx < span; idx += blockDim.x) {
         int i = i_base + idx;
@@ -114,9 +119,14 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
             i = i >= Lp ? 2 * (Lp - 1) - i : i;
             i = i < 0 ? 0 : i;                            // (an utterance shorter than n_fft / 2: torch refuses it, clamp)
         }
+        if (p.kind == 2 && Lp > 0) {                      // kaldi ExtractWindow: reflect without repeating the end sample, as often as needed
+            for (int bounce = 0; bounce < 8 && (i < 0 || i >= Lp); ++bounce) i = i < 0 ? -i - 1 : 2 * Lp - 1 - i;
+            i = i < 0 ? 0 : (i >= Lp ? Lp - 1 : i);
+        }
         if (i >= 0 && i < Lp) {
             const float x0 = fetch_sample(a, i, p.pad_left, len);
-            y = i >= 1 ? x0 - p.preemph * fetch_sample(a, i - 1, p.pad_left, len) : x0;
+            if (p.kind == 2) y = x0;                      // DC removal and pre-emphasis are per FRAME (below)
+            else y = i >= 1 ? x0 - p.preemph * fetch_sample(a, i - 1, p.pad_left, len) : x0;
         }
         ys[idx] = y;
     }
@@ -137,6 +147,19 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
         if (t >= n_valid || t >= p.t_max) return 0.0f;
         return ys[(t - f0) * p.hop + n] * win_s[n];
     };
+    // kaldi: (x[n] - mean) - preemph (x[n - 1] - mean), the first sample against itself; mean over the frame's win_length samples
+    auto frame_mean = [&](int t) -> float {
+        if (t >= n_valid || t >= p.t_max) return 0.0f;
+        float sm = 0.0f;
+        for (int n = lane; n < p.win_length; n += 64) sm += ys[(t - f0) * p.hop + n];
+        return wave_sum(sm) / (float)p.win_length;
+    };
+    auto sample_kaldi = [&](int t, int n, float mean) -> float {
+        if (t >= n_valid || t >= p.t_max || n >= p.win_length) return 0.0f;
+        const float* fr = ys + (t - f0) * p.hop;
+        const float cur = fr[n] - mean, prev = fr[n > 0 ? n - 1 : 0] - mean;
+        return (cur - p.preemph * prev) * win_s[n];
+    };
     const int k1 = lane & 7, hi = lane >> 3;              // (k1, l2) in the second step, (k1, m1) in the third
 
     for (int fi = 0; fi < FRAMES_PER_WAVE; fi += 2) {
@@ -146,8 +169,14 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
         // ---- step 1: two frames, samples n = lane + 64 k.  A circular shift of the FFT input only changes the phase,
         // so the 400 samples sit at n = 0 .. 399 directly.
         float2 v[8];
+        if (p.kind == 2) {
+            const float m0 = frame_mean(t), m1 = frame_mean(t + 1);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = make_float2(sample(t, lane + 64 * k), sample(t + 1, lane + 64 * k));
+            for (int k = 0; k < 8; ++k) v[k] = make_float2(sample_kaldi(t, lane + 64 * k, m0), sample_kaldi(t + 1, lane + 64 * k, m1));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = make_float2(sample(t, lane + 64 * k), sample(t + 1, lane + 64 * k));
+        }
         dft8(v);
 #pragma unroll
         for (int q = 0; q < 8; ++q) z[q * 68 + lane] = q ? cmul(v[q], w512(lane * q)) : v[q];
@@ -186,7 +215,7 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_kernel(FrontParams p) {
                 const float* w = p.fb_w + m * FB_MAXW;
                 float acc = 0.0f;
                 for (int j = 0; j < cnt; ++j) acc = fmaf(w[j], pw[wave][f][k0 + j], acc);
-                p.raw[((size_t)b * p.t_max + t + f) * p.n_mels + m] = p.kind == 1 ? logf(fmaxf(acc, p.log_guard)) : logf(acc + p.log_guard);
+                p.raw[((size_t)b * p.t_max + t + f) * p.n_mels + m] = p.kind >= 1 ? logf(fmaxf(acc, p.log_guard)) : logf(acc + p.log_guard);
             }
         }
         wave_sync();
@@ -302,10 +331,15 @@ int rs_launch_frontend(rs_ctx* ctx, const float* audio, const int32_t* lens, int
     p.kind = d.frontend_kind;
     const int fpb = WAVES * FRAMES_PER_WAVE;
     const dim3 grid((t_max + fpb - 1) / fpb, B), block(64 * WAVES);
+    if (d.frontend_kind == 2) {                   // kaldi fbank: the log-mel energies ARE the features; frames past an utterance are zeros
+        p.raw = feats;
+        RS_HIP(ctx, hipMemsetAsync(feats, 0, (size_t)B * t_max * d.n_mels * 4, s));
+    }
     const double bytes = (double)B * ((double)t_max * d.hop_length * 4.0 + (double)t_max * d.n_mels * 4.0 * 3.0);
     rs_prof_begin(ctx, RS_PROF_FRONTEND, s, (double)B * t_max * (5.0 * 512 * 9 + 3 * 257 + 2 * 600), bytes);
     hipLaunchKernelGGL(logmel_kernel, grid, block, 0, s, p);
-    if (d.frontend_kind == 1)
+    if (d.frontend_kind == 2) {
+    } else if (d.frontend_kind == 1)
         hipLaunchKernelGGL(feat_mvn_kernel, dim3((t_max * d.n_mels + 255) / 256, B), dim3(256), 0, s, raw, n_frames, t_max, d.n_mels,
                            ctx->fe_mvn_mean, ctx->fe_mvn_istd, feats);
     else

@@ -117,6 +117,9 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
     const int frow = lane & 15, fch = lane >> 4;
     const int flags = p.flags;
     const bool has_bias = flags & RS_GEMM_BIAS, relu = flags & RS_GEMM_RELU, silu = flags & RS_GEMM_SILU;
+    // the Swoosh activations exist in the plain bf16 / f32 epilogues only: the residual and GLU instantiations stay as they were
+    constexpr bool SWOOSH = OUT == OUT_BF16 || OUT == OUT_F32;
+    const bool swl = SWOOSH && (flags & RS_GEMM_SWOOSHL), swr = SWOOSH && (flags & RS_GEMM_SWOOSHR);
     const float alpha = p.alpha;
     // GLU: the output has N / 2 columns (ldc is the caller's row pitch of that narrower matrix).  The launcher keeps
     // M * ldc * element size below 2^31 (it cuts a taller problem into row chunks).
@@ -139,6 +142,10 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
                                acc[i][jj][3] + bias_r[jj].w);
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        if constexpr (SWOOSH) {
+            if (swl) { v.x = swoosh_l_f(v.x); v.y = swoosh_l_f(v.y); v.z = swoosh_l_f(v.z); v.w = swoosh_l_f(v.w); }
+            if (swr) { v.x = swoosh_r_f(v.x); v.y = swoosh_r_f(v.y); v.z = swoosh_r_f(v.z); v.w = swoosh_r_f(v.w); }
+        }
         v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
         return v;
     };
@@ -686,10 +693,12 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
                            ((uintptr_t)a.res_ln_b & 15) || ((uintptr_t)a.res_ln_stats & 7)))
         return rs_fail(ctx, RS_EINVAL, "gemm: a normalised residual needs the residual flag, row statistics and aligned weight / bias");
     if (a.flags & RS_GEMM_GLU) {
-        if (a.flags & (RS_GEMM_RELU | RS_GEMM_SILU | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32 | RS_GEMM_ROWMASK))
+        if (a.flags & (RS_GEMM_RELU | RS_GEMM_SILU | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32 | RS_GEMM_ROWMASK | RS_GEMM_SWOOSHL | RS_GEMM_SWOOSHR))
             return rs_fail(ctx, RS_EINVAL, "gemm: GLU combines with a bias only");
         if ((a.N % 64) || a.alpha != 1.0f) return rs_fail(ctx, RS_EINVAL, "gemm: GLU needs N %% 64 == 0 and alpha == 1 (N=%d)", a.N);
     }
+    if ((a.flags & (RS_GEMM_SWOOSHL | RS_GEMM_SWOOSHR)) && (a.flags & RS_GEMM_RESIDUAL))
+        return rs_fail(ctx, RS_EINVAL, "gemm: the Swoosh activations combine with plain bf16 / f32 output only");
     if ((size_t)a.N * a.ldw * 2 >= (1ull << 32)) return rs_fail(ctx, RS_EINVAL, "gemm: weight matrix beyond 4 GiB");
     gemm_knobs_from_env();
     if (ctx->n_cus <= 0) {

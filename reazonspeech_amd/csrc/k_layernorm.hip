@@ -362,6 +362,84 @@ __global__ __launch_bounds__(256) void dwconv_silu_dma_kernel(const uint16_t* __
     }
 }
 
+// Depthwise Conv1d over time for a compile-time kernel size K on the already-gated layout ([M][d] bf16), any d % 64 == 0:
+// the ESPnet conformer's k = 31 conv module and the Zipformer family's k = 31 / 15 / 7 modules (bias, no BatchNorm, SwooshR).
+// A workgroup makes 128 frames x 64 channels: thread = (8 channels, 4 CONSECUTIVE frames); the input tile (128 + K - 1 frames,
+// zero outside [0, min(T, len))) and the K taps are staged in LDS once; a thread reads each of its 4 + K - 1 input rows and each
+// tap once (a sliding window: 48 LDS bytes per 32 FMAs where the generic kernel reads 48 per 8).  Rows are 160 bytes apart so
+// that the 16 lanes a ds_read_b128 serves together (2 time lanes x 8 channel groups) cover all banks.
+// ACT: 0 = SiLU (conformer conv module, BatchNorm folded into w / bias), 1 = SwooshR (icefall ConvolutionModule).
+template <int K, int ACT>
+__global__ __launch_bounds__(256) void dwconv_act_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const int32_t* __restrict__ lens,
+                                                         int T, int d, uint16_t* __restrict__ out) {
+    constexpr int R = 4, TTF = 32 * R, ROWS = TTF + K - 1, HALF = (K - 1) / 2, PITCH = 80;   // bf16 elements per LDS row
+    __shared__ __attribute__((aligned(16))) uint16_t xs[ROWS * PITCH];
+    __shared__ __attribute__((aligned(16))) float ws[K * 64];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * TTF;
+    const int cg = threadIdx.x & 7, tl = threadIdx.x >> 3;
+    int len = lens[b];
+    len = len < T ? len : T;
+    for (int idx = threadIdx.x; idx < ROWS * 8; idx += 256) {
+        const int r = idx >> 3, g = idx & 7;
+        const int t = t0 + r - HALF;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (t >= 0 && t < len) v = *reinterpret_cast<const uint4*>(x + ((size_t)b * T + t) * d + c0 + g * 8);
+        *reinterpret_cast<uint4*>(xs + r * PITCH + g * 8) = v;
+    }
+    for (int idx = threadIdx.x; idx < K * 16; idx += 256) {
+        const int j = idx >> 4, q = idx & 15;
+        *reinterpret_cast<float4*>(ws + j * 64 + q * 4) = *reinterpret_cast<const float4*>(w + (size_t)j * d + c0 + q * 4);
+    }
+    const int c = c0 + cg * 8;
+    float acc[R][8];
+    {
+        float bb[8];
+        *reinterpret_cast<float4*>(&bb[0]) = *reinterpret_cast<const float4*>(bias + c);
+        *reinterpret_cast<float4*>(&bb[4]) = *reinterpret_cast<const float4*>(bias + c + 4);
+#pragma unroll
+        for (int o = 0; o < R; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = bb[e];
+    }
+    __syncthreads();
+    // wt[o] holds tap (row - o) of this thread's channels, zero when that tap does not exist: every FMA is unconditional and
+    // the loop stays rolled (unrolled by R, so the rotation of the tap registers is a renaming; fully unrolled the compiler
+    // hoisted every load and spilled at K = 31)
+    float wt[R][8];
+#pragma unroll
+    for (int o = 0; o < R; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wt[o][e] = 0.0f;
+#pragma unroll 4
+    for (int row = 0; row < R + K - 1; ++row) {
+        const u16x8_t a = *reinterpret_cast<const u16x8_t*>(xs + (tl * R + row) * PITCH + cg * 8);
+#pragma unroll
+        for (int o = R - 1; o > 0; --o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wt[o][e] = wt[o - 1][e];
+        const int jr = row < K ? row : 0;
+        const float4 w0 = *reinterpret_cast<const float4*>(ws + jr * 64 + cg * 8), w1 = *reinterpret_cast<const float4*>(ws + jr * 64 + cg * 8 + 4);
+        const float keep = row < K ? 1.0f : 0.0f;
+        wt[0][0] = w0.x * keep; wt[0][1] = w0.y * keep; wt[0][2] = w0.z * keep; wt[0][3] = w0.w * keep;
+        wt[0][4] = w1.x * keep; wt[0][5] = w1.y * keep; wt[0][6] = w1.z * keep; wt[0][7] = w1.w * keep;
+#pragma unroll
+        for (int o = 0; o < R; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(bf16_to_f32(a[e]), wt[o][e], acc[o][e]);
+    }
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+        const int t = t0 + tl * R + o;
+        if (t < T) {
+            u16x8_t ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = f32_to_bf16(ACT == 1 ? swoosh_r_f(acc[o][e]) : silu_f(acc[o][e]));
+            *reinterpret_cast<u16x8_t*>(out + ((size_t)b * T + t) * d + c) = ov;
+        }
+    }
+}
+
 int g_glu_generic = 0;
 
 }  // namespace
@@ -404,12 +482,38 @@ int rs_launch_layernorm2(rs_ctx* ctx, const float* x, const float* g1, const flo
     return RS_OK;
 }
 
+int rs_launch_dwconv_act(rs_ctx* ctx, const uint16_t* x, const float* w, const float* b, const int32_t* lens, int B, int T, int d, int k,
+                         int act, uint16_t* out, hipStream_t s) {
+    if (B <= 0 || T <= 0) return RS_OK;
+    if (d % 64) return rs_fail(ctx, RS_EINVAL, "dwconv: d=%d must be a multiple of 64", d);
+    if (act < 0 || act > 1) return rs_fail(ctx, RS_EINVAL, "dwconv: unknown activation %d", act);
+    const dim3 grid((T + 127) / 128, d / 64, B), block(256);
+    rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, (double)B * T * d * (2.0 * k + 12.0), (double)B * T * d * 4.0);
+#define RS_DW(KK)                                                                                              \
+    case KK:                                                                                                   \
+        if (act) hipLaunchKernelGGL((dwconv_act_kernel<KK, 1>), grid, block, 0, s, x, w, b, lens, T, d, out);  \
+        else hipLaunchKernelGGL((dwconv_act_kernel<KK, 0>), grid, block, 0, s, x, w, b, lens, T, d, out);      \
+        break;
+    switch (k) {
+        RS_DW(7) RS_DW(15) RS_DW(31)
+        default:
+            rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
+            return rs_fail(ctx, RS_EINVAL, "dwconv: kernel size %d is not built (7, 15, 31)", k);
+    }
+#undef RS_DW
+    rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
+    RS_CHECK_LAUNCH(ctx, "dwconv_act");
+    return RS_OK;
+}
+
 int rs_launch_glu_dwconv(rs_ctx* ctx, const uint16_t* x, int layout, const float* w, const float* b, const int32_t* lens,
                          int B, int T, int d, int k, uint16_t* out, hipStream_t s) {
     if (B <= 0 || T <= 0) return RS_OK;
     if (d % CT) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: d=%d must be a multiple of %d", d, CT);
     if (k < 1 || k > KMAX || !(k & 1)) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: kernel size %d unsupported", k);
     if (layout < 0 || layout > 2) return rs_fail(ctx, RS_EINVAL, "glu_dwconv: unknown input layout %d", layout);
+    // the gated layout with a kernel size the sliding-window kernel is built for (the ESPnet conformer's k = 31)
+    if (layout == 2 && (k == 7 || k == 15 || k == 31) && g_glu_generic != 1) return rs_launch_dwconv_act(ctx, x, w, b, lens, B, T, d, k, 0, out, s);
     const double bytes = (double)B * T * d * ((layout == 2 ? 2.0 : 4.0) + 2.0);
     rs_prof_begin(ctx, RS_PROF_ELEMENTWISE, s, (double)B * T * d * (2.0 * k + 12.0), bytes);
     if (k == 9 && g_glu_generic != 1) {

@@ -34,6 +34,7 @@ __global__ void rnnt_init_kernel(DecodeState st, const int32_t* __restrict__ enc
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         st.tcur[b] = 0; st.sym[b] = 0; st.token[b] = blank; st.act[b] = b;
+        if (st.token2) st.token2[b] = -1;                 // sherpa-onnx: the context starts as [-1, blank]
         n_ids[b] = 0;
         if (enc_lens[b] > 0) st.alive[atomicAdd(&n_alive_s, 1)] = b;
     }
@@ -376,12 +377,13 @@ __global__ __launch_bounds__(256) void rnnt_finalize_kernel(DecodeState st, cons
     if (lane != 0) return;
     int t = st.tcur[b], sy = st.sym[b];
     bool emitted = false;
-    if (idx == blank || idx == 0x7fffffff) {   // sentinel: every logit was NaN (cannot outrank -inf) -> treat as blank
+    if (idx == blank || idx == st.unk || idx == 0x7fffffff) {   // sentinel: every logit was NaN (cannot outrank -inf) -> treat as blank
         t += 1; sy = 0;
     } else {
         const int n = n_ids[b];
         if (n < u_max) { ids[(size_t)b * u_max + n] = idx; frames[(size_t)b * u_max + n] = t; n_ids[b] = n + 1; }
         else st.counters[1] = 1;
+        if (st.token2) st.token2[b] = st.token[b];
         st.token[b] = idx;
         emitted = true;
         sy += 1;
@@ -428,11 +430,12 @@ __global__ __launch_bounds__(256) void rnnt_finalize_la_kernel(DecodeState st, c
             const int oi = __shfl_xor(idx, off, 64);
             if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
         }
-        if (idx == blank || idx == 0x7fffffff) { t += 1; sy = 0; continue; }
+        if (idx == blank || idx == st.unk || idx == 0x7fffffff) { t += 1; sy = 0; continue; }
         if (lane == 0) {
             const int n = n_ids[b];
             if (n < u_max) { ids[(size_t)b * u_max + n] = idx; frames[(size_t)b * u_max + n] = t; n_ids[b] = n + 1; }
             else st.counters[1] = 1;
+            if (st.token2) st.token2[b] = st.token[b];
             st.token[b] = idx;
         }
         emitted = true;
@@ -817,6 +820,34 @@ __global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const 
 
 namespace {
 
+// ---- stateless decoder of the Zipformer family ([UPSTREAM] icefall decoder.py Decoder.forward(need_pad=False)): embedding of
+// the last two tokens (-1 embeds to zero), grouped Conv1d over them (groups = D / 4: output channel c sees input channels
+// 4 (c / 4) .. + 3 of both tokens, no bias), ReLU -> h_tmp[0][row][D], the operand of the joiner's decoder_proj
+// (rnnt_pred16_kernel).  Exact float32 in a fixed order (token before last first, then channel), mirrored by oracle/k2_greedy.c.
+// One workgroup per `act` row.
+__global__ __launch_bounds__(256) void k2_decoder_kernel(DecodeState st, int B, int D, const float* __restrict__ embed,
+                                                         const float* __restrict__ conv_w /* [D][4][2] */) {
+    const int n_rows = st.counters[0];
+    if ((int)blockIdx.x >= n_rows) return;
+    const int row = st.act[blockIdx.x];
+    const int t0 = st.token2[row], t1 = st.token[row];
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const int g4 = c & ~3;
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float e = t0 >= 0 ? embed[(size_t)t0 * D + g4 + i] : 0.0f;
+            acc = fmaf(conv_w[(c * 4 + i) * 2 + 0], e, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float e = t1 >= 0 ? embed[(size_t)t1 * D + g4 + i] : 0.0f;
+            acc = fmaf(conv_w[(c * 4 + i) * 2 + 1], e, acc);
+        }
+        st.h_tmp[(size_t)row * D + c] = fmaxf(acc, 0.0f);
+    }
+}
+
 constexpr int LSTM_LDS = SPLITK_LSTM * 4 * 32 * 16 * 4 + 32 * 4;
 constexpr int TILE_LDS = SPLITK_TILE * 32 * 65 * 4 + 32 * 4;
 
@@ -832,6 +863,11 @@ bool narrow_kernels_usable(const rs_ctx* ctx) {
 void launch_lstm_pred(rs_ctx* ctx, const DecodeState& st, int B, int rows_bound, bool narrow, hipStream_t s) {
     const int L = ctx->d.pred_layers, H = ctx->d.pred_hidden, J = ctx->d.joint_hidden;
     const int rts = (rows_bound + 31) / 32 > 0 ? (rows_bound + 31) / 32 : 1;
+    if (ctx->k2_conv_w) {                         // Zipformer family: the prediction network is the stateless decoder
+        hipLaunchKernelGGL(k2_decoder_kernel, dim3(rows_bound > 0 ? rows_bound : 1), dim3(256), 0, s, st, B, H, ctx->embed, ctx->k2_conv_w);
+        hipLaunchKernelGGL(rnnt_pred16_kernel, dim3((J + 15) / 16, rts), dim3(512), 0, s, st, B, 1, H, J, ctx->jpred_w, ctx->jpred_b);
+        return;
+    }
     if (narrow) {
         for (int l = 0; l < L; ++l)
             hipLaunchKernelGGL(rnnt_lstm4_kernel, dim3(H / 4, rts), dim3(1024), 0, s, st, l, B, H, ctx->embed, ctx->lstm_w4[l],
@@ -912,7 +948,7 @@ size_t rs_rnnt_workspace_bytes(const rs_ctx* ctx, int B) {
     size_t n = 0;
     n += 4 * rs_align((size_t)L * B * H * 4);
     n += rs_align((size_t)B * J * 4);
-    n += 6 * rs_align((size_t)B * 4);
+    n += 7 * rs_align((size_t)B * 4);
     n += rs_align(64);
     n += 2 * rs_align((size_t)B * LOOKAHEAD_MAX * nct * 4);
     const size_t vpad = (size_t)(d.n_logits + 15) / 16 * 16;
@@ -941,6 +977,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     st.g = (float*)take((size_t)B * J * 4);
     st.tcur = (int32_t*)take((size_t)B * 4); st.sym = (int32_t*)take((size_t)B * 4);
     st.token = (int32_t*)take((size_t)B * 4); st.act = (int32_t*)take((size_t)B * 4);
+    if (ctx->k2_conv_w) { st.token2 = (int32_t*)take((size_t)B * 4); st.unk = ctx->k2 ? rs_k2_unk_id(ctx) : -1; }
     st.alive = (int32_t*)take((size_t)2 * B * 4);
     st.counters = (int32_t*)take(64);
     st.pmax = (float*)take((size_t)B * LOOKAHEAD_MAX * nct * 4); st.pidx = (int32_t*)take((size_t)B * LOOKAHEAD_MAX * nct * 4);

@@ -64,6 +64,10 @@ struct DecodeState {
     const long long* g_off;   // rnnt_tile_kernel<3> only: [rows] offset (floats, from `g`) of row r's joint.pred vector
     const float* a_pre;       // rnnt_tile_kernel<4> only: [rows][J] act(f + g) of row r
     int joint_act;   // 0: relu(f + g) (NeMo RNNTJoint); 1: tanh(f + g) (ESPnet JointNetwork) — exact-tile kernels only
+    // Zipformer family (stateless decoder over the last two tokens; greedy search only): the token before `token`, and the id
+    // greedy search treats like blank besides the blank itself (sherpa-onnx: "<unk>" is not emitted); nullptr / -1 elsewhere
+    int32_t* token2 = nullptr;   // [B]
+    int unk = -1;
 };
 
 }  // namespace

@@ -1,0 +1,846 @@
+// k_zipformer.hip — the Zipformer2 encoder of `reazonspeech.k2.asr` (BASELINE.json configs[3]).
+//
+// The reference hands three ONNX files to sherpa-onnx (pkg/k2-asr/src/huggingface.py:73-83) and calls decode_stream once per
+// utterance (transcribe.py:36-39).  [UPSTREAM] the encoder file holds icefall's encoder_embed (Conv2dSubsampling), the
+// Zipformer2 stacks and joiner.encoder_proj (export-onnx.py OnnxEncoder); restated module by module in oracle/zipformer.py,
+// which this file is compared with.  What runs where:
+//
+//   dense contractions            every Linear / 1x1 conv / the third 3x3 conv (as patches) on gemm_smf16 (k_gemm_bf16.hip, MFMA
+//                                 16x16x32 bf16) with bias / SwooshL / SwooshR / GLU / f32-residual epilogues
+//   attention weights             k2_attn_weights_kernel: scores = q.k (one MFMA per 16 x 16 tile: head_dim 32 IS the MFMA's K)
+//                                 + p.pos[j - i] (4-wide position head on the VALU from an LDS-staged table), two-pass softmax,
+//                                 weights stored once as bf16 [B][H][T][T] and shared by the three consumers of a layer
+//   weights x values              k2_pv_kernel: MFMA over 32-key chunks, V^T staged in LDS; the non-linear attention's
+//                                 tanh gate and output gate are fused into its staging / epilogue
+//   everything else               HBM-bound element-wise kernels (casts, BiasNorm, bypass, down/up-sampling, depthwise convs)
+//
+// Batch semantics: the reference runs one utterance per call, so every kernel masks by the utterance's own length (keys past it
+// weigh 0, convolutions see zeros, SimpleDownsample repeats the utterance's own last frame): a row's result does not depend on
+// its batch mates.
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rs_common.h"
+
+struct rs_k2_layer {
+    const uint16_t *attw_in_w, *sa_in_w[2], *sa_out_w[2], *ff_in_w[3], *ff_out_w[3], *na_in_w, *na_out_w, *cm_in_w[2], *cm_out_w[2];
+    const float *attw_in_b, *pos_proj, *sa_in_b[2], *sa_out_b[2], *ff_in_b[3], *ff_out_b[3], *na_in_b, *na_out_b, *cm_in_b[2], *cm_dw_w[2],
+        *cm_dw_b[2], *cm_out_b[2], *norm_bias, *norm_scale, *bypass, *bypass_mid;
+};
+
+struct rs_k2 {
+    rs_k2_dims d{};
+    std::vector<std::vector<rs_k2_layer>> stacks;
+    const float *ds_w[8] = {}, *comb_scale[8] = {}, *out_ds_w = nullptr;
+    const float *conv0_w = nullptr, *conv0_b = nullptr, *conv1_w = nullptr, *conv1_b = nullptr, *conv2_b = nullptr, *cnx_dw_w = nullptr,
+                *cnx_dw_b = nullptr, *cnx_pw1_b = nullptr, *cnx_pw2_b = nullptr, *emb_out_b = nullptr, *emb_norm_bias = nullptr,
+                *emb_norm_scale = nullptr;
+    const uint16_t *conv2_w = nullptr, *cnx_pw1_w = nullptr, *cnx_pw2_w = nullptr, *emb_out_w = nullptr;
+    int pos_cap = 0;                 // rows of every "attw.pos_proj" table = 2 * pos_cap - 1
+    int embed_freq = 0, out_dim = 0;
+    float* tap_embed = nullptr;      // parity taps (rs_k2_encoder_set_taps)
+    float* tap_stacks = nullptr;
+};
+
+namespace {
+
+constexpr int K2_QD = 32, K2_PD = 4, K2_VD = 12;
+
+__host__ __device__ inline int pad64(int n) { return (n + 63) / 64 * 64; }
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- encoder_embed ---------------------------------------------------------------------------------------------------------
+// conv0: Conv2d(1, C1, 3, padding (0, 1)) + SwooshR.  feats f32 [B][T][F] -> a0 bf16 [B][T - 2][F][C1] (channels last)
+// grid (T1, B), block 256
+__global__ __launch_bounds__(256) void k2_conv0_kernel(const float* __restrict__ feats, int T, int F, int C1, const float* __restrict__ w /* [9][C1] */,
+                                                       const float* __restrict__ bias, uint16_t* __restrict__ out) {
+    __shared__ float rows[3][136];
+    const int t1 = blockIdx.x, b = blockIdx.y, T1 = T - 2;
+    for (int i = threadIdx.x; i < 3 * (F + 2); i += 256) {
+        const int r = i / (F + 2), f = i - r * (F + 2) - 1;
+        rows[r][f + 1] = (f >= 0 && f < F) ? feats[((size_t)b * T + t1 + r) * F + f] : 0.0f;
+    }
+    __syncthreads();
+    uint16_t* orow = out + ((size_t)b * T1 + t1) * F * C1;
+    for (int i = threadIdx.x; i < F * C1; i += 256) {
+        const int f = i / C1, c = i - f * C1;
+        float acc = bias[c];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) acc = fmaf(w[(kh * 3 + kw) * C1 + c], rows[kh][f + kw], acc);
+        orow[i] = f32_to_bf16(swoosh_r_f(acc));
+    }
+}
+
+// conv1: Conv2d(C1, C2, 3, stride 2) + SwooshR.  a0 bf16 [B][T1][F][C1] -> a1 bf16 [B][T2][F2][C2]; T2 = (T1 - 3) / 2 + 1.
+// grid (T2, B), block 256; the three input rows (3 x F x C1) and the weights (9 x C1 x C2) sit in LDS as f32
+__global__ __launch_bounds__(256) void k2_conv1_kernel(const uint16_t* __restrict__ a0, int T1, int F, int C1, int T2, int F2, int C2,
+                                                       const float* __restrict__ w /* [3][3][C1][C2] */, const float* __restrict__ bias,
+                                                       uint16_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rows = reinterpret_cast<float*>(smem);                 // [3][F * C1]
+    float* ws = rows + 3 * F * C1;                                 // [9 * C1][C2]
+    const int t2 = blockIdx.x, b = blockIdx.y;
+    for (int i = threadIdx.x; i < 3 * F * C1; i += 256) {
+        const int r = i / (F * C1), q = i - r * (F * C1);
+        rows[i] = bf16_to_f32(a0[((size_t)b * T1 + 2 * t2 + r) * F * C1 + q]);
+    }
+    for (int i = threadIdx.x; i < 9 * C1 * C2; i += 256) ws[i] = w[i];
+    __syncthreads();
+    uint16_t* orow = out + ((size_t)b * T2 + t2) * F2 * C2;
+    for (int i = threadIdx.x; i < F2 * C2; i += 256) {
+        const int f2 = i / C2, c2 = i - f2 * C2;
+        float acc = bias[c2];
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) {
+                const float* xr = rows + kh * F * C1 + (2 * f2 + kw) * C1;
+                const float* wr = ws + ((kh * 3 + kw) * C1) * C2 + c2;
+                for (int c1 = 0; c1 < C1; ++c1) acc = fmaf(wr[c1 * C2], xr[c1], acc);
+            }
+        orow[i] = f32_to_bf16(swoosh_r_f(acc));
+    }
+}
+
+// patches of conv2 = Conv2d(C2, C3, 3, stride (1, 2)): row (b, t3, f3) of the patch matrix holds the 3 x 3 x C2 inputs
+// a1[b][t3 + kh][2 f3 + kw][:] in (kh, kw, c) order, zero-padded to Kp columns.  One wave per row, 16-byte pieces.
+__global__ __launch_bounds__(256) void k2_im2col_kernel(const uint16_t* __restrict__ a1, int T2, int F2, int C2, int T3, int F3, int Kp,
+                                                        long long rows, uint16_t* __restrict__ col) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int f3 = (int)(row % F3);
+    const long long bt = row / F3;
+    const int t3 = (int)(bt % T3), b = (int)(bt / T3);
+    const int c8 = C2 / 8, n16 = Kp / 8;
+    uint4* dst = reinterpret_cast<uint4*>(col + row * Kp);
+    for (int q = lane; q < n16; q += 64) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (q < 9 * c8) {
+            const int tap = q / c8, c = q - tap * c8;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            v = reinterpret_cast<const uint4*>(a1 + (((size_t)b * T2 + t3 + kh) * F2 + 2 * f3 + kw) * C2)[c];
+        }
+        dst[q] = v;
+    }
+}
+
+// ConvNeXt depthwise 7 x 7 (padding 3) over (time, frequency), channels last.  a2 f32 [B][T3][F3][C] -> bf16 same shape.
+// Frames at or past the utterance's own length are zeros (the reference's single-utterance call ends there).
+// grid (T3, B), block 256
+__global__ __launch_bounds__(256) void k2_cnx_dw_kernel(const float* __restrict__ a2, const int32_t* __restrict__ lens3, int T3, int F3, int C,
+                                                        const float* __restrict__ w /* [49][C] */, const float* __restrict__ bias,
+                                                        uint16_t* __restrict__ out) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    int len = lens3[b];
+    len = len < T3 ? len : T3;
+    uint16_t* orow = out + ((size_t)b * T3 + t) * F3 * C;
+    for (int i = threadIdx.x; i < F3 * C; i += 256) {
+        const int f = i / C, c = i - f * C;
+        float acc = bias[c];
+        for (int kh = 0; kh < 7; ++kh) {
+            const int tt = t + kh - 3;
+            if (tt < 0 || tt >= len) continue;
+            const float* xr = a2 + ((size_t)b * T3 + tt) * F3 * C + c;
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const int ff = f + kw - 3;
+                if (ff >= 0 && ff < F3) acc = fmaf(w[(kh * 7 + kw) * C + c], xr[(size_t)ff * C], acc);
+            }
+        }
+        orow[i] = f32_to_bf16(acc);
+    }
+}
+
+// ---- element-wise pieces of the stacks ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k2_cast_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<u16x4_t*>(out)[i] = pack_bf16x4(v.x, v.y, v.z, v.w);
+}
+
+// BiasNorm (+ optional bypass): y = x * rsqrt(mean((x - bias)^2)) * scale; with x0: y = x0 + (y - x0) * bypass[c].
+// One wave per row; writes f32 (in place allowed) and optionally the bf16 copy the next GEMM reads.
+__global__ __launch_bounds__(256) void k2_biasnorm_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ scale_p,
+                                                          const float* __restrict__ x0, const float* __restrict__ bypass, int M, int d,
+                                                          float* __restrict__ out, uint16_t* __restrict__ out_bf16) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * d;
+    float ss = 0.0f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c), bb = *reinterpret_cast<const float4*>(bias + c);
+        const float a = v.x - bb.x, b2 = v.y - bb.y, c2 = v.z - bb.z, e = v.w - bb.w;
+        ss += a * a + b2 * b2 + c2 * c2 + e * e;
+    }
+    ss = wave_sum(ss);
+    const float sc = rsqrtf(ss / (float)d) * scale_p[0];
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(xr + c);
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        if (x0) {
+            const float4 o = *reinterpret_cast<const float4*>(x0 + (size_t)row * d + c), s = *reinterpret_cast<const float4*>(bypass + c);
+            v.x = o.x + (v.x - o.x) * s.x; v.y = o.y + (v.y - o.y) * s.y; v.z = o.z + (v.z - o.z) * s.z; v.w = o.w + (v.w - o.w) * s.w;
+        }
+        *reinterpret_cast<float4*>(out + (size_t)row * d + c) = v;
+        if (out_bf16) *reinterpret_cast<u16x4_t*>(out_bf16 + (size_t)row * d + c) = pack_bf16x4(v.x, v.y, v.z, v.w);
+    }
+}
+
+// bypass in the middle of a layer: x = x0 + (x - x0) * scale[c] (in place) and its bf16 copy
+__global__ __launch_bounds__(256) void k2_bypass_kernel(float* __restrict__ x, const float* __restrict__ x0, const float* __restrict__ scale, int d,
+                                                        size_t n4, uint16_t* __restrict__ out_bf16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % (size_t)d);
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    const float4 o = reinterpret_cast<const float4*>(x0)[i], s = *reinterpret_cast<const float4*>(scale + c);
+    v.x = o.x + (v.x - o.x) * s.x; v.y = o.y + (v.y - o.y) * s.y; v.z = o.z + (v.z - o.z) * s.z; v.w = o.w + (v.w - o.w) * s.w;
+    reinterpret_cast<float4*>(x)[i] = v;
+    reinterpret_cast<u16x4_t*>(out_bf16)[i] = pack_bf16x4(v.x, v.y, v.z, v.w);
+}
+
+// Entry of a stack: channel conversion (cut or zero-pad to d) of the previous stack's output -> src [B][T][d] (the operand of
+// the stack's out_combiner), and SimpleDownsample by ds -> xs [B][Ts][d]: weighted sum (softmax(bias), done on the host) of
+// each group of ds frames, frames past the utterance's end replaced by ITS last frame; rows past ceil(len / ds) are zeros.
+// grid (Ts, B), block 256
+__global__ __launch_bounds__(256) void k2_stack_in_kernel(const float* __restrict__ prev, int d_prev, const int32_t* __restrict__ lens, int T, int d,
+                                                          int ds, int Ts, const float* __restrict__ wds, float* __restrict__ src,
+                                                          float* __restrict__ xs) {
+    const int ts = blockIdx.x, b = blockIdx.y;
+    int len = lens[b];
+    len = len < T ? len : T;
+    const int dmin = d < d_prev ? d : d_prev;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float acc = 0.0f;
+        for (int k = 0; k < ds; ++k) {
+            const int t = ts * ds + k;
+            if (t < T && src) src[((size_t)b * T + t) * d + c] = c < dmin ? prev[((size_t)b * T + t) * d_prev + c] : 0.0f;
+            int tt = t < len ? t : len - 1;
+            const float v = (c < dmin && tt >= 0) ? prev[((size_t)b * T + tt) * d_prev + c] : 0.0f;
+            acc = fmaf(v, ds > 1 ? wds[k] : 1.0f, acc);
+        }
+        if (xs) xs[((size_t)b * Ts + ts) * d + c] = ts * ds < len ? acc : 0.0f;
+    }
+}
+
+// Exit of a down-sampled stack: SimpleUpsample (repeat each frame ds times, cut to T) + out_combiner:
+// out[b][t][c] = src + (xs[b][t / ds][c] - src) * scale[c].  grid (T, B)
+__global__ __launch_bounds__(256) void k2_stack_out_kernel(const float* __restrict__ src, const float* __restrict__ xs, int T, int Ts, int d, int ds,
+                                                           const float* __restrict__ scale, float* __restrict__ out) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        const float o = src[((size_t)b * T + t) * d + c];
+        const float v = xs[((size_t)b * Ts + t / ds) * d + c];
+        out[((size_t)b * T + t) * d + c] = o + (v - o) * scale[c];
+    }
+}
+
+// Output of the encoder: the last stack's channels extended by the extra channels of earlier, wider stacks (`pieces`: up to 8
+// (pointer, first channel, channel count, row pitch)), then SimpleDownsample by 2 with the utterance's own last frame repeated.
+// -> enc f32 [B][To][D] (optional) and its bf16 copy (the operand of joiner.encoder_proj); rows past (len + 1) / 2 are zeros.
+struct K2Pieces { const float* p[8]; int c0[8], n[8], ld[8]; int count; };
+__global__ __launch_bounds__(256) void k2_output_kernel(K2Pieces pc, const int32_t* __restrict__ lens, int T, int To, int D, const float* __restrict__ wds,
+                                                        float* __restrict__ enc, uint16_t* __restrict__ enc_bf16, int32_t* __restrict__ out_lens) {
+    const int to = blockIdx.x, b = blockIdx.y;
+    int len = lens[b];
+    len = len < T ? len : T;
+    if (to == 0 && threadIdx.x == 0) out_lens[b] = (len + 1) / 2;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        int pi = 0, base = 0;
+        while (pi + 1 < pc.count && c >= base + pc.n[pi]) { base += pc.n[pi]; ++pi; }
+        const float* src = pc.p[pi];
+        const int col = pc.c0[pi] + (c - base), ld = pc.ld[pi];
+        float acc = 0.0f;
+        for (int k = 0; k < 2; ++k) {
+            int t = 2 * to + k;
+            t = t < len ? t : len - 1;
+            acc = fmaf(t >= 0 ? src[((size_t)b * T + t) * ld + col] : 0.0f, wds[k], acc);
+        }
+        if (2 * to >= len) acc = 0.0f;
+        if (enc) enc[((size_t)b * To + to) * D + c] = acc;
+        enc_bf16[((size_t)b * To + to) * D + c] = f32_to_bf16(acc);
+    }
+}
+
+// ---- attention weights ----------------------------------------------------------------------------------------------------------
+// qkp bf16 [B*T][ld]: columns [0, H*32) queries, [H*32, 2*H*32) keys, [2*H*32, 2*H*32 + H*4) position queries (head-major).
+// pos f32 [2*cap-1][H*4]: linear_pos of the compact relative-position encoding, row n <-> relative position n - (cap - 1).
+// W bf16 [B][H][T][Tp]: softmax over the utterance's own keys of  q_i.k_j + p_i.pos[j - i];  keys / queries past the length: 0.
+// Block = (64 queries, head, utterance), 4 waves of 16 queries.  A 16 x 16 score tile is ONE v_mfma_f32_16x16x32_bf16
+// (head_dim 32 = the MFMA's K extent): first operand the key rows, second the query rows, so a lane holds the scores of query
+// (lane & 15) against keys 4 * (lane >> 4) .. + 3.  Two passes over the keys (maximum and sum, then the normalised weights):
+// the scores are recomputed instead of kept, so any T fits.  The position rows the block can touch (rel in [-(i0 + 63), len - 1 - i0])
+// sit in LDS as float4.
+__global__ __launch_bounds__(256) void k2_attn_weights_kernel(const uint16_t* __restrict__ qkp, int ld, const float* __restrict__ pos, int cap, int H,
+                                                              const int32_t* __restrict__ lens, int T, int Tp, uint16_t* __restrict__ W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* ps = reinterpret_cast<float4*>(smem);
+    const int h = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int len = lens[b];
+    len = len < T ? len : T;
+    uint16_t* wbase = W + (((size_t)b * H + h) * T) * Tp;
+    if (i0 >= len) {                                     // a tile of padding queries: zeros
+        for (int idx = threadIdx.x; idx < 64 * (Tp / 4); idx += 256) {
+            const int r = idx / (Tp / 4), q = idx - r * (Tp / 4);
+            if (i0 + r < T) reinterpret_cast<u16x4_t*>(wbase + (size_t)(i0 + r) * Tp)[q] = (u16x4_t){0, 0, 0, 0};
+        }
+        return;
+    }
+    // position rows for rel = -(i0 + 63) .. len - 1 - i0  ->  ps[rel + i0 + 63]
+    const int nrel = len + 63;
+    for (int r = threadIdx.x; r < nrel; r += 256) {
+        int n = r - (i0 + 63) + cap - 1;                  // (rows only padding queries could ask for are clamped: never used)
+        n = n < 0 ? 0 : (n > 2 * cap - 2 ? 2 * cap - 2 : n);
+        ps[r] = *reinterpret_cast<const float4*>(pos + (size_t)n * (H * K2_PD) + h * K2_PD);
+    }
+    __syncthreads();
+    const int qi = i0 + wave * 16 + (lane & 15);         // this lane's query
+    const int kq = lane >> 4;                             // its key quad within a 16-key tile
+    const bool q_ok = qi < len;
+    const int qrow = qi < T ? qi : T - 1;
+    const uint16_t* qp = qkp + ((size_t)b * T + qrow) * ld;
+    const bf16x8_t qfrag = *reinterpret_cast<const bf16x8_t*>(qp + h * K2_QD + 8 * kq);
+    float4 pq;
+    {
+        const u16x4_t pv = *reinterpret_cast<const u16x4_t*>(qp + 2 * H * K2_QD + h * K2_PD);
+        pq = make_float4(bf16_to_f32(pv[0]), bf16_to_f32(pv[1]), bf16_to_f32(pv[2]), bf16_to_f32(pv[3]));
+    }
+    const int ntile = (len + 15) / 16;
+    auto scores = [&](int jt, float (&s)[4]) {
+        int krow = jt * 16 + (lane & 15);
+        krow = krow < len ? krow : len - 1;
+        const bf16x8_t kfrag = *reinterpret_cast<const bf16x8_t*>(qkp + ((size_t)b * T + krow) * ld + H * K2_QD + h * K2_QD + 8 * kq);
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qfrag, acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = jt * 16 + 4 * kq + e;
+            int r = j - qi + i0 + 63;
+            r = r < 0 ? 0 : (r >= nrel ? nrel - 1 : r);
+            const float4 pr = ps[r];
+            const float v = acc[e] + (pq.x * pr.x + pq.y * pr.y + pq.z * pr.z + pq.w * pr.w);
+            s[e] = j < len ? v : -INFINITY;
+        }
+    };
+    // pass 1: row maximum, then the sum of exp (two sweeps keep the arithmetic of a plain softmax: max first)
+    float mx = -INFINITY;
+    for (int jt = 0; jt < ntile; ++jt) {
+        float s[4];
+        scores(jt, s);
+        mx = fmaxf(mx, fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.0f;
+    for (int jt = 0; jt < ntile; ++jt) {
+        float s[4];
+        scores(jt, s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += __expf(s[e] - mx);
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = q_ok ? 1.0f / sum : 0.0f;
+    // pass 2: the weights
+    const int ntile_all = Tp / 16;
+    for (int jt = 0; jt < ntile_all; ++jt) {
+        u16x4_t o = {0, 0, 0, 0};
+        if (jt < ntile) {
+            float s[4];
+            scores(jt, s);
+            o = pack_bf16x4(__expf(s[0] - mx) * inv, __expf(s[1] - mx) * inv, __expf(s[2] - mx) * inv, __expf(s[3] - mx) * inv);
+        }
+        if (qi < T) *reinterpret_cast<u16x4_t*>(wbase + (size_t)qi * Tp + jt * 16 + 4 * kq) = o;
+    }
+}
+
+// ---- weights x values ---------------------------------------------------------------------------------------------------------------
+// out[b][i][c] = sum_j W[b][h][i][j] * V[b][j][c]  for the channels of one head (self-attention: 12 of a 16-wide tile) or, MODE 1,
+// for 64-channel slices of the non-linear attention with head 0's weights:  V = u[:, hid + c] * tanh(u[:, c]) (rounded to bf16
+// like the oracle), result multiplied by u[:, 2 hid + c].  Block = (64 queries, channel tile, utterance x head), 4 waves of 16
+// queries; V^T of the block's channels is staged in LDS in chunks of KB keys ([channels][KB + 8] bf16), a step is one MFMA per
+// 16-channel tile over 32 keys: first operand V^T rows (channels), second the weight rows (queries), so a lane holds query
+// (lane & 15), channels 4 * (lane >> 4) .. + 3 of the tile.
+template <int CT, int MODE>
+__global__ __launch_bounds__(256) void k2_pv_kernel(const uint16_t* __restrict__ W, int H, int Tp, const uint16_t* __restrict__ u, int ldu, int hid,
+                                                    const int32_t* __restrict__ lens, int T, uint16_t* __restrict__ out, int ldo) {
+    constexpr int KB = 256, PITCH = KB + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t vt[CT * 16 * PITCH];
+    const int i0 = blockIdx.x * 64, ctile = blockIdx.y;
+    const int b = MODE == 1 ? blockIdx.z : blockIdx.z / H, h = MODE == 1 ? 0 : blockIdx.z % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int len = lens[b];
+    len = len < T ? len : T;
+    const int nch = MODE == 1 ? hid : K2_VD;              // real channels of this (head, tile) space
+    const int cbase = MODE == 1 ? ctile * CT * 16 : 0;    // first channel of the block
+    const int col0 = MODE == 1 ? hid + cbase : h * K2_VD; // column of channel cbase in u
+    const int qi = i0 + wave * 16 + (lane & 15), kq = lane >> 4;
+    const uint16_t* wrow = W + (((size_t)b * H + h) * T + (qi < T ? qi : T - 1)) * Tp;
+    f32x4_t acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < len; k0 += KB) {
+        __syncthreads();
+        // stage V^T: element (channel c, key k0 + kk); keys past the length and channels past nch are zeros
+        for (int idx = threadIdx.x; idx < CT * 16 * (KB / 8); idx += 256) {
+            const int c = idx % (CT * 16), kg = idx / (CT * 16);
+            u16x8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int key = k0 + kg * 8 + e;
+                unsigned short val = 0;
+                if (key < len && cbase + c < nch) {
+                    const uint16_t* ur = u + ((size_t)b * T + key) * ldu;
+                    if constexpr (MODE == 1) {
+                        const float xv = bf16_to_f32(ur[col0 + c]), sv = bf16_to_f32(ur[cbase + c]);
+                        const float th = 1.0f - 2.0f / (__expf(2.0f * sv) + 1.0f);
+                        val = f32_to_bf16(xv * th);
+                    } else {
+                        val = ur[col0 + c];
+                    }
+                }
+                v[e] = val;
+            }
+            *reinterpret_cast<u16x8_t*>(vt + c * PITCH + kg * 8) = v;
+        }
+        __syncthreads();
+        const int kend = len - k0 < KB ? len - k0 : KB;
+        for (int kk = 0; kk < kend; kk += 32) {
+            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wrow + k0 + kk + 8 * kq);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vt + (c * 16 + (lane & 15)) * PITCH + kk + 8 * kq);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, wf, acc[c], 0, 0, 0);
+            }
+        }
+    }
+    if (qi >= T) return;
+    const bool q_ok = qi < len;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int ch = cbase + c * 16 + 4 * kq;          // first of this lane's four channels
+        if (ch >= nch) continue;
+        float v[4] = {acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+        if constexpr (MODE == 1) {
+            const u16x4_t y = *reinterpret_cast<const u16x4_t*>(u + ((size_t)b * T + qi) * ldu + 2 * hid + ch);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= bf16_to_f32(y[e]);
+        }
+        if (!q_ok) v[0] = v[1] = v[2] = v[3] = 0.0f;
+        const int oc = MODE == 1 ? ch : h * K2_VD + ch;
+        *reinterpret_cast<u16x4_t*>(out + ((size_t)b * T + qi) * ldo + oc) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// per-stack lengths: l[s][b] = ceil(len3[b] / ds[s]); len3[b] = max((n_frames[b] - 7) / 2, 0).  rows: 0 = len3, 1 + s = stack s
+__global__ void k2_lens_kernel(const int32_t* __restrict__ n_frames, int B, int n_stacks, int ds0, int ds1, int ds2, int ds3, int ds4, int ds5, int ds6,
+                               int ds7, int32_t* __restrict__ out) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int ds[8] = {ds0, ds1, ds2, ds3, ds4, ds5, ds6, ds7};
+    int l3 = (n_frames[b] - 7) / 2;
+    l3 = l3 > 0 ? l3 : 0;
+    out[b] = l3;
+    for (int s = 0; s < n_stacks; ++s) out[(size_t)(1 + s) * B + b] = (l3 + ds[s] - 1) / ds[s];
+}
+
+struct K2Plan {
+    int T, T1, T2, T3, To, F, F2, F3, Kp;
+    int Ts[8], Tp[8];
+    size_t off_lens, off_a0, off_a1, off_col, off_a2, off_dwo, off_h, off_stackout[8], off_x, off_x0, off_src, off_xb, off_qkp, off_w, off_big, off_av,
+        off_encb, total;
+};
+
+K2Plan k2_plan(const rs_ctx* ctx, int B, int t_max) {
+    const rs_k2& k = *ctx->k2;
+    const rs_k2_dims& d = k.d;
+    K2Plan p{};
+    p.T = t_max; p.F = d.n_mels;
+    p.T1 = t_max - 2; p.T2 = p.T1 >= 3 ? (p.T1 - 3) / 2 + 1 : 0; p.T3 = p.T2 - 2;
+    if (p.T3 < 0) p.T3 = 0;
+    p.F2 = (p.F - 3) / 2 + 1; p.F3 = (p.F2 - 3) / 2 + 1;
+    p.To = (p.T3 + 1) / 2;
+    p.Kp = pad64(9 * d.embed_c2);
+    const size_t T3 = p.T3 > 0 ? p.T3 : 1, T1 = p.T1 > 0 ? p.T1 : 1, T2 = p.T2 > 0 ? p.T2 : 1;
+    const size_t rows3 = (size_t)B * T3 * p.F3;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += rs_align(bytes); return at; };
+    p.off_lens = take((size_t)(2 + d.n_stacks) * B * 4);
+    p.off_a0 = take((size_t)B * T1 * p.F * d.embed_c1 * 2);
+    p.off_a1 = take((size_t)B * T2 * p.F2 * d.embed_c2 * 2);
+    p.off_col = take(rows3 * p.Kp * 2);
+    p.off_a2 = take(rows3 * d.embed_c3 * 4);
+    p.off_dwo = take(rows3 * d.embed_c3 * 2);
+    p.off_h = take(rows3 * 3 * d.embed_c3 * 2);
+    int dmax = 0, nin_max = 0, big_max = 0, av_max = 0;
+    size_t w_max = 0;
+    for (int s = 0; s < d.n_stacks; ++s) {
+        const int dd = d.encoder_dim[s], H = d.num_heads[s], ds = d.downsampling[s];
+        p.Ts[s] = ceil_div((int)T3, ds);
+        p.Tp[s] = (p.Ts[s] + 31) / 32 * 32;
+        p.off_stackout[s] = take((size_t)B * T3 * dd * 4);
+        dmax = dd > dmax ? dd : dmax;
+        const int nin = (2 * K2_QD + K2_PD) * H;
+        const size_t rows = (size_t)B * p.Ts[s];
+        if ((size_t)nin * rows > (size_t)nin_max) nin_max = 0;       // (sized below in bytes)
+        const size_t wb = (size_t)B * H * p.Ts[s] * p.Tp[s] * 2;
+        w_max = wb > w_max ? wb : w_max;
+        (void)big_max; (void)av_max;
+    }
+    size_t x_b = 0, qkp_b = 0, big_b = 0, av_b = 0;
+    for (int s = 0; s < d.n_stacks; ++s) {
+        const size_t rows = (size_t)B * p.Ts[s], dd = d.encoder_dim[s], H = d.num_heads[s];
+        const size_t full = (size_t)B * T3 * dd * 4;
+        x_b = full > x_b ? full : x_b;
+        const size_t q = rows * (2 * K2_QD + K2_PD) * H * 2;
+        qkp_b = q > qkp_b ? q : qkp_b;
+        size_t widest = (size_t)d.ff_dim[s] * 5 / 4;
+        const size_t na = 3 * (3 * dd / 4);
+        widest = na > widest ? na : widest;
+        widest = 2 * dd > widest ? 2 * dd : widest;
+        big_b = rows * widest * 2 > big_b ? rows * widest * 2 : big_b;
+        size_t avw = pad64(3 * (int)dd / 4);
+        avw = (size_t)pad64((int)H * K2_VD) > avw ? (size_t)pad64((int)H * K2_VD) : avw;
+        avw = dd > avw ? dd : avw;
+        av_b = rows * avw * 2 > av_b ? rows * avw * 2 : av_b;
+    }
+    p.off_x = take(x_b); p.off_x0 = take(x_b); p.off_src = take(x_b);
+    p.off_xb = take(x_b / 2);
+    p.off_qkp = take(qkp_b);
+    p.off_w = take(w_max);
+    p.off_big = take(big_b);
+    p.off_av = take(av_b);
+    p.off_encb = take((size_t)B * (p.To > 0 ? p.To : 1) * k.out_dim * 2);
+    p.total = o + 256;
+    return p;
+}
+
+template <typename T>
+int k2_get(rs_ctx* ctx, const std::string& name, size_t elems, const T*& out) {
+    auto it = ctx->tensors.find(name);
+    if (it == ctx->tensors.end()) return rs_fail(ctx, RS_EMISSING, "weight tensor '%s' was not registered", name.c_str());
+    if (it->second.second != elems * sizeof(T))
+        return rs_fail(ctx, RS_EINVAL, "tensor '%s': expected %zu bytes, got %zu", name.c_str(), elems * sizeof(T), it->second.second);
+    if ((uintptr_t)it->second.first & 15) return rs_fail(ctx, RS_EINVAL, "tensor '%s' is not 16-byte aligned", name.c_str());
+    out = reinterpret_cast<const T*>(it->second.first);
+    return RS_OK;
+}
+
+void k2_free(rs_k2* k) { delete k; }
+
+}  // namespace
+
+extern "C" int rs_k2_create(rs_ctx** out, int device, const rs_k2_dims* dims) {
+    if (!out || !dims) return RS_EINVAL;
+    *out = nullptr;
+    rs_ctx* ctx = new (std::nothrow) rs_ctx();
+    if (!ctx) return RS_EINVAL;
+    *out = ctx;
+    ctx->device = device;
+    rs_k2* k = new (std::nothrow) rs_k2();
+    if (!k) return rs_fail(ctx, RS_EINVAL, "out of memory");
+    ctx->k2 = k;
+    ctx->k2_free = k2_free;
+    k->d = *dims;
+    const rs_k2_dims& d = k->d;
+    if (d.n_stacks < 1 || d.n_stacks > 8) return rs_fail(ctx, RS_EINVAL, "zipformer: 1..8 stacks");
+    if (d.query_head_dim != K2_QD || d.pos_head_dim != K2_PD || d.value_head_dim != K2_VD)
+        return rs_fail(ctx, RS_EINVAL, "zipformer: the attention kernels are built for head dims 32 / 4 / 12 (got %d / %d / %d)", d.query_head_dim,
+                       d.pos_head_dim, d.value_head_dim);
+    if (d.n_mels < 16 || d.n_mels > 128 || d.n_mels % 4 || d.frame_length > 512 || d.frame_shift < 1 || d.frame_shift > 256)
+        return rs_fail(ctx, RS_EINVAL, "zipformer: feature geometry (n_mels %d, frame %d / %d)", d.n_mels, d.frame_length, d.frame_shift);
+    if (d.embed_c1 < 1 || d.embed_c2 % 8 || d.embed_c3 % 64 || d.embed_c1 * d.n_mels > 4096) return rs_fail(ctx, RS_EINVAL, "zipformer: encoder_embed channels");
+    if (d.downsampling[0] != 1) return rs_fail(ctx, RS_EINVAL, "zipformer: the first stack runs at the full rate");
+    k->out_dim = 0;
+    for (int s = 0; s < d.n_stacks; ++s) {
+        const int ds = d.downsampling[s], kk = d.cnn_kernel[s];
+        if (d.encoder_dim[s] % 64 || d.ff_dim[s] % 256 || d.num_heads[s] < 1 || d.num_heads[s] > 16 || d.num_layers[s] < 1)
+            return rs_fail(ctx, RS_EINVAL, "zipformer: stack %d: encoder_dim %% 64, feedforward_dim %% 256, 1..16 heads", s);
+        if (ds != 1 && ds != 2 && ds != 4 && ds != 8) return rs_fail(ctx, RS_EINVAL, "zipformer: stack %d: down-sampling %d", s, ds);
+        if (kk != 7 && kk != 15 && kk != 31) return rs_fail(ctx, RS_EINVAL, "zipformer: stack %d: cnn_module_kernel %d (7, 15, 31 are built)", s, kk);
+        k->out_dim = d.encoder_dim[s] > k->out_dim ? d.encoder_dim[s] : k->out_dim;
+    }
+    if (d.decoder_dim % 128 || d.joiner_dim % 128 || d.context_size != 2 || d.blank_id != 0 || d.vocab_size < 2)
+        return rs_fail(ctx, RS_EINVAL, "zipformer: decoder_dim / joiner_dim %% 128, context_size 2, blank 0");
+    k->embed_freq = (((d.n_mels - 1) / 2) - 1) / 2;
+    // the shared stages (front-end, greedy search) read the dimensions they need from rs_dims
+    rs_dims& g = ctx->d;
+    g.n_mels = d.n_mels; g.n_fft = 512; g.win_length = d.frame_length; g.hop_length = d.frame_shift; g.preemph = d.preemph;
+    g.log_guard = 1.1920928955078125e-07f; g.norm_eps = 0.0f;
+    g.frontend_kind = 2;
+    g.d_model = k->out_dim; g.n_logits = d.vocab_size; g.blank_id = d.blank_id; g.pred_hidden = d.decoder_dim; g.pred_layers = 1;
+    g.joint_hidden = d.joiner_dim; g.max_symbols = 1; g.joint_act = 1;
+    if (hipSetDevice(device) != hipSuccess) return rs_fail(ctx, RS_EHIP, "hipSetDevice(%d) failed", device);
+    return RS_OK;
+}
+
+extern "C" int rs_k2_encoder_set_taps(rs_ctx* ctx, float* embed_out, float* stack_out) {
+    if (!ctx || !ctx->k2) return RS_EINVAL;
+    ctx->k2->tap_embed = embed_out;
+    ctx->k2->tap_stacks = stack_out;
+    return RS_OK;
+}
+
+int rs_k2_finalize_impl(rs_ctx* ctx) {
+    rs_k2& k = *ctx->k2;
+    const rs_k2_dims& d = k.d;
+    int rc;
+#define K2_GET(name, elems, field) do { rc = k2_get(ctx, name, (size_t)(elems), field); if (rc != RS_OK) return rc; } while (0)
+    K2_GET("fe.window", d.frame_length, ctx->fe_window);
+    K2_GET("fe.twiddle", 512, ctx->fe_twiddle);
+    K2_GET("fe.fb_idx", d.n_mels * 2, ctx->fe_fb_idx);
+    K2_GET("fe.fb_w", d.n_mels * 32, ctx->fe_fb_w);
+    const int c1 = d.embed_c1, c2 = d.embed_c2, c3 = d.embed_c3, d0 = d.encoder_dim[0];
+    K2_GET("emb.conv0.w", 9 * c1, k.conv0_w); K2_GET("emb.conv0.b", c1, k.conv0_b);
+    K2_GET("emb.conv1.w", 9 * c1 * c2, k.conv1_w); K2_GET("emb.conv1.b", c2, k.conv1_b);
+    K2_GET("emb.conv2.w", (size_t)c3 * pad64(9 * c2), k.conv2_w); K2_GET("emb.conv2.b", c3, k.conv2_b);
+    K2_GET("emb.cnx.dw.w", 49 * c3, k.cnx_dw_w); K2_GET("emb.cnx.dw.b", c3, k.cnx_dw_b);
+    K2_GET("emb.cnx.pw1.w", 3 * c3 * c3, k.cnx_pw1_w); K2_GET("emb.cnx.pw1.b", 3 * c3, k.cnx_pw1_b);
+    K2_GET("emb.cnx.pw2.w", 3 * c3 * c3, k.cnx_pw2_w); K2_GET("emb.cnx.pw2.b", c3, k.cnx_pw2_b);
+    K2_GET("emb.out.w", (size_t)d0 * k.embed_freq * c3, k.emb_out_w); K2_GET("emb.out.b", d0, k.emb_out_b);
+    K2_GET("emb.norm.bias", d0, k.emb_norm_bias); K2_GET("emb.norm.scale", 4, k.emb_norm_scale);
+    // the position tables all have 2 * cap - 1 rows
+    {
+        auto it = ctx->tensors.find("S0.L0.attw.pos_proj");
+        if (it == ctx->tensors.end()) return rs_fail(ctx, RS_EMISSING, "weight tensor 'S0.L0.attw.pos_proj' was not registered");
+        const size_t row = (size_t)d.num_heads[0] * K2_PD * 4;
+        if (it->second.second % row || !((it->second.second / row) & 1)) return rs_fail(ctx, RS_EINVAL, "attw.pos_proj must be f32 [2*cap-1][H*4]");
+        k.pos_cap = (int)((it->second.second / row + 1) / 2);
+    }
+    k.stacks.assign(d.n_stacks, {});
+    for (int s = 0; s < d.n_stacks; ++s) {
+        const size_t dd = d.encoder_dim[s], H = d.num_heads[s], hid = 3 * dd / 4, kk = d.cnn_kernel[s];
+        const size_t ff[3] = {(size_t)d.ff_dim[s] * 3 / 4, (size_t)d.ff_dim[s], (size_t)d.ff_dim[s] * 5 / 4};
+        k.stacks[s].assign(d.num_layers[s], rs_k2_layer{});
+        for (int j = 0; j < d.num_layers[s]; ++j) {
+            rs_k2_layer& L = k.stacks[s][j];
+            const std::string p = "S" + std::to_string(s) + ".L" + std::to_string(j) + ".";
+            const size_t nin = (2 * K2_QD + K2_PD) * H;
+            K2_GET(p + "attw.in.w", nin * dd, L.attw_in_w); K2_GET(p + "attw.in.b", nin, L.attw_in_b);
+            K2_GET(p + "attw.pos_proj", (size_t)(2 * k.pos_cap - 1) * H * K2_PD, L.pos_proj);
+            for (int a = 0; a < 2; ++a) {
+                const std::string q = p + (a ? "sa2." : "sa1.");
+                K2_GET(q + "in.w", H * K2_VD * dd, L.sa_in_w[a]); K2_GET(q + "in.b", H * K2_VD, L.sa_in_b[a]);
+                K2_GET(q + "out.w", dd * pad64((int)(H * K2_VD)), L.sa_out_w[a]); K2_GET(q + "out.b", dd, L.sa_out_b[a]);
+                const std::string c = p + (a ? "cm2." : "cm1.");
+                K2_GET(c + "in.w", 2 * dd * dd, L.cm_in_w[a]); K2_GET(c + "in.b", 2 * dd, L.cm_in_b[a]);
+                K2_GET(c + "dw.w", kk * dd, L.cm_dw_w[a]); K2_GET(c + "dw.b", dd, L.cm_dw_b[a]);
+                K2_GET(c + "out.w", dd * dd, L.cm_out_w[a]); K2_GET(c + "out.b", dd, L.cm_out_b[a]);
+            }
+            for (int f = 0; f < 3; ++f) {
+                const std::string q = p + "ff" + std::to_string(f + 1) + ".";
+                K2_GET(q + "in.w", ff[f] * dd, L.ff_in_w[f]); K2_GET(q + "in.b", ff[f], L.ff_in_b[f]);
+                K2_GET(q + "out.w", dd * ff[f], L.ff_out_w[f]); K2_GET(q + "out.b", dd, L.ff_out_b[f]);
+            }
+            K2_GET(p + "na.in.w", 3 * hid * dd, L.na_in_w); K2_GET(p + "na.in.b", 3 * hid, L.na_in_b);
+            K2_GET(p + "na.out.w", dd * pad64((int)hid), L.na_out_w); K2_GET(p + "na.out.b", dd, L.na_out_b);
+            K2_GET(p + "norm.bias", dd, L.norm_bias); K2_GET(p + "norm.scale", 4, L.norm_scale);
+            K2_GET(p + "bypass.scale", dd, L.bypass); K2_GET(p + "bypass_mid.scale", dd, L.bypass_mid);
+        }
+        if (d.downsampling[s] > 1) {
+            K2_GET("S" + std::to_string(s) + ".ds.w", 8, k.ds_w[s]);
+            K2_GET("S" + std::to_string(s) + ".comb.scale", dd, k.comb_scale[s]);
+        }
+    }
+    K2_GET("out.ds.w", 8, k.out_ds_w);
+    const size_t J = d.joiner_dim, D = d.decoder_dim, V = d.vocab_size;
+    K2_GET("joint.enc.w", J * k.out_dim, ctx->jenc_w); K2_GET("joint.enc.b", J, ctx->jenc_b);
+    K2_GET("dec.embed", V * D, ctx->embed);
+    K2_GET("dec.conv.w", D * 4 * 2, ctx->k2_conv_w);
+    K2_GET("joint.pred.w", J * D, ctx->jpred_w); K2_GET("joint.pred.b", J, ctx->jpred_b);
+    K2_GET("joint.out.w", ((V + 15) / 16 * 16) * J, ctx->jout_w); K2_GET("joint.out.b", V, ctx->jout_b);
+#undef K2_GET
+    ctx->jout_w16 = nullptr;
+    ctx->decode_screen = false;           // tanh joint: the exact kernels
+    ctx->decode_narrow = true;
+    ctx->finalized = true;
+    return RS_OK;
+}
+
+int rs_k2_unk_id(const rs_ctx* ctx) { return ctx->k2 ? ctx->k2->d.unk_id : -1; }
+
+int rs_k2_enc_frames_impl(const rs_ctx* ctx, int n_feat) {
+    (void)ctx;
+    const int t3 = (n_feat - 7) / 2;
+    return t3 > 0 ? (t3 + 1) / 2 : 0;
+}
+
+size_t rs_k2_workspace_bytes_impl(const rs_ctx* ctx, int B, int t_max) { return k2_plan(ctx, B, t_max > 9 ? t_max : 9).total; }
+
+int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n_frames, int B, int t_max, float* enc_out, float* joint_enc,
+                               int32_t* enc_lens, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    rs_k2& k = *ctx->k2;
+    const rs_k2_dims& d = k.d;
+    if (t_max < 9) return rs_fail(ctx, RS_EINVAL, "zipformer: %d feature frames are too few for encoder_embed (9 are needed)", t_max);
+    const K2Plan pl = k2_plan(ctx, B, t_max);
+    if (workspace_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "zipformer: workspace %zu < %zu", workspace_bytes, pl.total);
+    char* ws = reinterpret_cast<char*>(workspace);
+    int32_t* lens_all = reinterpret_cast<int32_t*>(ws + pl.off_lens);
+    const int32_t* lens3 = lens_all;
+    uint16_t* a0 = reinterpret_cast<uint16_t*>(ws + pl.off_a0);
+    uint16_t* a1 = reinterpret_cast<uint16_t*>(ws + pl.off_a1);
+    uint16_t* col = reinterpret_cast<uint16_t*>(ws + pl.off_col);
+    float* a2 = reinterpret_cast<float*>(ws + pl.off_a2);
+    uint16_t* dwo = reinterpret_cast<uint16_t*>(ws + pl.off_dwo);
+    uint16_t* hbuf = reinterpret_cast<uint16_t*>(ws + pl.off_h);
+    float* x = reinterpret_cast<float*>(ws + pl.off_x);
+    float* x0 = reinterpret_cast<float*>(ws + pl.off_x0);
+    float* src = reinterpret_cast<float*>(ws + pl.off_src);
+    uint16_t* xb = reinterpret_cast<uint16_t*>(ws + pl.off_xb);
+    uint16_t* qkp = reinterpret_cast<uint16_t*>(ws + pl.off_qkp);
+    uint16_t* W = reinterpret_cast<uint16_t*>(ws + pl.off_w);
+    uint16_t* big = reinterpret_cast<uint16_t*>(ws + pl.off_big);
+    uint16_t* av = reinterpret_cast<uint16_t*>(ws + pl.off_av);
+    uint16_t* encb = reinterpret_cast<uint16_t*>(ws + pl.off_encb);
+    const int c1 = d.embed_c1, c2 = d.embed_c2, c3 = d.embed_c3, T3 = pl.T3, F3 = pl.F3;
+    int rc;
+#define RS_TRY(call) do { rc = (call); if (rc != RS_OK) return rc; } while (0)
+    auto gemm = [&](const uint16_t* A, int lda, const uint16_t* Wt, int K, void* out, int ldc, long long M, int N, int flags, const float* bias,
+                    const float* res) -> int {
+        rs_gemm_args g{};
+        g.A = A; g.lda = lda; g.W = Wt; g.ldw = K; g.out = out; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K;
+        g.flags = flags; g.bias = bias; g.alpha = 1.0f; g.residual = res;
+        return rs_launch_gemm(ctx, g, s);
+    };
+    const int RES = RS_GEMM_BIAS | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32;
+    auto cast = [&](const float* in, uint16_t* out, size_t n) {
+        hipLaunchKernelGGL(k2_cast_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, in, out, n / 4);
+    };
+    hipLaunchKernelGGL(k2_lens_kernel, dim3((B + 255) / 256), dim3(256), 0, s, n_frames, B, d.n_stacks, d.downsampling[0], d.downsampling[1],
+                       d.downsampling[2], d.downsampling[3], d.downsampling[4], d.downsampling[5], d.downsampling[6], d.downsampling[7], lens_all);
+    // ---- encoder_embed ------------------------------------------------------------------------------------------------
+    rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, 0.0);
+    hipLaunchKernelGGL(k2_conv0_kernel, dim3(pl.T1, B), dim3(256), 0, s, feats, t_max, pl.F, c1, k.conv0_w, k.conv0_b, a0);
+    {
+        const size_t lds = (size_t)(3 * pl.F * c1 + 9 * c1 * c2) * 4;
+        if (lds > 64 * 1024) RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)k2_conv1_kernel, (int)lds));
+        hipLaunchKernelGGL(k2_conv1_kernel, dim3(pl.T2, B), dim3(256), lds, s, a0, pl.T1, pl.F, c1, pl.T2, pl.F2, c2, k.conv1_w, k.conv1_b, a1);
+    }
+    const long long rows3 = (long long)B * T3 * F3;
+    hipLaunchKernelGGL(k2_im2col_kernel, dim3((unsigned)((rows3 + 3) / 4)), dim3(256), 0, s, a1, pl.T2, pl.F2, c2, T3, F3, pl.Kp, rows3, col);
+    rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
+    RS_CHECK_LAUNCH(ctx, "zipformer encoder_embed convs");
+    RS_TRY(gemm(col, pl.Kp, k.conv2_w, pl.Kp, a2, c3, rows3, c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHR | RS_GEMM_OUT_F32, k.conv2_b, nullptr));
+    rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, 0.0);
+    hipLaunchKernelGGL(k2_cnx_dw_kernel, dim3(T3, B), dim3(256), 0, s, a2, lens3, T3, F3, c3, k.cnx_dw_w, k.cnx_dw_b, dwo);
+    rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
+    RS_TRY(gemm(dwo, c3, k.cnx_pw1_w, c3, hbuf, 3 * c3, rows3, 3 * c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHL, k.cnx_pw1_b, nullptr));
+    RS_TRY(gemm(hbuf, 3 * c3, k.cnx_pw2_w, 3 * c3, a2, c3, rows3, c3, RES, k.cnx_pw2_b, a2));
+    cast(a2, dwo, (size_t)rows3 * c3);                    // [B*T3][F3 * c3] in (f, c) order: the operand of `out`
+    const long long M3 = (long long)B * T3;
+    const int d0 = d.encoder_dim[0];
+    float* cur = reinterpret_cast<float*>(ws + pl.off_stackout[0]);       // embed output lands where stack 0's output will go ..
+    float* emb = x0;                                                         // .. after going through x0 (stack 0 reads it as `prev`)
+    RS_TRY(gemm(dwo, F3 * c3, k.emb_out_w, F3 * c3, emb, d0, M3, d0, RS_GEMM_BIAS | RS_GEMM_OUT_F32, k.emb_out_b, nullptr));
+    hipLaunchKernelGGL(k2_biasnorm_kernel, dim3((unsigned)((M3 + 3) / 4)), dim3(256), 0, s, emb, k.emb_norm_bias, k.emb_norm_scale, (const float*)nullptr,
+                       (const float*)nullptr, (int)M3, d0, emb, (uint16_t*)nullptr);
+    if (k.tap_embed) RS_HIP(ctx, hipMemcpyAsync(k.tap_embed, emb, (size_t)M3 * d0 * 4, hipMemcpyDeviceToDevice, s));
+    RS_CHECK_LAUNCH(ctx, "zipformer encoder_embed");
+    // ---- the stacks --------------------------------------------------------------------------------------------------------
+    const float* prev = emb;
+    int d_prev = d0;
+    size_t tap_off = 0;
+    for (int st = 0; st < d.n_stacks; ++st) {
+        const int dd = d.encoder_dim[st], H = d.num_heads[st], ds = d.downsampling[st], Ts = pl.Ts[st], Tp = pl.Tp[st], kk = d.cnn_kernel[st];
+        const int hid = 3 * dd / 4, hidp = pad64(hid), vw = H * K2_VD, vwp = pad64(vw), nin = (2 * K2_QD + K2_PD) * H;
+        const int32_t* lens = lens_all + (size_t)(1 + st) * B;
+        const long long M = (long long)B * Ts;
+        float* stack_out = reinterpret_cast<float*>(ws + pl.off_stackout[st]);
+        // full-rate stacks work in place on their output buffer; down-sampled ones on x, combined with src at the end
+        float* xs = ds == 1 ? stack_out : x;
+        hipLaunchKernelGGL(k2_stack_in_kernel, dim3(Ts, B), dim3(256), 0, s, prev, d_prev, lens3, T3, dd, ds, Ts, k.ds_w[st], ds == 1 ? (float*)nullptr : src, xs);
+        for (int j = 0; j < d.num_layers[st]; ++j) {
+            const rs_k2_layer& L = k.stacks[st][j];
+            const size_t n = (size_t)M * dd;
+            RS_HIP(ctx, hipMemcpyAsync(x0, xs, n * 4, hipMemcpyDeviceToDevice, s));
+            cast(xs, xb, n);
+            // attention weights, shared by the three attention modules of the layer
+            RS_TRY(gemm(xb, dd, L.attw_in_w, dd, qkp, nin, M, nin, RS_GEMM_BIAS, L.attw_in_b, nullptr));
+            {
+                const size_t lds = (size_t)(Ts + 64) * 16;
+                if (lds > 160 * 1024 - 1024) return rs_fail(ctx, RS_EINVAL, "zipformer: %d frames in stack %d exceed the attention kernel's position table in LDS", Ts, st);
+                if (lds > 64 * 1024) RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)k2_attn_weights_kernel, (int)lds));
+                if (Ts > k.pos_cap) return rs_fail(ctx, RS_EINVAL, "zipformer: %d frames exceed the registered position tables (%d)", Ts, k.pos_cap);
+                rs_prof_begin(ctx, RS_PROF_ATTN, s, (double)B * H * Ts * (double)Ts * (2.0 * K2_QD + 2.0 * K2_PD + 8.0) * 2.0, (double)B * H * Ts * (double)Tp * 2.0);
+                hipLaunchKernelGGL(k2_attn_weights_kernel, dim3((Ts + 63) / 64, H, B), dim3(256), lds, s, qkp, nin, L.pos_proj, k.pos_cap, H, lens, Ts, Tp, W);
+                rs_prof_end(ctx, RS_PROF_ATTN, s);
+            }
+            auto ffn = [&](int f, int width) -> int {
+                if (int r = gemm(xb, dd, L.ff_in_w[f], dd, big, width, M, width, RS_GEMM_BIAS | RS_GEMM_SWOOSHL, L.ff_in_b[f], nullptr); r != RS_OK) return r;
+                return gemm(big, width, L.ff_out_w[f], width, xs, dd, M, dd, RES, L.ff_out_b[f], xs);
+            };
+            auto self_attn = [&](int a) -> int {
+                if (int r = gemm(xb, dd, L.sa_in_w[a], dd, big, vw, M, vw, RS_GEMM_BIAS, L.sa_in_b[a], nullptr); r != RS_OK) return r;
+                // `av` is shared by the three kinds of branch (row pitches vwp / hidp / dd): the columns that pad the out projection's
+                // K extent to a multiple of 64 are zeroed before every use
+                if (vwp != vw && hipMemsetAsync(av, 0, (size_t)M * vwp * 2, s) != hipSuccess) return rs_fail(ctx, RS_EHIP, "memset failed");
+                rs_prof_begin(ctx, RS_PROF_ATTN, s, (double)B * H * Ts * (double)Ts * 2.0 * 16.0, (double)B * H * Ts * (double)Tp * 2.0);
+                hipLaunchKernelGGL((k2_pv_kernel<1, 0>), dim3((Ts + 63) / 64, 1, B * H), dim3(256), 0, s, W, H, Tp, big, vw, 0, lens, Ts, av, vwp);
+                rs_prof_end(ctx, RS_PROF_ATTN, s);
+                return gemm(av, vwp, L.sa_out_w[a], vwp, xs, dd, M, dd, RES, L.sa_out_b[a], xs);
+            };
+            auto conv_module = [&](int a) -> int {
+                if (int r = gemm(xb, dd, L.cm_in_w[a], dd, big, dd, M, 2 * dd, RS_GEMM_BIAS | RS_GEMM_GLU, L.cm_in_b[a], nullptr); r != RS_OK) return r;
+                if (int r = rs_launch_dwconv_act(ctx, big, L.cm_dw_w[a], L.cm_dw_b[a], lens, B, Ts, dd, kk, 1, av, s); r != RS_OK) return r;
+                return gemm(av, dd, L.cm_out_w[a], dd, xs, dd, M, dd, RES, L.cm_out_b[a], xs);
+            };
+            RS_TRY(ffn(0, d.ff_dim[st] * 3 / 4));
+            // non-linear attention: head 0's weights over tanh-gated values, output gate, out projection
+            cast(xs, xb, n);
+            RS_TRY(gemm(xb, dd, L.na_in_w, dd, big, 3 * hid, M, 3 * hid, RS_GEMM_BIAS, L.na_in_b, nullptr));
+            if (hidp != hid) RS_HIP(ctx, hipMemsetAsync(av, 0, (size_t)M * hidp * 2, s));
+            rs_prof_begin(ctx, RS_PROF_ATTN, s, (double)B * Ts * (double)Ts * 2.0 * hid, (double)B * Ts * (double)Tp * 2.0);
+            hipLaunchKernelGGL((k2_pv_kernel<4, 1>), dim3((Ts + 63) / 64, (hid + 63) / 64, B), dim3(256), 0, s, W, H, Tp, big, 3 * hid, hid, lens, Ts, av, hidp);
+            rs_prof_end(ctx, RS_PROF_ATTN, s);
+            RS_TRY(gemm(av, hidp, L.na_out_w, hidp, xs, dd, M, dd, RES, L.na_out_b, xs));
+            cast(xs, xb, n);
+            RS_TRY(self_attn(0));
+            cast(xs, xb, n);
+            RS_TRY(conv_module(0));
+            cast(xs, xb, n);
+            RS_TRY(ffn(1, d.ff_dim[st]));
+            hipLaunchKernelGGL(k2_bypass_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, xs, x0, L.bypass_mid, dd, n / 4, xb);
+            RS_TRY(self_attn(1));
+            cast(xs, xb, n);
+            RS_TRY(conv_module(1));
+            cast(xs, xb, n);
+            RS_TRY(ffn(2, d.ff_dim[st] * 5 / 4));
+            hipLaunchKernelGGL(k2_biasnorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, xs, L.norm_bias, L.norm_scale, x0, L.bypass, (int)M, dd, xs,
+                               (uint16_t*)nullptr);
+            RS_CHECK_LAUNCH(ctx, "zipformer layer");
+        }
+        if (ds > 1) hipLaunchKernelGGL(k2_stack_out_kernel, dim3(T3, B), dim3(256), 0, s, src, xs, T3, Ts, dd, ds, k.comb_scale[st], stack_out);
+        if (k.tap_stacks) {
+            RS_HIP(ctx, hipMemcpyAsync(k.tap_stacks + tap_off, stack_out, (size_t)M3 * dd * 4, hipMemcpyDeviceToDevice, s));
+            tap_off += (size_t)M3 * dd;
+        }
+        prev = stack_out;
+        d_prev = dd;
+        (void)cur;
+    }
+    // ---- output: widest channels of every stack, down-sampling by 2, joiner.encoder_proj -----------------------------------------
+    K2Pieces pc{};
+    {
+        int n = 0, cur_dim = d.encoder_dim[d.n_stacks - 1];
+        pc.p[n] = reinterpret_cast<const float*>(ws + pl.off_stackout[d.n_stacks - 1]); pc.c0[n] = 0; pc.n[n] = cur_dim; pc.ld[n] = cur_dim; ++n;
+        for (int st = d.n_stacks - 2; st >= 0; --st) {
+            const int dd = d.encoder_dim[st];
+            if (dd > cur_dim) {
+                pc.p[n] = reinterpret_cast<const float*>(ws + pl.off_stackout[st]); pc.c0[n] = cur_dim; pc.n[n] = dd - cur_dim; pc.ld[n] = dd; ++n;
+                cur_dim = dd;
+            }
+        }
+        pc.count = n;
+    }
+    const int To = pl.To;
+    hipLaunchKernelGGL(k2_output_kernel, dim3(To, B), dim3(256), 0, s, pc, lens3, T3, To, k.out_dim, k.out_ds_w, enc_out, encb, enc_lens);
+    RS_CHECK_LAUNCH(ctx, "zipformer output");
+    RS_TRY(gemm(encb, k.out_dim, ctx->jenc_w, k.out_dim, joint_enc, d.joiner_dim, (long long)B * To, d.joiner_dim, RS_GEMM_BIAS | RS_GEMM_OUT_F32, ctx->jenc_b,
+                nullptr));
+#undef RS_TRY
+    return RS_OK;
+}

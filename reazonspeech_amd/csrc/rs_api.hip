@@ -99,11 +99,11 @@ int rs_create(rs_ctx** out, int device, const rs_dims* dims) {
     else if (d.sub_stages < 2 || d.sub_stages > 4) rc = rs_fail(ctx, RS_EINVAL, "2..4 subsampling stages supported");
     else if (d.n_layers < 1) rc = rs_fail(ctx, RS_EINVAL, "n_layers");
     else if (d.pred_layers < 1 || d.pred_layers > 4) rc = rs_fail(ctx, RS_EINVAL, "pred_layers");
-    else if ((unsigned)d.frontend_kind > 1u || (unsigned)d.sub_kind > 1u || (unsigned)d.final_norm > 1u || (unsigned)d.joint_act > 1u)
+    else if ((unsigned)d.frontend_kind > 1u /* 2 = kaldi fbank: rs_k2_create only */ || (unsigned)d.sub_kind > 1u || (unsigned)d.final_norm > 1u || (unsigned)d.joint_act > 1u)
         rc = rs_fail(ctx, RS_EINVAL, "model family switches must be 0 or 1");
     else if (d.sub_kind == 1 && (d.sub_stages != 2 || d.sub_channels % 64)) rc = rs_fail(ctx, RS_EINVAL, "Conv2dSubsampling: x4 (two stages), channels %% 64");
     else if (d.frontend_kind == 1 && d.preemph != 0.0f) rc = rs_fail(ctx, RS_EINVAL, "the ESPnet front-end has no pre-emphasis");
-    else if (d.ctc_vocab < 0 || d.ctc_vocab % 4) rc = rs_fail(ctx, RS_EINVAL, "ctc_vocab %% 4");
+    else if (d.ctc_vocab < 0) rc = rs_fail(ctx, RS_EINVAL, "ctc_vocab < 0");
     if (rc != RS_OK) { *out = ctx; return rc; }  // caller can read rs_last_error, then rs_destroy
     ctx->head_dim = d.d_model / d.n_heads;
     int f = d.n_mels;
@@ -118,6 +118,7 @@ void rs_destroy(rs_ctx* ctx) {
     if (!ctx) return;
     for (auto& p : ctx->prof)
         for (auto e : p.ev) hipEventDestroy(e);
+    if (ctx->k2 && ctx->k2_free) ctx->k2_free(ctx->k2);
     delete ctx;
 }
 
@@ -158,6 +159,7 @@ extern "C" {
 
 int rs_finalize(rs_ctx* ctx) {
     if (!ctx) return RS_EINVAL;
+    if (ctx->k2) return rs_k2_finalize_impl(ctx);
     const rs_dims& d = ctx->d;
     Resolver r{ctx};
     const size_t C = d.sub_channels, dm = d.d_model, ff = d.ff_dim, H = d.pred_hidden, J = d.joint_hidden, V = d.n_logits;
@@ -170,7 +172,7 @@ int rs_finalize(rs_ctx* ctx) {
     if (d.frontend_kind == 1) { r.get("fe.mvn_mean", (size_t)d.n_mels, ctx->fe_mvn_mean); r.get("fe.mvn_istd", (size_t)d.n_mels, ctx->fe_mvn_istd); }
     if (d.sub_kind == 1) { r.get("sub.conv1.w", C * 9 * C, ctx->sub_conv1_w); r.get("sub.conv1.b", C, ctx->sub_conv1_b); }
     if (d.final_norm) { r.get("final_norm.g", dm, ctx->final_norm_g); r.get("final_norm.b", dm, ctx->final_norm_b); }
-    if (d.ctc_vocab > 0) { r.get("ctc.w", (size_t)d.ctc_vocab * dm, ctx->ctc_w); r.get("ctc.b", (size_t)d.ctc_vocab, ctx->ctc_b); }
+    if (d.ctc_vocab > 0) { r.get("ctc.w", (size_t)rs_ctc_pad(d.ctc_vocab) * dm, ctx->ctc_w); r.get("ctc.b", (size_t)rs_ctc_pad(d.ctc_vocab), ctx->ctc_b); }
     for (int s = 1; s < d.sub_stages && d.sub_kind == 0; ++s) {
         const std::string p = "sub.dw" + std::to_string(s), q = "sub.pw" + std::to_string(s);
         r.get(p + ".w", 9 * C, ctx->sub_dw_w[s - 1]);
@@ -245,7 +247,9 @@ int rs_finalize(rs_ctx* ctx) {
     ctx->has_f32 = false;
     if (ctx->tensors.count("sub.out.w.f32")) {
         rs_f32_weights& w = ctx->f32;
-        for (int s = 1; s < d.sub_stages; ++s) r.get("sub.pw" + std::to_string(s) + ".w.f32", C * C, w.sub_pw_w[s - 1]);
+        for (int s = 1; s < d.sub_stages && d.sub_kind == 0; ++s) r.get("sub.pw" + std::to_string(s) + ".w.f32", C * C, w.sub_pw_w[s - 1]);
+        if (d.sub_kind == 1) r.get("sub.conv1.w.f32", C * 9 * C, w.sub_conv1_w);
+        if (d.ctc_vocab > 0) r.get("ctc.w.f32", (size_t)rs_ctc_pad(d.ctc_vocab) * dm, w.ctc_w);
         r.get("sub.out.w.f32", dm * C * ctx->sub_freq, w.sub_out_w);
         w.layers.assign(d.n_layers, rs_layer_w32{});
         for (int i = 0; i < d.n_layers; ++i) {
@@ -313,6 +317,7 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return RS_EINVAL;
     if (!strcmp(key, "decode_screen")) { ctx->decode_screen = value != 0; return RS_OK; }
     if (!strcmp(key, "decode_narrow")) { ctx->decode_narrow = value != 0; return RS_OK; }
+    if (ctx->k2) return rs_fail(ctx, RS_EINVAL, "option '%s' does not apply to a Zipformer context", key);
     if (!strcmp(key, "fuse_glu")) {
         if (value < 0 || value > 1) return rs_fail(ctx, RS_EINVAL, "fuse_glu must be 0 or 1");
         ctx->fuse_glu = value;
@@ -339,9 +344,13 @@ int rs_encoder_set_taps(rs_ctx* ctx, float* sub_out, float* layer_out, const int
     return RS_OK;
 }
 
-int rs_mel_frames(const rs_ctx* ctx, int n_samples) { return n_samples / ctx->d.hop_length + (ctx->d.frontend_kind == 1 ? 1 : 0); }
+int rs_mel_frames(const rs_ctx* ctx, int n_samples) {
+    if (ctx->d.frontend_kind == 2) return (n_samples + ctx->d.hop_length / 2) / ctx->d.hop_length;     // kaldi, snip_edges = false
+    return n_samples / ctx->d.hop_length + (ctx->d.frontend_kind == 1 ? 1 : 0);
+}
 
 int rs_enc_frames(const rs_ctx* ctx, int n) {
+    if (ctx->k2) return rs_k2_enc_frames_impl(ctx, n);
     for (int s = 0; s < ctx->d.sub_stages; ++s) n = rs_conv_len(n, ctx->d.sub_kind);
     return n;
 }
@@ -401,7 +410,7 @@ EncPlan plan_encoder(const rs_ctx* ctx, int B, int t_max) {
     p.off_posp = o; o += rs_align((2 * Tp) * dm * 2);
     p.off_stats = o; o += rs_align(M * 2 * 4);          // (mean, rstd) per row of a deferred output norm
     p.off_ctc = o;
-    if (d.ctc_vocab > 0) o += rs_align(M * (size_t)d.ctc_vocab * 4);   // CTC logits when only the blank column is wanted
+    if (d.ctc_vocab > 0) o += rs_align(M * (size_t)rs_ctc_pad(d.ctc_vocab) * 4);   // CTC logits when only the blank column is wanted
     p.total = o + 256;
     return p;
 }
@@ -414,6 +423,11 @@ size_t rs_workspace_bytes(const rs_ctx* ctx, int B, int max_samples) {
     if (!ctx || B <= 0 || max_samples < 0) return 0;
     const int t_max = rs_mel_frames(ctx, max_samples);
     const size_t fe = rs_align((size_t)B * (t_max > 0 ? t_max : 1) * ctx->d.n_mels * 4) + 256;
+    if (ctx->k2) {
+        const size_t enc2 = rs_k2_workspace_bytes_impl(ctx, B, t_max), dec2 = rs_rnnt_workspace_bytes(ctx, B);
+        const size_t m2 = fe > enc2 ? fe : enc2;
+        return m2 > dec2 ? m2 : dec2;
+    }
     size_t enc = plan_encoder(ctx, B, t_max > 0 ? t_max : 1).total;
     if (ctx->has_f32) {                      // the float32 parity mode keeps float32 activations: about twice the scratch
         const size_t enc32 = rs_encoder_f32_workspace_bytes(ctx, B, t_max > 0 ? t_max : 1);
@@ -462,6 +476,7 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
     if (!feats || !n_frames || !joint_enc || !enc_lens || !workspace) return rs_fail(ctx, RS_EINVAL, "encoder: null pointer");
     const rs_dims& d = ctx->d;
     hipStream_t s = (hipStream_t)stream;
+    if (ctx->k2) return rs_k2_encoder_forward_impl(ctx, feats, n_frames, B, t_max, enc_out, joint_enc, enc_lens, workspace, workspace_bytes, s);
     if (ctx->precision_f32)
         return rs_encoder_forward_f32(ctx, feats, n_frames, B, t_max, enc_out, joint_enc, enc_lens, workspace, workspace_bytes, s);
     const EncPlan pl = plan_encoder(ctx, B, t_max);
@@ -612,8 +627,9 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
     if (d.ctc_vocab > 0 && (ctx->ctc_probs || ctx->ctc_blank)) {
         // CTC posteriors of every frame: logits by the same GEMM family, softmax in place
         float* z = ctx->ctc_probs ? ctx->ctc_probs : reinterpret_cast<float*>(ws + pl.off_ctc);
-        RS_TRY(gemm(hn, dm, ctx->ctc_w, dm, z, d.ctc_vocab, M, d.ctc_vocab, RS_GEMM_BIAS | RS_GEMM_OUT_F32, ctx->ctc_b, 1.0f, nullptr));
-        RS_TRY(rs_launch_ctc_softmax(ctx, z, M, d.ctc_vocab, d.ctc_vocab, d.blank_id, ctx->ctc_blank, s));
+        const int Vp = rs_ctc_pad(d.ctc_vocab);
+        RS_TRY(gemm(hn, dm, ctx->ctc_w, dm, z, Vp, M, Vp, RS_GEMM_BIAS | RS_GEMM_OUT_F32, ctx->ctc_b, 1.0f, nullptr));
+        RS_TRY(rs_launch_ctc_softmax(ctx, z, M, d.ctc_vocab, Vp, d.blank_id, ctx->ctc_blank, s));
     }
 #undef RS_TRY
     return RS_OK;

@@ -47,6 +47,10 @@ __device__ __forceinline__ float wave_max(float v) {
 // bf16 right after).  The exact-f32 decode path has its own polynomial versions in k_rnnt.hip.
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+// icefall's Swoosh activations (scaling.py; the Zipformer family): log(1 + exp(x - o)) - 0.08 x - c, softplus in its stable form
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))); }
+__device__ __forceinline__ float swoosh_l_f(float x) { return softplus_f(x - 4.0f) - 0.08f * x - 0.035f; }
+__device__ __forceinline__ float swoosh_r_f(float x) { return softplus_f(x - 1.0f) - 0.08f * x - 0.313261687f; }
 
 // ----------------------------------------------------------------------------------------
 // host side: context
@@ -79,6 +83,8 @@ struct rs_layer_w32 {
 };
 struct rs_f32_weights {
     const float* sub_pw_w[4] = {};
+    const float* sub_conv1_w = nullptr;  // ESPnet family: "sub.conv1.w.f32" [C][9C]
+    const float* ctc_w = nullptr;        // ESPnet family: "ctc.w.f32" [ctc rows padded to 4][d]
     const float* sub_out_w = nullptr;
     std::vector<rs_layer_w32> layers;
     const float* jenc_w = nullptr;
@@ -86,8 +92,12 @@ struct rs_f32_weights {
     size_t pos_table_bytes = 0;
 };
 
+struct rs_k2;                       // the Zipformer family's resolved weights and dimensions (k_zipformer.hip)
+
 struct rs_ctx {
     int device = 0;
+    rs_k2* k2 = nullptr;            // non-null: a context made by rs_k2_create (reazonspeech.k2.asr); the stage entry points dispatch on it
+    void (*k2_free)(rs_k2*) = nullptr;
     rs_dims d{};
     int head_dim = 0, sub_freq = 0;
     bool finalized = false;
@@ -114,6 +124,7 @@ struct rs_ctx {
     const uint16_t* jenc_w = nullptr;
     const float* jenc_b = nullptr;
     const float* lstm_w4[8] = {};   // optional "pred.lstm{l}.w4": fragment-major with rows permuted to (unit group, gate, unit)
+    const float* k2_conv_w = nullptr;   // stateless decoder (Zipformer family): grouped Conv1d over the last two tokens, f32 [D][4][2]
     const float *embed = nullptr, *lstm_w[8] = {}, *lstm_b[8] = {}, *jpred_w = nullptr, *jpred_b = nullptr,
                 *jout_w = nullptr, *jout_b = nullptr;
     // screened joint (optional tensors joint.out.w16 / .wrm / .bpad / .wmax; k_rnnt.hip)
@@ -219,5 +230,21 @@ int rs_launch_sub2d_conv0(rs_ctx* ctx, const float* feats, const int32_t* lens1,
                           uint16_t* out, hipStream_t s);
 int rs_launch_im2col3x3s2(rs_ctx* ctx, const uint16_t* in, int Bc, int T1, int F1, int T2, int F2, uint16_t* out, hipStream_t s);
 int rs_launch_ctc_softmax(rs_ctx* ctx, float* logits, int M, int V, int ld, int blank, float* blank_out, hipStream_t s);
+int rs_launch_sub2d_conv0_f32(rs_ctx* ctx, const float* feats, const int32_t* lens1, int b0, int Bc, int t_max, int T1, int F1,
+                              float* out, hipStream_t s);
+int rs_launch_im2col3x3s2_f32(rs_ctx* ctx, const float* in, int Bc, int T1, int F1, int T2, int F2, float* out, hipStream_t s);
+// rows of the registered CTC head ("ctc.w" / "ctc.b") and row pitch of the posteriors: the vocabulary padded to a multiple of 4
+static inline int rs_ctc_pad(int v) { return (v + 3) / 4 * 4; }
+// Zipformer family (k_zipformer.hip): the entry points of rs_api.hip dispatch to these when ctx->k2 is set
+int rs_k2_finalize_impl(rs_ctx* ctx);
+int rs_k2_unk_id(const rs_ctx* ctx);
+size_t rs_k2_workspace_bytes_impl(const rs_ctx* ctx, int B, int t_max);
+int rs_k2_enc_frames_impl(const rs_ctx* ctx, int n_feat);
+int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n_frames, int B, int t_max, float* enc_out, float* joint_enc,
+                               int32_t* enc_lens, void* workspace, size_t workspace_bytes, hipStream_t s);
+// depthwise Conv1d over time with a compile-time kernel size (7 / 15 / 31), frame mask, bias, activation (0 SiLU, 1 SwooshR):
+// x bf16 [B*T][d] -> out bf16 [B*T][d]; d % 64 == 0 (k_layernorm.hip)
+int rs_launch_dwconv_act(rs_ctx* ctx, const uint16_t* x, const float* w, const float* b, const int32_t* lens, int B, int T, int d, int k,
+                         int act, uint16_t* out, hipStream_t s);
 // output length of one subsampling conv (k 3, s 2): padding 1 (NeMo dw_striding) or none (ESPnet Conv2dSubsampling)
 static inline int rs_conv_len(int n, int sub_kind) { return sub_kind ? (n >= 3 ? (n - 3) / 2 + 1 : 0) : (n > 0 ? (n + 2 - 3) / 2 + 1 : 0); }

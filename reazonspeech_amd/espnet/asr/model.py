@@ -48,14 +48,14 @@ class _AsrModelView:
 
 
 class EspnetModel:
-    def __init__(self, cfg, state_dict, token_list, device="cuda", beam_size=1, max_pops=0):
+    def __init__(self, cfg, state_dict, token_list, device="cuda", beam_size=1, max_pops=0, precision="bf16"):
         assert cfg.espnet and len(token_list) == cfg.vocab_size
         if beam_size is not None and int(beam_size) > 1:
             cfg = cfg.with_(decoding="beam", beam_size=int(beam_size), beam_score_norm=True, beam_max_pops=int(max_pops))
         self.beam_size = cfg.beam_size if cfg.decoding == "beam" else 1
         self.cfg = cfg
         self.token_list = list(token_list)
-        self.am = AsrModel(cfg, state_dict, None, device=device, pad_seconds=0.0)
+        self.am = AsrModel(cfg, state_dict, None, device=device, pad_seconds=0.0, precision=precision)
         self.device = self.am.device
         self.dtype = "float32"
         self._last_enc = self._last_ctc = None
@@ -65,19 +65,50 @@ class EspnetModel:
     def __call__(self, speech):
         """Speech2Text.__call__: n-best list of (text, tokens, token ids, hypothesis); here nbest = 1 (upstream's default)"""
         wav = np.asarray(speech.detach().cpu().numpy() if isinstance(speech, torch.Tensor) else speech, dtype=np.float32).reshape(-1)
-        res = self.am.transcribe_waveforms([wav])
-        ids = res.ids[0]
+        ids = self._search([wav]).ids[0]
         tokens = [self.token_list[i] for i in ids]
-        return [("".join(tokens), tokens, ids, None)]
+        return [(self.tokens2text(tokens), tokens, ids, None)]
 
     # ---- direct forms -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def tokens2text(tokens):
+        """[UPSTREAM] espnet2 CharTokenizer.tokens2text (token_type: char): '<space>' stands for ' ', the rest joins as is"""
+        return "".join(" " if t == "<space>" else t for t in tokens)
+
     def ids_to_text(self, ids):
-        return "".join(self.token_list[i] for i in ids)
+        return self.tokens2text([self.token_list[i] for i in ids])
 
     def recognize_batch(self, waves):
         """padded like the reference pads each window (np.pad(samples, PADDING), transcribe.py:69) -> [text]"""
-        res = self.am.transcribe_waveforms([np.pad(np.asarray(w, np.float32), PADDING, mode="constant") for w in waves])
+        res = self._search([np.pad(np.asarray(w, np.float32), PADDING, mode="constant") for w in waves])
         return [self.ids_to_text(ids) for ids in res.ids]
+
+    def _search(self, waves):
+        """the transducer search over a batch of (padded) windows.  Upstream's default beam search has no bound on the
+        prediction-network evaluations a frame may take; the device search has one (`max_pops`, which sizes its workspace)
+        and reports RS_EOVERFLOW instead of truncating.  A batch that hits it is retried with 4x and 16x the bound, then
+        decoded greedily with a warning: one pathological window must not abort a whole file."""
+        from ...runtime.capi import RsError, RS_EOVERFLOW
+        am = self.am
+        if am.cfg.decoding != "beam":
+            return am.transcribe_waveforms(waves)
+        base = am.cfg
+        bound = base.beam_max_pops or 16 * base.beam_size
+        try:
+            for factor in (1, 4, 16):
+                am.cfg = base if factor == 1 else base.with_(beam_max_pops=bound * factor)
+                try:
+                    return am.transcribe_waveforms(waves)
+                except RsError as e:
+                    if e.code != RS_EOVERFLOW:
+                        raise
+            import warnings
+            warnings.warn(f"beam search: a frame needed more than {16 * bound} prediction-network evaluations; this window is "
+                          "decoded with the greedy search instead", RuntimeWarning, stacklevel=3)
+            am.cfg = base.with_(decoding="greedy_batch")
+            return am.transcribe_waveforms(waves)
+        finally:
+            am.cfg = base
 
     def recognize(self, samples):
         return self.recognize_batch([samples])[0]
@@ -86,7 +117,8 @@ class EspnetModel:
         am = self.am
         buf = am.stage([np.asarray(wav, np.float32)])
         M = buf.B * buf.tp_max
-        probs = torch.empty((M, self.cfg.n_logits), dtype=torch.float32, device=am.device)
+        vp = (self.cfg.n_logits + 3) // 4 * 4      # row pitch of the posteriors (include/rs_asr.h: rs_encoder_set_ctc_out)
+        probs = torch.empty((M, vp), dtype=torch.float32, device=am.device)
         enc = torch.empty((buf.B, buf.tp_max, self.cfg.d_model), dtype=torch.float32, device=am.device)
         with torch.cuda.device(am.device):
             stream = torch.cuda.current_stream().cuda_stream
@@ -98,7 +130,7 @@ class EspnetModel:
                 am.ctx.set_ctc_out(None, None)
             torch.cuda.synchronize(am.device)
         n = int(buf.enc_lens.cpu()[0])
-        return enc[:, :n].cpu(), probs.view(buf.B, buf.tp_max, -1)[:, :n].cpu()
+        return enc[:, :n].cpu(), probs.view(buf.B, buf.tp_max, vp)[:, :n, :self.cfg.n_logits].contiguous().cpu()
 
     def ctc_posteriors(self, samples):
         """softmax(ctc_lo(encoder(samples))) as float32 numpy [T'][vocab] (ctc.py:12-27 — no padding)"""

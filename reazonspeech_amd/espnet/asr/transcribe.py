@@ -21,7 +21,7 @@ PADDING = (16000, 8000)
 CHECKPOINT_ENV = "REAZONSPEECH_ESPNET_CHECKPOINT"
 
 
-def load_model(device=None, checkpoint=None, config=None, seed=0, beam_size=None, max_pops=0):
+def load_model(device=None, checkpoint=None, config=None, seed=0, beam_size=None, max_pops=0, precision="bf16"):
     """Load the ReazonSpeech ESPnet model onto a ROCm GPU (transcribe.py:12-32).
 
     Args:
@@ -35,7 +35,10 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, beam_size=None
         search.  None = 20 for a checkpoint (Speech2Text's default, which the reference keeps: :27-31) and 1 for synthetic
         weights (an untrained joint can make the default search extend one frame without end; see `max_pops`).
       max_pops (int): prediction-network evaluations the beam search may spend per frame (0 = 16 * beam_size); upstream has
-        no bound.  Exceeding it raises (RS_EOVERFLOW) rather than truncating.
+        no bound.  A window that exceeds it is retried with four and sixteen times the bound, then decoded greedily with a
+        warning (model.py: EspnetModel._search) — never truncated, and the windows already decoded are kept.
+      precision (str): "bf16" = the throughput mode; "fp32" = the float32 parity mode (float32 weights, activations and
+        arithmetic end to end — what ESPnet computes on the reference's path; include/rs_asr.h "precision_f32").
 
     The reference downloads `reazon-research/reazonspeech-espnet-v2` through espnet_model_zoo (:27-31), which an offline box
     cannot do; without a checkpoint this loads SEEDED SYNTHETIC weights of the architecture (timings are valid, transcripts
@@ -54,14 +57,30 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, beam_size=None
         if not os.path.exists(checkpoint):
             raise FileNotFoundError(f"checkpoint {checkpoint!r} does not exist")
         cfg, sd, tokens = read_espnet(checkpoint)
-        return EspnetModel(cfg, sd, tokens, device=device, beam_size=20 if beam_size is None else beam_size, max_pops=max_pops)
+        return EspnetModel(cfg, sd, tokens, device=device, beam_size=20 if beam_size is None else beam_size, max_pops=max_pops,
+                           precision=precision)
     cfg = config or ESPNET_CONFORMER_120M
     if config is None:
-        print("[reazonspeech_amd] WARNING: reazonspeech.espnet.asr has no checkpoint reader in this build — loading SEEDED SYNTHETIC "
-              "weights of the 120M Conformer-Transducer architecture: timings are valid, transcripts are meaningless.",
-              file=sys.stderr, flush=True)
+        print(f"[reazonspeech_amd] WARNING: no ESPnet2 checkpoint given (argument `checkpoint` or ${CHECKPOINT_ENV}: a model "
+              "directory / model-zoo .zip of reazon-research/reazonspeech-espnet-v2) — loading SEEDED SYNTHETIC weights of the 120M "
+              "Conformer-Transducer architecture: timings are valid, transcripts are meaningless.", file=sys.stderr, flush=True)
     return EspnetModel(cfg, synthetic_state_dict_espnet(cfg, seed), synthetic_token_list(cfg.vocab_size, seed), device=device,
-                       beam_size=1 if beam_size is None else beam_size, max_pops=max_pops)
+                       beam_size=1 if beam_size is None else beam_size, max_pops=max_pops, precision=precision)
+
+
+def _windows(model, waveform, window):
+    """Cut `waveform` into the pieces the recogniser sees (transcribe.py:59-67,78): everything that is left when it fits one
+    window, otherwise the head of the next `window` samples up to the middle of its longest silent stretch (`find_blank`).
+    Lazy: the blank finder of a piece runs after the previous piece has been recognised, like the reference's loop.
+    -> (offset, samples)"""
+    offset = 0
+    while offset < len(waveform):
+        rest = waveform[offset:]
+        if len(rest) > window:
+            gap = find_blank(model, rest[:window])
+            rest = rest[:int((gap.start + gap.end) / 2)]
+        yield offset, rest
+        offset += len(rest)
 
 
 def transcribe(model, audio, config=None):
@@ -75,33 +94,20 @@ def transcribe(model, audio, config=None):
     Returns:
       TranscribeResult
     """
-    if config is None:
-        config = TranscribeConfig()
+    config = config or TranscribeConfig()
     audio = norm_audio(audio)
-    pos = 0
-    fulltext = ""
-    segments = []
-    window = int(WINDOW_SECONDS * audio.samplerate)
+    rate = audio.samplerate
     total = len(audio.waveform)
-    while pos < total:
-        samples = audio.waveform[pos:]
-        # If the audio data is very long, find out the longest non-speech region and perform decoding up to that point.
-        if len(samples) > window:
-            blank = find_blank(model, samples[:window])
-            mid = int((blank.start + blank.end) / 2)
-            samples = samples[:mid]
-        asr = model(np.pad(samples, PADDING, mode="constant"))[0][0]
-        fulltext += asr
-        for start, end, text in split_text(model, samples, asr):
-            segments.append(Segment(
-                start_seconds=((pos + start) / audio.samplerate),
-                end_seconds=((pos + end) / audio.samplerate),
-                text=text,
-            ))
-        pos += len(samples)
-        if config.verbose:       # the reference draws a tqdm bar (transcribe.py:55-56,79-80)
-            print(f"\rTranscribe: {pos}/{total}", end="" if pos < total else "\n", file=sys.stderr, flush=True)
-    return TranscribeResult(fulltext, segments)
+    texts, segments = [], []
+    for offset, samples in _windows(model, audio.waveform, int(WINDOW_SECONDS * rate)):
+        text = model(np.pad(samples, PADDING, mode="constant"))[0][0]        # nbest[0] = (text, tokens, ids, hypothesis)
+        texts.append(text)
+        segments.extend(Segment(start_seconds=(offset + first) / rate, end_seconds=(offset + last) / rate, text=piece)
+                        for first, last, piece in split_text(model, samples, text))
+        if config.verbose:       # the reference draws a tqdm bar over the samples (transcribe.py:55-56,79-80)
+            done = offset + len(samples)
+            print(f"\rTranscribe: {done}/{total}", end="" if done < total else "\n", file=sys.stderr, flush=True)
+    return TranscribeResult("".join(texts), segments)
 
 
 def transcribe_batch(model, audios, config=None):

@@ -30,6 +30,7 @@ EXPORTS = [
     "rs_layernorm", "rs_relpos_attention", "rs_glu_dwconv_silu", "rs_glu_dwconv_silu_layout", "rs_encoder_set_taps", "rs_set_option", "rs_stream_create", "rs_stream_destroy",
     "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes", "rs_rnnt_beam", "rs_rnnt_beam_workspace_bytes", "rs_host_stage_rows",
     "rs_gemm_f32", "rs_relpos_attention_f32", "rs_glu_dwconv_silu_f32", "rs_profile_read_launches", "rs_encoder_set_ctc_out",
+    "rs_k2_create", "rs_k2_encoder_set_taps",
 ]
 
 
@@ -54,6 +55,27 @@ class RsDims(Structure):
                    cfg.att_right, cfg.n_global, cfg.n_logits, cfg.blank_id, cfg.pred_hidden, cfg.pred_layers,
                    cfg.joint_hidden, cfg.max_symbols,
                    *((1, 1, 1, 1, cfg.n_logits) if getattr(cfg, "espnet", False) else (0, 0, 0, 0, 0)))
+
+
+class RsK2Dims(Structure):
+    """mirror of `struct rs_k2_dims` (the Zipformer2 transducer of reazonspeech.k2.asr)"""
+    _fields_ = [
+        ("n_mels", c_int32), ("frame_length", c_int32), ("frame_shift", c_int32), ("preemph", c_float),
+        ("embed_c1", c_int32), ("embed_c2", c_int32), ("embed_c3", c_int32), ("n_stacks", c_int32),
+        ("encoder_dim", c_int32 * 8), ("num_layers", c_int32 * 8), ("ff_dim", c_int32 * 8), ("num_heads", c_int32 * 8),
+        ("cnn_kernel", c_int32 * 8), ("downsampling", c_int32 * 8),
+        ("query_head_dim", c_int32), ("value_head_dim", c_int32), ("pos_head_dim", c_int32), ("pos_dim", c_int32),
+        ("vocab_size", c_int32), ("decoder_dim", c_int32), ("joiner_dim", c_int32), ("context_size", c_int32),
+        ("blank_id", c_int32), ("unk_id", c_int32),
+    ]
+
+    @classmethod
+    def from_config(cls, cfg):
+        arr = lambda t: (c_int32 * 8)(*(list(t) + [0] * (8 - len(t))))      # noqa: E731
+        return cls(cfg.n_mels, cfg.frame_length, cfg.frame_shift, cfg.preemph, *cfg.embed_channels, cfg.n_stacks,
+                   arr(cfg.encoder_dim), arr(cfg.num_layers), arr(cfg.ff_dim), arr(cfg.num_heads), arr(cfg.cnn_kernel), arr(cfg.downsampling),
+                   cfg.query_head_dim, cfg.value_head_dim, cfg.pos_head_dim, cfg.pos_dim, cfg.vocab_size, cfg.decoder_dim, cfg.joiner_dim,
+                   cfg.context_size, cfg.blank_id, cfg.unk_id)
 
 
 class RsError(RuntimeError):
@@ -125,7 +147,9 @@ def load():
     lib.rs_relpos_attention_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp]
     lib.rs_glu_dwconv_silu_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp]
     lib.rs_encoder_set_ctc_out.argtypes = [vp, vp, vp]
-    if lib.rs_abi_version() != 4:
+    lib.rs_k2_create.argtypes = [POINTER(c_void_p), c_int, POINTER(RsK2Dims)]
+    lib.rs_k2_encoder_set_taps.argtypes = [vp, vp, vp]
+    if lib.rs_abi_version() != 5:
         raise ImportError("librs_asr.so ABI version mismatch")
     _lib = lib
     return lib
@@ -186,8 +210,12 @@ class Context:
         self.device_index = int(device_index)
         self._h = c_void_p()
         self._keep = {}
-        dims = RsDims.from_config(cfg)
-        rc = self.lib.rs_create(byref(self._h), int(device_index), byref(dims))
+        if getattr(cfg, "family", "nemo") == "k2":           # the Zipformer2 transducer of reazonspeech.k2.asr
+            dims = RsK2Dims.from_config(cfg)
+            rc = self.lib.rs_k2_create(byref(self._h), int(device_index), byref(dims))
+        else:
+            dims = RsDims.from_config(cfg)
+            rc = self.lib.rs_create(byref(self._h), int(device_index), byref(dims))
         if rc != RS_OK:
             msg = self.lib.rs_last_error(self._h).decode() if self._h else "rs_create failed"
             if self._h:
@@ -261,6 +289,12 @@ class Context:
         ids = (c_int32 * len(layer_ids))(*layer_ids)
         self._taps = (sub_out, layer_out)          # keep the buffers alive while registered
         self.check(self.lib.rs_encoder_set_taps(self._h, _ptr(sub_out), _ptr(layer_out), ids, len(layer_ids)))
+
+    def set_k2_taps(self, embed_out=None, stack_out=None):
+        """parity taps of a Zipformer context (tests): encoder_embed's output f32 [B*T3][encoder_dim[0]] and the stacks' outputs
+        f32 [B*T3][encoder_dim[s]] one after the other; no arguments = off"""
+        self._k2_taps = (embed_out, stack_out)
+        self.check(self.lib.rs_k2_encoder_set_taps(self._h, _ptr(embed_out), _ptr(stack_out)))
 
     def set_ctc_out(self, probs=None, blank_prob=None):
         """CTC posteriors of the next encoder calls (ESPnet family): f32 [B*tp_max][vocab] and / or the blank column

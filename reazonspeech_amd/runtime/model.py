@@ -157,7 +157,14 @@ class AsrModel:
         self.pos_cap = 0
         with torch.cuda.device(self.device):
             self.ctx = capi.Context(cfg, index)
-            if cfg.espnet:
+            if getattr(cfg, "family", "") == "k2":
+                if precision != "bf16":
+                    raise ValueError("the Zipformer path has no float32 parity mode")
+                from .k2_weights import prepare_weights_k2
+                self._k2_sd = state_dict          # the position tables are re-projected when a longer utterance arrives
+                self._upload_k2(prepare_weights_k2(cfg, state_dict, pos_cap))
+                self.pos_cap = pos_cap
+            elif cfg.espnet:
                 from .weights_espnet import prepare_weights_espnet
                 self._upload(prepare_weights_espnet(cfg, state_dict, pos_cap, f32=precision == "fp32"))
             else:
@@ -173,6 +180,14 @@ class AsrModel:
             self.ctx.set_tensor(name, dev[name])
         self._pos_w = [dev[f"L{i}.att.pos.w"] for i in range(self.cfg.n_layers)]
         self._set_pos_tables(dev["pos.table"], dev.get("pos.table.f32"))
+
+    def _upload_k2(self, tensors):
+        for name, t in tensors.items():
+            dev = t.to(self.device, non_blocking=False).contiguous()
+            for c in self._contexts():
+                c.set_tensor(name, dev)
+        for c in self._contexts():
+            c.finalize()
 
     def _contexts(self):
         return [self.ctx] + [c for c, _ in self._dec_lanes]
@@ -203,6 +218,19 @@ class AsrModel:
         """Long-form audio: the reference hands a whole file to the model as ONE utterance
         (pkg/nemo-asr/src/transcribe.py:44-53), so T' is unbounded.  The resident position tables cover T' up to
         `pos_cap`; a longer utterance grows them (next power of two) instead of failing."""
+        if getattr(self.cfg, "family", "") == "k2":
+            # the 50 Hz stack of a Zipformer has twice the output frames (+ 1): its position tables must cover that
+            need = 2 * int(tp) + 2
+            if need <= self.pos_cap:
+                return
+            from .k2_weights import prepare_weights_k2
+            cap = 1 << (need - 1).bit_length()
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.device(self.device):
+                tensors = prepare_weights_k2(self.cfg, self._k2_sd, cap)
+                self._upload_k2({k: v for k, v in tensors.items() if k.endswith("attw.pos_proj")})
+            self.pos_cap = cap
+            return
         if tp <= self.pos_cap:
             return
         from .weights import rel_pos_table
@@ -229,7 +257,7 @@ class AsrModel:
         $RS_DECODE_SCREEN / $RS_DECODE_NARROW override (A/B runs)."""
         if "RS_DECODE_SCREEN" in os.environ or "RS_DECODE_NARROW" in os.environ:
             return
-        if self is not None and self.cfg.espnet:   # tanh joint: the exact kernels (the screened joint's bound is derived for ReLU)
+        if self is not None and (self.cfg.espnet or getattr(self.cfg, "family", "") == "k2"):   # tanh joint: the exact kernels (the screened joint's bound is derived for ReLU)
             ctx.set_option("decode_screen", 0)
             ctx.set_option("decode_narrow", 0 if (pipelined and lanes == 1 and B >= 128) else 1)
             return

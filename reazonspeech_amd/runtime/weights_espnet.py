@@ -112,13 +112,20 @@ def prepare_weights_espnet(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_ca
       * "final_norm.*" (encoder.after_norm), "ctc.w" / "ctc.b" (ctc.ctc_lo);
       * joint: lin_enc -> "joint.enc.*", lin_dec (no bias) -> "joint.pred.*" with a zero bias, lin_out -> "joint.out.*".
     """
-    if f32:
-        raise UnsupportedCheckpoint("the float32 parity mode is built for the NeMo family only")
     assert cfg.espnet
+    want_f32 = bool(f32)
     out = {}
     used = set()
-    bf = lambda t: t.detach().to(torch.float32).to(torch.bfloat16).contiguous()   # noqa: E731
     f32t = lambda t: t.detach().to(torch.float32).contiguous()                     # noqa: E731
+
+    class _Dense:
+        """a GEMM weight: bf16 for the throughput mode and, for the float32 parity mode (`f32=True`, include/rs_asr.h
+        "precision_f32"), once more unrounded as "<name>.f32" in the same layout"""
+        def __init__(self, t):
+            self.t = t.detach().to(torch.float32).contiguous()
+
+    def bf(t):
+        return _Dense(t)
 
     def get(key):
         if key not in sd:
@@ -170,8 +177,11 @@ def prepare_weights_espnet(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_ca
         out[p + "att.bias_v"] = f32t(get(A + "pos_bias_v").reshape(-1))
         Cm = L + "conv_module."
         rows = glu_interleave_index(d)
-        out[p + "conv.pw1.w"] = bf(get(Cm + "pointwise_conv1.weight").squeeze(-1)[rows])
+        out[p + "conv.pw1.w"] = get(Cm + "pointwise_conv1.weight").squeeze(-1)[rows].detach().to(torch.float32).to(torch.bfloat16).contiguous()
         out[p + "conv.pw1.b"] = f32t(get(Cm + "pointwise_conv1.bias")[rows])
+        if want_f32:      # the float32 conv kernel applies the GLU itself: ESPnet's own row order (values | gates)
+            out[p + "conv.pw1.w.f32"] = f32t(get(Cm + "pointwise_conv1.weight").squeeze(-1))
+            out[p + "conv.pw1.b.f32"] = f32t(get(Cm + "pointwise_conv1.bias"))
         g, b = get(Cm + "norm.weight").double(), get(Cm + "norm.bias").double()
         mu, var = get(Cm + "norm.running_mean").double(), get(Cm + "norm.running_var").double()
         sc = g / torch.sqrt(var + cfg.bn_eps)
@@ -181,8 +191,16 @@ def prepare_weights_espnet(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_ca
         out[p + "conv.pw2.b"] = f32t(get(Cm + "pointwise_conv2.bias"))
     out["final_norm.g"] = f32t(get("encoder.after_norm.weight"))
     out["final_norm.b"] = f32t(get("encoder.after_norm.bias"))
-    out["ctc.w"] = bf(get("ctc.ctc_lo.weight"))
-    out["ctc.b"] = f32t(get("ctc.ctc_lo.bias"))
+    # the CTC head's rows padded to a multiple of 4 (the GEMMs' N % 4 rule; a real token list has any length): zero rows
+    # with a bias of -1e30, never read back (the softmax kernel runs over vocab_size columns and zeroes the rest)
+    V = cfg.n_logits
+    Vp = (V + 3) // 4 * 4
+    cw = torch.zeros((Vp, d), dtype=torch.float32)
+    cw[:V] = get("ctc.ctc_lo.weight").detach().to(torch.float32)
+    cb = torch.full((Vp,), -1.0e30, dtype=torch.float32)
+    cb[:V] = get("ctc.ctc_lo.bias").detach().to(torch.float32)
+    out["ctc.w"] = bf(cw)
+    out["ctc.b"] = cb
     out["joint.enc.w"] = bf(get("joint_network.lin_enc.weight"))
     out["joint.enc.b"] = f32t(get("joint_network.lin_enc.bias"))
     out["pred.embed"] = f32t(get("decoder.embed.weight"))
@@ -198,7 +216,14 @@ def prepare_weights_espnet(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_ca
     out["joint.pred.b"] = torch.zeros((cfg.joint_hidden,), dtype=torch.float32)           # lin_dec has no bias
     out["joint.out.w"] = to_fragment_major(get("joint_network.lin_out.weight"))
     out["joint.out.b"] = f32t(get("joint_network.lin_out.bias"))
+    for name in [k for k, v in out.items() if isinstance(v, _Dense)]:
+        t = out[name].t
+        out[name] = t.to(torch.bfloat16).contiguous()
+        if want_f32:
+            out[name + ".f32"] = t
     out["pos.table"] = torch.from_numpy(rel_pos_table(cfg, pos_cap)).to(torch.bfloat16).contiguous()
+    if want_f32:
+        out["pos.table.f32"] = torch.from_numpy(rel_pos_table(cfg, pos_cap)).contiguous()
     benign = ("num_batches_tracked",)
     left = [k for k in sd if k not in used and not k.endswith(benign)]
     if left:
@@ -232,9 +257,16 @@ def config_from_espnet_yaml(doc: dict) -> ModelConfig:
     need(doc.get("preencoder") in (None, "null") and doc.get("postencoder") in (None, "null"), "pre / post encoders")
     need(isinstance(tokens, (list, tuple)) and len(tokens) > 2, "a token_list")
     need(str(enc.get("input_layer", "conv2d")) == "conv2d", f"encoder_conf.input_layer={enc.get('input_layer')!r}")
-    need(str(enc.get("pos_enc_layer_type", "rel_pos")) == "rel_pos" and str(enc.get("selfattention_layer_type", "rel_selfattn")) == "rel_selfattn"
-         and str(enc.get("rel_pos_type", "latest")) == "latest", "anything but the latest rel_pos / rel_selfattn attention")
-    need(bool(enc.get("macaron_style", True)) and bool(enc.get("use_cnn_module", True)), "a conformer without macaron FFN / conv module")
+    # Absent keys take ESPnet's OWN constructor defaults ([UPSTREAM] espnet2 ConformerEncoder: rel_pos_type "legacy",
+    # macaron_style False, zero_triu False; TransducerDecoder hidden_size 320; JointNetwork joint_space_size 256): config.yaml
+    # stores encoder_conf as the recipe wrote it, so a recipe that omits rel_pos_type TRAINED the legacy attention — which has
+    # the same parameter shapes as the latest one and would load silently.
+    need(str(enc.get("pos_enc_layer_type", "rel_pos")) == "rel_pos" and str(enc.get("selfattention_layer_type", "rel_selfattn")) == "rel_selfattn",
+         f"pos_enc_layer_type={enc.get('pos_enc_layer_type')!r} / selfattention_layer_type={enc.get('selfattention_layer_type')!r}")
+    need(str(enc.get("rel_pos_type", "legacy")) == "latest",
+         f"rel_pos_type={enc.get('rel_pos_type', 'legacy (ESPnet default when the key is absent)')!r}: the legacy relative-position attention")
+    need(not enc.get("zero_triu", False), "zero_triu=True")
+    need(bool(enc.get("macaron_style", False)) and bool(enc.get("use_cnn_module", True)), "a conformer without macaron FFN / conv module")
     need(bool(enc.get("normalize_before", True)) and not enc.get("concat_after", False), "post-norm / concat_after blocks")
     need(str(enc.get("activation_type", "swish")) == "swish", f"encoder_conf.activation_type={enc.get('activation_type')!r}")
     need(str(enc.get("positionwise_layer_type", "linear")) == "linear", "non-linear position-wise layers")
@@ -244,7 +276,7 @@ def config_from_espnet_yaml(doc: dict) -> ModelConfig:
     fs_raw = str(fe.get("fs", 16000))                    # ESPnet accepts "16k" (humanfriendly) as well as 16000
     fs = int(float(fs_raw[:-1]) * 1000) if fs_raw.lower().endswith("k") else int(fs_raw)
     n_fft = int(fe.get("n_fft", 512))
-    hidden = int(dec.get("hidden_size", 256))
+    hidden = int(dec.get("hidden_size", 320))
     need(int(dec.get("embed_size", hidden)) == hidden or "embed_size" not in dec, "decoder embed_size != hidden_size")
     need(not fe.get("htk", False) and int(fe.get("fmin") or 0) == 0 and fe.get("fmax") in (None, "null", fs // 2),
          "a mel filterbank other than Slaney 0 .. fs/2")
@@ -285,15 +317,21 @@ def read_espnet(path: str):
     doc = yaml.safe_load(read(cfg_key))
     cfg = config_from_espnet_yaml(doc)
     sd = torch.load(io.BytesIO(read(pth_key)), map_location="cpu", weights_only=True)
+    token_type = str(doc.get("token_type", "char"))
+    if token_type != "char":
+        raise UnsupportedCheckpoint(f"{path}: token_type={token_type!r} (only character token lists are decoded to text here)")
+    sd = dict(sd)
+    if "normalize.mean" in sd and "normalize.std" in sd:
+        # [UPSTREAM] GlobalMVN registers mean / std as buffers: a saved model normally carries them already
+        return cfg, sd, list(doc["token_list"])
     stats_name = os.path.basename(str((doc.get("normalize_conf") or {}).get("stats_file", "feats_stats.npz")))
     st_key = next((k for k in sorted(files) if os.path.basename(k) == stats_name), None)
     if st_key is None:
-        raise UnsupportedCheckpoint(f"{path}: GlobalMVN statistics {stats_name!r} not found")
+        raise UnsupportedCheckpoint(f"{path}: GlobalMVN statistics {stats_name!r} not found (and no normalize.mean / .std in the state dict)")
     st = np.load(io.BytesIO(read(st_key)))
     count = float(st["count"])                        # [UPSTREAM] espnet2/layers/global_mvn.py: mean = sum / count, var = sum_sq / count - mean^2
     mean = st["sum"].astype(np.float64) / count
     var = st["sum_square"].astype(np.float64) / count - mean * mean
-    sd = dict(sd)
     sd["normalize.mean"] = torch.from_numpy(mean.astype(np.float32))
     sd["normalize.std"] = torch.from_numpy(np.sqrt(np.maximum(var, 1e-20)).astype(np.float32))
     return cfg, sd, list(doc["token_list"])

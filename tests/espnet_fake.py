@@ -104,3 +104,57 @@ class FakeEspnetModel:
 def long_audio(seconds, seed=3):
     rng = np.random.default_rng(seed)
     return (0.1 * rng.standard_normal(int(seconds * 16000))).astype(np.float32)
+
+
+class ColumnModel:
+    """a model whose CTC posteriors are GIVEN (blank column `col`, the rest spread over one other token): drives
+    `find_blank` on arbitrary blank patterns through both call forms"""
+    dtype = "float32"
+    device = "cpu"
+
+    def __init__(self, col):
+        col = np.asarray(col, np.float32)
+        self._lpz = np.zeros((len(col), 4), np.float32)
+        self._lpz[:, 0] = col
+        self._lpz[:, 2] = 1.0 - col
+        outer = self
+
+        class _A:
+            blank_id = 0
+            token_list = ["<blank>", "<unk>", "a", "<sos/eos>"]
+
+            def __init__(self):
+                self.ctc = _Ctc()
+
+            def encode(self, speech, length):
+                enc = torch.zeros((1, outer._lpz.shape[0], 1))
+                enc._lpz = torch.from_numpy(outer._lpz)[None]
+                return enc, torch.tensor([outer._lpz.shape[0]])
+        self.asr_model = _A()
+
+    def ctc_posteriors(self, samples):
+        return self._lpz
+
+
+def blank_patterns(n_cases=120, seed=11):
+    """(n_samples, blank column) cases for `find_blank`: runs that touch either end, ties in length, windows with fewer
+    samples than frames, all-silent and all-speech windows"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n_cases):
+        T = int(rng.integers(1, 90))
+        n = int(rng.integers(1, 40)) if k % 9 == 0 else int(rng.integers(T, 400 * T + 2))
+        col = np.full(T, 0.5, np.float32)
+        t = 0 if k % 4 == 0 else int(rng.integers(0, 6))
+        while t < T:
+            run = int(rng.integers(1, 12)) if k % 5 else 4
+            col[t:t + run] = 0.99
+            t += run + int(rng.integers(1, 9))
+        if k % 7 == 0:
+            col[:] = 0.99
+        if k % 13 == 0:
+            col[:] = 0.2
+        if k % 3 == 0:
+            col[-int(rng.integers(1, 5)):] = 0.995
+        out.append((n, col))
+    return out

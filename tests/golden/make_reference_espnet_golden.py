@@ -52,7 +52,10 @@ def cases():
 def main():
     import espnet_fake as fk
     ref = load_reference()
-    out = {"cases": {}, "find_end_of_segment": []}
+    out = {"cases": {}, "find_end_of_segment": [], "find_blank": []}
+    for n, col in fk.blank_patterns():
+        b = ref["ctc"].find_blank(fk.ColumnModel(col), np.zeros(n, np.float32))
+        out["find_blank"].append([int(b.start), int(b.end)])
     for name, wav in cases():
         model = fk.FakeEspnetModel()
         audio = ref["interface"].AudioData(wav, 16000)

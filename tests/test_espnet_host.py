@@ -43,6 +43,16 @@ def test_transcribe_windowing_and_segments_match_the_reference(name):
     assert sum(model.calls) == len(wav)                      # the windows tile the audio exactly
 
 
+def test_find_blank_matches_the_reference_on_arbitrary_blank_patterns():
+    """120 blank-posterior patterns (runs touching either end, ties, fewer samples than frames, all silent / all speech): the
+    run-length implementation returns what the reference's per-frame scan (ctc.py:29-58) returned"""
+    pats = fk.blank_patterns()
+    assert len(pats) == len(GOLD["find_blank"])
+    for (n, col), want in zip(pats, GOLD["find_blank"]):
+        b = ctc.find_blank(fk.ColumnModel(col), np.zeros(n, np.float32))
+        assert [int(b.start), int(b.end)] == want, (n, col.tolist())
+
+
 def test_find_end_of_segment_matches_the_reference():
     for case in GOLD["find_end_of_segment"]:
         assert ctc.find_end_of_segment(case["text"], case["timings"], case["start"]) == case["end"], case

@@ -1,0 +1,251 @@
+"""-m gpu: END-TO-END id parity of `reazonspeech.espnet.asr` (pkg/espnet-asr/src/transcribe.py:59-77, ctc.py:12-58).
+
+ESPnet computes this path in float32; `load_model(precision="fp32")` does too (include/rs_asr.h "precision_f32": exact-f32
+matrix-core GEMMs, float32 activations — Conv2dSubsampling, k = 31 conv module, after_norm and the CTC head included).
+The checker is the float32 CPU oracle run end to end, one utterance per call with the reference's (16000, 8000) padding:
+tests/golden/bench_espnet_fp32.npz (generator: tests/golden/make_espnet_golden.py) holds its output for EVERY row of the
+ESPnet benchmark batch (bench.py `configs.espnet_120m`: 256 x 10 s, seed 4242).
+
+  float32 mode vs the float32 oracle      joint projection (fingerprint of all rows, rows 0-1 in full), CTC blank posteriors:
+                                          <= 1e-4; greedy ids AND frames IDENTICAL on every row (near-tie rows named by the golden
+                                          may differ at a decision whose margin is below 1e-4)
+  beam search, whole utterances           the device search on the float32 mode's projection: bit-exact (labels, frames, float32
+                                          scores, pops) vs oracle/espnet_beam.c on the same tensor, and labels identical to the
+                                          float64 restatement of ESPnet's default_beam_search on the ORACLE's projection
+                                          (32 rows x 358 frames, beam 20)
+  bf16 throughput mode                    flip-audited on all 256 rows against the float32 mode (oracle/audit.py): every flip
+                                          inside the Lipschitz bound, every row without a flip identical to the golden
+PARITY UNPINNED against ESPnet itself (neither it nor its checkpoint can run here): every check is against oracle/espnet.py.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from reazonspeech_amd.runtime.config import ESPNET_TINY, ESPNET_CONFORMER_120M
+from reazonspeech_amd.runtime.synth import synthetic_batch
+from reazonspeech_amd.runtime.weights_espnet import synthetic_state_dict_espnet
+from reazonspeech_amd.espnet.asr.model import EspnetModel, synthetic_token_list, PADDING
+from oracle import espnet as oe, greedy as og
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "bench_espnet_fp32.npz")
+REPORT = os.path.join(os.path.dirname(HERE), "gpurun_out", "espnet_parity.json")
+TOL_F32 = 1e-4          # float32 mode vs float32 oracle (reassociation only)
+TOL_BF16 = 0.08         # bf16 mode joint projection vs float32 (tests/test_gpu_espnet.py states the same bar)
+
+
+def report(key, value):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    data = {}
+    if os.path.exists(REPORT):
+        try:
+            data = json.load(open(REPORT))
+        except Exception:
+            data = {}
+    data[key] = value
+    json.dump(data, open(REPORT, "w"), indent=1, sort_keys=True)
+
+
+def ragged(gold, name, b, off=None):
+    off = gold[(off or name) + "_offsets"]
+    return gold[name][off[b]:off[b + 1]].tolist()
+
+
+def run_with_ctc(model, waves):
+    am = model.am
+    buf = am.stage(waves, buf=am.new_buffers(len(waves), max(len(w) for w in waves)))
+    vp = (am.cfg.n_logits + 3) // 4 * 4
+    M = buf.B * buf.tp_max
+    probs = torch.zeros((M, vp), dtype=torch.float32, device=am.device)
+    blank = torch.zeros((M,), dtype=torch.float32, device=am.device)
+    am.ctx.set_ctc_out(probs, blank)
+    try:
+        am.run_device(buf)
+        torch.cuda.synchronize()
+    finally:
+        am.ctx.set_ctc_out(None, None)
+    return buf, probs.view(buf.B, buf.tp_max, vp), blank.view(buf.B, buf.tp_max), am.collect(buf)
+
+
+def test_tiny_fp32_mode_vs_fp32_oracle(gpu_device):
+    """toy geometry, ragged batch: float32 mode within 1e-4 of the float32 oracle at every stage it exposes, greedy ids and
+    frames identical to the oracle's own end-to-end greedy search, batch-invariant bits"""
+    cfg = ESPNET_TINY
+    sd = synthetic_state_dict_espnet(cfg, 3)
+    model = EspnetModel(cfg, sd, synthetic_token_list(cfg.vocab_size, 3), device="cuda:0", precision="fp32")
+    audio, lens = synthetic_batch(4, 3.0, seed=5, ragged=True, min_seconds=0.7)
+    waves = [audio[b, :lens[b]] for b in range(4)]
+    buf, probs, blank, got = run_with_ctc(model, waves)
+    ref = oe.forward(cfg, sd, torch.from_numpy(audio), torch.from_numpy(lens), "fp32")
+    assert got.enc_lens == ref["enc_lens"].tolist()
+    want = oe.greedy_torch(cfg, sd, ref["joint_enc"], ref["enc_lens"])
+    for b in range(4):
+        n = got.enc_lens[b]
+        assert (buf.joint_enc[b, :n].cpu() - ref["joint_enc"][b, :n]).abs().max() <= TOL_F32
+        assert (probs[b, :n, :cfg.n_logits].cpu() - ref["ctc"][b, :n]).abs().max() <= TOL_F32
+        assert torch.equal(blank[b, :n], probs[b, :n, cfg.blank_id])
+    assert got.ids == [w[0] for w in want] and got.frames == [w[1] for w in want]
+    _, p1, _, alone = run_with_ctc(model, waves[2:3])
+    n = alone.enc_lens[0]
+    assert torch.equal(p1[0, :n], probs[2, :n]) and alone.ids[0] == got.ids[2] and alone.frames[0] == got.frames[2]
+
+
+def test_ctc_vocabulary_not_a_multiple_of_four(gpu_device):
+    """a real token list has any length: the CTC head is registered padded to a multiple of 4 and the posteriors come back
+    with exactly vocab_size columns (both precisions)"""
+    cfg = ESPNET_TINY.with_(vocab_size=95)
+    sd = synthetic_state_dict_espnet(cfg, 4)
+    wav = synthetic_batch(1, 2.0, seed=6)[0][0]
+    ref = oe.forward(cfg, sd, torch.from_numpy(wav)[None], torch.tensor([len(wav)]), "fp32")["ctc"][0].numpy()
+    for precision, tol in (("fp32", TOL_F32), ("bf16", 3e-2)):
+        model = EspnetModel(cfg, sd, synthetic_token_list(95, 4), device="cuda:0", precision=precision)
+        post = model.ctc_posteriors(wav)
+        assert post.shape == ref.shape and post.shape[1] == 95
+        assert np.abs(post - ref).max() <= tol and abs(float(post.sum(-1).mean()) - 1.0) < 1e-4
+        assert isinstance(model.recognize(wav), str)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def bench_waves(gold):
+    audio, lens = synthetic_batch(256, 10.0, seed=int(gold["seed"]))
+    assert hashlib.sha256(audio.tobytes()).digest() == bytes(gold["audio_sha256"].tolist()), "inputs drifted from the golden's"
+    return [np.pad(audio[b, :lens[b]], PADDING) for b in range(256)]
+
+
+@pytest.fixture(scope="module")
+def run32(gpu_device, gold, bench_waves):
+    """the float32 mode over the whole benchmark batch -> (DecodedBatch, joint projection on the device, blank posteriors)"""
+    cfg = ESPNET_CONFORMER_120M
+    sd = synthetic_state_dict_espnet(cfg, 0)
+    model = EspnetModel(cfg, sd, synthetic_token_list(cfg.vocab_size, 0), device="cuda:0", precision="fp32")
+    buf, probs, blank, got = run_with_ctc(model, bench_waves)
+    out = (got, buf.joint_enc.clone(), blank.clone(), probs[:, :, :cfg.n_logits].argmax(-1).to(torch.int16).cpu().numpy())
+    del model, buf, probs
+    torch.cuda.empty_cache()
+    return out
+
+
+def test_120m_fp32_mode_every_row_vs_fp32_oracle_golden(gold, run32):
+    cfg = ESPNET_CONFORMER_120M
+    rows = int(gold["rows"])
+    got, f_dev, blank, ctc_argmax = run32
+    assert got.enc_lens[:rows] == gold["enc_lens"].tolist()
+    g = torch.Generator().manual_seed(int(gold["proj_seed"]))
+    R = (torch.randn((cfg.joint_hidden, 8), generator=g, dtype=torch.float32) / cfg.joint_hidden ** 0.5).to(f_dev.device)
+    proj = (f_dev @ R).cpu().numpy()
+    blank = blank.cpu().numpy()
+    worst_proj = worst_blank = worst_f = 0.0
+    agree = total = 0
+    for b in range(rows):
+        n = got.enc_lens[b]
+        worst_proj = max(worst_proj, float(np.abs(proj[b, :n] - gold["proj"][b, :n]).max()))
+        worst_blank = max(worst_blank, float(np.abs(blank[b, :n] - gold["ctc_blank"][b, :n]).max()))
+        agree += int((ctc_argmax[b, :n] == gold["ctc_argmax"][b, :n]).sum())
+        total += n
+    for b in range(2):
+        n = got.enc_lens[b]
+        worst_f = max(worst_f, float((f_dev[b, :n].cpu() - torch.from_numpy(gold["f_rows"][b, :n])).abs().max()))
+    assert worst_proj <= TOL_F32 and worst_f <= TOL_F32 and worst_blank <= TOL_F32, (worst_proj, worst_f, worst_blank)
+    assert agree >= 0.9995 * total, (agree, total)        # CTC argmax per frame: a float32 near-tie may move one frame in thousands
+    g_ids = [ragged(gold, "ids", b) for b in range(rows)]
+    g_frames = [ragged(gold, "frames", b, "ids") for b in range(rows)]
+    near = set(int(b) for b in np.nonzero(gold["min_margin"] < float(gold["near_tie"]))[0])
+    differ = [b for b in range(rows) if got.ids[b] != g_ids[b] or got.frames[b] != g_frames[b]]
+    assert not [b for b in differ if b not in near], f"rows {differ} differ from the float32 oracle without a near-tie"
+    report("espnet_fp32_mode", {"rows": rows, "ids_and_frames_exact": f"{rows - len(differ)}/{rows}", "near_tie_rows_in_golden": len(near),
+                                "differing_rows": differ, "joint_proj_fingerprint_max_err": worst_proj, "joint_enc_rows01_max_err": worst_f,
+                                "ctc_blank_max_err": worst_blank, "ctc_argmax_agreement": agree / max(total, 1), "decisions": int(total)})
+
+
+def test_120m_beam20_whole_utterances(gold, run32):
+    """Speech2Text's default search (beam 20, score_norm) over 32 WHOLE utterances of the benchmark batch on the float32 mode's
+    joint projection: the device against the C checker on the same tensor bit for bit, and against the float64 restatement of
+    ESPnet's algorithm run on the ORACLE's projection (labels; the score within the float32 sum's rounding)."""
+    cfg = ESPNET_CONFORMER_120M
+    got, f_dev, _, _ = run32
+    k = int(gold["beam_rows"])
+    beam, max_pops = int(gold["beam"]), int(gold["max_pops"])
+    sd = synthetic_state_dict_espnet(cfg, 0, blank_bias=16.0, dec_gain=8.0)
+    model = EspnetModel(cfg, sd, synthetic_token_list(cfg.vocab_size, 0), device="cuda:0", beam_size=beam, max_pops=max_pops)
+    am, dev = model.am, f_dev.device
+    tp = f_dev.shape[1]
+    cap = 2 * tp + 16
+    je = f_dev[:k].contiguous()
+    el = torch.tensor(got.enc_lens[:k], dtype=torch.int32, device=dev)
+    ids = torch.zeros((k, cap), dtype=torch.int32, device=dev)
+    frames = torch.zeros((k, cap), dtype=torch.int32, device=dev)
+    n_ids = torch.zeros((k,), dtype=torch.int32, device=dev)
+    sc = torch.zeros((k,), dtype=torch.float32, device=dev)
+    pp = torch.zeros((k,), dtype=torch.int32, device=dev)
+    ws = torch.empty((am.ctx.beam_workspace_bytes(k, beam, tp, max_pops),), dtype=torch.uint8, device=dev)
+    am.ctx.rnnt_beam(je, el, k, tp, beam, True, max_pops, ids, n_ids, sc, pp, ws, torch.cuda.current_stream().cuda_stream, frames=frames)
+    torch.cuda.synchronize()
+    n = n_ids.cpu().numpy()
+    dev_out = [(ids[i, :n[i]].cpu().tolist(), frames[i, :n[i]].cpu().tolist(), float(sc[i]), int(pp[i])) for i in range(k)]
+    want = og.espnet_beam(cfg, sd, je.cpu().numpy(), np.asarray(got.enc_lens[:k], np.int32), beam=beam, max_pops=max_pops, out_cap=cap, with_frames=True)
+    assert dev_out == [(w[0], w[1], float(np.float32(w[2])), w[3]) for w in want], "device search != oracle/espnet_beam.c on the same projection"
+    same = 0
+    worst = 0.0
+    for i in range(k):
+        g_ids, g_frames = ragged(gold, "beam_f64_ids", i), ragged(gold, "beam_f64_frames", i, "beam_f64_ids")
+        if dev_out[i][0] == g_ids and dev_out[i][1] == g_frames:
+            same += 1
+            worst = max(worst, abs(dev_out[i][2] - float(gold["beam_f64_score"][i])) / max(1.0, abs(float(gold["beam_f64_score"][i]))))
+    # the float64 restatement ran on the oracle's projection, the device on its own (1e-5 apart): identical hypotheses are
+    # expected on every row; allow one near-tie row in 32 and say how many there were
+    assert same >= k - 1, f"{same}/{k} rows identical to the float64 restatement"
+    assert worst <= 1e-4, worst
+    report("espnet_beam20_whole_utterances", {"rows": k, "frames_per_row": tp, "beam": beam,
+                                              "device_vs_c_checker_bit_exact": True,
+                                              "identical_to_float64_restatement": f"{same}/{k}", "score_rel_err_max": worst,
+                                              "mean_labels": float(np.mean([len(o[0]) for o in dev_out])), "mean_pops": float(np.mean([o[3] for o in dev_out]))})
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_120m_throughput_mode_flip_audit_over_all_256_rows(gold, bench_waves, run32):
+    """the bf16 throughput mode on all 256 rows, audited against the float32 mode's projection of the same rows (pinned to the
+    float32 oracle row by row above): joint projection within the stated bf16 tolerance, every local flip inside the Lipschitz
+    bound, every row without a flip identical to the float32 oracle golden"""
+    from oracle import audit
+    cfg = ESPNET_CONFORMER_120M
+    rows = int(gold["rows"])
+    got32, f32_dev, _, _ = run32
+    sd = synthetic_state_dict_espnet(cfg, 0)
+    model = EspnetModel(cfg, sd, synthetic_token_list(cfg.vocab_size, 0), device="cuda:0")
+    am = model.am
+    buf = am.stage(bench_waves, buf=am.new_buffers(256, len(bench_waves[0])))
+    am.run_device(buf)
+    torch.cuda.synchronize()
+    got = am.collect(buf)
+    f16 = buf.joint_enc
+    assert got.enc_lens == got32.enc_lens
+    dj = max(float((f16[b, :got.enc_lens[b]] - f32_dev[b, :got.enc_lens[b]]).abs().max()) for b in range(rows))
+    assert dj <= TOL_BF16, dj
+    audits = audit.flip_audit_batch(cfg, sd, f32_dev[:rows], f16[:rows], got.enc_lens[:rows], got.ids[:rows], got.frames[:rows], device=f32_dev.device)
+    g_ids = [ragged(gold, "ids", b) for b in range(rows)]
+    g_frames = [ragged(gold, "frames", b, "ids") for b in range(rows)]
+    equal = [got.ids[b] == g_ids[b] and got.frames[b] == g_frames[b] for b in range(rows)]
+    for a in audits:
+        for fl in a["flips"]:
+            assert fl["margin_ref"] <= fl["bound"] * (1 + 1e-9) + 1e-12, fl
+            assert fl["delta_f"] <= TOL_BF16 * cfg.joint_hidden ** 0.5
+    summary = audit.summarize(audits, equal)
+    assert summary["every_id_difference_starts_at_a_flip"] and summary["walk_reproduces_hip_path"], summary
+    n_tok = sum(len(x) for x in g_ids)
+    agree = sum(sum(1 for x, y in zip(got.ids[b], g_ids[b]) if x == y) for b in range(rows)) / max(n_tok, 1)
+    summary.update({"rows": rows, "rows_identical_to_fp32_oracle": int(sum(equal)), "joint_enc_max_err_vs_fp32_mode": dj,
+                    "token_agreement_positional": agree})
+    report("espnet_bf16_audit_all_rows", summary)
+    del model, buf
+    torch.cuda.empty_cache()
