@@ -381,6 +381,11 @@ def extra_configs(model, cfg, sd, args, host_sets):
         out["espnet_120m_beam20"] = espnet_beam_config(model.device, args)
     except Exception as e:
         out["espnet_120m_beam20"] = {"error": repr(e)}
+    # BASELINE configs[3]: reazonspeech.k2.asr, the Zipformer transducer behind sherpa-onnx in the reference
+    try:
+        out["k2_zipformer_159m"] = k2_config(model.device, args)
+    except Exception as e:
+        out["k2_zipformer_159m"] = {"error": repr(e)}
     return out
 
 
@@ -444,6 +449,68 @@ def espnet_parity(am, cfg, sd, buf256, first):
     del m32, b32
     torch.cuda.empty_cache()
     return out
+
+
+def k2_config(device, args, steps=10):
+    """`reazonspeech.k2.asr` (pkg/k2-asr/src/huggingface.py:73-83, transcribe.py:24-39): 256 x 10 s utterances with the reference's
+    0.9 s of padding on both sides through kaldi-style fbank + encoder_embed + the six Zipformer2 stacks + the stateless-decoder
+    greedy search, HBM-resident and pipelined like the headline loop.  Parity: four utterances against the CPU oracle of that model
+    (oracle/zipformer.py with the bf16 recipe — unpinned against icefall / sherpa-onnx), decode bit-exact vs oracle/k2_greedy.c on the
+    device's projection, and batch invariance (an utterance alone == inside the batch of 256, bits)."""
+    from reazonspeech_amd.runtime.k2_config import ZIPFORMER_159M
+    from reazonspeech_amd.runtime.k2_weights import synthetic_state_dict_k2
+    from reazonspeech_amd.k2.asr.model import K2Model, synthetic_tokens
+    cfg = ZIPFORMER_159M
+    sd = synthetic_state_dict_k2(cfg, 0)
+    km = K2Model(cfg, sd, synthetic_tokens(cfg.vocab_size, 0), device=str(device))
+    am = km.am
+    pad = int(0.9 * 16000)
+    n_sets = max(1 + args.dec_streams, 3)
+    bufs, secs = [], []
+    for k in range(n_sets):
+        audio, lens = synthetic_batch(args.batch, args.seconds, seed=4242 + 1000 * k)
+        waves = [np.pad(audio[i, :lens[i]], pad) for i in range(args.batch)]
+        bufs.append(am.stage(waves, buf=am.new_buffers(args.batch, len(waves[0]))))
+        secs.append(float(lens.sum()) / 16000.0)
+        if k == 0:
+            first = waves
+    torch.cuda.synchronize()
+    dt = timed_pipeline(am, bufs, steps, 3, args.dec_streams)
+    n_tok = bufs[0].n_ids.cpu().numpy()
+    res = {"workload": f"{args.batch} x {args.seconds:g} s per step (+ 0.9 s of padding on both sides), icefall Zipformer2 transducer "
+                       f"{cfg.n_params() / 1e6:.0f}M (6 stacks, 19 layers), stateless-decoder greedy search (one symbol per frame), HBM-resident, pipelined",
+           "value": round(sum(secs[i % n_sets] for i in range(steps)) / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+           "enc_frames": bufs[0].tp_max, "mean_tokens_per_utt": round(float(n_tok.mean()), 1)}
+    try:
+        from oracle import zipformer as oz, greedy as og
+        k = 4
+        am.run_device(bufs[0])
+        torch.cuda.synchronize()
+        got = am.collect(bufs[0])
+        f_dev = bufs[0].joint_enc
+        worst = mean = 0.0
+        for b in range(k):
+            ref = oz.forward(cfg, sd, first[b], "bf16")
+            n = ref["joint_enc"].shape[0]
+            e = (f_dev[b, :n].cpu() - ref["joint_enc"]).abs()
+            worst, mean = max(worst, float(e.max())), max(mean, float(e.mean()))
+        same = og.k2_greedy(cfg, sd, f_dev[:8].cpu().numpy(), np.asarray(got.enc_lens[:8], np.int32))
+        small = am.stage(first[:1], buf=am.new_buffers(1, len(first[0])))
+        am.run_device(small)
+        torch.cuda.synchronize()
+        alone = am.collect(small)
+        n0 = alone.enc_lens[0]
+        res["parity"] = {"utterances_vs_cpu_oracle": k, "checker": "oracle/zipformer.py (bf16-recipe CPU restatement of icefall's Zipformer2; unpinned "
+                         "against icefall / sherpa-onnx)", "joint_enc_max_err": round(worst, 4), "joint_enc_mean_err": round(mean, 5),
+                         "decode_bit_exact_given_same_joint_enc_rows_0_7": got.ids[:8] == [r[0] for r in same] and got.frames[:8] == [r[1] for r in same],
+                         "alone_equals_inside_batch_bits": bool(torch.equal(small.joint_enc[0, :n0], f_dev[0, :n0])) and alone.ids[0] == got.ids[0]
+                         and alone.frames[0] == got.frames[0]}
+        del small
+    except Exception as e:
+        res["parity"] = {"error": repr(e)}
+    del bufs, km
+    torch.cuda.empty_cache()
+    return res
 
 
 def espnet_config(device, args):

@@ -128,28 +128,54 @@ __global__ __launch_bounds__(256) void k2_im2col_kernel(const uint16_t* __restri
 
 // ConvNeXt depthwise 7 x 7 (padding 3) over (time, frequency), channels last.  a2 f32 [B][T3][F3][C] -> bf16 same shape.
 // Frames at or past the utterance's own length are zeros (the reference's single-utterance call ends there).
-// grid (T3, B), block 256
+// A workgroup makes CNX_TT consecutive frames of one utterance; a thread owns (f, c) pairs and walks time: every input row is
+// loaded ONCE per thread (7 frequency neighbours, served by L1 / L2 — the block's threads touch the same rows) and scattered into
+// the seven outputs it contributes to, which live in a ring of seven accumulators (slot = output frame mod 7, resolved at
+// compile time by unrolling rows in groups of seven); the 49 taps of the channel sit in registers.  The first version fetched
+// all 49 inputs per output: 11 ms per batch of 256 (profiles/r05b_k2_kernel_stats.txt); this one reads 7.
+constexpr int CNX_TT = 29;          // frames per workgroup: CNX_TT + 6 input rows = 5 groups of 7
+// grid (ceil(T3 / CNX_TT), B), block 256
 __global__ __launch_bounds__(256) void k2_cnx_dw_kernel(const float* __restrict__ a2, const int32_t* __restrict__ lens3, int T3, int F3, int C,
                                                         const float* __restrict__ w /* [49][C] */, const float* __restrict__ bias,
                                                         uint16_t* __restrict__ out) {
-    const int t = blockIdx.x, b = blockIdx.y;
+    const int t0 = blockIdx.x * CNX_TT, b = blockIdx.y;
     int len = lens3[b];
     len = len < T3 ? len : T3;
-    uint16_t* orow = out + ((size_t)b * T3 + t) * F3 * C;
-    for (int i = threadIdx.x; i < F3 * C; i += 256) {
-        const int f = i / C, c = i - f * C;
-        float acc = bias[c];
-        for (int kh = 0; kh < 7; ++kh) {
-            const int tt = t + kh - 3;
-            if (tt < 0 || tt >= len) continue;
-            const float* xr = a2 + ((size_t)b * T3 + tt) * F3 * C + c;
+    const float* xin = a2 + (size_t)b * T3 * F3 * C;
+    uint16_t* xo = out + (size_t)b * T3 * F3 * C;
+    for (int item = threadIdx.x; item < F3 * C; item += 256) {
+        const int f = item / C, c = item - f * C;
+        float wt[49];
 #pragma unroll
-            for (int kw = 0; kw < 7; ++kw) {
-                const int ff = f + kw - 3;
-                if (ff >= 0 && ff < F3) acc = fmaf(w[(kh * 7 + kw) * C + c], xr[(size_t)ff * C], acc);
+        for (int k = 0; k < 49; ++k) wt[k] = w[k * C + c];
+        const float bb = bias[c];
+        float acc[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[k] = 0.0f;
+        // rows r = t0 - 3 + 7 g + j; output frame o lives in ring slot (o - (t0 - 3)) mod 7
+        for (int g = 0; g < (CNX_TT + 6) / 7; ++g) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int r = t0 - 3 + 7 * g + j;
+                float x[7];
+                const bool row_ok = r >= 0 && r < len;
+#pragma unroll
+                for (int kw = 0; kw < 7; ++kw) {
+                    const int ff = f + kw - 3;
+                    x[kw] = (row_ok && ff >= 0 && ff < F3) ? xin[((size_t)r * F3 + ff) * C + c] : 0.0f;
+                }
+                // row r is tap kh of output frame r + 3 - kh, whose slot is (j + 3 - kh) mod 7
+#pragma unroll
+                for (int kh = 0; kh < 7; ++kh) {
+                    const int slot = (j + 3 - kh + 7) % 7;
+#pragma unroll
+                    for (int kw = 0; kw < 7; ++kw) acc[slot] = fmaf(wt[kh * 7 + kw], x[kw], acc[slot]);
+                }
+                const int done = r - 3, dslot = (j + 4) % 7;          // frame r - 3 has now received rows r - 6 .. r (this row was its tap kh = 6)
+                if (done >= t0 && done < t0 + CNX_TT && done < T3) xo[((size_t)done * F3 + f) * C + c] = f32_to_bf16(acc[dslot] + bb);
+                acc[dslot] = 0.0f;
             }
         }
-        orow[i] = f32_to_bf16(acc);
     }
 }
 
@@ -726,7 +752,7 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
     RS_CHECK_LAUNCH(ctx, "zipformer encoder_embed convs");
     RS_TRY(gemm(col, pl.Kp, k.conv2_w, pl.Kp, a2, c3, rows3, c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHR | RS_GEMM_OUT_F32, k.conv2_b, nullptr));
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, 0.0);
-    hipLaunchKernelGGL(k2_cnx_dw_kernel, dim3(T3, B), dim3(256), 0, s, a2, lens3, T3, F3, c3, k.cnx_dw_w, k.cnx_dw_b, dwo);
+    hipLaunchKernelGGL(k2_cnx_dw_kernel, dim3((T3 + CNX_TT - 1) / CNX_TT, B), dim3(256), 0, s, a2, lens3, T3, F3, c3, k.cnx_dw_w, k.cnx_dw_b, dwo);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
     RS_TRY(gemm(dwo, c3, k.cnx_pw1_w, c3, hbuf, 3 * c3, rows3, 3 * c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHL, k.cnx_pw1_b, nullptr));
     RS_TRY(gemm(hbuf, 3 * c3, k.cnx_pw2_w, 3 * c3, a2, c3, rows3, c3, RES, k.cnx_pw2_b, a2));
