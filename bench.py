@@ -343,13 +343,15 @@ def extra_configs(model, cfg, sd, args, host_sets):
         del audio, waves
     except Exception as e:
         out["ragged_u2_10"] = {"error": repr(e)}
-    # the reference checkpoint's decode strategy (decode.py:29,38-41): ALSD, beam 4.  (With random-init weights the beam
-    # search spends the whole 2 x T' label budget — ~310 labels per utterance against the greedy path's 46: an untrained
-    # prediction network has states in which a label stays the most probable symbol for ever, greedy leaves them through
-    # its max-symbols-per-frame cap, ALSD has none.  Scaling the joint output layer by 8 — peaked posteriors, greedy ids
-    # unchanged — does not change that: 286 labels, profiles/r03o_bench.json.  This line is a worst case, not a trained model.)
+    # the reference checkpoint's decode strategy (decode.py:29,38-41): ALSD, beam 4, on the synthetic recipe on which the search
+    # behaves like on a trained model (profiles/r04zz_alsd_recipe_sweep.txt): a prediction network that weighs in the joint
+    # (dec_gain 8) and peaked posteriors (out_gain 8, blank offset 53) -> tens of labels per utterance instead of the whole
+    # 2 x T' label budget the flat random joint spent (311 labels per utterance in rounds 2-4).  The search still runs all
+    # T' + budget alignment steps (a beam is never all-final in one step), so the time is per-step cost x 415.
+    sd_alsd = synthetic_state_dict(cfg, 0, blank_bias=53.0, dec_gain=8.0, out_gain=8.0)
     for key, cfg2, what, sd2 in (
-            ("alsd4", cfg.with_(decoding="alsd", beam_size=4), "ALSD beam-4 decode (max_target_len 2.0)", sd),
+            ("alsd4", cfg.with_(decoding="alsd", beam_size=4), "ALSD beam-4 decode (max_target_len 2.0; synthetic recipe dec_gain 8 / out_gain 8 / "
+             "blank offset 53: a trained model's label density)", sd_alsd),
             ("window_128_128_g1", cfg.with_(att_left=128, att_right=128, n_global=1),
              "limited-context attention [128, 128] + 1 global token (SURVEY row L5), greedy decode", sd)):
         try:
@@ -365,6 +367,21 @@ def extra_configs(model, cfg, sd, args, host_sets):
             if key.startswith("alsd"):
                 n_lab = bufs2[0].n_ids.cpu().numpy()[:args.batch]
                 out[key]["mean_tokens_per_utt"] = round(float(n_lab.mean()), 1)
+                out[key]["max_tokens_per_utt"] = int(n_lab.max())
+                try:                     # labels, alignment steps and float32 scores of the first rows against the C checker, bit for bit
+                    from oracle import greedy as og
+                    k = 2
+                    m2.run_device(bufs2[0])
+                    torch.cuda.synchronize()
+                    got = m2.collect(bufs2[0])
+                    st = bufs2[0].frames.cpu().numpy()
+                    nn = bufs2[0].n_ids.cpu().numpy()
+                    want = og.rnnt_alsd(cfg2, sd2, bufs2[0].joint_enc[:k].cpu().numpy(), np.asarray(got.enc_lens[:k], np.int32), beam=4, max_target_len=2.0)
+                    ok = all(got.ids[b] == want[b][0] and st[b, :nn[b]].tolist() == want[b][1] and np.float32(got.scores[b]) == np.float32(want[b][2]) for b in range(k))
+                    out[key]["parity"] = {"rows": k, "checker": "oracle/rnnt_alsd.c on the device's joint projection (follows oracle/alsd.py; unpinned against NeMo)",
+                                          "labels_steps_scores_bit_exact": bool(ok)}
+                except Exception as e:
+                    out[key]["parity"] = {"error": repr(e)}
             if key.startswith("window"):
                 out[key]["parity"] = window_parity(m2, cfg2, sd, host_sets[0])
             del bufs2, m2
@@ -836,6 +853,7 @@ def main():
             "ms_per_step_median": round(median_ms, 3) if median_ms else None,
             "step_intervals_ms": [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])],
             "higher_is_better": True,
+            "value_device_resident": round(value, 1),      # = `value` under its explicit name (the bench contract's definition)
             "value_definition": "bench contract: whole-job RTFx with the step's inputs already resident in HBM.  SURVEY 8(d)'s "
                                 "definition (host float32 -> TranscribeResult through the public transcribe_batch, H2D / D2H, "
                                 "pipeline fill and drain inside the clock) is `value_transcribe_batch`; `value_host_to_ids` stops "
@@ -884,6 +902,10 @@ def main():
                                "share_of_step": round(gemm["ms"] / max(prof_state["steps"], 1) / (dt / args.steps * 1e3), 3),
                                # committed PMC passes (sequential schedule): MFMA-pipe busy cycles at the clock the chip ran at
                                "mfma_busy_pct_pmc": mfma_busy, "clock_ghz_pmc": pmc_clock,
+                               "pmc_source": "profiles/gemm_traffic.json — separate rocprofv3 --pmc passes of THIS tree's evidence run "
+                                             "(scripts/evidence.sh), not collected by this process: `traffic`, `mfma_busy_pct_pmc` and "
+                                             "`clock_ghz_pmc` are as old as that file says (`collected`)",
+                               "pmc_collected": pmc.get("collected") if traffic else None,
                                "traffic_ratio": round(traffic / (gemm["bytes"] / gemm["launches"]), 3) if traffic else None,
                                # the same HIP-event records grouped by GEMM shape: the weakest shape is visible in the line
                                "per_shape": per_shape_roofline(gemm_launches)}

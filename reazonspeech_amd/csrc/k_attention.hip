@@ -42,8 +42,10 @@ struct AttnGeom {
     static constexpr int SCR_BYTES = 32 * KROW > 32 * SKEW_LD * 4 ? 32 * KROW : 32 * SKEW_LD * 4;
     static constexpr int RPP = 64 / NCH;           // rows one 64-lane pass of 16-byte pieces covers
     static constexpr int VH = NCH / 8;             // wave-wide V staging items per key block
+    // key blocks staged per workgroup barrier: HD 128: 5 (160 keys: all of T' = 138); HD 64 (half the bytes per key): 6, so that
+    // the ESPnet model's T' = 358 (12 key blocks) is two chunks, both staged by the register-transposing fast path
+    static constexpr int KB_CHUNK = HD == 128 ? 5 : 6;
 };
-constexpr int KB_CHUNK = 5;            // key blocks staged per workgroup barrier (160 keys: all of T' = 138)
 constexpr float NEG = -1.0e30f;
 
 struct AttnParams {
@@ -75,7 +77,7 @@ template <int HD, bool TRACE, bool WINDOW>
 __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     using G = AttnGeom<HD>;
     constexpr int NCH = G::NCH, KS = G::KS, DB = G::DB, KROW = G::KROW, K_BYTES = G::K_BYTES, VT_BYTES = G::VT_BYTES;
-    constexpr int SCR_BYTES = G::SCR_BYTES, RPP = G::RPP, VH = G::VH;
+    constexpr int SCR_BYTES = G::SCR_BYTES, RPP = G::RPP, VH = G::VH, KB_CHUNK = G::KB_CHUNK;
     long long ts[40];
     int nts = 0;
     // TRACE: drain the memory counters, make the newest MFMA result architecturally visible, then stamp
@@ -301,7 +303,14 @@ __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     for (int jc = 0; jc < n_kblocks; jc += KB_CHUNK) {
         const int nb = n_kblocks - jc < KB_CHUNK ? n_kblocks - jc : KB_CHUNK;
         if (!chunk_needed(jc, nb)) continue;      // workgroup-uniform
-        if (jc > 0) {
+        if (jc > 0 && HD == 64) {
+            // HD 64 has the registers (166 + the staging's 64 of 256) to run the prologue's staging path again: every load of
+            // the chunk in flight at once, V transposed in registers (the one-item-at-a-time path below cost the ESPnet shape,
+            // T' = 358 = three chunks of five, most of its 490 us per launch: profiles/r04zz_beam_kernel_stats.txt)
+            __syncthreads();
+            stage_kv(jc, nb);
+            __syncthreads();
+        } else if (jc > 0) {
             __syncthreads();                  // previous chunk fully consumed
             // later chunks (T' > 160 only) restage with everything live: one item at a time, 8 staging VGPRs
 #pragma unroll 1
@@ -478,6 +487,7 @@ int launch_attention_hd(rs_ctx* ctx, AttnParams& p, int B, int T, hipStream_t s)
     // at most 6 query blocks per workgroup (HD 128: 5 * (8704 + 10240) + 6 * 8704 = 147 KB of the 160 KB LDS)
     const int nw = qblocks < 6 ? qblocks : 6;
     const dim3 grid((qblocks + nw - 1) / nw, dm.n_heads, B), block(64 * nw);
+    constexpr int KB_CHUNK = G::KB_CHUNK;
     const size_t lds = (size_t)KB_CHUNK * (G::K_BYTES + G::VT_BYTES) + (size_t)nw * G::SCR_BYTES + 2 * HD * sizeof(float);
     {
         constexpr int MAX_LDS = KB_CHUNK * (G::K_BYTES + G::VT_BYTES) + 6 * G::SCR_BYTES + 2 * HD * (int)sizeof(float);

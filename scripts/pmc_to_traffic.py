@@ -3,6 +3,7 @@ of the bench line: mean HBM-side bytes per GEMM launch (all encoder linears), PM
 
     python scripts/pmc_to_traffic.py profiles/r02n_pmc_per_kernel.txt
 """
+import datetime
 import json
 import re
 import sys
@@ -37,6 +38,7 @@ out = {
               "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, guides/MI355X_MICROARCH.md §HBM); launch-weighted "
               "mean.  These are L2-miss bytes at the TCC/EA boundary: re-reads served by the 256 MiB infinity cache count too.",
     "source": src,
+    "collected": datetime.date.today().isoformat() + " (" + src + ")",
 }
 json.dump(out, open("profiles/gemm_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
