@@ -58,7 +58,10 @@ struct GemmParams {
     long long* trace;  // debug: per-tile timestamps (scripts/gemm_trace.py); nullptr in production
 };
 
-enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_RES = 2, OUT_GLU = 3, OUT_RESLN = 4 };
+// OUT_BF16S / OUT_F32S: the plain bf16 / f32 epilogues with icefall's Swoosh activations compiled in (the Zipformer family).
+// They are instantiations of their own: with the branches in the shared epilogue the FastConformer's ffn_up launches (256-row
+// tiles, SiLU) ran 7 % slower (317.6 vs 295.5 us, profiles/r05c_bench.json against BENCH_r04.json).
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_RES = 2, OUT_GLU = 3, OUT_RESLN = 4, OUT_BF16S = 5, OUT_F32S = 6 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -105,9 +108,11 @@ __host__ __device__ inline void xcd_split(int xcount, int pair_mode, int& n_pair
 // number of VMEM operations a wave issues here is a compile-time constant.
 // Lane layout of the accumulators: the weight fragment is the MFMA A operand, so D = (A.W^T)^T and block (i, j) holds
 // m = .. + i*16 + (lane & 15), n = .. + j*16 + 4*(lane >> 4) + 0..3.
-template <int MI, int NI, int OUT, bool MASK, int PF>
+template <int MI, int NI, int OUT_KIND, bool MASK, int PF>
 __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][NI], char* scr, int cm0, int cn0,
                                                int wm, int wn, int lane) {
+    constexpr bool SWOOSH = OUT_KIND == OUT_BF16S || OUT_KIND == OUT_F32S;
+    constexpr int OUT = OUT_KIND == OUT_BF16S ? OUT_BF16 : (OUT_KIND == OUT_F32S ? OUT_F32 : OUT_KIND);
     // OUT_RESLN: the residual operand is y, the previous layer's output BEFORE its output LayerNorm; that norm is applied
     // here from per-row statistics (layernorm2_kernel writes them instead of the normalised f32 rows: one 145-MB write
     // per layer boundary less), with the arithmetic of the norm kernel: fma((y - mean) * rstd, g, b).
@@ -117,8 +122,6 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
     const int frow = lane & 15, fch = lane >> 4;
     const int flags = p.flags;
     const bool has_bias = flags & RS_GEMM_BIAS, relu = flags & RS_GEMM_RELU, silu = flags & RS_GEMM_SILU;
-    // the Swoosh activations exist in the plain bf16 / f32 epilogues only: the residual and GLU instantiations stay as they were
-    constexpr bool SWOOSH = OUT == OUT_BF16 || OUT == OUT_F32;
     const bool swl = SWOOSH && (flags & RS_GEMM_SWOOSHL), swr = SWOOSH && (flags & RS_GEMM_SWOOSHR);
     const float alpha = p.alpha;
     // GLU: the output has N / 2 columns (ldc is the caller's row pitch of that narrower matrix).  The launcher keeps
@@ -600,7 +603,9 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     // K = 4096 and 6 below; one-tile-wide problems (the subsampling GEMMs) 16; everything else is flat from 6 up
     p.group_m = g_group_m.load() > 0 ? g_group_m.load()
               : (p.tiles_n == 4 ? (p.K >= 4096 ? 2 : 6) : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8)));
-    const int out = (p.flags & RS_GEMM_RESIDUAL) ? (p.res_ln_stats ? OUT_RESLN : OUT_RES) : ((p.flags & RS_GEMM_OUT_F32) ? OUT_F32 : ((p.flags & RS_GEMM_GLU) ? OUT_GLU : OUT_BF16));
+    const bool swoosh = p.flags & (RS_GEMM_SWOOSHL | RS_GEMM_SWOOSHR);
+    const int out = (p.flags & RS_GEMM_RESIDUAL) ? (p.res_ln_stats ? OUT_RESLN : OUT_RES)
+                  : ((p.flags & RS_GEMM_OUT_F32) ? (swoosh ? OUT_F32S : OUT_F32) : ((p.flags & RS_GEMM_GLU) ? OUT_GLU : (swoosh ? OUT_BF16S : OUT_BF16)));
     const bool mask = p.flags & RS_GEMM_ROWMASK;
 #define RS_SMF(O, MK, TR)                                                                                          \
     do {                                                                                                           \
@@ -623,7 +628,9 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     else if (out == OUT_BF16 && !mask) RS_SMF(OUT_BF16, false, false);
     else if (out == OUT_BF16 && mask) RS_SMF(OUT_BF16, true, false);
     else if (out == OUT_GLU && !mask) RS_SMF(OUT_GLU, false, false);
-    else return rs_fail(ctx, RS_EINVAL, "gemm: the row mask combines with bf16 output only");
+    else if (out == OUT_BF16S && !mask) RS_SMF(OUT_BF16S, false, false);
+    else if (out == OUT_F32S && !mask) RS_SMF(OUT_F32S, false, false);
+    else return rs_fail(ctx, RS_EINVAL, "gemm: the row mask combines with plain bf16 output only");
 #undef RS_SMF
     return RS_OK;
 }
