@@ -714,7 +714,8 @@ def main():
         left, right, n_glob = (int(x) for x in args.att_context.split(","))
         cfg = cfg.with_(att_left=left, att_right=right, n_global=n_glob)
     t0 = time.time()
-    sd = synthetic_state_dict(cfg, seed=0)
+    # (--decoding alsd: the synthetic recipe with a trained model's label density, see extra_configs)
+    sd = synthetic_state_dict(cfg, 0, blank_bias=53.0, dec_gain=8.0, out_gain=8.0) if alsd else synthetic_state_dict(cfg, seed=0)
     model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device=f"cuda:{local_rank}")
     # resident batches (different utterances): the pipelined path rotates through them
     n_sets = max(1 + args.dec_streams, args.buffer_sets)

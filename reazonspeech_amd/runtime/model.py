@@ -257,6 +257,13 @@ class AsrModel:
         $RS_DECODE_SCREEN / $RS_DECODE_NARROW override (A/B runs)."""
         if "RS_DECODE_SCREEN" in os.environ or "RS_DECODE_NARROW" in os.environ:
             return
+        if self is not None and self.cfg.decoding == "alsd" and B * self.cfg.beam_size >= 256:
+            # ALSD runs the LSTM over the hundreds of hypothesis rows that took a label (about half of B x beam per alignment
+            # step): that is throughput work, and the wide tiles re-read the weights a quarter as often as the narrow ones —
+            # 133 vs 160 ms per step at B = 256, beam 4 (profiles/r05f_alsd_narrow_ab.txt); results are bit-identical
+            ctx.set_option("decode_narrow", 0)
+            ctx.set_option("decode_screen", 0)
+            return
         if self is not None and (self.cfg.espnet or getattr(self.cfg, "family", "") == "k2"):   # tanh joint: the exact kernels (the screened joint's bound is derived for ReLU)
             ctx.set_option("decode_screen", 0)
             ctx.set_option("decode_narrow", 0 if (pipelined and lanes == 1 and B >= 128) else 1)
