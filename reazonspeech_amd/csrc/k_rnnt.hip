@@ -158,7 +158,7 @@ __global__ __launch_bounds__(1024) void rnnt_lstm_kernel(DecodeState st, int lay
 // itself and folding them left to right in registers — bit-identical, no LDS reduction, weights fetched once per 128 rows.  It
 // LOST to this kernel: ALSD 141.7 vs 135.4 ms per step, ESPnet beam-20 379 vs 311 ms per batch (profiles/r05g_lstm_tp_ab.txt):
 // with one wave per SIMD the L2 round trip of every operand fragment is exposed, which the 16 short chains per tile here hide.
-// Removed again; the change is in the history at the commit before this note.)
+// Removed again; its skeleton is kept in profiles/r05g_lstm_tp_kernel.hip.txt.)
 // ---- [32 rows] x [64 cols] tile of  out = W . a + bias  with the 8 K slices on the 8 waves --------------
 // MODE 0: prediction projection g = W_p . h_top + b_p over the `act` rows (+ LSTM state commit)
 // MODE 1: joint logits  W_o . relu(f[b][t_b] + g[b]) + b_o over the `alive` rows, per-tile argmax
