@@ -121,6 +121,7 @@ def rnnt_alsd(cfg, sd, f, enc_lens, beam=4, max_target_len=2.0, score_norm=True,
     PF = ctypes.POINTER(ctypes.c_float)
     wl = (PF * cfg.pred_layers)(*[_fp(w) for w in arr["lstm_w"]])
     bl = (PF * cfg.pred_layers)(*[_fp(b) for b in arr["lstm_b"]])
+    L.rs_oracle_set_joint_act(1 if getattr(cfg, "espnet", False) else 0)
     rc = L.rs_oracle_rnnt_alsd(_fp(f), _ip(enc_lens), B, Tp, J, cfg.pred_hidden, cfg.pred_layers, cfg.n_logits,
                                cfg.blank_id, _fp(arr["embed"]), wl, bl, _fp(arr["Wp"]), _fp(arr["bp"]),
                                _fp(arr["Wo"]), _fp(arr["bo"]), int(beam), _ip(u_max), int(bool(score_norm)),

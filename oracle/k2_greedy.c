@@ -22,6 +22,7 @@
 float rs_oracle_dot(const float* a, const float* w, int K);
 int rs_oracle_joint_argmax(const float* f, const float* g, const float* Wo, const float* bo, int J, int V, float* logits_out);
 void rs_oracle_set_joint_act(int act);
+int rs_oracle_get_joint_act(void);
 
 /* h[D] = relu(conv(embed[t0], embed[t1])) ; conv_w [D][4][2] */
 void rs_oracle_k2_decoder(const float* embed, const float* conv_w, int D, int t0, int t1, float* h) {
@@ -40,6 +41,7 @@ int rs_oracle_k2_greedy(const float* f, const int32_t* enc_lens, int B, int Tp, 
     int overflow = 0;
     float* h = (float*)malloc(sizeof(float) * D);
     float* g = (float*)malloc(sizeof(float) * J);
+    const int act_before = rs_oracle_get_joint_act();    /* the joint activation is a setting of the shared checker library */
     rs_oracle_set_joint_act(1);
     for (int b = 0; b < B; ++b) {
         int t0 = -1, t1 = blank, n = 0;
@@ -61,5 +63,6 @@ int rs_oracle_k2_greedy(const float* f, const int32_t* enc_lens, int B, int Tp, 
         n_ids[b] = n;
     }
     free(h); free(g);
+    rs_oracle_set_joint_act(act_before);
     return overflow ? -5 : 0;
 }

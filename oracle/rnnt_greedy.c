@@ -71,6 +71,7 @@ void rs_oracle_lstm_step(const float* x, const float* h, const float* c, const f
  * tile kernel evaluates operation for operation (k_rnnt.hip: DecodeState.joint_act). */
 static int g_joint_act = 0;
 void rs_oracle_set_joint_act(int act) { g_joint_act = act; }
+int rs_oracle_get_joint_act(void) { return g_joint_act; }
 
 /* logits[V] = Wo . act(f + g) + bo ; returns argmax (lowest index on ties) */
 int rs_oracle_joint_argmax(const float* f, const float* g, const float* Wo, const float* bo, int J, int V,

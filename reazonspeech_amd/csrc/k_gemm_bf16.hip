@@ -54,6 +54,8 @@ struct GemmParams {
     const float* res_ln_stats;   // OUT_RESLN: per row (mean, rstd) of the LayerNorm the residual operand still has to go through
     const float* res_ln_g;       //            its weight / bias [N]
     const float* res_ln_b;
+    uint16_t* out2;    // OUT_RES2: bf16 copy of the result, row pitch ld2 elements
+    int ld2;
     int pairs;         // > 0: a workgroup runs two consecutive tiles of its XCD's run (xcd_split); 2: the LDS ring carries over; 0: one tile
     long long* trace;  // debug: per-tile timestamps (scripts/gemm_trace.py); nullptr in production
 };
@@ -61,7 +63,8 @@ struct GemmParams {
 // OUT_BF16S / OUT_F32S: the plain bf16 / f32 epilogues with icefall's Swoosh activations compiled in (the Zipformer family).
 // They are instantiations of their own: with the branches in the shared epilogue the FastConformer's ffn_up launches (256-row
 // tiles, SiLU) ran 7 % slower (317.6 vs 295.5 us, profiles/r05c_bench.json against BENCH_r04.json).
-enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_RES = 2, OUT_GLU = 3, OUT_RESLN = 4, OUT_BF16S = 5, OUT_F32S = 6 };
+// OUT_RES2: OUT_RES that also stores the result as bf16 (GemmParams.out2): the Zipformer layers' residual branches.
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_RES = 2, OUT_GLU = 3, OUT_RESLN = 4, OUT_BF16S = 5, OUT_F32S = 6, OUT_RES2 = 7 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -111,8 +114,8 @@ __host__ __device__ inline void xcd_split(int xcount, int pair_mode, int& n_pair
 template <int MI, int NI, int OUT_KIND, bool MASK, int PF>
 __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][NI], char* scr, int cm0, int cn0,
                                                int wm, int wn, int lane) {
-    constexpr bool SWOOSH = OUT_KIND == OUT_BF16S || OUT_KIND == OUT_F32S;
-    constexpr int OUT = OUT_KIND == OUT_BF16S ? OUT_BF16 : (OUT_KIND == OUT_F32S ? OUT_F32 : OUT_KIND);
+    constexpr bool SWOOSH = OUT_KIND == OUT_BF16S || OUT_KIND == OUT_F32S, RES2 = OUT_KIND == OUT_RES2;
+    constexpr int OUT = OUT_KIND == OUT_BF16S ? OUT_BF16 : (OUT_KIND == OUT_F32S ? OUT_F32 : (RES2 ? OUT_RES : OUT_KIND));
     // OUT_RESLN: the residual operand is y, the previous layer's output BEFORE its output LayerNorm; that norm is applied
     // here from per-row statistics (layernorm2_kernel writes them instead of the normalised f32 rows: one 145-MB write
     // per layer boundary less), with the arithmetic of the norm kernel: fma((y - mean) * rstd, g, b).
@@ -278,6 +281,9 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
                 if (!row_keep(m)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 const unsigned off = (m < p.M && n < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), out_rsrc, off, 0, 0);
+                if constexpr (RES2) {
+                    if (m < p.M && n < p.N) *reinterpret_cast<u16x4_t*>(p.out2 + (size_t)m * p.ld2 + n) = pack_bf16x4(v.x, v.y, v.z, v.w);
+                }
             }
             if constexpr (RES) {
                 if (i + NPF < MI) load_res(i + NPF, rvq[i % NPF], stq[i % NPF]);   // refill the slot this chunk just consumed
@@ -604,7 +610,7 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     p.group_m = g_group_m.load() > 0 ? g_group_m.load()
               : (p.tiles_n == 4 ? (p.K >= 4096 ? 2 : 6) : (p.K >= 4096 ? 4 : (p.tiles_n <= 8 && p.K <= 2560 ? 16 : 8)));
     const bool swoosh = p.flags & (RS_GEMM_SWOOSHL | RS_GEMM_SWOOSHR);
-    const int out = (p.flags & RS_GEMM_RESIDUAL) ? (p.res_ln_stats ? OUT_RESLN : OUT_RES)
+    const int out = (p.flags & RS_GEMM_RESIDUAL) ? (p.res_ln_stats ? OUT_RESLN : (p.out2 ? OUT_RES2 : OUT_RES))
                   : ((p.flags & RS_GEMM_OUT_F32) ? (swoosh ? OUT_F32S : OUT_F32) : ((p.flags & RS_GEMM_GLU) ? OUT_GLU : (swoosh ? OUT_BF16S : OUT_BF16)));
     const bool mask = p.flags & RS_GEMM_ROWMASK;
 #define RS_SMF(O, MK, TR)                                                                                          \
@@ -628,6 +634,7 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     else if (out == OUT_BF16 && !mask) RS_SMF(OUT_BF16, false, false);
     else if (out == OUT_BF16 && mask) RS_SMF(OUT_BF16, true, false);
     else if (out == OUT_GLU && !mask) RS_SMF(OUT_GLU, false, false);
+    else if (out == OUT_RES2 && !mask) RS_SMF(OUT_RES2, false, false);
     else if (out == OUT_BF16S && !mask) RS_SMF(OUT_BF16S, false, false);
     else if (out == OUT_F32S && !mask) RS_SMF(OUT_F32S, false, false);
     else return rs_fail(ctx, RS_EINVAL, "gemm: the row mask combines with plain bf16 output only");
@@ -704,6 +711,8 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
             return rs_fail(ctx, RS_EINVAL, "gemm: GLU combines with a bias only");
         if ((a.N % 64) || a.alpha != 1.0f) return rs_fail(ctx, RS_EINVAL, "gemm: GLU needs N %% 64 == 0 and alpha == 1 (N=%d)", a.N);
     }
+    if (a.out_bf16 && (!(a.flags & RS_GEMM_RESIDUAL) || a.res_ln_stats || (a.ld_bf16 % 4) || ((uintptr_t)a.out_bf16 & 7)))
+        return rs_fail(ctx, RS_EINVAL, "gemm: the bf16 copy combines with a plain residual output only (8-byte aligned, pitch %% 4)");
     if ((a.flags & (RS_GEMM_SWOOSHL | RS_GEMM_SWOOSHR)) && (a.flags & RS_GEMM_RESIDUAL))
         return rs_fail(ctx, RS_EINVAL, "gemm: the Swoosh activations combine with plain bf16 / f32 output only");
     if ((size_t)a.N * a.ldw * 2 >= (1ull << 32)) return rs_fail(ctx, RS_EINVAL, "gemm: weight matrix beyond 4 GiB");
@@ -737,6 +746,7 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         p.res_ln_stats = a.res_ln_stats ? a.res_ln_stats + r0 * 2 : nullptr; p.res_ln_g = a.res_ln_g; p.res_ln_b = a.res_ln_b;
         p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc; p.M = (int)rows; p.N = a.N; p.K = a.K; p.flags = a.flags;
         p.alpha = a.alpha; p.mask_rows_per_step = a.mask_rows_per_step; p.mask_steps = a.mask_steps; p.mask_row0 = (int)r0;
+        p.out2 = a.out_bf16 ? a.out_bf16 + r0 * a.ld_bf16 : nullptr; p.ld2 = a.ld_bf16;
         p.tiles_m = p.tiles_n = 0; p.group_m = 1;
         p.trace = g_trace.load();
         rc = launch_rows(ctx, p, bm, s);

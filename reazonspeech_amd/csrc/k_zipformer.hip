@@ -725,11 +725,13 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
     const int c1 = d.embed_c1, c2 = d.embed_c2, c3 = d.embed_c3, T3 = pl.T3, F3 = pl.F3;
     int rc;
 #define RS_TRY(call) do { rc = (call); if (rc != RS_OK) return rc; } while (0)
+    // `copy`: the residual GEMM also stores its result rounded to bf16 (row pitch N) — the A operand of the branch that follows
     auto gemm = [&](const uint16_t* A, int lda, const uint16_t* Wt, int K, void* out, int ldc, long long M, int N, int flags, const float* bias,
-                    const float* res) -> int {
+                    const float* res, uint16_t* copy = nullptr) -> int {
         rs_gemm_args g{};
         g.A = A; g.lda = lda; g.W = Wt; g.ldw = K; g.out = out; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K;
         g.flags = flags; g.bias = bias; g.alpha = 1.0f; g.residual = res;
+        g.out_bf16 = copy; g.ld_bf16 = N;
         return rs_launch_gemm(ctx, g, s);
     };
     const int RES = RS_GEMM_BIAS | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32;
@@ -755,12 +757,11 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
     hipLaunchKernelGGL(k2_cnx_dw_kernel, dim3((T3 + CNX_TT - 1) / CNX_TT, B), dim3(256), 0, s, a2, lens3, T3, F3, c3, k.cnx_dw_w, k.cnx_dw_b, dwo);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
     RS_TRY(gemm(dwo, c3, k.cnx_pw1_w, c3, hbuf, 3 * c3, rows3, 3 * c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHL, k.cnx_pw1_b, nullptr));
-    RS_TRY(gemm(hbuf, 3 * c3, k.cnx_pw2_w, 3 * c3, a2, c3, rows3, c3, RES, k.cnx_pw2_b, a2));
-    cast(a2, dwo, (size_t)rows3 * c3);                    // [B*T3][F3 * c3] in (f, c) order: the operand of `out`
+    // (its bf16 copy lands in dwo, [B*T3][F3 * c3] in (f, c) order: the operand of `out`)
+    RS_TRY(gemm(hbuf, 3 * c3, k.cnx_pw2_w, 3 * c3, a2, c3, rows3, c3, RES, k.cnx_pw2_b, a2, dwo));
     const long long M3 = (long long)B * T3;
     const int d0 = d.encoder_dim[0];
-    float* cur = reinterpret_cast<float*>(ws + pl.off_stackout[0]);       // embed output lands where stack 0's output will go ..
-    float* emb = x0;                                                         // .. after going through x0 (stack 0 reads it as `prev`)
+    float* emb = x0;                       // encoder_embed's output; stack 0 reads it as `prev`
     RS_TRY(gemm(dwo, F3 * c3, k.emb_out_w, F3 * c3, emb, d0, M3, d0, RS_GEMM_BIAS | RS_GEMM_OUT_F32, k.emb_out_b, nullptr));
     hipLaunchKernelGGL(k2_biasnorm_kernel, dim3((unsigned)((M3 + 3) / 4)), dim3(256), 0, s, emb, k.emb_norm_bias, k.emb_norm_scale, (const float*)nullptr,
                        (const float*)nullptr, (int)M3, d0, emb, (uint16_t*)nullptr);
@@ -776,14 +777,19 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
         const int32_t* lens = lens_all + (size_t)(1 + st) * B;
         const long long M = (long long)B * Ts;
         float* stack_out = reinterpret_cast<float*>(ws + pl.off_stackout[st]);
-        // full-rate stacks work in place on their output buffer; down-sampled ones on x, combined with src at the end
-        float* xs = ds == 1 ? stack_out : x;
-        hipLaunchKernelGGL(k2_stack_in_kernel, dim3(Ts, B), dim3(256), 0, s, prev, d_prev, lens3, T3, dd, ds, Ts, k.ds_w[st], ds == 1 ? (float*)nullptr : src, xs);
+        // Two working buffers per stack: `cur` holds a layer's input and stays intact for the whole layer (it is the x0 of both
+        // bypass modules), the layer's first residual GEMM writes into `nxt` (out != residual) and everything after it works in
+        // place there; the buffers swap roles per layer — no copy of the layer input (it was a 1.1 ms memcpy per batch).  The
+        // last layer of a full-rate stack writes its result straight into the stack's output buffer.
+        float* cur = x;
+        float* nxt = x0;                       // (stack 0: `prev` IS x0 — encoder_embed's output — and is dead once stack_in has read it)
+        hipLaunchKernelGGL(k2_stack_in_kernel, dim3(Ts, B), dim3(256), 0, s, prev, d_prev, lens3, T3, dd, ds, Ts, k.ds_w[st], ds == 1 ? (float*)nullptr : src, cur);
         for (int j = 0; j < d.num_layers[st]; ++j) {
             const rs_k2_layer& L = k.stacks[st][j];
             const size_t n = (size_t)M * dd;
-            RS_HIP(ctx, hipMemcpyAsync(x0, xs, n * 4, hipMemcpyDeviceToDevice, s));
-            cast(xs, xb, n);
+            const bool last = j == d.num_layers[st] - 1;
+            float* xs = nxt;
+            if (j == 0) cast(cur, xb, n);           // later layers: the previous layer's BiasNorm wrote the bf16 copy
             // attention weights, shared by the three attention modules of the layer
             RS_TRY(gemm(xb, dd, L.attw_in_w, dd, qkp, nin, M, nin, RS_GEMM_BIAS, L.attw_in_b, nullptr));
             {
@@ -795,11 +801,11 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
                 hipLaunchKernelGGL(k2_attn_weights_kernel, dim3((Ts + 63) / 64, H, B), dim3(256), lds, s, qkp, nin, L.pos_proj, k.pos_cap, H, lens, Ts, Tp, W);
                 rs_prof_end(ctx, RS_PROF_ATTN, s);
             }
-            auto ffn = [&](int f, int width) -> int {
+            auto ffn = [&](int f, int width, const float* res, bool emit) -> int {
                 if (int r = gemm(xb, dd, L.ff_in_w[f], dd, big, width, M, width, RS_GEMM_BIAS | RS_GEMM_SWOOSHL, L.ff_in_b[f], nullptr); r != RS_OK) return r;
-                return gemm(big, width, L.ff_out_w[f], width, xs, dd, M, dd, RES, L.ff_out_b[f], xs);
+                return gemm(big, width, L.ff_out_w[f], width, xs, dd, M, dd, RES, L.ff_out_b[f], res, emit ? xb : nullptr);
             };
-            auto self_attn = [&](int a) -> int {
+            auto self_attn = [&](int a) -> int {       // (the out projection always feeds another branch: it writes the bf16 copy)
                 if (int r = gemm(xb, dd, L.sa_in_w[a], dd, big, vw, M, vw, RS_GEMM_BIAS, L.sa_in_b[a], nullptr); r != RS_OK) return r;
                 // `av` is shared by the three kinds of branch (row pitches vwp / hidp / dd): the columns that pad the out projection's
                 // K extent to a multiple of 64 are zeroed before every use
@@ -807,38 +813,36 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
                 rs_prof_begin(ctx, RS_PROF_ATTN, s, (double)B * H * Ts * (double)Ts * 2.0 * 16.0, (double)B * H * Ts * (double)Tp * 2.0);
                 hipLaunchKernelGGL((k2_pv_kernel<1, 0>), dim3((Ts + 63) / 64, 1, B * H), dim3(256), 0, s, W, H, Tp, big, vw, 0, lens, Ts, av, vwp);
                 rs_prof_end(ctx, RS_PROF_ATTN, s);
-                return gemm(av, vwp, L.sa_out_w[a], vwp, xs, dd, M, dd, RES, L.sa_out_b[a], xs);
+                return gemm(av, vwp, L.sa_out_w[a], vwp, xs, dd, M, dd, RES, L.sa_out_b[a], xs, xb);
             };
             auto conv_module = [&](int a) -> int {
                 if (int r = gemm(xb, dd, L.cm_in_w[a], dd, big, dd, M, 2 * dd, RS_GEMM_BIAS | RS_GEMM_GLU, L.cm_in_b[a], nullptr); r != RS_OK) return r;
                 if (int r = rs_launch_dwconv_act(ctx, big, L.cm_dw_w[a], L.cm_dw_b[a], lens, B, Ts, dd, kk, 1, av, s); r != RS_OK) return r;
-                return gemm(av, dd, L.cm_out_w[a], dd, xs, dd, M, dd, RES, L.cm_out_b[a], xs);
+                return gemm(av, dd, L.cm_out_w[a], dd, xs, dd, M, dd, RES, L.cm_out_b[a], xs, xb);
             };
-            RS_TRY(ffn(0, d.ff_dim[st] * 3 / 4));
+            RS_TRY(ffn(0, d.ff_dim[st] * 3 / 4, cur, true));    // xs = cur + ff1(cur): the layer leaves `cur` and moves into `nxt`
             // non-linear attention: head 0's weights over tanh-gated values, output gate, out projection
-            cast(xs, xb, n);
             RS_TRY(gemm(xb, dd, L.na_in_w, dd, big, 3 * hid, M, 3 * hid, RS_GEMM_BIAS, L.na_in_b, nullptr));
             if (hidp != hid) RS_HIP(ctx, hipMemsetAsync(av, 0, (size_t)M * hidp * 2, s));
             rs_prof_begin(ctx, RS_PROF_ATTN, s, (double)B * Ts * (double)Ts * 2.0 * hid, (double)B * Ts * (double)Tp * 2.0);
             hipLaunchKernelGGL((k2_pv_kernel<4, 1>), dim3((Ts + 63) / 64, (hid + 63) / 64, B), dim3(256), 0, s, W, H, Tp, big, 3 * hid, hid, lens, Ts, av, hidp);
             rs_prof_end(ctx, RS_PROF_ATTN, s);
-            RS_TRY(gemm(av, hidp, L.na_out_w, hidp, xs, dd, M, dd, RES, L.na_out_b, xs));
-            cast(xs, xb, n);
+            RS_TRY(gemm(av, hidp, L.na_out_w, hidp, xs, dd, M, dd, RES, L.na_out_b, xs, xb));
             RS_TRY(self_attn(0));
-            cast(xs, xb, n);
             RS_TRY(conv_module(0));
-            cast(xs, xb, n);
-            RS_TRY(ffn(1, d.ff_dim[st]));
-            hipLaunchKernelGGL(k2_bypass_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, xs, x0, L.bypass_mid, dd, n / 4, xb);
+            RS_TRY(ffn(1, d.ff_dim[st], xs, false));            // (bypass_mid rewrites x and its bf16 copy)
+            hipLaunchKernelGGL(k2_bypass_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, xs, cur, L.bypass_mid, dd, n / 4, xb);
             RS_TRY(self_attn(1));
-            cast(xs, xb, n);
             RS_TRY(conv_module(1));
-            cast(xs, xb, n);
-            RS_TRY(ffn(2, d.ff_dim[st] * 5 / 4));
-            hipLaunchKernelGGL(k2_biasnorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, xs, L.norm_bias, L.norm_scale, x0, L.bypass, (int)M, dd, xs,
-                               (uint16_t*)nullptr);
+            RS_TRY(ffn(2, d.ff_dim[st] * 5 / 4, xs, false));
+            float* dst = (last && ds == 1) ? stack_out : xs;
+            hipLaunchKernelGGL(k2_biasnorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, xs, L.norm_bias, L.norm_scale, cur, L.bypass, (int)M, dd, dst,
+                               last ? (uint16_t*)nullptr : xb);
             RS_CHECK_LAUNCH(ctx, "zipformer layer");
+            nxt = cur;
+            cur = xs;
         }
+        float* xs = cur;                       // the stack's result at its own rate (down-sampled stacks)
         if (ds > 1) hipLaunchKernelGGL(k2_stack_out_kernel, dim3(T3, B), dim3(256), 0, s, src, xs, T3, Ts, dd, ds, k.comb_scale[st], stack_out);
         if (k.tap_stacks) {
             RS_HIP(ctx, hipMemcpyAsync(k.tap_stacks + tap_off, stack_out, (size_t)M3 * dd * 4, hipMemcpyDeviceToDevice, s));
@@ -846,7 +850,6 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
         }
         prev = stack_out;
         d_prev = dd;
-        (void)cur;
     }
     // ---- output: widest channels of every stack, down-sampling by 2, joiner.encoder_proj -----------------------------------------
     K2Pieces pc{};

@@ -195,6 +195,9 @@ struct rs_gemm_args {
     // residual = LayerNorm(residual operand; res_ln_g, res_ln_b) with per-row (mean, rstd) in res_ln_stats [M][2]
     // (nullptr: the residual operand is used as it is)
     const float* res_ln_stats; const float* res_ln_g; const float* res_ln_b;
+    // residual GEMMs only: also store the result rounded to bf16 at out_bf16[m * ld_bf16 + n] (the A operand of the next GEMM:
+    // the Zipformer family has no norm between a residual add and the next Linear, so the copy would otherwise be a pass of its own)
+    uint16_t* out_bf16; int ld_bf16;
 };
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s);
 int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float* b, int M, int d, float eps,
