@@ -631,8 +631,12 @@ __global__ __launch_bounds__(256) void rnnt_prep_kernel(DecodeState st, const fl
     float ss = 0.0f;
     for (int k = 4 * lane; k < J; k += 256) {
         const float4 fv = *reinterpret_cast<const float4*>(fr + k), gv = *reinterpret_cast<const float4*>(gr + k);
-        const float a0 = fmaxf(fv.x + gv.x, 0.0f), a1 = fmaxf(fv.y + gv.y, 0.0f), a2 = fmaxf(fv.z + gv.z, 0.0f),
-                    a3 = fmaxf(fv.w + gv.w, 0.0f);
+        float a0, a1, a2, a3;
+        if (st.joint_act) {       // tanh joint (ESPnet, Zipformer): the exact polynomial, as rnnt_tile_kernel applies it
+            a0 = rs_tanhf(fv.x + gv.x); a1 = rs_tanhf(fv.y + gv.y); a2 = rs_tanhf(fv.z + gv.z); a3 = rs_tanhf(fv.w + gv.w);
+        } else {
+            a0 = fmaxf(fv.x + gv.x, 0.0f); a1 = fmaxf(fv.y + gv.y, 0.0f); a2 = fmaxf(fv.z + gv.z, 0.0f); a3 = fmaxf(fv.w + gv.w, 0.0f);
+        }
         ss = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, fmaf(a3, a3, ss))));
         *reinterpret_cast<u16x4_t*>(st.a16 + (size_t)slot * J + k) = pack_bf16x4(a0, a1, a2, a3);
     }
@@ -710,23 +714,37 @@ __global__ __launch_bounds__(256) void rnnt_screen_kernel(DecodeState st, const 
 //      values is taken.  The result is bit-identical to evaluating all 3001 columns exactly (oracle/rnnt_greedy.c);
 //      the number of candidates only changes the cost (typically 1-3; every column in the worst case).
 //   The same kernel then runs the greedy state machine for the row (emit / advance / work lists).
-template <int NCH>   // NCH * 64 >= V: the row's approximate logits live in registers
+// (NCH == 0: any V — the approximate logits are scanned from memory twice and the candidates are evaluated in batches of up to
+//  VER_CAP; the Zipformer family's 10 720 symbols.)  The error bound does not depend on the activation: a = act(f + g) is
+//  computed exactly (ReLU, or the shared tanh polynomial) and only then rounded for the screening product.
+constexpr int VER_CAP = 1024;
+template <int NCH>   // NCH > 0: NCH * 64 >= V and the row's approximate logits live in registers
 __global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const float* __restrict__ f,
                                                           const int32_t* __restrict__ enc_lens, int B, int Tp, int J, int V,
                                                           int Vpad, const float* __restrict__ Wrm /* [V][J] */,
                                                           const float* __restrict__ bo, const float* __restrict__ wmax, int blank,
                                                           int max_symbols, int u_max, int step, int32_t* __restrict__ ids,
                                                           int32_t* __restrict__ frames, int32_t* __restrict__ n_ids) {
-    extern __shared__ __attribute__((aligned(16))) char ver_smem[];          // [4 waves][J] float: the exact a = relu(f + g)
+    extern __shared__ __attribute__((aligned(16))) char ver_smem[];          // [4 waves][J] float: the exact a = act(f + g)
+    constexpr int CAND_ROWS = NCH > 0 ? NCH * 64 : VER_CAP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = blockIdx.x * 4 + wave;
     const int n_alive = st.counters[2 + (step & 1)];
     if (slot >= n_alive) return;
     const int b = st.alive[(size_t)(step & 1) * B + slot];
     const float* z = st.zapprox + (size_t)slot * Vpad;
-    float zr[NCH];
+    const int nchunk = (V + 63) / 64;
+    float zr[NCH > 0 ? NCH : 1];
+    float m = -INFINITY;
+    if constexpr (NCH > 0) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) zr[c] = (c * 64 + lane < V) ? z[c * 64 + lane] : -INFINITY;
+        for (int c = 0; c < NCH; ++c) zr[c] = (c * 64 + lane < V) ? z[c * 64 + lane] : -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) m = fmaxf(m, zr[c]);
+    } else {
+        for (int c = 0; c < nchunk; ++c) m = fmaxf(m, (c * 64 + lane < V) ? z[c * 64 + lane] : -INFINITY);
+    }
+    m = wave_max(m);
     int t = st.tcur[b];
     const int tc = t < Tp ? t : Tp - 1;
     const float* fr = f + ((size_t)b * Tp + tc) * J;
@@ -734,79 +752,102 @@ __global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const 
     float* a_s = reinterpret_cast<float*>(ver_smem) + wave * J;
     for (int k = 4 * lane; k < J; k += 256) {
         const float4 fv = *reinterpret_cast<const float4*>(fr + k), gv = *reinterpret_cast<const float4*>(gr + k);
-        *reinterpret_cast<float4*>(a_s + k) = make_float4(fmaxf(fv.x + gv.x, 0.0f), fmaxf(fv.y + gv.y, 0.0f),
-                                                          fmaxf(fv.z + gv.z, 0.0f), fmaxf(fv.w + gv.w, 0.0f));
+        if (st.joint_act)
+            *reinterpret_cast<float4*>(a_s + k) = make_float4(rs_tanhf(fv.x + gv.x), rs_tanhf(fv.y + gv.y), rs_tanhf(fv.z + gv.z), rs_tanhf(fv.w + gv.w));
+        else
+            *reinterpret_cast<float4*>(a_s + k) = make_float4(fmaxf(fv.x + gv.x, 0.0f), fmaxf(fv.y + gv.y, 0.0f),
+                                                              fmaxf(fv.z + gv.z, 0.0f), fmaxf(fv.w + gv.w, 0.0f));
     }
-    float m = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) m = fmaxf(m, zr[c]);
-    m = wave_max(m);
     // 2 eps = 2 * 2^-7 * 1.25 * ||a|| * max_v ||w_v||  (wmax[0] holds the largest row norm of W_o, rounded up)
     const float thr = m - 0.01953125f * wmax[0] * st.anorm[slot];
     const int cgrp = lane >> 3, sl = lane & 7;                    // 8 candidates per pass x 8 K slices
     const int kslice = J / SPLITK_TILE, nblk = kslice / 16;       // nblk <= 8 (launcher)
     // candidate columns, ascending, compacted into LDS (the unrolled part stays tiny: the exact evaluation
     // below exists once in the instruction stream)
-    int* cand_s = reinterpret_cast<int*>(ver_smem + 4 * J * 4) + wave * (NCH * 64);
-    int n_cand = 0;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const bool is = zr[c] >= thr;                             // -inf padding never passes (thr is finite)
-        const unsigned long long mask = __ballot(is);
-        if (is) cand_s[n_cand + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = c * 64 + lane;
-        n_cand += __builtin_popcountll(mask);
-    }
+    int* cand_s = reinterpret_cast<int*>(ver_smem + 4 * J * 4) + wave * CAND_ROWS;
     float best = -INFINITY;
     int best_idx = 0x7fffffff;
-    for (int c0 = 0; c0 < n_cand; c0 += 8) {                      // wave-uniform trip count
-        const bool valid = c0 + cgrp < n_cand;
-        const int cand = valid ? cand_s[c0 + cgrp] : 0;
-        const float* w = Wrm + (size_t)cand * J + sl * kslice;
-        const float* as = a_s + sl * kslice;
-        float4 wv[8][4];
+    // exact float32 logits of cand_s[0 .. n_cand): running argmax (lowest index on ties) into best / best_idx
+    auto evaluate = [&](int n_cand) {
+        for (int c0 = 0; c0 < n_cand; c0 += 8) {                  // wave-uniform trip count
+            const bool valid = c0 + cgrp < n_cand;
+            const int cand = valid ? cand_s[c0 + cgrp] : 0;
+            const float* w = Wrm + (size_t)cand * J + sl * kslice;
+            const float* as = a_s + sl * kslice;
+            float4 wv[8][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (u < nblk) {
+            for (int u = 0; u < 8; ++u)
+                if (u < nblk) {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) wv[u][kk] = *reinterpret_cast<const float4*>(w + 16 * u + 4 * kk);
-            }
-        float acc = 0.0f;
+                    for (int kk = 0; kk < 4; ++kk) wv[u][kk] = *reinterpret_cast<const float4*>(w + 16 * u + 4 * kk);
+                }
+            float acc = 0.0f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (u < nblk) {
-                // a 16-block: float4 loads give (e = 0..3) of each kk; the chain runs e-major, kk-minor
-                float4 av[4];
+            for (int u = 0; u < 8; ++u)
+                if (u < nblk) {
+                    // a 16-block: float4 loads give (e = 0..3) of each kk; the chain runs e-major, kk-minor
+                    float4 av[4];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) av[kk] = *reinterpret_cast<const float4*>(as + 16 * u + 4 * kk);
+                    for (int kk = 0; kk < 4; ++kk) av[kk] = *reinterpret_cast<const float4*>(as + 16 * u + 4 * kk);
 #define RS_CHAIN_E(cc) _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) acc = fmaf(av[kk].cc, wv[u][kk].cc, acc);
-                RS_CHAIN_E(x) RS_CHAIN_E(y) RS_CHAIN_E(z) RS_CHAIN_E(w)
+                    RS_CHAIN_E(x) RS_CHAIN_E(y) RS_CHAIN_E(z) RS_CHAIN_E(w)
 #undef RS_CHAIN_E
+                }
+            // partial chains combined left to right by the group's first lane, then + bias
+            float sum = __shfl(acc, lane & ~7, 64);
+#pragma unroll
+            for (int q = 1; q < SPLITK_TILE; ++q) sum = sum + __shfl(acc, (lane & ~7) + q, 64);
+            float val = valid ? sum + bo[cand] : -INFINITY;
+            int idx = valid ? cand : 0x7fffffff;
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {              // argmax over the 8 groups (exact values, lowest index on ties)
+                const float ov = __shfl_xor(val, off, 64);
+                const int oi = __shfl_xor(idx, off, 64);
+                if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
             }
-        // partial chains combined left to right by the group's first lane, then + bias
-        float sum = __shfl(acc, lane & ~7, 64);
-#pragma unroll
-        for (int q = 1; q < SPLITK_TILE; ++q) sum = sum + __shfl(acc, (lane & ~7) + q, 64);
-        float val = valid ? sum + bo[cand] : -INFINITY;
-        int idx = valid ? cand : 0x7fffffff;
-#pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {                  // argmax over the 8 groups (exact values, lowest index on ties)
-            const float ov = __shfl_xor(val, off, 64);
-            const int oi = __shfl_xor(idx, off, 64);
-            if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+            if (val > best || (val == best && idx < best_idx)) { best = val; best_idx = idx; }
         }
-        if (val > best || (val == best && idx < best_idx)) { best = val; best_idx = idx; }
+    };
+    int n_cand = 0;
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const bool is = zr[c] >= thr;                         // -inf padding never passes (thr is finite)
+            const unsigned long long mask = __ballot(is);
+            if (is) cand_s[n_cand + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = c * 64 + lane;
+            n_cand += __builtin_popcountll(mask);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        evaluate(n_cand);
+    } else {
+        for (int c = 0; c < nchunk; ++c) {
+            const bool is = c * 64 + lane < V && z[c * 64 + lane] >= thr;
+            const unsigned long long mask = __ballot(is);
+            if (is) cand_s[n_cand + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = c * 64 + lane;
+            n_cand += __builtin_popcountll(mask);
+            if (n_cand + 64 > VER_CAP || c == nchunk - 1) {       // wave-uniform: the batch is full (or the scan is over)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                evaluate(n_cand);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                n_cand = 0;
+            }
+        }
     }
     if (lane != 0) return;
     // greedy state machine (identical to rnnt_finalize_kernel)
     const int idx = best_idx;
     int sy = st.sym[b];
     bool emitted = false;
-    if (idx == blank || idx == 0x7fffffff) {
+    if (idx == blank || idx == st.unk || idx == 0x7fffffff) {
         t += 1; sy = 0;
     } else {
         const int n = n_ids[b];
         if (n < u_max) { ids[(size_t)b * u_max + n] = idx; frames[(size_t)b * u_max + n] = t; n_ids[b] = n + 1; }
         else st.counters[1] = 1;
+        if (st.token2) st.token2[b] = st.token[b];
         st.token[b] = idx;
         emitted = true;
         sy += 1;
@@ -990,7 +1031,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     st.a16 = (uint16_t*)take((size_t)B * J * 2); st.anorm = (float*)take((size_t)B * 4);
     st.zapprox = (float*)take((size_t)B * Vpad * 4);
     // the screened joint keeps a row's logits (<= 48 x 64) and a K slice (<= 8 blocks of 16) in registers, J / 32 <= 20 weight fragments
-    const bool screen = d.joint_act == 0 && ctx->decode_screen && ctx->jout_w16 && ctx->jout_wrm && ctx->jout_bpad && ctx->jout_wmax && V <= 48 * 64 &&
+    const bool screen = ctx->decode_screen && ctx->jout_w16 && ctx->jout_wrm && ctx->jout_bpad && ctx->jout_wmax &&
                         J / SPLITK_TILE / 16 <= 8 && J / 32 <= 20;
 
     if (int rc = ensure_decode_lds(ctx); rc != RS_OK) return rc;
@@ -1030,6 +1071,9 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
                 const dim3 vg((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1);
                 if (V <= 64 * 8)
                     hipLaunchKernelGGL(rnnt_verify_kernel<8>, vg, dim3(256), 4 * J * 4 + 4 * 8 * 64 * 4, s, st, joint_enc, enc_lens, B, tp_max, J, V, Vpad,
+                                       ctx->jout_wrm, ctx->jout_b, ctx->jout_wmax, d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
+                else if (V > 64 * 48)
+                    hipLaunchKernelGGL(rnnt_verify_kernel<0>, vg, dim3(256), 4 * J * 4 + 4 * VER_CAP * 4, s, st, joint_enc, enc_lens, B, tp_max, J, V, Vpad,
                                        ctx->jout_wrm, ctx->jout_b, ctx->jout_wmax, d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
                 else
                     hipLaunchKernelGGL(rnnt_verify_kernel<48>, vg, dim3(256), 4 * J * 4 + 4 * 48 * 64 * 4, s, st, joint_enc, enc_lens, B, tp_max, J, V, Vpad,

@@ -679,9 +679,16 @@ int rs_k2_finalize_impl(rs_ctx* ctx) {
     K2_GET("dec.conv.w", D * 4 * 2, ctx->k2_conv_w);
     K2_GET("joint.pred.w", J * D, ctx->jpred_w); K2_GET("joint.pred.b", J, ctx->jpred_b);
     K2_GET("joint.out.w", ((V + 15) / 16 * 16) * J, ctx->jout_w); K2_GET("joint.out.b", V, ctx->jout_b);
+    // optional: the screened joint's operands (all four or none), as for the other families
+    ctx->jout_w16 = nullptr; ctx->jout_wrm = ctx->jout_bpad = ctx->jout_wmax = nullptr;
+    if (ctx->tensors.count("joint.out.w16") || ctx->tensors.count("joint.out.wrm") || ctx->tensors.count("joint.out.bpad") || ctx->tensors.count("joint.out.wmax")) {
+        const size_t Vpad = (V + 15) / 16 * 16;
+        K2_GET("joint.out.w16", Vpad * J, ctx->jout_w16);
+        K2_GET("joint.out.wrm", V * J, ctx->jout_wrm);
+        K2_GET("joint.out.bpad", Vpad, ctx->jout_bpad);
+        K2_GET("joint.out.wmax", 4, ctx->jout_wmax);
+    }
 #undef K2_GET
-    ctx->jout_w16 = nullptr;
-    ctx->decode_screen = false;           // tanh joint: the exact kernels
     ctx->decode_narrow = true;
     ctx->finalized = true;
     return RS_OK;

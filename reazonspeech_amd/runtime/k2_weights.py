@@ -14,7 +14,7 @@ import torch
 
 from .config import UnsupportedCheckpoint
 from .k2_config import ZipformerConfig
-from .weights import _randn, _seed_for, banded_filterbank, fft_twiddles, glu_interleave_index, to_fragment_major
+from .weights import _randn, _seed_for, banded_filterbank, fft_twiddles, glu_interleave_index, screen_tensors, to_fragment_major
 
 K2_POS_CAP = 1024      # relative positions kept resident per stack: frames of the 50 Hz stack up to 1024 (~20 s); grown on demand
 BRANCH = 0.25          # gain of the residual branches' output projections (icefall's ScaledLinear initial_scale plays this role)
@@ -261,6 +261,7 @@ def prepare_weights_k2(cfg: ZipformerConfig, sd: Dict[str, torch.Tensor], pos_ca
     out["joint.pred.b"] = f32(get("joiner.decoder_proj.bias"))
     out["joint.out.w"] = to_fragment_major(get("joiner.output_linear.weight"))
     out["joint.out.b"] = f32(get("joiner.output_linear.bias"))
+    out.update(screen_tensors(get("joiner.output_linear.weight"), get("joiner.output_linear.bias")))      # screened joint (greedy search)
     left = [k for k in sd if k not in used]
     if left:
         raise UnsupportedCheckpoint(f"{len(left)} checkpoint tensor(s) have no counterpart in this implementation: "

@@ -264,7 +264,7 @@ class AsrModel:
             ctx.set_option("decode_narrow", 0)
             ctx.set_option("decode_screen", 0)
             return
-        if self is not None and (self.cfg.espnet or getattr(self.cfg, "family", "") == "k2"):   # tanh joint: the exact kernels (the screened joint's bound is derived for ReLU)
+        if self is not None and self.cfg.decoding == "beam":          # (the screened joint serves the greedy searches only)
             ctx.set_option("decode_screen", 0)
             ctx.set_option("decode_narrow", 0 if (pipelined and lanes == 1 and B >= 128) else 1)
             return

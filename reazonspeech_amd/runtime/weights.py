@@ -323,6 +323,22 @@ def glu_interleave_index(d: int) -> torch.Tensor:
     return torch.cat([32 * j + r, d + 32 * j + r], dim=1).reshape(-1)
 
 
+def screen_tensors(weight: torch.Tensor, bias: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """operands of the screened joint (k_rnnt.hip) for an output layer [V][J]: a bf16 copy for the screening GEMM (rows padded
+    to a multiple of 16 with zeros, bias pad -3e38 so a padded column can never be a candidate), the float32 row-major copy
+    the exact re-evaluation reads, and the largest row norm (rounded up: it scales an error BOUND)"""
+    wo = weight.detach().to(torch.float32)
+    n, j = wo.shape
+    vpad = (n + 15) // 16 * 16
+    w16 = torch.zeros((vpad, j), dtype=torch.bfloat16)
+    w16[:n] = wo.to(torch.bfloat16)
+    bpad = torch.full((vpad,), -3.0e38, dtype=torch.float32)
+    bpad[:n] = bias.detach().to(torch.float32)
+    wmax = float(wo.double().norm(dim=1).max()) * (1.0 + 2.0 ** -10)
+    return {"joint.out.w16": w16.contiguous(), "joint.out.wrm": wo.contiguous(), "joint.out.bpad": bpad,
+            "joint.out.wmax": torch.tensor([wmax, 0.0, 0.0, 0.0], dtype=torch.float32)}
+
+
 def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int = DEFAULT_POS_CAP, f32: bool = False):
     """-> dict name -> CPU torch tensor (float32 / bfloat16 / int32) exactly as registered with
     rs_set_tensor (DESIGN.md "Weights in HBM").  Host-side transforms, all one-off:
@@ -464,20 +480,7 @@ def prepare_weights(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_cap: int 
                                     f"({cfg.n_logits}, {cfg.joint_hidden}) (vocab_size + blank, joint_hidden)")
     out["joint.out.w"] = to_fragment_major(sd[jout + ".weight"])
     out["joint.out.b"] = f32(sd[jout + ".bias"])
-    # screened joint (k_rnnt.hip): bf16 copy for the screening GEMM (rows padded to a multiple of 16 with zeros, bias
-    # pad -3e38 so a padded column can never be a candidate), the float32 row-major copy the exact re-evaluation reads,
-    # and the largest row norm (rounded up: it scales an error BOUND)
-    wo = sd[jout + ".weight"].detach().to(torch.float32)
-    vpad = (cfg.n_logits + 15) // 16 * 16
-    w16 = torch.zeros((vpad, cfg.joint_hidden), dtype=torch.bfloat16)
-    w16[:cfg.n_logits] = wo.to(torch.bfloat16)
-    bpad = torch.full((vpad,), -3.0e38, dtype=torch.float32)
-    bpad[:cfg.n_logits] = sd[jout + ".bias"].detach().to(torch.float32)
-    out["joint.out.w16"] = w16.contiguous()
-    out["joint.out.wrm"] = wo.contiguous()
-    out["joint.out.bpad"] = bpad
-    wmax = float(wo.double().norm(dim=1).max()) * (1.0 + 2.0 ** -10)
-    out["joint.out.wmax"] = torch.tensor([wmax, 0.0, 0.0, 0.0], dtype=torch.float32)
+    out.update(screen_tensors(sd[jout + ".weight"], sd[jout + ".bias"]))
     out["pos.table"] = torch.from_numpy(rel_pos_table(cfg, pos_cap)).to(torch.bfloat16).contiguous()
     if want_f32:
         out["pos.table.f32"] = torch.from_numpy(rel_pos_table(cfg, pos_cap)).contiguous()

@@ -16,7 +16,7 @@ import torch
 
 from .config import ModelConfig, UnsupportedCheckpoint
 from .weights import (BRANCH_GAIN, _randn, _seed_for, banded_filterbank, fft_twiddles, glu_interleave_index, rel_pos_table,
-                      slaney_mel_filterbank, to_fragment_major, DEFAULT_POS_CAP)
+                      screen_tensors, slaney_mel_filterbank, to_fragment_major, DEFAULT_POS_CAP)
 
 
 def synthetic_state_dict_espnet(cfg: ModelConfig, seed: int = 0, blank_bias: float = None, dec_gain: float = 1.0) -> Dict[str, torch.Tensor]:
@@ -216,6 +216,7 @@ def prepare_weights_espnet(cfg: ModelConfig, sd: Dict[str, torch.Tensor], pos_ca
     out["joint.pred.b"] = torch.zeros((cfg.joint_hidden,), dtype=torch.float32)           # lin_dec has no bias
     out["joint.out.w"] = to_fragment_major(get("joint_network.lin_out.weight"))
     out["joint.out.b"] = f32t(get("joint_network.lin_out.bias"))
+    out.update(screen_tensors(get("joint_network.lin_out.weight"), get("joint_network.lin_out.bias")))     # screened joint (greedy search)
     for name in [k for k, v in out.items() if isinstance(v, _Dense)]:
         t = out[name].t
         out[name] = t.to(torch.bfloat16).contiguous()

@@ -95,6 +95,26 @@ def test_tiny_batch_invariance_bits(tiny):
         assert alone.ids[0] == together.ids[b] and alone.frames[0] == together.frames[b]
 
 
+def test_screened_joint_is_bit_identical_with_the_tanh_joint(tiny):
+    """the screened joint (bf16 screening product, exact float32 re-evaluation of every column that can still be the argmax) serves
+    the tanh JointNetwork too: its error bound only needs a = act(f + g) computed exactly before it is rounded"""
+    model, sd = tiny
+    am = model.am
+    audio, lens = synthetic_batch(6, 3.0, seed=21, ragged=True, min_seconds=0.5)
+    buf = am.stage([audio[b, :int(lens[b])] for b in range(6)])
+    am.run_device(buf)
+    torch.cuda.synchronize()
+    outs = []
+    for screen in (0, 1):
+        am.ctx.set_option("decode_screen", screen)
+        am.decode(am.ctx, buf, buf.ws, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(am.collect(buf))
+    want = og.rnnt_greedy(ESPNET_TINY, sd, buf.joint_enc.cpu().numpy(), np.asarray(outs[0].enc_lens, np.int32))
+    assert outs[0].ids == outs[1].ids == [r[0] for r in want] and outs[0].frames == outs[1].frames == [r[1] for r in want]
+    assert sum(len(x) for x in outs[0].ids) > 10
+
+
 def test_120m_geometry_vs_oracle(gpu_device):
     """d = 512, 8 heads of 64, FFN 2048, kernel 31, 17 blocks, Conv2dSubsampling with 512 channels (the dense 3x3 conv as a
     GEMM over gathered patches, in chunks), vocabulary 2600: two ragged utterances with the reference's (16000, 8000) padding"""
@@ -106,6 +126,17 @@ def test_120m_geometry_vs_oracle(gpu_device):
         padded[b, 16000:16000 + lens[b]] = audio[b, :lens[b]]
     stats, got = compare(cfg, sd, model, padded, lens + 24000, 0.08, 0.01)
     print("espnet 120M:", stats, [len(x) for x in got.ids])
+    am = model.am                                   # the screened joint at V = 2600 (48 x 64 columns in registers), tanh
+    buf = am.stage([padded[b, :int(lens[b]) + 24000] for b in range(2)])
+    am.run_device(buf)
+    torch.cuda.synchronize()
+    outs = []
+    for screen in (0, 1):
+        am.ctx.set_option("decode_screen", screen)
+        am.decode(am.ctx, buf, buf.ws, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(am.collect(buf))
+    assert outs[0].ids == outs[1].ids == got.ids and outs[0].frames == outs[1].frames == got.frames
 
 
 def test_model_object_answers_the_reference_call_forms(tiny):

@@ -127,13 +127,39 @@ def test_unk_is_never_emitted_and_costs_no_context(tiny):
     assert all(cfg.unk_id not in ids for ids in got.ids)
 
 
+def decode_with(model, buf, screen):
+    """the greedy search alone on the buffer's joint projection with the screened (bf16 screening product + exact re-evaluation of
+    the candidates) or the all-exact joint"""
+    am = model.am
+    am.ctx.set_option("decode_screen", screen)
+    am.ctx.set_option("decode_narrow", 1)
+    am.decode(am.ctx, buf, buf.ws, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return am.collect(buf)
+
+
+def test_screened_joint_is_bit_identical_with_the_tanh_joiner(tiny):
+    model, sd = tiny
+    waves = ragged_waves(6, 3.0, 13, 0.5)
+    buf, _, _, _, _ = run(model, waves, taps=False)
+    exact, screened = decode_with(model, buf, 0), decode_with(model, buf, 1)
+    want = og.k2_greedy(ZIPFORMER_TINY, sd, buf.joint_enc.cpu().numpy(), np.asarray(exact.enc_lens, np.int32))
+    assert exact.ids == screened.ids == [r[0] for r in want] and exact.frames == screened.frames == [r[1] for r in want]
+    assert sum(len(x) for x in exact.ids) > 10
+
+
 def test_159m_geometry_vs_oracle(gpu_device):
     """the published shape (6 stacks 192 .. 768 wide, 19 layers, down-sampling 1 / 2 / 4 / 8 / 4 / 2, kernels 31 / 15): two ragged
     utterances with the reference's 0.9 s padding"""
     cfg = ZIPFORMER_159M
     model, sd = build(cfg, 0)
-    stats, got = compare(cfg, sd, model, ragged_waves(2, 3.0, 123, 1.5))
+    waves = ragged_waves(2, 3.0, 123, 1.5)
+    stats, got = compare(cfg, sd, model, waves)
     print("k2 159M:", stats, [len(x) for x in got.ids])
+    # the screened joint over the 10 720-symbol vocabulary (candidates scanned from memory, batches of 1024): same ids and frames
+    buf, _, _, _, _ = run(model, waves, taps=False)
+    exact, screened = decode_with(model, buf, 0), decode_with(model, buf, 1)
+    assert exact.ids == screened.ids == got.ids and exact.frames == screened.frames == got.frames
 
 
 def test_model_object_answers_sherpa_onnx_call_forms(tiny):
