@@ -500,7 +500,7 @@ def k2_config(device, args, steps=10):
            "enc_frames": bufs[0].tp_max, "mean_tokens_per_utt": round(float(n_tok.mean()), 1)}
     try:
         from oracle import zipformer as oz, greedy as og
-        k = 4
+        k = 2
         am.run_device(bufs[0])
         torch.cuda.synchronize()
         got = am.collect(bufs[0])

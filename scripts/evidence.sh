@@ -11,6 +11,8 @@
 #   pmc          four --pmc passes (sequential schedule)  -> <tag>_pmc_per_kernel.txt (scripts/pmc_to_traffic.py turns it into profiles/gemm_traffic.json)
 #   gemm=ARGS    scripts/gemm_bench.py ARGS (commas = spaces; e.g. gemm=0,--yardstick) -> <tag>_gemm.txt
 #   espnet=B     scripts/espnet_bench.py --batch=B        -> <tag>_espnet_bench.txt
+#   k2           scripts/k2_bench.py (pipelined bench line of configs.k2_zipformer_159m) + a kernel trace of the sequential schedule -> <tag>_k2_bench.json, <tag>_k2_kernel_stats.txt
+#   espnettrace  kernel trace of scripts/espnet_bench.py -> <tag>_espnet_kernel_stats.txt
 #   beam[=ARGS]  scripts/espnet_beam_bench.py ARGS ('+' = space; default --bias=16+--beam=5,20) -> <tag>_beam_bench.txt;
 #                with RS_BEAM_TRACE=1 in the environment the step kernel's phase times are appended
 #   ab:VAR=a,b   the bench with environment VAR set to a, then b (same box, interleaved twice) -> <tag>_ab_VAR.txt
@@ -47,6 +49,17 @@ for WHAT in "$@"; do
     espnet|espnet=*)
       B=${WHAT#espnet=}; [ "$B" == "espnet" ] && B=256
       timeout 600 python scripts/espnet_bench.py --batch=$B > gpurun_out/${TAG}_espnet_bench.txt 2>&1; cat gpurun_out/${TAG}_espnet_bench.txt ;;
+    k2)
+      timeout 600 python scripts/k2_bench.py 8 > gpurun_out/${TAG}_k2_bench.json 2> gpurun_out/${TAG}_k2_bench.err; cut -c1-400 gpurun_out/${TAG}_k2_bench.json
+      OUT=gpurun_out/prof_${TAG}_k2; rm -rf $OUT
+      timeout 600 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python scripts/k2_bench.py 3 --seq > gpurun_out/${TAG}_k2_trace.log 2>&1
+      DB=$(find $OUT -name "*.db" | head -1); python scripts/rocprof_summary.py $DB 4 > gpurun_out/${TAG}_k2_kernel_stats.txt 2>&1
+      head -16 gpurun_out/${TAG}_k2_kernel_stats.txt; rm -rf $OUT ;;
+    espnettrace)
+      OUT=gpurun_out/prof_${TAG}_espnet; rm -rf $OUT
+      timeout 600 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python scripts/espnet_bench.py --batch=256 > gpurun_out/${TAG}_espnet_trace.log 2>&1
+      DB=$(find $OUT -name "*.db" | head -1); python scripts/rocprof_summary.py $DB > gpurun_out/${TAG}_espnet_kernel_stats.txt 2>&1
+      head -16 gpurun_out/${TAG}_espnet_kernel_stats.txt; rm -rf $OUT ;;
     beam|beam=*)
       A=${WHAT#beam=}; [ "$A" == "beam" ] && A="--bias=16+--beam=5,20"
       timeout 600 python scripts/espnet_beam_bench.py ${A//+/ } > gpurun_out/${TAG}_beam_bench.txt 2>&1; grep -v amdgpu.ids gpurun_out/${TAG}_beam_bench.txt ;;
