@@ -621,7 +621,10 @@ def espnet_beam_config(device, args, beam=20, max_pops=640):
         got = [(ids[i, :n[i]].cpu().tolist(), float(sc[i]), int(pp[i])) for i in range(k)]
         res["parity"] = {"utterances": k, "frames": T, "checker": "oracle/espnet_beam.c (float32, fixed order; follows the torch restatement of "
                          "ESPnet's default_beam_search — unpinned against ESPnet itself)",
-                         "labels_scores_pops_bit_exact": got == [(w[0], float(np.float32(w[1])), w[2]) for w in want]}
+                         "labels_scores_pops_bit_exact": got == [(w[0], float(np.float32(w[1])), w[2]) for w in want],
+                         "whole_utterances": "tests/test_gpu_espnet_fp32.py::test_120m_beam20_whole_utterances (-m gpu): 32 rows x 358 frames of "
+                                             "this batch, device == C checker bit for bit and labels == the float64 restatement's committed "
+                                             "golden (the C checker needs ~40 s of CPU per whole row: not repeated inside the bench)"}
         del sub
     except Exception as e:
         res["parity"] = {"error": repr(e)}

@@ -718,7 +718,92 @@ __global__ __launch_bounds__(256) void rnnt_screen_kernel(DecodeState st, const 
 //  VER_CAP; the Zipformer family's 10 720 symbols.)  The error bound does not depend on the activation: a = act(f + g) is
 //  computed exactly (ReLU, or the shared tanh polynomial) and only then rounded for the screening product.
 constexpr int VER_CAP = 1024;
-template <int NCH>   // NCH > 0: NCH * 64 >= V and the row's approximate logits live in registers
+
+// exact float32 logits of the candidate columns cand_s[0 .. n_cand) of one row (a_s = its exact act(f + g) in LDS), one wave:
+// running argmax (lowest index on ties) into best / best_idx.  8 candidates per pass x 8 K slices.
+__device__ __forceinline__ void verify_evaluate(const int* cand_s, int n_cand, const float* a_s, const float* __restrict__ Wrm,
+                                                const float* __restrict__ bo, int J, int lane, float& best, int& best_idx) {
+    const int cgrp = lane >> 3, sl = lane & 7;
+    const int kslice = J / SPLITK_TILE, nblk = kslice / 16;       // nblk <= 8 (launcher)
+    for (int c0 = 0; c0 < n_cand; c0 += 8) {                      // wave-uniform trip count
+        const bool valid = c0 + cgrp < n_cand;
+        const int cand = valid ? cand_s[c0 + cgrp] : 0;
+        const float* w = Wrm + (size_t)cand * J + sl * kslice;
+        const float* as = a_s + sl * kslice;
+        float4 wv[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < nblk) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) wv[u][kk] = *reinterpret_cast<const float4*>(w + 16 * u + 4 * kk);
+            }
+        float acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < nblk) {
+                // a 16-block: float4 loads give (e = 0..3) of each kk; the chain runs e-major, kk-minor
+                float4 av[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) av[kk] = *reinterpret_cast<const float4*>(as + 16 * u + 4 * kk);
+#define RS_CHAIN_E(cc) _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) acc = fmaf(av[kk].cc, wv[u][kk].cc, acc);
+                RS_CHAIN_E(x) RS_CHAIN_E(y) RS_CHAIN_E(z) RS_CHAIN_E(w)
+#undef RS_CHAIN_E
+            }
+        // partial chains combined left to right by the group's first lane, then + bias
+        float sum = __shfl(acc, lane & ~7, 64);
+#pragma unroll
+        for (int q = 1; q < SPLITK_TILE; ++q) sum = sum + __shfl(acc, (lane & ~7) + q, 64);
+        float val = valid ? sum + bo[cand] : -INFINITY;
+        int idx = valid ? cand : 0x7fffffff;
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {                  // argmax over the 8 groups (exact values, lowest index on ties)
+            const float ov = __shfl_xor(val, off, 64);
+            const int oi = __shfl_xor(idx, off, 64);
+            if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+        }
+        if (val > best || (val == best && idx < best_idx)) { best = val; best_idx = idx; }
+    }
+}
+
+// the row's exact a = act(f[b][t] + g[b]) into LDS: `nthr` threads, thread `tid`
+__device__ __forceinline__ void verify_act_row(const DecodeState& st, const float* fr, const float* gr, float* a_s, int J, int tid, int nthr) {
+    for (int k = 4 * tid; k < J; k += 4 * nthr) {
+        const float4 fv = *reinterpret_cast<const float4*>(fr + k), gv = *reinterpret_cast<const float4*>(gr + k);
+        if (st.joint_act)
+            *reinterpret_cast<float4*>(a_s + k) = make_float4(rs_tanhf(fv.x + gv.x), rs_tanhf(fv.y + gv.y), rs_tanhf(fv.z + gv.z), rs_tanhf(fv.w + gv.w));
+        else
+            *reinterpret_cast<float4*>(a_s + k) = make_float4(fmaxf(fv.x + gv.x, 0.0f), fmaxf(fv.y + gv.y, 0.0f),
+                                                              fmaxf(fv.z + gv.z, 0.0f), fmaxf(fv.w + gv.w, 0.0f));
+    }
+}
+
+// greedy state machine of one row (identical to rnnt_finalize_kernel); one thread
+__device__ __forceinline__ void verify_commit(const DecodeState& st, int b, int t, int idx, const int32_t* __restrict__ enc_lens, int B,
+                                              int blank, int max_symbols, int u_max, int step, int32_t* __restrict__ ids,
+                                              int32_t* __restrict__ frames, int32_t* __restrict__ n_ids) {
+    int sy = st.sym[b];
+    bool emitted = false;
+    if (idx == blank || idx == st.unk || idx == 0x7fffffff) {
+        t += 1; sy = 0;
+    } else {
+        const int n = n_ids[b];
+        if (n < u_max) { ids[(size_t)b * u_max + n] = idx; frames[(size_t)b * u_max + n] = t; n_ids[b] = n + 1; }
+        else st.counters[1] = 1;
+        if (st.token2) st.token2[b] = st.token[b];
+        st.token[b] = idx;
+        emitted = true;
+        sy += 1;
+        if (sy >= max_symbols) { t += 1; sy = 0; }
+    }
+    st.tcur[b] = t; st.sym[b] = sy;
+    if (t < enc_lens[b]) {
+        const int pos = atomicAdd(&st.counters[2 + ((step + 1) & 1)], 1);
+        st.alive[(size_t)((step + 1) & 1) * B + pos] = b;
+        if (emitted) { const int pa = atomicAdd(&st.counters[0], 1); st.act[pa] = b; }
+    }
+}
+
+template <int NCH>   // one WAVE per row.  NCH > 0: NCH * 64 >= V and the row's approximate logits live in registers
 __global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const float* __restrict__ f,
                                                           const int32_t* __restrict__ enc_lens, int B, int Tp, int J, int V,
                                                           int Vpad, const float* __restrict__ Wrm /* [V][J] */,
@@ -745,69 +830,17 @@ __global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const 
         for (int c = 0; c < nchunk; ++c) m = fmaxf(m, (c * 64 + lane < V) ? z[c * 64 + lane] : -INFINITY);
     }
     m = wave_max(m);
-    int t = st.tcur[b];
+    const int t = st.tcur[b];
     const int tc = t < Tp ? t : Tp - 1;
-    const float* fr = f + ((size_t)b * Tp + tc) * J;
-    const float* gr = st.g + (size_t)b * J;
     float* a_s = reinterpret_cast<float*>(ver_smem) + wave * J;
-    for (int k = 4 * lane; k < J; k += 256) {
-        const float4 fv = *reinterpret_cast<const float4*>(fr + k), gv = *reinterpret_cast<const float4*>(gr + k);
-        if (st.joint_act)
-            *reinterpret_cast<float4*>(a_s + k) = make_float4(rs_tanhf(fv.x + gv.x), rs_tanhf(fv.y + gv.y), rs_tanhf(fv.z + gv.z), rs_tanhf(fv.w + gv.w));
-        else
-            *reinterpret_cast<float4*>(a_s + k) = make_float4(fmaxf(fv.x + gv.x, 0.0f), fmaxf(fv.y + gv.y, 0.0f),
-                                                              fmaxf(fv.z + gv.z, 0.0f), fmaxf(fv.w + gv.w, 0.0f));
-    }
+    verify_act_row(st, f + ((size_t)b * Tp + tc) * J, st.g + (size_t)b * J, a_s, J, lane, 64);
     // 2 eps = 2 * 2^-7 * 1.25 * ||a|| * max_v ||w_v||  (wmax[0] holds the largest row norm of W_o, rounded up)
     const float thr = m - 0.01953125f * wmax[0] * st.anorm[slot];
-    const int cgrp = lane >> 3, sl = lane & 7;                    // 8 candidates per pass x 8 K slices
-    const int kslice = J / SPLITK_TILE, nblk = kslice / 16;       // nblk <= 8 (launcher)
-    // candidate columns, ascending, compacted into LDS (the unrolled part stays tiny: the exact evaluation
-    // below exists once in the instruction stream)
+    // candidate columns, ascending, compacted into LDS (the unrolled part stays tiny: the exact evaluation exists once in
+    // the instruction stream)
     int* cand_s = reinterpret_cast<int*>(ver_smem + 4 * J * 4) + wave * CAND_ROWS;
     float best = -INFINITY;
     int best_idx = 0x7fffffff;
-    // exact float32 logits of cand_s[0 .. n_cand): running argmax (lowest index on ties) into best / best_idx
-    auto evaluate = [&](int n_cand) {
-        for (int c0 = 0; c0 < n_cand; c0 += 8) {                  // wave-uniform trip count
-            const bool valid = c0 + cgrp < n_cand;
-            const int cand = valid ? cand_s[c0 + cgrp] : 0;
-            const float* w = Wrm + (size_t)cand * J + sl * kslice;
-            const float* as = a_s + sl * kslice;
-            float4 wv[8][4];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (u < nblk) {
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) wv[u][kk] = *reinterpret_cast<const float4*>(w + 16 * u + 4 * kk);
-                }
-            float acc = 0.0f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (u < nblk) {
-                    // a 16-block: float4 loads give (e = 0..3) of each kk; the chain runs e-major, kk-minor
-                    float4 av[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) av[kk] = *reinterpret_cast<const float4*>(as + 16 * u + 4 * kk);
-#define RS_CHAIN_E(cc) _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) acc = fmaf(av[kk].cc, wv[u][kk].cc, acc);
-                    RS_CHAIN_E(x) RS_CHAIN_E(y) RS_CHAIN_E(z) RS_CHAIN_E(w)
-#undef RS_CHAIN_E
-                }
-            // partial chains combined left to right by the group's first lane, then + bias
-            float sum = __shfl(acc, lane & ~7, 64);
-#pragma unroll
-            for (int q = 1; q < SPLITK_TILE; ++q) sum = sum + __shfl(acc, (lane & ~7) + q, 64);
-            float val = valid ? sum + bo[cand] : -INFINITY;
-            int idx = valid ? cand : 0x7fffffff;
-#pragma unroll
-            for (int off = 8; off < 64; off <<= 1) {              // argmax over the 8 groups (exact values, lowest index on ties)
-                const float ov = __shfl_xor(val, off, 64);
-                const int oi = __shfl_xor(idx, off, 64);
-                if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
-            }
-            if (val > best || (val == best && idx < best_idx)) { best = val; best_idx = idx; }
-        }
-    };
     int n_cand = 0;
     if constexpr (NCH > 0) {
 #pragma unroll
@@ -819,7 +852,7 @@ __global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        evaluate(n_cand);
+        verify_evaluate(cand_s, n_cand, a_s, Wrm, bo, J, lane, best, best_idx);
     } else {
         for (int c = 0; c < nchunk; ++c) {
             const bool is = c * 64 + lane < V && z[c * 64 + lane] >= thr;
@@ -829,7 +862,7 @@ __global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const 
             if (n_cand + 64 > VER_CAP || c == nchunk - 1) {       // wave-uniform: the batch is full (or the scan is over)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                evaluate(n_cand);
+                verify_evaluate(cand_s, n_cand, a_s, Wrm, bo, J, lane, best, best_idx);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 n_cand = 0;
@@ -837,28 +870,70 @@ __global__ __launch_bounds__(256) void rnnt_verify_kernel(DecodeState st, const 
         }
     }
     if (lane != 0) return;
-    // greedy state machine (identical to rnnt_finalize_kernel)
-    const int idx = best_idx;
-    int sy = st.sym[b];
-    bool emitted = false;
-    if (idx == blank || idx == st.unk || idx == 0x7fffffff) {
-        t += 1; sy = 0;
-    } else {
-        const int n = n_ids[b];
-        if (n < u_max) { ids[(size_t)b * u_max + n] = idx; frames[(size_t)b * u_max + n] = t; n_ids[b] = n + 1; }
-        else st.counters[1] = 1;
-        if (st.token2) st.token2[b] = st.token[b];
-        st.token[b] = idx;
-        emitted = true;
-        sy += 1;
-        if (sy >= max_symbols) { t += 1; sy = 0; }
+    verify_commit(st, b, t, best_idx, enc_lens, B, blank, max_symbols, u_max, step, ids, frames, n_ids);
+}
+
+// One WORKGROUP per row: wave w owns the columns of chunks [w * NCHW, (w + 1) * NCHW) — V <= 4 * NCHW * 64 — with its part of the
+// approximate logits in registers (one pass over memory, every load independent: the one-wave scan of the Zipformer family's
+// 10 720 columns was 168 dependent load round trips, 86 us per step), compacts and evaluates its own candidates, and the four
+// (value, index) pairs meet in LDS.  The argmax with the lowest index on ties does not depend on how the candidates are grouped.
+template <int NCHW>
+__global__ __launch_bounds__(256) void rnnt_verify_wide_kernel(DecodeState st, const float* __restrict__ f,
+                                                               const int32_t* __restrict__ enc_lens, int B, int Tp, int J, int V,
+                                                               int Vpad, const float* __restrict__ Wrm /* [V][J] */,
+                                                               const float* __restrict__ bo, const float* __restrict__ wmax, int blank,
+                                                               int max_symbols, int u_max, int step, int32_t* __restrict__ ids,
+                                                               int32_t* __restrict__ frames, int32_t* __restrict__ n_ids) {
+    extern __shared__ __attribute__((aligned(16))) char ver_smem[];          // [J] float a | [4][NCHW * 64] candidates | [4] max, [4] best, [4] index
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x;
+    const int n_alive = st.counters[2 + (step & 1)];
+    if (slot >= n_alive) return;                                   // workgroup-uniform
+    const int b = st.alive[(size_t)(step & 1) * B + slot];
+    const float* z = st.zapprox + (size_t)slot * Vpad;
+    float zr[NCHW];
+#pragma unroll
+    for (int c = 0; c < NCHW; ++c) {
+        const int col = (wave * NCHW + c) * 64 + lane;
+        zr[c] = col < V ? z[col] : -INFINITY;
     }
-    st.tcur[b] = t; st.sym[b] = sy;
-    if (t < enc_lens[b]) {
-        const int pos = atomicAdd(&st.counters[2 + ((step + 1) & 1)], 1);
-        st.alive[(size_t)((step + 1) & 1) * B + pos] = b;
-        if (emitted) { const int pa = atomicAdd(&st.counters[0], 1); st.act[pa] = b; }
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCHW; ++c) m = fmaxf(m, zr[c]);
+    m = wave_max(m);
+    float* a_s = reinterpret_cast<float*>(ver_smem);
+    int* cand_s = reinterpret_cast<int*>(ver_smem + (size_t)J * 4) + wave * (NCHW * 64);
+    float* red = reinterpret_cast<float*>(ver_smem + (size_t)J * 4 + (size_t)4 * NCHW * 64 * 4);
+    const int t = st.tcur[b];
+    const int tc = t < Tp ? t : Tp - 1;
+    verify_act_row(st, f + ((size_t)b * Tp + tc) * J, st.g + (size_t)b * J, a_s, J, threadIdx.x, 256);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float thr = m - 0.01953125f * wmax[0] * st.anorm[slot];
+    int n_cand = 0;
+#pragma unroll
+    for (int c = 0; c < NCHW; ++c) {
+        const bool is = zr[c] >= thr;
+        const unsigned long long mask = __ballot(is);
+        if (is) cand_s[n_cand + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (wave * NCHW + c) * 64 + lane;
+        n_cand += __builtin_popcountll(mask);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float best = -INFINITY;
+    int best_idx = 0x7fffffff;
+    verify_evaluate(cand_s, n_cand, a_s, Wrm, bo, J, lane, best, best_idx);
+    if (lane == 0) { red[4 + wave] = best; reinterpret_cast<int*>(red)[8 + wave] = best_idx; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float v = red[4 + w];
+        const int i = reinterpret_cast<int*>(red)[8 + w];
+        if (v > best || (v == best && i < best_idx)) { best = v; best_idx = i; }
+    }
+    verify_commit(st, b, t, best_idx, enc_lens, B, blank, max_symbols, u_max, step, ids, frames, n_ids);
 }
 
 }  // namespace
@@ -1055,6 +1130,7 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
     // and 40 ms for the first capture of a geometry — profiles/r03x_decode_graph_b1_ab.txt: not kept.)
     const int CHUNK = 16;
     const bool lookahead = getenv("RS_DECODE_NO_LOOKAHEAD") == nullptr;   // A/B and test hook
+    const bool verify_wide = getenv("RS_VERIFY_WIDE") && atoi(getenv("RS_VERIFY_WIDE")) != 0;         // A/B and test hook: a workgroup per row for V <= 3072 too
     int32_t host_counters[4] = {0, 0, 0, 0};
     int steps = 0, alive_bound = B;
     bool finished = false;
@@ -1068,16 +1144,19 @@ int rs_rnnt_greedy_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_
                                    tp_max, J, steps);
                 hipLaunchKernelGGL(rnnt_screen_kernel, dim3((Vpad + 63) / 64, rts), dim3(256), 32 * (J * 2 + 16), s, st, joint_enc, B,
                                    tp_max, J, Vpad, ctx->jout_w16, ctx->jout_bpad, steps);
-                const dim3 vg((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1);
-                if (V <= 64 * 8)
-                    hipLaunchKernelGGL(rnnt_verify_kernel<8>, vg, dim3(256), 4 * J * 4 + 4 * 8 * 64 * 4, s, st, joint_enc, enc_lens, B, tp_max, J, V, Vpad,
-                                       ctx->jout_wrm, ctx->jout_b, ctx->jout_wmax, d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
+                const dim3 vg((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1), vgw(rows > 0 ? rows : 1);
+#define RS_VERIFY_ARGS st, joint_enc, enc_lens, B, tp_max, J, V, Vpad, ctx->jout_wrm, ctx->jout_b, ctx->jout_wmax, d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids
+                if (V > 64 * 48 && V <= 4 * 64 * 48)
+                    hipLaunchKernelGGL(rnnt_verify_wide_kernel<48>, vgw, dim3(256), J * 4 + 4 * 48 * 64 * 4 + 64, s, RS_VERIFY_ARGS);
                 else if (V > 64 * 48)
-                    hipLaunchKernelGGL(rnnt_verify_kernel<0>, vg, dim3(256), 4 * J * 4 + 4 * VER_CAP * 4, s, st, joint_enc, enc_lens, B, tp_max, J, V, Vpad,
-                                       ctx->jout_wrm, ctx->jout_b, ctx->jout_wmax, d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
+                    hipLaunchKernelGGL(rnnt_verify_kernel<0>, vg, dim3(256), 4 * J * 4 + 4 * VER_CAP * 4, s, RS_VERIFY_ARGS);
+                else if (verify_wide)
+                    hipLaunchKernelGGL(rnnt_verify_wide_kernel<12>, vgw, dim3(256), J * 4 + 4 * 12 * 64 * 4 + 64, s, RS_VERIFY_ARGS);
+                else if (V <= 64 * 8)
+                    hipLaunchKernelGGL(rnnt_verify_kernel<8>, vg, dim3(256), 4 * J * 4 + 4 * 8 * 64 * 4, s, RS_VERIFY_ARGS);
                 else
-                    hipLaunchKernelGGL(rnnt_verify_kernel<48>, vg, dim3(256), 4 * J * 4 + 4 * 48 * 64 * 4, s, st, joint_enc, enc_lens, B, tp_max, J, V, Vpad,
-                                       ctx->jout_wrm, ctx->jout_b, ctx->jout_wmax, d.blank_id, d.max_symbols, u_max, steps, ids, frames, n_ids);
+                    hipLaunchKernelGGL(rnnt_verify_kernel<48>, vg, dim3(256), 4 * J * 4 + 4 * 48 * 64 * 4, s, RS_VERIFY_ARGS);
+#undef RS_VERIFY_ARGS
             } else {
                 // both kernels walk the compacted alive list: only the row tiles / slots the bound covers are launched
                 // (next to the encoder every workgroup, even one that exits at once, has to wait for a free CU)
