@@ -86,7 +86,7 @@ def encoder_embed(cfg, sd, feats: torch.Tensor, recipe="fp32", taps=None) -> tor
     rb = lambda t: _rb(t, recipe)        # noqa: E731
     x = feats[None, None]                # (1, 1, T, F)
     x = rb(swoosh_r(F.conv2d(x, sd[E + "conv.0.weight"], sd[E + "conv.0.bias"], padding=(0, 1))))
-    x = rb(swoosh_r(F.conv2d(x, sd[E + "conv.4.weight"], sd[E + "conv.4.bias"], stride=2)))
+    x = rb(swoosh_r(F.conv2d(x, rb(sd[E + "conv.4.weight"]), sd[E + "conv.4.bias"], stride=2)))
     x = swoosh_r(F.conv2d(x, rb(sd[E + "conv.7.weight"]), sd[E + "conv.7.bias"], stride=(1, 2)))
     if taps is not None:
         taps["embed_conv"] = x[0].permute(1, 2, 0).clone()          # (T3, F, C)

@@ -10,8 +10,11 @@
 //   attention weights             k2_attn_weights_kernel: scores = q.k (one MFMA per 16 x 16 tile: head_dim 32 IS the MFMA's K)
 //                                 + p.pos[j - i] (4-wide position head on the VALU from an LDS-staged table), two-pass softmax,
 //                                 weights stored once as bf16 [B][H][T][T] and shared by the three consumers of a layer
-//   weights x values              k2_pv_kernel: MFMA over 32-key chunks, V^T staged in LDS; the non-linear attention's
-//                                 tanh gate and output gate are fused into its staging / epilogue
+//   weights x values              k2_vt_kernel (V^T once per branch; the non-linear attention's tanh gate applied there) +
+//                                 k2_pv_kernel: MFMA over 32-key chunks, V^T staged in LDS, 128 queries per block, the
+//                                 non-linear attention's output gate in the epilogue
+//   encoder_embed                 conv0 on the VALU, conv1 on MFMA straight from global memory (k2_conv1_mfma_kernel), conv2 as
+//                                 patches + GEMM, ConvNeXt depthwise 7 x 7 with a ring of seven output frames
 //   everything else               HBM-bound element-wise kernels (casts, BiasNorm, bypass, down/up-sampling, depthwise convs)
 //
 // Batch semantics: the reference runs one utterance per call, so every kernel masks by the utterance's own length (keys past it
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void k2_conv1_kernel(const uint16_t* __restric
         const int r = i / (F * C1), q = i - r * (F * C1);
         rows[i] = bf16_to_f32(a0[((size_t)b * T1 + 2 * t2 + r) * F * C1 + q]);
     }
-    for (int i = threadIdx.x; i < 9 * C1 * C2; i += 256) ws[i] = w[i];
+    for (int i = threadIdx.x; i < 9 * C1 * C2; i += 256) ws[i] = round_bf16(w[i]);     // (bf16 weights like every GEMM: the MFMA form's operand)
     __syncthreads();
     uint16_t* orow = out + ((size_t)b * T2 + t2) * F2 * C2;
     for (int i = threadIdx.x; i < F2 * C2; i += 256) {
@@ -100,6 +103,75 @@ __global__ __launch_bounds__(256) void k2_conv1_kernel(const uint16_t* __restric
                 for (int c1 = 0; c1 < C1; ++c1) acc = fmaf(wr[c1 * C2], xr[c1], acc);
             }
         orow[i] = f32_to_bf16(swoosh_r_f(acc));
+    }
+}
+
+// conv1 on the matrix cores (second form; the first keeps rows and weights in LDS as f32 and pays two LDS reads per FMA: 1.9 ms
+// per batch of 256).  Per output frame t2 the convolution is a [C2 = 32] x [K = 72 -> 96] x [F2 = 39 -> 48 pixels] product; with
+// channels-last input the K index (kh, kw, c1) makes every 8-element piece of a pixel's patch — (kh, kw, c1 = 0 .. 7) — 16
+// contiguous bytes of the input row 2 t2 + kh at column 2 f2 + kw: the second MFMA operand is read straight from global memory,
+// no patch matrix, no LDS.  The weights (first operand: rows = output channels) are rounded to bf16 once per wave and stay in
+// registers; a wave walks CONV1_TT consecutive frames.  D[c2 = 4 kq + e][pixel = lane & 15]: a lane stores four consecutive
+// channels of one pixel.  Requires C1 == 8, C2 == 32, F2 <= 48 (the launcher checks; anything else runs the first form).
+constexpr int CONV1_TT = 4;
+// grid (ceil(T2 / (4 * CONV1_TT)), B), block 256
+__global__ __launch_bounds__(256) void k2_conv1_mfma_kernel(const uint16_t* __restrict__ a0, int T1, int F, int T2, int F2,
+                                                            const float* __restrict__ w /* [3][3][8][32] */, const float* __restrict__ bias,
+                                                            uint16_t* __restrict__ out) {
+    constexpr int C1 = 8, C2 = 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const int li = lane & 15, kq = lane >> 4;
+    // weights: fragment (nt, ks) = W[c2 = 16 nt + li][k = 32 ks + 8 kq + e], k = (kh * 3 + kw) * 8 + c1; zeros for k >= 72
+    bf16x8_t wf[2][3];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            u16x8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 32 * ks + 8 * kq + e;
+                v[e] = k < 72 ? f32_to_bf16(w[(size_t)k * C2 + 16 * nt + li]) : (unsigned short)0;
+            }
+            wf[nt][ks] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    float bs[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[nt][e] = bias[16 * nt + 4 * kq + e];
+    const int t_first = (blockIdx.x * 4 + wave) * CONV1_TT;
+    for (int tt = 0; tt < CONV1_TT; ++tt) {
+        const int t2 = t_first + tt;
+        if (t2 >= T2) return;
+        // patches: fragment (mt, ks) of pixel f2 = 16 mt + li: piece g = 4 ks + kq -> (kh = g / 3, kw = g % 3)
+        bf16x8_t pf[3][3];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const int f2 = 16 * mt + li, g = 4 * ks + kq;
+                u16x8_t v = (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+                if (f2 < F2 && g < 9) {
+                    const int kh = g / 3, kw = g - 3 * kh;
+                    v = *reinterpret_cast<const u16x8_t*>(a0 + (((size_t)b * T1 + 2 * t2 + kh) * F + 2 * f2 + kw) * C1);
+                }
+                pf[mt][ks] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+            const int f2 = 16 * mt + li;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], pf[mt][ks], acc, 0, 0, 0);
+                if (f2 < F2)
+                    *reinterpret_cast<u16x4_t*>(out + (((size_t)b * T2 + t2) * F2 + f2) * C2 + 16 * nt + 4 * kq) =
+                        pack_bf16x4(swoosh_r_f(acc[0] + bs[nt][0]), swoosh_r_f(acc[1] + bs[nt][1]), swoosh_r_f(acc[2] + bs[nt][2]),
+                                    swoosh_r_f(acc[3] + bs[nt][3]));
+            }
+        }
     }
 }
 
@@ -128,52 +200,80 @@ __global__ __launch_bounds__(256) void k2_im2col_kernel(const uint16_t* __restri
 
 // ConvNeXt depthwise 7 x 7 (padding 3) over (time, frequency), channels last.  a2 f32 [B][T3][F3][C] -> bf16 same shape.
 // Frames at or past the utterance's own length are zeros (the reference's single-utterance call ends there).
-// A workgroup makes CNX_TT consecutive frames of one utterance; a thread owns (f, c) pairs and walks time: every input row is
-// loaded ONCE per thread (7 frequency neighbours, served by L1 / L2 — the block's threads touch the same rows) and scattered into
-// the seven outputs it contributes to, which live in a ring of seven accumulators (slot = output frame mod 7, resolved at
-// compile time by unrolling rows in groups of seven); the 49 taps of the channel sit in registers.  The first version fetched
-// all 49 inputs per output: 11 ms per batch of 256 (profiles/r05b_k2_kernel_stats.txt); this one reads 7.
+// A workgroup makes CNX_TT consecutive frames of one utterance; a thread owns one channel and FH consecutive frequencies and
+// walks time: every input row is loaded once (FH + 6 values for 49 FH multiply-adds; the next row's loads fly under this row's
+// arithmetic) and scattered into the seven output frames it contributes to, which live in a ring of seven accumulator sets
+// (slot = output frame mod 7, resolved at compile time by unrolling rows in groups of seven); the 49 taps of the channel sit in
+// registers.  History: all 49 inputs fetched per output, 11 ms per batch of 256 (profiles/r05b_k2_kernel_stats.txt); the ring
+// with one frequency per thread (7 loads per 49 multiply-adds), 2.1 ms; this form 1.1 ms less (profiles/r05x_k2_forms_ab.txt).
+// Order of the sums: rows ascending, taps left to right, bias last.
 constexpr int CNX_TT = 29;          // frames per workgroup: CNX_TT + 6 input rows = 5 groups of 7
 // grid (ceil(T3 / CNX_TT), B), block 256
-__global__ __launch_bounds__(256) void k2_cnx_dw_kernel(const float* __restrict__ a2, const int32_t* __restrict__ lens3, int T3, int F3, int C,
-                                                        const float* __restrict__ w /* [49][C] */, const float* __restrict__ bias,
-                                                        uint16_t* __restrict__ out) {
+template <int FH>
+__global__ __launch_bounds__(256, 2) void k2_cnx_dw_kernel(const float* __restrict__ a2, const int32_t* __restrict__ lens3, int T3, int F3, int C,
+                                                         const float* __restrict__ w /* [49][C] */, const float* __restrict__ bias,
+                                                         uint16_t* __restrict__ out) {
     const int t0 = blockIdx.x * CNX_TT, b = blockIdx.y;
     int len = lens3[b];
     len = len < T3 ? len : T3;
     const float* xin = a2 + (size_t)b * T3 * F3 * C;
     uint16_t* xo = out + (size_t)b * T3 * F3 * C;
-    for (int item = threadIdx.x; item < F3 * C; item += 256) {
-        const int f = item / C, c = item - f * C;
+    const int nfh = (F3 + FH - 1) / FH;
+    for (int item = threadIdx.x; item < nfh * C; item += 256) {
+        const int fh = item / C, c = item - fh * C, f_lo = fh * FH;
         float wt[49];
 #pragma unroll
         for (int k = 0; k < 49; ++k) wt[k] = w[k * C + c];
         const float bb = bias[c];
-        float acc[7];
+        float acc[7][FH];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc[k] = 0.0f;
-        // rows r = t0 - 3 + 7 g + j; output frame o lives in ring slot (o - (t0 - 3)) mod 7
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int fo = 0; fo < FH; ++fo) acc[k][fo] = 0.0f;
+        // branch-free loads: clamped addresses (the row base is wave-uniform, the FH + 6 offsets are per-thread constants) and the
+        // out-of-range inputs zeroed by a bit mask
+        int offq[FH + 6];
+        unsigned okm[FH + 6];
+#pragma unroll
+        for (int q = 0; q < FH + 6; ++q) {
+            const int ff = f_lo + q - 3;
+            okm[q] = (ff >= 0 && ff < F3) ? 0xffffffffu : 0u;
+            offq[q] = (ff < 0 ? 0 : ff >= F3 ? F3 - 1 : ff) * C + c;
+        }
+        auto load_row = [&](int r, float (&x)[FH + 6]) {
+            const unsigned rowmask = (r >= 0 && r < len) ? 0xffffffffu : 0u;
+            const int rc = max(0, min(r, T3 - 1));
+            const float* row = xin + (size_t)rc * F3 * C;
+#pragma unroll
+            for (int q = 0; q < FH + 6; ++q) x[q] = __uint_as_float(__float_as_uint(row[offq[q]]) & okm[q] & rowmask);
+        };
+        float x[FH + 6];
+        load_row(t0 - 3, x);
         for (int g = 0; g < (CNX_TT + 6) / 7; ++g) {
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const int r = t0 - 3 + 7 * g + j;
-                float x[7];
-                const bool row_ok = r >= 0 && r < len;
-#pragma unroll
-                for (int kw = 0; kw < 7; ++kw) {
-                    const int ff = f + kw - 3;
-                    x[kw] = (row_ok && ff >= 0 && ff < F3) ? xin[((size_t)r * F3 + ff) * C + c] : 0.0f;
-                }
-                // row r is tap kh of output frame r + 3 - kh, whose slot is (j + 3 - kh) mod 7
+                float xn[FH + 6];
+                load_row(r + 1, xn);                     // the next row's loads fly under this row's multiply-adds
 #pragma unroll
                 for (int kh = 0; kh < 7; ++kh) {
                     const int slot = (j + 3 - kh + 7) % 7;
 #pragma unroll
-                    for (int kw = 0; kw < 7; ++kw) acc[slot] = fmaf(wt[kh * 7 + kw], x[kw], acc[slot]);
+                    for (int fo = 0; fo < FH; ++fo)
+#pragma unroll
+                        for (int kw = 0; kw < 7; ++kw) acc[slot][fo] = fmaf(wt[kh * 7 + kw], x[fo + kw], acc[slot][fo]);
                 }
-                const int done = r - 3, dslot = (j + 4) % 7;          // frame r - 3 has now received rows r - 6 .. r (this row was its tap kh = 6)
-                if (done >= t0 && done < t0 + CNX_TT && done < T3) xo[((size_t)done * F3 + f) * C + c] = f32_to_bf16(acc[dslot] + bb);
-                acc[dslot] = 0.0f;
+                const int done = r - 3, dslot = (j + 4) % 7;
+                if (done >= t0 && done < t0 + CNX_TT && done < T3) {
+#pragma unroll
+                    for (int fo = 0; fo < FH; ++fo)
+                        if (f_lo + fo < F3) xo[((size_t)done * F3 + f_lo + fo) * C + c] = f32_to_bf16(acc[dslot][fo] + bb);
+                }
+#pragma unroll
+                for (int fo = 0; fo < FH; ++fo) acc[dslot][fo] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < FH + 6; ++q) x[q] = xn[q];
+                __builtin_amdgcn_sched_barrier(0);       // keeps the scheduler from hoisting all seven rows' loads (256 VGPRs + spills)
             }
         }
     }
@@ -391,74 +491,111 @@ __global__ __launch_bounds__(256) void k2_attn_weights_kernel(const uint16_t* __
 // queries; V^T of the block's channels is staged in LDS in chunks of KB keys ([channels][KB + 8] bf16), a step is one MFMA per
 // 16-channel tile over 32 keys: first operand V^T rows (channels), second the weight rows (queries), so a lane holds query
 // (lane & 15), channels 4 * (lane >> 4) .. + 3 of the tile.
+// ---- weights x values: V^T is built ONCE per branch by k2_vt_kernel, the product kernel stages it with 16-byte loads and covers
+// 128 queries per block.  (The first form transposed — and, for the non-linear attention, re-evaluated tanh — inside every
+// 64-query block: 128 two-byte loads per thread and 256 keys against 32 MFMAs; same values and accumulation order, 1.3 ms per
+// batch slower: profiles/r05x_k2_forms_ab.txt.)
+//   vT[b][c][key], pitch Tp, C rows per utterance (a multiple of 64): MODE 0  c = 16 h + channel (12 real, 4 zero),
+//   MODE 1  c = channel of x * tanh(s); zeros past the utterance's length and past the real channels.
+template <int MODE>
+__global__ __launch_bounds__(256) void k2_vt_kernel(const uint16_t* __restrict__ u, int ldu, int hid, const int32_t* __restrict__ lens, int T, int Tp,
+                                                    int C, uint16_t* __restrict__ vT) {
+    constexpr int TP = 72;                               // pitch of the tile in LDS: 144 bytes, rows stay 16-byte aligned
+    __shared__ __attribute__((aligned(16))) uint16_t tile[64 * TP];
+    const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    int len = lens[b];
+    len = len < T ? len : T;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int c = idx & 63, key = idx >> 6;
+        unsigned short val = 0;
+        if (k0 + key < len) {
+            const uint16_t* ur = u + ((size_t)b * T + k0 + key) * ldu;
+            if constexpr (MODE == 1) {
+                if (c0 + c < hid) {
+                    const float xv = bf16_to_f32(ur[hid + c0 + c]), sv = bf16_to_f32(ur[c0 + c]);
+                    const float th = 1.0f - 2.0f / (__expf(2.0f * sv) + 1.0f);
+                    val = f32_to_bf16(xv * th);
+                }
+            } else {
+                const int h = (c0 + c) >> 4, cc = (c0 + c) & 15;
+                if (cc < K2_VD && h * K2_VD + cc < hid) val = ur[h * K2_VD + cc];        // (hid = H * 12 here)
+            }
+        }
+        tile[c * TP + key] = val;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 8; idx += 256) {
+        const int c = idx >> 3, piece = idx & 7;
+        if (k0 + piece * 8 < Tp)
+            *reinterpret_cast<u16x8_t*>(vT + ((size_t)b * C + c0 + c) * Tp + k0 + piece * 8) = *reinterpret_cast<const u16x8_t*>(tile + c * TP + piece * 8);
+    }
+}
+
 template <int CT, int MODE>
-__global__ __launch_bounds__(256) void k2_pv_kernel(const uint16_t* __restrict__ W, int H, int Tp, const uint16_t* __restrict__ u, int ldu, int hid,
-                                                    const int32_t* __restrict__ lens, int T, uint16_t* __restrict__ out, int ldo) {
-    constexpr int KB = 256, PITCH = KB + 8;
+__global__ __launch_bounds__(256) void k2_pv_kernel(const uint16_t* __restrict__ W, int H, int Tp, const uint16_t* __restrict__ vT, int C,
+                                                     const uint16_t* __restrict__ u, int ldu, int hid, const int32_t* __restrict__ lens, int T,
+                                                     uint16_t* __restrict__ out, int ldo) {
+    constexpr int KB = 256, PITCH = KB + 8, QT = 2;
     __shared__ __attribute__((aligned(16))) uint16_t vt[CT * 16 * PITCH];
-    const int i0 = blockIdx.x * 64, ctile = blockIdx.y;
+    const int i0 = blockIdx.x * (64 * QT), ctile = blockIdx.y;
     const int b = MODE == 1 ? blockIdx.z : blockIdx.z / H, h = MODE == 1 ? 0 : blockIdx.z % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int len = lens[b];
     len = len < T ? len : T;
-    const int nch = MODE == 1 ? hid : K2_VD;              // real channels of this (head, tile) space
-    const int cbase = MODE == 1 ? ctile * CT * 16 : 0;    // first channel of the block
-    const int col0 = MODE == 1 ? hid + cbase : h * K2_VD; // column of channel cbase in u
-    const int qi = i0 + wave * 16 + (lane & 15), kq = lane >> 4;
-    const uint16_t* wrow = W + (((size_t)b * H + h) * T + (qi < T ? qi : T - 1)) * Tp;
-    f32x4_t acc[CT];
+    const int nch = MODE == 1 ? hid : K2_VD;
+    const int cbase = MODE == 1 ? ctile * CT * 16 : 0;
+    const uint16_t* vbase = vT + ((size_t)b * C + (MODE == 1 ? cbase : h * 16)) * Tp;
+    const int kq = lane >> 4;
+    int qi[QT];
+    const uint16_t* wrow[QT];
+    f32x4_t acc[QT][CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) acc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < QT; ++q) {
+        qi[q] = i0 + (wave * QT + q) * 16 + (lane & 15);
+        wrow[q] = W + (((size_t)b * H + h) * T + (qi[q] < T ? qi[q] : T - 1)) * Tp;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[q][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
     for (int k0 = 0; k0 < len; k0 += KB) {
         __syncthreads();
-        // stage V^T: element (channel c, key k0 + kk); keys past the length and channels past nch are zeros
         for (int idx = threadIdx.x; idx < CT * 16 * (KB / 8); idx += 256) {
-            const int c = idx % (CT * 16), kg = idx / (CT * 16);
-            u16x8_t v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int key = k0 + kg * 8 + e;
-                unsigned short val = 0;
-                if (key < len && cbase + c < nch) {
-                    const uint16_t* ur = u + ((size_t)b * T + key) * ldu;
-                    if constexpr (MODE == 1) {
-                        const float xv = bf16_to_f32(ur[col0 + c]), sv = bf16_to_f32(ur[cbase + c]);
-                        const float th = 1.0f - 2.0f / (__expf(2.0f * sv) + 1.0f);
-                        val = f32_to_bf16(xv * th);
-                    } else {
-                        val = ur[col0 + c];
-                    }
-                }
-                v[e] = val;
-            }
-            *reinterpret_cast<u16x8_t*>(vt + c * PITCH + kg * 8) = v;
+            const int c = idx / (KB / 8), piece = idx % (KB / 8);
+            u16x8_t v = (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+            if (k0 + piece * 8 < Tp) v = *reinterpret_cast<const u16x8_t*>(vbase + (size_t)c * Tp + k0 + piece * 8);
+            *reinterpret_cast<u16x8_t*>(vt + c * PITCH + piece * 8) = v;
         }
         __syncthreads();
         const int kend = len - k0 < KB ? len - k0 : KB;
         for (int kk = 0; kk < kend; kk += 32) {
-            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wrow + k0 + kk + 8 * kq);
+            bf16x8_t vf[CT];
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vt + (c * 16 + (lane & 15)) * PITCH + kk + 8 * kq);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, wf, acc[c], 0, 0, 0);
+            for (int c = 0; c < CT; ++c) vf[c] = *reinterpret_cast<const bf16x8_t*>(vt + (c * 16 + (lane & 15)) * PITCH + kk + 8 * kq);
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wrow[q] + k0 + kk + 8 * kq);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[c], wf, acc[q][c], 0, 0, 0);
             }
         }
     }
-    if (qi >= T) return;
-    const bool q_ok = qi < len;
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int ch = cbase + c * 16 + 4 * kq;          // first of this lane's four channels
-        if (ch >= nch) continue;
-        float v[4] = {acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
-        if constexpr (MODE == 1) {
-            const u16x4_t y = *reinterpret_cast<const u16x4_t*>(u + ((size_t)b * T + qi) * ldu + 2 * hid + ch);
+    for (int q = 0; q < QT; ++q) {
+        if (qi[q] >= T) continue;
+        const bool q_ok = qi[q] < len;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= bf16_to_f32(y[e]);
+        for (int c = 0; c < CT; ++c) {
+            const int ch = cbase + c * 16 + 4 * kq;          // first of this lane's four channels
+            if (ch >= nch) continue;
+            float v[4] = {acc[q][c][0], acc[q][c][1], acc[q][c][2], acc[q][c][3]};
+            if constexpr (MODE == 1) {
+                const u16x4_t y = *reinterpret_cast<const u16x4_t*>(u + ((size_t)b * T + qi[q]) * ldu + 2 * hid + ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= bf16_to_f32(y[e]);
+            }
+            if (!q_ok) v[0] = v[1] = v[2] = v[3] = 0.0f;
+            const int oc = MODE == 1 ? ch : h * K2_VD + ch;
+            *reinterpret_cast<u16x4_t*>(out + ((size_t)b * T + qi[q]) * ldo + oc) = pack_bf16x4(v[0], v[1], v[2], v[3]);
         }
-        if (!q_ok) v[0] = v[1] = v[2] = v[3] = 0.0f;
-        const int oc = MODE == 1 ? ch : h * K2_VD + ch;
-        *reinterpret_cast<u16x4_t*>(out + ((size_t)b * T + qi) * ldo + oc) = pack_bf16x4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -477,7 +614,7 @@ __global__ void k2_lens_kernel(const int32_t* __restrict__ n_frames, int B, int 
 struct K2Plan {
     int T, T1, T2, T3, To, F, F2, F3, Kp;
     int Ts[8], Tp[8];
-    size_t off_lens, off_a0, off_a1, off_col, off_a2, off_dwo, off_h, off_stackout[8], off_x, off_x0, off_src, off_xb, off_qkp, off_w, off_big, off_av,
+    size_t off_lens, off_a0, off_a1, off_col, off_a2, off_dwo, off_h, off_stackout[8], off_x, off_x0, off_src, off_xb, off_qkp, off_w, off_big, off_av, off_vt,
         off_encb, total;
 };
 
@@ -517,7 +654,7 @@ K2Plan k2_plan(const rs_ctx* ctx, int B, int t_max) {
         w_max = wb > w_max ? wb : w_max;
         (void)big_max; (void)av_max;
     }
-    size_t x_b = 0, qkp_b = 0, big_b = 0, av_b = 0;
+    size_t x_b = 0, qkp_b = 0, big_b = 0, av_b = 0, vt_b = 0;
     for (int s = 0; s < d.n_stacks; ++s) {
         const size_t rows = (size_t)B * p.Ts[s], dd = d.encoder_dim[s], H = d.num_heads[s];
         const size_t full = (size_t)B * T3 * dd * 4;
@@ -533,6 +670,10 @@ K2Plan k2_plan(const rs_ctx* ctx, int B, int t_max) {
         avw = (size_t)pad64((int)H * K2_VD) > avw ? (size_t)pad64((int)H * K2_VD) : avw;
         avw = dd > avw ? dd : avw;
         av_b = rows * avw * 2 > av_b ? rows * avw * 2 : av_b;
+        size_t vc = pad64(3 * (int)dd / 4);
+        vc = (size_t)pad64((int)H * 16) > vc ? (size_t)pad64((int)H * 16) : vc;
+        const size_t vb = (size_t)B * vc * p.Tp[s] * 2;
+        vt_b = vb > vt_b ? vb : vt_b;
     }
     p.off_x = take(x_b); p.off_x0 = take(x_b); p.off_src = take(x_b);
     p.off_xb = take(x_b / 2);
@@ -540,6 +681,7 @@ K2Plan k2_plan(const rs_ctx* ctx, int B, int t_max) {
     p.off_w = take(w_max);
     p.off_big = take(big_b);
     p.off_av = take(av_b);
+    p.off_vt = take(vt_b);
     p.off_encb = take((size_t)B * (p.To > 0 ? p.To : 1) * k.out_dim * 2);
     p.total = o + 256;
     return p;
@@ -728,6 +870,7 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
     uint16_t* W = reinterpret_cast<uint16_t*>(ws + pl.off_w);
     uint16_t* big = reinterpret_cast<uint16_t*>(ws + pl.off_big);
     uint16_t* av = reinterpret_cast<uint16_t*>(ws + pl.off_av);
+    uint16_t* vT = reinterpret_cast<uint16_t*>(ws + pl.off_vt);
     uint16_t* encb = reinterpret_cast<uint16_t*>(ws + pl.off_encb);
     const int c1 = d.embed_c1, c2 = d.embed_c2, c3 = d.embed_c3, T3 = pl.T3, F3 = pl.F3;
     int rc;
@@ -750,7 +893,11 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
     // ---- encoder_embed ------------------------------------------------------------------------------------------------
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, 0.0);
     hipLaunchKernelGGL(k2_conv0_kernel, dim3(pl.T1, B), dim3(256), 0, s, feats, t_max, pl.F, c1, k.conv0_w, k.conv0_b, a0);
-    {
+    static const bool conv1_first_form = getenv("RS_K2_CONV1_OLD") != nullptr;   // A/B and test hook (the form other channel counts run)
+    if (c1 == 8 && c2 == 32 && pl.F2 <= 48 && !conv1_first_form) {
+        hipLaunchKernelGGL(k2_conv1_mfma_kernel, dim3((pl.T2 + 4 * CONV1_TT - 1) / (4 * CONV1_TT), B), dim3(256), 0, s, a0, pl.T1, pl.F, pl.T2, pl.F2, k.conv1_w,
+                           k.conv1_b, a1);
+    } else {
         const size_t lds = (size_t)(3 * pl.F * c1 + 9 * c1 * c2) * 4;
         if (lds > 64 * 1024) RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)k2_conv1_kernel, (int)lds));
         hipLaunchKernelGGL(k2_conv1_kernel, dim3(pl.T2, B), dim3(256), lds, s, a0, pl.T1, pl.F, c1, pl.T2, pl.F2, c2, k.conv1_w, k.conv1_b, a1);
@@ -761,7 +908,7 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
     RS_CHECK_LAUNCH(ctx, "zipformer encoder_embed convs");
     RS_TRY(gemm(col, pl.Kp, k.conv2_w, pl.Kp, a2, c3, rows3, c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHR | RS_GEMM_OUT_F32, k.conv2_b, nullptr));
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, 0.0);
-    hipLaunchKernelGGL(k2_cnx_dw_kernel, dim3((T3 + CNX_TT - 1) / CNX_TT, B), dim3(256), 0, s, a2, lens3, T3, F3, c3, k.cnx_dw_w, k.cnx_dw_b, dwo);
+    hipLaunchKernelGGL(k2_cnx_dw_kernel<10>, dim3((T3 + CNX_TT - 1) / CNX_TT, B), dim3(256), 0, s, a2, lens3, T3, F3, c3, k.cnx_dw_w, k.cnx_dw_b, dwo);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
     RS_TRY(gemm(dwo, c3, k.cnx_pw1_w, c3, hbuf, 3 * c3, rows3, 3 * c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHL, k.cnx_pw1_b, nullptr));
     // (its bf16 copy lands in dwo, [B*T3][F3 * c3] in (f, c) order: the operand of `out`)
@@ -818,7 +965,9 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
                 // K extent to a multiple of 64 are zeroed before every use
                 if (vwp != vw && hipMemsetAsync(av, 0, (size_t)M * vwp * 2, s) != hipSuccess) return rs_fail(ctx, RS_EHIP, "memset failed");
                 rs_prof_begin(ctx, RS_PROF_ATTN, s, (double)B * H * Ts * (double)Ts * 2.0 * 16.0, (double)B * H * Ts * (double)Tp * 2.0);
-                hipLaunchKernelGGL((k2_pv_kernel<1, 0>), dim3((Ts + 63) / 64, 1, B * H), dim3(256), 0, s, W, H, Tp, big, vw, 0, lens, Ts, av, vwp);
+                const int C = pad64(H * 16);
+                hipLaunchKernelGGL((k2_vt_kernel<0>), dim3((Tp + 63) / 64, C / 64, B), dim3(256), 0, s, big, vw, vw, lens, Ts, Tp, C, vT);
+                hipLaunchKernelGGL((k2_pv_kernel<1, 0>), dim3((Ts + 127) / 128, 1, B * H), dim3(256), 0, s, W, H, Tp, vT, C, big, vw, 0, lens, Ts, av, vwp);
                 rs_prof_end(ctx, RS_PROF_ATTN, s);
                 return gemm(av, vwp, L.sa_out_w[a], vwp, xs, dd, M, dd, RES, L.sa_out_b[a], xs, xb);
             };
@@ -832,7 +981,8 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
             RS_TRY(gemm(xb, dd, L.na_in_w, dd, big, 3 * hid, M, 3 * hid, RS_GEMM_BIAS, L.na_in_b, nullptr));
             if (hidp != hid) RS_HIP(ctx, hipMemsetAsync(av, 0, (size_t)M * hidp * 2, s));
             rs_prof_begin(ctx, RS_PROF_ATTN, s, (double)B * Ts * (double)Ts * 2.0 * hid, (double)B * Ts * (double)Tp * 2.0);
-            hipLaunchKernelGGL((k2_pv_kernel<4, 1>), dim3((Ts + 63) / 64, (hid + 63) / 64, B), dim3(256), 0, s, W, H, Tp, big, 3 * hid, hid, lens, Ts, av, hidp);
+            hipLaunchKernelGGL((k2_vt_kernel<1>), dim3((Tp + 63) / 64, hidp / 64, B), dim3(256), 0, s, big, 3 * hid, hid, lens, Ts, Tp, hidp, vT);
+            hipLaunchKernelGGL((k2_pv_kernel<4, 1>), dim3((Ts + 127) / 128, (hid + 63) / 64, B), dim3(256), 0, s, W, H, Tp, vT, hidp, big, 3 * hid, hid, lens, Ts, av, hidp);
             rs_prof_end(ctx, RS_PROF_ATTN, s);
             RS_TRY(gemm(av, hidp, L.na_out_w, hidp, xs, dd, M, dd, RES, L.na_out_b, xs, xb));
             RS_TRY(self_attn(0));
