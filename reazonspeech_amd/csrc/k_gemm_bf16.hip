@@ -58,6 +58,11 @@ struct GemmParams {
     int ld2;
     int pairs;         // > 0: a workgroup runs two consecutive tiles of its XCD's run (xcd_split); 2: the LDS ring carries over; 0: one tile
     long long* trace;  // debug: per-tile timestamps (scripts/gemm_trace.py); nullptr in production
+    // CONVA instantiations (rs_gemm_args.conv_C > 0): byte strides of the patch rows in the channels-last input and the K-tile walk
+    int cv_T2, cv_F2;                       // m = (b * cv_T2 + t2) * cv_F2 + f2
+    unsigned cv_b_bytes, cv_t_bytes, cv_f_bytes;   // T1 * F1 * C * 2, 2 * F1 * C * 2, 2 * C * 2
+    unsigned cv_seg_bytes;                  // F1 * C * 2: from a kernel row of the patch to the next
+    int cv_tps, cv_inv;                     // K tiles per kernel row (3 * C / 64); ceil(65536 / cv_tps): k / cv_tps == (k * cv_inv) >> 16 (launcher checks)
 };
 
 // OUT_BF16S / OUT_F32S: the plain bf16 / f32 epilogues with icefall's Swoosh activations compiled in (the Zipformer family).
@@ -308,7 +313,7 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
 // tile (16 MFMAs each, the guide's 8-phase shape).  Per shape they are within +-4 % of this one either way — the loop is
 // paced by the LDS traffic of the 128 x 64 wave tile and the clock, not by its barrier structure — and on the whole
 // path both lose ~1 % (58.8 vs 59.5 ms / step).
-template <int BM, int OUT, bool MASK, int EPF, bool TRACE>
+template <int BM, int OUT, bool MASK, int EPF, bool TRACE, bool CONVA = false>
 __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     constexpr int BN = 256, WN = 4, NWAVES = 8;
     constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -372,7 +377,13 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
             const int row = (wave + NWAVES * j) * 8 + dr;
             int gr = m0 + row;
             gr = gr < p.M ? gr : p.M - 1;
-            o[j] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
+            if constexpr (CONVA) {                                // patch row of pixel (b, t2, f2) in the channels-last input
+                const int bt = gr / p.cv_F2, f2 = gr - bt * p.cv_F2;
+                const int b = bt / p.cv_T2, t2 = bt - b * p.cv_T2;
+                o[j] = (unsigned)b * p.cv_b_bytes + (unsigned)t2 * p.cv_t_bytes + (unsigned)f2 * p.cv_f_bytes + (unsigned)((dpc ^ swz64(row)) * 16);
+            } else {
+                o[j] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
+            }
         }
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
@@ -399,8 +410,13 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     // piece j of K tile k (k >= nk: K tile k - nk of the NEXT tile) into slot sl
     auto dma_a = [&](int j, int k, int dst) {                     // dst: byte offset of the part in LDS
         const bool nx = k >= nk;
-        glds16(nx ? offn[j] : off[j], reinterpret_cast<const char*>(p.A) + (size_t)(nx ? k - nk : k) * 128,
-               lds0 + dst + (wave + NWAVES * j) * 1024);
+        const int kt = nx ? k - nk : k;
+        size_t kbytes = (size_t)kt * 128;
+        if constexpr (CONVA) {                                    // K tile kt = kernel row sg of the patch, tile kt - sg * tps inside it
+            const int sg = (kt * p.cv_inv) >> 16;
+            kbytes = (size_t)sg * p.cv_seg_bytes + (size_t)(kt - sg * p.cv_tps) * 128;
+        }
+        glds16(nx ? offn[j] : off[j], reinterpret_cast<const char*>(p.A) + kbytes, lds0 + dst + (wave + NWAVES * j) * 1024);
     };
     auto dma_b = [&](int j, int k, int dst) {
         const bool nx = k >= nk;
@@ -613,6 +629,11 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
     const int out = (p.flags & RS_GEMM_RESIDUAL) ? (p.res_ln_stats ? OUT_RESLN : (p.out2 ? OUT_RES2 : OUT_RES))
                   : ((p.flags & RS_GEMM_OUT_F32) ? (swoosh ? OUT_F32S : OUT_F32) : ((p.flags & RS_GEMM_GLU) ? OUT_GLU : (swoosh ? OUT_BF16S : OUT_BF16)));
     const bool mask = p.flags & RS_GEMM_ROWMASK;
+    if (p.cv_tps > 0) {                                           // patches read in place (launcher: plain bf16 output + row mask)
+        if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, OUT_BF16, true, EPF, false, true>, LDS); rc != RS_OK) return rc;
+        hipLaunchKernelGGL((gemm_smf16_kernel<BM, OUT_BF16, true, EPF, false, true>), dim3(nwg), dim3(512), LDS, s, p);
+        return RS_OK;
+    }
 #define RS_SMF(O, MK, TR)                                                                                          \
     do {                                                                                                           \
         if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, MK, EPF, TR>, LDS); rc != RS_OK) return rc; \
@@ -716,6 +737,21 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     if ((a.flags & (RS_GEMM_SWOOSHL | RS_GEMM_SWOOSHR)) && (a.flags & RS_GEMM_RESIDUAL))
         return rs_fail(ctx, RS_EINVAL, "gemm: the Swoosh activations combine with plain bf16 / f32 output only");
     if ((size_t)a.N * a.ldw * 2 >= (1ull << 32)) return rs_fail(ctx, RS_EINVAL, "gemm: weight matrix beyond 4 GiB");
+    int cv_tps = 0, cv_inv = 0;
+    if (a.conv_C > 0) {
+        const int C = a.conv_C;
+        if (C % 64 || a.K != 9 * C || a.conv_T2 <= 0 || a.conv_F2 <= 0 || a.M % (a.conv_T2 * a.conv_F2) || 2 * (a.conv_T2 - 1) + 3 > a.conv_T1 ||
+            2 * (a.conv_F2 - 1) + 3 > a.conv_F1)
+            return rs_fail(ctx, RS_EINVAL, "gemm: convolution patches need C %% 64 == 0, K == 9 C and an input that covers the output (C %d K %d)", C, a.K);
+        if ((a.flags & ~(RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_SILU)) != RS_GEMM_ROWMASK)
+            return rs_fail(ctx, RS_EINVAL, "gemm: convolution patches combine with plain bf16 output and the row mask only");
+        if ((size_t)(a.M / (a.conv_T2 * a.conv_F2)) * a.conv_T1 * a.conv_F1 * C * 2 >= (1ull << 32) - 65536)
+            return rs_fail(ctx, RS_EINVAL, "gemm: convolution input beyond 4 GiB (run it in chunks of utterances)");
+        cv_tps = 3 * C / 64;
+        cv_inv = (65536 + cv_tps - 1) / cv_tps;
+        for (int k = 0; k < 2 * (a.K / 64); ++k)
+            if (((k * cv_inv) >> 16) != k / cv_tps) return rs_fail(ctx, RS_EINVAL, "gemm: K-tile reciprocal is not exact for C = %d", C);
+    }
     gemm_knobs_from_env();
     if (ctx->n_cus <= 0) {
         int n = 0;
@@ -725,9 +761,10 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
     const int bm = g_tile.load() > 0 ? g_tile.load() : pick_tile_height(a.M, a.N, a.K, ctx->n_cus, a.flags);
     if (bm != 256 && bm != 192 && bm != 128 && bm != 64) return rs_fail(ctx, RS_EINVAL, "gemm: RS_GEMM_TILE=%d (256, 192, 128 or 64)", bm);
     // the kernel addresses A and the output with 32-bit byte offsets: a taller problem runs as row chunks
-    const size_t out_row = (size_t)a.ldc * (f32 ? 4 : 2), a_row = (size_t)a.lda * 2;
+    const size_t out_row = (size_t)a.ldc * (f32 ? 4 : 2), a_row = a.conv_C > 0 ? 2 : (size_t)a.lda * 2;   // (patches: the input size was checked above)
     size_t max_rows = ((1ull << 31) - 65536) / out_row;
     if (((1ull << 32) - 65536) / a_row < max_rows) max_rows = ((1ull << 32) - 65536) / a_row;
+    if (a.conv_C > 0 && (size_t)a.M > max_rows / 768 * 768) return rs_fail(ctx, RS_EINVAL, "gemm: convolution output beyond 2 GiB (run it in chunks of utterances)");
     if (max_rows < 768) return rs_fail(ctx, RS_EINVAL, "gemm: row pitch too large (lda %d, ldc %d)", a.lda, a.ldc);
     max_rows = max_rows / 768 * 768;                              // whole tiles of every height
     const double flops = 2.0 * a.M * (double)a.N * a.K;
@@ -749,6 +786,14 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         p.out2 = a.out_bf16 ? a.out_bf16 + r0 * a.ld_bf16 : nullptr; p.ld2 = a.ld_bf16;
         p.tiles_m = p.tiles_n = 0; p.group_m = 1;
         p.trace = g_trace.load();
+        p.cv_tps = cv_tps; p.cv_inv = cv_inv; p.cv_T2 = a.conv_T2; p.cv_F2 = a.conv_F2;
+        if (cv_tps > 0) {
+            p.trace = nullptr;
+            p.cv_b_bytes = (unsigned)((size_t)a.conv_T1 * a.conv_F1 * a.conv_C * 2);
+            p.cv_t_bytes = (unsigned)((size_t)2 * a.conv_F1 * a.conv_C * 2);
+            p.cv_f_bytes = (unsigned)(2 * a.conv_C * 2);
+            p.cv_seg_bytes = (unsigned)((size_t)a.conv_F1 * a.conv_C * 2);
+        }
         rc = launch_rows(ctx, p, bm, s);
     }
     rs_prof_end(ctx, RS_PROF_GEMM, s);      // paired with rs_prof_begin on every path

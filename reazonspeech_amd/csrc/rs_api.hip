@@ -371,6 +371,7 @@ struct EncPlan {
     int T[5], F[5];  // per stage time / freq extents (index 0 = mel)
     size_t off_lens, off_sa, off_sb, off_x, off_hn, off_big, off_ctx, off_posp, off_stats, off_col, off_ctc, total;
     int chunk;       // Conv2dSubsampling: utterances per pass of conv0 / patch gather / dense-conv GEMM
+    size_t col_bytes = 0;   // > 0: the plan holds the gathered patch matrix ($RS_SUB_IM2COL)
 };
 
 EncPlan plan_encoder(const rs_ctx* ctx, int B, int t_max) {
@@ -387,16 +388,22 @@ EncPlan plan_encoder(const rs_ctx* ctx, int B, int t_max) {
     p.chunk = B;
     p.off_col = 0;
     if (d.sub_kind == 1) {
-        // sa = conv0 output of ONE chunk of utterances [chunk][T1][F1][C]; col = its 3x3 patches [chunk*T2*F2][9C];
-        // sb = the dense conv's output of the WHOLE batch [B][T2][F2][C].  The chunk keeps the patch matrix near 1 GiB.
+        // sa = conv0 output of ONE chunk of utterances [chunk][T1][F1][C]; sb = the dense conv's output of the WHOLE batch
+        // [B][T2][F2][C].  The GEMM reads the 3 x 3 patches in place (rs_gemm_args.conv_C): the chunk keeps sa within the
+        // kernel's 32-bit offsets (2 GiB here).  With $RS_SUB_IM2COL (A/B and test hook: the gathered patch matrix
+        // col [chunk * T2 * F2][9C], the first form — 16 GB written and read again per 256 x 10 s, 4.2 ms) the chunk keeps col
+        // near 1 GiB instead.
+        const bool gathered = getenv("RS_SUB_IM2COL") != nullptr;
         const size_t per_utt_col = (size_t)(p.T[2] > 0 ? p.T[2] : 1) * p.F[2] * 9 * C * 2;
-        size_t chunk = ((size_t)1 << 30) / per_utt_col;
+        const size_t per_utt_sa = (size_t)(p.T[1] > 0 ? p.T[1] : 1) * p.F[1] * C * 2;
+        size_t chunk = gathered ? ((size_t)1 << 30) / per_utt_col : ((size_t)1 << 31) / per_utt_sa;
         if (chunk < 1) chunk = 1;
         if (chunk > (size_t)B) chunk = (size_t)B;
-        while (chunk > 1 && chunk * (size_t)p.T[2] > 65535) --chunk;            // grid limit of the gather kernel
+        while (chunk > 1 && chunk * (size_t)(p.T[1] > 0 ? p.T[1] : 1) > 65535) --chunk;   // grid limit of the conv0 / gather kernels
         p.chunk = (int)chunk;
-        p.off_sa = o; o += rs_align(chunk * (size_t)(p.T[1] > 0 ? p.T[1] : 1) * p.F[1] * C * 2);
-        p.off_col = o; o += rs_align(chunk * per_utt_col);
+        p.off_sa = o; o += rs_align(chunk * per_utt_sa);
+        p.off_col = o; o += gathered ? rs_align(chunk * per_utt_col) : 0;
+        p.col_bytes = gathered ? chunk * per_utt_col : 0;
         p.off_sb = o; o += rs_align((size_t)B * (p.T[2] > 0 ? p.T[2] : 1) * p.F[2] * C * 2);
     } else {
         const size_t sub_elems = (size_t)B * p.T[2] * p.F[2] * C;  // stage-2 extent is the largest stored one
@@ -507,9 +514,12 @@ int rs_encoder_forward(rs_ctx* ctx, const float* feats, const int32_t* n_frames,
         for (int b0 = 0; b0 < B; b0 += pl.chunk) {
             const int bc = B - b0 < pl.chunk ? B - b0 : pl.chunk;
             RS_TRY(rs_launch_sub2d_conv0(ctx, feats, lens_stage, b0, bc, t_max, T1, F1, sa, s));
-            RS_TRY(rs_launch_im2col3x3s2(ctx, sa, bc, T1, F1, T2, F2, col, s));
+            const bool patches_in_place = pl.col_bytes == 0;                              // (plan_encoder: $RS_SUB_IM2COL)
+            if (!patches_in_place) RS_TRY(rs_launch_im2col3x3s2(ctx, sa, bc, T1, F1, T2, F2, col, s));
             rs_gemm_args g{};
-            g.A = col; g.lda = 9 * C; g.W = ctx->sub_conv1_w; g.ldw = 9 * C; g.out = sb + (size_t)b0 * T2 * F2 * C; g.ldc = C;
+            if (patches_in_place) { g.A = sa; g.conv_C = C; g.conv_T1 = T1; g.conv_F1 = F1; g.conv_T2 = T2; g.conv_F2 = F2; }
+            else g.A = col;
+            g.lda = 9 * C; g.W = ctx->sub_conv1_w; g.ldw = 9 * C; g.out = sb + (size_t)b0 * T2 * F2 * C; g.ldc = C;
             g.M = bc * T2 * F2; g.N = C; g.K = 9 * C;
             g.flags = RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_ROWMASK; g.bias = ctx->sub_conv1_b; g.alpha = 1.0f;
             g.mask_lens = lens_stage + B + b0; g.mask_rows_per_step = F2; g.mask_steps = T2;

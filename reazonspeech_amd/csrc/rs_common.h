@@ -198,6 +198,11 @@ struct rs_gemm_args {
     // residual GEMMs only: also store the result rounded to bf16 at out_bf16[m * ld_bf16 + n] (the A operand of the next GEMM:
     // the Zipformer family has no norm between a residual add and the next Linear, so the copy would otherwise be a pass of its own)
     uint16_t* out_bf16; int ld_bf16;
+    // conv_C > 0: A is not a matrix but the channels-last input [Bc][conv_T1][conv_F1][conv_C] of a 3 x 3, stride-2, un-padded
+    // convolution; row m = (b * conv_T2 + t2) * conv_F2 + f2 of the product is the patch of output pixel (t2, f2), K = 9 * conv_C
+    // ordered (kernel row, kernel column, channel) — the matrix im2col3x3s2 would write, read in place: a kernel row of a patch
+    // is 3 * conv_C contiguous elements of the input (lda is ignored; plain bf16 output with the row mask only)
+    int conv_C, conv_T1, conv_F1, conv_T2, conv_F2;
 };
 int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s);
 int rs_launch_layernorm(rs_ctx* ctx, const float* x, const float* g, const float* b, int M, int d, float eps,
