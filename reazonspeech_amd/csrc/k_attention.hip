@@ -21,6 +21,9 @@
 // half is the previous block's upper half.  The per-row skew  bd[key][query] = BD^T[key - query + 31][query]
 // goes through a per-wave LDS scratch (conflict-free both ways: the query is the fastest index);
 // the same scratch first stages the 32 position rows (coalesced 256-byte reads from L2).
+#include <cstdlib>
+#include <cstring>
+
 #include "rs_common.h"
 
 namespace {
@@ -73,11 +76,15 @@ __device__ __forceinline__ int vt_pos(int key) {
 // the K / V barrier instead of after it — bit-identical, 152.4 / 153.1 vs 151.1 / 152.4 us on one box
 // (profiles/r03w_attn_prologue_ab.txt): the microsecond moved under the loads comes back as a longer load phase.)
 // WINDOW: limited-context / global-token masks compiled in (full attention otherwise: no per-score branches)
-template <int HD, bool TRACE, bool WINDOW>
+// KBC: key blocks staged per barrier (0: the geometry's default).  The small-chunk instantiations of head_dim 64 (4 blocks with
+// <= 4 waves: 74 KB) fit TWO workgroups per CU: the staging of one overlaps the products of the other (launcher).  The same for
+// head_dim 128 (2 blocks, <= 3 waves) was measured and is slower — its later chunks restage on the one-item path, there are no
+// registers for the fast one: 72.7 -> 73.4 ms per batch, profiles/r05u_attn_2wg_ab.txt — and is not built.
+template <int HD, bool TRACE, bool WINDOW, int KBC = 0>
 __global__ __launch_bounds__(384) void relpos_attention_kernel(AttnParams p) {
     using G = AttnGeom<HD>;
     constexpr int NCH = G::NCH, KS = G::KS, DB = G::DB, KROW = G::KROW, K_BYTES = G::K_BYTES, VT_BYTES = G::VT_BYTES;
-    constexpr int SCR_BYTES = G::SCR_BYTES, RPP = G::RPP, VH = G::VH, KB_CHUNK = G::KB_CHUNK;
+    constexpr int SCR_BYTES = G::SCR_BYTES, RPP = G::RPP, VH = G::VH, KB_CHUNK = KBC > 0 ? KBC : G::KB_CHUNK;
     long long ts[40];
     int nts = 0;
     // TRACE: drain the memory counters, make the newest MFMA result architecturally visible, then stamp
@@ -503,6 +510,32 @@ int launch_attention_hd(rs_ctx* ctx, AttnParams& p, int B, int T, hipStream_t s)
     rs_prof_begin(ctx, RS_PROF_ATTN, s, flops, bytes);
     p.trace = HD == 128 ? g_attn_trace : nullptr;
     const bool window = p.att_left >= 0 || p.att_right >= 0;
+    if constexpr (HD == 64) {
+        // head_dim 64: small key chunks and fewer waves per workgroup so that TWO workgroups share a CU and the K / V staging of
+        // one overlaps the products of the other (default 4 key blocks x 4 waves: 74 KB; $RS_ATTN64="kbc,nw" for the A/B,
+        // "0" = the one-workgroup geometry).  Same order of the online softmax: bit-identical.
+        int kbc = 4, nwmax = 4;
+        if (const char* e = getenv("RS_ATTN64")) { kbc = atoi(e); const char* c = strchr(e, ','); nwmax = c ? atoi(c + 1) : 4; }
+        if (kbc > 0 && !window && !p.trace) {
+            const int nw2 = qblocks < nwmax ? qblocks : (nwmax < 1 ? 1 : nwmax > 6 ? 6 : nwmax);
+            const dim3 grid2((qblocks + nw2 - 1) / nw2, dm.n_heads, B), block2(64 * nw2);
+            int rc = RS_EINVAL;
+            auto go = [&](auto kern, int KBC) {
+                const size_t lds2 = (size_t)KBC * (G::K_BYTES + G::VT_BYTES) + (size_t)nw2 * G::SCR_BYTES + 2 * HD * sizeof(float);
+                rc = rs_ensure_dynamic_lds(ctx, (const void*)kern, (int)lds2);
+                if (rc == RS_OK) hipLaunchKernelGGL(kern, grid2, block2, lds2, s, p);
+            };
+            // stage_kv's register budget: nb <= 2 nw key blocks per chunk
+            if (kbc == 2 && nw2 >= 1) go(relpos_attention_kernel<HD, false, false, 2>, 2);
+            else if (kbc == 3 && nw2 >= 2) go(relpos_attention_kernel<HD, false, false, 3>, 3);
+            else if (kbc == 4 && nw2 >= 2) go(relpos_attention_kernel<HD, false, false, 4>, 4);
+            else if (nw2 == 1) go(relpos_attention_kernel<HD, false, false, 2>, 2);
+            rs_prof_end(ctx, RS_PROF_ATTN, s);
+            if (rc != RS_OK) return rc == RS_EINVAL ? rs_fail(ctx, RS_EINVAL, "attention: $RS_ATTN64 geometry %d,%d is not built", kbc, nwmax) : rc;
+            RS_CHECK_LAUNCH(ctx, "relpos_attention (head_dim 64)");
+            return RS_OK;
+        }
+    }
     if (window) hipLaunchKernelGGL((relpos_attention_kernel<HD, false, true>), grid, block, lds, s, p);
     else if (p.trace) {
         if constexpr (HD == 128) hipLaunchKernelGGL((relpos_attention_kernel<HD, true, false>), grid, block, lds, s, p);
