@@ -131,10 +131,13 @@ def rnnt_alsd(cfg, sd, f, enc_lens, beam=4, max_target_len=2.0, score_norm=True,
     return [(ids[b, :n_ids[b]].tolist(), steps[b, :n_ids[b]].tolist(), float(scores[b])) for b in range(B)]
 
 
-def espnet_beam(cfg, sd, f, enc_lens, beam=20, score_norm=True, max_pops=None, out_cap=None, with_frames=False):
+def espnet_beam(cfg, sd, f, enc_lens, beam=20, score_norm=True, max_pops=None, out_cap=None, with_frames=False, workers=None):
     """f float32 [B, Tp, J] (numpy), enc_lens int[B] -> list of (ids, score, pops) of the best hypothesis per utterance
     under ESPnet's default transducer beam search, in the fixed float32 evaluation order of espnet_beam.c.
-    with_frames: (ids, frames, score, pops) — frames = the frame each label was appended at."""
+    with_frames: (ids, frames, score, pops) — frames = the frame each label was appended at.
+    Utterances are independent and the C routine is re-entrant (its only global, the joint activation, is set before the
+    calls): rows run on `workers` threads (default: one per core, at most 32) — a whole 358-frame row at beam 20 is ~20 - 40 s
+    of scalar C."""
     L = lib()
     L.rs_oracle_set_joint_act(1 if getattr(cfg, "espnet", False) else 0)
     arr = decoder_arrays(cfg, sd)
@@ -154,10 +157,22 @@ def espnet_beam(cfg, sd, f, enc_lens, beam=20, score_norm=True, max_pops=None, o
     wl = (PF * cfg.pred_layers)(*[_fp(w) for w in arr["lstm_w"]])
     bl = (PF * cfg.pred_layers)(*[_fp(b) for b in arr["lstm_b"]])
     L.rs_oracle_espnet_beam.restype = ctypes.c_int
-    rc = L.rs_oracle_espnet_beam(_fp(f), _ip(enc_lens), B, Tp, J, cfg.pred_hidden, cfg.pred_layers, cfg.n_logits,
-                                 cfg.blank_id, _fp(arr["embed"]), wl, bl, _fp(arr["Wp"]), _fp(arr["bp"]), _fp(arr["Wo"]),
-                                 _fp(arr["bo"]), int(beam), int(bool(score_norm)), int(max_pops), int(out_cap), _ip(ids),
-                                 _ip(frames), _ip(n_ids), _fp(scores), _ip(pops))
+
+    def rows(b0, b1):          # utterances [b0, b1): views into the shared input / output arrays
+        return L.rs_oracle_espnet_beam(_fp(f[b0:b1]), _ip(enc_lens[b0:b1]), b1 - b0, Tp, J, cfg.pred_hidden, cfg.pred_layers, cfg.n_logits,
+                                       cfg.blank_id, _fp(arr["embed"]), wl, bl, _fp(arr["Wp"]), _fp(arr["bp"]), _fp(arr["Wo"]),
+                                       _fp(arr["bo"]), int(beam), int(bool(score_norm)), int(max_pops), int(out_cap), _ip(ids[b0:b1]),
+                                       _ip(frames[b0:b1]), _ip(n_ids[b0:b1]), _fp(scores[b0:b1]), _ip(pops[b0:b1]))
+
+    if workers is None:
+        workers = min(32, os.cpu_count() or 1)
+    if B > 1 and workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(workers, B)) as pool:
+            rcs = list(pool.map(lambda b: rows(b, b + 1), range(B)))
+        rc = max(rcs)
+    else:
+        rc = rows(0, B)
     if rc != 0:
         raise RuntimeError(f"oracle espnet beam search overflowed (max_pops={max_pops}, out_cap={out_cap})")
     if with_frames:
