@@ -468,12 +468,89 @@ def espnet_parity(am, cfg, sd, buf256, first):
     return out
 
 
+def k2_parity(am, cfg, sd, buf256, waves, audio):
+    """End-to-end id parity of the Zipformer family (pkg/k2-asr/src/transcribe.py:36-45: create_stream / accept_waveform /
+    decode_stream -> tokens, timestamps) on ALL 256 rows of the timed batch against the committed float32-oracle golden
+    (tests/golden/bench_k2_fp32.npz: oracle/zipformer.py, its own window / mel banks / position rows, run end to end on every
+    row, one utterance per call): the float32 parity mode must reproduce ids and frames, the bf16 throughput mode is flip-audited
+    against the parity mode's projection (oracle/audit.py: flip_audit_batch_k2)."""
+    import hashlib
+    from oracle import audit, greedy as og, zipformer as oz
+    from reazonspeech_amd.k2.asr.model import K2Model, synthetic_tokens
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "bench_k2_fp32.npz"))
+    if hashlib.sha256(audio.tobytes()).digest() != bytes(gold["audio_sha256"].tolist()):
+        return {"error": "the resident batch is not the golden's batch (seed / rank / --seconds differ)"}
+    rows = int(gold["rows"])
+    off = gold["ids_offsets"]
+    g_ids = [gold["ids"][off[b]:off[b + 1]].tolist() for b in range(rows)]
+    g_frames = [gold["frames"][off[b]:off[b + 1]].tolist() for b in range(rows)]
+    t0 = time.perf_counter()
+    m32 = K2Model(cfg, sd, synthetic_tokens(cfg.vocab_size, 0), device=str(am.device), precision="fp32").am
+    b32 = m32.stage(waves, buf=m32.new_buffers(len(waves), len(waves[0])))
+    m32.run_device(b32)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    m32.run_device(b32)
+    torch.cuda.synchronize()
+    ms32 = (time.perf_counter() - t1) * 1e3
+    got32 = m32.collect(b32)
+    g = torch.Generator().manual_seed(int(gold["proj_seed"]))
+    R = (torch.randn((cfg.joiner_dim, 8), generator=g, dtype=torch.float32) / cfg.joiner_dim ** 0.5).to(am.device)
+    proj = (b32.joint_enc @ R).cpu().numpy()
+    perr = max(float(np.abs(proj[b, :got32.enc_lens[b]] - gold["proj"][b, :got32.enc_lens[b]]).max()) for b in range(rows))
+    exact = [got32.ids[b] == g_ids[b] and got32.frames[b] == g_frames[b] for b in range(rows)]
+    secs = float(sum(len(w) for w in waves) - 2 * len(waves) * int(0.9 * 16000)) / 16000.0
+    out = {"checker": "tests/golden/bench_k2_fp32.npz: oracle/zipformer.py (float32 CPU restatement of icefall's Zipformer2 transducer + sherpa-onnx's greedy "
+                      "search, its own fbank / position tables; unpinned against icefall / sherpa-onnx themselves) end to end on every row; generator "
+                      "tests/golden/make_k2_golden.py",
+           "rows": rows, "ids_exact": f"{sum(exact)}/{rows}",
+           "fp32_mode": {"rows": rows, "ids_exact": f"{sum(exact)}/{rows}", "enc_lens_equal": got32.enc_lens[:rows] == gold["enc_lens"].tolist(),
+                         "joint_proj_fingerprint_max_err_all_rows": round(perr, 7), "rows_differing": [b for b in range(rows) if not exact[b]],
+                         "golden_rows_with_a_margin_below_1e-3": int((gold["min_margin"] < float(gold["near_tie"])).sum()),
+                         "decisions": int(gold["n_decisions"].sum()), "ms_per_batch_of_256": round(ms32, 1),
+                         "rtfx": round(secs / (ms32 * 1e-3), 1), "load_and_first_run_s": round(t1 - t0, 1)}}
+    # the bf16 throughput mode (the timed kernels) on the same rows, audited against the parity mode's projection
+    am.run_device(buf256)
+    torch.cuda.synchronize()
+    got16 = am.collect(buf256)
+    f16 = buf256.joint_enc
+    dj = max(float((f16[b, :got16.enc_lens[b]] - b32.joint_enc[b, :got16.enc_lens[b]]).abs().max()) for b in range(rows))
+    audits = audit.flip_audit_batch_k2(cfg, sd, b32.joint_enc[:rows], f16[:rows], got16.enc_lens[:rows], got16.ids[:rows], got16.frames[:rows], device=am.device)
+    equal = [got16.ids[b] == g_ids[b] and got16.frames[b] == g_frames[b] for b in range(rows)]
+    s = audit.summarize(audits, equal)
+    ref_tokens = sum(len(x) for x in g_ids)
+    dist = sum(edit_distance(got16.ids[b], g_ids[b]) for b in range(rows) if not equal[b])
+    same = og.k2_greedy(cfg, sd, f16[:8].cpu().numpy(), np.asarray(got16.enc_lens[:8], np.int32))
+    worst = mean = 0.0
+    for b in range(2):                         # rows 0-1 (full 10 s rows of the timed batch) against the bf16-recipe oracle
+        ref = oz.forward(cfg, sd, waves[b], "bf16")
+        n = ref["joint_enc"].shape[0]
+        e = (f16[b, :n].cpu() - ref["joint_enc"]).abs()
+        worst, mean = max(worst, float(e.max())), max(mean, float(e.mean()))
+    small = am.stage(waves[:1], buf=am.new_buffers(1, len(waves[0])))
+    am.run_device(small)
+    torch.cuda.synchronize()
+    alone = am.collect(small)
+    n0 = alone.enc_lens[0]
+    s.update(rows=rows, ids_exact_vs_fp32_oracle=f"{sum(equal)}/{rows}", token_agreement=round(1.0 - dist / max(ref_tokens, 1), 4),
+             joint_enc_max_diff_vs_fp32_mode=round(dj, 4),
+             every_flip_obeys_the_lipschitz_bound=all(fl["margin_ref"] <= fl["bound"] * (1 + 1e-9) + 1e-12 for a in audits for fl in a["flips"]),
+             decode_bit_exact_given_same_joint_enc_rows_0_7=got16.ids[:8] == [r[0] for r in same] and got16.frames[:8] == [r[1] for r in same],
+             joint_enc_rows01_vs_bf16_recipe_oracle_max_err=round(worst, 4), joint_enc_rows01_vs_bf16_recipe_oracle_mean_err=round(mean, 5),
+             alone_equals_inside_batch_bits=bool(torch.equal(small.joint_enc[0, :n0], f16[0, :n0])) and alone.ids[0] == got16.ids[0]
+             and alone.frames[0] == got16.frames[0])
+    out["bf16_audit_all_rows"] = s
+    del m32, b32, small
+    torch.cuda.empty_cache()
+    return out
+
+
 def k2_config(device, args, steps=10):
     """`reazonspeech.k2.asr` (pkg/k2-asr/src/huggingface.py:73-83, transcribe.py:24-39): 256 x 10 s utterances with the reference's
     0.9 s of padding on both sides through kaldi-style fbank + encoder_embed + the six Zipformer2 stacks + the stateless-decoder
-    greedy search, HBM-resident and pipelined like the headline loop.  Parity: four utterances against the CPU oracle of that model
-    (oracle/zipformer.py with the bf16 recipe — unpinned against icefall / sherpa-onnx), decode bit-exact vs oracle/k2_greedy.c on the
-    device's projection, and batch invariance (an utterance alone == inside the batch of 256, bits)."""
+    greedy search, HBM-resident and pipelined like the headline loop.  Parity (`k2_parity`): ALL 256 rows of the timed batch against
+    the committed float32-oracle golden — the float32 parity mode's ids / frames, the bf16 mode flip-audited — plus rows 0-1 against
+    the bf16-recipe oracle, decode bit-exact vs oracle/k2_greedy.c, batch invariance (an utterance alone == inside the batch, bits)."""
     from reazonspeech_amd.runtime.k2_config import ZIPFORMER_159M
     from reazonspeech_amd.runtime.k2_weights import synthetic_state_dict_k2
     from reazonspeech_amd.k2.asr.model import K2Model, synthetic_tokens
@@ -490,7 +567,7 @@ def k2_config(device, args, steps=10):
         bufs.append(am.stage(waves, buf=am.new_buffers(args.batch, len(waves[0]))))
         secs.append(float(lens.sum()) / 16000.0)
         if k == 0:
-            first = waves
+            first, first_audio = waves, audio
     torch.cuda.synchronize()
     dt = timed_pipeline(am, bufs, steps, 3, args.dec_streams)
     n_tok = bufs[0].n_ids.cpu().numpy()
@@ -499,30 +576,7 @@ def k2_config(device, args, steps=10):
            "value": round(sum(secs[i % n_sets] for i in range(steps)) / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
            "enc_frames": bufs[0].tp_max, "mean_tokens_per_utt": round(float(n_tok.mean()), 1)}
     try:
-        from oracle import zipformer as oz, greedy as og
-        k = 2
-        am.run_device(bufs[0])
-        torch.cuda.synchronize()
-        got = am.collect(bufs[0])
-        f_dev = bufs[0].joint_enc
-        worst = mean = 0.0
-        for b in range(k):
-            ref = oz.forward(cfg, sd, first[b], "bf16")
-            n = ref["joint_enc"].shape[0]
-            e = (f_dev[b, :n].cpu() - ref["joint_enc"]).abs()
-            worst, mean = max(worst, float(e.max())), max(mean, float(e.mean()))
-        same = og.k2_greedy(cfg, sd, f_dev[:8].cpu().numpy(), np.asarray(got.enc_lens[:8], np.int32))
-        small = am.stage(first[:1], buf=am.new_buffers(1, len(first[0])))
-        am.run_device(small)
-        torch.cuda.synchronize()
-        alone = am.collect(small)
-        n0 = alone.enc_lens[0]
-        res["parity"] = {"utterances_vs_cpu_oracle": k, "checker": "oracle/zipformer.py (bf16-recipe CPU restatement of icefall's Zipformer2; unpinned "
-                         "against icefall / sherpa-onnx)", "joint_enc_max_err": round(worst, 4), "joint_enc_mean_err": round(mean, 5),
-                         "decode_bit_exact_given_same_joint_enc_rows_0_7": got.ids[:8] == [r[0] for r in same] and got.frames[:8] == [r[1] for r in same],
-                         "alone_equals_inside_batch_bits": bool(torch.equal(small.joint_enc[0, :n0], f_dev[0, :n0])) and alone.ids[0] == got.ids[0]
-                         and alone.frames[0] == got.frames[0]}
-        del small
+        res["parity"] = k2_parity(am, cfg, sd, bufs[0], first, first_audio)
     except Exception as e:
         res["parity"] = {"error": repr(e)}
     del bufs, km

@@ -236,3 +236,80 @@ def flip_audit_batch(cfg, sd, f_ref, f_hip, enc_lens, hyp_ids, hyp_frames, devic
                               "bound": float((wn[kr] + wn[kh]) * df_all[b, d]), "delta_f": float(df_all[b, d])})
         out.append({"decisions": n, "flips": flips, "margins": margins[b, :n].astype(np.float64), "path_ok": not bool(path_bad[b])})
     return out
+
+
+def flip_audit_batch_k2(cfg, sd, f_ref, f_hip, enc_lens, hyp_ids, hyp_frames, device="cpu"):
+    """`flip_audit_batch` for the Zipformer family ([UPSTREAM] sherpa-onnx greedy search over icefall's STATELESS decoder;
+    restated at oracle/zipformer.py: greedy_search): one decision per frame, the context is the last `context_size` emitted
+    tokens, and blank and `<unk>` are one decision class ("nothing emitted": neither is recorded nor enters the context).
+    The walk follows the audited side's own hypothesis with the decoder in float64, so at every frame both sides share the
+    context and differ only in the encoder-projection row; tanh is 1-Lipschitz, hence the same bound as for the LSTM families:
+        z_ref[k_ref] - z_ref[k_hip]  <=  (|w[k_ref]| + |w[k_hip]|) |f_ref[t] - f_hip[t]|_2
+    where, for a frame without an emission, k_hip is the better of (blank, unk) on the audited row.
+    -> list of per-row dicts with the keys of `flip_audit`."""
+    import torch
+    dev = torch.device(device)
+    f64 = lambda t: t.detach().to(device=dev, dtype=torch.float64)  # noqa: E731
+    B = len(enc_lens)
+    blank, unk, C = cfg.blank_id, cfg.unk_id, cfg.context_size
+    emb, cw = f64(sd["decoder.embedding.weight"]), f64(sd["decoder.conv.weight"])            # [V][D], [D][4][C]
+    wp, bp = f64(sd["joiner.decoder_proj.weight"]), f64(sd["joiner.decoder_proj.bias"])
+    wo, bo = f64(sd["joiner.output_linear.weight"]), f64(sd["joiner.output_linear.bias"])
+    Dd = emb.shape[1]
+    wnorm = wo.norm(dim=1)
+    fr, fh = f64(f_ref), f64(f_hip)
+    Tm = int(max(enc_lens)) if B else 0
+    emitted = torch.full((B, max(Tm, 1)), -1, dtype=torch.long)
+    for b in range(B):
+        for k, t in zip(hyp_ids[b], hyp_frames[b]):
+            emitted[b, int(t)] = int(k)
+    emitted = emitted.to(dev)
+    lens = torch.as_tensor(list(enc_lens), dtype=torch.long, device=dev)
+    hist = torch.full((B, C), -1, dtype=torch.long, device=dev)
+    hist[:, -1] = blank
+
+    def dec(h):
+        e = emb[h.clamp(min=0)] * (h >= 0).unsqueeze(-1)                                         # [B][C][D]
+        e = e.permute(0, 2, 1).reshape(B, Dd // 4, 1, 4, C).expand(B, Dd // 4, 4, 4, C).reshape(B, Dd, 4, C)
+        return torch.relu((e * cw[None]).sum(dim=(2, 3))) @ wp.t() + bp
+
+    g = dec(hist)
+    none = [blank] + ([unk] if unk >= 0 else [])
+    margins = torch.zeros((B, max(Tm, 1)), dtype=torch.float64, device=dev)
+    k_ref_all = torch.zeros((B, max(Tm, 1)), dtype=torch.long, device=dev)
+    k_hip_all = torch.zeros((B, max(Tm, 1)), dtype=torch.long, device=dev)
+    m_flip = torch.zeros((B, max(Tm, 1)), dtype=torch.float64, device=dev)
+    df_all = torch.zeros((B, max(Tm, 1)), dtype=torch.float64, device=dev)
+    path_bad = torch.zeros((B,), dtype=torch.bool, device=dev)
+    rows = torch.arange(B, device=dev)
+    for t in range(Tm):
+        v = lens > t
+        z_ref = torch.tanh(fr[:, t] + g) @ wo.t() + bo
+        z_hip = torch.tanh(fh[:, t] + g) @ wo.t() + bo
+        top2 = z_ref.topk(2, dim=1).values
+        margins[:, t] = top2[:, 0] - top2[:, 1]
+        best_none = torch.tensor(none, device=dev)[z_hip[:, none].argmax(dim=1)]
+        k_hip = torch.where(emitted[:, t] >= 0, emitted[:, t], best_none)
+        k_ref = z_ref.argmax(dim=1)
+        k_ref_all[:, t], k_hip_all[:, t] = k_ref, k_hip
+        m_flip[:, t] = z_ref[rows, k_ref] - z_ref[rows, k_hip]
+        df_all[:, t] = (fr[:, t] - fh[:, t]).norm(dim=1)
+        path_bad |= v & ((z_hip.max(dim=1).values - z_hip[rows, k_hip]) > 1e-3)
+        emit = v & (emitted[:, t] >= 0)
+        if bool(emit.any()):
+            hist = torch.where(emit[:, None], torch.cat([hist[:, 1:], emitted[:, t:t + 1]], dim=1), hist)
+            g = torch.where(emit[:, None], dec(hist), g)
+    margins, k_ref_all, k_hip_all = margins.cpu().numpy(), k_ref_all.cpu().numpy(), k_hip_all.cpu().numpy()
+    m_flip, df_all, wn, path_bad = m_flip.cpu().numpy(), df_all.cpu().numpy(), wnorm.cpu().numpy(), path_bad.cpu().numpy()
+    cls = lambda k: -1 if k in none else k          # noqa: E731
+    out = []
+    for b in range(B):
+        n = int(enc_lens[b])
+        flips = []
+        for t in range(n):
+            kr, kh = int(k_ref_all[b, t]), int(k_hip_all[b, t])
+            if cls(kr) != cls(kh):
+                flips.append({"frame": t, "k_ref": kr, "k_hip": kh, "margin_ref": float(m_flip[b, t]),
+                              "bound": float((wn[kr] + wn[kh]) * df_all[b, t]), "delta_f": float(df_all[b, t])})
+        out.append({"decisions": n, "flips": flips, "margins": margins[b, :n].astype(np.float64), "path_ok": not bool(path_bad[b])})
+    return out

@@ -15,12 +15,74 @@ weights) so that the comparison tolerance measures the kernels and not the preci
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
-from reazonspeech_amd.runtime.k2_weights import (compact_rel_pos_table, kaldi_mel_banks, layer_prefix, povey_window)
-
 FLT_EPSILON = 1.1920928955078125e-07
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# constant tables, from the published formulas in float64.  The oracle builds its OWN window, mel banks and relative-position
+# rows: importing the product's arrays (reazonspeech_amd/runtime/k2_weights.py, what the HIP path uploads) would compare the
+# device with itself on these three pieces.  tests/test_k2_host.py asserts the two sets agree to float32 resolution.
+# ------------------------------------------------------------------------------------------------------------------
+def layer_prefix(cfg, s: int, j: int) -> str:
+    """[UPSTREAM] zipformer.py: a stack that runs at the full rate is a bare Zipformer2Encoder (`encoders.S.layers.J`), a
+    down-sampled one is a DownsampledZipformer2Encoder wrapping it (`encoders.S.encoder.layers.J`)"""
+    inner = "layers" if cfg.downsampling[s] == 1 else "encoder.layers"
+    return f"encoder.encoders.{s}.{inner}.{j}."
+
+
+def povey_window(n: int) -> np.ndarray:
+    """[UPSTREAM] kaldi-native-fbank feature-window.cc, window_type "povey": w[i] = (0.5 - 0.5 cos(2 pi i / (n - 1))) ** 0.85.
+    -> float64 [n]"""
+    phase = 2.0 * math.pi / (n - 1) * np.arange(n, dtype=np.float64)
+    return np.power(0.5 - 0.5 * np.cos(phase), 0.85)
+
+
+def mel_scale(hz):
+    """[UPSTREAM] kaldi MelBanks::MelScale: 1127 ln(1 + f / 700)"""
+    return 1127.0 * np.log1p(np.asarray(hz, dtype=np.float64) / 700.0)
+
+
+def kaldi_mel_banks(cfg) -> np.ndarray:
+    """[UPSTREAM] kaldi-native-fbank mel-computations.cc MelBanks (no vtln): n_mels triangles, equally spaced IN MEL between
+    low_freq and high_freq (a non-positive high_freq is an offset from Nyquist); the weight of FFT bin i (frequency i * sr / n_fft,
+    i < n_fft / 2: the Nyquist bin is not used) is its position on the rising or falling edge, bins ON an outer edge weigh 0.
+    -> float64 [n_mels][n_fft / 2 + 1] (last column zero)"""
+    nyquist = cfg.sample_rate / 2.0
+    high = cfg.high_freq if cfg.high_freq > 0 else nyquist + cfg.high_freq
+    lo_m, hi_m = float(mel_scale(cfg.low_freq)), float(mel_scale(high))
+    step = (hi_m - lo_m) / (cfg.n_mels + 1)
+    edges = lo_m + step * np.arange(cfg.n_mels + 2, dtype=np.float64)              # left edge of bank b = edges[b]
+    n_bins = cfg.n_fft // 2
+    m = mel_scale(np.arange(n_bins, dtype=np.float64) * (cfg.sample_rate / cfg.n_fft))[None, :]      # [1][bins]
+    left, centre, right = edges[:-2, None], edges[1:-1, None], edges[2:, None]
+    rising = (m - left) / (centre - left)
+    falling = (right - m) / (right - centre)
+    inside = (m > left) & (m < right)
+    banks = np.where(inside, np.where(m <= centre, rising, falling), 0.0)
+    return np.concatenate([banks, np.zeros((cfg.n_mels, 1))], axis=1)
+
+
+def compact_rel_pos_table(cfg, T: int) -> np.ndarray:
+    """[UPSTREAM] zipformer.py CompactRelPositionalEncoding.extend_pe (length_factor 1.0) for relative positions -(T-1) .. T-1
+    (row n <-> key index minus query index = n - (T - 1)):  the offset is compressed logarithmically,
+    x_c = sqrt(D) sign(x) (ln(|x| + sqrt(D)) - ln sqrt(D)), squashed by atan(x_c 2 pi / D), and the angle feeds D / 2 harmonics:
+    even columns cos(k a), odd columns sin(k a), k = 1 .. D / 2; the LAST column is overwritten with 1 (a bias input).
+    -> float64 [2 T - 1][D]"""
+    D = cfg.pos_dim
+    x = np.arange(-(T - 1), T, dtype=np.float64)
+    c = math.sqrt(D)
+    xc = c * np.sign(x) * (np.log(np.abs(x) + c) - math.log(c))
+    angle = np.arctan(xc / (D / (2.0 * math.pi)))
+    k = np.arange(1, D // 2 + 1, dtype=np.float64)
+    pe = np.empty((x.shape[0], D), np.float64)
+    pe[:, 0::2] = np.cos(angle[:, None] * k[None, :])
+    pe[:, 1::2] = np.sin(angle[:, None] * k[None, :])
+    pe[:, D - 1] = 1.0
+    return pe
 
 
 def _rb(x, recipe):
@@ -68,10 +130,10 @@ def fbank(cfg, wav: torch.Tensor) -> torch.Tensor:
     fr = fr - fr.mean(dim=1, keepdim=True)
     prev = torch.cat([fr[:, :1], fr[:, :-1]], dim=1)
     fr = fr - cfg.preemph * prev
-    fr = fr * torch.from_numpy(povey_window(N))
+    fr = fr * torch.from_numpy(povey_window(N).astype(np.float32))
     spec = torch.fft.rfft(F.pad(fr, (0, cfg.n_fft - N)), dim=1)
     power = spec.real ** 2 + spec.imag ** 2                # [T][257]
-    mel = power @ torch.from_numpy(kaldi_mel_banks(cfg)).t()
+    mel = power @ torch.from_numpy(kaldi_mel_banks(cfg).astype(np.float32)).t()
     return torch.log(torch.clamp(mel, min=FLT_EPSILON))
 
 
@@ -220,7 +282,7 @@ def zipformer(cfg, sd, x: torch.Tensor, recipe="fp32", taps=None) -> torch.Tenso
 
     def pos_rows(T):
         if T not in pe_cache:
-            pe_cache[T] = torch.from_numpy(compact_rel_pos_table(cfg, T))
+            pe_cache[T] = torch.from_numpy(compact_rel_pos_table(cfg, T).astype(np.float32))
         return pe_cache[T]
 
     outputs = []

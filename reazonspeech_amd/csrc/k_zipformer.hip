@@ -20,6 +20,7 @@
 // Batch semantics: the reference runs one utterance per call, so every kernel masks by the utterance's own length (keys past it
 // weigh 0, convolutions see zeros, SimpleDownsample repeats the utterance's own last frame): a row's result does not depend on
 // its batch mates.
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <vector>
@@ -32,9 +33,18 @@ struct rs_k2_layer {
         *cm_dw_b[2], *cm_out_b[2], *norm_bias, *norm_scale, *bypass, *bypass_mid;
 };
 
+// float32 parity mode: the dense weights once more, unrounded ("<name>.f32"; the conv modules' in_proj in icefall's own row
+// order: values, then gates).  Biases, BiasNorm / bypass / down-sampling constants, depthwise taps and the projected position
+// rows are float32 in the throughput mode already and are shared.
+struct rs_k2_layer32 {
+    const float *attw_in_w, *sa_in_w[2], *sa_out_w[2], *ff_in_w[3], *ff_out_w[3], *na_in_w, *na_out_w, *cm_in_w[2], *cm_in_b[2], *cm_out_w[2];
+};
+
 struct rs_k2 {
     rs_k2_dims d{};
     std::vector<std::vector<rs_k2_layer>> stacks;
+    std::vector<std::vector<rs_k2_layer32>> stacks32;
+    const float *conv2_w32 = nullptr, *cnx_pw1_w32 = nullptr, *cnx_pw2_w32 = nullptr, *emb_out_w32 = nullptr, *jenc_w32 = nullptr;
     const float *ds_w[8] = {}, *comb_scale[8] = {}, *out_ds_w = nullptr;
     const float *conv0_w = nullptr, *conv0_b = nullptr, *conv1_w = nullptr, *conv1_b = nullptr, *conv2_b = nullptr, *cnx_dw_w = nullptr,
                 *cnx_dw_b = nullptr, *cnx_pw1_b = nullptr, *cnx_pw2_b = nullptr, *emb_out_b = nullptr, *emb_norm_bias = nullptr,
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256) void k2_bypass_kernel(float* __restrict__ x, c
     const float4 o = reinterpret_cast<const float4*>(x0)[i], s = *reinterpret_cast<const float4*>(scale + c);
     v.x = o.x + (v.x - o.x) * s.x; v.y = o.y + (v.y - o.y) * s.y; v.z = o.z + (v.z - o.z) * s.z; v.w = o.w + (v.w - o.w) * s.w;
     reinterpret_cast<float4*>(x)[i] = v;
-    reinterpret_cast<u16x4_t*>(out_bf16)[i] = pack_bf16x4(v.x, v.y, v.z, v.w);
+    if (out_bf16) reinterpret_cast<u16x4_t*>(out_bf16)[i] = pack_bf16x4(v.x, v.y, v.z, v.w);
 }
 
 // Entry of a stack: channel conversion (cut or zero-pad to d) of the previous stack's output -> src [B][T][d] (the operand of
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(256) void k2_output_kernel(K2Pieces pc, const int32
         }
         if (2 * to >= len) acc = 0.0f;
         if (enc) enc[((size_t)b * To + to) * D + c] = acc;
-        enc_bf16[((size_t)b * To + to) * D + c] = f32_to_bf16(acc);
+        if (enc_bf16) enc_bf16[((size_t)b * To + to) * D + c] = f32_to_bf16(acc);
     }
 }
 
@@ -599,6 +609,215 @@ __global__ __launch_bounds__(256) void k2_pv_kernel(const uint16_t* __restrict__
     }
 }
 
+
+// ---- float32 parity mode (rs_set_option "precision_f32") ----------------------------------------------------------------------------
+// The reference's default files are the float32 ONNX graphs (pkg/k2-asr/src/huggingface.py:16,40-45: precision="fp32") and
+// onnxruntime computes them in float32.  These kernels are the same encoder with float32 weights, activations and arithmetic end
+// to end (dense products on rs_launch_gemm_f32's exact v_mfma_f32_16x16x4_f32 chain, IEEE exp / log1p / tanh / divide), written
+// to be read against oracle/zipformer.py statement by statement: one thread or one wave per output, sums in ascending index order,
+// nothing tiled, nothing rounded below float32.  Speed is not the object.  Batch semantics as above: every kernel masks by the
+// utterance's own length.
+
+// conv0 in float32: feats [B][T][F] -> a0 f32 [B][T - 2][F][C1].  grid (T1, B), block 256
+__global__ __launch_bounds__(256) void k2f_conv0_kernel(const float* __restrict__ feats, int T, int F, int C1, const float* __restrict__ w /* [9][C1] */,
+                                                        const float* __restrict__ bias, float* __restrict__ out) {
+    const int t1 = blockIdx.x, b = blockIdx.y, T1 = T - 2;
+    float* orow = out + ((size_t)b * T1 + t1) * F * C1;
+    for (int i = threadIdx.x; i < F * C1; i += 256) {
+        const int f = i / C1, c = i - f * C1;
+        float acc = 0.0f;
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ff = f + kw - 1;
+                const float x = (ff >= 0 && ff < F) ? feats[((size_t)b * T + t1 + kh) * F + ff] : 0.0f;
+                acc = fmaf(w[(kh * 3 + kw) * C1 + c], x, acc);
+            }
+        orow[i] = swoosh_r_exact(acc + bias[c]);
+    }
+}
+
+// conv1 in float32: a0 [B][T1][F][C1] -> a1 [B][T2][F2][C2], stride 2.  One thread per output, taps (kh, kw, c1) ascending.
+__global__ __launch_bounds__(256) void k2f_conv1_kernel(const float* __restrict__ a0, int T1, int F, int C1, int T2, int F2, int C2,
+                                                        const float* __restrict__ w /* [3][3][C1][C2] */, const float* __restrict__ bias,
+                                                        float* __restrict__ out) {
+    const int t2 = blockIdx.x, b = blockIdx.y;
+    float* orow = out + ((size_t)b * T2 + t2) * F2 * C2;
+    for (int i = threadIdx.x; i < F2 * C2; i += 256) {
+        const int f2 = i / C2, c2 = i - f2 * C2;
+        float acc = 0.0f;
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) {
+                const float* xr = a0 + (((size_t)b * T1 + 2 * t2 + kh) * F + 2 * f2 + kw) * C1;
+                const float* wr = w + ((size_t)(kh * 3 + kw) * C1) * C2 + c2;
+                for (int c1 = 0; c1 < C1; ++c1) acc = fmaf(wr[(size_t)c1 * C2], xr[c1], acc);
+            }
+        orow[i] = swoosh_r_exact(acc + bias[c2]);
+    }
+}
+
+// patches of conv2 in float32: row (b, t3, f3) = a1[b][t3 + kh][2 f3 + kw][:] in (kh, kw, c) order, zero-padded to Kp = 9 C2 rounded up to 32
+__global__ __launch_bounds__(256) void k2f_im2col_kernel(const float* __restrict__ a1, int T2, int F2, int C2, int T3, int F3, int Kp, long long rows,
+                                                         float* __restrict__ col) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int f3 = (int)(row % F3);
+    const long long bt = row / F3;
+    const int t3 = (int)(bt % T3), b = (int)(bt / T3);
+    const int c4 = C2 / 4;
+    float4* dst = reinterpret_cast<float4*>(col + row * Kp);
+    for (int q = lane; q < Kp / 4; q += 64) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < 9 * c4) {
+            const int tap = q / c4, c = q - tap * c4;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            v = reinterpret_cast<const float4*>(a1 + (((size_t)b * T2 + t3 + kh) * F2 + 2 * f3 + kw) * C2)[c];
+        }
+        dst[q] = v;
+    }
+}
+
+// ConvNeXt depthwise 7 x 7 in float32, one thread per output; rows past the utterance's length and columns outside the map are zeros
+__global__ __launch_bounds__(256) void k2f_cnx_dw_kernel(const float* __restrict__ a2, const int32_t* __restrict__ lens3, int T3, int F3, int C,
+                                                         const float* __restrict__ w /* [49][C] */, const float* __restrict__ bias,
+                                                         float* __restrict__ out) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    int len = lens3[b];
+    len = len < T3 ? len : T3;
+    for (int i = threadIdx.x; i < F3 * C; i += 256) {
+        const int f = i / C, c = i - f * C;
+        float acc = 0.0f;
+        for (int kh = 0; kh < 7; ++kh) {
+            const int r = t + kh - 3;
+            if (r < 0 || r >= len) continue;
+            for (int kw = 0; kw < 7; ++kw) {
+                const int ff = f + kw - 3;
+                if (ff < 0 || ff >= F3) continue;
+                acc = fmaf(w[(kh * 7 + kw) * C + c], a2[(((size_t)b * T3 + r) * F3 + ff) * C + c], acc);
+            }
+        }
+        out[(((size_t)b * T3 + t) * F3 + f) * C + c] = acc + bias[c];
+    }
+}
+
+// attention weights in float32: one wave per (query, head, utterance); a lane owns keys lane, lane + 64, ..
+//   s[i][j] = q_i . k_j + p_i . pos[j - i];  W[b][h][i][:] = softmax over the utterance's own keys; padded queries / keys: 0
+// qkp f32 [B*T][ld] as in the bf16 kernel; W f32 [B][H][T][Tp].  grid (ceil(T / 4), H, B), block 256
+__global__ __launch_bounds__(256) void k2f_attn_weights_kernel(const float* __restrict__ qkp, int ld, const float* __restrict__ pos, int cap, int H,
+                                                               const int32_t* __restrict__ lens, int T, int Tp, float* __restrict__ W) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, b = blockIdx.z;
+    if (i >= T) return;
+    int len = lens[b];
+    len = len < T ? len : T;
+    float* wrow = W + (((size_t)b * H + h) * T + i) * Tp;
+    if (i >= len) {
+        for (int j = lane; j < Tp; j += 64) wrow[j] = 0.0f;
+        return;
+    }
+    const float* qr = qkp + ((size_t)b * T + i) * ld;
+    float q[K2_QD], pq[K2_PD];
+#pragma unroll
+    for (int e = 0; e < K2_QD; ++e) q[e] = qr[h * K2_QD + e];
+#pragma unroll
+    for (int e = 0; e < K2_PD; ++e) pq[e] = qr[2 * H * K2_QD + h * K2_PD + e];
+    float mx = -INFINITY;
+    for (int j = lane; j < len; j += 64) {
+        const float* kr = qkp + ((size_t)b * T + j) * ld + H * K2_QD + h * K2_QD;
+        const float* pr = pos + (size_t)(j - i + cap - 1) * (H * K2_PD) + h * K2_PD;
+        float qk = 0.0f, pp = 0.0f;
+#pragma unroll
+        for (int e = 0; e < K2_QD; ++e) qk = fmaf(q[e], kr[e], qk);
+#pragma unroll
+        for (int e = 0; e < K2_PD; ++e) pp = fmaf(pq[e], pr[e], pp);
+        const float sc = qk + pp;
+        wrow[j] = sc;
+        mx = fmaxf(mx, sc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int j = lane; j < len; j += 64) {          // (a lane re-reads only what it wrote itself)
+        const float e = expf(wrow[j] - mx);
+        wrow[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    for (int j = lane; j < Tp; j += 64) wrow[j] = j < len ? wrow[j] / sum : 0.0f;
+}
+
+// self-attention values in float32: out[b][i][h * 12 + c] = sum_j W[b][h][i][j] v[b][j][h * 12 + c].  One thread per output column
+// of one query, keys ascending.  v f32 [B*T][ldv], out f32 [B*T][ldo] (columns >= H * 12 are left alone: zeroed by the caller).
+// grid (T, B), block = H * 12 rounded up to 64
+__global__ void k2f_pv_kernel(const float* __restrict__ W, int H, int Tp, const float* __restrict__ v, int ldv, const int32_t* __restrict__ lens,
+                              int T, float* __restrict__ out, int ldo) {
+    const int i = blockIdx.x, b = blockIdx.y, col = threadIdx.x;
+    if (col >= H * K2_VD) return;
+    int len = lens[b];
+    len = len < T ? len : T;
+    float acc = 0.0f;
+    if (i < len) {
+        const float* wrow = W + (((size_t)b * H + col / K2_VD) * T + i) * Tp;
+        const float* vc = v + (size_t)b * T * ldv + col;
+        for (int j = 0; j < len; ++j) acc = fmaf(wrow[j], vc[(size_t)j * ldv], acc);
+    }
+    out[((size_t)b * T + i) * ldo + col] = acc;
+}
+
+// non-linear attention in float32, first half: g[b][j][c] = u[.., hid + c] * tanh(u[.., c])   (u = in_proj output [B*T][3 hid])
+__global__ __launch_bounds__(256) void k2f_na_gate_kernel(const float* __restrict__ u, int hid, size_t rows, float* __restrict__ g) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * hid) return;
+    const size_t r = idx / hid;
+    const int c = (int)(idx - r * hid);
+    const float* ur = u + r * 3 * hid;
+    g[idx] = ur[hid + c] * tanhf(ur[c]);
+}
+
+// second half: out[b][i][c] = (sum_j W[b][0][i][j] g[b][j][c]) * u[b][i][2 hid + c]; four queries per thread (they share the
+// loads of g), keys ascending.  grid (ceil(hid / 256), ceil(T / 4), B), block 256
+__global__ __launch_bounds__(256) void k2f_na_pv_kernel(const float* __restrict__ W, int H, int Tp, const float* __restrict__ g, const float* __restrict__ u,
+                                                        int hid, const int32_t* __restrict__ lens, int T, float* __restrict__ out, int ldo) {
+    const int c = blockIdx.x * 256 + threadIdx.x, i0 = blockIdx.y * 4, b = blockIdx.z;
+    if (c >= hid) return;
+    int len = lens[b];
+    len = len < T ? len : T;
+    const float* wr[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wr[q] = W + (((size_t)b * H + 0) * T + (i0 + q < T ? i0 + q : T - 1)) * Tp;
+    const float* gc = g + (size_t)b * T * hid + c;
+    for (int j = 0; j < len; ++j) {
+        const float gv = gc[(size_t)j * hid];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fmaf(wr[q][j], gv, acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q;
+        if (i >= T) continue;
+        out[((size_t)b * T + i) * ldo + c] = i < len ? acc[q] * u[((size_t)b * T + i) * 3 * hid + 2 * hid + c] : 0.0f;
+    }
+}
+
+// conv-module middle in float32: x [B*T][2d] (values | gates, icefall's own order) -> x * sigmoid(gate) -> frame mask -> depthwise k
+// -> + bias -> SwooshR -> out [B*T][d].  One thread per output, taps ascending (absent taps skipped)
+__global__ __launch_bounds__(256) void k2f_glu_dwconv_swoosh_kernel(const float* __restrict__ x, const float* __restrict__ w /* [k][d] */,
+                                                                    const float* __restrict__ bias, const int32_t* __restrict__ lens, int T, int d,
+                                                                    int k, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y, b = blockIdx.z;
+    if (c >= d) return;
+    int len = lens[b];
+    len = len < T ? len : T;
+    const int half = (k - 1) >> 1;
+    float acc = 0.0f;
+    for (int j = 0; j < k; ++j) {
+        const int tj = t + j - half;
+        if (tj < 0 || tj >= len) continue;
+        const float* px = x + ((size_t)b * T + tj) * 2 * d;
+        acc = fmaf(w[(size_t)j * d + c], px[c] * (1.0f / (1.0f + expf(-px[d + c]))), acc);
+    }
+    out[((size_t)b * T + t) * d + c] = swoosh_r_exact(acc + bias[c]);
+}
+
 // per-stack lengths: l[s][b] = ceil(len3[b] / ds[s]); len3[b] = max((n_frames[b] - 7) / 2, 0).  rows: 0 = len3, 1 + s = stack s
 __global__ void k2_lens_kernel(const int32_t* __restrict__ n_frames, int B, int n_stacks, int ds0, int ds1, int ds2, int ds3, int ds4, int ds5, int ds6,
                                int ds7, int32_t* __restrict__ out) {
@@ -683,6 +902,64 @@ K2Plan k2_plan(const rs_ctx* ctx, int B, int t_max) {
     p.off_av = take(av_b);
     p.off_vt = take(vt_b);
     p.off_encb = take((size_t)B * (p.To > 0 ? p.To : 1) * k.out_dim * 2);
+    p.total = o + 256;
+    return p;
+}
+
+
+__host__ __device__ inline int pad32(int n) { return (n + 31) / 32 * 32; }
+
+// workspace of the float32 parity mode: the bf16 plan's tensors as float32, patches un-padded (K = 9 C2), no V^T copies
+struct K2PlanF32 {
+    int T, T1, T2, T3, To, F, F2, F3;
+    int Ts[8], Tp[8];
+    size_t off_lens, off_a0, off_a1, off_col, off_a2, off_dwo, off_h, off_stackout[8], off_x, off_x0, off_src, off_qkp, off_w, off_big, off_av, off_gate,
+        off_enc, total;
+};
+
+K2PlanF32 k2_plan_f32(const rs_ctx* ctx, int B, int t_max) {
+    const rs_k2& k = *ctx->k2;
+    const rs_k2_dims& d = k.d;
+    K2PlanF32 p{};
+    p.T = t_max; p.F = d.n_mels;
+    p.T1 = t_max - 2; p.T2 = p.T1 >= 3 ? (p.T1 - 3) / 2 + 1 : 0; p.T3 = p.T2 - 2;
+    if (p.T3 < 0) p.T3 = 0;
+    p.F2 = (p.F - 3) / 2 + 1; p.F3 = (p.F2 - 3) / 2 + 1;
+    p.To = (p.T3 + 1) / 2;
+    const size_t T3 = p.T3 > 0 ? p.T3 : 1, T1 = p.T1 > 0 ? p.T1 : 1, T2 = p.T2 > 0 ? p.T2 : 1;
+    const size_t rows3 = (size_t)B * T3 * p.F3;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += rs_align(bytes); return at; };
+    p.off_lens = take((size_t)(2 + d.n_stacks) * B * 4);
+    p.off_a0 = take((size_t)B * T1 * p.F * d.embed_c1 * 4);
+    p.off_a1 = take((size_t)B * T2 * p.F2 * d.embed_c2 * 4);
+    p.off_col = take(rows3 * pad32(9 * d.embed_c2) * 4);
+    p.off_a2 = take(rows3 * d.embed_c3 * 4);
+    p.off_dwo = take(rows3 * d.embed_c3 * 4);
+    p.off_h = take(rows3 * 3 * d.embed_c3 * 4);
+    size_t x_b = 0, qkp_b = 0, w_b = 0, big_b = 0, av_b = 0, gate_b = 0;
+    for (int s = 0; s < d.n_stacks; ++s) {
+        const size_t dd = d.encoder_dim[s], H = d.num_heads[s], hid = 3 * dd / 4;
+        p.Ts[s] = ceil_div((int)T3, d.downsampling[s]);
+        p.Tp[s] = (p.Ts[s] + 31) / 32 * 32;
+        const size_t rows = (size_t)B * p.Ts[s];
+        p.off_stackout[s] = take((size_t)B * T3 * dd * 4);
+        x_b = std::max(x_b, (size_t)B * T3 * dd * 4);
+        qkp_b = std::max(qkp_b, rows * (2 * K2_QD + K2_PD) * H * 4);
+        w_b = std::max(w_b, (size_t)B * H * p.Ts[s] * p.Tp[s] * 4);
+        const size_t widest = std::max(std::max((size_t)d.ff_dim[s] * 5 / 4, 3 * hid), 2 * dd);
+        big_b = std::max(big_b, rows * widest * 4);
+        const size_t avw = std::max(std::max((size_t)pad32((int)hid), (size_t)pad32((int)H * K2_VD)), dd);
+        av_b = std::max(av_b, rows * avw * 4);
+        gate_b = std::max(gate_b, rows * hid * 4);
+    }
+    p.off_x = take(x_b); p.off_x0 = take(x_b); p.off_src = take(x_b);
+    p.off_qkp = take(qkp_b);
+    p.off_w = take(w_b);
+    p.off_big = take(big_b);
+    p.off_av = take(av_b);
+    p.off_gate = take(gate_b);
+    p.off_enc = take((size_t)B * (p.To > 0 ? p.To : 1) * k.out_dim * 4);
     p.total = o + 256;
     return p;
 }
@@ -830,6 +1107,41 @@ int rs_k2_finalize_impl(rs_ctx* ctx) {
         K2_GET("joint.out.bpad", Vpad, ctx->jout_bpad);
         K2_GET("joint.out.wmax", 4, ctx->jout_wmax);
     }
+    // optional: the float32 parity mode's dense weights ("<name>.f32": all or none)
+    ctx->has_f32 = false;
+    k.stacks32.clear();
+    if (ctx->tensors.count("emb.out.w.f32")) {
+        K2_GET("emb.conv2.w.f32", (size_t)c3 * pad32(9 * c2), k.conv2_w32);
+        K2_GET("emb.cnx.pw1.w.f32", 3 * c3 * c3, k.cnx_pw1_w32); K2_GET("emb.cnx.pw2.w.f32", 3 * c3 * c3, k.cnx_pw2_w32);
+        K2_GET("emb.out.w.f32", (size_t)d0 * k.embed_freq * c3, k.emb_out_w32);
+        K2_GET("joint.enc.w.f32", J * k.out_dim, k.jenc_w32);
+        k.stacks32.assign(d.n_stacks, {});
+        for (int s = 0; s < d.n_stacks; ++s) {
+            const size_t dd = d.encoder_dim[s], H = d.num_heads[s], hid = 3 * dd / 4;
+            const size_t ff[3] = {(size_t)d.ff_dim[s] * 3 / 4, (size_t)d.ff_dim[s], (size_t)d.ff_dim[s] * 5 / 4};
+            k.stacks32[s].assign(d.num_layers[s], rs_k2_layer32{});
+            for (int j = 0; j < d.num_layers[s]; ++j) {
+                rs_k2_layer32& L = k.stacks32[s][j];
+                const std::string p = "S" + std::to_string(s) + ".L" + std::to_string(j) + ".";
+                K2_GET(p + "attw.in.w.f32", (2 * K2_QD + K2_PD) * H * dd, L.attw_in_w);
+                for (int a = 0; a < 2; ++a) {
+                    const std::string q = p + (a ? "sa2." : "sa1."), c = p + (a ? "cm2." : "cm1.");
+                    K2_GET(q + "in.w.f32", H * K2_VD * dd, L.sa_in_w[a]);
+                    K2_GET(q + "out.w.f32", dd * pad32((int)(H * K2_VD)), L.sa_out_w[a]);
+                    K2_GET(c + "in.w.f32", 2 * dd * dd, L.cm_in_w[a]); K2_GET(c + "in.b.f32", 2 * dd, L.cm_in_b[a]);
+                    K2_GET(c + "out.w.f32", dd * dd, L.cm_out_w[a]);
+                }
+                for (int f = 0; f < 3; ++f) {
+                    const std::string q = p + "ff" + std::to_string(f + 1) + ".";
+                    K2_GET(q + "in.w.f32", ff[f] * dd, L.ff_in_w[f]); K2_GET(q + "out.w.f32", dd * ff[f], L.ff_out_w[f]);
+                }
+                K2_GET(p + "na.in.w.f32", 3 * hid * dd, L.na_in_w);
+                K2_GET(p + "na.out.w.f32", dd * pad32((int)hid), L.na_out_w);
+            }
+        }
+        ctx->has_f32 = true;
+    }
+    if (ctx->precision_f32 && !ctx->has_f32) ctx->precision_f32 = 0;
 #undef K2_GET
     ctx->decode_narrow = true;
     ctx->finalized = true;
@@ -844,13 +1156,22 @@ int rs_k2_enc_frames_impl(const rs_ctx* ctx, int n_feat) {
     return t3 > 0 ? (t3 + 1) / 2 : 0;
 }
 
-size_t rs_k2_workspace_bytes_impl(const rs_ctx* ctx, int B, int t_max) { return k2_plan(ctx, B, t_max > 9 ? t_max : 9).total; }
+size_t rs_k2_workspace_bytes_impl(const rs_ctx* ctx, int B, int t_max) {
+    const size_t a = k2_plan(ctx, B, t_max > 9 ? t_max : 9).total;
+    if (!ctx->has_f32) return a;                      // the float32 parity mode keeps float32 activations: about twice the scratch
+    const size_t b = k2_plan_f32(ctx, B, t_max > 9 ? t_max : 9).total;
+    return a > b ? a : b;
+}
+
+static int rs_k2_encoder_forward_f32(rs_ctx* ctx, const float* feats, const int32_t* n_frames, int B, int t_max, float* enc_out, float* joint_enc,
+                                     int32_t* enc_lens, void* workspace, size_t workspace_bytes, hipStream_t s);
 
 int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n_frames, int B, int t_max, float* enc_out, float* joint_enc,
                                int32_t* enc_lens, void* workspace, size_t workspace_bytes, hipStream_t s) {
     rs_k2& k = *ctx->k2;
     const rs_k2_dims& d = k.d;
     if (t_max < 9) return rs_fail(ctx, RS_EINVAL, "zipformer: %d feature frames are too few for encoder_embed (9 are needed)", t_max);
+    if (ctx->precision_f32) return rs_k2_encoder_forward_f32(ctx, feats, n_frames, B, t_max, enc_out, joint_enc, enc_lens, workspace, workspace_bytes, s);
     const K2Plan pl = k2_plan(ctx, B, t_max);
     if (workspace_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "zipformer: workspace %zu < %zu", workspace_bytes, pl.total);
     char* ws = reinterpret_cast<char*>(workspace);
@@ -1027,6 +1348,137 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
     RS_CHECK_LAUNCH(ctx, "zipformer output");
     RS_TRY(gemm(encb, k.out_dim, ctx->jenc_w, k.out_dim, joint_enc, d.joiner_dim, (long long)B * To, d.joiner_dim, RS_GEMM_BIAS | RS_GEMM_OUT_F32, ctx->jenc_b,
                 nullptr));
+#undef RS_TRY
+    return RS_OK;
+}
+
+// The float32 encoder: the call sequence of rs_k2_encoder_forward_impl with float32 operands everywhere (oracle/zipformer.py with
+// recipe "fp32" is its line-by-line counterpart).
+static int rs_k2_encoder_forward_f32(rs_ctx* ctx, const float* feats, const int32_t* n_frames, int B, int t_max, float* enc_out, float* joint_enc,
+                                     int32_t* enc_lens, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    rs_k2& k = *ctx->k2;
+    const rs_k2_dims& d = k.d;
+    const K2PlanF32 pl = k2_plan_f32(ctx, B, t_max);
+    if (workspace_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "zipformer (float32 mode): workspace %zu < %zu", workspace_bytes, pl.total);
+    char* ws = reinterpret_cast<char*>(workspace);
+    auto fp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    int32_t* lens_all = reinterpret_cast<int32_t*>(ws + pl.off_lens);
+    const int32_t* lens3 = lens_all;
+    float *a0 = fp(pl.off_a0), *a1 = fp(pl.off_a1), *col = fp(pl.off_col), *a2 = fp(pl.off_a2), *dwo = fp(pl.off_dwo), *hbuf = fp(pl.off_h);
+    float *x = fp(pl.off_x), *x0 = fp(pl.off_x0), *src = fp(pl.off_src), *qkp = fp(pl.off_qkp), *W = fp(pl.off_w), *big = fp(pl.off_big);
+    float *av = fp(pl.off_av), *gate = fp(pl.off_gate), *encf = enc_out ? enc_out : fp(pl.off_enc);
+    const int c1 = d.embed_c1, c2 = d.embed_c2, c3 = d.embed_c3, T3 = pl.T3, F3 = pl.F3;
+    int rc;
+#define RS_TRY(call) do { rc = (call); if (rc != RS_OK) return rc; } while (0)
+    auto gemm = [&](const float* A, int lda, const float* Wt, int K, float* out, int ldc, long long M, int N, int flags, const float* bias,
+                    const float* res) -> int {
+        return rs_launch_gemm_f32(ctx, A, lda, Wt, K, out, ldc, (int)M, N, K, flags, bias, 1.0f, res, nullptr, 0, 0, s);
+    };
+    const int RES = RS_GEMM_BIAS | RS_GEMM_RESIDUAL;
+    hipLaunchKernelGGL(k2_lens_kernel, dim3((B + 255) / 256), dim3(256), 0, s, n_frames, B, d.n_stacks, d.downsampling[0], d.downsampling[1],
+                       d.downsampling[2], d.downsampling[3], d.downsampling[4], d.downsampling[5], d.downsampling[6], d.downsampling[7], lens_all);
+    // ---- encoder_embed
+    const long long rows3 = (long long)B * T3 * F3, M3 = (long long)B * T3;
+    if (rows3 > 0x7fffffffLL / 4) return rs_fail(ctx, RS_EINVAL, "zipformer (float32 mode): %lld patch rows exceed the float32 GEMM's row count", rows3);
+    hipLaunchKernelGGL(k2f_conv0_kernel, dim3(pl.T1, B), dim3(256), 0, s, feats, t_max, pl.F, c1, k.conv0_w, k.conv0_b, a0);
+    hipLaunchKernelGGL(k2f_conv1_kernel, dim3(pl.T2, B), dim3(256), 0, s, a0, pl.T1, pl.F, c1, pl.T2, pl.F2, c2, k.conv1_w, k.conv1_b, a1);
+    const int Kc = pad32(9 * c2);
+    hipLaunchKernelGGL(k2f_im2col_kernel, dim3((unsigned)((rows3 + 3) / 4)), dim3(256), 0, s, a1, pl.T2, pl.F2, c2, T3, F3, Kc, rows3, col);
+    RS_CHECK_LAUNCH(ctx, "zipformer (float32 mode) encoder_embed convs");
+    RS_TRY(gemm(col, Kc, k.conv2_w32, Kc, a2, c3, rows3, c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHR, k.conv2_b, nullptr));
+    hipLaunchKernelGGL(k2f_cnx_dw_kernel, dim3(T3, B), dim3(256), 0, s, a2, lens3, T3, F3, c3, k.cnx_dw_w, k.cnx_dw_b, dwo);
+    RS_TRY(gemm(dwo, c3, k.cnx_pw1_w32, c3, hbuf, 3 * c3, rows3, 3 * c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHL, k.cnx_pw1_b, nullptr));
+    RS_TRY(gemm(hbuf, 3 * c3, k.cnx_pw2_w32, 3 * c3, a2, c3, rows3, c3, RES, k.cnx_pw2_b, a2));
+    const int d0 = d.encoder_dim[0];
+    float* emb = x0;
+    RS_TRY(gemm(a2, F3 * c3, k.emb_out_w32, F3 * c3, emb, d0, M3, d0, RS_GEMM_BIAS, k.emb_out_b, nullptr));
+    hipLaunchKernelGGL(k2_biasnorm_kernel, dim3((unsigned)((M3 + 3) / 4)), dim3(256), 0, s, emb, k.emb_norm_bias, k.emb_norm_scale, (const float*)nullptr,
+                       (const float*)nullptr, (int)M3, d0, emb, (uint16_t*)nullptr);
+    if (k.tap_embed) RS_HIP(ctx, hipMemcpyAsync(k.tap_embed, emb, (size_t)M3 * d0 * 4, hipMemcpyDeviceToDevice, s));
+    RS_CHECK_LAUNCH(ctx, "zipformer (float32 mode) encoder_embed");
+    // ---- the stacks
+    const float* prev = emb;
+    int d_prev = d0;
+    size_t tap_off = 0;
+    for (int st = 0; st < d.n_stacks; ++st) {
+        const int dd = d.encoder_dim[st], H = d.num_heads[st], ds = d.downsampling[st], Ts = pl.Ts[st], Tp = pl.Tp[st], kk = d.cnn_kernel[st];
+        const int hid = 3 * dd / 4, hidp = pad32(hid), vw = H * K2_VD, vwp = pad32(vw), nin = (2 * K2_QD + K2_PD) * H;
+        const int32_t* lens = lens_all + (size_t)(1 + st) * B;
+        const long long M = (long long)B * Ts;
+        float* stack_out = fp(pl.off_stackout[st]);
+        float* cur = x;
+        float* nxt = x0;
+        if (Ts > k.pos_cap) return rs_fail(ctx, RS_EINVAL, "zipformer: %d frames exceed the registered position tables (%d)", Ts, k.pos_cap);
+        hipLaunchKernelGGL(k2_stack_in_kernel, dim3(Ts, B), dim3(256), 0, s, prev, d_prev, lens3, T3, dd, ds, Ts, k.ds_w[st], ds == 1 ? (float*)nullptr : src, cur);
+        for (int j = 0; j < d.num_layers[st]; ++j) {
+            const rs_k2_layer& L = k.stacks[st][j];
+            const rs_k2_layer32& L32 = k.stacks32[st][j];
+            const size_t n = (size_t)M * dd;
+            const bool last = j == d.num_layers[st] - 1;
+            float* xs = nxt;
+            // attention weights from the layer's input
+            RS_TRY(gemm(cur, dd, L32.attw_in_w, dd, qkp, nin, M, nin, RS_GEMM_BIAS, L.attw_in_b, nullptr));
+            hipLaunchKernelGGL(k2f_attn_weights_kernel, dim3((Ts + 3) / 4, H, B), dim3(256), 0, s, qkp, nin, L.pos_proj, k.pos_cap, H, lens, Ts, Tp, W);
+            auto ffn = [&](int f, int width, const float* in, const float* res) -> int {
+                if (int r = gemm(in, dd, L32.ff_in_w[f], dd, big, width, M, width, RS_GEMM_BIAS | RS_GEMM_SWOOSHL, L.ff_in_b[f], nullptr); r != RS_OK) return r;
+                return gemm(big, width, L32.ff_out_w[f], width, xs, dd, M, dd, RES, L.ff_out_b[f], res);
+            };
+            auto self_attn = [&](int a) -> int {
+                if (int r = gemm(xs, dd, L32.sa_in_w[a], dd, big, vw, M, vw, RS_GEMM_BIAS, L.sa_in_b[a], nullptr); r != RS_OK) return r;
+                if (vwp != vw && hipMemsetAsync(av, 0, (size_t)M * vwp * 4, s) != hipSuccess) return rs_fail(ctx, RS_EHIP, "memset failed");
+                hipLaunchKernelGGL(k2f_pv_kernel, dim3(Ts, B), dim3((vw + 63) / 64 * 64), 0, s, W, H, Tp, big, vw, lens, Ts, av, vwp);
+                return gemm(av, vwp, L32.sa_out_w[a], vwp, xs, dd, M, dd, RES, L.sa_out_b[a], xs);
+            };
+            auto conv_module = [&](int a) -> int {
+                if (int r = gemm(xs, dd, L32.cm_in_w[a], dd, big, 2 * dd, M, 2 * dd, RS_GEMM_BIAS, L32.cm_in_b[a], nullptr); r != RS_OK) return r;
+                hipLaunchKernelGGL(k2f_glu_dwconv_swoosh_kernel, dim3((dd + 255) / 256, Ts, B), dim3(256), 0, s, big, L.cm_dw_w[a], L.cm_dw_b[a], lens, Ts, dd, kk, av);
+                return gemm(av, dd, L32.cm_out_w[a], dd, xs, dd, M, dd, RES, L.cm_out_b[a], xs);
+            };
+            RS_TRY(ffn(0, d.ff_dim[st] * 3 / 4, cur, cur));         // xs = cur + ff1(cur)
+            // non-linear attention
+            RS_TRY(gemm(xs, dd, L32.na_in_w, dd, big, 3 * hid, M, 3 * hid, RS_GEMM_BIAS, L.na_in_b, nullptr));
+            if (hidp != hid) RS_HIP(ctx, hipMemsetAsync(av, 0, (size_t)M * hidp * 4, s));
+            hipLaunchKernelGGL(k2f_na_gate_kernel, dim3((unsigned)(((size_t)M * hid + 255) / 256)), dim3(256), 0, s, big, hid, (size_t)M, gate);
+            hipLaunchKernelGGL(k2f_na_pv_kernel, dim3((hid + 255) / 256, (Ts + 3) / 4, B), dim3(256), 0, s, W, H, Tp, gate, big, hid, lens, Ts, av, hidp);
+            RS_TRY(gemm(av, hidp, L32.na_out_w, hidp, xs, dd, M, dd, RES, L.na_out_b, xs));
+            RS_TRY(self_attn(0));
+            RS_TRY(conv_module(0));
+            RS_TRY(ffn(1, d.ff_dim[st], xs, xs));
+            hipLaunchKernelGGL(k2_bypass_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, xs, cur, L.bypass_mid, dd, n / 4, (uint16_t*)nullptr);
+            RS_TRY(self_attn(1));
+            RS_TRY(conv_module(1));
+            RS_TRY(ffn(2, d.ff_dim[st] * 5 / 4, xs, xs));
+            float* dst = (last && ds == 1) ? stack_out : xs;
+            hipLaunchKernelGGL(k2_biasnorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, xs, L.norm_bias, L.norm_scale, cur, L.bypass, (int)M, dd, dst,
+                               (uint16_t*)nullptr);
+            RS_CHECK_LAUNCH(ctx, "zipformer (float32 mode) layer");
+            nxt = cur;
+            cur = xs;
+        }
+        if (ds > 1) hipLaunchKernelGGL(k2_stack_out_kernel, dim3(T3, B), dim3(256), 0, s, src, cur, T3, Ts, dd, ds, k.comb_scale[st], stack_out);
+        if (k.tap_stacks) {
+            RS_HIP(ctx, hipMemcpyAsync(k.tap_stacks + tap_off, stack_out, (size_t)M3 * dd * 4, hipMemcpyDeviceToDevice, s));
+            tap_off += (size_t)M3 * dd;
+        }
+        prev = stack_out;
+        d_prev = dd;
+    }
+    K2Pieces pc{};
+    {
+        int n = 0, cur_dim = d.encoder_dim[d.n_stacks - 1];
+        pc.p[n] = fp(pl.off_stackout[d.n_stacks - 1]); pc.c0[n] = 0; pc.n[n] = cur_dim; pc.ld[n] = cur_dim; ++n;
+        for (int st = d.n_stacks - 2; st >= 0; --st) {
+            const int dd = d.encoder_dim[st];
+            if (dd > cur_dim) {
+                pc.p[n] = fp(pl.off_stackout[st]); pc.c0[n] = cur_dim; pc.n[n] = dd - cur_dim; pc.ld[n] = dd; ++n;
+                cur_dim = dd;
+            }
+        }
+        pc.count = n;
+    }
+    hipLaunchKernelGGL(k2_output_kernel, dim3(pl.To, B), dim3(256), 0, s, pc, lens3, T3, pl.To, k.out_dim, k.out_ds_w, encf, (uint16_t*)nullptr, enc_lens);
+    RS_CHECK_LAUNCH(ctx, "zipformer (float32 mode) output");
+    RS_TRY(gemm(encf, k.out_dim, k.jenc_w32, k.out_dim, joint_enc, d.joiner_dim, (long long)B * pl.To, d.joiner_dim, RS_GEMM_BIAS, ctx->jenc_b, nullptr));
 #undef RS_TRY
     return RS_OK;
 }

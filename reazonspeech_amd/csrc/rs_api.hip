@@ -317,6 +317,12 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return RS_EINVAL;
     if (!strcmp(key, "decode_screen")) { ctx->decode_screen = value != 0; return RS_OK; }
     if (!strcmp(key, "decode_narrow")) { ctx->decode_narrow = value != 0; return RS_OK; }
+    if (!strcmp(key, "precision_f32")) {
+        if (value && !ctx->has_f32)
+            return rs_fail(ctx, RS_EMISSING, "precision_f32: the float32 weights (\"*.f32\" tensors) are not registered / rs_finalize has not run");
+        ctx->precision_f32 = value != 0;
+        return RS_OK;
+    }
     if (ctx->k2) return rs_fail(ctx, RS_EINVAL, "option '%s' does not apply to a Zipformer context", key);
     if (!strcmp(key, "fuse_glu")) {
         if (value < 0 || value > 1) return rs_fail(ctx, RS_EINVAL, "fuse_glu must be 0 or 1");
@@ -324,17 +330,12 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
         return RS_OK;
     }
     if (!strcmp(key, "defer_out_norm")) { ctx->defer_out_norm = value != 0; return RS_OK; }
-    if (!strcmp(key, "precision_f32")) {
-        if (value && !ctx->has_f32)
-            return rs_fail(ctx, RS_EMISSING, "precision_f32: the float32 weights (\"*.f32\" tensors) are not registered / rs_finalize has not run");
-        ctx->precision_f32 = value != 0;
-        return RS_OK;
-    }
     return rs_fail(ctx, RS_EINVAL, "unknown option '%s'", key);
 }
 
 int rs_encoder_set_taps(rs_ctx* ctx, float* sub_out, float* layer_out, const int32_t* layer_ids, int n_layer_ids) {
     if (!ctx) return RS_EINVAL;
+    if (ctx->k2) return rs_fail(ctx, RS_EINVAL, "taps: a Zipformer context takes rs_k2_encoder_set_taps");
     if (n_layer_ids < 0 || (n_layer_ids > 0 && (!layer_out || !layer_ids))) return rs_fail(ctx, RS_EINVAL, "taps: null pointer");
     for (int i = 0; i < n_layer_ids; ++i)
         if (layer_ids[i] < 0 || layer_ids[i] >= ctx->d.n_layers) return rs_fail(ctx, RS_EINVAL, "taps: layer %d out of range", layer_ids[i]);
@@ -357,6 +358,7 @@ int rs_enc_frames(const rs_ctx* ctx, int n) {
 
 int rs_encoder_set_ctc_out(rs_ctx* ctx, float* probs, float* blank_prob) {
     if (!ctx) return RS_EINVAL;
+    if (ctx->k2 && (probs || blank_prob)) return rs_fail(ctx, RS_EINVAL, "a Zipformer context has no CTC head");
     if ((probs || blank_prob) && ctx->d.ctc_vocab <= 0) return rs_fail(ctx, RS_EINVAL, "this model has no CTC head (rs_dims.ctc_vocab)");
     ctx->ctc_probs = probs;
     ctx->ctc_blank = blank_prob;
@@ -674,6 +676,7 @@ int rs_rnnt_alsd(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, i
                  int32_t* n_ids, float* scores, void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx) return RS_EINVAL;
     if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_rnnt_alsd");
+    if (ctx->k2) return rs_fail(ctx, RS_EINVAL, "alsd: a Zipformer context has a stateless decoder; only rs_rnnt_greedy applies (sherpa-onnx greedy_search)");
     if (B < 0 || tp_max < 0 || out_cap < 0) return rs_fail(ctx, RS_EINVAL, "alsd: negative size");
     if (max_target_abs < 0 && !(max_target_ratio >= 0.0 && max_target_ratio <= 64.0))
         return rs_fail(ctx, RS_EINVAL, "alsd: max_target_ratio must be in [0, 64]");
@@ -699,6 +702,7 @@ int rs_rnnt_beam(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_lens, i
                  size_t workspace_bytes, void* stream) {
     if (!ctx) return RS_EINVAL;
     if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_rnnt_beam");
+    if (ctx->k2) return rs_fail(ctx, RS_EINVAL, "beam search: a Zipformer context has a stateless decoder; only rs_rnnt_greedy applies (sherpa-onnx greedy_search)");
     if (B < 0 || tp_max < 0 || out_cap < 0 || max_pops < 0) return rs_fail(ctx, RS_EINVAL, "beam search: negative size");
     if (beam < 1) return rs_fail(ctx, RS_EINVAL, "beam search: beam size must be >= 1");
     if (B == 0) return RS_OK;

@@ -51,6 +51,10 @@ __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))); }
 __device__ __forceinline__ float swoosh_l_f(float x) { return softplus_f(x - 4.0f) - 0.08f * x - 0.035f; }
 __device__ __forceinline__ float swoosh_r_f(float x) { return softplus_f(x - 1.0f) - 0.08f * x - 0.313261687f; }
+// the same in IEEE arithmetic (float32 parity mode): torch's F.softplus (log1p(exp(x)), identity above the threshold 20)
+__device__ __forceinline__ float softplus_exact(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float swoosh_l_exact(float x) { return softplus_exact(x - 4.0f) - 0.08f * x - 0.035f; }
+__device__ __forceinline__ float swoosh_r_exact(float x) { return softplus_exact(x - 1.0f) - 0.08f * x - 0.313261687f; }
 
 // ----------------------------------------------------------------------------------------
 // host side: context

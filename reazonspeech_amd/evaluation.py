@@ -190,3 +190,29 @@ class RSEspnetAmdEvaluator(RSAmdEvaluator):
     def _transcribe_batch(model, audios, config=None):
         from .espnet.asr import transcribe_batch as tb
         return tb(model, audios, config)
+
+
+class RSK2AmdEvaluator(RSAmdEvaluator):
+    """Counterpart of `RSK2Evaluator` (pkg/evaluation/examples/rs-k2/eval.py:15-33) over `reazonspeech.k2.asr` of this package:
+    `_evaluate` is the reference's hook (load on cuda:{rank % num_gpus}, `transcribe(model, audio).text`), `_evaluate_batch` —
+    which the reference leaves unimplemented (:32-33) — recognises the whole batch through `transcribe_batch`."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from .k2.asr import TranscribeConfig as K2Config
+        self.config = K2Config(verbose=False)
+
+    @staticmethod
+    def _load_model(device=None):
+        from .k2.asr import load_model as lm
+        return lm(device=device)
+
+    @staticmethod
+    def _transcribe(model, audio, config=None):
+        from .k2.asr import transcribe as tr
+        return tr(model, audio, config)
+
+    @staticmethod
+    def _transcribe_batch(model, audios, config=None):
+        from .k2.asr import transcribe_batch as tb
+        return tb(model, audios, config)

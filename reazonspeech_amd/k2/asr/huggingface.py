@@ -35,28 +35,28 @@ def repo_files(language, precision):
     return repo, files[precision]
 
 
+SYNTHETIC_ENV = "REAZONSPEECH_AMD_SYNTHETIC"
+
+
 def resolve_checkpoint(language, precision, checkpoint=None):
     """directory holding the four files: the argument, $REAZONSPEECH_K2_CHECKPOINT, the Hugging Face cache
-    (`snapshot_download(local_files_only=True)`, :68-69), then the hub (:70-71) unless HF_HUB_OFFLINE; None when all fail"""
+    (`snapshot_download(local_files_only=True)`, :68-69), then the hub (:70-71).  Like the reference, a failed lookup RAISES
+    (a missing `huggingface_hub`, no cache entry while offline, a network / authentication error, a partial download): a
+    caller with a transient hub error must not get a model with made-up weights."""
     repo, files = repo_files(language, precision)
     for cand in (checkpoint, os.environ.get(CHECKPOINT_ENV)):
         if cand:
             if not os.path.isdir(cand):
                 raise FileNotFoundError(f"checkpoint directory {cand!r} does not exist")
             return cand, files
+    import huggingface_hub as hf
     try:
-        import huggingface_hub as hf
-        try:
-            return hf.snapshot_download(repo, local_files_only=True), files
-        except Exception:
-            if os.environ.get("HF_HUB_OFFLINE", "0") not in ("", "0"):
-                return None, files
-            return hf.snapshot_download(repo), files
-    except Exception:
-        return None, files
+        return hf.snapshot_download(repo, local_files_only=True), files
+    except hf.utils.LocalEntryNotFoundError:
+        return hf.snapshot_download(repo), files
 
 
-def load_model(device=None, precision="fp32", language="ja", checkpoint=None, config=None, seed=0):
+def load_model(device=None, precision="fp32", language="ja", checkpoint=None, config=None, seed=0, compute="bf16", synthetic=False):
     """Load the ReazonSpeech k2 model onto a ROCm GPU (huggingface.py:16-83).
 
     Args:
@@ -67,7 +67,18 @@ def load_model(device=None, precision="fp32", language="ja", checkpoint=None, co
       language (str): "ja", "ja-en" or "ja-en-mls-5k" (:26-38)
       checkpoint (str): directory with tokens.txt and the three ONNX files (default: $REAZONSPEECH_K2_CHECKPOINT, then the
         Hugging Face cache, then the hub)
-      config (ZipformerConfig), seed: architecture / seed of SYNTHETIC weights when no checkpoint can be found
+      config (ZipformerConfig), seed, synthetic: SEEDED SYNTHETIC weights are loaded only on request — `config=` (an architecture),
+        `synthetic=True` or $REAZONSPEECH_AMD_SYNTHETIC=1 (benchmarks, tests: timings are valid, transcripts meaningless).  Without
+        such a request a checkpoint that cannot be found or downloaded raises, as `hf.snapshot_download` does in the reference.
+      compute (str): "bf16" (default): the throughput mode — bf16 matrix-core operands, float32 accumulation and residual stream,
+        exact float32 decode.  "fp32": the parity mode — float32 weights, activations and arithmetic end to end, i.e. what
+        onnxruntime computes from the reference's default float32 graphs; greedy ids identical to the float32 oracle, ~6x slower.
+        (`precision` keeps the reference's meaning: WHICH files are read.)
+
+    A real icefall export has never been read by runtime/k2_onnx.py (no file is reachable from the build environment): the reader
+    is verified against files written in the documented export layout only, and checks itself after loading (every expected
+    tensor found exactly once, parameter count == cfg.n_params(), folded softmax constants summing to 1) — treat a first real
+    checkpoint as UNVERIFIED until one transcript has been compared with sherpa-onnx.
 
     Returns:
       K2Model (answers sherpa_onnx.OfflineRecognizer's create_stream / decode_stream)
@@ -83,7 +94,13 @@ def load_model(device=None, precision="fp32", language="ja", checkpoint=None, co
                            "(use the reference package for those)")
     if not torch.cuda.is_available():
         raise RuntimeError("reazonspeech_amd needs a ROCm GPU: torch.cuda.is_available() is False")
-    basedir, files = (None, None) if config is not None else resolve_checkpoint(language, precision, checkpoint)
+    if compute not in ("bf16", "fp32"):
+        raise ValueError(f"compute must be 'bf16' or 'fp32', not {compute!r}")
+    want_synthetic = config is not None or synthetic or os.environ.get(SYNTHETIC_ENV, "0") not in ("", "0")
+    if want_synthetic and not checkpoint:
+        basedir, files = None, None
+    else:
+        basedir, files = resolve_checkpoint(language, precision, checkpoint)
     if basedir:
         from ...runtime.k2_onnx import read_k2_onnx
         cfg, sd = read_k2_onnx(os.path.join(basedir, files["encoder"]), os.path.join(basedir, files["decoder"]), os.path.join(basedir, files["joiner"]))
@@ -91,10 +108,8 @@ def load_model(device=None, precision="fp32", language="ja", checkpoint=None, co
         if len(tokens) != cfg.vocab_size:
             raise ValueError(f"tokens.txt has {len(tokens)} symbols, the joiner {cfg.vocab_size} outputs")
         cfg = cfg.with_(unk_id=tokens.index("<unk>") if "<unk>" in tokens else -1)
-        return K2Model(cfg, sd, tokens, device=device)
+        return K2Model(cfg, sd, tokens, device=device, precision=compute)
     cfg = config or ZIPFORMER_159M
-    if config is None:
-        print(f"[reazonspeech_amd] WARNING: no k2 checkpoint found (argument `checkpoint`, ${CHECKPOINT_ENV}, Hugging Face cache / hub of "
-              f"{REPOS[language][0]}) — loading SEEDED SYNTHETIC weights of the 159M Zipformer architecture: timings are valid, "
-              "transcripts are meaningless.", file=sys.stderr, flush=True)
-    return K2Model(cfg, synthetic_state_dict_k2(cfg, seed), synthetic_tokens(cfg.vocab_size, seed), device=device)
+    print(f"[reazonspeech_amd] WARNING: SEEDED SYNTHETIC weights of the {cfg.n_params() / 1e6:.0f}M Zipformer architecture were requested "
+          f"(`config=` / `synthetic=True` / ${SYNTHETIC_ENV}): timings are valid, transcripts are meaningless.", file=sys.stderr, flush=True)
+    return K2Model(cfg, synthetic_state_dict_k2(cfg, seed), synthetic_tokens(cfg.vocab_size, seed), device=device, precision=compute)

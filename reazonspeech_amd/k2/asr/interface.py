@@ -20,8 +20,9 @@ class AudioData:
 
 @dataclass
 class Subword:
-    """One emitted token and the single point in time, in seconds of the ORIGINAL audio (the 0.9 s of leading padding already
-    subtracted), at which the transducer emitted it (interface.py:10-14; transcribe.py:43)."""
+    """One emitted token and the single point in time at which the transducer emitted it, in seconds of the PADDED audio the
+    recogniser saw: like the reference, the 0.9 s of leading padding (transcribe.py:7,31-33) is NOT subtracted
+    (interface.py:10-14; transcribe.py:43)."""
     seconds: float
     token: str
 

@@ -5,7 +5,7 @@ calls the reference makes on it (transcribe.py:36-45):
     stream = model.create_stream(); stream.accept_waveform(samplerate, waveform); model.decode_stream(stream)
     stream.result.tokens / .timestamps / .text
 plus the batched form `decode_streams` (sherpa-onnx has it too).  [UPSTREAM] conventions of sherpa-onnx's result conversion
-(offline-recognizer-transducer-impl.h Convert, symbol-table.cc): a token's text is its tokens.txt symbol with U+2581 replaced by
+(offline-recognizer-transducer-impl.h Convert, symbol-table.cc): a token's text is its tokens.txt symbol with a leading U+2581 replaced by
 a space and `<0xNN>` byte tokens joined into UTF-8; text = the tokens concatenated; timestamp = frame index x 0.04 s."""
 import re
 
@@ -59,12 +59,14 @@ def synthetic_tokens(vocab_size, seed=0):
 
 
 class K2Model:
-    def __init__(self, cfg, state_dict, tokens, device="cuda", pad_seconds=0.0):
+    def __init__(self, cfg, state_dict, tokens, device="cuda", pad_seconds=0.0, precision="bf16"):
+        """precision: "bf16" = the throughput mode; "fp32" = float32 weights, activations and arithmetic end to end (what
+        onnxruntime computes from the reference's default float32 graphs: pkg/k2-asr/src/huggingface.py:16,40-45)"""
         assert cfg.family == "k2" and len(tokens) == cfg.vocab_size
         self.cfg = cfg
         self.tokens = list(tokens)
         # the reference pads with np.pad before handing the samples over (transcribe.py:24); a stream's samples arrive padded
-        self.am = AsrModel(cfg, state_dict, None, device=device, pad_seconds=pad_seconds)
+        self.am = AsrModel(cfg, state_dict, None, device=device, pad_seconds=pad_seconds, precision=precision)
         self.device = self.am.device
 
     # ---- sherpa-onnx's surface ------------------------------------------------------------------------------------------
@@ -84,7 +86,9 @@ class K2Model:
 
     # ---- result conversion ------------------------------------------------------------------------------------------------
     def symbol(self, i):
-        return self.tokens[i].replace("▁", " ")
+        """[UPSTREAM] sherpa-onnx SymbolTable: only a LEADING U+2581 (the SentencePiece word boundary) becomes a space"""
+        s = self.tokens[i]
+        return " " + s[1:] if s.startswith("▁") else s
 
     def convert(self, ids, frames):
         syms = [self.symbol(i) for i in ids]

@@ -148,7 +148,7 @@ class ZipformerConfig:
         assert self.n_fft == 512 and self.frame_length <= 512 and self.n_mels <= 128
         assert all(d % 64 == 0 for d in self.encoder_dim), "encoder_dim % 64 (GEMM K tiles)"
         assert all(f % 256 == 0 for f in self.ff_dim), "feedforward_dim % 256 (3/4 and 5/4 of it are GEMM K extents)"
-        assert all(k % 2 == 1 and k <= 31 for k in self.cnn_kernel)
+        assert all(k in (7, 15, 31) for k in self.cnn_kernel), "cnn_module_kernel: the depthwise kernels are built for 7 / 15 / 31 taps"
         assert all(ds in (1, 2, 4, 8) for ds in self.downsampling) and self.downsampling[0] == 1
         assert self.query_head_dim == 32 and self.pos_head_dim == 4 and self.value_head_dim == 12, "the attention kernels are built for head dims 32 / 4 / 12"
         assert self.output_downsampling == 2 and self.context_size == 2

@@ -22,7 +22,7 @@ import torch
 from . import onnx_lite
 from .config import UnsupportedCheckpoint
 from .k2_config import ZipformerConfig
-from .k2_weights import layer_prefix
+from .k2_weights import expected_shapes_k2
 
 _RENAME = (("encoder_proj.", "joiner.encoder_proj."), ("decoder_proj.", "joiner.decoder_proj."), ("output_linear.", "joiner.output_linear."))
 
@@ -40,7 +40,18 @@ def _canonical(key):
     return key
 
 
-def _collect(model, sd):
+def _put(sd, seen, key, value):
+    """first occurrence wins (the same folded constant may appear at several nodes), a SECOND DIFFERENT value for one key is a
+    layout this reader does not understand: refuse instead of loading a wrongly matched constant"""
+    seen[key] = seen.get(key, 0) + 1
+    if key in sd:
+        if tuple(sd[key].shape) != tuple(value.shape) or not torch.equal(sd[key], value):
+            raise UnsupportedCheckpoint(f"two different constants in the ONNX graph map to {key!r} (export layout differs from what this reader expects)")
+        return
+    sd[key] = value
+
+
+def _collect(model, sd, seen):
     if any(n.op_type in ("DynamicQuantizeLinear", "MatMulInteger", "QLinearMatMul", "ConvInteger", "DequantizeLinear") for n in model.nodes):
         raise UnsupportedCheckpoint("a quantized (int8) ONNX graph: only the float32 files are read")
     init = model.initializers
@@ -53,21 +64,24 @@ def _collect(model, sd):
             continue
         scope = _canonical(_scope(n.name) + ".")[:-1]
         if n.op_type == "MatMul" and len(n.inputs) == 2 and n.inputs[1] in init and init[n.inputs[1]].ndim == 2:
-            sd.setdefault(scope + ".weight", torch.from_numpy(np.array(init[n.inputs[1]]).T.copy()))
+            _put(sd, seen, scope + ".weight", torch.from_numpy(np.array(init[n.inputs[1]]).T.copy()))
         elif n.op_type == "Gemm" and len(n.inputs) >= 2 and n.inputs[1] in init:
-            sd.setdefault(scope + ".weight", torch.from_numpy(np.array(init[n.inputs[1]])))
+            _put(sd, seen, scope + ".weight", torch.from_numpy(np.array(init[n.inputs[1]])))
             if len(n.inputs) > 2 and n.inputs[2] in init:
-                sd.setdefault(scope + ".bias", torch.from_numpy(np.array(init[n.inputs[2]])))
-        elif n.op_type == "Add" and scope + ".weight" in sd and scope + ".bias" not in sd:
+                _put(sd, seen, scope + ".bias", torch.from_numpy(np.array(init[n.inputs[2]])))
+        elif n.op_type == "Add" and scope + ".weight" in sd:
             c = init[consts[0]]
             if c.ndim == 1 and c.shape[0] == sd[scope + ".weight"].shape[0]:
-                sd[scope + ".bias"] = torch.from_numpy(np.array(c))
+                _put(sd, seen, scope + ".bias", torch.from_numpy(np.array(c)))
         elif n.op_type == "Mul":
             c = init[consts[0]]
-            if (scope.endswith("norm") or scope.endswith("out_norm")) and c.size == 1 and float(c.reshape(-1)[0]) > 0 and scope + ".log_scale" not in sd:
-                sd[scope + ".log_scale"] = torch.tensor(math.log(float(c.reshape(-1)[0])), dtype=torch.float32)
+            if (scope.endswith("norm") or scope.endswith("out_norm")) and c.size == 1 and float(c.reshape(-1)[0]) > 0:
+                _put(sd, seen, scope + ".log_scale", torch.tensor(math.log(float(c.reshape(-1)[0])), dtype=torch.float32))
             elif (scope.endswith("downsample") or scope.endswith("downsample_output")) and c.ndim >= 1 and c.size in (2, 4, 8) and np.all(c > 0):
-                sd.setdefault(scope + ".bias", torch.from_numpy(np.log(np.array(c, np.float64).reshape(-1)).astype(np.float32)))
+                total = float(np.array(c, np.float64).sum())
+                if abs(total - 1.0) > 1e-4:
+                    raise UnsupportedCheckpoint(f"the constant under {scope!r} sums to {total:.6f}: not a folded softmax(bias) (export layout differs)")
+                _put(sd, seen, scope + ".bias", torch.from_numpy(np.log(np.array(c, np.float64).reshape(-1)).astype(np.float32)))
 
 
 def derive_config(sd) -> ZipformerConfig:
@@ -108,57 +122,38 @@ def layer_prefix_from(dss, s):
     return f"encoder.encoders.{s}." + ("" if dss[s] == 1 else "encoder.") + "layers.0."
 
 
+def self_check(cfg, sd):
+    """what a wrongly matched constant cannot survive: the recovered keys are EXACTLY the keys of an icefall Zipformer2 transducer
+    of the derived architecture, every shape agrees, the parameter count equals cfg.n_params(), BiasNorm log-scales and bypass
+    scales are finite and in the range training keeps them in ([UPSTREAM] scaling.py: log_scale limited to +-1.5, bypass_scale
+    to [0, 1] with slack)."""
+    want = expected_shapes_k2(cfg)
+    missing, extra = sorted(set(want) - set(sd)), sorted(set(sd) - set(want))
+    if missing or extra:
+        raise UnsupportedCheckpoint(f"the ONNX files do not map onto an icefall Zipformer2 transducer of the derived architecture: "
+                                    f"{len(missing)} tensor(s) not found ({', '.join(missing[:4])}{' ...' if len(missing) > 4 else ''}), "
+                                    f"{len(extra)} unexpected ({', '.join(extra[:4])}{' ...' if len(extra) > 4 else ''})")
+    for k, shp in want.items():
+        if tuple(sd[k].shape) != shp:
+            raise UnsupportedCheckpoint(f"tensor {k!r} has shape {tuple(sd[k].shape)}, the derived architecture needs {shp}")
+        if not bool(torch.isfinite(sd[k]).all()):
+            raise UnsupportedCheckpoint(f"tensor {k!r} holds non-finite values")
+    n = sum(int(v.numel()) for v in sd.values())
+    if n != cfg.n_params():
+        raise UnsupportedCheckpoint(f"{n} parameters recovered, the derived architecture has {cfg.n_params()}")
+    for k, v in sd.items():
+        if k.endswith(".log_scale") and abs(float(v)) > 4.0:
+            raise UnsupportedCheckpoint(f"{k!r} = {float(v):.3f}: not a BiasNorm log-scale (a wrongly matched Mul constant?)")
+        if k.endswith(".bypass_scale") and (float(v.min()) < -0.5 or float(v.max()) > 1.5):
+            raise UnsupportedCheckpoint(f"{k!r} outside [-0.5, 1.5]: not a bypass scale")
+
+
 def read_k2_onnx(encoder_path, decoder_path, joiner_path):
-    """-> (ZipformerConfig, icefall-style state dict)"""
-    sd = {}
+    """-> (ZipformerConfig, icefall-style state dict), checked by `self_check`.  UNVERIFIED against a real export (module
+    docstring): compare one transcript with sherpa-onnx before trusting a first real checkpoint."""
+    sd, seen = {}, {}
     for path in (encoder_path, decoder_path, joiner_path):
-        _collect(onnx_lite.load(path), sd)
+        _collect(onnx_lite.load(path), sd, seen)
     cfg = derive_config(sd)
+    self_check(cfg, sd)
     return cfg, sd
-
-
-# ---- writer (tests) --------------------------------------------------------------------------------------------------------
-def write_k2_onnx(cfg, sd, encoder_path, decoder_path, joiner_path):
-    """three files in the layout `read_k2_onnx` is written for (see the module docstring): conv / bias / embedding / bypass tensors
-    by name, Linear weights as anonymous transposed MatMul operands under scoped node names, BiasNorm scales and down-sampling
-    weights constant-folded"""
-    enc, dec, joi = onnx_lite.Model(), onnx_lite.Model(), onnx_lite.Model()
-    counter = [0]
-
-    def anon(model, arr):
-        counter[0] += 1
-        name = f"onnx::MatMul_{counter[0]}"
-        model.initializers[name] = np.ascontiguousarray(arr, dtype=np.float32)
-        return name
-
-    def put(model, key, onnx_key):
-        t = sd[key].detach().to(torch.float32).numpy()
-        scope = "/" + onnx_key.rsplit(".", 1)[0].replace(".", "/").replace("/encoders/", "/encoders.").replace("/layers/", "/layers.").replace("/conv/", "/conv.")
-        scope = re.sub(r"/(\d+)", r".\1", "/" + "/".join(onnx_key.split(".")[:-1]))
-        if key.endswith("log_scale"):
-            model.nodes.append(onnx_lite.Node(scope + "/Mul", "Mul", ["x", anon(model, np.exp(t).reshape(()))], ["y"]))
-        elif key.endswith("downsample.bias") or key.endswith("downsample_output.bias"):
-            e = np.exp(t - t.max())
-            model.nodes.append(onnx_lite.Node(scope + "/Mul", "Mul", ["x", anon(model, (e / e.sum()).reshape(-1, 1, 1))], ["y"]))
-        elif key.endswith(".weight") and t.ndim == 2 and "embedding" not in key:
-            model.nodes.append(onnx_lite.Node(scope + "/MatMul", "MatMul", ["x", anon(model, t.T)], ["y"]))
-        else:
-            model.initializers[onnx_key] = np.ascontiguousarray(t)
-
-    for key in sd:
-        if key.startswith("joiner.encoder_proj."):
-            put(enc, key, key[len("joiner."):])
-        elif key.startswith("joiner.decoder_proj."):
-            put(dec, key, key[len("joiner."):])
-        elif key.startswith("joiner.output_linear."):
-            put(joi, key, key[len("joiner."):])
-        elif key.startswith("decoder."):
-            put(dec, key, key)
-        else:
-            put(enc, key, key)
-    enc.metadata.update({"model_type": "zipformer2", "version": "1", "model_author": "k2-fsa", "comment": "non-streaming zipformer2"})
-    dec.metadata.update({"context_size": str(cfg.context_size), "vocab_size": str(cfg.vocab_size)})
-    joi.metadata.update({"joiner_dim": str(cfg.joiner_dim)})
-    onnx_lite.dump(encoder_path, enc)
-    onnx_lite.dump(decoder_path, dec)
-    onnx_lite.dump(joiner_path, joi)

@@ -20,17 +20,35 @@ K2_POS_CAP = 1024      # relative positions kept resident per stack: frames of t
 BRANCH = 0.25          # gain of the residual branches' output projections (icefall's ScaledLinear initial_scale plays this role)
 
 
+def _rand_scale(name, seed, d, meta):
+    if meta:
+        return torch.empty((d,), dtype=torch.float32, device="meta")
+    g = torch.Generator().manual_seed(_seed_for(name, seed))
+    return 0.35 + 0.3 * torch.rand((d,), generator=g)
+
+
 def layer_prefix(cfg: ZipformerConfig, s: int, j: int) -> str:
     """icefall: a full-rate stack is a Zipformer2Encoder (`layers`), a down-sampled one wraps it (`encoder.layers`)"""
     return f"encoder.encoders.{s}." + ("" if cfg.downsampling[s] == 1 else "encoder.") + f"layers.{j}."
 
 
-def synthetic_state_dict_k2(cfg: ZipformerConfig, seed: int = 0, blank_bias: float = None) -> Dict[str, torch.Tensor]:
+def expected_shapes_k2(cfg: ZipformerConfig) -> Dict[str, tuple]:
+    """every key of an icefall Zipformer2 transducer state dict at this architecture -> its shape (the checkpoint readers check
+    what they recovered against this list: runtime/k2_onnx.py)"""
+    return {k: tuple(v.shape) for k, v in synthetic_state_dict_k2(cfg, meta=True).items()}
+
+
+def synthetic_state_dict_k2(cfg: ZipformerConfig, seed: int = 0, blank_bias: float = None, meta: bool = False) -> Dict[str, torch.Tensor]:
     """Seeded random weights with icefall's keys and shapes.  Linears are N(0, 1 / fan_in) with small gains on the residual
     branches; BiasNorm log-scales around 0; bypass scales around 0.5 (icefall's initial value); a blank-logit offset makes
-    greedy search emit a realistic number of tokens."""
+    greedy search emit a realistic number of tokens.  meta = True: shapes only (tensors on the "meta" device)."""
     cfg.validate()
     sd: Dict[str, torch.Tensor] = {}
+    if meta:
+        def _randn(name, seed, shape, std):                     # noqa: F811 (shadows the generator: no storage, no random numbers)
+            return torch.empty(shape, dtype=torch.float32, device="meta")
+    else:
+        from .weights import _randn
 
     def lin(name, out_f, in_f, bias=True, gain=1.0):
         sd[name + ".weight"] = _randn(name + ".weight", seed, (out_f, in_f), gain / math.sqrt(in_f))
@@ -78,13 +96,11 @@ def synthetic_state_dict_k2(cfg: ZipformerConfig, seed: int = 0, blank_bias: flo
                 lin(L + cm + ".out_proj", d, d, gain=BRANCH)
             biasnorm(L + "norm", d)
             for b in ("bypass", "bypass_mid"):
-                g = torch.Generator().manual_seed(_seed_for(L + b, seed))
-                sd[L + b + ".bypass_scale"] = 0.35 + 0.3 * torch.rand((d,), generator=g)
+                sd[L + b + ".bypass_scale"] = _rand_scale(L + b, seed, d, meta)
         if cfg.downsampling[s] > 1:
             P = f"encoder.encoders.{s}."
             sd[P + "downsample.bias"] = _randn(P + "downsample.bias", seed, (cfg.downsampling[s],), 0.3)
-            g = torch.Generator().manual_seed(_seed_for(P + "out_combiner", seed))
-            sd[P + "out_combiner.bypass_scale"] = 0.35 + 0.3 * torch.rand((d,), generator=g)
+            sd[P + "out_combiner.bypass_scale"] = _rand_scale(P + "out_combiner", seed, d, meta)
     sd["encoder.downsample_output.bias"] = _randn("encoder.downsample_output.bias", seed, (cfg.output_downsampling,), 0.3)
     D, J, V = cfg.decoder_dim, cfg.joiner_dim, cfg.vocab_size
     sd["decoder.embedding.weight"] = _randn("decoder.embedding.weight", seed, (V, D), 1.0)
@@ -92,6 +108,8 @@ def synthetic_state_dict_k2(cfg: ZipformerConfig, seed: int = 0, blank_bias: flo
     lin("joiner.encoder_proj", J, cfg.out_dim)
     lin("joiner.decoder_proj", J, D, gain=3.0)
     lin("joiner.output_linear", V, J, gain=6.0)
+    if meta:
+        return sd
     if blank_bias is None:
         # scanned with the CPU oracle (oracle/zipformer.py + oracle/k2_greedy.c): about 35 tokens per 10 s utterance (293 frames) at the 159M shape
         blank_bias = {(768, 10720): 11.0, (128, 97): 6.0}.get((cfg.out_dim, cfg.vocab_size), 10.0)
@@ -159,7 +177,7 @@ def pad_cols(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
     return out
 
 
-def prepare_weights_k2(cfg: ZipformerConfig, sd: Dict[str, torch.Tensor], pos_cap: int = K2_POS_CAP):
+def prepare_weights_k2(cfg: ZipformerConfig, sd: Dict[str, torch.Tensor], pos_cap: int = K2_POS_CAP, f32: bool = False):
     """-> dict name -> CPU tensor as registered with rs_k2_set_tensor (include/rs_asr.h).  One-off host transforms:
       * GEMM weights bf16 [N][K] with K zero-padded to a multiple of 64 where the model's extent is not one (attention values
         H * 12, the 3/4-width non-linear attention of a 192-wide stack, the 3x3x32 patches of encoder_embed's third conv);
@@ -168,11 +186,13 @@ def prepare_weights_k2(cfg: ZipformerConfig, sd: Dict[str, torch.Tensor], pos_ca
       * BiasNorm: exp(log_scale) taken on the host; SimpleDownsample: softmax(bias) taken on the host;
       * relative positions: CompactRelPositionalEncoding rows for |rel| < pos_cap projected by every layer's linear_pos
         (float32 [2 * cap - 1][H * 4]) — the encoding depends on the relative position only;
-      * decoder / joiner: float32, the joiner's two matrices fragment-major for the exact-f32 decode kernels."""
+      * decoder / joiner: float32, the joiner's two matrices fragment-major for the exact-f32 decode kernels;
+      * f32 = True adds the float32 parity mode's dense weights as "<name>.f32" (unrounded; K zero-padded to a multiple of 32
+        where the bf16 copy pads to 64; the conv modules' in_proj and its bias in icefall's own row order: values, then gates)."""
     cfg.validate()
     out, used = {}, set()
     bf = lambda t: t.detach().to(torch.float32).to(torch.bfloat16).contiguous()   # noqa: E731
-    f32 = lambda t: t.detach().to(torch.float32).contiguous()                      # noqa: E731
+    f32_ = lambda t: t.detach().to(torch.float32).contiguous()                     # noqa: E731
 
     def get(key):
         if key not in sd:
@@ -195,22 +215,22 @@ def prepare_weights_k2(cfg: ZipformerConfig, sd: Dict[str, torch.Tensor], pos_ca
     out["fe.fb_w"] = torch.from_numpy(w)
     c1, c2, c3 = cfg.embed_channels
     E = "encoder_embed."
-    out["emb.conv0.w"] = f32(get(E + "conv.0.weight").reshape(c1, 9).t())                       # [9][c1]
-    out["emb.conv0.b"] = f32(get(E + "conv.0.bias"))
-    out["emb.conv1.w"] = f32(get(E + "conv.4.weight").permute(2, 3, 1, 0))                      # [3][3][c1][c2]
-    out["emb.conv1.b"] = f32(get(E + "conv.4.bias"))
+    out["emb.conv0.w"] = f32_(get(E + "conv.0.weight").reshape(c1, 9).t())                       # [9][c1]
+    out["emb.conv0.b"] = f32_(get(E + "conv.0.bias"))
+    out["emb.conv1.w"] = f32_(get(E + "conv.4.weight").permute(2, 3, 1, 0))                      # [3][3][c1][c2]
+    out["emb.conv1.b"] = f32_(get(E + "conv.4.bias"))
     out["emb.conv2.w"] = bf(pad_cols(get(E + "conv.7.weight").permute(0, 2, 3, 1).reshape(c3, 9 * c2).float()))   # K = (kh, kw, cin)
-    out["emb.conv2.b"] = f32(get(E + "conv.7.bias"))
-    out["emb.cnx.dw.w"] = f32(get(E + "convnext.depthwise_conv.weight").reshape(c3, 49).t())    # [49][c3]
-    out["emb.cnx.dw.b"] = f32(get(E + "convnext.depthwise_conv.bias"))
+    out["emb.conv2.b"] = f32_(get(E + "conv.7.bias"))
+    out["emb.cnx.dw.w"] = f32_(get(E + "convnext.depthwise_conv.weight").reshape(c3, 49).t())    # [49][c3]
+    out["emb.cnx.dw.b"] = f32_(get(E + "convnext.depthwise_conv.bias"))
     out["emb.cnx.pw1.w"] = bf(get(E + "convnext.pointwise_conv1.weight").reshape(3 * c3, c3))
-    out["emb.cnx.pw1.b"] = f32(get(E + "convnext.pointwise_conv1.bias"))
+    out["emb.cnx.pw1.b"] = f32_(get(E + "convnext.pointwise_conv1.bias"))
     out["emb.cnx.pw2.w"] = bf(get(E + "convnext.pointwise_conv2.weight").reshape(c3, 3 * c3))
-    out["emb.cnx.pw2.b"] = f32(get(E + "convnext.pointwise_conv2.bias"))
+    out["emb.cnx.pw2.b"] = f32_(get(E + "convnext.pointwise_conv2.bias"))
     F, d0 = cfg.embed_freq, cfg.encoder_dim[0]
     out["emb.out.w"] = bf(get(E + "out.weight").reshape(d0, c3, F).permute(0, 2, 1).reshape(d0, F * c3))
-    out["emb.out.b"] = f32(get(E + "out.bias"))
-    out["emb.norm.bias"] = f32(get(E + "out_norm.bias"))
+    out["emb.out.b"] = f32_(get(E + "out.bias"))
+    out["emb.norm.bias"] = f32_(get(E + "out_norm.bias"))
     out["emb.norm.scale"] = scale4(get(E + "out_norm.log_scale"))
     pe = torch.from_numpy(compact_rel_pos_table(cfg, pos_cap))
     qd, pd = cfg.query_head_dim, cfg.pos_head_dim
@@ -219,49 +239,72 @@ def prepare_weights_k2(cfg: ZipformerConfig, sd: Dict[str, torch.Tensor], pos_ca
         for j in range(cfg.num_layers[s]):
             L, p = layer_prefix(cfg, s, j), f"S{s}.L{j}."
             out[p + "attw.in.w"] = bf(get(L + "self_attn_weights.in_proj.weight"))
-            out[p + "attw.in.b"] = f32(get(L + "self_attn_weights.in_proj.bias"))
+            out[p + "attw.in.b"] = f32_(get(L + "self_attn_weights.in_proj.bias"))
             wp = get(L + "self_attn_weights.linear_pos.weight").to(torch.float32)              # [h * pd][pos_dim]
             out[p + "attw.pos_proj"] = (pe @ wp.t()).contiguous()                                 # [2 cap - 1][h * pd]
             for a, q in (("self_attn1", "sa1"), ("self_attn2", "sa2")):
                 out[p + q + ".in.w"] = bf(get(L + a + ".in_proj.weight"))
-                out[p + q + ".in.b"] = f32(get(L + a + ".in_proj.bias"))
+                out[p + q + ".in.b"] = f32_(get(L + a + ".in_proj.bias"))
                 out[p + q + ".out.w"] = bf(pad_cols(get(L + a + ".out_proj.weight").float()))
-                out[p + q + ".out.b"] = f32(get(L + a + ".out_proj.bias"))
+                out[p + q + ".out.b"] = f32_(get(L + a + ".out_proj.bias"))
             for n, q in (("feed_forward1", "ff1"), ("feed_forward2", "ff2"), ("feed_forward3", "ff3")):
                 out[p + q + ".in.w"] = bf(get(L + n + ".in_proj.weight"))
-                out[p + q + ".in.b"] = f32(get(L + n + ".in_proj.bias"))
+                out[p + q + ".in.b"] = f32_(get(L + n + ".in_proj.bias"))
                 out[p + q + ".out.w"] = bf(get(L + n + ".out_proj.weight"))
-                out[p + q + ".out.b"] = f32(get(L + n + ".out_proj.bias"))
+                out[p + q + ".out.b"] = f32_(get(L + n + ".out_proj.bias"))
             out[p + "na.in.w"] = bf(get(L + "nonlin_attention.in_proj.weight"))
-            out[p + "na.in.b"] = f32(get(L + "nonlin_attention.in_proj.bias"))
+            out[p + "na.in.b"] = f32_(get(L + "nonlin_attention.in_proj.bias"))
             out[p + "na.out.w"] = bf(pad_cols(get(L + "nonlin_attention.out_proj.weight").float()))
-            out[p + "na.out.b"] = f32(get(L + "nonlin_attention.out_proj.bias"))
+            out[p + "na.out.b"] = f32_(get(L + "nonlin_attention.out_proj.bias"))
             rows = glu_interleave_index(d)
             for cm, q in (("conv_module1", "cm1"), ("conv_module2", "cm2")):
                 out[p + q + ".in.w"] = bf(get(L + cm + ".in_proj.weight")[rows])
-                out[p + q + ".in.b"] = f32(get(L + cm + ".in_proj.bias")[rows])
-                out[p + q + ".dw.w"] = f32(get(L + cm + ".depthwise_conv.weight").squeeze(1).t())   # [k][d]
-                out[p + q + ".dw.b"] = f32(get(L + cm + ".depthwise_conv.bias"))
+                out[p + q + ".in.b"] = f32_(get(L + cm + ".in_proj.bias")[rows])
+                out[p + q + ".dw.w"] = f32_(get(L + cm + ".depthwise_conv.weight").squeeze(1).t())   # [k][d]
+                out[p + q + ".dw.b"] = f32_(get(L + cm + ".depthwise_conv.bias"))
                 out[p + q + ".out.w"] = bf(get(L + cm + ".out_proj.weight"))
-                out[p + q + ".out.b"] = f32(get(L + cm + ".out_proj.bias"))
-            out[p + "norm.bias"] = f32(get(L + "norm.bias"))
+                out[p + q + ".out.b"] = f32_(get(L + cm + ".out_proj.bias"))
+            out[p + "norm.bias"] = f32_(get(L + "norm.bias"))
             out[p + "norm.scale"] = scale4(get(L + "norm.log_scale"))
-            out[p + "bypass.scale"] = f32(get(L + "bypass.bypass_scale"))
-            out[p + "bypass_mid.scale"] = f32(get(L + "bypass_mid.bypass_scale"))
+            out[p + "bypass.scale"] = f32_(get(L + "bypass.bypass_scale"))
+            out[p + "bypass_mid.scale"] = f32_(get(L + "bypass_mid.bypass_scale"))
         if cfg.downsampling[s] > 1:
             P = f"encoder.encoders.{s}."
             out[f"S{s}.ds.w"] = soft8(get(P + "downsample.bias"))
-            out[f"S{s}.comb.scale"] = f32(get(P + "out_combiner.bypass_scale"))
+            out[f"S{s}.comb.scale"] = f32_(get(P + "out_combiner.bypass_scale"))
     out["out.ds.w"] = soft8(get("encoder.downsample_output.bias"))
     out["joint.enc.w"] = bf(get("joiner.encoder_proj.weight"))
-    out["joint.enc.b"] = f32(get("joiner.encoder_proj.bias"))
-    out["dec.embed"] = f32(get("decoder.embedding.weight"))
-    out["dec.conv.w"] = f32(get("decoder.conv.weight"))                                   # [D][4][context]
+    out["joint.enc.b"] = f32_(get("joiner.encoder_proj.bias"))
+    out["dec.embed"] = f32_(get("decoder.embedding.weight"))
+    out["dec.conv.w"] = f32_(get("decoder.conv.weight"))                                   # [D][4][context]
     out["joint.pred.w"] = to_fragment_major(get("joiner.decoder_proj.weight"))
-    out["joint.pred.b"] = f32(get("joiner.decoder_proj.bias"))
+    out["joint.pred.b"] = f32_(get("joiner.decoder_proj.bias"))
     out["joint.out.w"] = to_fragment_major(get("joiner.output_linear.weight"))
-    out["joint.out.b"] = f32(get("joiner.output_linear.bias"))
+    out["joint.out.b"] = f32_(get("joiner.output_linear.bias"))
     out.update(screen_tensors(get("joiner.output_linear.weight"), get("joiner.output_linear.bias")))      # screened joint (greedy search)
+    if f32:
+        p32 = lambda t: pad_cols(t.detach().to(torch.float32), 32)        # noqa: E731
+        out["emb.conv2.w.f32"] = p32(sd[E + "conv.7.weight"].permute(0, 2, 3, 1).reshape(c3, 9 * c2))
+        out["emb.cnx.pw1.w.f32"] = f32_(sd[E + "convnext.pointwise_conv1.weight"].reshape(3 * c3, c3))
+        out["emb.cnx.pw2.w.f32"] = f32_(sd[E + "convnext.pointwise_conv2.weight"].reshape(c3, 3 * c3))
+        out["emb.out.w.f32"] = f32_(sd[E + "out.weight"].reshape(d0, c3, F).permute(0, 2, 1).reshape(d0, F * c3))
+        out["joint.enc.w.f32"] = f32_(sd["joiner.encoder_proj.weight"])
+        for s in range(cfg.n_stacks):
+            for j in range(cfg.num_layers[s]):
+                L, p = layer_prefix(cfg, s, j), f"S{s}.L{j}."
+                out[p + "attw.in.w.f32"] = f32_(sd[L + "self_attn_weights.in_proj.weight"])
+                for a, q in (("self_attn1", "sa1"), ("self_attn2", "sa2")):
+                    out[p + q + ".in.w.f32"] = f32_(sd[L + a + ".in_proj.weight"])
+                    out[p + q + ".out.w.f32"] = p32(sd[L + a + ".out_proj.weight"])
+                for n, q in (("feed_forward1", "ff1"), ("feed_forward2", "ff2"), ("feed_forward3", "ff3")):
+                    out[p + q + ".in.w.f32"] = f32_(sd[L + n + ".in_proj.weight"])
+                    out[p + q + ".out.w.f32"] = f32_(sd[L + n + ".out_proj.weight"])
+                out[p + "na.in.w.f32"] = f32_(sd[L + "nonlin_attention.in_proj.weight"])
+                out[p + "na.out.w.f32"] = p32(sd[L + "nonlin_attention.out_proj.weight"])
+                for cm, q in (("conv_module1", "cm1"), ("conv_module2", "cm2")):
+                    out[p + q + ".in.w.f32"] = f32_(sd[L + cm + ".in_proj.weight"])
+                    out[p + q + ".in.b.f32"] = f32_(sd[L + cm + ".in_proj.bias"])
+                    out[p + q + ".out.w.f32"] = f32_(sd[L + cm + ".out_proj.weight"])
     left = [k for k in sd if k not in used]
     if left:
         raise UnsupportedCheckpoint(f"{len(left)} checkpoint tensor(s) have no counterpart in this implementation: "

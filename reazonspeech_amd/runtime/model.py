@@ -158,11 +158,9 @@ class AsrModel:
         with torch.cuda.device(self.device):
             self.ctx = capi.Context(cfg, index)
             if getattr(cfg, "family", "") == "k2":
-                if precision != "bf16":
-                    raise ValueError("the Zipformer path has no float32 parity mode")
                 from .k2_weights import prepare_weights_k2
                 self._k2_sd = state_dict          # the position tables are re-projected when a longer utterance arrives
-                self._upload_k2(prepare_weights_k2(cfg, state_dict, pos_cap))
+                self._upload_k2(prepare_weights_k2(cfg, state_dict, pos_cap, f32=precision == "fp32"))
                 self.pos_cap = pos_cap
             elif cfg.espnet:
                 from .weights_espnet import prepare_weights_espnet
@@ -188,6 +186,8 @@ class AsrModel:
                 c.set_tensor(name, dev)
         for c in self._contexts():
             c.finalize()
+            if self.precision == "fp32":
+                c.set_option("precision_f32", 1)
 
     def _contexts(self):
         return [self.ctx] + [c for c, _ in self._dec_lanes]

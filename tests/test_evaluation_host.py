@@ -157,3 +157,20 @@ def test_espnet_evaluator_hooks_use_the_espnet_package():
     assert single == batch == [fk.text_of(r["audio"]["array"]) for r in rows]
     out = ev.evaluate(rows, batch_size=2)
     assert [r["prediction"] for r in out] == single and all("distance" in r for r in out)
+
+
+def test_k2_evaluator_hooks_use_the_k2_package():
+    """`RSK2AmdEvaluator` (examples/rs-k2/eval.py:15-33): the single hook is the reference's (`transcribe(model, audio).text`), the
+    batch hook — NotImplementedError in the reference (:32-33) — goes through `transcribe_batch`, both of `reazonspeech.k2.asr`;
+    driven with the deterministic fake recogniser"""
+    import k2_fake as fk
+    model = fk.FakeRecognizer()
+    model.decode_streams = lambda streams: [model.decode_stream(s) for s in streams]
+    ev = E.RSK2AmdEvaluator(model=model, batch_size=2)
+    rows = [{"audio": {"array": fk.audio(1.0 + 0.5 * s, s), "sampling_rate": 16000}, "text": "あいう"} for s in (1, 2, 3)]
+    single = [ev._evaluate(r)["prediction"] for r in rows]
+    batch = ev._evaluate_batch({"audio": [r["audio"] for r in rows]})["predictions"]
+    assert single == batch and all(isinstance(t, str) and t for t in single)
+    assert all(n == len(r["audio"]["array"]) + 2 * 14400 for (_, n, _), r in zip(model.seen[:3], rows))      # 0.9 s of padding on both sides
+    out = ev.evaluate(rows, batch_size=2)
+    assert [r["prediction"] for r in out] == single and all("distance" in r for r in out)

@@ -14,6 +14,7 @@ import pytest
 import torch
 
 import k2_fake as fk
+from k2_onnx_writer import write_k2_onnx
 from reazonspeech_amd.k2.asr import interface, huggingface as hfm
 from reazonspeech_amd.k2.asr.model import K2Model, read_tokens, synthetic_tokens
 from reazonspeech_amd.runtime.k2_config import ZIPFORMER_TINY, ZIPFORMER_159M
@@ -79,6 +80,44 @@ def test_rel_shift_equals_icefalls_as_strided_form():
     strided = ps.as_strided((H, B, T, T), (ps.stride(0), ps.stride(1), ps.stride(2) - ps.stride(3), ps.stride(3)), storage_offset=ps.stride(3) * (T - 1))
     i, j = torch.arange(T).unsqueeze(1), torch.arange(T).unsqueeze(0)
     assert torch.equal(strided, ps.gather(3, (j - i + T - 1).expand(H, B, T, T)))
+
+
+def test_the_oracles_own_tables_equal_the_products_and_have_the_published_values():
+    """oracle/zipformer.py builds its window, mel banks and relative-position rows itself (float64, from the published
+    kaldi-native-fbank / icefall formulas); the arrays the HIP path uploads (runtime/k2_weights.py) must agree with them to
+    float32 resolution, so a wrong mel edge / window exponent / position formula on EITHER side fails here, and a handful of
+    values are checked against numbers worked out by hand from the formulas"""
+    import inspect
+    imports = [ln for ln in inspect.getsource(oz).splitlines() if ln.startswith(("import ", "from "))]
+    assert imports and not any("reazonspeech_amd" in ln for ln in imports), "the oracle must not import its constants from the product"
+    for cfg in (ZIPFORMER_159M, ZIPFORMER_TINY):
+        w64, w32 = oz.povey_window(cfg.frame_length), kw.povey_window(cfg.frame_length)
+        assert w64.dtype == np.float64 and np.array_equal(w64.astype(np.float32), w32)
+        b64, b32 = oz.kaldi_mel_banks(cfg), kw.kaldi_mel_banks(cfg)
+        assert b64.shape == b32.shape and np.abs(b64 - b32).max() < 1e-7 and np.array_equal(b64 > 0, b32 > 0)
+        for T in (1, 2, 37, 293, 586):
+            p64, p32 = oz.compact_rel_pos_table(cfg, T), kw.compact_rel_pos_table(cfg, T)
+            assert p64.shape == p32.shape == (2 * T - 1, cfg.pos_dim) and np.abs(p64 - p32).max() < 1e-5
+        for s in range(cfg.n_stacks):
+            assert oz.layer_prefix(cfg, s, 1) == kw.layer_prefix(cfg, s, 1)
+    cfg = ZIPFORMER_159M
+    # povey: (0.5 - 0.5 cos(2 pi i / 399)) ** 0.85 at i = 100 -> (0.5 - 0.5 cos(1.574733..)) ** 0.85
+    assert abs(oz.povey_window(400)[100] - (0.5 - 0.5 * np.cos(2 * np.pi * 100 / 399)) ** 0.85) < 1e-15
+    assert abs(oz.povey_window(400)[100] - 0.55664) < 1e-5       # (0.50222) ** 0.85
+    # mel: 1127 ln(1 + f / 700); 20 Hz -> 31.75, 7600 Hz -> 2787.0 (1127 x ln 11.857 = 1127 x 2.47293); 81 steps of 34.0; bank 0 peaks at mel 65.75 = 42.05 Hz,
+    # between FFT bins 1 (31.25 Hz) and 2 (62.5 Hz): both carry weight, bin 0 and bin 3 (93.75 Hz = mel 141.6 > right edge 99.7) none
+    assert abs(float(oz.mel_scale(20.0)) - 31.748) < 1e-2 and abs(float(oz.mel_scale(7600.0)) - 2786.99) < 1e-2
+    fb = oz.kaldi_mel_banks(cfg)
+    assert fb[0, 0] == 0 and fb[0, 1] > 0 and fb[0, 2] > 0 and fb[0, 3] == 0
+    m1, lo, step = float(oz.mel_scale(31.25)), float(oz.mel_scale(20.0)), (float(oz.mel_scale(7600.0)) - float(oz.mel_scale(20.0))) / 81
+    assert abs(fb[0, 1] - (m1 - lo) / step) < 1e-12
+    assert fb[79, 243] > 0 and fb[79, 244] == 0                   # 7600 Hz / 31.25 = bin 243.2: the last filter ends there
+    # compact rel-pos: rel 0 -> angle 0 -> cos columns 1, sin columns 0, last column 1; antisymmetric sines
+    pe = oz.compact_rel_pos_table(cfg, 5)
+    assert np.allclose(pe[4, 0::2][:-1], 1.0) and np.allclose(pe[4, 1::2][:-1], 0.0) and (pe[:, -1] == 1.0).all()
+    assert np.allclose(pe[0, 1:-1:2], -pe[8, 1:-1:2]) and np.allclose(pe[0, 0::2], pe[8, 0::2])
+    a1 = np.arctan(np.sqrt(48.0) * (np.log(1 + np.sqrt(48.0)) - np.log(np.sqrt(48.0))) / (48 / (2 * np.pi)))
+    assert abs(pe[5, 0] - np.cos(a1)) < 1e-15 and abs(pe[5, 3] - np.sin(2 * a1)) < 1e-15
 
 
 def test_fbank_geometry_and_invariances():
@@ -152,7 +191,7 @@ def test_onnx_reader_round_trip(tmp_path):
     cfg = ZIPFORMER_TINY
     sd = kw.synthetic_state_dict_k2(cfg, 5)
     paths = [str(tmp_path / n) for n in ("encoder.onnx", "decoder.onnx", "joiner.onnx")]
-    k2_onnx.write_k2_onnx(cfg, sd, *paths)
+    write_k2_onnx(cfg, sd, *paths)
     m = onnx_lite.load(paths[1])
     assert m.metadata["context_size"] == "2" and "decoder.embedding.weight" in m.initializers
     cfg2, sd2 = k2_onnx.read_k2_onnx(*paths)
@@ -168,4 +207,25 @@ def test_onnx_reader_round_trip(tmp_path):
     q = onnx_lite.Model(nodes=[onnx_lite.Node("/x/MatMulInteger", "MatMulInteger", ["a", "b"], ["c"])])
     onnx_lite.dump(paths[0], q)
     with pytest.raises(ValueError, match="quantized"):
+        k2_onnx.read_k2_onnx(*paths)
+    # the reader checks what it recovered: a dropped tensor, a down-sampling constant that is not a softmax, and two
+    # different constants landing on one key are refused instead of loading silently
+    write_k2_onnx(cfg, {k: v for k, v in sd.items() if k != "encoder.encoders.1.encoder.layers.0.bypass.bypass_scale"}, *paths)
+    with pytest.raises(ValueError, match="not found"):
+        k2_onnx.read_k2_onnx(*paths)
+    write_k2_onnx(cfg, sd, *paths)
+    m = onnx_lite.load(paths[0])
+    for n in m.nodes:
+        if n.name.endswith("encoders.1/downsample/Mul"):
+            m.initializers[n.inputs[1]] = m.initializers[n.inputs[1]] * 3.0
+    onnx_lite.dump(paths[0], m)
+    with pytest.raises(ValueError, match="softmax"):
+        k2_onnx.read_k2_onnx(*paths)
+    write_k2_onnx(cfg, sd, *paths)
+    m = onnx_lite.load(paths[0])
+    twin = [n for n in m.nodes if n.name.endswith("layers.0/norm/Mul")][0]
+    m.initializers["dup_scale"] = np.asarray(2.5, np.float32)
+    m.nodes.append(onnx_lite.Node(twin.name, "Mul", ["x", "dup_scale"], ["y2"]))
+    onnx_lite.dump(paths[0], m)
+    with pytest.raises(ValueError, match="two different constants"):
         k2_onnx.read_k2_onnx(*paths)

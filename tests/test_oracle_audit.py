@@ -74,3 +74,34 @@ def test_batched_audit_equals_the_per_row_walk():
         assert [(x["frame"], x["k_ref"], x["k_hip"]) for x in a["flips"]] == [(x["frame"], x["k_ref"], x["k_hip"]) for x in b["flips"]]
         for x, y in zip(a["flips"], b["flips"]):
             assert abs(x["margin_ref"] - y["margin_ref"]) < 1e-9 and abs(x["bound"] - y["bound"]) < 1e-9
+
+
+def test_k2_audit_stateless_decoder_one_decision_per_frame():
+    """`flip_audit_batch_k2` (Zipformer family: stateless decoder, one decision per frame, blank and <unk> one class): without
+    noise no flips and the walk reproduces the hypothesis; under large noise every difference from the reference's ids starts at a
+    flip and every flip obeys the Lipschitz bound (tanh joiner)"""
+    import torch
+    from reazonspeech_amd.runtime.k2_config import ZIPFORMER_TINY as kcfg
+    from reazonspeech_amd.runtime.k2_weights import synthetic_state_dict_k2
+    from oracle import greedy as og
+    sd = synthetic_state_dict_k2(kcfg, 7)
+    sd["joiner.output_linear.bias"][kcfg.unk_id] += 4.0            # <unk> wins now and then: it must count as "nothing emitted"
+    torch.manual_seed(3)
+    B, T = 4, 50
+    f_ref = torch.randn(B, T, kcfg.joiner_dim)
+    lens = [50, 37, 50, 12]
+    ref = og.k2_greedy(kcfg, sd, f_ref.numpy(), lens)
+    for noise in (0.0, 0.6):
+        f_hip = f_ref + noise * torch.randn(B, T, kcfg.joiner_dim)
+        hyp = og.k2_greedy(kcfg, sd, f_hip.numpy(), lens)
+        au = audit.flip_audit_batch_k2(kcfg, sd, f_ref, f_hip, lens, [h[0] for h in hyp], [h[1] for h in hyp])
+        equal = [hyp[b] == ref[b] for b in range(B)]
+        s = audit.summarize(au, equal)
+        assert s["every_id_difference_starts_at_a_flip"] and s["walk_reproduces_hip_path"] and s["decisions"] == sum(lens)
+        for a in au:
+            for fl in a["flips"]:
+                assert fl["margin_ref"] <= fl["bound"] * (1 + 1e-9) + 1e-12
+        if noise == 0.0:
+            assert s["local_flips"] == 0 and all(equal)
+        else:
+            assert s["local_flips"] > 0 and not all(equal)
