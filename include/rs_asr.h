@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 5
+#define RS_ABI_VERSION 6
 
 enum {
     RS_OK = 0,
@@ -133,6 +133,59 @@ int rs_k2_create(rs_ctx** out, int device, const rs_k2_dims* dims);
 /* Parity taps of a Zipformer context (tests only): embed_out f32 [B*T3][encoder_dim[0]] (encoder_embed's output) and stack_out,
  * the stacks' outputs f32 [B*T3][encoder_dim[s]] one after the other; NULL disables. */
 int rs_k2_encoder_set_taps(rs_ctx* ctx, float* embed_out, float* stack_out);
+
+/* ---- reazonspeech.avsr: the AV-HuBERT encoder-decoder (csrc/k_avsr.hip) ---------------------------------------------------------
+ * The reference is in-tree torch code: AVHubertForConditionalGeneration (pkg/avsr/src/avhubert/modeling_avhubert.py:216-391) over
+ * AVHubertModel (:119-213: audio Linear, Conv3d + ResNet-18 video front-end modeling_resnet.py:140-178, concatenation, LayerNorm,
+ * post_extract_proj, transformers' HubertEncoder) and AVHubertDecoder (decoder.py:467-617).  Everything is float32, as in the
+ * reference.  Tensor names and layouts: reazonspeech_amd/runtime/avsr_weights.py: prepare_weights_avsr. */
+typedef struct rs_avsr_dims {
+    int32_t encoder_layers;        /* 12  (configuration_avhubert.py:9-13) */
+    int32_t encoder_embed_dim;     /* 768 */
+    int32_t encoder_ffn_dim;       /* 3072 */
+    int32_t encoder_heads;         /* 12 */
+    int32_t conv_pos;              /* 128: kernel of the positional convolution (even) */
+    int32_t conv_pos_groups;       /* 16 */
+    int32_t audio_feat_dim;        /* 104 = 4 stacked 26-dim log filterbank frames (feature_extraction_avhubert.py:120-137) */
+    int32_t fuse_concat;           /* 1: modality_fuse "concat" (the only form built) */
+    int32_t image_size;            /* 88 (feature_extraction_avhubert.py:24) */
+    int32_t decoder_layers;        /* 6 */
+    int32_t decoder_embed_dim;     /* 768 (== encoder_embed_dim) */
+    int32_t decoder_ffn_dim;       /* 3072 */
+    int32_t decoder_heads;         /* 4 */
+    int32_t max_positions;         /* 2048 rows of the sinusoidal table */
+    int32_t vocab_size;
+    float layer_norm_eps;          /* 1e-5 */
+} rs_avsr_dims;
+/* Replaces: AVHubertForConditionalGeneration.__init__ / from_pretrained (modeling_avhubert.py:216-254).  The context takes
+ * rs_set_tensor / rs_finalize / rs_destroy / rs_last_error and the rs_avsr_* stage functions below (the transducer stages do not
+ * apply to it). */
+int rs_avsr_create(rs_ctx** out, int device, const rs_avsr_dims* dims);
+size_t rs_avsr_workspace_bytes(const rs_ctx* ctx, int B, int T);
+/* Replaces: AVHubertModel.forward (modeling_avhubert.py:162-213).
+ *   input_values f32[B][T][audio_feat_dim], pixel_values f32[B][T][image_size][image_size] (the reference's [B][T][1][H][W]),
+ *   padding_mask f32[B][T] (nonzero = padding frame; the reference's padding_mask, :192-195) -> enc_out f32[B][T][encoder_embed_dim]
+ *   = last_hidden_state.  Padded frames go through the front-ends like any other (as in the reference); their encoder inputs are
+ *   zeroed and they are masked as attention keys. */
+int rs_avsr_encoder_forward(rs_ctx* ctx, const float* input_values, const float* pixel_values, const float* padding_mask, int B,
+                            int T, float* enc_out, void* workspace, size_t workspace_bytes, void* stream);
+/* Parity taps (tests only; NULL disables): video = feature_extractor_video output f32[B*T][d], fused_ln = avhubert.layer_norm output
+ * f32[B*T][2d], enc_ln = encoder.layer_norm output f32[B*T][d], layer_out = the listed encoder layers' outputs one after the other. */
+int rs_avsr_encoder_set_taps(rs_ctx* ctx, float* video, float* fused_ln, float* enc_ln, float* layer_out, const int32_t* layer_ids,
+                             int n_layer_ids);
+/* Replaces: the decoder half of AVHubertForConditionalGeneration.forward inside generate() (modeling_avhubert.py:283-298,
+ * decoder.py:488-617), one token per call with a KV cache (the reference re-feeds the prefix and re-runs the encoder every step,
+ * :372-391; same results).  rows = B * beams hypothesis rows, row = clip * beams + beam (transformers' flattening).
+ *   rs_avsr_decoder_begin   cross-attention keys / values of every layer from enc f32[B][T][d]; call once per batch
+ *   rs_avsr_decoder_step    tokens i32[rows] = the token at position `step` of every row (step 0: the bos prompt); src_rows i32[rows]
+ *                           or NULL = the row whose prefix each row continues (beam search re-parenting; give it at EVERY step >= 1
+ *                           or at none); padding_mask as above; -> logits f32[rows][vocab_size rounded up to 4] of position `step`
+ * `state` is caller-owned device memory of rs_avsr_decoder_state_bytes(B, T, beams, max_len) bytes, untouched between calls. */
+size_t rs_avsr_decoder_state_bytes(const rs_ctx* ctx, int B, int T, int beams, int max_len);
+int rs_avsr_decoder_begin(rs_ctx* ctx, const float* enc, int B, int T, int beams, int max_len, void* state, size_t state_bytes,
+                          void* stream);
+int rs_avsr_decoder_step(rs_ctx* ctx, const int32_t* tokens, const int32_t* src_rows, int step, const float* padding_mask, int B,
+                         int T, int beams, int max_len, float* logits, void* state, size_t state_bytes, void* stream);
 void rs_destroy(rs_ctx* ctx);
 const char* rs_last_error(const rs_ctx* ctx);
 int rs_abi_version(void);
@@ -341,7 +394,9 @@ enum { RS_GEMM_BIAS = 1, RS_GEMM_RELU = 2, RS_GEMM_SILU = 4, RS_GEMM_RESIDUAL = 
         * N % 64 == 0 */
        RS_GEMM_GLU = 64,
        /* icefall's SwooshL / SwooshR activations (the Zipformer family; plain bf16 or f32 output only) */
-       RS_GEMM_SWOOSHL = 128, RS_GEMM_SWOOSHR = 256 };
+       RS_GEMM_SWOOSHL = 128, RS_GEMM_SWOOSHR = 256,
+       /* exact GELU, 0.5 x (1 + erf(x / sqrt 2)) (the AV-HuBERT family; rs_gemm_f32 only) */
+       RS_GEMM_GELU = 512 };
 int rs_gemm_bf16(rs_ctx* ctx, const uint16_t* A, int lda, const uint16_t* W, int ldw,
                  void* out, int ldc, int M, int N, int K, int flags, const float* bias, float alpha,
                  const float* residual, const int32_t* mask_lens, int mask_rows_per_step,

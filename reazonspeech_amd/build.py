@@ -19,7 +19,7 @@ LIB = os.path.join(LIBDIR, "librs_asr.so")
 ARCH = "gfx950"
 
 SOURCES = ["rs_api.hip", "k_gemm_bf16.hip", "k_layernorm.hip", "k_attention.hip", "k_frontend.hip",
-           "k_subsample.hip", "k_rnnt.hip", "k_rnnt_alsd.hip", "k_rnnt_beam.hip", "k_f32.hip", "k_espnet.hip", "k_zipformer.hip"]
+           "k_subsample.hip", "k_rnnt.hip", "k_rnnt_alsd.hip", "k_rnnt_beam.hip", "k_f32.hip", "k_espnet.hip", "k_zipformer.hip", "k_avsr.hip"]
 EXTRA = {"k_rnnt.hip": ["-ffp-contract=off"],
          "k_rnnt_alsd.hip": ["-ffp-contract=off"],
          "k_rnnt_beam.hip": ["-ffp-contract=off"]}

@@ -1,0 +1,706 @@
+// k_avsr.hip — the AV-HuBERT encoder-decoder of `reazonspeech.avsr` (BASELINE.json configs[4]: "audio-visual
+// path: video-frame + log-mel fusion encoder, batch = 16 clips").
+//
+// The reference is in-tree torch code (pkg/avsr/src/avhubert/): modeling_resnet.py:140-178 (Conv3d front-end + ResNet-18 trunk),
+// modeling_avhubert.py:40-65 (audio / video projections), :162-213 (fusion, LayerNorm, post_extract_proj, transformers'
+// HubertEncoder), decoder.py:297-369, :467-617 (Transformer decoder), generate() through transformers' GenerationMixin
+// (modeling_avhubert.py:372-391 re-feeds the prefix and re-runs the encoder every step).  Restated in oracle/avsr.py, which is
+// pinned to the reference itself (tests/golden/avsr_ref_*.npz).  What runs where:
+//
+//   dense contractions     every Linear, the 3 x 3 / 1 x 1 convolutions of the ResNet trunk (as channels-last patches) on
+//                          rs_launch_gemm_f32's exact v_mfma_f32_16x16x4_f32 chain: the reference computes float32 and so does
+//                          this path, end to end (there is no reduced-precision mode of this family yet)
+//   Conv3d(1, 64, 5x7x7)   avsr_conv3d_kernel: the five frames' seven input rows of an output row staged in LDS, a thread owns a
+//                          channel and every fourth output pixel, taps from L1; BatchNorm + PReLU in its epilogue
+//   positional conv        avsr_posconv_kernel: grouped Conv1d (kernel 128, 16 groups) with the group's frames in LDS, GELU and the
+//                          residual add fused
+//   attention              avsr_attn_kernel: one wave per (query, head), two passes over the visible keys; serves the encoder
+//                          (padding mask), the decoder's self-attention over its KV cache and the cross-attention
+//   decoder                rs_avsr_decoder_begin projects the encoder states once per layer (cross-attention K / V),
+//                          rs_avsr_decoder_step advances every hypothesis row by one token with a per-layer KV cache that is
+//                          re-gathered by beam index — the reference recomputes everything every step; results are the same
+//
+// Batch semantics: the reference runs the whole padded batch through the front-ends (padded frames are real inputs to the
+// Conv3d) and masks only attention keys and the encoder input rows; so does this file — a clip's result inside a batch equals the
+// reference's result for that batch.
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "rs_common.h"
+
+struct rs_avsr_block {
+    const float *conv1_w, *conv2_w, *bn1_a, *bn1_b, *bn2_a, *bn2_b, *relu1, *relu2, *ds_w, *ds_a, *ds_b;
+};
+struct rs_avsr_attn {
+    const float *qkv_w, *qkv_b, *o_w, *o_b;          // self-attention: q | k | v rows concatenated
+    const float *q_w, *q_b, *kv_w, *kv_b;            // cross-attention: q, then k | v
+};
+struct rs_avsr_layer {
+    rs_avsr_attn sa, ca;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b, *ff1_w, *ff1_b, *ff2_w, *ff2_b;
+};
+struct rs_avsr {
+    rs_avsr_dims d{};
+    const float *audio_w = nullptr, *audio_b = nullptr, *conv3d_w = nullptr, *bn0_a = nullptr, *bn0_b = nullptr, *prelu0 = nullptr;
+    rs_avsr_block blocks[4][2] = {};
+    const float *vproj_w = nullptr, *vproj_b = nullptr, *fuse_g = nullptr, *fuse_b = nullptr, *fproj_w = nullptr, *fproj_b = nullptr;
+    const float *pos_w = nullptr, *pos_b = nullptr, *encln_g = nullptr, *encln_b = nullptr;
+    std::vector<rs_avsr_layer> enc, dec;
+    const float *embed = nullptr, *dec_pos = nullptr, *decln_g = nullptr, *decln_b = nullptr, *lm_w = nullptr;
+    // parity taps (rs_avsr_encoder_set_taps)
+    float *tap_video = nullptr, *tap_fused = nullptr, *tap_encln = nullptr, *tap_layers = nullptr;
+    std::vector<int> tap_ids;
+};
+
+namespace {
+
+__host__ __device__ inline int pad32(int n) { return (n + 31) / 32 * 32; }
+__host__ __device__ inline int pad4(int n) { return (n + 3) / 4 * 4; }
+constexpr int TRUNK_C[5] = {64, 64, 128, 256, 512};
+
+// ---- video front-end ----------------------------------------------------------------------------------------------------------------
+// Conv3d(1, 64, (5, 7, 7), stride (1, 2, 2), padding (2, 3, 3)) + BatchNorm3d (inference form: x * alpha + beta) + PReLU.
+// pixels f32 [B][T][H][W] -> out f32 [B*T][H/2][W/2][64] (channels last).  grid (H/2, T, B), block 256 = 64 channels x 4 pixel
+// phases; a thread owns channel c and output pixels ow = phase, phase + 4, ..  Frames outside [0, T) and pixels outside the image
+// are zeros (the convolution's own padding); padded frames of a clip are ordinary inputs, as in the reference.
+__global__ __launch_bounds__(256) void avsr_conv3d_kernel(const float* __restrict__ pix, int T, int H, int W, const float* __restrict__ w /* [245][64] */,
+                                                          const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ slope,
+                                                          float* __restrict__ out) {
+    constexpr int PXMAX = 12, WMAX = 96;
+    __shared__ float rows[5][7][WMAX + 6];
+    const int oh = blockIdx.x, t = blockIdx.y, b = blockIdx.z, OW = W / 2, OH = H / 2;
+    for (int i = threadIdx.x; i < 5 * 7 * (W + 6); i += 256) {
+        const int kt = i / (7 * (W + 6)), r = i - kt * 7 * (W + 6), kh = r / (W + 6), x = r - kh * (W + 6);
+        const int tt = t + kt - 2, ih = 2 * oh + kh - 3, iw = x - 3;
+        rows[kt][kh][x] = (tt >= 0 && tt < T && ih >= 0 && ih < H && iw >= 0 && iw < W) ? pix[(((size_t)b * T + tt) * H + ih) * W + iw] : 0.0f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    float acc[PXMAX];
+#pragma unroll
+    for (int j = 0; j < PXMAX; ++j) acc[j] = 0.0f;
+    for (int kt = 0; kt < 5; ++kt)
+        for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const float wv = w[((kt * 7 + kh) * 7 + kw) * 64 + c];
+#pragma unroll
+                for (int j = 0; j < PXMAX; ++j) {
+                    const int ow = ph + 4 * j;
+                    if (ow < OW) acc[j] = fmaf(wv, rows[kt][kh][2 * ow + kw], acc[j]);
+                }
+            }
+    const float a = alpha[c], bb = beta[c], sl = slope[c];
+    float* orow = out + (((size_t)b * T + t) * OH + oh) * OW * 64;
+#pragma unroll
+    for (int j = 0; j < PXMAX; ++j) {
+        const int ow = ph + 4 * j;
+        if (ow < OW) {
+            const float v = fmaf(acc[j], a, bb);
+            orow[(size_t)ow * 64 + c] = v >= 0.0f ? v : v * sl;
+        }
+    }
+}
+
+// MaxPool over (3, 3) windows, stride 2, padding 1 (-inf): [N][H][W][C] -> [N][(H + 1) / 2][(W + 1) / 2][C]
+__global__ __launch_bounds__(256) void avsr_maxpool_kernel(const float* __restrict__ in, int H, int W, int C, int OH, int OW, size_t total, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    size_t r = idx / C;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const size_t n = r / OH;
+    float m = -INFINITY;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = 2 * oh + kh - 1;
+        if (ih < 0 || ih >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = 2 * ow + kw - 1;
+            if (iw < 0 || iw >= W) continue;
+            m = fmaxf(m, in[((n * H + ih) * W + iw) * C + c]);
+        }
+    }
+    out[idx] = m;
+}
+
+// 3 x 3 patches with padding 1 and stride s of a channels-last map: row (n, oh, ow) = in[n][s oh + kh - 1][s ow + kw - 1][:] in
+// (kh, kw, c) order, zeros outside.  One thread per 16-byte piece.
+__global__ __launch_bounds__(256) void avsr_im2col3_kernel(const float* __restrict__ in, int H, int W, int C, int OH, int OW, int stride, size_t pieces,
+                                                           float* __restrict__ col) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= pieces) return;
+    const int c4 = C / 4, per_row = 9 * c4;
+    const size_t row = idx / per_row;
+    const int q = (int)(idx - row * per_row), tap = q / c4, cc = q - tap * c4, kh = tap / 3, kw = tap - 3 * kh;
+    const int ow = (int)(row % OW);
+    const size_t r = row / OW;
+    const int oh = (int)(r % OH);
+    const size_t n = r / OH;
+    const int ih = stride * oh + kh - 1, iw = stride * ow + kw - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = reinterpret_cast<const float4*>(in + ((n * H + ih) * W + iw) * C)[cc];
+    reinterpret_cast<float4*>(col)[idx] = v;
+}
+
+// the 1 x 1 stride-2 down-sampling convolution's input: in[n][2 oh][2 ow][:] -> rows of C
+__global__ __launch_bounds__(256) void avsr_stride2_kernel(const float* __restrict__ in, int H, int W, int C, int OH, int OW, size_t pieces, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= pieces) return;
+    const int c4 = C / 4;
+    const size_t row = idx / c4;
+    const int cc = (int)(idx - row * c4), ow = (int)(row % OW);
+    const size_t r = row / OW;
+    const int oh = (int)(r % OH);
+    const size_t n = r / OH;
+    reinterpret_cast<float4*>(out)[idx] = reinterpret_cast<const float4*>(in + ((n * H + 2 * oh) * W + 2 * ow) * C)[cc];
+}
+
+// BatchNorm (inference form) [+ residual] [+ PReLU]: x = act(x * alpha[c] + beta[c] + res), in place.  slope == nullptr: no activation
+__global__ __launch_bounds__(256) void avsr_bn_act_kernel(float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                          const float* __restrict__ res, const float* __restrict__ slope, int C, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % (size_t)C);
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    const float4 a = *reinterpret_cast<const float4*>(alpha + c), b = *reinterpret_cast<const float4*>(beta + c);
+    v.x = fmaf(v.x, a.x, b.x); v.y = fmaf(v.y, a.y, b.y); v.z = fmaf(v.z, a.z, b.z); v.w = fmaf(v.w, a.w, b.w);
+    if (res) {
+        const float4 r = reinterpret_cast<const float4*>(res)[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (slope) {
+        const float4 s = *reinterpret_cast<const float4*>(slope + c);
+        v.x = v.x >= 0.f ? v.x : v.x * s.x; v.y = v.y >= 0.f ? v.y : v.y * s.y; v.z = v.z >= 0.f ? v.z : v.z * s.z; v.w = v.w >= 0.f ? v.w : v.w * s.w;
+    }
+    reinterpret_cast<float4*>(x)[i] = v;
+}
+
+// AdaptiveAvgPool2d(1): [N][HW][C] -> [N][C]
+__global__ __launch_bounds__(256) void avsr_avgpool_kernel(const float* __restrict__ in, int HW, int C, size_t total, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t n = idx / C;
+    const int c = (int)(idx - n * C);
+    float s = 0.0f;
+    for (int p = 0; p < HW; ++p) s += in[(n * HW + p) * C + c];
+    out[idx] = s / (float)HW;
+}
+
+// rows [M][K] -> [M][Kp] zero-padded (the audio features' K = 104 -> 128)
+__global__ __launch_bounds__(256) void avsr_padcols_kernel(const float* __restrict__ in, int K, int Kp, size_t total, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t m = idx / Kp;
+    const int k = (int)(idx - m * Kp);
+    out[idx] = k < K ? in[m * K + k] : 0.0f;
+}
+
+// LayerNorm over the last axis, one wave per row: mean, then the biased variance of the centred values (two passes, like torch),
+// (x - mean) / sqrt(var + eps) * g + b.  `zero_rows` (optional, [M], nonzero = write zeros instead: HubertEncoder zeroes padded
+// frames before the positional convolution) is applied to the OUTPUT.
+__global__ __launch_bounds__(256) void avsr_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b, int M, int d,
+                                                             float eps, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * d;
+    float s = 0.0f;
+    for (int c = lane; c < d; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)d;
+    float v = 0.0f;
+    for (int c = lane; c < d; c += 64) { const float e = xr[c] - mean; v = fmaf(e, e, v); }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+    for (int c = lane; c < d; c += 64) out[(size_t)row * d + c] = (xr[c] - mean) * rstd * g[c] + b[c];
+}
+
+// rows whose mask entry is nonzero become zeros (HubertEncoder.forward: hidden_states[~attention_mask] = 0)
+__global__ __launch_bounds__(256) void avsr_mask_rows_kernel(float* __restrict__ x, const float* __restrict__ mask, int d, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    if (mask[idx / d] != 0.0f) x[idx] = 0.0f;
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// HubertPositionalConvEmbedding + residual: y[b][t][g cg + oc] = x + gelu(bias + sum_{k, ic} w[g][k][ic][oc] x[b][t + k - K / 2][g cg + ic])
+// (an even kernel drops its last output frame: the window of frame t is [t - K/2, t + K/2 - 1]).  grid (ceil(T / 8), G, B); the
+// group's frames [t0 - K/2, t0 + 8 + K/2) sit in LDS; a thread owns (frame, output channel) pairs, taps then input channels ascending.
+__global__ __launch_bounds__(256) void avsr_posconv_kernel(const float* __restrict__ x, int T, int d, int cg, int K, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                    // [8 + K][cg]
+    const int t0 = blockIdx.x * 8, g = blockIdx.y, b = blockIdx.z, half = K / 2;
+    for (int i = threadIdx.x; i < (8 + K) * cg; i += 256) {
+        const int r = i / cg, c = i - r * cg, t = t0 + r - half;
+        xs[i] = (t >= 0 && t < T) ? x[((size_t)b * T + t) * d + g * cg + c] : 0.0f;
+    }
+    __syncthreads();
+    const float* wg = w + (size_t)g * K * cg * cg;
+    for (int o = threadIdx.x; o < 8 * cg; o += 256) {
+        const int tl = o / cg, oc = o - tl * cg, t = t0 + tl;
+        if (t >= T) continue;
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float* xr = xs + (tl + k) * cg;
+            const float* wr = wg + (size_t)k * cg * cg + oc;
+            for (int ic = 0; ic < cg; ++ic) acc = fmaf(wr[(size_t)ic * cg], xr[ic], acc);
+        }
+        const size_t at = ((size_t)b * T + t) * d + g * cg + oc;
+        out[at] = x[at] + gelu_exact(acc + bias[g * cg + oc]);
+    }
+}
+
+// Scaled dot-product attention, one wave per (query, head, query batch row); a lane owns head-dim elements lane, lane + 64, ..
+//   s_j = (q . k_j) * scaling over the visible keys j < n_keys, j <= causal limit, kmask[kb][j] == 0;  out = softmax(s) v
+// Two passes (maximum, then exp / sum / PV; scores recomputed).  Query rows qb = blockIdx.z read keys of batch kb = qb / rows_per_kb.
+// q [Bq][Tq][ldq], k / v [Bk][Tk_pitch][ldk] (+ head offset), out [Bq][Tq][ldo].
+template <int NV>
+__global__ __launch_bounds__(256) void avsr_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldk,
+                                                        size_t k_batch_stride, const float* __restrict__ kmask, int mask_pitch, int rows_per_kb, int Tq,
+                                                        int n_keys, int hd, float scaling, int causal, float* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, qb = blockIdx.z;
+    if (i >= Tq) return;
+    const int kb = qb / rows_per_kb;
+    const float* qr = q + ((size_t)qb * Tq + i) * ldq + h * hd;
+    const float* kbase = k + (size_t)kb * k_batch_stride + h * hd;
+    const float* vbase = v + (size_t)kb * k_batch_stride + h * hd;
+    const float* mk = kmask ? kmask + (size_t)kb * mask_pitch : nullptr;
+    const int last = causal ? (i < n_keys - 1 ? i : n_keys - 1) : n_keys - 1;
+    float qv[NV], acc[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        ok[e] = lane + 64 * e < hd;
+        qv[e] = ok[e] ? qr[lane + 64 * e] : 0.0f;
+        acc[e] = 0.0f;
+    }
+    auto score = [&](int j) -> float {
+        const float* kr = kbase + (size_t)j * ldk;
+        float s = 0.0f;
+#pragma unroll
+        for (int e = 0; e < NV; ++e)
+            if (ok[e]) s = fmaf(qv[e], kr[lane + 64 * e], s);
+        return wave_sum(s) * scaling;
+    };
+    float mx = -INFINITY;
+    for (int j = 0; j <= last; ++j)
+        if (!mk || mk[j] == 0.0f) mx = fmaxf(mx, score(j));
+    float den = 0.0f;
+    for (int j = 0; j <= last; ++j) {
+        if (mk && mk[j] != 0.0f) continue;
+        const float p = expf(score(j) - mx);
+        den += p;
+        const float* vr = vbase + (size_t)j * ldk;
+#pragma unroll
+        for (int e = 0; e < NV; ++e)
+            if (ok[e]) acc[e] = fmaf(p, vr[lane + 64 * e], acc[e]);
+    }
+    float* orow = out + ((size_t)qb * Tq + i) * ldo + h * hd;
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+        if (ok[e]) orow[lane + 64 * e] = den > 0.0f ? acc[e] / den : 0.0f;
+}
+
+// decoder input of one step: x[r] = embed[token[r]] + pos[step]
+__global__ __launch_bounds__(256) void avsr_embed_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ embed, const float* __restrict__ pos, int step, int d,
+                                                         int V, size_t total, float* __restrict__ x) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t r = idx / d;
+    const int c = (int)(idx - r * d);
+    int tok = tokens[r];
+    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+    x[idx] = embed[(size_t)tok * d + c] + pos[(size_t)step * d + c];
+}
+
+// self-attention cache of one step: the row's prefix is re-gathered from its source row (beam search: rows change parents), then this
+// step's keys / values are appended.  old / neu: [layers][2][R][Lmax][d]; qkv of the CURRENT layer only is appended by the caller's
+// per-layer launch (append_kernel); this kernel moves the prefixes of ALL layers at once.  grid (step, R, layers * 2)
+__global__ __launch_bounds__(256) void avsr_cache_gather_kernel(const float* __restrict__ old, float* __restrict__ neu, const int32_t* __restrict__ src_rows, int R,
+                                                                int Lmax, int d) {
+    const int pos = blockIdx.x, r = blockIdx.y, lk = blockIdx.z;
+    const int src = src_rows[r];
+    const float4* from = reinterpret_cast<const float4*>(old + (((size_t)lk * R + src) * Lmax + pos) * d);
+    float4* to = reinterpret_cast<float4*>(neu + (((size_t)lk * R + r) * Lmax + pos) * d);
+    for (int c = threadIdx.x; c < d / 4; c += 256) to[c] = from[c];
+}
+
+// append this step's k | v (columns [d, 3d) of the layer's qkv rows) to the layer's cache at position `step`
+__global__ __launch_bounds__(256) void avsr_cache_append_kernel(const float* __restrict__ qkv, float* __restrict__ kcache, float* __restrict__ vcache, int Lmax, int d,
+                                                                int step, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t r = idx / d;
+    const int c = (int)(idx - r * d);
+    kcache[(r * Lmax + step) * d + c] = qkv[r * 3 * d + d + c];
+    vcache[(r * Lmax + step) * d + c] = qkv[r * 3 * d + 2 * d + c];
+}
+
+struct AvsrPlan {
+    int H1, H2;                      // after the Conv3d (H / 2) and after the max-pool
+    size_t off_a0, off_a1, off_col, off_x, off_y, off_z, off_pool, off_apad, off_fused, off_h, off_t, off_qkv, off_big, total;
+};
+
+AvsrPlan avsr_plan(const rs_avsr& k, int B, int T) {
+    const rs_avsr_dims& d = k.d;
+    AvsrPlan p{};
+    p.H1 = d.image_size / 2;
+    p.H2 = (p.H1 + 1) / 2;
+    const size_t N = (size_t)B * T, dm = d.encoder_embed_dim;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += rs_align(bytes); return at; };
+    p.off_a0 = take(N * p.H1 * p.H1 * 64 * 4);
+    const size_t map = N * p.H2 * p.H2 * 64 * 4;           // the largest trunk map (layer 1); later layers halve the pixels and double the channels
+    p.off_x = take(map); p.off_y = take(map); p.off_z = take(map);
+    p.off_col = take(N * p.H2 * p.H2 * 9 * 64 * 4);       // the largest patch matrix (layer 1: K = 576)
+    p.off_a1 = take(map / 2);                              // strided rows of a down-sampling convolution
+    p.off_pool = take(N * 512 * 4);
+    p.off_apad = take(N * pad32(d.audio_feat_dim) * 4);
+    p.off_fused = take(N * 2 * dm * 4);
+    p.off_h = take(N * dm * 4);
+    p.off_t = take(N * dm * 4);
+    p.off_qkv = take(N * 3 * dm * 4);
+    p.off_big = take(N * (size_t)std::max(d.encoder_ffn_dim, 2 * d.encoder_embed_dim) * 4);
+    p.total = o + 256;
+    return p;
+}
+
+template <typename T>
+int avsr_get(rs_ctx* ctx, const std::string& name, size_t elems, const T*& out) {
+    auto it = ctx->tensors.find(name);
+    if (it == ctx->tensors.end()) return rs_fail(ctx, RS_EMISSING, "weight tensor '%s' was not registered", name.c_str());
+    if (it->second.second != elems * sizeof(T))
+        return rs_fail(ctx, RS_EINVAL, "tensor '%s': expected %zu bytes, got %zu", name.c_str(), elems * sizeof(T), it->second.second);
+    if ((uintptr_t)it->second.first & 15) return rs_fail(ctx, RS_EINVAL, "tensor '%s' is not 16-byte aligned", name.c_str());
+    out = reinterpret_cast<const T*>(it->second.first);
+    return RS_OK;
+}
+
+void avsr_free(rs_avsr* k) { delete k; }
+
+int launch_attn(rs_ctx* ctx, const float* q, int ldq, const float* k, const float* v, int ldk, size_t kstride, const float* kmask, int mask_pitch, int rows_per_kb,
+                int Bq, int Tq, int n_keys, int H, int hd, int causal, float* out, int ldo, hipStream_t s) {
+    if (Bq <= 0 || Tq <= 0 || n_keys <= 0) return RS_OK;
+    if (hd > 256) return rs_fail(ctx, RS_EINVAL, "avsr attention: head_dim %d > 256", hd);
+    const dim3 grid((Tq + 3) / 4, H, Bq), block(256);
+    const float scaling = 1.0f / sqrtf((float)hd);
+#define RS_AV_ATT(NV) hipLaunchKernelGGL((avsr_attn_kernel<NV>), grid, block, 0, s, q, ldq, k, v, ldk, kstride, kmask, mask_pitch, rows_per_kb, Tq, n_keys, hd, scaling, causal, out, ldo)
+    if (hd <= 64) RS_AV_ATT(1);
+    else if (hd <= 128) RS_AV_ATT(2);
+    else RS_AV_ATT(4);
+#undef RS_AV_ATT
+    RS_CHECK_LAUNCH(ctx, "avsr attention");
+    return RS_OK;
+}
+
+}  // namespace
+
+extern "C" int rs_avsr_create(rs_ctx** out, int device, const rs_avsr_dims* dims) {
+    if (!out || !dims) return RS_EINVAL;
+    *out = nullptr;
+    rs_ctx* ctx = new (std::nothrow) rs_ctx();
+    if (!ctx) return RS_EINVAL;
+    *out = ctx;
+    ctx->device = device;
+    rs_avsr* k = new (std::nothrow) rs_avsr();
+    if (!k) return rs_fail(ctx, RS_EINVAL, "out of memory");
+    ctx->avsr = k;
+    ctx->avsr_free = avsr_free;
+    k->d = *dims;
+    const rs_avsr_dims& d = k->d;
+    if (d.encoder_layers < 1 || d.decoder_layers < 1 || d.encoder_embed_dim % 32 || d.decoder_embed_dim != d.encoder_embed_dim || d.encoder_ffn_dim % 32 ||
+        d.decoder_ffn_dim % 32 || d.encoder_heads < 1 || d.decoder_heads < 1 || d.encoder_embed_dim % d.encoder_heads || d.decoder_embed_dim % d.decoder_heads)
+        return rs_fail(ctx, RS_EINVAL, "avsr: widths must be multiples of 32 and divisible by the head counts; encoder and decoder share one width");
+    if (d.conv_pos < 2 || d.conv_pos % 2 || d.conv_pos_groups < 1 || d.encoder_embed_dim % d.conv_pos_groups)
+        return rs_fail(ctx, RS_EINVAL, "avsr: positional convolution (kernel %d, groups %d)", d.conv_pos, d.conv_pos_groups);
+    if (d.image_size < 16 || d.image_size > 96 || d.image_size % 8) return rs_fail(ctx, RS_EINVAL, "avsr: image_size %d (16 .. 96, a multiple of 8)", d.image_size);
+    if (d.audio_feat_dim < 1 || d.vocab_size < 2 || d.max_positions < 2 || !d.fuse_concat)
+        return rs_fail(ctx, RS_EINVAL, "avsr: audio_feat_dim / vocab_size / max_positions; modality_fuse 'concat' is built");
+    if (hipSetDevice(device) != hipSuccess) return rs_fail(ctx, RS_EHIP, "hipSetDevice(%d) failed", device);
+    return RS_OK;
+}
+
+int rs_avsr_finalize_impl(rs_ctx* ctx) {
+    rs_avsr& k = *ctx->avsr;
+    const rs_avsr_dims& d = k.d;
+    int rc;
+    const size_t dm = d.encoder_embed_dim, ffn = d.encoder_ffn_dim, dffn = d.decoder_ffn_dim;
+#define AV_GET(name, elems, field) do { rc = avsr_get(ctx, name, (size_t)(elems), field); if (rc != RS_OK) return rc; } while (0)
+    AV_GET("fe.audio.w", dm * pad32(d.audio_feat_dim), k.audio_w); AV_GET("fe.audio.b", dm, k.audio_b);
+    AV_GET("v.conv3d.w", 245 * 64, k.conv3d_w); AV_GET("v.bn0.alpha", 64, k.bn0_a); AV_GET("v.bn0.beta", 64, k.bn0_b); AV_GET("v.prelu0", 64, k.prelu0);
+    for (int L = 1; L <= 4; ++L)
+        for (int b = 0; b < 2; ++b) {
+            rs_avsr_block& B = k.blocks[L - 1][b];
+            const std::string p = "v.l" + std::to_string(L) + "." + std::to_string(b) + ".";
+            const size_t cin = b == 0 ? TRUNK_C[L - 1] : TRUNK_C[L], c = TRUNK_C[L];
+            AV_GET(p + "conv1.w", c * 9 * cin, B.conv1_w); AV_GET(p + "conv2.w", c * 9 * c, B.conv2_w);
+            AV_GET(p + "bn1.alpha", c, B.bn1_a); AV_GET(p + "bn1.beta", c, B.bn1_b); AV_GET(p + "bn2.alpha", c, B.bn2_a); AV_GET(p + "bn2.beta", c, B.bn2_b);
+            AV_GET(p + "relu1", c, B.relu1); AV_GET(p + "relu2", c, B.relu2);
+            B.ds_w = B.ds_a = B.ds_b = nullptr;
+            if (b == 0 && L > 1) { AV_GET(p + "ds.w", c * cin, B.ds_w); AV_GET(p + "ds.bn.alpha", c, B.ds_a); AV_GET(p + "ds.bn.beta", c, B.ds_b); }
+        }
+    AV_GET("v.proj.w", dm * 512, k.vproj_w); AV_GET("v.proj.b", dm, k.vproj_b);
+    AV_GET("fuse.ln.g", 2 * dm, k.fuse_g); AV_GET("fuse.ln.b", 2 * dm, k.fuse_b);
+    AV_GET("fuse.proj.w", dm * 2 * dm, k.fproj_w); AV_GET("fuse.proj.b", dm, k.fproj_b);
+    const size_t cg = dm / d.conv_pos_groups;
+    AV_GET("enc.pos.w", (size_t)d.conv_pos_groups * d.conv_pos * cg * cg, k.pos_w); AV_GET("enc.pos.b", dm, k.pos_b);
+    AV_GET("enc.ln.g", dm, k.encln_g); AV_GET("enc.ln.b", dm, k.encln_b);
+    k.enc.assign(d.encoder_layers, rs_avsr_layer{});
+    for (int i = 0; i < d.encoder_layers; ++i) {
+        rs_avsr_layer& L = k.enc[i];
+        const std::string p = "E" + std::to_string(i) + ".";
+        AV_GET(p + "qkv.w", 3 * dm * dm, L.sa.qkv_w); AV_GET(p + "qkv.b", 3 * dm, L.sa.qkv_b); AV_GET(p + "o.w", dm * dm, L.sa.o_w); AV_GET(p + "o.b", dm, L.sa.o_b);
+        AV_GET(p + "ln1.g", dm, L.ln1_g); AV_GET(p + "ln1.b", dm, L.ln1_b); AV_GET(p + "ln2.g", dm, L.ln2_g); AV_GET(p + "ln2.b", dm, L.ln2_b);
+        AV_GET(p + "ff1.w", ffn * dm, L.ff1_w); AV_GET(p + "ff1.b", ffn, L.ff1_b); AV_GET(p + "ff2.w", dm * ffn, L.ff2_w); AV_GET(p + "ff2.b", dm, L.ff2_b);
+    }
+    AV_GET("dec.embed", (size_t)d.vocab_size * dm, k.embed); AV_GET("dec.pos", (size_t)d.max_positions * dm, k.dec_pos);
+    AV_GET("dec.ln.g", dm, k.decln_g); AV_GET("dec.ln.b", dm, k.decln_b);
+    AV_GET("dec.lm.w", (size_t)pad4(d.vocab_size) * dm, k.lm_w);
+    k.dec.assign(d.decoder_layers, rs_avsr_layer{});
+    for (int i = 0; i < d.decoder_layers; ++i) {
+        rs_avsr_layer& L = k.dec[i];
+        const std::string p = "D" + std::to_string(i) + ".";
+        AV_GET(p + "sa.qkv.w", 3 * dm * dm, L.sa.qkv_w); AV_GET(p + "sa.qkv.b", 3 * dm, L.sa.qkv_b); AV_GET(p + "sa.o.w", dm * dm, L.sa.o_w); AV_GET(p + "sa.o.b", dm, L.sa.o_b);
+        AV_GET(p + "ca.q.w", dm * dm, L.ca.q_w); AV_GET(p + "ca.q.b", dm, L.ca.q_b); AV_GET(p + "ca.kv.w", 2 * dm * dm, L.ca.kv_w); AV_GET(p + "ca.kv.b", 2 * dm, L.ca.kv_b);
+        AV_GET(p + "ca.o.w", dm * dm, L.ca.o_w); AV_GET(p + "ca.o.b", dm, L.ca.o_b);
+        AV_GET(p + "ln1.g", dm, L.ln1_g); AV_GET(p + "ln1.b", dm, L.ln1_b); AV_GET(p + "ln2.g", dm, L.ln2_g); AV_GET(p + "ln2.b", dm, L.ln2_b);
+        AV_GET(p + "ln3.g", dm, L.ln3_g); AV_GET(p + "ln3.b", dm, L.ln3_b);
+        AV_GET(p + "ff1.w", dffn * dm, L.ff1_w); AV_GET(p + "ff1.b", dffn, L.ff1_b); AV_GET(p + "ff2.w", dm * dffn, L.ff2_w); AV_GET(p + "ff2.b", dm, L.ff2_b);
+    }
+#undef AV_GET
+    ctx->finalized = true;
+    return RS_OK;
+}
+
+extern "C" int rs_avsr_encoder_set_taps(rs_ctx* ctx, float* video, float* fused_ln, float* enc_ln, float* layer_out, const int32_t* layer_ids, int n_layer_ids) {
+    if (!ctx || !ctx->avsr) return RS_EINVAL;
+    rs_avsr& k = *ctx->avsr;
+    if (n_layer_ids < 0 || (n_layer_ids > 0 && (!layer_out || !layer_ids))) return rs_fail(ctx, RS_EINVAL, "avsr taps: null pointer");
+    for (int i = 0; i < n_layer_ids; ++i)
+        if (layer_ids[i] < 0 || layer_ids[i] >= k.d.encoder_layers) return rs_fail(ctx, RS_EINVAL, "avsr taps: layer %d out of range", layer_ids[i]);
+    k.tap_video = video; k.tap_fused = fused_ln; k.tap_encln = enc_ln;
+    k.tap_layers = n_layer_ids > 0 ? layer_out : nullptr;
+    k.tap_ids.assign(layer_ids, layer_ids + n_layer_ids);
+    return RS_OK;
+}
+
+extern "C" size_t rs_avsr_workspace_bytes(const rs_ctx* ctx, int B, int T) {
+    if (!ctx || !ctx->avsr || B <= 0 || T <= 0) return 0;
+    return avsr_plan(*ctx->avsr, B, T).total;
+}
+
+extern "C" int rs_avsr_encoder_forward(rs_ctx* ctx, const float* input_values, const float* pixel_values, const float* padding_mask, int B, int T, float* enc_out,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx || !ctx->avsr) return RS_EINVAL;
+    if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_avsr_encoder_forward");
+    if (B <= 0 || T <= 0) return B < 0 || T < 0 ? rs_fail(ctx, RS_EINVAL, "avsr encoder: negative size") : RS_OK;
+    if (!input_values || !pixel_values || !padding_mask || !enc_out || !workspace) return rs_fail(ctx, RS_EINVAL, "avsr encoder: null pointer");
+    rs_avsr& k = *ctx->avsr;
+    const rs_avsr_dims& d = k.d;
+    hipStream_t s = (hipStream_t)stream;
+    const AvsrPlan pl = avsr_plan(k, B, T);
+    if (workspace_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "avsr encoder: workspace %zu < %zu", workspace_bytes, pl.total);
+    if (T > 65535 || B > 65535) return rs_fail(ctx, RS_EINVAL, "avsr encoder: more than 65535 frames / clips per call");
+    char* ws = reinterpret_cast<char*>(workspace);
+    auto fp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    float *a0 = fp(pl.off_a0), *x = fp(pl.off_x), *y = fp(pl.off_y), *z = fp(pl.off_z), *col = fp(pl.off_col), *a1 = fp(pl.off_a1), *pool = fp(pl.off_pool);
+    float *apad = fp(pl.off_apad), *fused = fp(pl.off_fused), *h = fp(pl.off_h), *t = fp(pl.off_t), *qkv = fp(pl.off_qkv), *big = fp(pl.off_big);
+    const int dm = d.encoder_embed_dim, ffn = d.encoder_ffn_dim, H = d.image_size;
+    const size_t N = (size_t)B * T;
+    const int M = (int)N;
+    int rc;
+#define RS_TRY(call) do { rc = (call); if (rc != RS_OK) return rc; } while (0)
+    auto gemm = [&](const float* A, int lda, const float* W, int K, float* out, int ldc, long long rows, int Nc, int flags, const float* bias, const float* res) -> int {
+        if (rows > 0x7fffffffLL) return rs_fail(ctx, RS_EINVAL, "avsr: %lld GEMM rows", rows);
+        return rs_launch_gemm_f32(ctx, A, lda, W, K, out, ldc, (int)rows, Nc, K, flags, bias, 1.0f, res, nullptr, 0, 0, s);
+    };
+    auto blocks1d = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    // ---- video: Conv3d + BN + PReLU, max-pool, ResNet-18 trunk, average pool, projection
+    rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 2.0 * N * pl.H1 * pl.H1 * 64 * 245.0, 0.0);
+    hipLaunchKernelGGL(avsr_conv3d_kernel, dim3(pl.H1, T, B), dim3(256), 0, s, pixel_values, T, H, H, k.conv3d_w, k.bn0_a, k.bn0_b, k.prelu0, a0);
+    {
+        const size_t total = N * pl.H2 * pl.H2 * 64;
+        hipLaunchKernelGGL(avsr_maxpool_kernel, blocks1d(total), dim3(256), 0, s, a0, pl.H1, pl.H1, 64, pl.H2, pl.H2, total, x);
+    }
+    rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
+    RS_CHECK_LAUNCH(ctx, "avsr video front-end");
+    int hw = pl.H2;
+    float *cur = x, *o1 = y, *o2 = z;
+    for (int L = 1; L <= 4; ++L)
+        for (int b = 0; b < 2; ++b) {
+            const rs_avsr_block& Bk = k.blocks[L - 1][b];
+            const int cin = b == 0 ? TRUNK_C[L - 1] : TRUNK_C[L], c = TRUNK_C[L];
+            const int stride = (b == 0 && L > 1) ? 2 : 1;
+            const int ohw = stride == 2 ? (hw - 1) / 2 + 1 : hw;            // 3 x 3, padding 1
+            const size_t rows_out = N * ohw * ohw;
+            // conv1 -> bn1 -> relu1
+            hipLaunchKernelGGL(avsr_im2col3_kernel, blocks1d(rows_out * 9 * cin / 4), dim3(256), 0, s, cur, hw, hw, cin, ohw, ohw, stride, rows_out * 9 * cin / 4, col);
+            RS_TRY(gemm(col, 9 * cin, Bk.conv1_w, 9 * cin, o1, c, (long long)rows_out, c, 0, nullptr, nullptr));
+            hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o1, Bk.bn1_a, Bk.bn1_b, (const float*)nullptr, Bk.relu1, c, rows_out * c / 4);
+            // conv2 -> bn2 -> (+ residual) -> relu2
+            hipLaunchKernelGGL(avsr_im2col3_kernel, blocks1d(rows_out * 9 * c / 4), dim3(256), 0, s, o1, ohw, ohw, c, ohw, ohw, 1, rows_out * 9 * c / 4, col);
+            RS_TRY(gemm(col, 9 * c, Bk.conv2_w, 9 * c, o2, c, (long long)rows_out, c, 0, nullptr, nullptr));
+            const float* res = cur;
+            if (Bk.ds_w) {                                                   // 1 x 1 convolution with the block's stride + BatchNorm on the block input
+                const float* src = cur;
+                if (stride == 2) {
+                    hipLaunchKernelGGL(avsr_stride2_kernel, blocks1d(rows_out * cin / 4), dim3(256), 0, s, cur, hw, hw, cin, ohw, ohw, rows_out * cin / 4, a1);
+                    src = a1;
+                }
+                RS_TRY(gemm(src, cin, Bk.ds_w, cin, o1, c, (long long)rows_out, c, 0, nullptr, nullptr));       // (o1 is free again: conv2's patches were taken)
+                hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o1, Bk.ds_a, Bk.ds_b, (const float*)nullptr, (const float*)nullptr, c,
+                                   rows_out * c / 4);
+                res = o1;
+            }
+            hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o2, Bk.bn2_a, Bk.bn2_b, res, Bk.relu2, c, rows_out * c / 4);
+            RS_CHECK_LAUNCH(ctx, "avsr ResNet block");
+            float* nxt = o2;                      // rotate: the block's output becomes the input, the old input and o1 are scratch
+            o2 = cur; cur = nxt;
+            hw = ohw;
+        }
+    hipLaunchKernelGGL(avsr_avgpool_kernel, blocks1d(N * 512), dim3(256), 0, s, cur, hw * hw, 512, N * 512, pool);
+    // audio and video projections straight into the two halves of the fused rows [M][2 d]
+    const int Ka = pad32(d.audio_feat_dim);
+    hipLaunchKernelGGL(avsr_padcols_kernel, blocks1d(N * Ka), dim3(256), 0, s, input_values, d.audio_feat_dim, Ka, N * Ka, apad);
+    RS_TRY(gemm(apad, Ka, k.audio_w, Ka, fused, 2 * dm, M, dm, RS_GEMM_BIAS, k.audio_b, nullptr));
+    RS_TRY(gemm(pool, 512, k.vproj_w, 512, fused + dm, 2 * dm, M, dm, RS_GEMM_BIAS, k.vproj_b, nullptr));
+    if (k.tap_video) RS_HIP(ctx, hipMemcpy2DAsync(k.tap_video, (size_t)dm * 4, fused + dm, (size_t)2 * dm * 4, (size_t)dm * 4, N, hipMemcpyDeviceToDevice, s));
+    // fusion LayerNorm, post_extract_proj, padded frames zeroed, positional convolution, encoder LayerNorm
+    hipLaunchKernelGGL(avsr_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, fused, k.fuse_g, k.fuse_b, M, 2 * dm, 1e-5f, fused);
+    if (k.tap_fused) RS_HIP(ctx, hipMemcpyAsync(k.tap_fused, fused, N * 2 * dm * 4, hipMemcpyDeviceToDevice, s));
+    RS_TRY(gemm(fused, 2 * dm, k.fproj_w, 2 * dm, h, dm, M, dm, RS_GEMM_BIAS, k.fproj_b, nullptr));
+    hipLaunchKernelGGL(avsr_mask_rows_kernel, blocks1d(N * dm), dim3(256), 0, s, h, padding_mask, dm, N * dm);
+    {
+        const int cg = dm / d.conv_pos_groups;
+        const size_t lds = (size_t)(8 + d.conv_pos) * cg * 4;
+        if (lds > 64 * 1024) RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)avsr_posconv_kernel, (int)lds));
+        hipLaunchKernelGGL(avsr_posconv_kernel, dim3((T + 7) / 8, d.conv_pos_groups, B), dim3(256), lds, s, h, T, dm, cg, d.conv_pos, k.pos_w, k.pos_b, t);
+    }
+    hipLaunchKernelGGL(avsr_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, t, k.encln_g, k.encln_b, M, dm, d.layer_norm_eps, h);
+    if (k.tap_encln) RS_HIP(ctx, hipMemcpyAsync(k.tap_encln, h, N * dm * 4, hipMemcpyDeviceToDevice, s));
+    RS_CHECK_LAUNCH(ctx, "avsr fusion");
+    // ---- HuBERT encoder layers (post-LayerNorm): x = LN(x + attn(x)); x = LN(x + ffn(x))
+    const int hd = dm / d.encoder_heads;
+    for (int i = 0; i < d.encoder_layers; ++i) {
+        const rs_avsr_layer& L = k.enc[i];
+        RS_TRY(gemm(h, dm, L.sa.qkv_w, dm, qkv, 3 * dm, M, 3 * dm, RS_GEMM_BIAS, L.sa.qkv_b, nullptr));
+        RS_TRY(launch_attn(ctx, qkv, 3 * dm, qkv + dm, qkv + 2 * dm, 3 * dm, (size_t)T * 3 * dm, padding_mask, T, 1, B, T, T, d.encoder_heads, hd, 0, t, dm, s));
+        RS_TRY(gemm(t, dm, L.sa.o_w, dm, big, dm, M, dm, RS_GEMM_BIAS | RS_GEMM_RESIDUAL, L.sa.o_b, h));
+        hipLaunchKernelGGL(avsr_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, big, L.ln1_g, L.ln1_b, M, dm, d.layer_norm_eps, h);
+        RS_TRY(gemm(h, dm, L.ff1_w, dm, big, ffn, M, ffn, RS_GEMM_BIAS | RS_GEMM_GELU, L.ff1_b, nullptr));
+        RS_TRY(gemm(big, ffn, L.ff2_w, ffn, t, dm, M, dm, RS_GEMM_BIAS | RS_GEMM_RESIDUAL, L.ff2_b, h));
+        hipLaunchKernelGGL(avsr_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, t, L.ln2_g, L.ln2_b, M, dm, d.layer_norm_eps, h);
+        for (size_t q = 0; q < k.tap_ids.size(); ++q)
+            if (k.tap_ids[q] == i) RS_HIP(ctx, hipMemcpyAsync(k.tap_layers + q * N * dm, h, N * dm * 4, hipMemcpyDeviceToDevice, s));
+        RS_CHECK_LAUNCH(ctx, "avsr encoder layer");
+    }
+    RS_HIP(ctx, hipMemcpyAsync(enc_out, h, N * dm * 4, hipMemcpyDeviceToDevice, s));
+#undef RS_TRY
+    return RS_OK;
+}
+
+// ---- decoder ----------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct AvsrDecPlan {
+    size_t off_cross, off_cache[2], off_x, off_t, off_u, off_qkv, off_big, off_src, total;
+};
+AvsrDecPlan avsr_dec_plan(const rs_avsr& k, int B, int T, int beams, int max_len) {
+    const rs_avsr_dims& d = k.d;
+    const size_t dm = d.decoder_embed_dim, R = (size_t)B * beams, Ld = d.decoder_layers;
+    AvsrDecPlan p{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += rs_align(bytes); return at; };
+    p.off_cross = take(Ld * (size_t)B * T * 2 * dm * 4);
+    p.off_cache[0] = take(Ld * 2 * R * max_len * dm * 4);
+    p.off_cache[1] = take(Ld * 2 * R * max_len * dm * 4);
+    p.off_x = take(R * dm * 4); p.off_t = take(R * dm * 4); p.off_u = take(R * dm * 4);
+    p.off_qkv = take(R * 3 * dm * 4);
+    p.off_big = take(R * (size_t)std::max(d.decoder_ffn_dim, d.decoder_embed_dim) * 4);
+    p.off_src = take(R * 4);
+    p.total = o + 256;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t rs_avsr_decoder_state_bytes(const rs_ctx* ctx, int B, int T, int beams, int max_len) {
+    if (!ctx || !ctx->avsr || B <= 0 || T <= 0 || beams <= 0 || max_len <= 0) return 0;
+    return avsr_dec_plan(*ctx->avsr, B, T, beams, max_len).total;
+}
+
+extern "C" int rs_avsr_decoder_begin(rs_ctx* ctx, const float* enc, int B, int T, int beams, int max_len, void* state, size_t state_bytes, void* stream) {
+    if (!ctx || !ctx->avsr) return RS_EINVAL;
+    if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_avsr_decoder_begin");
+    if (B <= 0 || T <= 0 || beams <= 0 || max_len <= 0 || !enc || !state) return rs_fail(ctx, RS_EINVAL, "avsr decoder: bad argument");
+    rs_avsr& k = *ctx->avsr;
+    const rs_avsr_dims& d = k.d;
+    if (max_len > d.max_positions) return rs_fail(ctx, RS_EINVAL, "avsr decoder: %d positions exceed max_target_positions %d", max_len, d.max_positions);
+    const AvsrDecPlan pl = avsr_dec_plan(k, B, T, beams, max_len);
+    if (state_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "avsr decoder: state %zu < %zu", state_bytes, pl.total);
+    hipStream_t s = (hipStream_t)stream;
+    const int dm = d.decoder_embed_dim;
+    float* cross = reinterpret_cast<float*>(reinterpret_cast<char*>(state) + pl.off_cross);
+    for (int i = 0; i < d.decoder_layers; ++i) {          // cross-attention keys | values of every layer, once per utterance batch
+        const rs_avsr_layer& L = k.dec[i];
+        const int rc = rs_launch_gemm_f32(ctx, enc, dm, L.ca.kv_w, dm, cross + (size_t)i * B * T * 2 * dm, 2 * dm, B * T, 2 * dm, dm, RS_GEMM_BIAS, L.ca.kv_b, 1.0f, nullptr,
+                                          nullptr, 0, 0, s);
+        if (rc != RS_OK) return rc;
+    }
+    return RS_OK;
+}
+
+extern "C" int rs_avsr_decoder_step(rs_ctx* ctx, const int32_t* tokens, const int32_t* src_rows, int step, const float* padding_mask, int B, int T, int beams,
+                                    int max_len, float* logits, void* state, size_t state_bytes, void* stream) {
+    if (!ctx || !ctx->avsr) return RS_EINVAL;
+    if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_avsr_decoder_step");
+    if (B <= 0 || T <= 0 || beams <= 0 || max_len <= 0 || step < 0 || step >= max_len || !tokens || !padding_mask || !logits || !state)
+        return rs_fail(ctx, RS_EINVAL, "avsr decoder step: bad argument (step %d of %d)", step, max_len);
+    rs_avsr& k = *ctx->avsr;
+    const rs_avsr_dims& d = k.d;
+    const AvsrDecPlan pl = avsr_dec_plan(k, B, T, beams, max_len);
+    if (state_bytes < pl.total) return rs_fail(ctx, RS_EWORKSPACE, "avsr decoder: state %zu < %zu", state_bytes, pl.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* st = reinterpret_cast<char*>(state);
+    auto fp = [&](size_t off) { return reinterpret_cast<float*>(st + off); };
+    const int dm = d.decoder_embed_dim, R = B * beams, ffn = d.decoder_ffn_dim, Ld = d.decoder_layers, hd = dm / d.decoder_heads, Vp = pad4(d.vocab_size);
+    // Self-attention caches: without re-parenting (greedy search: src_rows == NULL at every step) everything lives in buffer 0.  With
+    // re-parenting (beam search: src_rows given at every step >= 1) step s writes buffer s & 1: the prefixes [0, s) are gathered from
+    // the other buffer by source row first, then this step's keys / values are appended.
+    const bool reorder = src_rows != nullptr;
+    float* cache_cur = fp(pl.off_cache[reorder ? (step & 1) : 0]);
+    if (reorder && step > 0)
+        hipLaunchKernelGGL(avsr_cache_gather_kernel, dim3(step, R, Ld * 2), dim3(256), 0, s, fp(pl.off_cache[(step & 1) ^ 1]), cache_cur, src_rows, R, max_len, dm);
+    float *x = fp(pl.off_x), *t = fp(pl.off_t), *u = fp(pl.off_u), *qkv = fp(pl.off_qkv), *big = fp(pl.off_big), *cross = fp(pl.off_cross);
+    int rc;
+#define RS_TRY(call) do { rc = (call); if (rc != RS_OK) return rc; } while (0)
+    auto gemm = [&](const float* A, int lda, const float* W, int K, float* out, int ldc, int Nc, int flags, const float* bias, const float* res) -> int {
+        return rs_launch_gemm_f32(ctx, A, lda, W, K, out, ldc, R, Nc, K, flags, bias, 1.0f, res, nullptr, 0, 0, s);
+    };
+    auto ln = [&](const float* in, const float* g, const float* b, float* out) {
+        hipLaunchKernelGGL(avsr_layernorm_kernel, dim3((R + 3) / 4), dim3(256), 0, s, in, g, b, R, dm, d.layer_norm_eps, out);
+    };
+    hipLaunchKernelGGL(avsr_embed_kernel, dim3((unsigned)(((size_t)R * dm + 255) / 256)), dim3(256), 0, s, tokens, k.embed, k.dec_pos, step, dm, d.vocab_size, (size_t)R * dm, x);
+    for (int i = 0; i < Ld; ++i) {
+        const rs_avsr_layer& L = k.dec[i];
+        float* kc = cache_cur + ((size_t)(2 * i) * R) * max_len * dm;
+        float* vc = cache_cur + ((size_t)(2 * i + 1) * R) * max_len * dm;
+        RS_TRY(gemm(x, dm, L.sa.qkv_w, dm, qkv, 3 * dm, 3 * dm, RS_GEMM_BIAS, L.sa.qkv_b, nullptr));
+        hipLaunchKernelGGL(avsr_cache_append_kernel, dim3((unsigned)(((size_t)R * dm + 255) / 256)), dim3(256), 0, s, qkv, kc, vc, max_len, dm, step, (size_t)R * dm);
+        RS_TRY(launch_attn(ctx, qkv, 3 * dm, kc, vc, dm, (size_t)max_len * dm, nullptr, 0, 1, R, 1, step + 1, d.decoder_heads, hd, 0, t, dm, s));
+        RS_TRY(gemm(t, dm, L.sa.o_w, dm, u, dm, dm, RS_GEMM_BIAS | RS_GEMM_RESIDUAL, L.sa.o_b, x));
+        ln(u, L.ln1_g, L.ln1_b, x);
+        RS_TRY(gemm(x, dm, L.ca.q_w, dm, qkv, dm, dm, RS_GEMM_BIAS, L.ca.q_b, nullptr));
+        const float* ck = cross + (size_t)i * B * T * 2 * dm;
+        RS_TRY(launch_attn(ctx, qkv, dm, ck, ck + dm, 2 * dm, (size_t)T * 2 * dm, padding_mask, T, beams, R, 1, T, d.decoder_heads, hd, 0, t, dm, s));
+        RS_TRY(gemm(t, dm, L.ca.o_w, dm, u, dm, dm, RS_GEMM_BIAS | RS_GEMM_RESIDUAL, L.ca.o_b, x));
+        ln(u, L.ln2_g, L.ln2_b, x);
+        RS_TRY(gemm(x, dm, L.ff1_w, dm, big, ffn, ffn, RS_GEMM_BIAS | RS_GEMM_GELU, L.ff1_b, nullptr));
+        RS_TRY(gemm(big, ffn, L.ff2_w, ffn, u, dm, dm, RS_GEMM_BIAS | RS_GEMM_RESIDUAL, L.ff2_b, x));
+        ln(u, L.ln3_g, L.ln3_b, x);
+    }
+    ln(x, k.decln_g, k.decln_b, t);
+    RS_TRY(gemm(t, dm, k.lm_w, dm, logits, Vp, Vp, 0, nullptr, nullptr));
+    RS_CHECK_LAUNCH(ctx, "avsr decoder step");
+#undef RS_TRY
+    return RS_OK;
+}

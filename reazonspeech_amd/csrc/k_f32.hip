@@ -27,6 +27,7 @@ namespace {
 // IEEE forms (the throughput mode uses v_exp / v_rcp approximations: rs_common.h sigmoid_f)
 __device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }     // torch's exact GELU
 
 struct GemmF32 {
     const float* A; const float* W; float* out;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
     // epilogue, the order of k_gemm_bf16.hip: + bias, activation, * alpha, + residual, row mask
     const bool has_bias = p.flags & RS_GEMM_BIAS, relu = p.flags & RS_GEMM_RELU, silu = p.flags & RS_GEMM_SILU;
     const bool res = p.flags & RS_GEMM_RESIDUAL, rowmask = p.flags & RS_GEMM_ROWMASK;
-    const bool swl = p.flags & RS_GEMM_SWOOSHL, swr = p.flags & RS_GEMM_SWOOSHR;
+    const bool swl = p.flags & RS_GEMM_SWOOSHL, swr = p.flags & RS_GEMM_SWOOSHR, gelu = p.flags & RS_GEMM_GELU;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + fr;
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
             }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (silu) { v.x = silu_exact(v.x); v.y = silu_exact(v.y); v.z = silu_exact(v.z); v.w = silu_exact(v.w); }
+            if (gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
             if (swl) { v.x = swoosh_l_exact(v.x); v.y = swoosh_l_exact(v.y); v.z = swoosh_l_exact(v.z); v.w = swoosh_l_exact(v.w); }
             if (swr) { v.x = swoosh_r_exact(v.x); v.y = swoosh_r_exact(v.y); v.z = swoosh_r_exact(v.z); v.w = swoosh_r_exact(v.w); }
             v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
@@ -282,7 +284,7 @@ int rs_launch_gemm_f32(rs_ctx* ctx, const float* A, int lda, const float* W, int
     if (M <= 0 || N <= 0) return RS_OK;
     if (K <= 0 || K % GK || N % 4 || (lda % 4) || (ldw % 4) || (ldc % 4))
         return rs_fail(ctx, RS_EINVAL, "gemm_f32: K %% %d, N %% 4 and 16-byte row pitches required (M %d N %d K %d)", GK, M, N, K);
-    if (flags & ~(RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_SILU | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32 | RS_GEMM_ROWMASK | RS_GEMM_SWOOSHL | RS_GEMM_SWOOSHR))
+    if (flags & ~(RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_SILU | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32 | RS_GEMM_ROWMASK | RS_GEMM_SWOOSHL | RS_GEMM_SWOOSHR | RS_GEMM_GELU))
         return rs_fail(ctx, RS_EINVAL, "gemm_f32: unsupported flags %d", flags);
     if ((flags & RS_GEMM_BIAS) && !bias) return rs_fail(ctx, RS_EINVAL, "gemm_f32: bias flag without a bias");
     if ((flags & RS_GEMM_RESIDUAL) && !residual) return rs_fail(ctx, RS_EINVAL, "gemm_f32: residual flag without a residual");

@@ -63,6 +63,7 @@ struct GemmParams {
     unsigned cv_b_bytes, cv_t_bytes, cv_f_bytes;   // T1 * F1 * C * 2, 2 * F1 * C * 2, 2 * C * 2
     unsigned cv_seg_bytes;                  // F1 * C * 2: from a kernel row of the patch to the next
     int cv_tps, cv_inv;                     // K tiles per kernel row (3 * C / 64); ceil(65536 / cv_tps): k / cv_tps == (k * cv_inv) >> 16 (launcher checks)
+    const uint16_t* Wfm;                    // BREG instantiations: the weight once more, fragment-major [N / 16][K / 32][64 lanes][8] (wfm_shuffle_kernel)
 };
 
 // OUT_BF16S / OUT_F32S: the plain bf16 / f32 epilogues with icefall's Swoosh activations compiled in (the Zipformer family).
@@ -82,6 +83,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
@@ -94,6 +96,38 @@ __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigne
 }
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// BREG instantiations: a weight fragment goes global -> VGPR (one contiguous 1-KiB run per wave instruction in the fragment-major
+// copy), never through LDS.  Issued from inline asm like the DMAs so that the counted vmcnt waits below see ONE in-order queue;
+// the compiler believes the register is written at once, so every consumer is fenced by breg_wait, which names the registers as
+// read-write operands of the s_waitcnt.
+__device__ __forceinline__ void gload16(u32x4_t& dst, unsigned voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// ONE fence per use, after whichever counted wait ran: an asm per branch would give the registers one definition per branch and
+// the merge makes the compiler copy them — at a point where the loads may still be in flight (seen in the ISA of the first
+// version: v_mov_b64 of the set at the loop head, stale fragments in 192-row launches).
+__device__ __forceinline__ void breg_fence(u32x4_t (&r)[4]) {
+    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+// W bf16 [N][ldw] -> fragment-major [N / 16][K / 32][64][8]: fragment (nb, kb), lane l = W[16 nb + (l & 15)][32 kb + 8 (l >> 4) .. + 8]
+// — what v_mfma_f32_16x16x32_bf16 takes as its weight operand.  One thread per 16-byte piece; N % 16 == 0, K % 32 == 0.
+__global__ __launch_bounds__(256) void wfm_shuffle_kernel(const uint16_t* __restrict__ W, int ldw, int N, int K, uint16_t* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)N * K / 8;
+    if (idx >= total) return;
+    const int l = (int)(idx & 63);
+    const size_t f = idx >> 6;
+    const int kbs = K / 32;
+    const int kb = (int)(f % kbs), nb = (int)(f / kbs);
+    reinterpret_cast<uint4*>(out)[idx] = *reinterpret_cast<const uint4*>(W + (size_t)(nb * 16 + (l & 15)) * ldw + kb * 32 + (l >> 4) * 8);
+}
 
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 
@@ -313,7 +347,7 @@ __device__ __forceinline__ void smf16_epilogue(const GemmParams& p, f32x4_t (&ac
 // tile (16 MFMAs each, the guide's 8-phase shape).  Per shape they are within +-4 % of this one either way — the loop is
 // paced by the LDS traffic of the 128 x 64 wave tile and the clock, not by its barrier structure — and on the whole
 // path both lose ~1 % (58.8 vs 59.5 ms / step).
-template <int BM, int OUT, bool MASK, int EPF, bool TRACE, bool CONVA = false>
+template <int BM, int OUT, bool MASK, int EPF, bool TRACE, bool CONVA = false, bool BREG = false>
 __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     constexpr int BN = 256, WN = 4, NWAVES = 8;
     constexpr int TM = BM / 2, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -329,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
     // stages in 160 KiB.
     constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + SLOT;
     constexpr bool R3 = 3 * STAGE <= NSLOT * SLOT;
+    static_assert(!BREG || (!R3 && !TRACE && NI == 4), "BREG: split-ring tiles (256 / 192 rows) only");
     long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_w0 = 0, tr_stall = 0;
     if constexpr (TRACE) { tr_t0 = __builtin_readcyclecounter(); tr_w0 = (long long)wall_clock64(); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -385,6 +420,7 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
                 o[j] = (unsigned)gr * (unsigned)(p.lda * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
             }
         }
+        if constexpr (BREG) return;                              // the weights do not go through LDS
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
             const int row = (wave * LB + j) * 8 + dr;
@@ -392,6 +428,25 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
             gr = gr < p.N ? gr : p.N - 1;
             o[LA + j] = (unsigned)gr * (unsigned)(p.ldw * 2) + (unsigned)((dpc ^ swz64(row)) * 16);
         }
+    };
+    // BREG: two register sets of NI fragments, one per phase of a K tile.  Set ks is reloaded with the fragments of K tile t + 1
+    // right after the MFMAs of phase (t, ks) were issued (their operand reads are long done when the data comes back), and waited
+    // for in the memory half of phase (t + 1, ks): 1.5 phases of flight.  Queue order per K tile t and wave:
+    //   A(t+2) x LA (between the MFMAs of phase 0) | B(t+1, 0) x NI | B(t+1, 1) x NI
+    // so "B(t, 0) landed" = vmcnt(NI) (B(t, 1) younger), "B(t, 1) landed" = vmcnt(LA if A(t+2) was issued + NI if B(t+1, 0) was),
+    // and A(t+1), issued during K tile t-1 BEFORE B(t, *), has landed whenever B(t, 1) has: the wait_next of the LDS form is implied.
+    u32x4_t breg[2][4];
+    const unsigned bvoff = (unsigned)lane * 16u;
+    auto bfrag_base = [&](int n0_, int kb) -> const char* {       // fragment (column block of this wave, k-step kb), jj = 0
+        const int nb = (n0_ >> 4) + wn * NI;
+        const size_t off = ((size_t)nb * (size_t)(p.K >> 5) + (size_t)kb) << 10;
+        return reinterpret_cast<const char*>(p.Wfm) + off;
+    };
+    auto bload = [&](int set, int n0_, int kb) {
+        const char* b0 = bfrag_base(n0_, kb);
+        const size_t jstride = (size_t)(p.K >> 5) << 10;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) gload16(breg[set][jj], bvoff, b0 + jj * jstride);
     };
     auto frag = [&](const char* part, int row, int chunk) -> bf16x8_t {
         return *reinterpret_cast<const bf16x8_t*>(part + row * 128 + ((chunk ^ swz64(row)) << 4));
@@ -419,10 +474,34 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
         glds16(nx ? offn[j] : off[j], reinterpret_cast<const char*>(p.A) + kbytes, lds0 + dst + (wave + NWAVES * j) * 1024);
     };
     auto dma_b = [&](int j, int k, int dst) {
+        if constexpr (BREG) return;
         const bool nx = k >= nk;
         glds16(nx ? offn[LA + j] : off[LA + j], reinterpret_cast<const char*>(p.W) + (size_t)(nx ? k - nk : k) * 128,
                lds0 + dst + (wave * LB + j) * 1024);
     };
+    if constexpr (BREG) {
+        if (it == 0 || !carry) {
+            // prologue: A(0) -> slot 0, A(1) -> slot 2, then the weight fragments of K tile 0 into the two register sets;
+            // A(0) has landed when at most A(1) and the fragments are still in flight
+            sa = 0;
+#pragma unroll
+            for (int j = 0; j < LA; ++j) dma_a(j, 0, 0);
+            if (nk > 1) {
+#pragma unroll
+                for (int j = 0; j < LA; ++j) dma_a(j, 1, 2 * SLOT);
+            }
+            bload(0, n0, 0);
+            bload(1, n0, 1);
+            if (nk > 1) wait_vmcnt_imm<LA + 2 * NI>();
+            else wait_vmcnt_imm<2 * NI>();
+            __builtin_amdgcn_s_barrier();
+        } else {
+            // second tile of a pair with the A ring carried over: A(0), A(1) were issued by the previous tile's last K tiles; the
+            // weight fragments are NOT held across the epilogue (registers), they are asked for here
+            bload(0, n0, 0);
+            bload(1, n0, 1);
+        }
+    } else
     if (it == 0 || !carry) {
         // prologue: A(0) -> slot 0, B(0) -> slot 1, A(1) -> slot 2; K tile 0 is complete when all but the last LA landed
         // (R3: K tiles 0 and 1 whole -> stages 0 and 1; all but the last LA + LB)
@@ -491,10 +570,24 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
         for (int ks = 0; ks < NPH; ++ks) {                        // phase = one 32-deep k-step
             const bool last = ks == NPH - 1;
             bf16x8_t bfr[NI], af[MI];
+            const bool has_b1 = t + 1 < nk;                       // BREG: K tile t + 1 of THIS tile exists (its fragments are reloaded below)
+            if constexpr (!BREG) {
 #pragma unroll
-            for (int jj = 0; jj < NI; ++jj) bfr[jj] = frag(bt, wn * TN + jj * 16 + frow, ks * 4 + fch);
+                for (int jj = 0; jj < NI; ++jj) bfr[jj] = frag(bt, wn * TN + jj * 16 + frow, ks * 4 + fch);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = frag(at, wm * TM + i * 16 + frow, ks * 4 + fch);
+            if constexpr (BREG) {
+                // the fragments of this phase (see the queue order at `breg`)
+                if (ks == 0) wait_vmcnt_imm<NI>();
+                else if (has_a && has_b1) wait_vmcnt_imm<LA + NI>();
+                else if (has_a) wait_vmcnt_imm<LA>();
+                else if (has_b1) wait_vmcnt_imm<NI>();
+                else wait_vmcnt_imm<0>();
+                breg_fence(breg[ks]);
+#pragma unroll
+                for (int jj = 0; jj < NI; ++jj) bfr[jj] = __builtin_bit_cast(bf16x8_t, breg[ks][jj]);
+            }
             // Split ring: wave group 0 issues its B pieces of K tile t+1 here, beside its fragment reads — the slot (the one
             // A(t-1) lived in) is free from the barrier that opened this phase.  Group 1 runs one barrier behind and must
             // have its pieces landed by the end of ITS phase-1 memory half (group 0 reads K tile t+1 right after that
@@ -508,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < LB; ++j) dma_b(j, t + KB, bdst);
             }
+            if constexpr (!BREG)
             if (last && has_1 && wm == 1) timed_wait_next();      // group 1: one barrier behind, waits in its memory half
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -532,6 +626,13 @@ __global__ __launch_bounds__(512, 2) void gemm_smf16_kernel(GemmParams p) {
                     }
                 }
             }
+            if constexpr (BREG) {
+                if (has_b1) {                                     // this set's fragments of K tile t + 1 (the MFMAs above have read it)
+                    __builtin_amdgcn_sched_barrier(0);
+                    bload(ks, n0, 2 * (t + 1) + ks);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
             if (last && has_1 && wm == 0) timed_wait_next();      // group 0: before the barrier its reads follow
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -592,6 +693,7 @@ std::atomic<int> g_tile{0};        // forced tile height (RS_GEMM_TILE / rs_debu
 std::atomic<int> g_group_m{0};     // row panels per XCD tile group; 0 = by shape
 std::atomic<int> g_pairs{2};       // RS_GEMM_PAIRS: 2 = two tiles per workgroup with the LDS ring carried from the first into the second,
                                    // 1 = two tiles, the ring restarts, 0 = one tile per workgroup
+std::atomic<int> g_breg{0};        // RS_GEMM_BREG: 1 = 256- / 192-row launches keep the weight operand out of LDS (fragment-major copy, global -> VGPR)
 void gemm_knobs_from_env() {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -599,7 +701,35 @@ void gemm_knobs_from_env() {
         env("RS_GEMM_TILE", g_tile);
         env("RS_GEMM_GROUP_M", g_group_m);
         env("RS_GEMM_PAIRS", g_pairs);
+        env("RS_GEMM_BREG", g_breg);
     });
+}
+
+// The fragment-major copy of a weight operand.  A registered tensor (rs_set_tensor: immutable for the life of the context) is
+// shuffled once and cached; anything else (tests, micro-benchmarks) is shuffled into a scratch on every launch.
+int wfm_operand(rs_ctx* ctx, const uint16_t* W, int ldw, int N, int K, hipStream_t s, const uint16_t** out) {
+    const size_t bytes = (size_t)N * K * 2;
+    auto it = ctx->wfm.find(W);
+    if (it != ctx->wfm.end()) { *out = reinterpret_cast<const uint16_t*>(it->second); return RS_OK; }
+    bool registered = false;
+    for (const auto& kv : ctx->tensors)
+        if (kv.second.first == (const void*)W && kv.second.second >= (size_t)N * ldw * 2) { registered = true; break; }
+    void* dst = nullptr;
+    if (registered) {
+        if (hipMalloc(&dst, bytes) != hipSuccess) return rs_fail(ctx, RS_EHIP, "gemm: no memory for the fragment-major copy of a weight (%zu bytes)", bytes);
+        ctx->wfm[W] = dst;
+    } else {
+        if (ctx->wfm_scratch_bytes < bytes) {
+            if (ctx->wfm_scratch) { (void)hipStreamSynchronize(s); (void)hipFree(ctx->wfm_scratch); ctx->wfm_scratch = nullptr; ctx->wfm_scratch_bytes = 0; }
+            if (hipMalloc(&ctx->wfm_scratch, bytes) != hipSuccess) return rs_fail(ctx, RS_EHIP, "gemm: no memory for the fragment-major scratch (%zu bytes)", bytes);
+            ctx->wfm_scratch_bytes = bytes;
+        }
+        dst = ctx->wfm_scratch;
+    }
+    const size_t pieces = (size_t)N * K / 8;
+    hipLaunchKernelGGL(wfm_shuffle_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, W, ldw, N, K, reinterpret_cast<uint16_t*>(dst));
+    *out = reinterpret_cast<const uint16_t*>(dst);
+    return RS_OK;
 }
 
 template <int BM>
@@ -633,6 +763,25 @@ int launch_smf16(rs_ctx* ctx, GemmParams& p, hipStream_t s) {
         if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, OUT_BF16, true, EPF, false, true>, LDS); rc != RS_OK) return rc;
         hipLaunchKernelGGL((gemm_smf16_kernel<BM, OUT_BF16, true, EPF, false, true>), dim3(nwg), dim3(512), LDS, s, p);
         return RS_OK;
+    }
+    // register-resident weights ($RS_GEMM_BREG): the tall split-ring tiles of the FastConformer's epilogues, whole 64-column wave tiles
+    if constexpr (BM >= 192) {
+        if (g_breg.load() > 0 && !p.trace && !mask && p.N % 64 == 0 && p.N >= 256 &&
+            (out == OUT_BF16 || out == OUT_RES || out == OUT_RESLN || out == OUT_F32 || out == OUT_GLU)) {
+            if (int rc = wfm_operand(ctx, p.W, p.ldw, p.N, p.K, s, &p.Wfm); rc != RS_OK) return rc;
+#define RS_SMF_B(O)                                                                                                \
+            do {                                                                                                   \
+                if (int rc = rs_ensure_dynamic_lds(ctx, (const void*)gemm_smf16_kernel<BM, O, false, EPF, false, false, true>, LDS); rc != RS_OK) return rc; \
+                hipLaunchKernelGGL((gemm_smf16_kernel<BM, O, false, EPF, false, false, true>), dim3(nwg), dim3(512), LDS, s, p); \
+            } while (0)
+            if (out == OUT_BF16) RS_SMF_B(OUT_BF16);
+            else if (out == OUT_RES) RS_SMF_B(OUT_RES);
+            else if (out == OUT_RESLN) RS_SMF_B(OUT_RESLN);
+            else if (out == OUT_F32) RS_SMF_B(OUT_F32);
+            else RS_SMF_B(OUT_GLU);
+#undef RS_SMF_B
+            return RS_OK;
+        }
     }
 #define RS_SMF(O, MK, TR)                                                                                          \
     do {                                                                                                           \
@@ -697,6 +846,7 @@ extern "C" void rs_debug_set_gemm_tile(int bm) { gemm_knobs_from_env(); g_tile =
 extern "C" void rs_debug_set_gemm_trace(long long* buf) { g_trace = buf; }
 extern "C" void rs_debug_set_gemm_group_m(int v) { gemm_knobs_from_env(); g_group_m = v; }
 extern "C" void rs_debug_set_gemm_pairs(int v) { gemm_knobs_from_env(); g_pairs = v; }
+extern "C" void rs_debug_set_gemm_breg(int v) { gemm_knobs_from_env(); g_breg = v; }
 extern "C" int rs_debug_gemm_tile_height(int M, int N, int K, int n_cus, int flags) { return pick_tile_height(M, N, K, n_cus > 0 ? n_cus : 256, flags); }
 
 static int launch_rows(rs_ctx* ctx, GemmParams& p, int bm, hipStream_t s) {
@@ -787,6 +937,7 @@ int rs_launch_gemm(rs_ctx* ctx, const rs_gemm_args& a, hipStream_t s) {
         p.tiles_m = p.tiles_n = 0; p.group_m = 1;
         p.trace = g_trace.load();
         p.cv_tps = cv_tps; p.cv_inv = cv_inv; p.cv_T2 = a.conv_T2; p.cv_F2 = a.conv_F2;
+        p.Wfm = nullptr;
         if (cv_tps > 0) {
             p.trace = nullptr;
             p.cv_b_bytes = (unsigned)((size_t)a.conv_T1 * a.conv_F1 * a.conv_C * 2);

@@ -118,7 +118,10 @@ void rs_destroy(rs_ctx* ctx) {
     if (!ctx) return;
     for (auto& p : ctx->prof)
         for (auto e : p.ev) hipEventDestroy(e);
+    for (auto& kv : ctx->wfm) (void)hipFree(kv.second);
+    if (ctx->wfm_scratch) (void)hipFree(ctx->wfm_scratch);
     if (ctx->k2 && ctx->k2_free) ctx->k2_free(ctx->k2);
+    if (ctx->avsr && ctx->avsr_free) ctx->avsr_free(ctx->avsr);
     delete ctx;
 }
 
@@ -159,6 +162,7 @@ extern "C" {
 
 int rs_finalize(rs_ctx* ctx) {
     if (!ctx) return RS_EINVAL;
+    if (ctx->avsr) return rs_avsr_finalize_impl(ctx);
     if (ctx->k2) return rs_k2_finalize_impl(ctx);
     const rs_dims& d = ctx->d;
     Resolver r{ctx};

@@ -97,11 +97,14 @@ struct rs_f32_weights {
 };
 
 struct rs_k2;                       // the Zipformer family's resolved weights and dimensions (k_zipformer.hip)
+struct rs_avsr;                     // the AV-HuBERT family's (k_avsr.hip)
 
 struct rs_ctx {
     int device = 0;
     rs_k2* k2 = nullptr;            // non-null: a context made by rs_k2_create (reazonspeech.k2.asr); the stage entry points dispatch on it
     void (*k2_free)(rs_k2*) = nullptr;
+    rs_avsr* avsr = nullptr;        // non-null: a context made by rs_avsr_create (reazonspeech.avsr); only the rs_avsr_* stage entry points apply
+    void (*avsr_free)(rs_avsr*) = nullptr;
     rs_dims d{};
     int head_dim = 0, sub_freq = 0;
     bool finalized = false;
@@ -150,6 +153,11 @@ struct rs_ctx {
     float* tap_sub = nullptr;
     float* tap_layers = nullptr;
     std::vector<int> tap_ids;
+    // k_gemm_bf16.hip, register-resident weight form ($RS_GEMM_BREG): fragment-major copies of registered GEMM weights (made on first
+    // use, owned by the context) and a scratch for operands that are not registered tensors (re-shuffled on every launch)
+    std::unordered_map<const void*, void*> wfm;
+    void* wfm_scratch = nullptr;
+    size_t wfm_scratch_bytes = 0;
     // profiling
     int prof_mask = 0;
     rs_prof_slot prof[8];
@@ -248,6 +256,7 @@ int rs_launch_im2col3x3s2_f32(rs_ctx* ctx, const float* in, int Bc, int T1, int 
 // rows of the registered CTC head ("ctc.w" / "ctc.b") and row pitch of the posteriors: the vocabulary padded to a multiple of 4
 static inline int rs_ctc_pad(int v) { return (v + 3) / 4 * 4; }
 // Zipformer family (k_zipformer.hip): the entry points of rs_api.hip dispatch to these when ctx->k2 is set
+int rs_avsr_finalize_impl(rs_ctx* ctx);
 int rs_k2_finalize_impl(rs_ctx* ctx);
 int rs_k2_unk_id(const rs_ctx* ctx);
 size_t rs_k2_workspace_bytes_impl(const rs_ctx* ctx, int B, int t_max);

@@ -1,7 +1,8 @@
 """A/B the GEMM tile heights / main-loop schedules on the shapes of the 619M encoder (run on the GPU box).
 
     python scripts/gemm_bench.py [TILE[p0|p1] ...] [--batch=32] [--shape=ffn] [--group-m=N] [--quick]
-TILE = 0 (what the launcher picks), 256, 192, 128, 64; suffix p0 = one tile per workgroup, p1 = pairs (ring restarted), p2 (default) = pairs with the ring carried over.  Prints per shape and variant: correctness vs a torch bf16 matmul, median
+TILE = 0 (what the launcher picks), 256, 192, 128, 64; suffix p0 = one tile per workgroup, p1 = pairs (ring restarted), p2 (default) = pairs with the ring carried over;
+a trailing b = the register-resident weight form ($RS_GEMM_BREG: fragment-major weights global -> VGPR, only A in the LDS ring), e.g. "0 0b".  Prints per shape and variant: correctness vs a torch bf16 matmul, median
 microseconds, TFLOP/s.  The variants are interleaved per shape inside one process (guide §5.4 rule 24).
 """
 import ctypes
@@ -31,7 +32,11 @@ SHAPES = [  # name, M, N, K, flags
 
 def main():
     quick = "--quick" in sys.argv
-    variants = [(int(v.split("p")[0]), int(v.split("p")[1]) if "p" in v else 2) for v in sys.argv[1:] if not v.startswith("--")] or [(0, 2)]
+    def parse(v):
+        breg = v.endswith("b")
+        v = v.rstrip("b")
+        return (int(v.split("p")[0]), int(v.split("p")[1]) if "p" in v else 2, int(breg))
+    variants = [parse(v) for v in sys.argv[1:] if not v.startswith("--")] or [(0, 2, 0)]
     groups = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--group-m=")] or [None]
     # row pitch of A / W in elements beyond K (power-of-two pitches can camp on a few L2 / HBM channels)
     pad_a = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--pad-a=")] or [0])[0]
@@ -41,7 +46,8 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = capi.Context(FASTCONFORMER_619M, 0)
     sett, setp, pick = ctx.lib.rs_debug_set_gemm_tile, ctx.lib.rs_debug_set_gemm_pairs, ctx.lib.rs_debug_gemm_tile_height
-    for f in (sett, setp):
+    setb = ctx.lib.rs_debug_set_gemm_breg
+    for f in (sett, setp, setb):
         f.argtypes = [ctypes.c_int]
         f.restype = None
     pick.argtypes = [ctypes.c_int] * 5
@@ -49,6 +55,7 @@ def main():
     def setv(v):
         sett(v[0])
         setp(v[1])
+        setb(v[2] if len(v) > 2 else 0)
     setg = ctx.lib.rs_debug_set_gemm_group_m
     setg.argtypes = [ctypes.c_int]
     setg.restype = None
@@ -66,6 +73,8 @@ def main():
             Wp = torch.zeros((n, k + pad_w), dtype=torch.bfloat16, device=dev)
             Wp[:, :k] = W
             W = Wp[:, :k]
+        if any(v[2] for v in variants):
+            ctx.set_tensor("bench." + name.split()[0], W)     # a registered weight: the fragment-major copy is made once, like the model's weights
         bias = torch.randn((n,), generator=g).to(dev)
         res = torch.randn((m, n), generator=g).to(dev) if flags & capi.GEMM_RESIDUAL else None
         glu = bool(flags & capi.GEMM_GLU)
@@ -109,7 +118,7 @@ def main():
                 ts.append(e0.elapsed_time(e1) / (1 if quick else 4))
             ts.sort()
             us = ts[len(ts) // 2] * 1e3
-            v = f"{v[0] or pick(m, n, k, 256, flags)}{'*' if not v[0] else ''} p{v[1]}"
+            v = f"{v[0] or pick(m, n, k, 256, flags)}{'*' if not v[0] else ''} p{v[1]}{' breg' if v[2] else ''}"
             print(f"{name} M{m} N{n} K{k} tile {v}{'' if gm is None else f' gm{gm}'}{f' padA{pad_a}' if pad_a else ''}{f' padW{pad_w}' if pad_w else ''}{f' padC{pad_c}' if pad_c else ''}: err {err:.3g}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
         if "--yardstick" in sys.argv:
             # the vendor library on the same operands, same box, same process: torch.mm -> hipBLASLt / rocBLAS, plain bf16
@@ -131,7 +140,7 @@ def main():
             print(f"{name} M{m} N{n} K{k} yardstick torch.mm (hipBLASLt, no epilogue): {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
             del y
         del A, W, out, res
-    setv((0, 2))
+    setv((0, 2, 0))
 
 
 if __name__ == "__main__":

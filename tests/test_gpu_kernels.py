@@ -23,21 +23,23 @@ import ctypes
 
 
 @contextlib.contextmanager
-def gemm_knobs(ctx, tile=0, pairs=2):
+def gemm_knobs(ctx, tile=0, pairs=2, breg=0):
     """force the GEMM tile height (256 / 192 / 128 / 64; 0 = by shape) and the tiles-per-workgroup mode (2 = pairs with
     the LDS ring carried from the first tile into the second, the default; 1 = pairs, ring restarted; 0 = one tile per
     workgroup) for the calls inside"""
     lib = ctx.lib
-    for f in (lib.rs_debug_set_gemm_tile, lib.rs_debug_set_gemm_pairs):
+    for f in (lib.rs_debug_set_gemm_tile, lib.rs_debug_set_gemm_pairs, lib.rs_debug_set_gemm_breg):
         f.argtypes = [ctypes.c_int]
         f.restype = None
     try:
         lib.rs_debug_set_gemm_tile(tile)
         lib.rs_debug_set_gemm_pairs(pairs)
+        lib.rs_debug_set_gemm_breg(breg)      # 1 = the weight operand stays out of LDS (fragment-major copy, global -> VGPR)
         yield
     finally:
         lib.rs_debug_set_gemm_tile(0)
         lib.rs_debug_set_gemm_pairs(2)
+        lib.rs_debug_set_gemm_breg(0)
 
 
 @pytest.fixture(scope="module")
@@ -199,6 +201,45 @@ def test_gemm_is_tile_and_batch_invariant(ctx, gpu_device):
     alone = run(A[lo:lo + n].contiguous(), x[lo:lo + n].contiguous(), 0)           # picks the 64-row tile on its own
     for got, want in zip(alone, base):
         assert torch.equal(got, want[lo:lo + n])
+
+
+def test_gemm_register_resident_weights_are_bit_identical(ctx, gpu_device):
+    """$RS_GEMM_BREG (round 6's A/B form: the weight operand as fragment-major global -> VGPR loads, only A in the LDS ring) does
+    the same per-element arithmetic as the LDS form — ascending 32-deep k-steps into one accumulator — so every epilogue gives
+    the same BITS: 256- and 192-row tiles, pairs with the ring carried / restarted / single tiles, K = 64 (one K tile) ..
+    4096, ragged M, a registered weight (cached copy) and an unregistered one (scratch)."""
+    g = torch.Generator().manual_seed(321)
+    for M, N, K in ((35328 - 37, 1024, 1024), (5000, 2048, 64), (9000, 1024, 4096), (3000, 256, 128), (4444, 3072, 320)):
+        A = bf(torch.randn((M, K), generator=g)).to(gpu_device)
+        W = bf(torch.randn((N, K), generator=g) / K ** 0.5).to(gpu_device)
+        bias = torch.randn((N,), generator=g).to(gpu_device)
+        x = torch.randn((M, N), generator=g).to(gpu_device)
+        if K == 4096:
+            ctx.set_tensor("test.breg.w", W)          # registered: the fragment-major copy is made once and cached
+
+        def run(tile, pairs, breg):
+            outs = []
+            with gemm_knobs(ctx, tile=tile, pairs=pairs, breg=breg):
+                o = torch.zeros((M, N), dtype=torch.bfloat16, device=gpu_device)
+                ctx.gemm(A, W, o, flags=capi.GEMM_BIAS | capi.GEMM_SILU, bias=bias)
+                outs.append(o)
+                o = x.clone()
+                ctx.gemm(A, W, o, flags=capi.GEMM_BIAS | capi.GEMM_RESIDUAL | capi.GEMM_OUT_F32, bias=bias, alpha=0.5, residual=o)
+                outs.append(o)
+                o = torch.zeros((M, N), dtype=torch.float32, device=gpu_device)
+                ctx.gemm(A, W, o, flags=capi.GEMM_BIAS | capi.GEMM_OUT_F32, bias=bias)
+                outs.append(o)
+                o = torch.zeros((M, N // 2), dtype=torch.bfloat16, device=gpu_device)
+                ctx.gemm(A, W, o, flags=capi.GEMM_BIAS | capi.GEMM_GLU, bias=bias)
+                outs.append(o)
+                sync()
+            return outs
+        base = run(256, 2, 0)
+        for tile, pairs in ((256, 2), (192, 2), (256, 1), (192, 0), (256, 0)):
+            for k, (got, want) in enumerate(zip(run(tile, pairs, 1), base)):
+                assert torch.equal(got, want), (M, N, K, tile, pairs, k)
+        for got, want in zip(run(0, 2, 1), base):          # twice through the cache / scratch
+            assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("K", [64, 128, 320])
