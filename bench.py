@@ -403,6 +403,11 @@ def extra_configs(model, cfg, sd, args, host_sets):
         out["k2_zipformer_159m"] = k2_config(model.device, args)
     except Exception as e:
         out["k2_zipformer_159m"] = {"error": repr(e)}
+    # BASELINE configs[4]: reazonspeech.avsr, the AV-HuBERT audio-visual encoder-decoder, batch = 16 clips
+    try:
+        out["avsr_b16"] = avsr_config(model.device, args)
+    except Exception as e:
+        out["avsr_b16"] = {"error": repr(e)}
     return out
 
 
@@ -466,6 +471,35 @@ def espnet_parity(am, cfg, sd, buf256, first):
     del m32, b32
     torch.cuda.empty_cache()
     return out
+
+
+def family_roofline(am, buf, utterances, top=8):
+    """`roofline` object of another model family: one batch through the sequential schedule with the library's HIP-event
+    profiler on the GEMM class (the MFMA-bound class of every family) -> achieved TFLOP/s of Σ 2·M·N·K over Σ launch durations,
+    fraction of the dense bf16 peak, the `top` shapes by time, and the algorithmic GEMM work per utterance."""
+    ctx = am.ctx
+    am.run_device(buf)
+    torch.cuda.synchronize()
+    ctx.profile_enable(capi.PROF_GEMM)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    am.run_device(buf)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    g = ctx.profile_read(capi.PROF_GEMM)
+    launches = ctx.profile_launches(capi.PROF_GEMM)
+    ctx.profile_enable(0)
+    if not g["launches"] or g["ms"] <= 0:
+        return None
+    achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    shapes = per_shape_roofline(launches)
+    return {"bound": "mfma", "kernel": "gemm_smf16_kernel (every dense contraction of this family's encoder)", "achieved": round(achieved, 1),
+            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": int(g["launches"]), "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2), "schedule": "sequential, one batch",
+            "gemm_ms_per_batch": round(g["ms"], 2), "batch_ms_sequential": round(dt * 1e3, 2), "share_of_sequential_batch": round(g["ms"] / (dt * 1e3), 3),
+            "algorithmic_gemm_gflop_per_utt": round(g["flops"] / utterances / 1e9, 2),
+            "algorithmic_bytes_per_launch": round(g["bytes"] / g["launches"]),
+            "per_shape": dict(list(shapes.items())[:top])}
 
 
 def k2_parity(am, cfg, sd, buf256, waves, audio):
@@ -576,10 +610,92 @@ def k2_config(device, args, steps=10):
            "value": round(sum(secs[i % n_sets] for i in range(steps)) / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
            "enc_frames": bufs[0].tp_max, "mean_tokens_per_utt": round(float(n_tok.mean()), 1)}
     try:
+        res["roofline"] = family_roofline(am, bufs[0], args.batch)
+    except Exception as e:
+        res["roofline"] = {"error": repr(e)}
+    try:
         res["parity"] = k2_parity(am, cfg, sd, bufs[0], first, first_audio)
     except Exception as e:
         res["parity"] = {"error": repr(e)}
     del bufs, km
+    torch.cuda.empty_cache()
+    return res
+
+
+def avsr_config(device, args):
+    """BASELINE configs[4] `reazonspeech.avsr`: the AV-HuBERT encoder-decoder (pkg/avsr/src/avhubert/; 161M parameters: Conv3d + ResNet-18
+    video front-end, 12 x 768 HuBERT encoder, 6-layer Transformer decoder) on 16 clips of 10 s (250 frames at 25 Hz: four stacked log
+    filterbank frames + one 88 x 88 mouth crop per frame), float32 like the reference.  Timed: `AVHubertModel.forward`
+    (rs_avsr_encoder_forward) and `generate(num_beams=5, max_new_tokens=32)` (the README's call with a shorter token budget: random
+    weights never emit eos).  Parity: the committed golden of THE REFERENCE ITSELF (tests/golden/avsr_ref_base.npz: the reference's own
+    modules run on these weights and 16 ragged clips of <= 4 s) — encoder output, teacher-forced logits, greedy and beam-search ids."""
+    import hashlib
+    from reazonspeech_amd.runtime.avsr_config import AVSR_BASE
+    from reazonspeech_amd.runtime.avsr_synth import synthetic_clips
+    from reazonspeech_amd.runtime.avsr_weights import synthetic_state_dict_avsr
+    from reazonspeech_amd.avsr import AVHubertForConditionalGeneration
+    cfg = AVSR_BASE
+    sd = synthetic_state_dict_avsr(cfg, 0)
+    model = AVHubertForConditionalGeneration(cfg, sd, device=str(device))
+    B, T, beams, new_tokens = 16, 250, 5, 32
+    a, v, mask, _ = synthetic_clips(B, T, seed=4242)
+    ad, vd, md = (torch.from_numpy(x).to(model.device) for x in (a, v[:, :, 0], mask))
+    model.dev.encode(ad, vd, md)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        enc = model.dev.encode(ad, vd, md)
+    torch.cuda.synchronize()
+    enc_ms = (time.perf_counter() - t0) / reps * 1e3
+    model.generate(input_values=ad, pixel_values=vd, padding_mask=md, num_beams=beams, max_new_tokens=4)
+    t0 = time.perf_counter()
+    seq = model.generate(input_values=ad, pixel_values=vd, padding_mask=md, num_beams=beams, max_new_tokens=new_tokens)
+    torch.cuda.synchronize()
+    gen_ms = (time.perf_counter() - t0) * 1e3
+    secs = B * T / 25.0
+    # algorithmic work of the encoder half: ResNet front-end + projections + encoder layers (2 x multiply-adds)
+    d, f, L = cfg.encoder_embed_dim, cfg.encoder_ffn_embed_dim, cfg.encoder_layers
+    h1, h2 = cfg.image_size // 2, cfg.image_size // 4
+    per_frame = 2.0 * (h1 * h1 * 64 * 245 + h2 * h2 * (4 * 64 * 64 * 9) + (h2 // 2 + h2 % 2) ** 2 * (64 * 128 * 9 + 3 * 128 * 128 * 9 + 64 * 128)
+                       + 36 * (128 * 256 * 9 + 3 * 256 * 256 * 9 + 128 * 256) + 9 * (256 * 512 * 9 + 3 * 512 * 512 * 9 + 256 * 512)
+                       + 512 * d + 104 * d + 2 * d * d + d * (d // cfg.conv_pos_groups) * cfg.conv_pos + L * (4 * d * d + 2 * d * f + 2 * T * d))
+    res = {"workload": f"{B} clips x {T / 25.0:g} s ({T} frames at 25 Hz: 104-dim stacked log filterbank + 88 x 88 mouth crop per frame), AV-HuBERT "
+                       f"{cfg.n_params() / 1e6:.0f}M, float32 end to end like the reference; generate(num_beams={beams}, max_new_tokens={new_tokens})",
+           "value": round(secs / ((gen_ms) * 1e-3), 1), "unit": "audio-visual seconds per wall second (encoder + beam search, one batch of 16)",
+           "encoder_ms": round(enc_ms, 2), "generate_ms": round(gen_ms, 2), "value_encoder_only": round(secs / (enc_ms * 1e-3), 1),
+           "generated_tokens_per_clip": int(seq.shape[1] - 1), "dtype": "f32",
+           "algorithmic_gflop_per_clip_encoder": round(per_frame * T / 1e9, 1),
+           "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_16x16x4_f32: every convolution patch product and Linear)",
+                        "achieved": round(per_frame * T * B / (enc_ms * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s (encoder forward, algorithmic FLOPs / wall)",
+                        "frac": round(per_frame * T * B / (enc_ms * 1e-3) / 1e12 / 157.3, 4), "traffic": None}}
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "avsr_ref_base.npz"))
+        Bg, Tg = int(g["clips"]), int(g["frames"])
+        ga, gv, gm, _ = synthetic_clips(Bg, Tg, seed=int(g["input_seed"]), ragged=True, min_frames=max(8, Tg // 3))
+        if hashlib.sha256(ga.tobytes() + gv.tobytes() + gm.tobytes()).digest() != bytes(g["input_sha256"].tolist()):
+            raise RuntimeError("inputs drifted from the golden's")
+        enc_g = model.dev.encode(ga, gv, gm).cpu()
+        R = torch.randn((cfg.encoder_embed_dim, 8), generator=torch.Generator().manual_seed(int(g["proj_seed"]))) / cfg.encoder_embed_dim ** 0.5
+        logits = model(input_values=ga, pixel_values=gv, padding_mask=gm, decoder_input_ids=g["greedy"][:, :-1]).logits.cpu()
+        Rv = torch.randn((cfg.vocab_size, 8), generator=torch.Generator().manual_seed(int(g["proj_seed"]) + 1)) / cfg.vocab_size ** 0.5
+        kb = int(g["beam_clips"])
+        greedy = model.generate(input_values=ga, pixel_values=gv, padding_mask=gm, num_beams=1, max_new_tokens=int(g["new_tokens"]))
+        bm = model.generate(input_values=ga[:kb], pixel_values=gv[:kb], padding_mask=gm[:kb], num_beams=int(g["beams"]), max_new_tokens=int(g["new_tokens"]),
+                            return_dict_in_generate=True)
+        res["parity"] = {"checker": "tests/golden/avsr_ref_base.npz: THE REFERENCE ITSELF (pkg/avsr/src/avhubert/*.py imported unchanged, float32 CPU) on these "
+                                    "synthetic weights and 16 ragged clips; generator tests/golden/make_avsr_golden.py",
+                         "clips": Bg, "frames": Tg,
+                         "encoder_clip0_max_err": round(float((enc_g[0] - torch.from_numpy(g["enc"][0])).abs().max()), 7),
+                         "encoder_fingerprint_max_err_all_clips": round(float(((enc_g @ R) - torch.from_numpy(g["enc_proj"])).abs().max()), 7),
+                         "logits_clips01_max_err": round(float((logits[:2] - torch.from_numpy(g["logits"])).abs().max()), 6),
+                         "logits_fingerprint_max_err_all_clips": round(float(((logits @ Rv) - torch.from_numpy(g["logits_proj"])).abs().max()), 6),
+                         "greedy_ids_exact": f"{int((greedy.numpy() == g['greedy']).all(axis=1).sum())}/{Bg}",
+                         "beam_ids_exact": f"{int((bm.sequences.numpy() == g['beam']).all(axis=1).sum())}/{kb}" if bm.sequences.shape == g["beam"].shape else "shape differs",
+                         "beam_scores_max_err": round(float(np.abs(bm.sequences_scores.numpy() - g["beam_scores"]).max()), 7)}
+    except Exception as e:
+        res["parity"] = {"error": repr(e)}
+    del model
     torch.cuda.empty_cache()
     return res
 
@@ -612,6 +728,10 @@ def espnet_config(device, args):
                        f"{cfg.n_params() / 1e6:.0f}M, transducer greedy search (one symbol per frame), HBM-resident, pipelined",
            "value": round(sum(secs[i % n_sets] for i in range(steps)) / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
            "enc_frames": bufs[0].tp_max, "mean_tokens_per_utt": round(float(n_tok.mean()), 1)}
+    try:
+        res["roofline"] = family_roofline(am, bufs[0], args.batch)
+    except Exception as e:
+        res["roofline"] = {"error": repr(e)}
     try:
         res["parity"] = espnet_parity(am, cfg, sd, bufs[0], first)
     except Exception as e:

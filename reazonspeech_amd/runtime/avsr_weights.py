@@ -90,20 +90,23 @@ def synthetic_state_dict_avsr(cfg: AvsrConfig, seed: int = 0, meta: bool = False
     sd[E + "pos_conv_embed.conv.parametrizations.weight.original1"] = rnd(E + "pos.v", (d, d // cfg.conv_pos_groups, cfg.conv_pos), 1.0)
     norm(E + "layer_norm", d)
 
-    def attention(P, width):
+    def attention(P, width, out_gain):
         for nm in ("k_proj", "v_proj", "q_proj"):
             lin(P + nm, width, width, gain=1.2)
-        lin(P + "out_proj", width, width, gain=0.5)
+        lin(P + "out_proj", width, width, gain=out_gain)
 
     for i in range(cfg.encoder_layers):
         P = E + f"layers.{i}."
-        attention(P + "attention.", d)
+        attention(P + "attention.", d, 0.3)                  # small branch gains: a deep random post-LayerNorm stack otherwise maps every frame to one vector
         norm(P + "layer_norm", d)
         lin(P + "feed_forward.intermediate_dense", ffn, d, gain=1.4)
-        lin(P + "feed_forward.output_dense", d, ffn, gain=0.5)
+        lin(P + "feed_forward.output_dense", d, ffn, gain=0.3)
         norm(P + "final_layer_norm", d)
     norm(A + "layer_norm", cfg.fused_dim)
-    sd["embed_tokens.weight"] = rnd("embed_tokens.weight", (V, dd), 1.0)
+    # token embeddings that dominate the decoder's residual stream (with small attention / FFN branches below) make the next token depend
+    # on the previous one and on the clip: random weights otherwise fall into one repeated token after a step or two (tuned with
+    # oracle/avsr.py: 12 different tokens in 12 steps at the 161M shape)
+    sd["embed_tokens.weight"] = rnd("embed_tokens.weight", (V, dd), 4.0)
     if not meta:
         sd["embed_tokens.weight"][cfg.pad_token_id] = 0.0              # nn.Embedding(padding_idx=...)
     sd["decoder.pos_embed.position_embeddings"] = (torch.empty((cfg.max_target_positions, dd), device="meta") if meta
@@ -111,12 +114,12 @@ def synthetic_state_dict_avsr(cfg: AvsrConfig, seed: int = 0, meta: bool = False
     norm("decoder.layer_norm", dd)
     for i in range(cfg.decoder_layers):
         P = f"decoder.layers.{i}."
-        attention(P + "attention.", dd)
+        attention(P + "attention.", dd, 0.2)
         norm(P + "layer_norm", dd)
-        attention(P + "encoder_attn.", dd)
+        attention(P + "encoder_attn.", dd, 0.2)
         norm(P + "encoder_layer_norm", dd)
         lin(P + "feed_forward.intermediate_dense", dffn, dd, gain=1.4)
-        lin(P + "feed_forward.output_dense", dd, dffn, gain=0.5)
+        lin(P + "feed_forward.output_dense", dd, dffn, gain=0.3)
         norm(P + "final_layer_norm", dd)
     sd["lm_head.weight"] = rnd("lm_head.weight", (V, dd), 4.0 / math.sqrt(dd))
     return sd

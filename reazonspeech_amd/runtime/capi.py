@@ -18,6 +18,7 @@ ERRORS = {-1: "RS_EINVAL", -2: "RS_EMISSING", -3: "RS_EWORKSPACE", -4: "RS_EHIP"
           -6: "RS_ESTATE"}
 
 GEMM_BIAS, GEMM_RELU, GEMM_SILU, GEMM_RESIDUAL, GEMM_OUT_F32, GEMM_ROWMASK, GEMM_GLU = 1, 2, 4, 8, 16, 32, 64
+GEMM_SWOOSHL, GEMM_SWOOSHR, GEMM_GELU = 128, 256, 512
 GLU_HALVES, GLU_BLOCK32, GLU_APPLIED = 0, 1, 2
 ALSD_SCORE_NORM, ALSD_MERGE = 1, 2
 PROF_GEMM, PROF_ATTN, PROF_FRONTEND, PROF_DECODE, PROF_ELEMENTWISE, PROF_SUBSAMPLE = 1, 2, 4, 8, 16, 32
@@ -31,6 +32,8 @@ EXPORTS = [
     "rs_rnnt_alsd", "rs_rnnt_alsd_workspace_bytes", "rs_rnnt_beam", "rs_rnnt_beam_workspace_bytes", "rs_host_stage_rows",
     "rs_gemm_f32", "rs_relpos_attention_f32", "rs_glu_dwconv_silu_f32", "rs_profile_read_launches", "rs_encoder_set_ctc_out",
     "rs_k2_create", "rs_k2_encoder_set_taps",
+    "rs_avsr_create", "rs_avsr_workspace_bytes", "rs_avsr_encoder_forward", "rs_avsr_encoder_set_taps", "rs_avsr_decoder_state_bytes",
+    "rs_avsr_decoder_begin", "rs_avsr_decoder_step",
 ]
 
 
@@ -76,6 +79,22 @@ class RsK2Dims(Structure):
                    arr(cfg.encoder_dim), arr(cfg.num_layers), arr(cfg.ff_dim), arr(cfg.num_heads), arr(cfg.cnn_kernel), arr(cfg.downsampling),
                    cfg.query_head_dim, cfg.value_head_dim, cfg.pos_head_dim, cfg.pos_dim, cfg.vocab_size, cfg.decoder_dim, cfg.joiner_dim,
                    cfg.context_size, cfg.blank_id, cfg.unk_id)
+
+
+class RsAvsrDims(Structure):
+    """mirror of `struct rs_avsr_dims` (the AV-HuBERT encoder-decoder of reazonspeech.avsr)"""
+    _fields_ = [
+        ("encoder_layers", c_int32), ("encoder_embed_dim", c_int32), ("encoder_ffn_dim", c_int32), ("encoder_heads", c_int32),
+        ("conv_pos", c_int32), ("conv_pos_groups", c_int32), ("audio_feat_dim", c_int32), ("fuse_concat", c_int32), ("image_size", c_int32),
+        ("decoder_layers", c_int32), ("decoder_embed_dim", c_int32), ("decoder_ffn_dim", c_int32), ("decoder_heads", c_int32),
+        ("max_positions", c_int32), ("vocab_size", c_int32), ("layer_norm_eps", c_float),
+    ]
+
+    @classmethod
+    def from_config(cls, cfg):
+        return cls(cfg.encoder_layers, cfg.encoder_embed_dim, cfg.encoder_ffn_embed_dim, cfg.encoder_attention_heads, cfg.conv_pos, cfg.conv_pos_groups,
+                   cfg.audio_feat_dim, int(cfg.modality_fuse == "concat"), cfg.image_size, cfg.decoder_layers, cfg.decoder_embed_dim,
+                   cfg.decoder_ffn_embed_dim, cfg.decoder_attention_heads, cfg.max_target_positions, cfg.vocab_size, cfg.layer_norm_eps)
 
 
 class RsError(RuntimeError):
@@ -149,7 +168,16 @@ def load():
     lib.rs_encoder_set_ctc_out.argtypes = [vp, vp, vp]
     lib.rs_k2_create.argtypes = [POINTER(c_void_p), c_int, POINTER(RsK2Dims)]
     lib.rs_k2_encoder_set_taps.argtypes = [vp, vp, vp]
-    if lib.rs_abi_version() != 5:
+    lib.rs_avsr_create.argtypes = [POINTER(c_void_p), c_int, POINTER(RsAvsrDims)]
+    lib.rs_avsr_workspace_bytes.argtypes = [vp, c_int, c_int]
+    lib.rs_avsr_workspace_bytes.restype = c_size_t
+    lib.rs_avsr_encoder_forward.argtypes = [vp, vp, vp, vp, c_int, c_int, vp, vp, c_size_t, vp]
+    lib.rs_avsr_encoder_set_taps.argtypes = [vp, vp, vp, vp, vp, POINTER(c_int32), c_int]
+    lib.rs_avsr_decoder_state_bytes.argtypes = [vp, c_int, c_int, c_int, c_int]
+    lib.rs_avsr_decoder_state_bytes.restype = c_size_t
+    lib.rs_avsr_decoder_begin.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, c_size_t, vp]
+    lib.rs_avsr_decoder_step.argtypes = [vp, vp, vp, c_int, vp, c_int, c_int, c_int, c_int, vp, vp, c_size_t, vp]
+    if lib.rs_abi_version() != 6:
         raise ImportError("librs_asr.so ABI version mismatch")
     _lib = lib
     return lib
@@ -210,7 +238,10 @@ class Context:
         self.device_index = int(device_index)
         self._h = c_void_p()
         self._keep = {}
-        if getattr(cfg, "family", "nemo") == "k2":           # the Zipformer2 transducer of reazonspeech.k2.asr
+        if getattr(cfg, "family", "nemo") == "avsr":         # the AV-HuBERT encoder-decoder of reazonspeech.avsr
+            dims = RsAvsrDims.from_config(cfg)
+            rc = self.lib.rs_avsr_create(byref(self._h), int(device_index), byref(dims))
+        elif getattr(cfg, "family", "nemo") == "k2":         # the Zipformer2 transducer of reazonspeech.k2.asr
             dims = RsK2Dims.from_config(cfg)
             rc = self.lib.rs_k2_create(byref(self._h), int(device_index), byref(dims))
         else:

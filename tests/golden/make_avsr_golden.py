@@ -39,7 +39,7 @@ from oracle import _ref_avsr as ra                                              
 
 PROJ_SEED = 20240930
 RECIPES = {     # name: (config, weight seed, input seed, clips, frames, new tokens, beams, clips in the beam run)
-    "tiny": (AVSR_TINY, 3, 11, 5, 24, 10, 3, 5),
+    "tiny": (AVSR_TINY, 0, 11, 5, 24, 10, 3, 5),
     "base": (AVSR_BASE, 0, 4242, 16, 100, 12, 5, 4),
 }
 
