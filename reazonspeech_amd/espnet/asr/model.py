@@ -83,32 +83,45 @@ class EspnetModel:
         res = self._search([np.pad(np.asarray(w, np.float32), PADDING, mode="constant") for w in waves])
         return [self.ids_to_text(ids) for ids in res.ids]
 
-    def _search(self, waves):
+    def _search(self, waves, max_batch=256):
         """the transducer search over a batch of (padded) windows.  Upstream's default beam search has no bound on the
         prediction-network evaluations a frame may take; the device search has one (`max_pops`, which sizes its workspace)
-        and reports RS_EOVERFLOW instead of truncating.  A batch that hits it is retried with 4x and 16x the bound, then
-        decoded greedily with a warning: one pathological window must not abort a whole file."""
+        and reports RS_EOVERFLOW instead of truncating.  The front end and the encoder run ONCE per batch; a decode that hits
+        the bound is retried on the same joint projection with 4x and 16x the bound, then done greedily with a warning — one
+        pathological window must not abort a whole file — and the result says so (`DecodedBatch.degraded`).  The overrides are
+        arguments of the decode call: nothing is written into the shared model configuration."""
         from ...runtime.capi import RsError, RS_EOVERFLOW
+        from ...runtime.model import DecodedBatch
         am = self.am
         if am.cfg.decoding != "beam":
             return am.transcribe_waveforms(waves)
-        base = am.cfg
-        bound = base.beam_max_pops or 16 * base.beam_size
-        try:
-            for factor in (1, 4, 16):
-                am.cfg = base if factor == 1 else base.with_(beam_max_pops=bound * factor)
-                try:
-                    return am.transcribe_waveforms(waves)
-                except RsError as e:
-                    if e.code != RS_EOVERFLOW:
-                        raise
-            import warnings
-            warnings.warn(f"beam search: a frame needed more than {16 * bound} prediction-network evaluations; this window is "
-                          "decoded with the greedy search instead", RuntimeWarning, stacklevel=3)
-            am.cfg = base.with_(decoding="greedy_batch")
-            return am.transcribe_waveforms(waves)
-        finally:
-            am.cfg = base
+        bound = am.cfg.beam_max_pops or 16 * am.cfg.beam_size
+        out = DecodedBatch([], [], [], [], [])
+        for lo in range(0, len(waves), max_batch):
+            buf = am.stage([np.asarray(w, np.float32) for w in waves[lo:lo + max_batch]])
+            with torch.cuda.device(am.device):
+                stream = torch.cuda.current_stream().cuda_stream
+                am.run_encoder(buf, stream)
+                used = None
+                for factor in (1, 4, 16):
+                    try:
+                        am.decode(am.ctx, buf, buf.ws, stream, max_pops=bound * factor)
+                        used = "beam"
+                        break
+                    except RsError as e:
+                        if e.code != RS_EOVERFLOW:
+                            raise
+                if used is None:
+                    import warnings
+                    warnings.warn(f"beam search: a frame needed more than {16 * bound} prediction-network evaluations; this batch of windows "
+                                  "is decoded with the greedy search instead", RuntimeWarning, stacklevel=3)
+                    am.decode(am.ctx, buf, buf.ws, stream, decoding="greedy_batch")
+                    used = "greedy_batch"
+                res = am.collect(buf, decoding=used)
+            out.ids += res.ids; out.frames += res.frames; out.enc_lens += res.enc_lens
+            out.scores += res.scores if res.scores is not None else [float("nan")] * buf.B
+            out.degraded += [used != "beam"] * buf.B
+        return out
 
     def recognize(self, samples):
         return self.recognize_batch([samples])[0]

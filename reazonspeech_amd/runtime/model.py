@@ -29,6 +29,7 @@ class DecodedBatch:
     frames: List[List[int]]
     enc_lens: List[int]
     scores: Optional[List[float]] = None
+    degraded: Optional[List[bool]] = None     # per utterance: the requested search overflowed its bound and a weaker one was used (espnet `_search`)
 
 
 def alsd_label_budget(t_frames: int, max_target_len) -> int:
@@ -312,11 +313,13 @@ class AsrModel:
                              buf.ws, stream)
             self.decode(self.ctx, buf, buf.ws, stream)
 
-    def decode(self, ctx, buf: _Buffers, ws, stream):
+    def decode(self, ctx, buf: _Buffers, ws, stream, max_pops=None, decoding=None):
         """stage 3 on `stream`: the checkpoint's decoding strategy (cfg.decoding).  Greedy fills buf.ids / buf.frames
         (emission frames); ALSD fills buf.ids / buf.frames (alignment steps i = frame + labels before) / buf.scores.
         Both synchronise the stream."""
         cfg = self.cfg
+        if max_pops is not None or decoding is not None:     # per-call overrides (the caller's retry policy): never written into self.cfg
+            cfg = cfg.with_(**({"beam_max_pops": int(max_pops)} if max_pops is not None else {}), **({"decoding": decoding} if decoding is not None else {}))
         if cfg.decoding == "beam":
             n = ctx.beam_workspace_bytes(buf.B, cfg.beam_size, buf.tp_max, cfg.beam_max_pops)
             if buf.ws_alsd is None or buf.ws_alsd.numel() < n:
@@ -528,17 +531,19 @@ class AsrModel:
             buf.lens.copy_(buf.h_lens, non_blocking=True)
         return buf
 
-    def collect(self, buf, host=None) -> DecodedBatch:
+    def collect(self, buf, host=None, decoding=None) -> DecodedBatch:
         """hypotheses of a decoded batch as host lists; `host` = the (n_ids, ids, frames, enc_lens, scores) tensors a
-        pipeline worker already copied back (buf.h_out), otherwise they are fetched here"""
+        pipeline worker already copied back (buf.h_out), otherwise they are fetched here; `decoding`: the search that
+        produced them when it was overridden for the call (see `decode`)"""
+        decoding = decoding or self.cfg.decoding
         if host is None:
             host = (buf.n_ids.cpu(), buf.ids.cpu(), buf.frames.cpu(), buf.enc_lens.cpu(),
-                    buf.scores.cpu() if self.cfg.has_scores else None)
+                    buf.scores.cpu() if decoding in ("alsd", "beam") else None)
         n, ids, frames, el = (t.numpy() for t in host[:4])
-        if self.cfg.decoding == "alsd":      # alignment step i = frame + labels emitted before
+        if decoding == "alsd":      # alignment step i = frame + labels emitted before
             frames = frames - np.arange(frames.shape[1], dtype=frames.dtype)[None, :]
             scores = host[4].numpy().tolist()
-        elif self.cfg.decoding == "beam":    # frames = the frame each label was appended at ([UPSTREAM] NeMo Hypothesis.timestep)
+        elif decoding == "beam":    # frames = the frame each label was appended at ([UPSTREAM] NeMo Hypothesis.timestep)
             scores = host[4].numpy().tolist()
         else:
             scores = None

@@ -199,3 +199,33 @@ def test_nemo_family_two_lstm_layers_blank_last(gpu_device):
         pytest.skip("this synthetic decoder does not settle within max_pops (both sides agree)")
     assert got == [(w[0], w[1], float(np.float32(w[2])), w[3]) for w in want]
     assert sum(len(g_[0]) for g_ in got) > 0
+
+
+def test_search_retries_the_decode_only_and_flags_a_degraded_batch(gpu_device):
+    """`EspnetModel._search`: an overflowing beam search is retried on the SAME joint projection with a larger bound
+    passed as a call argument (the shared model configuration is never touched: `transcribe_batch` workers may share the model) and,
+    if that fails too, decoded greedily — the result then says so (`DecodedBatch.degraded`)"""
+    import warnings
+    model, sd = build(ESPNET_TINY, 11, 12.0, beam_size=6)
+    audio, lens = synthetic_batch(3, 1.5, seed=4)
+    waves = [audio[b, :int(lens[b])] for b in range(3)]
+    cfg0 = model.am.cfg
+    fine = model._search(waves)
+    assert model.am.cfg is cfg0 and fine.degraded == [False] * 3 and fine.scores is not None
+    # a bound of ONE evaluation per frame overflows at 1x, 4x and 16x: the greedy fallback answers, flagged and with a warning
+    model.am.cfg = cfg0.with_(beam_max_pops=1)
+    tight = model.am.cfg
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        res = model._search(waves)
+    assert model.am.cfg is tight, "the retry policy must not write into the shared configuration"
+    greedy = model.am.transcribe_waveforms.__self__           # (same object: just to keep the model alive in this scope)
+    assert greedy is model.am
+    if res.degraded == [True] * 3:
+        assert any("greedy search instead" in str(x.message) for x in w)
+        model.am.cfg = cfg0.with_(decoding="greedy_batch")
+        want = model.am.transcribe_waveforms(waves)
+        assert res.ids == want.ids and res.frames == want.frames
+    else:                                                     # 16 evaluations were enough for this toy model: then the beam result stands
+        assert res.degraded == [False] * 3 and res.ids == fine.ids
+    model.am.cfg = cfg0
