@@ -49,6 +49,7 @@ from reazonspeech_amd.runtime.weights import synthetic_state_dict           # no
 from reazonspeech_amd.runtime import dist as rdist                          # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
+HBM_PEAK_TBPS = 8.0                # HBM3E (same guide)
 
 
 def algorithmic_gflop_per_utt(cfg, tp, mean_tokens):
@@ -240,15 +241,23 @@ def per_shape_roofline(launches):
         key = names.get((N, K), f"n{N}_k{K}")
         if (N, K) == (1024, 1024):
             key = "att_out_pw2" if flags & capi.GEMM_RESIDUAL else "pos_proj"
-        a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "M": M, "N": N, "K": K})
+        a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "M": M, "N": N, "K": K})
         a["launches"] += 1
         a["ms"] += ms
         a["flops"] += flops
+        # algorithmic bytes of the launch: A + W (bf16) + the output (bf16, GLU halves it, f32) + the f32 residual read once
+        out_b = 4.0 * M * N if flags & (capi.GEMM_OUT_F32 | capi.GEMM_RESIDUAL) else (1.0 * M * N if flags & capi.GEMM_GLU else 2.0 * M * N)
+        a["bytes"] += 2.0 * M * K + 2.0 * N * K + out_b + (4.0 * M * N if flags & capi.GEMM_RESIDUAL else 0.0)
     out = {}
     for key, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        tbs = a["bytes"] / (a["ms"] * 1e-3) / 1e12
+        # a shape is priced against the roofline it is closer to: a K = 256 product of 1.4 M rows moves its operands at HBM rate
+        # long before it fills the matrix cores
         out[key] = {"M": a["M"], "N": a["N"], "K": a["K"], "launches": a["launches"], "avg_us": round(a["ms"] / a["launches"] * 1e3, 1),
-                    "tflops": round(tf, 1), "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
+                    "tflops": round(tf, 1), "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "algorithmic_tb_per_s": round(tbs, 2), "hbm_frac": round(tbs / HBM_PEAK_TBPS, 3),
+                    "bound": "hbm" if tbs / HBM_PEAK_TBPS > tf / MFMA_BF16_PEAK_TFLOPS else "mfma"}
     return out
 
 

@@ -23,6 +23,8 @@
 // Batch semantics: the reference runs the whole padded batch through the front-ends (padded frames are real inputs to the
 // Conv3d) and masks only attention keys and the encoder input rows; so does this file — a clip's result inside a batch equals the
 // reference's result for that batch.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -251,6 +253,58 @@ __global__ __launch_bounds__(256) void avsr_posconv_kernel(const float* __restri
     }
 }
 
+// The same positional convolution on the matrix cores (round 6: the form above ran 18 ms per batch of 16 x 250 frames, one scalar FMA
+// chain of 6144 terms per output: profiles/r06_05_f32_avsr_kernel_stats_before.txt).  Per tap k the group's product is a
+// [cg out] x [cg in] x [frames] matrix product: v_mfma_f32_16x16x4_f32 with the weights w[g][k][ic][oc] as the first operand (16
+// output channels x 4 input channels, read from L2: 4 runs of 64 bytes per wave instruction) and the frames' inputs as the second
+// (16 frames x 4 input channels from the LDS tile, row pitch cg + 1: conflict-free), so a lane's accumulator registers are four
+// consecutive output channels of one frame.  A wave owns 16 frames x cg output channels of one group (cg / 16 accumulator tiles);
+// a workgroup 64 frames.  Order of a sum: taps ascending, input channels ascending in 4-deep exact-f32 chains, bias last.
+// cg % 16 == 0, cg <= 64; grid (ceil(T / 64), G, B)
+template <int NT>
+__global__ __launch_bounds__(256) void avsr_posconv_mfma_kernel(const float* __restrict__ x, int T, int d, int K, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ out) {
+    constexpr int CG = NT * 16, PITCH = CG + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                    // [64 + K][PITCH]
+    const int t0 = blockIdx.x * 64, g = blockIdx.y, b = blockIdx.z, half = K / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    for (int i = threadIdx.x; i < (64 + K) * CG; i += 256) {
+        const int r = i / CG, c = i - r * CG, t = t0 + r - half;
+        xs[r * PITCH + c] = (t >= 0 && t < T) ? x[((size_t)b * T + t) * d + g * CG + c] : 0.0f;
+    }
+    __syncthreads();
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const float* wg = w + (size_t)g * K * CG * CG;
+    const float* xrow = xs + (wave * 16 + li) * PITCH;             // this lane's frame, tap 0
+    for (int k = 0; k < K; ++k) {
+        const float* wk = wg + (size_t)k * CG * CG;
+        const float* xr = xrow + k * PITCH;
+#pragma unroll
+        for (int ic0 = 0; ic0 < CG; ic0 += 4) {
+            const float xv = xr[ic0 + kq];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[(size_t)(ic0 + kq) * CG + n * 16 + li], xv, acc[n], 0, 0, 0);
+        }
+    }
+    const int t = t0 + wave * 16 + li;
+    if (t < T) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int oc = g * CG + n * 16 + 4 * kq;
+            const size_t at = ((size_t)b * T + t) * d + oc;
+            const float4 xin = *reinterpret_cast<const float4*>(x + at), bb = *reinterpret_cast<const float4*>(bias + oc);
+            float4 o;
+            o.x = xin.x + gelu_exact(acc[n][0] + bb.x); o.y = xin.y + gelu_exact(acc[n][1] + bb.y);
+            o.z = xin.z + gelu_exact(acc[n][2] + bb.z); o.w = xin.w + gelu_exact(acc[n][3] + bb.w);
+            *reinterpret_cast<float4*>(out + at) = o;
+        }
+    }
+}
+
 // Scaled dot-product attention, one wave per (query, head, query batch row); a lane owns head-dim elements lane, lane + 64, ..
 //   s_j = (q . k_j) * scaling over the visible keys j < n_keys, j <= causal limit, kmask[kb][j] == 0;  out = softmax(s) v
 // Two passes (maximum, then exp / sum / PV; scores recomputed).  Query rows qb = blockIdx.z read keys of batch kb = qb / rows_per_kb.
@@ -300,6 +354,70 @@ __global__ __launch_bounds__(256) void avsr_attn_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < NV; ++e)
         if (ok[e]) orow[lane + 64 * e] = den > 0.0f ? acc[e] / den : 0.0f;
+}
+
+// The same attention with the lanes over the KEYS (see attention_f32_keys_kernel in k_f32.hip: the per-key wave reductions of the form
+// above were 30 % of this family's kernel time, profiles/r06_05_f32_avsr_kernel_stats_before.txt): a lane computes the whole dot
+// products of keys lane, lane + 64, .. against the wave's query (in LDS, read as broadcasts), two wave reductions per query, then the
+// P.V sum walks the keys with coalesced value rows.  n_keys <= 64 NCH; more keys take the kernel above.
+template <int NCH>
+__global__ __launch_bounds__(256) void avsr_attn_keys_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldk,
+                                                             size_t k_batch_stride, const float* __restrict__ kmask, int mask_pitch, int rows_per_kb, int Tq,
+                                                             int n_keys, int hd, float scaling, float* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) float qs[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = blockIdx.x * 4 + wave, h = blockIdx.y, qb = blockIdx.z;
+    if (i >= Tq) return;
+    const int kb = qb / rows_per_kb;
+    const float* qr = q + ((size_t)qb * Tq + i) * ldq + h * hd;
+    const float* kbase = k + (size_t)kb * k_batch_stride + h * hd;
+    const float* vbase = v + (size_t)kb * k_batch_stride + h * hd;
+    const float* mk = kmask ? kmask + (size_t)kb * mask_pitch : nullptr;
+    for (int e = lane; e < hd; e += 64) qs[wave][e] = qr[e];
+    __builtin_amdgcn_wave_barrier();
+    const float4* q4 = reinterpret_cast<const float4*>(qs[wave]);
+    float sc[NCH];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j = lane + 64 * c;
+        sc[c] = -INFINITY;
+        if (j < n_keys && (!mk || mk[j] == 0.0f)) {
+            const float4* kr = reinterpret_cast<const float4*>(kbase + (size_t)j * ldk);
+            float a = 0.0f;
+            for (int e4 = 0; e4 < hd / 4; ++e4) {
+                const float4 kv = kr[e4], qq = q4[e4];
+                a = fmaf(qq.x, kv.x, a); a = fmaf(qq.y, kv.y, a); a = fmaf(qq.z, kv.z, a); a = fmaf(qq.w, kv.w, a);
+            }
+            sc[c] = a * scaling;
+            mx = fmaxf(mx, sc[c]);
+        }
+    }
+    mx = wave_max(mx);
+    float den = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        sc[c] = sc[c] > -INFINITY ? expf(sc[c] - mx) : 0.0f;
+        den += sc[c];
+    }
+    den = wave_sum(den);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int jn = n_keys - 64 * c < 64 ? n_keys - 64 * c : 64;
+        for (int jj = 0; jj < jn; ++jj) {
+            const float p = __shfl(sc[c], jj, 64);
+            if (p != 0.0f) {
+                const float* vr = vbase + (size_t)(64 * c + jj) * ldk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (lane + 64 * e < hd) acc[e] = fmaf(p, vr[lane + 64 * e], acc[e]);
+            }
+        }
+    }
+    float* orow = out + ((size_t)qb * Tq + i) * ldo + h * hd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (lane + 64 * e < hd) orow[lane + 64 * e] = den > 0.0f ? acc[e] / den : 0.0f;
 }
 
 // decoder input of one step: x[r] = embed[token[r]] + pos[step]
@@ -385,6 +503,14 @@ int launch_attn(rs_ctx* ctx, const float* q, int ldq, const float* k, const floa
     if (hd > 256) return rs_fail(ctx, RS_EINVAL, "avsr attention: head_dim %d > 256", hd);
     const dim3 grid((Tq + 3) / 4, H, Bq), block(256);
     const float scaling = 1.0f / sqrtf((float)hd);
+    if (!causal && n_keys <= 512 && hd % 4 == 0) {         // lanes over the keys (scores in registers)
+        if (n_keys <= 256)
+            hipLaunchKernelGGL((avsr_attn_keys_kernel<4>), grid, block, 0, s, q, ldq, k, v, ldk, kstride, kmask, mask_pitch, rows_per_kb, Tq, n_keys, hd, scaling, out, ldo);
+        else
+            hipLaunchKernelGGL((avsr_attn_keys_kernel<8>), grid, block, 0, s, q, ldq, k, v, ldk, kstride, kmask, mask_pitch, rows_per_kb, Tq, n_keys, hd, scaling, out, ldo);
+        RS_CHECK_LAUNCH(ctx, "avsr attention");
+        return RS_OK;
+    }
 #define RS_AV_ATT(NV) hipLaunchKernelGGL((avsr_attn_kernel<NV>), grid, block, 0, s, q, ldq, k, v, ldk, kstride, kmask, mask_pitch, rows_per_kb, Tq, n_keys, hd, scaling, causal, out, ldo)
     if (hd <= 64) RS_AV_ATT(1);
     else if (hd <= 128) RS_AV_ATT(2);
@@ -573,9 +699,21 @@ extern "C" int rs_avsr_encoder_forward(rs_ctx* ctx, const float* input_values, c
     hipLaunchKernelGGL(avsr_mask_rows_kernel, blocks1d(N * dm), dim3(256), 0, s, h, padding_mask, dm, N * dm);
     {
         const int cg = dm / d.conv_pos_groups;
-        const size_t lds = (size_t)(8 + d.conv_pos) * cg * 4;
-        if (lds > 64 * 1024) RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)avsr_posconv_kernel, (int)lds));
-        hipLaunchKernelGGL(avsr_posconv_kernel, dim3((T + 7) / 8, d.conv_pos_groups, B), dim3(256), lds, s, h, T, dm, cg, d.conv_pos, k.pos_w, k.pos_b, t);
+        if (cg % 16 == 0 && cg <= 64 && !getenv("RS_AVSR_POSCONV_OLD")) {
+            const size_t lds = (size_t)(64 + d.conv_pos) * (cg + 1) * 4;
+            const dim3 grid((T + 63) / 64, d.conv_pos_groups, B);
+#define RS_AV_POS(NT)                                                                                                                         \
+            do {                                                                                                                              \
+                if (lds > 64 * 1024) RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)avsr_posconv_mfma_kernel<NT>, (int)lds));                  \
+                hipLaunchKernelGGL((avsr_posconv_mfma_kernel<NT>), grid, dim3(256), lds, s, h, T, dm, d.conv_pos, k.pos_w, k.pos_b, t);          \
+            } while (0)
+            if (cg == 16) RS_AV_POS(1); else if (cg == 32) RS_AV_POS(2); else if (cg == 48) RS_AV_POS(3); else RS_AV_POS(4);
+#undef RS_AV_POS
+        } else {
+            const size_t lds = (size_t)(8 + d.conv_pos) * cg * 4;
+            if (lds > 64 * 1024) RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)avsr_posconv_kernel, (int)lds));
+            hipLaunchKernelGGL(avsr_posconv_kernel, dim3((T + 7) / 8, d.conv_pos_groups, B), dim3(256), lds, s, h, T, dm, cg, d.conv_pos, k.pos_w, k.pos_b, t);
+        }
     }
     hipLaunchKernelGGL(avsr_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, t, k.encln_g, k.encln_b, M, dm, d.layer_norm_eps, h);
     if (k.tap_encln) RS_HIP(ctx, hipMemcpyAsync(k.tap_encln, h, N * dm * 4, hipMemcpyDeviceToDevice, s));

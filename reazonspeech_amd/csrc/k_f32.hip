@@ -15,6 +15,8 @@
 //
 // Speed is not the object (about 1 s per batch of 256 x 10 s against 55 ms in the throughput mode); the kernels are kept
 // simple enough to be read against oracle/model.py line by line.
+#include <stdlib.h>
+
 #include "rs_common.h"
 
 int rs_launch_sub_conv0_dw1_f32(rs_ctx* ctx, const float* feats, const int32_t* lens_stage, int B, int t_max, int T2, int F2,
@@ -44,46 +46,68 @@ constexpr int GP = 36;    // LDS row pitch in floats (144 B: 16-byte aligned, ro
 // out[M][N] = epilogue(A[M][K] . W[N][K]^T), all float32.  256 threads = 2 x 2 waves, a wave owns 64 x 64 outputs
 // (4 x 4 MFMA blocks).  The weight fragment is the MFMA A operand, so a lane's four accumulator registers are four
 // CONSECUTIVE columns of one output row: bias / residual / store are float4 accesses.
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
-    __shared__ __attribute__((aligned(16))) float As[GT * GP];
-    __shared__ __attribute__((aligned(16))) float Ws[GT * GP];
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
+    // Two LDS stages (round 6): the next K stage is fetched into registers while this one is multiplied and written into the OTHER
+    // buffer afterwards, so a stage costs one workgroup barrier instead of two; two workgroups per CU (launch bound) leave the
+    // prefetch registers in VGPRs — at three the compiler parked them in scratch on their way to LDS (profiles/r06_05_*: 144 bytes
+    // of scratch per lane).  The arithmetic per output element is unchanged: ascending 16-blocks, inside a block k = e + 4 kk.
+    __shared__ __attribute__((aligned(16))) float As[2][GT * GP];
+    __shared__ __attribute__((aligned(16))) float Ws[2][GT * GP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
     const int lr = tid >> 3, lc = tid & 7;            // staging: row lr + 32 i, 16-byte chunk lc of the 128-byte K slice
-    float4 ra[4], rw[4];
-    auto gload = [&](int k0) {
+    // (macros, not lambdas: with the prefetch registers captured by reference the arrays stayed stack objects — 128 bytes of scratch
+    // traffic per lane and K stage)
+    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    const float* a_ptr[4];
+    const float* w_ptr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int m = m0 + lr + 32 * i, n = n0 + lr + 32 * i;
-            m = m < p.M ? m : p.M - 1;                // rows past the matrix: clamped, their products are never stored
-            n = n < p.N ? n : p.N - 1;
-            ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + k0 + 4 * lc);
-            rw[i] = *reinterpret_cast<const float4*>(p.W + (size_t)n * p.ldw + k0 + 4 * lc);
-        }
-    };
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + lr + 32 * i, n = n0 + lr + 32 * i;
+        m = m < p.M ? m : p.M - 1;                    // rows past the matrix: clamped, their products are never stored
+        n = n < p.N ? n : p.N - 1;
+        a_ptr[i] = p.A + (size_t)m * p.lda + 4 * lc;
+        w_ptr[i] = p.W + (size_t)n * p.ldw + 4 * lc;
+    }
+#define RS_F32_GLOAD(k0)                                                                                        \
+    do {                                                                                                       \
+        ra0 = *reinterpret_cast<const float4*>(a_ptr[0] + (k0)); rw0 = *reinterpret_cast<const float4*>(w_ptr[0] + (k0)); \
+        ra1 = *reinterpret_cast<const float4*>(a_ptr[1] + (k0)); rw1 = *reinterpret_cast<const float4*>(w_ptr[1] + (k0)); \
+        ra2 = *reinterpret_cast<const float4*>(a_ptr[2] + (k0)); rw2 = *reinterpret_cast<const float4*>(w_ptr[2] + (k0)); \
+        ra3 = *reinterpret_cast<const float4*>(a_ptr[3] + (k0)); rw3 = *reinterpret_cast<const float4*>(w_ptr[3] + (k0)); \
+    } while (0)
+#define RS_F32_STASH(buf)                                                                                       \
+    do {                                                                                                       \
+        float* ad = As[buf] + lr * GP + 4 * lc;                                                               \
+        float* wd = Ws[buf] + lr * GP + 4 * lc;                                                               \
+        *reinterpret_cast<float4*>(ad) = ra0; *reinterpret_cast<float4*>(ad + 32 * GP) = ra1;                 \
+        *reinterpret_cast<float4*>(ad + 64 * GP) = ra2; *reinterpret_cast<float4*>(ad + 96 * GP) = ra3;       \
+        *reinterpret_cast<float4*>(wd) = rw0; *reinterpret_cast<float4*>(wd + 32 * GP) = rw1;                 \
+        *reinterpret_cast<float4*>(wd + 64 * GP) = rw2; *reinterpret_cast<float4*>(wd + 96 * GP) = rw3;       \
+    } while (0)
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
-    gload(0);
+    RS_F32_GLOAD(0);
+    RS_F32_STASH(0);
+    __syncthreads();
+    int cur = 0;
     for (int k0 = 0; k0 < p.K; k0 += GK) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(As + (lr + 32 * i) * GP + 4 * lc) = ra[i];
-            *reinterpret_cast<float4*>(Ws + (lr + 32 * i) * GP + 4 * lc) = rw[i];
-        }
-        __syncthreads();
-        if (k0 + GK < p.K) gload(k0 + GK);
+        const bool more = k0 + GK < p.K;
+        if (more) RS_F32_GLOAD(k0 + GK);
+        const float* Ab = As[cur];
+        const float* Wb = Ws[cur];
 #pragma unroll
         for (int kb = 0; kb < GK / 16; ++kb) {
             float4 af[4], wf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const float4*>(As + (wm * 64 + i * 16 + fr) * GP + kb * 16 + 4 * fq);
-                wf[i] = *reinterpret_cast<const float4*>(Ws + (wn * 64 + i * 16 + fr) * GP + kb * 16 + 4 * fq);
+                af[i] = *reinterpret_cast<const float4*>(Ab + (wm * 64 + i * 16 + fr) * GP + kb * 16 + 4 * fq);
+                wf[i] = *reinterpret_cast<const float4*>(Wb + (wn * 64 + i * 16 + fr) * GP + kb * 16 + 4 * fq);
             }
             // step e of a 16-block multiplies k = 16 kb + 4 kk + e for the four lane groups kk at once
 #define RS_F32_STEP(E)                                                                                          \
@@ -93,8 +117,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
             RS_F32_STEP(x) RS_F32_STEP(y) RS_F32_STEP(z) RS_F32_STEP(w)
 #undef RS_F32_STEP
         }
+        if (more) RS_F32_STASH(cur ^ 1);              // nobody reads that buffer: its readers passed the barrier that ended the previous stage
         __syncthreads();
+        cur ^= 1;
     }
+#undef RS_F32_GLOAD
+#undef RS_F32_STASH
     // epilogue, the order of k_gemm_bf16.hip: + bias, activation, * alpha, + residual, row mask
     const bool has_bias = p.flags & RS_GEMM_BIAS, relu = p.flags & RS_GEMM_RELU, silu = p.flags & RS_GEMM_SILU;
     const bool res = p.flags & RS_GEMM_RESIDUAL, rowmask = p.flags & RS_GEMM_ROWMASK;
@@ -206,6 +234,90 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
         if (ok[v]) orow[lane + 64 * v] = den > 0.0f ? acc[v] / den : 0.0f;
 }
 
+// The same attention with the LANES OVER THE KEYS (round 6): the kernel above spends its time in the two 6-step wave reductions
+// it makes per key (profiles/r06_05_f32_*_before.txt: 34 % of the NeMo float32 mode, 70 % of the ESPnet one).  Here a lane owns keys
+// lane, lane + 64, .. and computes the whole head_dim dot products of ITS keys (ascending e, one fma chain per term; the wave's query
+// vectors q + u, q + v sit in LDS and are read as broadcasts), so a query costs two wave reductions in total (maximum, denominator);
+// the P.V sum then walks the keys with the probability read from its lane (v_readlane) and the value row read coalesced.  Scores live
+// in registers: T <= 64 NCH (NCH = 4 / 8); longer inputs (long-form windows) take the kernel above.  Same mask semantics.
+template <int NCH>
+__global__ __launch_bounds__(256) void attention_f32_keys_kernel(const float* __restrict__ qkv, const float* __restrict__ pos,
+                                                                 const float* __restrict__ bias_u, const float* __restrict__ bias_v,
+                                                                 const int32_t* __restrict__ lens, float* __restrict__ out, int T,
+                                                                 int d, int hd, int att_left, int att_right, int n_global, float scale) {
+    __shared__ __attribute__((aligned(16))) float qs[4][2][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+    if (i >= T) return;                                    // (no workgroup barrier below: a wave only reads the LDS rows it wrote)
+    int len = lens[b];
+    len = len < T ? len : T;
+    float* orow = out + ((size_t)b * T + i) * d + h * hd;
+    if (i >= len) {
+        for (int e = lane; e < hd; e += 64) orow[e] = 0.0f;
+        return;
+    }
+    const size_t ld = 3 * (size_t)d;
+    const float* base = qkv + (size_t)b * T * ld + h * hd;
+    for (int e = lane; e < hd; e += 64) {
+        const float q = base[(size_t)i * ld + e];
+        qs[wave][0][e] = q + bias_u[h * hd + e];
+        qs[wave][1][e] = q + bias_v[h * hd + e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float4* qu4 = reinterpret_cast<const float4*>(qs[wave][0]);
+    const float4* qv4 = reinterpret_cast<const float4*>(qs[wave][1]);
+    const bool window = att_left >= 0 || att_right >= 0;
+    const int left = att_left >= 0 ? att_left : T, right = att_right >= 0 ? att_right : T;
+    float sc[NCH];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j = lane + 64 * c;
+        bool vis = j < len;
+        if (vis && window) vis = ((i - j) <= left && (j - i) <= right) || i < n_global || j < n_global;
+        sc[c] = -INFINITY;
+        if (vis) {
+            const float4* kr = reinterpret_cast<const float4*>(base + (size_t)j * ld + d);
+            const float4* pr = reinterpret_cast<const float4*>(pos + (size_t)(j - i + T - 1) * d + h * hd);
+            float ac = 0.0f, bd = 0.0f;
+            for (int e4 = 0; e4 < hd / 4; ++e4) {
+                const float4 kv = kr[e4], pv = pr[e4], a = qu4[e4], g = qv4[e4];
+                ac = fmaf(a.x, kv.x, ac); ac = fmaf(a.y, kv.y, ac); ac = fmaf(a.z, kv.z, ac); ac = fmaf(a.w, kv.w, ac);
+                bd = fmaf(g.x, pv.x, bd); bd = fmaf(g.y, pv.y, bd); bd = fmaf(g.z, pv.z, bd); bd = fmaf(g.w, pv.w, bd);
+            }
+            sc[c] = (ac + bd) * scale;
+            mx = fmaxf(mx, sc[c]);
+        }
+    }
+    mx = wave_max(mx);
+    float den = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        sc[c] = sc[c] > -INFINITY ? expf(sc[c] - mx) : 0.0f;
+        den += sc[c];
+    }
+    den = wave_sum(den);
+    // P.V: this lane's output elements e = lane, lane + 64, ..; keys in ascending order
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* vbase = base + 2 * d;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int jn = len - 64 * c < 64 ? len - 64 * c : 64;
+        for (int jj = 0; jj < jn; ++jj) {
+            const float p = __shfl(sc[c], jj, 64);
+            if (p != 0.0f) {                               // (wave-uniform: masked keys contribute nothing)
+                const float* vr = vbase + (size_t)(64 * c + jj) * ld;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (lane + 64 * v < hd) acc[v] = fmaf(p, vr[lane + 64 * v], acc[v]);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+        if (lane + 64 * v < hd) orow[lane + 64 * v] = den > 0.0f ? acc[v] / den : 0.0f;
+}
+
 // conv-module middle in float32: x [B*T][2d] (values | gates, NeMo's own order) -> GLU -> frame mask -> depthwise k
 // (BatchNorm folded) -> SiLU -> out [B*T][d].  One thread per output element, channel fastest.
 __global__ __launch_bounds__(256) void glu_dwconv_silu_f32_kernel(const float* __restrict__ x, const float* __restrict__ w /* [k][d] */,
@@ -308,13 +420,22 @@ int rs_launch_attention_f32(rs_ctx* ctx, const float* qkv, const float* pos, con
     const dim3 grid((T + 3) / 4, dm.n_heads, B), block(256);
     const float scale = 1.0f / sqrtf((float)hd);
     rs_prof_begin(ctx, RS_PROF_ATTN, s, (double)B * dm.n_heads * 3.0 * 2.0 * T * (double)T * hd, (double)B * T * dm.d_model * 4.0 * 4.0);
+#define RS_ATT_KEYS(NCH)                                                                                                 \
+    hipLaunchKernelGGL((attention_f32_keys_kernel<NCH>), grid, block, 0, s, qkv, pos, bias_u, bias_v, lens, out, T, dm.d_model, hd, \
+                       dm.att_left, dm.att_right, dm.n_global, scale)
 #define RS_ATT_CASE(NV)                                                                                                  \
     hipLaunchKernelGGL((attention_f32_kernel<NV>), grid, block, 0, s, qkv, pos, bias_u, bias_v, lens, out, T, dm.d_model, hd, \
                        dm.att_left, dm.att_right, dm.n_global, scale)
+    static const bool one_wave_per_key_sum = getenv("RS_ATTN_F32_OLD") != nullptr;      // A/B and test hook: the first form
+    if (!one_wave_per_key_sum && T <= 512 && hd % 4 == 0) {
+        if (T <= 256) RS_ATT_KEYS(4);
+        else RS_ATT_KEYS(8);
+    } else
     if (hd <= 64) RS_ATT_CASE(1);
     else if (hd <= 128) RS_ATT_CASE(2);
     else RS_ATT_CASE(4);
 #undef RS_ATT_CASE
+#undef RS_ATT_KEYS
     rs_prof_end(ctx, RS_PROF_ATTN, s);
     RS_CHECK_LAUNCH(ctx, "attention_f32");
     return RS_OK;

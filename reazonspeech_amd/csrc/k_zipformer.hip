@@ -494,6 +494,103 @@ __global__ __launch_bounds__(256) void k2_attn_weights_kernel(const uint16_t* __
     }
 }
 
+// The same weights in ONE sweep over the keys (round 6): the 16 x 16 score tiles of a wave's 16 queries stay
+// in registers — NT tiles of four scores per lane, T <= 16 NT — so the q.k MFMA, the position-table reads and the 16 position
+// multiply-adds of a tile run once instead of three times.  Same score arithmetic, same order of the maximum, of the sum (tiles
+// ascending, then the lane's four scores, then the two shuffles) and of the normalisation as the three-sweep kernel above:
+// BIT-IDENTICAL weights (tests/test_gpu_k2.py batch-invariance and oracle tests run on this kernel; $RS_K2_ATTW_SWEEPS=3 selects the
+// old one).  Instantiated for NT = 10 / 20 / 40 (T <= 160 / 320 / 640: every stack of a 12.8 s utterance); longer inputs take the
+// three-sweep kernel, which has no length limit.
+template <int NT>
+__global__ __launch_bounds__(256) void k2_attn_weights1_kernel(const uint16_t* __restrict__ qkp, int ld, const float* __restrict__ pos, int cap, int H,
+                                                               const int32_t* __restrict__ lens, int T, int Tp, uint16_t* __restrict__ W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* ps = reinterpret_cast<float4*>(smem);
+    const int h = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int len = lens[b];
+    len = len < T ? len : T;
+    uint16_t* wbase = W + (((size_t)b * H + h) * T) * Tp;
+    if (i0 >= len) {
+        for (int idx = threadIdx.x; idx < 64 * (Tp / 4); idx += 256) {
+            const int r = idx / (Tp / 4), q = idx - r * (Tp / 4);
+            if (i0 + r < T) reinterpret_cast<u16x4_t*>(wbase + (size_t)(i0 + r) * Tp)[q] = (u16x4_t){0, 0, 0, 0};
+        }
+        return;
+    }
+    const int nrel = len + 63;
+    for (int r = threadIdx.x; r < nrel; r += 256) {
+        int n = r - (i0 + 63) + cap - 1;
+        n = n < 0 ? 0 : (n > 2 * cap - 2 ? 2 * cap - 2 : n);
+        ps[r] = *reinterpret_cast<const float4*>(pos + (size_t)n * (H * K2_PD) + h * K2_PD);
+    }
+    __syncthreads();
+    const int qi = i0 + wave * 16 + (lane & 15);
+    const int kq = lane >> 4;
+    const bool q_ok = qi < len;
+    const int qrow = qi < T ? qi : T - 1;
+    const uint16_t* qp = qkp + ((size_t)b * T + qrow) * ld;
+    const bf16x8_t qfrag = *reinterpret_cast<const bf16x8_t*>(qp + h * K2_QD + 8 * kq);
+    float4 pq;
+    {
+        const u16x4_t pv = *reinterpret_cast<const u16x4_t*>(qp + 2 * H * K2_QD + h * K2_PD);
+        pq = make_float4(bf16_to_f32(pv[0]), bf16_to_f32(pv[1]), bf16_to_f32(pv[2]), bf16_to_f32(pv[3]));
+    }
+    const int ntile = (len + 15) / 16;
+    float s[NT][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        if (jt < ntile) {                                   // (wave-uniform: the MFMA below runs with every lane)
+            int krow = jt * 16 + (lane & 15);
+            krow = krow < len ? krow : len - 1;
+            const bf16x8_t kfrag = *reinterpret_cast<const bf16x8_t*>(qkp + ((size_t)b * T + krow) * ld + H * K2_QD + h * K2_QD + 8 * kq);
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qfrag, acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = jt * 16 + 4 * kq + e;
+                int r = j - qi + i0 + 63;
+                r = r < 0 ? 0 : (r >= nrel ? nrel - 1 : r);
+                const float4 pr = ps[r];
+                const float v = acc[e] + (pq.x * pr.x + pq.y * pr.y + pq.z * pr.z + pq.w * pr.w);
+                s[jt][e] = j < len ? v : -INFINITY;
+            }
+            mx = fmaxf(mx, fmaxf(fmaxf(s[jt][0], s[jt][1]), fmaxf(s[jt][2], s[jt][3])));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[jt][e] = -INFINITY;
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+        if (jt < ntile) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[jt][e] = __expf(s[jt][e] - mx);
+                sum += s[jt][e];
+            }
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = q_ok ? 1.0f / sum : 0.0f;
+    const int ntile_all = Tp / 16;
+    if (qi < T) {
+        uint16_t* wr = wbase + (size_t)qi * Tp + 4 * kq;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            if (jt < ntile_all) {                          // (no `break`: the loops must unroll completely for s[][] to live in registers)
+                u16x4_t o = {0, 0, 0, 0};
+                if (jt < ntile) o = pack_bf16x4(s[jt][0] * inv, s[jt][1] * inv, s[jt][2] * inv, s[jt][3] * inv);
+                *reinterpret_cast<u16x4_t*>(wr + jt * 16) = o;
+            }
+        }
+    }
+}
+
 // ---- weights x values ---------------------------------------------------------------------------------------------------------------
 // out[b][i][c] = sum_j W[b][h][i][j] * V[b][j][c]  for the channels of one head (self-attention: 12 of a 16-wide tile) or, MODE 1,
 // for 64-channel slices of the non-linear attention with head 0's weights:  V = u[:, hid + c] * tanh(u[:, c]) (rounded to bf16
@@ -1273,7 +1370,18 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
                 if (lds > 64 * 1024) RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)k2_attn_weights_kernel, (int)lds));
                 if (Ts > k.pos_cap) return rs_fail(ctx, RS_EINVAL, "zipformer: %d frames exceed the registered position tables (%d)", Ts, k.pos_cap);
                 rs_prof_begin(ctx, RS_PROF_ATTN, s, (double)B * H * Ts * (double)Ts * (2.0 * K2_QD + 2.0 * K2_PD + 8.0) * 2.0, (double)B * H * Ts * (double)Tp * 2.0);
-                hipLaunchKernelGGL(k2_attn_weights_kernel, dim3((Ts + 63) / 64, H, B), dim3(256), lds, s, qkp, nin, L.pos_proj, k.pos_cap, H, lens, Ts, Tp, W);
+                static const bool three_sweeps = getenv("RS_K2_ATTW_SWEEPS") != nullptr && atoi(getenv("RS_K2_ATTW_SWEEPS")) == 3;   // A/B and test hook
+                const dim3 grid((Ts + 63) / 64, H, B);
+#define RS_K2_ATTW1(NT)                                                                                                                     \
+                do {                                                                                                                        \
+                    if (lds > 64 * 1024) RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)k2_attn_weights1_kernel<NT>, (int)lds));            \
+                    hipLaunchKernelGGL((k2_attn_weights1_kernel<NT>), grid, dim3(256), lds, s, qkp, nin, L.pos_proj, k.pos_cap, H, lens, Ts, Tp, W); \
+                } while (0)
+                if (three_sweeps || Tp > 640) hipLaunchKernelGGL(k2_attn_weights_kernel, grid, dim3(256), lds, s, qkp, nin, L.pos_proj, k.pos_cap, H, lens, Ts, Tp, W);
+                else if (Tp <= 160) RS_K2_ATTW1(10);
+                else if (Tp <= 320) RS_K2_ATTW1(20);
+                else RS_K2_ATTW1(40);
+#undef RS_K2_ATTW1
                 rs_prof_end(ctx, RS_PROF_ATTN, s);
             }
             auto ffn = [&](int f, int width, const float* res, bool emit) -> int {

@@ -11,7 +11,7 @@ for f in $FAMS; do
   rm -rf $OUT
   timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python scripts/family_f32_run.py $f > gpurun_out/${TAG}_f32_$f.log 2>&1
   tail -2 gpurun_out/${TAG}_f32_$f.log
-  F=$(find $OUT -name "*kernel_stats.csv" | head -1)
-  if [ -n "$F" ]; then head -14 "$F" | cut -c1-200; cp "$F" gpurun_out/${TAG}_f32_${f}_kernel_stats.csv; fi
+  DB=$(find $OUT -name "*.db" | head -1); python scripts/rocprof_summary.py $DB 2 > gpurun_out/${TAG}_f32_${f}_kernel_stats.txt 2>&1
+  head -22 gpurun_out/${TAG}_f32_${f}_kernel_stats.txt | cut -c1-200
   rm -rf $OUT
 done

@@ -212,8 +212,9 @@ def test_search_retries_the_decode_only_and_flags_a_degraded_batch(gpu_device):
     cfg0 = model.am.cfg
     fine = model._search(waves)
     assert model.am.cfg is cfg0 and fine.degraded == [False] * 3 and fine.scores is not None
-    # a bound of ONE evaluation per frame overflows at 1x, 4x and 16x: the greedy fallback answers, flagged and with a warning
-    model.am.cfg = cfg0.with_(beam_max_pops=1)
+    # the smallest bound the library accepts (max_pops == beam): it may overflow at 1x, 4x and 16x — then the greedy fallback answers,
+    # flagged and with a warning — or a retry succeeds and the beam result stands
+    model.am.cfg = cfg0.with_(beam_max_pops=6)
     tight = model.am.cfg
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
