@@ -318,6 +318,143 @@ __global__ __launch_bounds__(256) void attention_f32_keys_kernel(const float* __
         if (lane + 64 * v < hd) orow[lane + 64 * v] = den > 0.0f ? acc[v] / den : 0.0f;
 }
 
+// Full-context rel-pos attention in float32 on the matrix cores (round 6).  A wave owns 16 queries of one (utterance, head) and walks
+// the keys 16 at a time with an online softmax; every product is v_mfma_f32_16x16x4_f32 with operands read straight from global
+// memory as 16-byte pieces (lane (li, kq) takes elements 16 S + 4 kq .. + 3 of row li: step (S, E) of a chain multiplies element
+// 16 S + 4 kq + E of the four lane groups at once — the summation order of gemm_f32_kernel):
+//   AC   D[key][query]  = K rows x (q + u) rows                                   1 accumulator tile
+//   BD   G[c][query]    = P rows (r0 + c, c = 0 .. 31) x (q + v) rows              2 tiles; r0 = j0 - i0 - 15 + T - 1, so the score of
+//        (query i0 + a, key j0 + k) needs G[k - a + 15][a]: the rel-shift is a read of a query-major skew tile in wave-private LDS
+//   P.V  O[e][query]   += V^T x probabilities, the four keys of an MFMA step chosen as j0 + 4 kq + m so that a lane's own probability
+//        register m IS its operand (no shuffle); element e = 64 g + 4 (4 kq + r) + n of tile (g, n), so a lane ends up with 16
+//        consecutive output elements per 64-wide group
+// Masking: keys at or past the utterance's length weigh 0, padded queries give zeros.  Limited-context variants (att_left / att_right /
+// global tokens) take attention_f32_keys_kernel.  HD = 64 or 128.  grid (ceil(T / 64), H, B), block 256 (four independent waves).
+template <int HD>
+__global__ __launch_bounds__(256) void attention_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ pos,
+                                                                 const float* __restrict__ bias_u, const float* __restrict__ bias_v,
+                                                                 const int32_t* __restrict__ lens, float* __restrict__ out, int T, int d, float scale) {
+    constexpr int NS = HD / 16, NG = HD / 64;
+    __shared__ float skew[4][16][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.x * 64 + wave * 16, h = blockIdx.y, b = blockIdx.z;
+    if (i0 >= T) return;
+    int len = lens[b];
+    len = len < T ? len : T;
+    const size_t ld = 3 * (size_t)d;
+    const float* base = qkv + (size_t)b * T * ld + h * HD;
+    const int qi = i0 + li;
+    float* orow = out + ((size_t)b * T + (qi < T ? qi : T - 1)) * d + h * HD;
+    if (i0 >= len) {                                        // a tile of padding queries
+        if (qi < T)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(orow + 64 * g + 16 * kq + 4 * r) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int qrow = qi < T ? qi : T - 1;
+    float4 qu[NS], qv[NS];
+#pragma unroll
+    for (int S = 0; S < NS; ++S) {
+        const float4 q4 = *reinterpret_cast<const float4*>(base + (size_t)qrow * ld + 16 * S + 4 * kq);
+        const float4 u4 = *reinterpret_cast<const float4*>(bias_u + h * HD + 16 * S + 4 * kq);
+        const float4 v4 = *reinterpret_cast<const float4*>(bias_v + h * HD + 16 * S + 4 * kq);
+        qu[S] = make_float4(q4.x + u4.x, q4.y + u4.y, q4.z + u4.z, q4.w + u4.w);
+        qv[S] = make_float4(q4.x + v4.x, q4.y + v4.y, q4.z + v4.z, q4.w + v4.w);
+    }
+    f32x4_t O[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) O[g][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int ntile = (len + 15) / 16;
+    float (*sk)[33] = skew[wave];
+    for (int jt = 0; jt < ntile; ++jt) {
+        const int j0 = jt * 16;
+        const int krow = j0 + li < len ? j0 + li : len - 1;
+        const int r0 = j0 - i0 - 15 + T - 1;
+        int pr0 = r0 + li, pr1 = r0 + 16 + li;
+        pr0 = pr0 < 0 ? 0 : (pr0 > 2 * T - 2 ? 2 * T - 2 : pr0);
+        pr1 = pr1 < 0 ? 0 : (pr1 > 2 * T - 2 ? 2 * T - 2 : pr1);
+        const float* kp = base + (size_t)krow * ld + d + 4 * kq;
+        const float* p0p = pos + (size_t)pr0 * d + h * HD + 4 * kq;
+        const float* p1p = pos + (size_t)pr1 * d + h * HD + 4 * kq;
+        f32x4_t ac = {0.f, 0.f, 0.f, 0.f}, g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int S = 0; S < NS; ++S) {
+            const float4 kf = *reinterpret_cast<const float4*>(kp + 16 * S);
+            const float4 pa = *reinterpret_cast<const float4*>(p0p + 16 * S);
+            const float4 pb = *reinterpret_cast<const float4*>(p1p + 16 * S);
+#define RS_ATT_STEP(E)                                                                      \
+            ac = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.E, qu[S].E, ac, 0, 0, 0);          \
+            g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.E, qv[S].E, g0, 0, 0, 0);          \
+            g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pb.E, qv[S].E, g1, 0, 0, 0);
+            RS_ATT_STEP(x) RS_ATT_STEP(y) RS_ATT_STEP(z) RS_ATT_STEP(w)
+#undef RS_ATT_STEP
+        }
+        // rel-shift through the query-major skew tile: G[c][query li] with c = 16 t + 4 kq + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sk[li][4 * kq + r] = g0[r];
+            sk[li][16 + 4 * kq + r] = g1[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float sc[4];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float bd = sk[li][4 * kq + r - li + 15];
+            sc[r] = j0 + 4 * kq + r < len ? (ac[r] + bd) * scale : -INFINITY;
+            mt = fmaxf(mt, sc[r]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);               // finite from the first tile on (key 0 is always visible)
+        const float alpha = expf(m_run - m_new);
+        float pr[4], lt = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pr[r] = expf(sc[r] - m_new);
+            lt += pr[r];
+        }
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        l_run = l_run * alpha + lt;
+        m_run = m_new;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) O[g][n][r] *= alpha;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int vrow = j0 + 4 * kq + m < len ? j0 + 4 * kq + m : len - 1;
+            const float* vp = base + (size_t)vrow * ld + 2 * d + 4 * li;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const float4 v4 = *reinterpret_cast<const float4*>(vp + 64 * g);
+                O[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.x, pr[m], O[g][0], 0, 0, 0);
+                O[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.y, pr[m], O[g][1], 0, 0, 0);
+                O[g][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.z, pr[m], O[g][2], 0, 0, 0);
+                O[g][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.w, pr[m], O[g][3], 0, 0, 0);
+            }
+        }
+    }
+    if (qi < T) {
+        const float inv = qi < len ? 1.0f / l_run : 0.0f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<float4*>(orow + 64 * g + 16 * kq + 4 * r) =
+                    make_float4(O[g][0][r] * inv, O[g][1][r] * inv, O[g][2][r] * inv, O[g][3][r] * inv);
+    }
+}
+
 // conv-module middle in float32: x [B*T][2d] (values | gates, NeMo's own order) -> GLU -> frame mask -> depthwise k
 // (BatchNorm folded) -> SiLU -> out [B*T][d].  One thread per output element, channel fastest.
 __global__ __launch_bounds__(256) void glu_dwconv_silu_f32_kernel(const float* __restrict__ x, const float* __restrict__ w /* [k][d] */,
@@ -427,6 +564,12 @@ int rs_launch_attention_f32(rs_ctx* ctx, const float* qkv, const float* pos, con
     hipLaunchKernelGGL((attention_f32_kernel<NV>), grid, block, 0, s, qkv, pos, bias_u, bias_v, lens, out, T, dm.d_model, hd, \
                        dm.att_left, dm.att_right, dm.n_global, scale)
     static const bool one_wave_per_key_sum = getenv("RS_ATTN_F32_OLD") != nullptr;      // A/B and test hook: the first form
+    static const bool no_mfma = getenv("RS_ATTN_F32_KEYS") != nullptr;                 // A/B and test hook: the second form
+    if (!one_wave_per_key_sum && !no_mfma && dm.att_left < 0 && dm.att_right < 0 && (hd == 64 || hd == 128)) {
+        const dim3 grid16((T + 63) / 64, dm.n_heads, B);
+        if (hd == 128) hipLaunchKernelGGL((attention_f32_mfma_kernel<128>), grid16, block, 0, s, qkv, pos, bias_u, bias_v, lens, out, T, dm.d_model, scale);
+        else hipLaunchKernelGGL((attention_f32_mfma_kernel<64>), grid16, block, 0, s, qkv, pos, bias_u, bias_v, lens, out, T, dm.d_model, scale);
+    } else
     if (!one_wave_per_key_sum && T <= 512 && hd % 4 == 0) {
         if (T <= 256) RS_ATT_KEYS(4);
         else RS_ATT_KEYS(8);
