@@ -811,7 +811,9 @@ extern "C" int rs_avsr_decoder_step(rs_ctx* ctx, const int32_t* tokens, const in
     float *x = fp(pl.off_x), *t = fp(pl.off_t), *u = fp(pl.off_u), *qkv = fp(pl.off_qkv), *big = fp(pl.off_big), *cross = fp(pl.off_cross);
     int rc;
 #define RS_TRY(call) do { rc = (call); if (rc != RS_OK) return rc; } while (0)
+    // up to 128 hypothesis rows: the few-rows form (N / 16 workgroups, K cut over the waves); more rows: the tiled kernel
     auto gemm = [&](const float* A, int lda, const float* W, int K, float* out, int ldc, int Nc, int flags, const float* bias, const float* res) -> int {
+        if (R <= 128) return rs_launch_gemm_f32_skinny(ctx, A, lda, W, K, out, ldc, R, Nc, K, flags, bias, res, s);
         return rs_launch_gemm_f32(ctx, A, lda, W, K, out, ldc, R, Nc, K, flags, bias, 1.0f, res, nullptr, 0, 0, s);
     };
     auto ln = [&](const float* in, const float* g, const float* b, float* out) {

@@ -162,6 +162,80 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
     }
 }
 
+// out[M][N] = epilogue(A[M][K] . W[N][K]^T) for a FEW rows (M <= 128: the hypothesis rows of an autoregressive decoder step, k_avsr.hip).
+// gemm_f32_kernel gives such a product N / 128 workgroups that each walk all of K alone — 6 workgroups and 24 dependent global-load
+// round trips for a 768 x 768 layer, ~125 us per launch in profiles/r06_06_f32_avsr_*.  Here a workgroup owns 16 output columns, its
+// four waves split K into four contiguous runs of 16-blocks (weights and rows straight from global memory / L2 as 16-byte pieces,
+// v_mfma_f32_16x16x4_f32, the weight fragment first: a lane holds four consecutive columns of one row), and the partial sums are
+// added in LDS in wave order 0 + 1 + 2 + 3.  N / 16 workgroups, K / 64 steps each.  The summation order differs from
+// gemm_f32_kernel's (K is cut in four): callers that promise bit-identical results across batch sizes must not mix the two.
+// K % 16 == 0, N % 4 == 0.  grid (ceil(N / 16)), block 256
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF32 p) {
+    __shared__ __attribute__((aligned(16))) float part[3][MT][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nblk = p.K / 16, per = (nblk + 3) / 4;
+    const int s_lo = wave * per, s_hi = s_lo + per < nblk ? s_lo + per : nblk;
+    int nrow = n0 + li;
+    nrow = nrow < p.N ? nrow : p.N - 1;
+    const float* wp = p.W + (size_t)nrow * p.ldw + 4 * kq;
+    const float* ap[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int m = 16 * t + li;
+        m = m < p.M ? m : p.M - 1;
+        ap[t] = p.A + (size_t)m * p.lda + 4 * kq;
+    }
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int S = s_lo; S < s_hi; ++S) {
+        const float4 wf = *reinterpret_cast<const float4*>(wp + 16 * S);
+        float4 af[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const float4*>(ap[t] + 16 * S);
+#define RS_SK_STEP(E)                                                                              \
+        _Pragma("unroll") for (int t = 0; t < MT; ++t)                                            \
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.E, af[t].E, acc[t], 0, 0, 0);
+        RS_SK_STEP(x) RS_SK_STEP(y) RS_SK_STEP(z) RS_SK_STEP(w)
+#undef RS_SK_STEP
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) *reinterpret_cast<f32x4_t*>(part[wave - 1][t][lane]) = acc[t];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const bool has_bias = p.flags & RS_GEMM_BIAS, relu = p.flags & RS_GEMM_RELU, silu = p.flags & RS_GEMM_SILU, gelu = p.flags & RS_GEMM_GELU;
+    const bool res = p.flags & RS_GEMM_RESIDUAL;
+    const int n = n0 + 4 * kq;
+    if (n >= p.N) return;
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_bias) bb = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = 16 * t + li;
+        if (m >= p.M) continue;
+        f32x4_t a = acc[t];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const f32x4_t q = *reinterpret_cast<const f32x4_t*>(part[w][t][lane]);
+            a[0] += q[0]; a[1] += q[1]; a[2] += q[2]; a[3] += q[3];
+        }
+        float4 v = make_float4(a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (silu) { v.x = silu_exact(v.x); v.y = silu_exact(v.y); v.z = silu_exact(v.z); v.w = silu_exact(v.w); }
+        if (gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+        if (res) {
+            const float4 r = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldc + n);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldc + n) = v;
+    }
+}
+
 // Rel-pos attention in float32 (oracle/model.py: attention_core).  One wave per query row; a lane holds elements
 // lane, lane + 64, .. of the head dimension.  Two passes over the visible keys (maximum, then exp / sum / PV), the
 // scores are recomputed in the second pass.
@@ -593,6 +667,25 @@ int rs_launch_glu_dwconv_f32(rs_ctx* ctx, const float* x, const float* w, const 
     hipLaunchKernelGGL(glu_dwconv_silu_f32_kernel, grid, block, 0, s, x, w, b, lens, T, d, k, out);
     rs_prof_end(ctx, RS_PROF_ELEMENTWISE, s);
     RS_CHECK_LAUNCH(ctx, "glu_dwconv_silu_f32");
+    return RS_OK;
+}
+
+int rs_launch_gemm_f32_skinny(rs_ctx* ctx, const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K, int flags,
+                              const float* bias, const float* residual, hipStream_t s) {
+    if (M <= 0 || N <= 0) return RS_OK;
+    if (M > 128 || K <= 0 || K % 16 || N % 4 || (lda % 4) || (ldw % 4) || (ldc % 4))
+        return rs_fail(ctx, RS_EINVAL, "gemm_f32 (skinny): M <= 128, K %% 16, N %% 4 and 16-byte row pitches required (M %d N %d K %d)", M, N, K);
+    if (flags & ~(RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_SILU | RS_GEMM_GELU | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32))
+        return rs_fail(ctx, RS_EINVAL, "gemm_f32 (skinny): unsupported flags %d", flags);
+    GemmF32 p{A, W, out, bias, residual, nullptr, lda, ldw, ldc, M, N, K, flags, 1.0f, 0, 0};
+    const dim3 grid((N + 15) / 16), block(256);
+    rs_prof_begin(ctx, RS_PROF_GEMM, s, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    if (M <= 16) hipLaunchKernelGGL((gemm_f32_skinny_kernel<1>), grid, block, 0, s, p);
+    else if (M <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<2>), grid, block, 0, s, p);
+    else if (M <= 64) hipLaunchKernelGGL((gemm_f32_skinny_kernel<4>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<8>), grid, block, 0, s, p);
+    rs_prof_end(ctx, RS_PROF_GEMM, s);
+    RS_CHECK_LAUNCH(ctx, "gemm_f32_skinny");
     return RS_OK;
 }
 

@@ -410,6 +410,16 @@ __global__ __launch_bounds__(256) void k2_output_kernel(K2Pieces pc, const int32
 // (lane & 15) against keys 4 * (lane >> 4) .. + 3.  Two passes over the keys (maximum and sum, then the normalised weights):
 // the scores are recomputed instead of kept, so any T fits.  The position rows the block can touch (rel in [-(i0 + 63), len - 1 - i0])
 // sit in LDS as float4.
+// one score: the q.k product of the MFMA plus the 4-wide position term as ONE explicit fma chain (both attention-weight kernels call
+// this, so the compiler cannot contract the two differently: their weights are bit-identical)
+__device__ __forceinline__ float k2_score(float qk, const float4& pq, const float4& pr) {
+    float t = pq.x * pr.x;
+    t = fmaf(pq.y, pr.y, t);
+    t = fmaf(pq.z, pr.z, t);
+    t = fmaf(pq.w, pr.w, t);
+    return qk + t;
+}
+
 __global__ __launch_bounds__(256) void k2_attn_weights_kernel(const uint16_t* __restrict__ qkp, int ld, const float* __restrict__ pos, int cap, int H,
                                                               const int32_t* __restrict__ lens, int T, int Tp, uint16_t* __restrict__ W) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(256) void k2_attn_weights_kernel(const uint16_t* __
             int r = j - qi + i0 + 63;
             r = r < 0 ? 0 : (r >= nrel ? nrel - 1 : r);
             const float4 pr = ps[r];
-            const float v = acc[e] + (pq.x * pr.x + pq.y * pr.y + pq.z * pr.z + pq.w * pr.w);
+            const float v = k2_score(acc[e], pq, pr);
             s[e] = j < len ? v : -INFINITY;
         }
     };
@@ -498,8 +508,8 @@ __global__ __launch_bounds__(256) void k2_attn_weights_kernel(const uint16_t* __
 // in registers — NT tiles of four scores per lane, T <= 16 NT — so the q.k MFMA, the position-table reads and the 16 position
 // multiply-adds of a tile run once instead of three times.  Same score arithmetic, same order of the maximum, of the sum (tiles
 // ascending, then the lane's four scores, then the two shuffles) and of the normalisation as the three-sweep kernel above:
-// BIT-IDENTICAL weights (tests/test_gpu_k2.py batch-invariance and oracle tests run on this kernel; $RS_K2_ATTW_SWEEPS=3 selects the
-// old one).  Instantiated for NT = 10 / 20 / 40 (T <= 160 / 320 / 640: every stack of a 12.8 s utterance); longer inputs take the
+// BIT-IDENTICAL weights (both kernels take a score from k2_score; scripts/k2_attw_bits.py compares the two forms' encoder output;
+// $RS_K2_ATTW_SWEEPS=3 selects the old one).  Instantiated for NT = 10 / 20 / 40 (T <= 160 / 320 / 640: every stack of a 12.8 s utterance); longer inputs take the
 // three-sweep kernel, which has no length limit.
 template <int NT>
 __global__ __launch_bounds__(256) void k2_attn_weights1_kernel(const uint16_t* __restrict__ qkp, int ld, const float* __restrict__ pos, int cap, int H,
@@ -553,7 +563,7 @@ __global__ __launch_bounds__(256) void k2_attn_weights1_kernel(const uint16_t* _
                 int r = j - qi + i0 + 63;
                 r = r < 0 ? 0 : (r >= nrel ? nrel - 1 : r);
                 const float4 pr = ps[r];
-                const float v = acc[e] + (pq.x * pr.x + pq.y * pr.y + pq.z * pr.z + pq.w * pr.w);
+                const float v = k2_score(acc[e], pq, pr);
                 s[jt][e] = j < len ? v : -INFINITY;
             }
             mx = fmaxf(mx, fmaxf(fmaxf(s[jt][0], s[jt][1]), fmaxf(s[jt][2], s[jt][3])));

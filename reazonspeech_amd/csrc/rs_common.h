@@ -237,6 +237,9 @@ int rs_launch_sub_dw(rs_ctx* ctx, const uint16_t* in, const float* w, const floa
 int rs_launch_gemm_f32(rs_ctx* ctx, const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K,
                        int flags, const float* bias, float alpha, const float* residual, const int32_t* mask_lens,
                        int mask_rows_per_step, int mask_steps, hipStream_t s);
+// the same product for M <= 128 rows (a decoder step's hypothesis rows): N / 16 workgroups, K cut over the four waves (k_f32.hip)
+int rs_launch_gemm_f32_skinny(rs_ctx* ctx, const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K, int flags,
+                              const float* bias, const float* residual, hipStream_t s);
 int rs_launch_attention_f32(rs_ctx* ctx, const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
                             const int32_t* lens, int B, int T, float* out, hipStream_t s);
 int rs_launch_glu_dwconv_f32(rs_ctx* ctx, const float* x, const float* w, const float* b, const int32_t* lens, int B, int T,

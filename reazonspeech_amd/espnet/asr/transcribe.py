@@ -21,7 +21,7 @@ PADDING = (16000, 8000)
 CHECKPOINT_ENV = "REAZONSPEECH_ESPNET_CHECKPOINT"
 
 
-def load_model(device=None, checkpoint=None, config=None, seed=0, beam_size=None, max_pops=0, precision="bf16"):
+def load_model(device=None, checkpoint=None, config=None, seed=0, beam_size=None, max_pops=0, precision="bf16", synthetic=False):
     """Load the ReazonSpeech ESPnet model onto a ROCm GPU (transcribe.py:12-32).
 
     Args:
@@ -41,8 +41,9 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, beam_size=None
         arithmetic end to end — what ESPnet computes on the reference's path; include/rs_asr.h "precision_f32").
 
     The reference downloads `reazon-research/reazonspeech-espnet-v2` through espnet_model_zoo (:27-31), which an offline box
-    cannot do; without a checkpoint this loads SEEDED SYNTHETIC weights of the architecture (timings are valid, transcripts
-    are meaningless) and says so."""
+    cannot do: give `checkpoint=` / the environment variable.  Without a checkpoint this RAISES; seeded synthetic weights of
+    the architecture (timings valid, transcripts meaningless) are loaded only on request — `config=`, `synthetic=True` or
+    $REAZONSPEECH_AMD_SYNTHETIC=1 — and a warning says so."""
     from ...runtime.config import ESPNET_CONFORMER_120M
     from ...runtime.weights_espnet import synthetic_state_dict_espnet
     from .model import EspnetModel, synthetic_token_list
@@ -61,9 +62,12 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, beam_size=None
                            precision=precision)
     cfg = config or ESPNET_CONFORMER_120M
     if config is None:
-        print(f"[reazonspeech_amd] WARNING: no ESPnet2 checkpoint given (argument `checkpoint` or ${CHECKPOINT_ENV}: a model "
-              "directory / model-zoo .zip of reazon-research/reazonspeech-espnet-v2) — loading SEEDED SYNTHETIC weights of the 120M "
-              "Conformer-Transducer architecture: timings are valid, transcripts are meaningless.", file=sys.stderr, flush=True)
+        if not (synthetic or os.environ.get("REAZONSPEECH_AMD_SYNTHETIC", "0") not in ("", "0")):
+            raise FileNotFoundError(f"no ESPnet2 checkpoint: give `checkpoint=` or ${CHECKPOINT_ENV} (a model directory / model-zoo .zip of "
+                                    "reazon-research/reazonspeech-espnet-v2; the reference downloads it through espnet_model_zoo, :27-31).  Seeded "
+                                    "synthetic weights are loaded only on request: config=..., synthetic=True or $REAZONSPEECH_AMD_SYNTHETIC=1.")
+        print("[reazonspeech_amd] WARNING: SEEDED SYNTHETIC weights of the 120M Conformer-Transducer architecture were requested "
+              "(`synthetic=True` / $REAZONSPEECH_AMD_SYNTHETIC): timings are valid, transcripts are meaningless.", file=sys.stderr, flush=True)
     return EspnetModel(cfg, synthetic_state_dict_espnet(cfg, seed), synthetic_token_list(cfg.vocab_size, seed), device=device,
                        beam_size=1 if beam_size is None else beam_size, max_pops=max_pops, precision=precision)
 

@@ -54,8 +54,11 @@ def resolve_checkpoint(checkpoint=None, allow_download=True):
     return None
 
 
+SYNTHETIC_ENV = "REAZONSPEECH_AMD_SYNTHETIC"
+
+
 def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, decoding=None, beam_size=None,
-               precision="bf16"):
+               precision="bf16", synthetic=False):
     """Load the ReazonSpeech FastConformer-RNNT model onto a ROCm GPU.
 
     Args:
@@ -63,11 +66,12 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
         available, like the reference (transcribe.py:18-22); there is no CPU execution path
         in this package, so "cpu" raises.
       checkpoint (str): path of a `.nemo` archive.  Defaults to $REAZONSPEECH_NEMO_CHECKPOINT, then to the Hugging Face
-        cache / hub copy of 'reazon-research/reazonspeech-nemo-v2' (`resolve_checkpoint`).  Without any, seeded
-        synthetic weights of the 619M architecture are generated and a warning says so (benchmarks / tests;
-        transcripts are then meaningless).
-      config (ModelConfig): architecture for synthetic weights (no checkpoint lookup is made when it is given).
-      seed (int): seed of the synthetic weights.
+        cache / hub copy of 'reazon-research/reazonspeech-nemo-v2' (`resolve_checkpoint`).  When none can be found or
+        downloaded this RAISES, as `from_pretrained` does in the reference (transcribe.py:26-28) — a transient hub error
+        must not produce a model with made-up weights.
+      config (ModelConfig), seed (int), synthetic (bool): SEEDED SYNTHETIC weights are loaded only on request — `config=`
+        (an architecture; no checkpoint lookup is made), `synthetic=True` or $REAZONSPEECH_AMD_SYNTHETIC=1 (benchmarks /
+        tests: timings are valid, transcripts meaningless), and a warning says so.
       decoding (str): override the checkpoint's decoding strategy: "greedy_batch", "alsd" (alignment-length
         synchronous beam search, what the reference checkpoint ships with: decode.py:29,38-41) or "beam" ([UPSTREAM] NeMo's
         `strategy: beam`, the default Graves beam search — the one ESPnet runs, csrc/k_rnnt_beam.hip).
@@ -97,17 +101,20 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
             print(f"[reazonspeech_amd] WARNING: ${CHECKPOINT_ENV} is set but ignored because an explicit `config` was passed "
                   f"(synthetic weights of that architecture are generated); pass `checkpoint=` to load the archive.", file=sys.stderr, flush=True)
     resolve_checkpoint.last_error = None
-    checkpoint = None if config is not None and checkpoint is None else resolve_checkpoint(checkpoint)
+    want_synthetic = config is not None or synthetic or os.environ.get(SYNTHETIC_ENV, "0") not in ("", "0")
+    checkpoint = None if want_synthetic and checkpoint is None else resolve_checkpoint(checkpoint)
+    if not checkpoint and not want_synthetic:
+        raise FileNotFoundError(
+            f"no checkpoint: neither the `checkpoint` argument, ${CHECKPOINT_ENV}, nor a cached / downloadable copy of '{HF_REPO}' was found"
+            + (f" (last lookup failure — {resolve_checkpoint.last_error})" if getattr(resolve_checkpoint, "last_error", None) else "")
+            + f".  Seeded synthetic weights are loaded only on request: config=..., synthetic=True or ${SYNTHETIC_ENV}=1.")
     if checkpoint:
         cfg, sd, tok_bytes = W.read_nemo(checkpoint)
         tokenizer = SentencePieceTokenizer(tok_bytes) if tok_bytes else SyntheticTokenizer(cfg.vocab_size)
     else:
         if config is None:
-            print(f"[reazonspeech_amd] WARNING: no checkpoint — neither ${CHECKPOINT_ENV} nor a cached / downloadable copy "
-                  f"of '{HF_REPO}' was found.  Loading SEEDED SYNTHETIC weights of the 619M architecture: timings are "
-                  f"valid, transcripts are meaningless."
-                  + (f"  (last lookup failure — {resolve_checkpoint.last_error})" if getattr(resolve_checkpoint, "last_error", None) else ""),
-                  file=sys.stderr, flush=True)
+            print("[reazonspeech_amd] WARNING: SEEDED SYNTHETIC weights of the 619M architecture were requested "
+                  f"(`synthetic=True` / ${SYNTHETIC_ENV}): timings are valid, transcripts are meaningless.", file=sys.stderr, flush=True)
         cfg = config or FASTCONFORMER_619M
         sd = W.synthetic_state_dict(cfg, seed)
         tokenizer = SyntheticTokenizer(cfg.vocab_size, seed)

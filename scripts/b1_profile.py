@@ -17,7 +17,7 @@ from reazonspeech_amd.nemo.asr import load_model   # noqa: E402
 def main():
     warnings.simplefilter("ignore")
     dec = ([a.split("=")[1] for a in sys.argv[1:] if a.startswith("--decoding=")] or [None])[0]
-    model = load_model("cuda:0", decoding=dec)
+    model = load_model("cuda:0", decoding=dec, synthetic=True)
     rng = np.random.default_rng(0)
     secs = ([float(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--seconds=")] or [10.0])[0]
     wave = (0.1 * rng.standard_normal(int(secs * 16000))).astype(np.float32)

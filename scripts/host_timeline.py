@@ -19,7 +19,7 @@ def main():
     reps = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--reps=")] or [3])[0]
     import warnings
     warnings.simplefilter("ignore")
-    model = load_model("cuda:0")
+    model = load_model("cuda:0", synthetic=True)
     rng = np.random.default_rng(0)
     if "--ragged" in sys.argv:          # SURVEY 8(d)'s ragged set: lengths U(2 s, 10 s), seed 1235
         from reazonspeech_amd.runtime.synth import synthetic_batch

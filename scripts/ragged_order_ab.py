@@ -11,7 +11,7 @@ from reazonspeech_amd.runtime.model import AsrModel         # noqa: E402
 from reazonspeech_amd.runtime.synth import synthetic_batch  # noqa: E402
 
 warnings.simplefilter("ignore")
-model = load_model("cuda:0")
+model = load_model("cuda:0", synthetic=True)
 audio, lens = synthetic_batch(1024, 10.0, seed=1235, ragged=True, min_seconds=2.0)
 waves = [audio[i, :lens[i]] for i in range(1024)]
 secs = float(lens.sum()) / 16000.0

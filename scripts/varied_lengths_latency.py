@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reazonspeech_amd.nemo.asr import load_model   # noqa: E402
 
 warnings.simplefilter("ignore")
-model = load_model("cuda:0")
+model = load_model("cuda:0", synthetic=True)
 rng = np.random.default_rng(0)
 secs = [5.0, 12.3, 3.1, 25.0, 8.8, 17.5, 2.2, 29.0, 6.4, 21.0, 4.0, 14.2]
 waves = [(0.1 * rng.standard_normal(int(s * 16000))).astype(np.float32) for s in secs]
