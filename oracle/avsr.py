@@ -96,8 +96,17 @@ def encode(cfg, sd, input_values, pixel_values, padding_mask, taps=None):
     input_values [B][T][104], pixel_values [B][T][1][H][W], padding_mask [B][T] (1 = padding) -> [B][T][d]"""
     A, E = "avhubert.", "avhubert.encoder."
     eps = cfg.layer_norm_eps
-    fa = F.linear(input_values, sd[A + "feature_extractor_audio.proj.weight"], sd[A + "feature_extractor_audio.proj.bias"])     # :40-47
-    fv = video_frontend(cfg, sd, pixel_values)
+    if input_values is None and pixel_values is None:
+        raise ValueError("Either `input_values` or `pixel_values` must be passed")                                               # :181
+    fa = fv = None
+    if input_values is not None:
+        fa = F.linear(input_values, sd[A + "feature_extractor_audio.proj.weight"], sd[A + "feature_extractor_audio.proj.bias"]) # :40-47
+    if pixel_values is not None:
+        fv = video_frontend(cfg, sd, pixel_values)
+    if fa is None:
+        fa = torch.zeros_like(fv)                                                                                              # :172-177: a missing modality = zero FEATURES
+    if fv is None:
+        fv = torch.zeros_like(fa)
     feats = torch.cat([fa, fv], dim=2) if cfg.modality_fuse == "concat" else fa + fv                                          # :183-187
     feats = F.layer_norm(feats, (feats.shape[-1],), sd[A + "layer_norm.weight"], sd[A + "layer_norm.bias"], 1e-5)              # :190 (nn.LayerNorm default eps)
     keep = ~padding_mask.bool()                                                                                                # :192-195 (T frames, one mask entry each)

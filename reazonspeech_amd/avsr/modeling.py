@@ -51,12 +51,8 @@ class AVHubertModel:
     def forward(self, input_values=None, pixel_values=None, padding_mask=None, **kwargs):
         if input_values is None and pixel_values is None:
             raise ValueError("Either `input_values` or `pixel_values` must be passed")            # modeling_avhubert.py:181
-        cfg = self.config
-        if input_values is None:            # :172-177 a missing modality contributes zero FEATURES (after its projection); here: not built
-            raise NotImplementedError("video-only input: the reference substitutes zero audio features after the projection; not built")
-        if pixel_values is None:
-            raise NotImplementedError("audio-only input: the reference substitutes zero video features after the projection; not built")
-        B, T = input_values.shape[:2]
+        # :172-177 a missing modality contributes zero FEATURES in its half of the fused vector (rs_avsr_encoder_forward takes NULL for it)
+        B, T = (input_values if input_values is not None else pixel_values).shape[:2]
         if padding_mask is None:
             padding_mask = np.zeros((B, T), np.float32)
         return AVHubertOutput(last_hidden_state=self.dev.encode(input_values, pixel_values, padding_mask))

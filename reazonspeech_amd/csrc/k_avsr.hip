@@ -621,7 +621,8 @@ extern "C" int rs_avsr_encoder_forward(rs_ctx* ctx, const float* input_values, c
     if (!ctx || !ctx->avsr) return RS_EINVAL;
     if (!ctx->finalized) return rs_fail(ctx, RS_ESTATE, "rs_finalize must precede rs_avsr_encoder_forward");
     if (B <= 0 || T <= 0) return B < 0 || T < 0 ? rs_fail(ctx, RS_EINVAL, "avsr encoder: negative size") : RS_OK;
-    if (!input_values || !pixel_values || !padding_mask || !enc_out || !workspace) return rs_fail(ctx, RS_EINVAL, "avsr encoder: null pointer");
+    if ((!input_values && !pixel_values) || !padding_mask || !enc_out || !workspace)
+        return rs_fail(ctx, RS_EINVAL, "avsr encoder: null pointer (one of input_values / pixel_values may be NULL: that modality's FEATURES are zeros, modeling_avhubert.py:172-177)");
     rs_avsr& k = *ctx->avsr;
     const rs_avsr_dims& d = k.d;
     hipStream_t s = (hipStream_t)stream;
@@ -642,55 +643,61 @@ extern "C" int rs_avsr_encoder_forward(rs_ctx* ctx, const float* input_values, c
         return rs_launch_gemm_f32(ctx, A, lda, W, K, out, ldc, (int)rows, Nc, K, flags, bias, 1.0f, res, nullptr, 0, 0, s);
     };
     auto blocks1d = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
-    // ---- video: Conv3d + BN + PReLU, max-pool, ResNet-18 trunk, average pool, projection
-    rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 2.0 * N * pl.H1 * pl.H1 * 64 * 245.0, 0.0);
-    hipLaunchKernelGGL(avsr_conv3d_kernel, dim3(pl.H1, T, B), dim3(256), 0, s, pixel_values, T, H, H, k.conv3d_w, k.bn0_a, k.bn0_b, k.prelu0, a0);
-    {
-        const size_t total = N * pl.H2 * pl.H2 * 64;
-        hipLaunchKernelGGL(avsr_maxpool_kernel, blocks1d(total), dim3(256), 0, s, a0, pl.H1, pl.H1, 64, pl.H2, pl.H2, total, x);
-    }
-    rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
-    RS_CHECK_LAUNCH(ctx, "avsr video front-end");
-    int hw = pl.H2;
-    float *cur = x, *o1 = y, *o2 = z;
-    for (int L = 1; L <= 4; ++L)
-        for (int b = 0; b < 2; ++b) {
-            const rs_avsr_block& Bk = k.blocks[L - 1][b];
-            const int cin = b == 0 ? TRUNK_C[L - 1] : TRUNK_C[L], c = TRUNK_C[L];
-            const int stride = (b == 0 && L > 1) ? 2 : 1;
-            const int ohw = stride == 2 ? (hw - 1) / 2 + 1 : hw;            // 3 x 3, padding 1
-            const size_t rows_out = N * ohw * ohw;
-            // conv1 -> bn1 -> relu1
-            hipLaunchKernelGGL(avsr_im2col3_kernel, blocks1d(rows_out * 9 * cin / 4), dim3(256), 0, s, cur, hw, hw, cin, ohw, ohw, stride, rows_out * 9 * cin / 4, col);
-            RS_TRY(gemm(col, 9 * cin, Bk.conv1_w, 9 * cin, o1, c, (long long)rows_out, c, 0, nullptr, nullptr));
-            hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o1, Bk.bn1_a, Bk.bn1_b, (const float*)nullptr, Bk.relu1, c, rows_out * c / 4);
-            // conv2 -> bn2 -> (+ residual) -> relu2
-            hipLaunchKernelGGL(avsr_im2col3_kernel, blocks1d(rows_out * 9 * c / 4), dim3(256), 0, s, o1, ohw, ohw, c, ohw, ohw, 1, rows_out * 9 * c / 4, col);
-            RS_TRY(gemm(col, 9 * c, Bk.conv2_w, 9 * c, o2, c, (long long)rows_out, c, 0, nullptr, nullptr));
-            const float* res = cur;
-            if (Bk.ds_w) {                                                   // 1 x 1 convolution with the block's stride + BatchNorm on the block input
-                const float* src = cur;
-                if (stride == 2) {
-                    hipLaunchKernelGGL(avsr_stride2_kernel, blocks1d(rows_out * cin / 4), dim3(256), 0, s, cur, hw, hw, cin, ohw, ohw, rows_out * cin / 4, a1);
-                    src = a1;
-                }
-                RS_TRY(gemm(src, cin, Bk.ds_w, cin, o1, c, (long long)rows_out, c, 0, nullptr, nullptr));       // (o1 is free again: conv2's patches were taken)
-                hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o1, Bk.ds_a, Bk.ds_b, (const float*)nullptr, (const float*)nullptr, c,
-                                   rows_out * c / 4);
-                res = o1;
-            }
-            hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o2, Bk.bn2_a, Bk.bn2_b, res, Bk.relu2, c, rows_out * c / 4);
-            RS_CHECK_LAUNCH(ctx, "avsr ResNet block");
-            float* nxt = o2;                      // rotate: the block's output becomes the input, the old input and o1 are scratch
-            o2 = cur; cur = nxt;
-            hw = ohw;
+    if (pixel_values) {
+        // ---- video: Conv3d + BN + PReLU, max-pool, ResNet-18 trunk, average pool, projection
+        rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 2.0 * N * pl.H1 * pl.H1 * 64 * 245.0, 0.0);
+        hipLaunchKernelGGL(avsr_conv3d_kernel, dim3(pl.H1, T, B), dim3(256), 0, s, pixel_values, T, H, H, k.conv3d_w, k.bn0_a, k.bn0_b, k.prelu0, a0);
+        {
+            const size_t total = N * pl.H2 * pl.H2 * 64;
+            hipLaunchKernelGGL(avsr_maxpool_kernel, blocks1d(total), dim3(256), 0, s, a0, pl.H1, pl.H1, 64, pl.H2, pl.H2, total, x);
         }
-    hipLaunchKernelGGL(avsr_avgpool_kernel, blocks1d(N * 512), dim3(256), 0, s, cur, hw * hw, 512, N * 512, pool);
-    // audio and video projections straight into the two halves of the fused rows [M][2 d]
+        rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
+        RS_CHECK_LAUNCH(ctx, "avsr video front-end");
+        int hw = pl.H2;
+        float *cur = x, *o1 = y, *o2 = z;
+        for (int L = 1; L <= 4; ++L)
+            for (int b = 0; b < 2; ++b) {
+                const rs_avsr_block& Bk = k.blocks[L - 1][b];
+                const int cin = b == 0 ? TRUNK_C[L - 1] : TRUNK_C[L], c = TRUNK_C[L];
+                const int stride = (b == 0 && L > 1) ? 2 : 1;
+                const int ohw = stride == 2 ? (hw - 1) / 2 + 1 : hw;            // 3 x 3, padding 1
+                const size_t rows_out = N * ohw * ohw;
+                // conv1 -> bn1 -> relu1
+                hipLaunchKernelGGL(avsr_im2col3_kernel, blocks1d(rows_out * 9 * cin / 4), dim3(256), 0, s, cur, hw, hw, cin, ohw, ohw, stride, rows_out * 9 * cin / 4, col);
+                RS_TRY(gemm(col, 9 * cin, Bk.conv1_w, 9 * cin, o1, c, (long long)rows_out, c, 0, nullptr, nullptr));
+                hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o1, Bk.bn1_a, Bk.bn1_b, (const float*)nullptr, Bk.relu1, c, rows_out * c / 4);
+                // conv2 -> bn2 -> (+ residual) -> relu2
+                hipLaunchKernelGGL(avsr_im2col3_kernel, blocks1d(rows_out * 9 * c / 4), dim3(256), 0, s, o1, ohw, ohw, c, ohw, ohw, 1, rows_out * 9 * c / 4, col);
+                RS_TRY(gemm(col, 9 * c, Bk.conv2_w, 9 * c, o2, c, (long long)rows_out, c, 0, nullptr, nullptr));
+                const float* res = cur;
+                if (Bk.ds_w) {                                                   // 1 x 1 convolution with the block's stride + BatchNorm on the block input
+                    const float* src = cur;
+                    if (stride == 2) {
+                        hipLaunchKernelGGL(avsr_stride2_kernel, blocks1d(rows_out * cin / 4), dim3(256), 0, s, cur, hw, hw, cin, ohw, ohw, rows_out * cin / 4, a1);
+                        src = a1;
+                    }
+                    RS_TRY(gemm(src, cin, Bk.ds_w, cin, o1, c, (long long)rows_out, c, 0, nullptr, nullptr));       // (o1 is free again: conv2's patches were taken)
+                    hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o1, Bk.ds_a, Bk.ds_b, (const float*)nullptr, (const float*)nullptr, c,
+                                       rows_out * c / 4);
+                    res = o1;
+                }
+                hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o2, Bk.bn2_a, Bk.bn2_b, res, Bk.relu2, c, rows_out * c / 4);
+                RS_CHECK_LAUNCH(ctx, "avsr ResNet block");
+                float* nxt = o2;                      // rotate: the block's output becomes the input, the old input and o1 are scratch
+                o2 = cur; cur = nxt;
+                hw = ohw;
+            }
+        hipLaunchKernelGGL(avsr_avgpool_kernel, blocks1d(N * 512), dim3(256), 0, s, cur, hw * hw, 512, N * 512, pool);
+    }
+    // audio and video projections straight into the two halves of the fused rows [M][2 d]; a missing modality contributes ZERO
+    // features (after where its projection would be: modeling_avhubert.py:172-177 torch.zeros_like of the other extractor's output)
+    if (!input_values || !pixel_values) RS_HIP(ctx, hipMemsetAsync(fused, 0, N * 2 * dm * 4, s));
     const int Ka = pad32(d.audio_feat_dim);
-    hipLaunchKernelGGL(avsr_padcols_kernel, blocks1d(N * Ka), dim3(256), 0, s, input_values, d.audio_feat_dim, Ka, N * Ka, apad);
-    RS_TRY(gemm(apad, Ka, k.audio_w, Ka, fused, 2 * dm, M, dm, RS_GEMM_BIAS, k.audio_b, nullptr));
-    RS_TRY(gemm(pool, 512, k.vproj_w, 512, fused + dm, 2 * dm, M, dm, RS_GEMM_BIAS, k.vproj_b, nullptr));
+    if (input_values) {
+        hipLaunchKernelGGL(avsr_padcols_kernel, blocks1d(N * Ka), dim3(256), 0, s, input_values, d.audio_feat_dim, Ka, N * Ka, apad);
+        RS_TRY(gemm(apad, Ka, k.audio_w, Ka, fused, 2 * dm, M, dm, RS_GEMM_BIAS, k.audio_b, nullptr));
+    }
+    if (pixel_values) RS_TRY(gemm(pool, 512, k.vproj_w, 512, fused + dm, 2 * dm, M, dm, RS_GEMM_BIAS, k.vproj_b, nullptr));
     if (k.tap_video) RS_HIP(ctx, hipMemcpy2DAsync(k.tap_video, (size_t)dm * 4, fused + dm, (size_t)2 * dm * 4, (size_t)dm * 4, N, hipMemcpyDeviceToDevice, s));
     // fusion LayerNorm, post_extract_proj, padded frames zeroed, positional convolution, encoder LayerNorm
     hipLaunchKernelGGL(avsr_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, fused, k.fuse_g, k.fuse_b, M, 2 * dm, 1e-5f, fused);

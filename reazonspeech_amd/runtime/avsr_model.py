@@ -42,13 +42,16 @@ class AvsrDevice:
         [B][T][H][W]), padding_mask [B][T] (nonzero / True = padding) -> last_hidden_state float32 [B][T][d] on the device.
         taps: list of encoder layer indices -> also returns {video, fused_ln, enc_ln, layers} (parity tests)."""
         cfg, lib, h = self.cfg, self.ctx.lib, self.ctx._h
-        a = self._dev(input_values)
-        v = self._dev(pixel_values)
-        if v.dim() == 5:
-            v = v[:, :, 0]
+        if input_values is None and pixel_values is None:
+            raise ValueError("Either `input_values` or `pixel_values` must be passed")            # modeling_avhubert.py:181
+        a = self._dev(input_values) if input_values is not None else None
+        v = self._dev(pixel_values) if pixel_values is not None else None
+        if v is not None and v.dim() == 5:
+            v = v[:, :, 0].contiguous()
         m = self._dev(padding_mask)
-        B, T = a.shape[:2]
-        assert a.shape == (B, T, cfg.audio_feat_dim) and v.shape == (B, T, cfg.image_size, cfg.image_size) and m.shape == (B, T)
+        B, T = m.shape
+        assert a is None or a.shape == (B, T, cfg.audio_feat_dim)
+        assert v is None or v.shape == (B, T, cfg.image_size, cfg.image_size)
         d = cfg.encoder_embed_dim
         with torch.cuda.device(self.device):
             need = int(lib.rs_avsr_workspace_bytes(h, B, T))

@@ -16,6 +16,7 @@ Stored per configuration (B clips, T frames, ragged lengths):
   tap_*                               clip 0: video front-end output, audio projection, fused LayerNorm, post_extract_proj,
                                       encoder.layer_norm (after the positional convolution), encoder layers 0 / mid / last
   enc_proj                            enc @ R [d][8] for every clip (R seeded N(0, 1) / sqrt(d))
+  enc_audio_only / enc_video_only     (tiny) last_hidden_state with only one modality passed
   greedy                              generate(num_beams=1, do_sample=False, max_new_tokens=N)  [B][1 + N] (prompt = bos)
   beam / beam_scores                  generate(num_beams=K, ...) sequences and sequences_scores for the first `beam_clips` clips
   logits                              teacher-forced forward(decoder_input_ids = greedy[:, :-1]).logits: clips 0-1 in full, all clips
@@ -83,6 +84,10 @@ def run(name):
     R = projection(cfg.encoder_embed_dim)
     store["enc_proj"] = (enc @ R).numpy()
     store["enc"] = enc.numpy() if name == "tiny" else enc[:1].numpy()
+    if name == "tiny":                       # a missing modality (modeling_avhubert.py:172-177: zero features in its place)
+        with torch.no_grad():
+            store["enc_audio_only"] = av(input_values=kw["input_values"], padding_mask=kw["padding_mask"]).last_hidden_state.numpy()
+            store["enc_video_only"] = av(pixel_values=kw["pixel_values"], padding_mask=kw["padding_mask"]).last_hidden_state.numpy()
     t0 = time.time()
     with torch.no_grad():
         greedy = model.generate(**kw, num_beams=1, do_sample=False, max_new_tokens=new_tokens, use_cache=False)

@@ -87,6 +87,12 @@ def test_tiny_vs_the_reference(gpu_device):
         assert (got - want).abs().max() <= TOL_ENC
         assert np.array_equal(model.generate(input_values=a2, pixel_values=v2, padding_mask=m2, num_beams=4, max_new_tokens=9).numpy(),
                               oa.beam_generate(cfg, sd, want, torch.from_numpy(m2), 4, 9)[0].numpy())
+    # one modality only (the reference puts zero FEATURES in the other's place: modeling_avhubert.py:172-177)
+    for kw, key in ((dict(input_values=a, padding_mask=mask), "enc_audio_only"), (dict(pixel_values=v, padding_mask=mask), "enc_video_only")):
+        got = model.avhubert(**kw).last_hidden_state.cpu()
+        assert (got - torch.from_numpy(g[key])).abs().max() <= TOL_ENC, key
+    with pytest.raises(ValueError):
+        model.avhubert(padding_mask=mask)
     # a clip alone == inside the batch when it is the longest one (no padding differences): bits
     lens = g["lens"]
     b = int(np.argmax(lens))

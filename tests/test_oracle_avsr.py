@@ -44,6 +44,9 @@ def test_oracle_equals_the_reference_golden_tiny():
         R = torch.randn((cfg.encoder_embed_dim, 8), generator=torch.Generator().manual_seed(int(g["proj_seed"]))) / cfg.encoder_embed_dim ** 0.5
         assert ((enc @ R) - torch.from_numpy(g["enc_proj"])).abs().max() <= 2e-4
         m = torch.from_numpy(mask)
+        # one modality only (modeling_avhubert.py:172-177: zero features in the other's place)
+        assert (oa.encode(cfg, sd, torch.from_numpy(a), None, m) - torch.from_numpy(g["enc_audio_only"])).abs().max() <= 2e-4
+        assert (oa.encode(cfg, sd, None, torch.from_numpy(v), m) - torch.from_numpy(g["enc_video_only"])).abs().max() <= 2e-4
         greedy = oa.greedy_generate(cfg, sd, enc, m, int(g["new_tokens"]))
         assert np.array_equal(greedy.numpy(), g["greedy"])
         logits = oa.decode_logits(cfg, sd, enc, m, torch.from_numpy(g["greedy"][:, :-1]).long())
