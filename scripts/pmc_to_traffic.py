@@ -13,7 +13,7 @@ tot_n = tot_b = 0
 busy_t = busy_w = clk_w = 0.0
 per = {}
 for line in open(src):
-    m = re.match(r"(gemm_\w+<[^>]*>)\s+n=(\d+)\s+avg\s+([\d.]+) us\s+clk\s+([\d.]+) GHz\s+mfma_util\s+([\d.]+)%.*hbm_rd\s+([\d.]+) MB wr\s+([\d.]+) MB", line)
+    m = re.match(r"(gemm_\w+<.*?)\s+n=(\d+)\s+avg\s+([\d.]+) us\s+clk\s+([\d.]+) GHz\s+mfma_util\s+([\d.]+)%.*hbm_rd\s+([\d.]+) MB wr\s+([\d.]+) MB", line)
     if not m:
         continue
     name, n, rd, wr = m.group(1), int(m.group(2)), float(m.group(6)) * 1e6, float(m.group(7)) * 1e6

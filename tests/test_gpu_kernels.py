@@ -481,6 +481,48 @@ def test_relpos_attention(gpu_device, T, lens, window, heads):
     c.close()
 
 
+@pytest.mark.parametrize("form", ["streaming", "persistent"])
+@pytest.mark.parametrize("T,lens", [(19, [19, 14]), (138, [138, 97, 5, 0]), (300, [300, 161, 32])])
+@pytest.mark.parametrize("heads", [2, 4])
+def test_relpos_attention_alternative_forms(gpu_device, T, lens, heads, form):
+    """the two forms of full attention that round 6 built and measured SLOWER than the default (csrc/k_attention.hip: the
+    streaming kernel — 16-query waves, K / V through a DMA ring, V^T by ds_read_b64_tr_b16 — and the staged kernel on resident
+    workgroups; profiles/r06_10_*): off by default, kept correct.  streaming: the oracle's tolerance (another summation
+    order); persistent: bit-identical to the default"""
+    cfg = TINY.with_(n_heads=heads)
+    c = capi.Context(cfg, 0)
+    g = torch.Generator().manual_seed(T + len(lens))
+    B, H, dh, d = len(lens), cfg.n_heads, cfg.head_dim, cfg.d_model
+    qkv = rb(torch.randn((B, T, 3 * d), generator=g))
+    p = rb(torch.randn((2 * T - 1, d), generator=g))
+    bu = 0.3 * torch.randn((H, dh), generator=g)
+    bv = 0.3 * torch.randn((H, dh), generator=g)
+    lens_t = torch.tensor(lens, dtype=torch.int64)
+    q, k, v = (qkv[..., i * d:(i + 1) * d].reshape(B, T, H, dh) for i in range(3))
+    ref = om.attention_core(cfg, q, k, v, p.view(2 * T - 1, H, dh), bu, bv, lens_t, "bf16")
+    args = (bf(qkv).reshape(B * T, 3 * d).to(gpu_device), bf(p).to(gpu_device), bu.reshape(-1).to(gpu_device),
+            bv.reshape(-1).to(gpu_device), lens_t.to(torch.int32).to(gpu_device), B, T)
+    base = torch.full((B * T, d), 3.0, dtype=torch.bfloat16, device=gpu_device)
+    c.attention(*args, base)
+    out = torch.full((B * T, d), 3.0, dtype=torch.bfloat16, device=gpu_device)
+    hook = c.lib.rs_debug_set_attn_stream if form == "streaming" else c.lib.rs_debug_set_attn_persist
+    hook(1 if form == "streaming" else 2)             # persistent: two resident workgroups walk all the items
+    try:
+        c.attention(*args, out)
+        sync()
+    finally:
+        hook(0)
+    if form == "persistent":
+        assert torch.equal(out, base)
+    got = out.cpu().float().view(B, T, d)
+    for b in range(B):
+        n = lens[b]
+        if n:
+            assert (got[b, :n] - ref[b, :n]).abs().max().item() <= 2e-2, b
+        assert torch.all(got[b, n:] == 0)
+    c.close()
+
+
 def test_rejects_wrong_head_dim(gpu_device):
     with pytest.raises(capi.RsError):
         capi.Context(TINY.with_(n_heads=8), 0)            # head_dim 32: 128 and 64 are built
