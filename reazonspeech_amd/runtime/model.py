@@ -346,7 +346,7 @@ class AsrModel:
         ctx.encoder(buf.feats, buf.n_frames, buf.B, buf.t_max, None, buf.joint_enc, buf.enc_lens, buf.ws, stream)
 
     def run_pipelined(self, bufs: Sequence[_Buffers], steps: int, after_decode=None, from_host: bool = False,
-                      dec_streams: int = 1, before_encoder=None, fill=None):
+                      dec_streams: int = 1, before_encoder=None, fill=None, enc_streams: Optional[int] = None):
         """Process `steps` batches as a pipeline with up to len(bufs) batches in flight: the throughput-bound front-end +
         encoder of batch i+1 (i+2) runs on one HIP stream while the latency-bound decode of batch i (and i+1) — a
         dependency chain of small launches that leaves most CUs idle — runs on one (two) more streams, each driven by a
@@ -365,8 +365,15 @@ class AsrModel:
         fill            `fill(i, buf) -> buf or a narrowed view of it`: a stager thread calls it for step i as soon as the
                         buffer set's previous use is over, to put batch i into the pinned staging buffers (implies
                         `from_host`) while the GPU works on the batches before it; the encoder of step i waits for it.
-        before_encoder  `before_encoder(i)` on the caller's thread right before batch i's encoder is enqueued."""
+        before_encoder  `before_encoder(i)` on the caller's thread right before batch i's encoder is enqueued.
+        enc_streams     encoder lanes: consecutive batches' front-end + encoder alternate between that many HIP streams (each
+                        batch has its own workspace in its buffer set).  None: `encoder_lanes(B)` — one lane for batches that
+                        fill the chip, two for small ones, whose launches leave a third to half of the CUs idle
+                        (profiles/r06_11_small_batch_enc_lanes_ab.txt); needs dec_streams + enc_streams buffer sets."""
         nb = len(bufs)
+        if enc_streams is None:
+            enc_streams = self.encoder_lanes(bufs[0].B, nb, dec_streams)
+        assert enc_streams >= 1 and (enc_streams == 1 or nb >= dec_streams + enc_streams), "n encoder lanes + m decode lanes need n + m buffer sets"
         assert nb >= 2 or steps <= 1, "the pipeline needs two buffer sets"
         assert dec_streams >= 1 and (dec_streams == 1 or nb >= dec_streams + 1), "n decode streams need n + 1 buffer sets"
         from_host = from_host or fill is not None
@@ -380,7 +387,9 @@ class AsrModel:
                 self._streams = (enc,)
                 self._streams_prio = dec_prio
                 self._dec_lanes = [(c, None) for c, _ in self._dec_lanes]       # keep the contexts, remake the streams
-            enc_stream = self._streams[0]
+            while len(self._streams) < enc_streams:
+                self._streams = self._streams + (torch.cuda.Stream(device=self.device),)
+            enc_lanes = self._streams[:enc_streams]
             dec_cus = int(os.environ.get("RS_DECODE_CUS", "0"))
             while len(self._dec_lanes) < dec_streams:
                 self._dec_lanes.append((self.ctx.clone(), None))
@@ -397,7 +406,8 @@ class AsrModel:
                     self._dec_lanes[k] = (ctx_d, st)
                 self._decode_policy(ctx_d, bufs[0].B, pipelined=True, lanes=dec_streams)
                 dec_lanes.append((ctx_d, st))
-            enc_stream.wait_stream(torch.cuda.current_stream())
+            for es in enc_lanes:
+                es.wait_stream(torch.cuda.current_stream())
             queues = [queue.Queue() for _ in dec_lanes]
             done = [threading.Event() for _ in range(steps)]
             hooked = [threading.Event() for _ in range(steps)]
@@ -470,6 +480,7 @@ class AsrModel:
                     buf.step = i
                     if before_encoder is not None:
                         before_encoder(i)
+                    enc_stream = enc_lanes[i % len(enc_lanes)]
                     if from_host:
                         with torch.cuda.stream(enc_stream):          # only the columns this batch's geometry reads
                             w = buf.l_max
@@ -485,11 +496,18 @@ class AsrModel:
                     q.put(None)
                 for th in threads:
                     th.join()
-            torch.cuda.current_stream().wait_stream(enc_stream)
+            for es in enc_lanes:
+                torch.cuda.current_stream().wait_stream(es)
             for _, ds in dec_lanes:
                 torch.cuda.current_stream().wait_stream(ds)
             if errors:
                 raise errors[0]
+
+    def encoder_lanes(self, B: int, n_sets: int, dec_streams: int) -> int:
+        """encoder lanes `run_pipelined` uses for batches of B utterances when the caller does not say ($RS_ENC_STREAMS overrides)"""
+        e = os.environ.get("RS_ENC_STREAMS")
+        want = int(e) if e else 1
+        return max(1, min(want, n_sets - dec_streams))
 
     def new_buffers(self, B, l_max) -> _Buffers:
         """an un-cached buffer set (the pipelined path keeps two batches in flight)"""

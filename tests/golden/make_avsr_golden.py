@@ -2,7 +2,7 @@
 AVHubertForConditionalGeneration: forward :256-314, generate through transformers' GenerationMixin) on this repo's seeded
 synthetic weights and inputs.  Run in the BUILD container (CPU; the reference tree must be at /root/reference):
 
-    python tests/golden/make_avsr_golden.py [tiny] [base]
+    python tests/golden/make_avsr_golden.py [tiny] [base] [config]
 
 This is the one model family whose checker is the reference's own code: the modules are imported unchanged (oracle/_ref_avsr.py)
 under this container's torch / transformers, `load_state_dict(strict=True)` takes runtime/avsr_weights.py's synthetic state dict
@@ -110,6 +110,19 @@ def run(name):
     print("wrote", path, os.path.getsize(path), "bytes", flush=True)
 
 
+def write_configs():
+    """tests/golden/avsr_ref_config_{tiny,base}.json: `config.json` exactly as the reference's AVHubertConfig serialises itself
+    (PretrainedConfig.to_json_string of the model built for the goldens) — what runtime/avsr_weights.read_avsr has to parse"""
+    for name, (cfg, wseed, *_rest) in RECIPES.items():
+        model = ra.build(cfg, synthetic_state_dict_avsr(cfg, wseed))
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"avsr_ref_config_{name}.json")
+        with open(path, "w", encoding="utf-8") as fp:
+            fp.write(model.config.to_json_string())
+        print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+
+
 if __name__ == "__main__":
-    for name in ([a for a in sys.argv[1:] if a in RECIPES] or list(RECIPES)):
+    if "config" in sys.argv[1:]:
+        write_configs()
+    for name in ([a for a in sys.argv[1:] if a in RECIPES] or ([] if "config" in sys.argv[1:] else list(RECIPES))):
         run(name)

@@ -108,3 +108,38 @@ def test_base_161m_vs_the_reference(gpu_device):
     os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
     import json
     json.dump(stats, open(os.path.join(os.path.dirname(HERE), "gpurun_out", "avsr_parity.json"), "w"), indent=1, sort_keys=True)
+
+
+def test_the_readme_flow_from_a_pretrained_directory(gpu_device, tmp_path):
+    """pkg/avsr/README.rst end to end: AVHubertProcessor.from_pretrained(dir) / AVHubertForConditionalGeneration.from_pretrained(dir),
+    inputs = processor(raw_audio=, raw_video=), outputs = model.generate(**inputs, num_beams=5, max_new_tokens=...),
+    processor.decode(outputs[0], skip_special_tokens=True).  The directory holds config.json AS THE REFERENCE WRITES IT
+    (tests/golden/avsr_ref_config_tiny.json), model.safetensors under the reference's parameter names, preprocessor_config.json and a
+    PreTrainedTokenizerFast; the result equals the model built from (config, state dict) directly."""
+    from safetensors.torch import save_file
+    from test_avsr_host import make_processor_dir
+    from reazonspeech_amd.avsr import AVHubertProcessor
+    cfg = AVSR_TINY
+    sd = synthetic_state_dict_avsr(cfg, 0)
+    with open(os.path.join(HERE, "golden", "avsr_ref_config_tiny.json"), encoding="utf-8") as fp:
+        (tmp_path / "config.json").write_text(fp.read(), encoding="utf-8")
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / "model.safetensors"))
+    make_processor_dir(str(tmp_path), vocab_size=cfg.vocab_size)
+    processor = AVHubertProcessor.from_pretrained(str(tmp_path))
+    model = AVHubertForConditionalGeneration.from_pretrained(str(tmp_path), device=str(gpu_device))
+    assert model.config == cfg
+    rng = np.random.default_rng(5)
+    clips = [((0.1 * rng.standard_normal(n)).astype(np.float32), rng.integers(0, 256, (n // 640, 96, 96), dtype=np.uint8)) for n in (16000, 9600)]
+    inputs = processor(raw_audio=[a for a, _ in clips], raw_video=[v for _, v in clips])
+    assert inputs["input_values"].shape == (2, 25, 104) and inputs["padding_mask"][1, 15:].all() and not inputs["padding_mask"][1, :15].any()
+    outputs = model.generate(**inputs, num_beams=5, max_new_tokens=8)
+    assert outputs.shape[0] == 2 and outputs.shape[1] <= 9 and (outputs[:, 0] == cfg.bos_token_id).all()      # the prompt the reference's generate() starts from (goldens)
+    text = processor.decode(outputs[0], skip_special_tokens=True)
+    assert isinstance(text, str) and "<s>" not in text and "</s>" not in text
+    assert len(processor.batch_decode(outputs, skip_special_tokens=True)) == 2
+    direct = AVHubertForConditionalGeneration(cfg, sd, device=str(gpu_device)).generate(**inputs, num_beams=5, max_new_tokens=8)
+    assert torch.equal(direct, outputs)
+    # one clip alone, audio only (the processor substitutes a zero video; README's extractor path for the pretrained encoder)
+    solo = processor(raw_audio=clips[0][0])
+    enc = model.avhubert(**solo).last_hidden_state
+    assert enc.shape == (1, 25, cfg.encoder_embed_dim) and torch.isfinite(enc).all()
