@@ -102,6 +102,18 @@ class AVHubertForConditionalGeneration:
         -> LongTensor [B][<= 1 + max_new_tokens] starting with bos (CPU), or BeamOutput with `sequences_scores`"""
         if do_sample:
             raise NotImplementedError("sampling is not built (the reference's documented call is deterministic beam search)")
+        # transformers' generate() takes dozens of options; the ones that change the search and are not restated here must not be
+        # dropped silently
+        if "max_length" in kwargs and kwargs["max_length"] is not None:
+            max_new_tokens = int(kwargs.pop("max_length")) - 1              # the prompt is the one bos token
+        neutral = {"use_cache": None, "output_scores": None, "early_stopping": False, "num_return_sequences": 1, "num_beam_groups": 1,
+                   "repetition_penalty": 1.0, "no_repeat_ngram_size": 0, "temperature": 1.0, "top_k": None, "top_p": None,
+                   "attention_mask": None, "max_length": None}
+        for k, v in kwargs.items():
+            if k not in neutral:
+                raise TypeError(f"generate(): option `{k}` is not built (greedy and beam search with num_beams, max_new_tokens / max_length, length_penalty are)")
+            if neutral[k] is not None and v is not None and v != neutral[k]:
+                raise NotImplementedError(f"generate(): `{k}={v!r}` changes the search and is not built (only {neutral[k]!r})")
         enc = self.avhubert(input_values=input_values, pixel_values=pixel_values, padding_mask=padding_mask).last_hidden_state
         mask = padding_mask if padding_mask is not None else np.zeros(enc.shape[:2], np.float32)
         if num_beams <= 1:

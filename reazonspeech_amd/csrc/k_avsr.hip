@@ -420,6 +420,92 @@ __global__ __launch_bounds__(256) void avsr_attn_keys_kernel(const float* __rest
         if (lane + 64 * e < hd) orow[lane + 64 * e] = den > 0.0f ? acc[e] / den : 0.0f;
 }
 
+// One decoding step (Tq == 1): the kernel above gives a (row, head) to ONE wave — 320 waves on a 1024-SIMD chip walking 250 keys
+// each, 157 us per launch and 12 launches per token (profiles/r06_09_f32_avsr_kernel_stats.txt: more than half of a step).  Here a
+// workgroup owns the (row, head) and its four waves split the keys (chunk c * 4 + wave of 64): a lane computes the whole dot
+// product of its key, a wave its own max / sum / P.V partial, and the four partials combine in LDS with the usual
+// exp(m_w - M) weights.  n_keys <= 256 NC.
+template <int NC>
+__global__ __launch_bounds__(256) void avsr_attn_step_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldk,
+                                                             size_t k_batch_stride, const float* __restrict__ kmask, int mask_pitch, int rows_per_kb, int n_keys,
+                                                             int hd, float scaling, float* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) float qs[256];
+    __shared__ float part_m[4], part_l[4];
+    __shared__ float part_acc[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.x, qb = blockIdx.y;
+    const int kb = qb / rows_per_kb;
+    const float* qr = q + (size_t)qb * ldq + h * hd;
+    const float* kbase = k + (size_t)kb * k_batch_stride + h * hd;
+    const float* vbase = v + (size_t)kb * k_batch_stride + h * hd;
+    const float* mk = kmask ? kmask + (size_t)kb * mask_pitch : nullptr;
+    if ((int)threadIdx.x < hd) qs[threadIdx.x] = qr[threadIdx.x];
+    __syncthreads();
+    const float4* q4 = reinterpret_cast<const float4*>(qs);
+    float sc[NC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = (c * 4 + wave) * 64 + lane;
+        sc[c] = -INFINITY;
+        if (j < n_keys && (!mk || mk[j] == 0.0f)) {
+            const float4* kr = reinterpret_cast<const float4*>(kbase + (size_t)j * ldk);
+            float a0 = 0.0f, a1 = 0.0f;
+            int e4 = 0;
+            for (; e4 + 1 < hd / 4; e4 += 2) {                        // two chains: the loads of a key row are independent
+                const float4 k0 = kr[e4], q0 = q4[e4], k1 = kr[e4 + 1], q1 = q4[e4 + 1];
+                a0 = fmaf(q0.x, k0.x, a0); a0 = fmaf(q0.y, k0.y, a0); a0 = fmaf(q0.z, k0.z, a0); a0 = fmaf(q0.w, k0.w, a0);
+                a1 = fmaf(q1.x, k1.x, a1); a1 = fmaf(q1.y, k1.y, a1); a1 = fmaf(q1.z, k1.z, a1); a1 = fmaf(q1.w, k1.w, a1);
+            }
+            if (e4 < hd / 4) {
+                const float4 k0 = kr[e4], q0 = q4[e4];
+                a0 = fmaf(q0.x, k0.x, a0); a0 = fmaf(q0.y, k0.y, a0); a0 = fmaf(q0.z, k0.z, a0); a0 = fmaf(q0.w, k0.w, a0);
+            }
+            sc[c] = (a0 + a1) * scaling;
+            mx = fmaxf(mx, sc[c]);
+        }
+    }
+    mx = wave_max(mx);
+    float den = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        sc[c] = sc[c] > -INFINITY ? expf(sc[c] - mx) : 0.0f;
+        den += sc[c];
+    }
+    den = wave_sum(den);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j0 = (c * 4 + wave) * 64;
+        const int jn = n_keys - j0 < 64 ? n_keys - j0 : 64;
+        for (int jj = 0; jj < jn; ++jj) {
+            const float p = __shfl(sc[c], jj, 64);
+            if (p != 0.0f) {
+                const float* vr = vbase + (size_t)(j0 + jj) * ldk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (lane + 64 * e < hd) acc[e] = fmaf(p, vr[lane + 64 * e], acc[e]);
+            }
+        }
+    }
+    if (lane == 0) { part_m[wave] = mx; part_l[wave] = den; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part_acc[wave][lane + 64 * e] = acc[e];
+    __syncthreads();
+    if ((int)threadIdx.x < hd) {
+        const float M = fmaxf(fmaxf(part_m[0], part_m[1]), fmaxf(part_m[2], part_m[3]));
+        float L = 0.0f, o = 0.0f;
+        if (M > -INFINITY) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float f = part_m[w] > -INFINITY ? expf(part_m[w] - M) : 0.0f;
+                L = fmaf(part_l[w], f, L);
+                o = fmaf(part_acc[w][threadIdx.x], f, o);
+            }
+        }
+        out[(size_t)qb * ldo + h * hd + threadIdx.x] = L > 0.0f ? o / L : 0.0f;
+    }
+}
+
 // decoder input of one step: x[r] = embed[token[r]] + pos[step]
 __global__ __launch_bounds__(256) void avsr_embed_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ embed, const float* __restrict__ pos, int step, int d,
                                                          int V, size_t total, float* __restrict__ x) {
@@ -503,6 +589,14 @@ int launch_attn(rs_ctx* ctx, const float* q, int ldq, const float* k, const floa
     if (hd > 256) return rs_fail(ctx, RS_EINVAL, "avsr attention: head_dim %d > 256", hd);
     const dim3 grid((Tq + 3) / 4, H, Bq), block(256);
     const float scaling = 1.0f / sqrtf((float)hd);
+    if (Tq == 1 && n_keys <= 512 && hd % 4 == 0) {         // a decoding step: the keys over the four waves of a workgroup
+        if (n_keys <= 256)
+            hipLaunchKernelGGL((avsr_attn_step_kernel<1>), dim3(H, Bq), block, 0, s, q, ldq, k, v, ldk, kstride, kmask, mask_pitch, rows_per_kb, n_keys, hd, scaling, out, ldo);
+        else
+            hipLaunchKernelGGL((avsr_attn_step_kernel<2>), dim3(H, Bq), block, 0, s, q, ldq, k, v, ldk, kstride, kmask, mask_pitch, rows_per_kb, n_keys, hd, scaling, out, ldo);
+        RS_CHECK_LAUNCH(ctx, "avsr attention (step)");
+        return RS_OK;
+    }
     if (!causal && n_keys <= 512 && hd % 4 == 0) {         // lanes over the keys (scores in registers)
         if (n_keys <= 256)
             hipLaunchKernelGGL((avsr_attn_keys_kernel<4>), grid, block, 0, s, q, ldq, k, v, ldk, kstride, kmask, mask_pitch, rows_per_kb, Tq, n_keys, hd, scaling, out, ldo);

@@ -139,6 +139,15 @@ def test_the_readme_flow_from_a_pretrained_directory(gpu_device, tmp_path):
     assert len(processor.batch_decode(outputs, skip_special_tokens=True)) == 2
     direct = AVHubertForConditionalGeneration(cfg, sd, device=str(gpu_device)).generate(**inputs, num_beams=5, max_new_tokens=8)
     assert torch.equal(direct, outputs)
+    # generate() options: the neutral values of transformers' defaults pass, max_length counts the bos prompt, anything that would
+    # change the search is refused instead of dropped
+    assert torch.equal(model.generate(**inputs, num_beams=5, max_length=9, early_stopping=False, repetition_penalty=1.0, use_cache=True), outputs)
+    with pytest.raises(NotImplementedError):
+        model.generate(**inputs, num_beams=5, max_new_tokens=8, repetition_penalty=1.2)
+    with pytest.raises(NotImplementedError):
+        model.generate(**inputs, num_beams=5, max_new_tokens=8, do_sample=True)
+    with pytest.raises(TypeError):
+        model.generate(**inputs, num_beams=5, max_new_tokens=8, logits_processor=[])
     # one clip alone, audio only (the processor substitutes a zero video; README's extractor path for the pretrained encoder)
     solo = processor(raw_audio=clips[0][0])
     enc = model.avhubert(**solo).last_hidden_state
