@@ -127,25 +127,6 @@ __global__ __launch_bounds__(256) void avsr_maxpool_kernel(const float* __restri
     out[idx] = m;
 }
 
-// 3 x 3 patches with padding 1 and stride s of a channels-last map: row (n, oh, ow) = in[n][s oh + kh - 1][s ow + kw - 1][:] in
-// (kh, kw, c) order, zeros outside.  One thread per 16-byte piece.
-__global__ __launch_bounds__(256) void avsr_im2col3_kernel(const float* __restrict__ in, int H, int W, int C, int OH, int OW, int stride, size_t pieces,
-                                                           float* __restrict__ col) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= pieces) return;
-    const int c4 = C / 4, per_row = 9 * c4;
-    const size_t row = idx / per_row;
-    const int q = (int)(idx - row * per_row), tap = q / c4, cc = q - tap * c4, kh = tap / 3, kw = tap - 3 * kh;
-    const int ow = (int)(row % OW);
-    const size_t r = row / OW;
-    const int oh = (int)(r % OH);
-    const size_t n = r / OH;
-    const int ih = stride * oh + kh - 1, iw = stride * ow + kw - 1;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = reinterpret_cast<const float4*>(in + ((n * H + ih) * W + iw) * C)[cc];
-    reinterpret_cast<float4*>(col)[idx] = v;
-}
-
 // the 1 x 1 stride-2 down-sampling convolution's input: in[n][2 oh][2 ow][:] -> rows of C
 __global__ __launch_bounds__(256) void avsr_stride2_kernel(const float* __restrict__ in, int H, int W, int C, int OH, int OW, size_t pieces, float* __restrict__ out) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -157,26 +138,6 @@ __global__ __launch_bounds__(256) void avsr_stride2_kernel(const float* __restri
     const int oh = (int)(r % OH);
     const size_t n = r / OH;
     reinterpret_cast<float4*>(out)[idx] = reinterpret_cast<const float4*>(in + ((n * H + 2 * oh) * W + 2 * ow) * C)[cc];
-}
-
-// BatchNorm (inference form) [+ residual] [+ PReLU]: x = act(x * alpha[c] + beta[c] + res), in place.  slope == nullptr: no activation
-__global__ __launch_bounds__(256) void avsr_bn_act_kernel(float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                          const float* __restrict__ res, const float* __restrict__ slope, int C, size_t n4) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const int c = (int)((i * 4) % (size_t)C);
-    float4 v = reinterpret_cast<float4*>(x)[i];
-    const float4 a = *reinterpret_cast<const float4*>(alpha + c), b = *reinterpret_cast<const float4*>(beta + c);
-    v.x = fmaf(v.x, a.x, b.x); v.y = fmaf(v.y, a.y, b.y); v.z = fmaf(v.z, a.z, b.z); v.w = fmaf(v.w, a.w, b.w);
-    if (res) {
-        const float4 r = reinterpret_cast<const float4*>(res)[i];
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-    }
-    if (slope) {
-        const float4 s = *reinterpret_cast<const float4*>(slope + c);
-        v.x = v.x >= 0.f ? v.x : v.x * s.x; v.y = v.y >= 0.f ? v.y : v.y * s.y; v.z = v.z >= 0.f ? v.z : v.z * s.z; v.w = v.w >= 0.f ? v.w : v.w * s.w;
-    }
-    reinterpret_cast<float4*>(x)[i] = v;
 }
 
 // AdaptiveAvgPool2d(1): [N][HW][C] -> [N][C]
@@ -420,6 +381,105 @@ __global__ __launch_bounds__(256) void avsr_attn_keys_kernel(const float* __rest
         if (lane + 64 * e < hd) orow[lane + 64 * e] = den > 0.0f ? acc[e] / den : 0.0f;
 }
 
+// Encoder self-attention on the exact-f32 matrix cores (the form of attention_f32_mfma_kernel in k_f32.hip without the position
+// term): a wave owns 16 queries, walks the keys 16 at a time — S^T = K . Q^T with the key rows as the MFMA's first operand straight
+// from global memory, online softmax per tile (scores scaled AFTER the dot product, like the reference; a masked key weighs 0), and
+// O^T += V^T . P^T with the four keys of a step chosen so that a lane's own probability register is its operand.  Padded QUERIES
+// are computed like any other (the reference does not mask them either).  HD % 64 == 0.
+template <int HD>
+__global__ __launch_bounds__(256) void avsr_attn_mfma_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldk,
+                                                             size_t k_batch_stride, const float* __restrict__ kmask, int mask_pitch, int rows_per_kb, int Tq,
+                                                             int n_keys, float scaling, float* __restrict__ out, int ldo) {
+    constexpr int NS = HD / 16, NG = HD / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.x * 64 + wave * 16, h = blockIdx.y, qb = blockIdx.z;
+    if (i0 >= Tq) return;
+    const int kb = qb / rows_per_kb;
+    const float* kbase = k + (size_t)kb * k_batch_stride + h * HD;
+    const float* vbase = v + (size_t)kb * k_batch_stride + h * HD;
+    const float* mk = kmask ? kmask + (size_t)kb * mask_pitch : nullptr;
+    const int qi = i0 + li, qrow = qi < Tq ? qi : Tq - 1;
+    const float* qr = q + ((size_t)qb * Tq + qrow) * ldq + h * HD + 4 * kq;
+    float4 qf[NS];
+#pragma unroll
+    for (int S = 0; S < NS; ++S) qf[S] = *reinterpret_cast<const float4*>(qr + 16 * S);
+    f32x4_t O[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) O[g][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int ntile = (n_keys + 15) / 16;
+    for (int jt = 0; jt < ntile; ++jt) {
+        const int j0 = jt * 16;
+        const int krow = j0 + li < n_keys ? j0 + li : n_keys - 1;
+        const float* kp = kbase + (size_t)krow * ldk + 4 * kq;
+        f32x4_t ac = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int S = 0; S < NS; ++S) {
+            const float4 kf = *reinterpret_cast<const float4*>(kp + 16 * S);
+            ac = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[S].x, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[S].y, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[S].z, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[S].w, ac, 0, 0, 0);
+        }
+        float sc[4];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + 4 * kq + r;
+            const bool ok = j < n_keys && (!mk || mk[j < n_keys ? j : n_keys - 1] == 0.0f);
+            sc[r] = ok ? ac[r] * scaling : -INFINITY;
+            mt = fmaxf(mt, sc[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        if (m_new == -INFINITY) continue;                  // every key so far is masked — the same for all 16 queries of the wave (they
+                                                           // share the clip's key mask): a wave-uniform skip, no MFMA under a partial EXEC
+        const float alpha = expf(m_run - m_new);           // exp(-inf) = 0 on the first visible tile
+        float pr[4], lt = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pr[r] = expf(sc[r] - m_new);
+            lt += pr[r];
+        }
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        l_run = l_run * alpha + lt;
+        m_run = m_new;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) O[g][n][r] *= alpha;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int vrow = j0 + 4 * kq + m < n_keys ? j0 + 4 * kq + m : n_keys - 1;
+            const float* vp = vbase + (size_t)vrow * ldk + 4 * li;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const float4 v4 = *reinterpret_cast<const float4*>(vp + 64 * g);
+                O[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.x, pr[m], O[g][0], 0, 0, 0);
+                O[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.y, pr[m], O[g][1], 0, 0, 0);
+                O[g][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.z, pr[m], O[g][2], 0, 0, 0);
+                O[g][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.w, pr[m], O[g][3], 0, 0, 0);
+            }
+        }
+    }
+    if (qi < Tq) {
+        const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+        float* orow = out + ((size_t)qb * Tq + qi) * ldo + h * HD;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<float4*>(orow + 64 * g + 16 * kq + 4 * r) =
+                    make_float4(O[g][0][r] * inv, O[g][1][r] * inv, O[g][2][r] * inv, O[g][3][r] * inv);
+    }
+}
+
 // One decoding step (Tq == 1): the kernel above gives a (row, head) to ONE wave — 320 waves on a 1024-SIMD chip walking 250 keys
 // each, 157 us per launch and 12 launches per token (profiles/r06_09_f32_avsr_kernel_stats.txt: more than half of a step).  Here a
 // workgroup owns the (row, head) and its four waves split the keys (chunk c * 4 + wave of 64): a lane computes the whole dot
@@ -557,7 +617,7 @@ AvsrPlan avsr_plan(const rs_avsr& k, int B, int T) {
     p.off_a0 = take(N * p.H1 * p.H1 * 64 * 4);
     const size_t map = N * p.H2 * p.H2 * 64 * 4;           // the largest trunk map (layer 1); later layers halve the pixels and double the channels
     p.off_x = take(map); p.off_y = take(map); p.off_z = take(map);
-    p.off_col = take(N * p.H2 * p.H2 * 9 * 64 * 4);       // the largest patch matrix (layer 1: K = 576)
+    p.off_col = take(N * p.H2 * p.H2 * 64 * 4);           // the down-sampling branch's output (at most a stage-1 map)
     p.off_a1 = take(map / 2);                              // strided rows of a down-sampling convolution
     p.off_pool = take(N * 512 * 4);
     p.off_apad = take(N * pad32(d.audio_feat_dim) * 4);
@@ -589,6 +649,15 @@ int launch_attn(rs_ctx* ctx, const float* q, int ldq, const float* k, const floa
     if (hd > 256) return rs_fail(ctx, RS_EINVAL, "avsr attention: head_dim %d > 256", hd);
     const dim3 grid((Tq + 3) / 4, H, Bq), block(256);
     const float scaling = 1.0f / sqrtf((float)hd);
+    if (Tq > 1 && !causal && (hd == 64 || hd == 128) && ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0) {       // the encoder: exact-f32 MFMA
+        const dim3 grid16((Tq + 63) / 64, H, Bq);
+        if (hd == 64)
+            hipLaunchKernelGGL((avsr_attn_mfma_kernel<64>), grid16, block, 0, s, q, ldq, k, v, ldk, kstride, kmask, mask_pitch, rows_per_kb, Tq, n_keys, scaling, out, ldo);
+        else
+            hipLaunchKernelGGL((avsr_attn_mfma_kernel<128>), grid16, block, 0, s, q, ldq, k, v, ldk, kstride, kmask, mask_pitch, rows_per_kb, Tq, n_keys, scaling, out, ldo);
+        RS_CHECK_LAUNCH(ctx, "avsr attention (mfma)");
+        return RS_OK;
+    }
     if (Tq == 1 && n_keys <= 512 && hd % 4 == 0) {         // a decoding step: the keys over the four waves of a workgroup
         if (n_keys <= 256)
             hipLaunchKernelGGL((avsr_attn_step_kernel<1>), dim3(H, Bq), block, 0, s, q, ldq, k, v, ldk, kstride, kmask, mask_pitch, rows_per_kb, n_keys, hd, scaling, out, ldo);
@@ -756,13 +825,10 @@ extern "C" int rs_avsr_encoder_forward(rs_ctx* ctx, const float* input_values, c
                 const int stride = (b == 0 && L > 1) ? 2 : 1;
                 const int ohw = stride == 2 ? (hw - 1) / 2 + 1 : hw;            // 3 x 3, padding 1
                 const size_t rows_out = N * ohw * ohw;
-                // conv1 -> bn1 -> relu1
-                hipLaunchKernelGGL(avsr_im2col3_kernel, blocks1d(rows_out * 9 * cin / 4), dim3(256), 0, s, cur, hw, hw, cin, ohw, ohw, stride, rows_out * 9 * cin / 4, col);
-                RS_TRY(gemm(col, 9 * cin, Bk.conv1_w, 9 * cin, o1, c, (long long)rows_out, c, 0, nullptr, nullptr));
-                hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o1, Bk.bn1_a, Bk.bn1_b, (const float*)nullptr, Bk.relu1, c, rows_out * c / 4);
-                // conv2 -> bn2 -> (+ residual) -> relu2
-                hipLaunchKernelGGL(avsr_im2col3_kernel, blocks1d(rows_out * 9 * c / 4), dim3(256), 0, s, o1, ohw, ohw, c, ohw, ohw, 1, rows_out * 9 * c / 4, col);
-                RS_TRY(gemm(col, 9 * c, Bk.conv2_w, 9 * c, o2, c, (long long)rows_out, c, 0, nullptr, nullptr));
+                // conv1 -> bn1 -> relu1 and conv2 -> bn2 -> (+ residual) -> relu2, each ONE launch: the 3 x 3 patches are gathered by the
+                // GEMM's loader, BatchNorm / residual / PReLU run in its epilogue (rs_launch_conv3x3_f32; until round 6 the patch
+                // matrices went through HBM — 4.5 GB per convolution of the first stage — followed by a BatchNorm pass)
+                RS_TRY(rs_launch_conv3x3_f32(ctx, cur, (int)N, hw, hw, cin, ohw, ohw, stride, Bk.conv1_w, c, Bk.bn1_a, Bk.bn1_b, nullptr, Bk.relu1, o1, 0, s));
                 const float* res = cur;
                 if (Bk.ds_w) {                                                   // 1 x 1 convolution with the block's stride + BatchNorm on the block input
                     const float* src = cur;
@@ -770,12 +836,10 @@ extern "C" int rs_avsr_encoder_forward(rs_ctx* ctx, const float* input_values, c
                         hipLaunchKernelGGL(avsr_stride2_kernel, blocks1d(rows_out * cin / 4), dim3(256), 0, s, cur, hw, hw, cin, ohw, ohw, rows_out * cin / 4, a1);
                         src = a1;
                     }
-                    RS_TRY(gemm(src, cin, Bk.ds_w, cin, o1, c, (long long)rows_out, c, 0, nullptr, nullptr));       // (o1 is free again: conv2's patches were taken)
-                    hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o1, Bk.ds_a, Bk.ds_b, (const float*)nullptr, (const float*)nullptr, c,
-                                       rows_out * c / 4);
-                    res = o1;
+                    RS_TRY(rs_launch_conv3x3_f32(ctx, src, (int)N, ohw, ohw, cin, ohw, ohw, 1, Bk.ds_w, c, Bk.ds_a, Bk.ds_b, nullptr, nullptr, col, 1, s));
+                    res = col;
                 }
-                hipLaunchKernelGGL(avsr_bn_act_kernel, blocks1d(rows_out * c / 4), dim3(256), 0, s, o2, Bk.bn2_a, Bk.bn2_b, res, Bk.relu2, c, rows_out * c / 4);
+                RS_TRY(rs_launch_conv3x3_f32(ctx, o1, (int)N, ohw, ohw, c, ohw, ohw, 1, Bk.conv2_w, c, Bk.bn2_a, Bk.bn2_b, res, Bk.relu2, o2, 0, s));
                 RS_CHECK_LAUNCH(ctx, "avsr ResNet block");
                 float* nxt = o2;                      // rotate: the block's output becomes the input, the old input and o1 are scratch
                 o2 = cur; cur = nxt;

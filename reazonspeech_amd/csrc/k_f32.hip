@@ -37,6 +37,12 @@ struct GemmF32 {
     int lda, ldw, ldc, M, N, K, flags;
     float alpha;
     int mask_rows_per_step, mask_steps;
+    // CONV instantiations: A is a channels-last map [n][H][W][C] and row m = (n, oh, ow) of the product is its 3 x 3 patch with padding 1
+    // and stride cv_stride in (kh, kw, c) order (K = 9 C, C % 32 == 0), gathered by the loader instead of being written out first
+    int cv_H, cv_W, cv_C, cv_OH, cv_OW, cv_stride;
+    // per-column affine + PReLU epilogue (a folded inference BatchNorm): v = fma(v, col_scale[n], col_shift[n]) (+ residual), then
+    // v < 0 ? prelu[n] * v : v when prelu is given; replaces the bias / activation / alpha steps when col_scale != nullptr
+    const float* col_scale; const float* col_shift; const float* prelu;
 };
 
 constexpr int GT = 128;   // tile rows / columns
@@ -46,36 +52,64 @@ constexpr int GP = 36;    // LDS row pitch in floats (144 B: 16-byte aligned, ro
 // out[M][N] = epilogue(A[M][K] . W[N][K]^T), all float32.  256 threads = 2 x 2 waves, a wave owns 64 x 64 outputs
 // (4 x 4 MFMA blocks).  The weight fragment is the MFMA A operand, so a lane's four accumulator registers are four
 // CONSECUTIVE columns of one output row: bias / residual / store are float4 accesses.
+// N64: tiles of 128 rows x 64 columns, the four waves stacked over the rows (32 x 64 each) — for products with 64 output columns
+// (the first ResNet stage of the AV-HuBERT video trunk) whose 128-column tiles would multiply a clamped copy of the weights half the
+// time.  CONV: see GemmF32.  Neither changes the order in which the K products of an output element are added.
+template <bool CONV, bool N64>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
     // Two LDS stages (round 6): the next K stage is fetched into registers while this one is multiplied and written into the OTHER
     // buffer afterwards, so a stage costs one workgroup barrier instead of two; two workgroups per CU (launch bound) leave the
     // prefetch registers in VGPRs — at three the compiler parked them in scratch on their way to LDS (profiles/r06_05_*: 144 bytes
     // of scratch per lane).  The arithmetic per output element is unchanged: ascending 16-blocks, inside a block k = e + 4 kk.
+    constexpr int TN = N64 ? 64 : GT, MI = N64 ? 2 : 4;
     __shared__ __attribute__((aligned(16))) float As[2][GT * GP];
-    __shared__ __attribute__((aligned(16))) float Ws[2][GT * GP];
+    __shared__ __attribute__((aligned(16))) float Ws[2][TN * GP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int wm = N64 ? wave : wave >> 1, wn = N64 ? 0 : wave & 1;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * TN;
     const int lr = tid >> 3, lc = tid & 7;            // staging: row lr + 32 i, 16-byte chunk lc of the 128-byte K slice
     // (macros, not lambdas: with the prefetch registers captured by reference the arrays stayed stack objects — 128 bytes of scratch
     // traffic per lane and K stage)
     float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
     const float* a_ptr[4];
     const float* w_ptr[4];
+    int cv_ih[4], cv_iw[4];                           // CONV: top-left input pixel of the row's patch (may be -1)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int m = m0 + lr + 32 * i, n = n0 + lr + 32 * i;
         m = m < p.M ? m : p.M - 1;                    // rows past the matrix: clamped, their products are never stored
         n = n < p.N ? n : p.N - 1;
-        a_ptr[i] = p.A + (size_t)m * p.lda + 4 * lc;
+        if constexpr (CONV) {
+            const int ow = m % p.cv_OW, r = m / p.cv_OW, oh = r % p.cv_OH, img = r / p.cv_OH;
+            cv_ih[i] = p.cv_stride * oh - 1;
+            cv_iw[i] = p.cv_stride * ow - 1;
+            a_ptr[i] = p.A + (size_t)img * p.cv_H * p.cv_W * p.cv_C + 4 * lc;
+        } else {
+            cv_ih[i] = cv_iw[i] = 0;
+            a_ptr[i] = p.A + (size_t)m * p.lda + 4 * lc;
+        }
         w_ptr[i] = p.W + (size_t)n * p.ldw + 4 * lc;
     }
+    // CONV: a K stage of 32 lies inside one tap (C % 32 == 0); a pixel outside the map reads a clamped address and is replaced by zeros
+    // (an unconditional load + select: a predicated definition of the prefetch registers is what the compiler demotes to scratch)
+#define RS_F32_ALOAD(R, I, k0)                                                                                  \
+    do {                                                                                                       \
+        if constexpr (CONV) {                                                                                  \
+            const int tap = (k0) / p.cv_C, c0 = (k0) - tap * p.cv_C, kh = tap / 3, kw = tap - 3 * kh;         \
+            const int ih = cv_ih[I] + kh, iw = cv_iw[I] + kw;                                                  \
+            const bool ok = (unsigned)ih < (unsigned)p.cv_H && (unsigned)iw < (unsigned)p.cv_W;                \
+            const float4 t = *reinterpret_cast<const float4*>(a_ptr[I] + ((size_t)((ok ? ih : 0) * p.cv_W + (ok ? iw : 0)) * p.cv_C + c0)); \
+            R = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
+        } else {                                                                                               \
+            R = *reinterpret_cast<const float4*>(a_ptr[I] + (k0));                                             \
+        }                                                                                                      \
+    } while (0)
 #define RS_F32_GLOAD(k0)                                                                                        \
     do {                                                                                                       \
-        ra0 = *reinterpret_cast<const float4*>(a_ptr[0] + (k0)); rw0 = *reinterpret_cast<const float4*>(w_ptr[0] + (k0)); \
-        ra1 = *reinterpret_cast<const float4*>(a_ptr[1] + (k0)); rw1 = *reinterpret_cast<const float4*>(w_ptr[1] + (k0)); \
-        ra2 = *reinterpret_cast<const float4*>(a_ptr[2] + (k0)); rw2 = *reinterpret_cast<const float4*>(w_ptr[2] + (k0)); \
-        ra3 = *reinterpret_cast<const float4*>(a_ptr[3] + (k0)); rw3 = *reinterpret_cast<const float4*>(w_ptr[3] + (k0)); \
+        RS_F32_ALOAD(ra0, 0, k0); rw0 = *reinterpret_cast<const float4*>(w_ptr[0] + (k0));                     \
+        RS_F32_ALOAD(ra1, 1, k0); rw1 = *reinterpret_cast<const float4*>(w_ptr[1] + (k0));                     \
+        RS_F32_ALOAD(ra2, 2, k0); if constexpr (!N64) rw2 = *reinterpret_cast<const float4*>(w_ptr[2] + (k0)); \
+        RS_F32_ALOAD(ra3, 3, k0); if constexpr (!N64) rw3 = *reinterpret_cast<const float4*>(w_ptr[3] + (k0)); \
     } while (0)
 #define RS_F32_STASH(buf)                                                                                       \
     do {                                                                                                       \
@@ -84,13 +118,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
         *reinterpret_cast<float4*>(ad) = ra0; *reinterpret_cast<float4*>(ad + 32 * GP) = ra1;                 \
         *reinterpret_cast<float4*>(ad + 64 * GP) = ra2; *reinterpret_cast<float4*>(ad + 96 * GP) = ra3;       \
         *reinterpret_cast<float4*>(wd) = rw0; *reinterpret_cast<float4*>(wd + 32 * GP) = rw1;                 \
-        *reinterpret_cast<float4*>(wd + 64 * GP) = rw2; *reinterpret_cast<float4*>(wd + 96 * GP) = rw3;       \
+        if constexpr (!N64) { *reinterpret_cast<float4*>(wd + 64 * GP) = rw2; *reinterpret_cast<float4*>(wd + 96 * GP) = rw3; } \
     } while (0)
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][MI];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     RS_F32_GLOAD(0);
     RS_F32_STASH(0);
@@ -103,16 +137,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
         const float* Wb = Ws[cur];
 #pragma unroll
         for (int kb = 0; kb < GK / 16; ++kb) {
-            float4 af[4], wf[4];
+            float4 af[MI], wf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const float4*>(Ab + (wm * 64 + i * 16 + fr) * GP + kb * 16 + 4 * fq);
-                wf[i] = *reinterpret_cast<const float4*>(Wb + (wn * 64 + i * 16 + fr) * GP + kb * 16 + 4 * fq);
-            }
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + (wm * 16 * MI + i * 16 + fr) * GP + kb * 16 + 4 * fq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const float4*>(Wb + (wn * 64 + i * 16 + fr) * GP + kb * 16 + 4 * fq);
             // step e of a 16-block multiplies k = 16 kb + 4 kk + e for the four lane groups kk at once
 #define RS_F32_STEP(E)                                                                                          \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
-                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                               \
+                _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni].E, af[mi].E, acc[ni][mi], 0, 0, 0);
             RS_F32_STEP(x) RS_F32_STEP(y) RS_F32_STEP(z) RS_F32_STEP(w)
 #undef RS_F32_STEP
@@ -122,14 +155,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
         cur ^= 1;
     }
 #undef RS_F32_GLOAD
+#undef RS_F32_ALOAD
 #undef RS_F32_STASH
     // epilogue, the order of k_gemm_bf16.hip: + bias, activation, * alpha, + residual, row mask
     const bool has_bias = p.flags & RS_GEMM_BIAS, relu = p.flags & RS_GEMM_RELU, silu = p.flags & RS_GEMM_SILU;
     const bool res = p.flags & RS_GEMM_RESIDUAL, rowmask = p.flags & RS_GEMM_ROWMASK;
     const bool swl = p.flags & RS_GEMM_SWOOSHL, swr = p.flags & RS_GEMM_SWOOSHR, gelu = p.flags & RS_GEMM_GELU;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + fr;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * 16 * MI + mi * 16 + fr;
         if (m >= p.M) continue;
         bool keep = true;
         if (rowmask) {
@@ -142,6 +176,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
             const int n = n0 + wn * 64 + ni * 16 + 4 * fq;
             if (n >= p.N) continue;
             float4 v = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+            if (p.col_scale) {                            // folded BatchNorm (+ residual) (+ PReLU): the arithmetic of k_avsr.hip's avsr_bn_act_kernel
+                const float4 a = *reinterpret_cast<const float4*>(p.col_scale + n), bb = *reinterpret_cast<const float4*>(p.col_shift + n);
+                v.x = fmaf(v.x, a.x, bb.x); v.y = fmaf(v.y, a.y, bb.y); v.z = fmaf(v.z, a.z, bb.z); v.w = fmaf(v.w, a.w, bb.w);
+                if (res) {
+                    const float4 r = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldc + n);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (p.prelu) {
+                    const float4 sl = *reinterpret_cast<const float4*>(p.prelu + n);
+                    v.x = v.x >= 0.f ? v.x : sl.x * v.x; v.y = v.y >= 0.f ? v.y : sl.y * v.y;
+                    v.z = v.z >= 0.f ? v.z : sl.z * v.z; v.w = v.w >= 0.f ? v.w : sl.w * v.w;
+                }
+                *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldc + n) = v;
+                continue;
+            }
             if (has_bias) {
                 const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                 v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -613,12 +662,39 @@ int rs_launch_gemm_f32(rs_ctx* ctx, const float* A, int lda, const float* W, int
     if ((flags & RS_GEMM_RESIDUAL) && !residual) return rs_fail(ctx, RS_EINVAL, "gemm_f32: residual flag without a residual");
     if ((flags & RS_GEMM_ROWMASK) && (!mask_lens || mask_rows_per_step <= 0 || mask_steps <= 0))
         return rs_fail(ctx, RS_EINVAL, "gemm_f32: row mask without lengths");
-    GemmF32 p{A, W, out, bias, residual, mask_lens, lda, ldw, ldc, M, N, K, flags, alpha, mask_rows_per_step, mask_steps};
+    GemmF32 p{A, W, out, bias, residual, mask_lens, lda, ldw, ldc, M, N, K, flags, alpha, mask_rows_per_step, mask_steps, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
     const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(256);
     rs_prof_begin(ctx, RS_PROF_GEMM, s, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, s, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
     rs_prof_end(ctx, RS_PROF_GEMM, s);
     RS_CHECK_LAUNCH(ctx, "gemm_f32");
+    return RS_OK;
+}
+
+// A 3 x 3 convolution (padding 1, stride 1 or 2) of a channels-last float32 map as ONE product: out[(n, oh, ow)][co] =
+// sum over (kh, kw, c) of in[n][s oh + kh - 1][s ow + kw - 1][c] * W[co][(kh, kw, c)], the patches gathered by the GEMM's loader (no patch
+// matrix in HBM: the AV-HuBERT trunk's were 4.5 GB per convolution of the first stage), followed by the folded inference BatchNorm,
+// an optional residual [rows][Cout] and an optional per-channel PReLU in the epilogue.  in_rows_as_matrix: the 1 x 1 form (K = C, no
+// gather) with the same epilogue, for the down-sampling branch.  Same summation order as patches + rs_launch_gemm_f32.
+int rs_launch_conv3x3_f32(rs_ctx* ctx, const float* in, int n_img, int H, int Wd, int C, int OH, int OW, int stride, const float* W, int Cout,
+                          const float* bn_scale, const float* bn_shift, const float* residual, const float* prelu, float* out, int one_by_one, hipStream_t s) {
+    const long long rows = (long long)n_img * OH * OW;
+    if (rows <= 0) return RS_OK;
+    const int K = one_by_one ? C : 9 * C;
+    if (C % GK || Cout % 4 || rows > 0x7fffffffLL || !bn_scale || !bn_shift)
+        return rs_fail(ctx, RS_EINVAL, "conv3x3_f32: C %% %d, Cout %% 4, < 2^31 output rows and a folded BatchNorm required (C %d Cout %d rows %lld)", GK, C, Cout, rows);
+    GemmF32 p{in, W, out, nullptr, residual, nullptr, C, K, Cout, (int)rows, Cout, K, residual ? RS_GEMM_RESIDUAL : 0, 1.0f, 0, 0,
+              H, Wd, C, OH, OW, stride, bn_scale, bn_shift, prelu};
+    const bool n64 = Cout <= 64;
+    const dim3 grid((Cout + (n64 ? 64 : GT) - 1) / (n64 ? 64 : GT), (unsigned)((rows + GT - 1) / GT)), block(256);
+    rs_prof_begin(ctx, RS_PROF_GEMM, s, 2.0 * rows * (double)Cout * K, 4.0 * ((double)n_img * H * Wd * C + (double)Cout * K + 2.0 * rows * Cout));
+    if (one_by_one) {
+        if (n64) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
+    } else if (n64) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, p);
+    rs_prof_end(ctx, RS_PROF_GEMM, s);
+    RS_CHECK_LAUNCH(ctx, "conv3x3_f32");
     return RS_OK;
 }
 

@@ -238,6 +238,8 @@ int rs_launch_gemm_f32(rs_ctx* ctx, const float* A, int lda, const float* W, int
                        int flags, const float* bias, float alpha, const float* residual, const int32_t* mask_lens,
                        int mask_rows_per_step, int mask_steps, hipStream_t s);
 // the same product for M <= 128 rows (a decoder step's hypothesis rows): N / 16 workgroups, K cut over the four waves (k_f32.hip)
+int rs_launch_conv3x3_f32(rs_ctx* ctx, const float* in, int n_img, int H, int Wd, int C, int OH, int OW, int stride, const float* W, int Cout,
+                          const float* bn_scale, const float* bn_shift, const float* residual, const float* prelu, float* out, int one_by_one, hipStream_t s);
 int rs_launch_gemm_f32_skinny(rs_ctx* ctx, const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K, int flags,
                               const float* bias, const float* residual, hipStream_t s);
 int rs_launch_attention_f32(rs_ctx* ctx, const float* qkv, const float* pos, const float* bias_u, const float* bias_v,
