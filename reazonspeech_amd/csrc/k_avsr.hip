@@ -7,11 +7,11 @@
 // (modeling_avhubert.py:372-391 re-feeds the prefix and re-runs the encoder every step).  Restated in oracle/avsr.py, which is
 // pinned to the reference itself (tests/golden/avsr_ref_*.npz).  What runs where:
 //
-//   dense contractions     every Linear, the 3 x 3 / 1 x 1 convolutions of the ResNet trunk (as channels-last patches) on
+//   dense contractions     every Linear, the 3 x 3 / 1 x 1 convolutions of the ResNet trunk (channels-last patches gathered by the loader) on
 //                          rs_launch_gemm_f32's exact v_mfma_f32_16x16x4_f32 chain: the reference computes float32 and so does
 //                          this path, end to end (there is no reduced-precision mode of this family yet)
-//   Conv3d(1, 64, 5x7x7)   avsr_conv3d_kernel: the five frames' seven input rows of an output row staged in LDS, a thread owns a
-//                          channel and every fourth output pixel, taps from L1; BatchNorm + PReLU in its epilogue
+//   Conv3d(1, 64, 5x7x7)   avsr_conv3d_kernel: the five frames' seven input rows of an output row staged in LDS, the 245 taps (padded to
+//                          280) on the exact-f32 MFMA, a wave per 16 channels; BatchNorm + PReLU in its epilogue
 //   positional conv        avsr_posconv_kernel: grouped Conv1d (kernel 128, 16 groups) with the group's frames in LDS, GELU and the
 //                          residual add fused
 //   attention              avsr_attn_kernel: one wave per (query, head), two passes over the visible keys; serves the encoder
@@ -63,44 +63,51 @@ constexpr int TRUNK_C[5] = {64, 64, 128, 256, 512};
 
 // ---- video front-end ----------------------------------------------------------------------------------------------------------------
 // Conv3d(1, 64, (5, 7, 7), stride (1, 2, 2), padding (2, 3, 3)) + BatchNorm3d (inference form: x * alpha + beta) + PReLU.
-// pixels f32 [B][T][H][W] -> out f32 [B*T][H/2][W/2][64] (channels last).  grid (H/2, T, B), block 256 = 64 channels x 4 pixel
-// phases; a thread owns channel c and output pixels ow = phase, phase + 4, ..  Frames outside [0, T) and pixels outside the image
-// are zeros (the convolution's own padding); padded frames of a clip are ordinary inputs, as in the reference.
+// pixels f32 [B][T][H][W] -> out f32 [B*T][H/2][W/2][64] (channels last).  Frames outside [0, T) and pixels outside the image are zeros
+// (the convolution's own padding); padded frames of a clip are ordinary inputs, as in the reference.
+//
+// On the exact-f32 matrix cores (round 6; the VALU form — a thread per channel and every fourth pixel — ran at 23 TF/s, 10.4 ms per
+// 16 x 10 s): grid (H/2, T, B), a workgroup computes one output row; its 35 input rows (5 frames x 7 rows) sit in LDS with three
+// zero columns of padding on the left and five on the right.  The contraction index is laid out as k' = 8 (7 kt + kh) + kw with the
+// eighth tap of every row a ZERO weight, so that one v_mfma_f32_16x16x4_f32 step s covers taps kw = 4 (s & 1) + 0..3 of input row
+// s / 2 and a lane's patch operand is rows[s / 2][2 ow + 4 (s & 1) + kq]: the address is the lane's base plus a compile-time offset.
+// Wave w owns channels 16 w .. + 15 (the weight operand: 70 registers, loaded once) and walks the row's pixel tiles of 16.  The taps
+// of an output element are added in the order (kt, kh, kw) — the order of the VALU form; the zero tap adds an exact zero.
 __global__ __launch_bounds__(256) void avsr_conv3d_kernel(const float* __restrict__ pix, int T, int H, int W, const float* __restrict__ w /* [245][64] */,
                                                           const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ slope,
                                                           float* __restrict__ out) {
-    constexpr int PXMAX = 12, WMAX = 96;
-    __shared__ float rows[5][7][WMAX + 6];
+    constexpr int WMAX = 96, RP = WMAX + 8;               // row pitch: x = 2 ow + kw <= 2 * 47 + 7
+    __shared__ float rows[35][RP];
     const int oh = blockIdx.x, t = blockIdx.y, b = blockIdx.z, OW = W / 2, OH = H / 2;
-    for (int i = threadIdx.x; i < 5 * 7 * (W + 6); i += 256) {
-        const int kt = i / (7 * (W + 6)), r = i - kt * 7 * (W + 6), kh = r / (W + 6), x = r - kh * (W + 6);
+    for (int i = threadIdx.x; i < 35 * RP; i += 256) {
+        const int r = i / RP, x = i - r * RP, kt = r / 7, kh = r - 7 * kt;
         const int tt = t + kt - 2, ih = 2 * oh + kh - 3, iw = x - 3;
-        rows[kt][kh][x] = (tt >= 0 && tt < T && ih >= 0 && ih < H && iw >= 0 && iw < W) ? pix[(((size_t)b * T + tt) * H + ih) * W + iw] : 0.0f;
+        rows[r][x] = (tt >= 0 && tt < T && ih >= 0 && ih < H && iw >= 0 && iw < W) ? pix[(((size_t)b * T + tt) * H + ih) * W + iw] : 0.0f;
+    }
+    const int lane = threadIdx.x & 63, ct = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    float wreg[70];
+#pragma unroll
+    for (int s = 0; s < 70; ++s) {
+        const int kw = 4 * (s & 1) + kq;
+        const float v = w[((s >> 1) * 7 + (kw < 7 ? kw : 6)) * 64 + 16 * ct + li];
+        wreg[s] = kw < 7 ? v : 0.0f;
     }
     __syncthreads();
-    const int c = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    float acc[PXMAX];
+    const int tiles = (OW + 15) / 16;                      // <= 3
+    const float4 a4 = *reinterpret_cast<const float4*>(alpha + 16 * ct + 4 * kq), b4 = *reinterpret_cast<const float4*>(beta + 16 * ct + 4 * kq);
+    const float4 s4 = *reinterpret_cast<const float4*>(slope + 16 * ct + 4 * kq);
+    float* orow = out + (((size_t)b * T + t) * OH + oh) * OW * 64 + 16 * ct + 4 * kq;
+    for (int pt = 0; pt < tiles; ++pt) {
+        const float* pr = &rows[0][2 * (16 * pt + li) + kq];
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < PXMAX; ++j) acc[j] = 0.0f;
-    for (int kt = 0; kt < 5; ++kt)
-        for (int kh = 0; kh < 7; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 7; ++kw) {
-                const float wv = w[((kt * 7 + kh) * 7 + kw) * 64 + c];
-#pragma unroll
-                for (int j = 0; j < PXMAX; ++j) {
-                    const int ow = ph + 4 * j;
-                    if (ow < OW) acc[j] = fmaf(wv, rows[kt][kh][2 * ow + kw], acc[j]);
-                }
-            }
-    const float a = alpha[c], bb = beta[c], sl = slope[c];
-    float* orow = out + (((size_t)b * T + t) * OH + oh) * OW * 64;
-#pragma unroll
-    for (int j = 0; j < PXMAX; ++j) {
-        const int ow = ph + 4 * j;
+        for (int s = 0; s < 70; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], pr[(s >> 1) * RP + 4 * (s & 1)], acc, 0, 0, 0);
+        const int ow = 16 * pt + li;
         if (ow < OW) {
-            const float v = fmaf(acc[j], a, bb);
-            orow[(size_t)ow * 64 + c] = v >= 0.0f ? v : v * sl;
+            float4 v = make_float4(fmaf(acc[0], a4.x, b4.x), fmaf(acc[1], a4.y, b4.y), fmaf(acc[2], a4.z, b4.z), fmaf(acc[3], a4.w, b4.w));
+            v.x = v.x >= 0.0f ? v.x : v.x * s4.x; v.y = v.y >= 0.0f ? v.y : v.y * s4.y;
+            v.z = v.z >= 0.0f ? v.z : v.z * s4.z; v.w = v.w >= 0.0f ? v.w : v.w * s4.w;
+            *reinterpret_cast<float4*>(orow + (size_t)ow * 64) = v;
         }
     }
 }
