@@ -214,17 +214,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
 // out[M][N] = epilogue(A[M][K] . W[N][K]^T) for a FEW rows (M <= 128: the hypothesis rows of an autoregressive decoder step, k_avsr.hip).
 // gemm_f32_kernel gives such a product N / 128 workgroups that each walk all of K alone — 6 workgroups and 24 dependent global-load
 // round trips for a 768 x 768 layer, ~125 us per launch in profiles/r06_06_f32_avsr_*.  Here a workgroup owns 16 output columns, its
-// four waves split K into four contiguous runs of 16-blocks (weights and rows straight from global memory / L2 as 16-byte pieces,
+// eight waves split K into eight contiguous runs of 16-blocks (weights and rows straight from global memory / L2 as 16-byte pieces,
 // v_mfma_f32_16x16x4_f32, the weight fragment first: a lane holds four consecutive columns of one row), and the partial sums are
-// added in LDS in wave order 0 + 1 + 2 + 3.  N / 16 workgroups, K / 64 steps each.  The summation order differs from
+// added in LDS in wave order 0 + 1 + .. + 7.  N / 16 workgroups, K / 128 blocks per wave.  The summation order differs from
 // gemm_f32_kernel's (K is cut in four): callers that promise bit-identical results across batch sizes must not mix the two.
-// K % 16 == 0, N % 4 == 0.  grid (ceil(N / 16)), block 256
+// K % 16 == 0, N % 4 == 0.  grid (ceil(N / 16)), block 512
+constexpr int SK_WAVES = 8;      // waves of a skinny workgroup = the contiguous runs K is cut into
 template <int MT>
-__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF32 p) {
-    __shared__ __attribute__((aligned(16))) float part[3][MT][64][4];
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_f32_skinny_kernel(GemmF32 p) {
+    __shared__ __attribute__((aligned(16))) float part[SK_WAVES - 1][MT][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int nblk = p.K / 16, per = (nblk + 3) / 4;
+    const int nblk = p.K / 16, per = (nblk + SK_WAVES - 1) / SK_WAVES;
     const int s_lo = wave * per, s_hi = s_lo + per < nblk ? s_lo + per : nblk;
     int nrow = n0 + li;
     nrow = nrow < p.N ? nrow : p.N - 1;
@@ -239,15 +240,26 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF32 p) {
     f32x4_t acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    for (int S = s_lo; S < s_hi; ++S) {
-        const float4 wf = *reinterpret_cast<const float4*>(wp + 16 * S);
-        float4 af[MT];
+    // three 16-blocks per trip, every load of a trip issued before its first product: the loop is a chain of L2 round trips
+    // (29 us per launch with one block per trip: profiles/r06_12_*), so fewer and fatter trips and twice the waves
+    constexpr int U = 3;
+    for (int S = s_lo; S < s_hi; S += U) {
+        float4 wf[U], af[U][MT];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const float4*>(ap[t] + 16 * S);
-#define RS_SK_STEP(E)                                                                              \
+        for (int u = 0; u < U; ++u) {
+            const int Su = S + u < s_hi ? S + u : s_hi - 1;           // (wave-uniform) a block past the run: read again, multiplied by zeros
+            wf[u] = *reinterpret_cast<const float4*>(wp + 16 * Su);
+            if (S + u >= s_hi) wf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[u][t] = *reinterpret_cast<const float4*>(ap[t] + 16 * Su);
+        }
+#define RS_SK_STEP(u, E)                                                                           \
         _Pragma("unroll") for (int t = 0; t < MT; ++t)                                            \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.E, af[t].E, acc[t], 0, 0, 0);
-        RS_SK_STEP(x) RS_SK_STEP(y) RS_SK_STEP(z) RS_SK_STEP(w)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].E, af[u][t].E, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (S + u < s_hi) { RS_SK_STEP(u, x) RS_SK_STEP(u, y) RS_SK_STEP(u, z) RS_SK_STEP(u, w) }
+        }
 #undef RS_SK_STEP
     }
     if (wave > 0) {
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmF32 p) {
         if (m >= p.M) continue;
         f32x4_t a = acc[t];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
+        for (int w = 0; w < SK_WAVES - 1; ++w) {
             const f32x4_t q = *reinterpret_cast<const f32x4_t*>(part[w][t][lane]);
             a[0] += q[0]; a[1] += q[1]; a[2] += q[2]; a[3] += q[3];
         }
@@ -754,12 +766,17 @@ int rs_launch_gemm_f32_skinny(rs_ctx* ctx, const float* A, int lda, const float*
     if (flags & ~(RS_GEMM_BIAS | RS_GEMM_RELU | RS_GEMM_SILU | RS_GEMM_GELU | RS_GEMM_RESIDUAL | RS_GEMM_OUT_F32))
         return rs_fail(ctx, RS_EINVAL, "gemm_f32 (skinny): unsupported flags %d", flags);
     GemmF32 p{A, W, out, bias, residual, nullptr, lda, ldw, ldc, M, N, K, flags, 1.0f, 0, 0};
-    const dim3 grid((N + 15) / 16), block(256);
+    const dim3 grid((N + 15) / 16), block(64 * SK_WAVES);
     rs_prof_begin(ctx, RS_PROF_GEMM, s, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    if (M <= 16) hipLaunchKernelGGL((gemm_f32_skinny_kernel<1>), grid, block, 0, s, p);
-    else if (M <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<2>), grid, block, 0, s, p);
-    else if (M <= 64) hipLaunchKernelGGL((gemm_f32_skinny_kernel<4>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<8>), grid, block, 0, s, p);
+    switch ((M + 15) / 16) {                      // row tiles of 16: only as many as there are rows
+        case 1: hipLaunchKernelGGL((gemm_f32_skinny_kernel<1>), grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_f32_skinny_kernel<2>), grid, block, 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_f32_skinny_kernel<3>), grid, block, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((gemm_f32_skinny_kernel<4>), grid, block, 0, s, p); break;
+        case 5: hipLaunchKernelGGL((gemm_f32_skinny_kernel<5>), grid, block, 0, s, p); break;
+        case 6: hipLaunchKernelGGL((gemm_f32_skinny_kernel<6>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_f32_skinny_kernel<8>), grid, block, 0, s, p); break;
+    }
     rs_prof_end(ctx, RS_PROF_GEMM, s);
     RS_CHECK_LAUNCH(ctx, "gemm_f32_skinny");
     return RS_OK;

@@ -1,3 +1,6 @@
+"""Where an AV-HuBERT generate() call spends its time on the device: encoder, one decoding step (16 and 80 hypothesis rows, with /
+without re-parenting), steps back to back without a host sync, the step + log-softmax + top-k + D2H round trip, whole generate()
+calls (cold, then warm).     python scripts/avsr_step_time.py"""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from reazonspeech_amd.avsr import synthetic_model
@@ -35,6 +38,6 @@ for rows_k in (1, 5):
     top = torch.topk(logp.view(B, -1), k=2 * rows_k)
     x = top[0].cpu().numpy(), top[1].cpu().numpy()
     print("   step + log_softmax + topk + D2H:", (time.perf_counter() - t0) * 1e3, "ms")
-for nb, nt in ((1, 32), (5, 32)):
+for nb, nt in ((1, 32), (5, 32), (1, 32), (5, 32)):
     t0 = time.perf_counter(); out = m.generate(input_values=a, pixel_values=v, padding_mask=mask, num_beams=nb, max_new_tokens=nt); torch.cuda.synchronize()
     print(f"generate beams {nb} tokens {nt}: {(time.perf_counter()-t0)*1e3:.1f} ms total (incl. encode), out len {out.shape[1]}")
