@@ -544,14 +544,22 @@ __global__ __launch_bounds__(256) void avsr_attn_step_kernel(const float* __rest
     for (int c = 0; c < NC; ++c) {
         const int j0 = (c * 4 + wave) * 64;
         const int jn = n_keys - j0 < 64 ? n_keys - j0 : 64;
-        for (int jj = 0; jj < jn; ++jj) {
-            const float p = __shfl(sc[c], jj, 64);
-            if (p != 0.0f) {
-                const float* vr = vbase + (size_t)(j0 + jj) * ldk;
+        // eight value rows per trip, their loads issued before the first product (a masked key weighs 0: its row is multiplied, not
+        // skipped — one branch-free chain of L2 round trips per eight keys instead of one per key)
+        for (int jj = 0; jj < jn; jj += 8) {
+            float vv[8][4], pj[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (lane + 64 * e < hd) acc[e] = fmaf(p, vr[lane + 64 * e], acc[e]);
+            for (int u = 0; u < 8; ++u) {
+                const int ju = jj + u < jn ? jj + u : jn - 1;
+                const float* vr = vbase + (size_t)(j0 + ju) * ldk;
+                pj[u] = jj + u < jn ? __shfl(sc[c], ju, 64) : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vv[u][e] = lane + 64 * e < hd ? vr[lane + 64 * e] : 0.0f;
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(pj[u], vv[u][e], acc[e]);
         }
     }
     if (lane == 0) { part_m[wave] = mx; part_l[wave] = den; }
