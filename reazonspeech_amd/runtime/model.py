@@ -367,9 +367,12 @@ class AsrModel:
                         `from_host`) while the GPU works on the batches before it; the encoder of step i waits for it.
         before_encoder  `before_encoder(i)` on the caller's thread right before batch i's encoder is enqueued.
         enc_streams     encoder lanes: consecutive batches' front-end + encoder alternate between that many HIP streams (each
-                        batch has its own workspace in its buffer set).  None: `encoder_lanes(B)` — one lane for batches that
-                        fill the chip, two for small ones, whose launches leave a third to half of the CUs idle
-                        (profiles/r06_11_small_batch_enc_lanes_ab.txt); needs dec_streams + enc_streams buffer sets."""
+                        batch has its own workspace in its buffer set); needs dec_streams + enc_streams buffer sets.  None:
+                        `encoder_lanes()` = ONE lane ($RS_ENC_STREAMS overrides) — two lanes were measured slower at B = 256
+                        (profiles/r04f_ab_RS_ENC_STREAMS.txt) AND at B = 32 / 64 / 128, whose launches leave a third to half of
+                        the CUs idle (profiles/r06_11_small_batch_enc_lanes_ab.txt).
+                        (Also measured and dropped in round 6: the LAST batch's greedy decode split by rows over the decode
+                        lanes to shorten the drain — 55.15 vs 55.45 ms per step over 20 steps, no gain.)"""
         nb = len(bufs)
         if enc_streams is None:
             enc_streams = self.encoder_lanes(bufs[0].B, nb, dec_streams)
