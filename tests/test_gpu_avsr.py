@@ -152,3 +152,33 @@ def test_the_readme_flow_from_a_pretrained_directory(gpu_device, tmp_path):
     solo = processor(raw_audio=clips[0][0])
     enc = model.avhubert(**solo).last_hidden_state
     assert enc.shape == (1, 25, cfg.encoder_embed_dim) and torch.isfinite(enc).all()
+
+
+def test_long_decoding_crosses_every_attention_form(gpu_device):
+    """README.rst asks for max_new_tokens=256: the self-attention of a decoding step then runs over 1 .. 257 cached keys, and a longer
+    prompt beyond 512 — the step kernel's one- and two-chunk forms and the general kernel.  Teacher-forced logits over 530 positions
+    through the KV cache (and a re-parented cache, the beam-search path) against the oracle's full-prefix forward, toy geometry."""
+    cfg = AVSR_TINY.with_(max_target_positions=640)
+    sd = synthetic_state_dict_avsr(cfg, 3)
+    a, v, mask, _ = synthetic_clips(2, 21, seed=5, ragged=True)
+    model = AVHubertForConditionalGeneration(cfg, sd, device=str(gpu_device))
+    L = 530
+    ids = torch.randint(3, cfg.vocab_size, (2, L), generator=torch.Generator().manual_seed(9))
+    ids[:, 0] = cfg.bos_token_id
+    got = model(input_values=a, pixel_values=v, padding_mask=mask, decoder_input_ids=ids).logits.cpu()
+    with torch.no_grad():
+        enc = oa.encode(cfg, sd, torch.from_numpy(a), torch.from_numpy(v), torch.from_numpy(mask))
+        want = oa.decode_logits(cfg, sd, enc, torch.from_numpy(mask), ids)
+    for lo, hi in ((0, 64), (64, 256), (256, 512), (512, L)):
+        err = float((got[:, lo:hi] - want[:, lo:hi]).abs().max())
+        assert err <= TOL_LOGITS, (lo, hi, err)
+    # beam rows: three hypotheses per clip fed the same tokens, the cache re-gathered by a permutation of a clip's rows every step
+    enc_d = model.avhubert(input_values=a, pixel_values=v, padding_mask=mask).last_hidden_state
+    dec = model.dev.decoding(enc_d, mask, 3, 300)
+    perm = np.array([1, 2, 0, 5, 3, 4])
+    for t in range(290):
+        lg = dec.step(np.repeat(ids[:, t].numpy(), 3), t, perm if t else None)
+    torch.cuda.synchronize()
+    lg = lg.cpu().view(2, 3, -1)
+    for r in range(3):
+        assert float((lg[:, r] - want[:, 289]).abs().max()) <= TOL_LOGITS, r
