@@ -99,6 +99,10 @@ __global__ void alsd_init_kernel(DecodeState st, AlsdState as, const int32_t* __
 // label q of a candidate = its parent's label q, or the candidate's own token at the end
 __device__ __forceinline__ int cand_len(int parent_len, int tok) { return parent_len + (tok >= 0 ? 1 : 0); }
 
+// NVR > 0: the logits row of a hypothesis is read ONCE into NVR registers per lane (V <= 64 NVR), every load in flight before the
+// first comparison; the scan for the maximum / the W best and the exp-sum then walk the registers in the same ascending order as
+// the two memory passes of the NVR = 0 form — identical arithmetic, one memory round trip instead of two chains of 47.
+template <int NVR>
 __global__ __launch_bounds__(64 * MAX_BEAM) void alsd_select_kernel(
     DecodeState st, AlsdState as, const float* __restrict__ zbuf, int zstride, const int32_t* __restrict__ enc_lens, int B, int W,
     int V, int blank, int i, double ratio, int abs_len, int score_norm, int merge, int out_cap, int32_t* __restrict__ ids,
@@ -142,8 +146,7 @@ __global__ __launch_bounds__(64 * MAX_BEAM) void alsd_select_kernel(
             int tv[MAX_BEAM];
 #pragma unroll
             for (int k = 0; k < MAX_BEAM; ++k) { tz[k] = -INFINITY; tv[k] = -1; }
-            for (int v = lane; v < V; v += 64) {
-                const float zv = zr[v];
+            auto scan = [&](int v, float zv) {
                 if (zv > m) m = zv;
                 if (v != blank) {
                     float cz = zv;
@@ -156,15 +159,35 @@ __global__ __launch_bounds__(64 * MAX_BEAM) void alsd_select_kernel(
                             tz[k] = cz; tv[k] = cv;
                             cz = sz; cv = sv;
                             ins = true;
-                            if (cv < 0) break;
                         }
                     }
                 }
+            };
+            float zreg[NVR > 0 ? NVR : 1];
+            if constexpr (NVR > 0) {
+#pragma unroll
+                for (int q = 0; q < NVR; ++q) {
+                    const int v = lane + 64 * q;
+                    zreg[q] = zr[v < V ? v : V - 1];
+                }
+#pragma unroll
+                for (int q = 0; q < NVR; ++q) {
+                    const int v = lane + 64 * q;
+                    if (v < V) scan(v, zreg[q]);
+                }
+            } else {
+                for (int v = lane; v < V; v += 64) scan(v, zr[v]);
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off, 64); if (o > m) m = o; }
             float sum = 0.0f;
-            for (int v = lane; v < V; v += 64) sum = sum + rs_expf(zr[v] - m);
+            if constexpr (NVR > 0) {
+#pragma unroll
+                for (int q = 0; q < NVR; ++q)
+                    if (lane + 64 * q < V) sum = sum + rs_expf(zreg[q] - m);
+            } else {
+                for (int v = lane; v < V; v += 64) sum = sum + rs_expf(zr[v] - m);
+            }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off, 64);
             sum = __shfl(sum, 0, 64);
@@ -452,7 +475,9 @@ int rs_rnnt_alsd_impl(rs_ctx* ctx, const float* joint_enc, const int32_t* enc_le
         for (int c = 0; c < CHUNK && i <= max_steps; ++c, ++i) {
             const int p = i & 1, pn = p ^ 1;
             if (int rc = rs_rnnt_launch_joint_logits(ctx, &st[p], joint_enc, rows, tp_max, W, i, s); rc != RS_OK) { rs_prof_end(ctx, RS_PROF_DECODE, s); return rc; }
-            hipLaunchKernelGGL(alsd_select_kernel, dim3(B), dim3(64 * W), 0, s, st[p], as, zbuf, zstride, enc_lens, B, W, V,
+            if (V <= 64 * 48) hipLaunchKernelGGL((alsd_select_kernel<48>), dim3(B), dim3(64 * W), 0, s, st[p], as, zbuf, zstride, enc_lens, B, W, V,
+                               d.blank_id, i, ratio, abs_len, score_norm, merge, out_cap, ids, steps, n_ids, scores);
+            else hipLaunchKernelGGL((alsd_select_kernel<0>), dim3(B), dim3(64 * W), 0, s, st[p], as, zbuf, zstride, enc_lens, B, W, V,
                                d.blank_id, i, ratio, abs_len, score_norm, merge, out_cap, ids, steps, n_ids, scores);
             hipLaunchKernelGGL(alsd_reorder_kernel, dim3(rows), dim3(256), 0, s, as, pn, W, rows, L, H, J, hset[p], cset[p],
                                gset[p], hset[pn], cset[pn], gset[pn]);
