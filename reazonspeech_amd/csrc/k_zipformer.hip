@@ -208,6 +208,127 @@ __global__ __launch_bounds__(256) void k2_im2col_kernel(const uint16_t* __restri
     }
 }
 
+// ConvNeXt's two pointwise convolutions as ONE kernel (round 6): out = bf16(res + W2 . swooshL(W1 . a + b1) + b2) for rows of C = 128
+// channels, hidden width 3 C = 384.  As two GEMM launches the [rows][384] hidden tensor (2.2 GB at the benchmark batch) was written and
+// read back: 1.85 + 1.13 ms per batch.  Here it never leaves the CU.  Both weight matrices are only 96 KB each, but 160 KB of LDS cannot
+// hold both next to the operand tiles — and a row tile's stages are shorter than one L2 round trip, so streaming them per tile stalls.
+// So the WEIGHTS live in registers, cut over the eight waves of a persistent workgroup: wave w owns hidden channels 48 w .. + 47 of W1
+// (12 fragments) and output channels 16 w .. + 15 of W2 (12 fragments), 96 VGPRs for the whole launch; LDS holds the row tile (two
+// buffers of 128 x 128 bf16, filled by global_load_lds one tile ahead) and the hidden tile (128 x 384 bf16), through which the waves
+// exchange what each computed for ALL 128 rows.  Per tile: stage 1 (wave: 3 x 8 output tiles, K = 128) -> + b1, SwooshL, bf16 -> hidden
+// tile -> barrier -> stage 2 (wave: 1 x 8 output tiles, K = 384) -> + b2 + residual -> bf16 through the dead row-tile buffer ->
+// whole-row stores.  The K order of both products and every rounding point are those of the two GEMM launches: bit-identical
+// ($RS_K2_CNX_FUSED=0 runs the launches; tests compare the two).  grid = CUs, block 512, 160 KB of dynamic LDS.
+__device__ __forceinline__ void cx_glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+constexpr int CX_C = 128, CX_H = 384, CX_ROWS = 128;
+constexpr int CX_A_BYTES = CX_ROWS * CX_C * 2, CX_H_BYTES = CX_ROWS * CX_H * 2, CX_LDS = 2 * CX_A_BYTES + CX_H_BYTES;
+__global__ __launch_bounds__(512) void k2_cnx_pw_fused_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W1, const float* __restrict__ b1,
+                                                              const uint16_t* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ res,
+                                                              uint16_t* __restrict__ out, long long rows) {
+    extern __shared__ __attribute__((aligned(16))) char cx_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cx_smem;
+    char* Hs = cx_smem + 2 * CX_A_BYTES;
+    const long long n_tiles = (rows + CX_ROWS - 1) / CX_ROWS;
+    // the wave's weight fragments, for the whole launch: lane (channel li of a 16-tile, k group kq) holds 8 consecutive k
+    bf16x8_t w1[3][4], w2[12];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            w1[t][ks] = *reinterpret_cast<const bf16x8_t*>(W1 + (size_t)(48 * wave + 16 * t + li) * CX_C + 32 * ks + 8 * kq);
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) w2[ks] = *reinterpret_cast<const bf16x8_t*>(W2 + (size_t)(16 * wave + li) * CX_H + 32 * ks + 8 * kq);
+    float4 bias1[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bias1[t] = *reinterpret_cast<const float4*>(b1 + 48 * wave + 16 * t + 4 * kq);
+    const float4 bias2 = *reinterpret_cast<const float4*>(b2 + 16 * wave + 4 * kq);
+    // row tile -> LDS buffer: 32 DMA instructions of 4 rows (1 KB), four per wave; 16-byte pieces XOR-swizzled by the row
+    auto issue_a = [&](long long tile, int buf) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int q = wave + 8 * jj;
+            const int r = 4 * q + (lane >> 4), pc = lane & 15;
+            long long gr = tile * CX_ROWS + r;
+            gr = gr < rows ? gr : rows - 1;
+            // (the matrix can exceed 4 GiB: the tile's base goes into the scalar address, the lane offset stays below 32 KiB)
+            const long long gr0 = tile * CX_ROWS < rows ? tile * CX_ROWS : rows - 1;
+            const unsigned voff = (unsigned)((gr - gr0) * (CX_C * 2) + ((pc ^ (r & 15)) << 4));
+            cx_glds16(voff, reinterpret_cast<const char*>(A) + gr0 * (CX_C * 2), lds0 + buf * CX_A_BYTES + q * 1024);
+        }
+    };
+    long long tile = blockIdx.x;
+    if (tile < n_tiles) issue_a(tile, 0);
+    int buf = 0;
+    for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this tile's rows (and the previous tile's stores) are done
+        __builtin_amdgcn_s_barrier();                                // ... for every wave; the hidden tile and the other buffer are free
+        asm volatile("" ::: "memory");
+        if (tile + gridDim.x < n_tiles) issue_a(tile + gridDim.x, buf ^ 1);
+        const char* As = cx_smem + buf * CX_A_BYTES;
+        // ---- stage 1: hidden channels 48 wave .. + 47 of all 128 rows
+#pragma unroll 2
+        for (int mt = 0; mt < 8; ++mt) {
+            const int row = 16 * mt + li;
+            f32x4_t acc[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(As + row * (CX_C * 2) + (((4 * ks + kq) ^ (row & 15)) << 4));
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[t][ks], af, acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const u16x4_t hv = pack_bf16x4(swoosh_l_f(acc[t][0] + bias1[t].x), swoosh_l_f(acc[t][1] + bias1[t].y),
+                                               swoosh_l_f(acc[t][2] + bias1[t].z), swoosh_l_f(acc[t][3] + bias1[t].w));
+                const int c = 6 * wave + 2 * t + (kq >> 1);          // 16-byte piece of the hidden row that holds channels 48 w + 16 t + 4 kq ..
+                const int cs = (c & ~15) | ((c & 15) ^ (row & 15));
+                *reinterpret_cast<u16x4_t*>(Hs + row * (CX_H * 2) + (cs << 4) + 8 * (kq & 1)) = hv;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // the hidden tile is complete; nobody reads the row tile any more
+        asm volatile("" ::: "memory");
+        // ---- stage 2: output channels 16 wave .. + 15 of all 128 rows
+        char* Os = cx_smem + buf * CX_A_BYTES;                       // the dead row tile: the output tile's staging
+#pragma unroll 2
+        for (int mt = 0; mt < 8; ++mt) {
+            const int row = 16 * mt + li;
+            long long gr = tile * CX_ROWS + row;
+            gr = gr < rows ? gr : rows - 1;
+            const float4 r4 = *reinterpret_cast<const float4*>(res + gr * CX_C + 16 * wave + 4 * kq);
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 12; ++ks) {
+                const int c = 4 * ks + kq;
+                const int cs = (c & ~15) | ((c & 15) ^ (row & 15));
+                const bf16x8_t hf = *reinterpret_cast<const bf16x8_t*>(Hs + row * (CX_H * 2) + (cs << 4));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[ks], hf, acc, 0, 0, 0);
+            }
+            // the residual GEMM's epilogue: + bias, (* alpha = 1,) + residual, round to bf16
+            const u16x4_t ov = pack_bf16x4((acc[0] + bias2.x) * 1.0f + r4.x, (acc[1] + bias2.y) * 1.0f + r4.y, (acc[2] + bias2.z) * 1.0f + r4.z,
+                                           (acc[3] + bias2.w) * 1.0f + r4.w);
+            const int c = 2 * wave + (kq >> 1);
+            *reinterpret_cast<u16x4_t*>(Os + row * (CX_C * 2) + ((c ^ (row & 15)) << 4) + 8 * (kq & 1)) = ov;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // the output tile is complete
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int pss = 0; pss < 4; ++pss) {                          // wave: rows 16 wave .. + 15 as whole 256-byte rows
+            const int row = 16 * wave + 4 * pss + (lane >> 4), pc = lane & 15;
+            const uint4 v = *reinterpret_cast<const uint4*>(Os + row * (CX_C * 2) + ((pc ^ (row & 15)) << 4));
+            const long long gr = tile * CX_ROWS + row;
+            if (gr < rows) *reinterpret_cast<uint4*>(out + gr * CX_C + 8 * pc) = v;
+        }
+    }
+}
+
 // ConvNeXt depthwise 7 x 7 (padding 3) over (time, frequency), channels last.  a2 f32 [B][T3][F3][C] -> bf16 same shape.
 // Frames at or past the utterance's own length are zeros (the reference's single-utterance call ends there).
 // A workgroup makes CNX_TT consecutive frames of one utterance; a thread owns one channel and FH consecutive frequencies and
@@ -1338,9 +1459,24 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, 0.0);
     hipLaunchKernelGGL(k2_cnx_dw_kernel<10>, dim3((T3 + CNX_TT - 1) / CNX_TT, B), dim3(256), 0, s, a2, lens3, T3, F3, c3, k.cnx_dw_w, k.cnx_dw_b, dwo);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
+    static const bool cnx_fused = [] { const char* e = getenv("RS_K2_CNX_FUSED"); return e ? atoi(e) != 0 : true; }();
+    if (cnx_fused && c3 == CX_C) {
+        // both pointwise convolutions in one launch, the hidden tensor stays on the CU; result (bf16) in place over dwo
+        RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)k2_cnx_pw_fused_kernel, CX_LDS));
+        if (ctx->n_cus <= 0) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
+            ctx->n_cus = n;
+        }
+        const long long n_tiles = (rows3 + CX_ROWS - 1) / CX_ROWS;
+        hipLaunchKernelGGL(k2_cnx_pw_fused_kernel, dim3((unsigned)(n_tiles < ctx->n_cus ? n_tiles : ctx->n_cus)), dim3(512), CX_LDS, s, dwo, k.cnx_pw1_w, k.cnx_pw1_b,
+                           k.cnx_pw2_w, k.cnx_pw2_b, a2, dwo, rows3);
+        RS_CHECK_LAUNCH(ctx, "zipformer ConvNeXt pointwise pair");
+    } else {
     RS_TRY(gemm(dwo, c3, k.cnx_pw1_w, c3, hbuf, 3 * c3, rows3, 3 * c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHL, k.cnx_pw1_b, nullptr));
     // (its bf16 copy lands in dwo, [B*T3][F3 * c3] in (f, c) order: the operand of `out`)
     RS_TRY(gemm(hbuf, 3 * c3, k.cnx_pw2_w, 3 * c3, a2, c3, rows3, c3, RES, k.cnx_pw2_b, a2, dwo));
+    }
     const long long M3 = (long long)B * T3;
     const int d0 = d.encoder_dim[0];
     float* emb = x0;                       // encoder_embed's output; stack 0 reads it as `prev`

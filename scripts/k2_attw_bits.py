@@ -1,5 +1,6 @@
-"""The one-sweep and the three-sweep attention-weights kernels of the Zipformer path give the same BITS: run once per form (the knob is
-read once per process) and compare the dumps.
+"""Alternative kernel forms of the Zipformer path give the same BITS (the one-sweep / three-sweep attention-weights kernels:
+$RS_K2_ATTW_SWEEPS=3; the fused / two-launch ConvNeXt pointwise pair: $RS_K2_CNX_FUSED=0): run once per form (the knobs are read once
+per process) and compare the dumps.
     python scripts/k2_attw_bits.py dump gpurun_out/k2_a.pt ; RS_K2_ATTW_SWEEPS=3 python scripts/k2_attw_bits.py dump gpurun_out/k2_b.pt
     python scripts/k2_attw_bits.py cmp gpurun_out/k2_a.pt gpurun_out/k2_b.pt"""
 import os
@@ -23,7 +24,7 @@ if sys.argv[1] == "dump":
     am.run_device(buf)
     torch.cuda.synchronize()
     got = am.collect(buf)
-    torch.save({"joint_enc": buf.joint_enc.cpu(), "ids": got.ids, "frames": got.frames, "form": os.environ.get("RS_K2_ATTW_SWEEPS", "1")}, sys.argv[2])
+    torch.save({"joint_enc": buf.joint_enc.cpu(), "ids": got.ids, "frames": got.frames, "form": os.environ.get("RS_K2_ATTW_SWEEPS", "1") + "/cnx" + os.environ.get("RS_K2_CNX_FUSED", "1")}, sys.argv[2])
     print("dumped", sys.argv[2], "form", os.environ.get("RS_K2_ATTW_SWEEPS", "1"), "tokens", sum(len(x) for x in got.ids))
 else:
     a, b = torch.load(sys.argv[2]), torch.load(sys.argv[3])
