@@ -263,11 +263,24 @@ __global__ __launch_bounds__(512) void k2_cnx_pw_fused_kernel(const uint16_t* __
     long long tile = blockIdx.x;
     if (tile < n_tiles) issue_a(tile, 0);
     int buf = 0;
+    bool first = true;
     for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this tile's rows (and the previous tile's stores) are done
+        // this tile's rows have landed: the only younger entries of the (in-order) queue are the previous tile's four output stores
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        first = false;
         __builtin_amdgcn_s_barrier();                                // ... for every wave; the hidden tile and the other buffer are free
         asm volatile("" ::: "memory");
         if (tile + gridDim.x < n_tiles) issue_a(tile + gridDim.x, buf ^ 1);
+        // the residual rows of stage 2, asked for now: a 1.5 GB stream that no cache holds — loaded where they are used they cost a DRAM
+        // round trip per 16 rows (the first version: 1.50 ms per batch)
+        float4 rres[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            long long gr = tile * CX_ROWS + 16 * mt + li;
+            gr = gr < rows ? gr : rows - 1;
+            rres[mt] = *reinterpret_cast<const float4*>(res + gr * CX_C + 16 * wave + 4 * kq);
+        }
         const char* As = cx_smem + buf * CX_A_BYTES;
         // ---- stage 1: hidden channels 48 wave .. + 47 of all 128 rows
 #pragma unroll 2
@@ -296,12 +309,10 @@ __global__ __launch_bounds__(512) void k2_cnx_pw_fused_kernel(const uint16_t* __
         asm volatile("" ::: "memory");
         // ---- stage 2: output channels 16 wave .. + 15 of all 128 rows
         char* Os = cx_smem + buf * CX_A_BYTES;                       // the dead row tile: the output tile's staging
-#pragma unroll 2
+#pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             const int row = 16 * mt + li;
-            long long gr = tile * CX_ROWS + row;
-            gr = gr < rows ? gr : rows - 1;
-            const float4 r4 = *reinterpret_cast<const float4*>(res + gr * CX_C + 16 * wave + 4 * kq);
+            const float4 r4 = rres[mt];
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 12; ++ks) {
@@ -1459,7 +1470,8 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, 0.0);
     hipLaunchKernelGGL(k2_cnx_dw_kernel<10>, dim3((T3 + CNX_TT - 1) / CNX_TT, B), dim3(256), 0, s, a2, lens3, T3, F3, c3, k.cnx_dw_w, k.cnx_dw_b, dwo);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
-    static const bool cnx_fused = [] { const char* e = getenv("RS_K2_CNX_FUSED"); return e ? atoi(e) != 0 : true; }();
+    static const bool cnx_fused_env = [] { const char* e = getenv("RS_K2_CNX_FUSED"); return e ? atoi(e) != 0 : true; }();
+    const bool cnx_fused = ctx->k2_cnx_fused < 0 ? cnx_fused_env : ctx->k2_cnx_fused != 0;
     if (cnx_fused && c3 == CX_C) {
         // both pointwise convolutions in one launch, the hidden tensor stays on the CU; result (bf16) in place over dwo
         RS_TRY(rs_ensure_dynamic_lds(ctx, (const void*)k2_cnx_pw_fused_kernel, CX_LDS));

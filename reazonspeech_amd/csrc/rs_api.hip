@@ -327,6 +327,11 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
         ctx->precision_f32 = value != 0;
         return RS_OK;
     }
+    if (!strcmp(key, "k2_cnx_fused")) {            // the ConvNeXt pointwise pair as one kernel (1, default) or as two GEMM launches (0): same bits
+        if (!ctx->k2) return rs_fail(ctx, RS_EINVAL, "option 'k2_cnx_fused' applies to a Zipformer context only");
+        ctx->k2_cnx_fused = value != 0;
+        return RS_OK;
+    }
     if (ctx->k2) return rs_fail(ctx, RS_EINVAL, "option '%s' does not apply to a Zipformer context", key);
     if (!strcmp(key, "fuse_glu")) {
         if (value < 0 || value > 1) return rs_fail(ctx, RS_EINVAL, "fuse_glu must be 0 or 1");

@@ -162,6 +162,22 @@ def test_159m_geometry_vs_oracle(gpu_device):
     assert exact.ids == screened.ids == got.ids and exact.frames == screened.frames == got.frames
 
 
+def test_convnext_pointwise_pair_as_one_kernel_is_bit_identical(gpu_device):
+    """csrc/k_zipformer.hip k2_cnx_pw_fused_kernel (weights register-resident over a persistent workgroup's waves, the hidden tile in
+    LDS) against the two GEMM launches it replaces, at the published geometry (embed channels 128): the encoder projection of ragged
+    utterances, bits"""
+    model, sd = build(ZIPFORMER_159M, 0)
+    waves = ragged_waves(5, 4.0, 31, 0.7)
+    outs = {}
+    for form in (1, 0):
+        model.am.ctx.set_option("k2_cnx_fused", form)
+        buf, _, _, _, _ = run(model, waves, taps=False)
+        outs[form] = buf.joint_enc.clone()
+    model.am.ctx.set_option("k2_cnx_fused", 1)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[1].abs().max()) > 0.1
+
+
 def test_model_object_answers_sherpa_onnx_call_forms(tiny):
     """create_stream / accept_waveform / decode_stream / result.{tokens, timestamps, text} (pkg/k2-asr/src/transcribe.py:36-45) and
     the package's transcribe(): padding of 0.9 s on both sides, timestamps = frame x 0.04 s, text = the tokens joined"""
