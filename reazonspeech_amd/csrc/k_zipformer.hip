@@ -208,6 +208,80 @@ __global__ __launch_bounds__(256) void k2_im2col_kernel(const uint16_t* __restri
     }
 }
 
+// conv2 = Conv2d(32, 128, 3, stride (1, 2)) + SwooshR as ONE kernel (round 6; the pattern of k2_cnx_pw_fused_kernel below): until now a
+// patch matrix [rows][320] went through HBM (k2_im2col_kernel, 1.8 GB at the benchmark batch) into a GEMM launch: 0.78 + 1.07 ms.
+// Here a persistent workgroup gathers the 3 x 3 x 32 patches of 128 output positions straight into LDS with global_load_lds (36
+// 16-byte pieces per row, two tile buffers of 72 KB, the next tile's gather in flight under this tile's products), the weights
+// (128 x 288 bf16) live in registers, cut over the eight waves by output channel (9 fragments each), and a wave multiplies its 16
+// channels against all 128 rows.  K = 288 is nine 32-deep steps; the GEMM's tenth step (its K is padded to 320) multiplies zeros:
+// same sums.  Epilogue of the GEMM launch: + bias, SwooshR, float32 out.  $RS_K2_CONV2_FUSED=0 / rs_set_option("k2_conv2_fused", 0)
+// runs the two launches; a test compares the bits.  grid = CUs, block 512, 144 KB of dynamic LDS.
+constexpr int C2_K = 288, C2_ROWB = C2_K * 2, C2_TILE = 128 * C2_ROWB, C2_LDS = 2 * C2_TILE;
+__global__ __launch_bounds__(512) void k2_conv2_fused_kernel(const uint16_t* __restrict__ a1, int T2, int F2, int T3, int F3, const uint16_t* __restrict__ W, int ldw,
+                                                             const float* __restrict__ bias, float* __restrict__ out, long long rows) {
+    extern __shared__ __attribute__((aligned(16))) char c2_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)c2_smem;
+    const long long n_tiles = (rows + 127) / 128;
+    bf16x8_t wf[9];
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(W + (size_t)(16 * wave + li) * ldw + 32 * ks + 8 * kq);
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + 16 * wave + 4 * kq);
+    // 128 rows x 36 pieces = 72 DMA instructions of 64 consecutive pieces, nine per wave.  Piece pc of row r (physical position in
+    // LDS) holds logical piece (pc & ~3) | ((pc & 3) ^ ((r >> 2) & 3)): rows are 576 bytes apart, i.e. rows r and r + 4 start in the
+    // same bank group, and the XOR spreads the sixteen rows of a fragment read over all sixteen 16-byte slots of a bank row.
+    auto issue_tile = [&](long long tile, int buf) {
+#pragma unroll
+        for (int jj = 0; jj < 9; ++jj) {
+            const int q = wave + 8 * jj;
+            const int g = 64 * q + lane, r = g / 36, pc = g - 36 * r;
+            const int piece = (pc & ~3) | ((pc & 3) ^ ((r >> 2) & 3));
+            long long row = tile * 128 + r;
+            row = row < rows ? row : rows - 1;
+            const int f3 = (int)(row % F3);
+            const long long bt = row / F3;
+            const int t3 = (int)(bt % T3);
+            const long long b = bt / T3;
+            const int tap = piece >> 2, c = piece & 3, kh = tap / 3, kw = tap - 3 * kh;
+            const long long src = (((b * T2 + t3 + kh) * F2 + 2 * f3 + kw) * 32 + 8 * c) * 2;      // bytes into a1 (may exceed 4 GiB: 64-bit address)
+            // per-lane 64-bit address: global_load_lds with a vector address (no scalar base)
+            const char* ptr = reinterpret_cast<const char*>(a1) + src;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(ptr), "s"(lds0 + buf * C2_TILE + q * 1024) : "memory");
+        }
+    };
+    long long tile = blockIdx.x;
+    if (tile < n_tiles) issue_tile(tile, 0);
+    int buf = 0;
+    bool first = true;
+    for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        // this tile's patches have landed; the previous tile's eight output stores (younger in the in-order queue) may still be in flight
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tile + gridDim.x < n_tiles) issue_tile(tile + gridDim.x, buf ^ 1);
+        const char* Ps = c2_smem + buf * C2_TILE;
+#pragma unroll 2
+        for (int mt = 0; mt < 8; ++mt) {
+            const int row = 16 * mt + li;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                const int c = 4 * ks + kq;
+                const int pc = (c & ~3) | ((c & 3) ^ ((row >> 2) & 3));
+                const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(Ps + row * C2_ROWB + (pc << 4));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], pf, acc, 0, 0, 0);
+            }
+            const long long gr = tile * 128 + row;
+            const float4 v = make_float4(swoosh_r_f(acc[0] + b4.x) * 1.0f, swoosh_r_f(acc[1] + b4.y) * 1.0f, swoosh_r_f(acc[2] + b4.z) * 1.0f,
+                                         swoosh_r_f(acc[3] + b4.w) * 1.0f);
+            if (gr < rows) *reinterpret_cast<float4*>(out + gr * 128 + 16 * wave + 4 * kq) = v;
+        }
+    }
+}
+
 // ConvNeXt's two pointwise convolutions as ONE kernel (round 6): out = bf16(res + W2 . swooshL(W1 . a + b1) + b2) for rows of C = 128
 // channels, hidden width 3 C = 384.  As two GEMM launches the [rows][384] hidden tensor (2.2 GB at the benchmark batch) was written and
 // read back: 1.85 + 1.13 ms per batch.  Here it never leaves the CU.  Both weight matrices are only 96 KB each, but 160 KB of LDS cannot
@@ -1463,10 +1537,27 @@ int rs_k2_encoder_forward_impl(rs_ctx* ctx, const float* feats, const int32_t* n
         hipLaunchKernelGGL(k2_conv1_kernel, dim3(pl.T2, B), dim3(256), lds, s, a0, pl.T1, pl.F, c1, pl.T2, pl.F2, c2, k.conv1_w, k.conv1_b, a1);
     }
     const long long rows3 = (long long)B * T3 * F3;
+    static const bool conv2_fused_env = [] { const char* e = getenv("RS_K2_CONV2_FUSED"); return e ? atoi(e) != 0 : true; }();
+    const bool conv2_fused = (ctx->k2_conv2_fused < 0 ? conv2_fused_env : ctx->k2_conv2_fused != 0) && c2 == 32 && c3 == 128;
+    if (ctx->n_cus <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
+        ctx->n_cus = n;
+    }
+    if (conv2_fused) {
+        // patches gathered into LDS, weights in registers: no patch matrix in HBM
+        if (int rc2 = rs_ensure_dynamic_lds(ctx, (const void*)k2_conv2_fused_kernel, C2_LDS); rc2 != RS_OK) { rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s); return rc2; }
+        const long long n_tiles = (rows3 + 127) / 128;
+        hipLaunchKernelGGL(k2_conv2_fused_kernel, dim3((unsigned)(n_tiles < ctx->n_cus ? n_tiles : ctx->n_cus)), dim3(512), C2_LDS, s, a1, pl.T2, pl.F2, T3, F3, k.conv2_w,
+                           pl.Kp, k.conv2_b, a2, rows3);
+        rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
+        RS_CHECK_LAUNCH(ctx, "zipformer encoder_embed convs");
+    } else {
     hipLaunchKernelGGL(k2_im2col_kernel, dim3((unsigned)((rows3 + 3) / 4)), dim3(256), 0, s, a1, pl.T2, pl.F2, c2, T3, F3, pl.Kp, rows3, col);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);
     RS_CHECK_LAUNCH(ctx, "zipformer encoder_embed convs");
     RS_TRY(gemm(col, pl.Kp, k.conv2_w, pl.Kp, a2, c3, rows3, c3, RS_GEMM_BIAS | RS_GEMM_SWOOSHR | RS_GEMM_OUT_F32, k.conv2_b, nullptr));
+    }
     rs_prof_begin(ctx, RS_PROF_SUBSAMPLE, s, 0.0, 0.0);
     hipLaunchKernelGGL(k2_cnx_dw_kernel<10>, dim3((T3 + CNX_TT - 1) / CNX_TT, B), dim3(256), 0, s, a2, lens3, T3, F3, c3, k.cnx_dw_w, k.cnx_dw_b, dwo);
     rs_prof_end(ctx, RS_PROF_SUBSAMPLE, s);

@@ -327,6 +327,11 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
         ctx->precision_f32 = value != 0;
         return RS_OK;
     }
+    if (!strcmp(key, "k2_conv2_fused")) {          // conv2 with its patches gathered into LDS (1, default) or as patch matrix + GEMM launch (0): same bits
+        if (!ctx->k2) return rs_fail(ctx, RS_EINVAL, "option 'k2_conv2_fused' applies to a Zipformer context only");
+        ctx->k2_conv2_fused = value != 0;
+        return RS_OK;
+    }
     if (!strcmp(key, "k2_cnx_fused")) {            // the ConvNeXt pointwise pair as one kernel (1, default) or as two GEMM launches (0): same bits
         if (!ctx->k2) return rs_fail(ctx, RS_EINVAL, "option 'k2_cnx_fused' applies to a Zipformer context only");
         ctx->k2_cnx_fused = value != 0;

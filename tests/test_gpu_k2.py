@@ -164,18 +164,20 @@ def test_159m_geometry_vs_oracle(gpu_device):
 
 def test_convnext_pointwise_pair_as_one_kernel_is_bit_identical(gpu_device):
     """csrc/k_zipformer.hip k2_cnx_pw_fused_kernel (weights register-resident over a persistent workgroup's waves, the hidden tile in
-    LDS) against the two GEMM launches it replaces, at the published geometry (embed channels 128): the encoder projection of ragged
-    utterances, bits"""
+    LDS) against the two GEMM launches it replaces, and k2_conv2_fused_kernel (3 x 3 x 32 patches gathered into LDS) against the patch
+    matrix + GEMM launch, at the published geometry (embed channels 32 / 128): the encoder projection of ragged utterances, bits"""
     model, sd = build(ZIPFORMER_159M, 0)
     waves = ragged_waves(5, 4.0, 31, 0.7)
     outs = {}
-    for form in (1, 0):
-        model.am.ctx.set_option("k2_cnx_fused", form)
+    for form in ((1, 1), (0, 1), (1, 0), (0, 0)):           # (ConvNeXt pair fused, conv2 fused)
+        model.am.ctx.set_option("k2_cnx_fused", form[0])
+        model.am.ctx.set_option("k2_conv2_fused", form[1])
         buf, _, _, _, _ = run(model, waves, taps=False)
         outs[form] = buf.joint_enc.clone()
     model.am.ctx.set_option("k2_cnx_fused", 1)
-    assert torch.equal(outs[0], outs[1])
-    assert float(outs[1].abs().max()) > 0.1
+    model.am.ctx.set_option("k2_conv2_fused", 1)
+    assert all(torch.equal(outs[f], outs[(0, 0)]) for f in outs)
+    assert float(outs[(1, 1)].abs().max()) > 0.1
 
 
 def test_model_object_answers_sherpa_onnx_call_forms(tiny):
