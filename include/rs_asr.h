@@ -281,7 +281,10 @@ int rs_stream_destroy(void* stream);
  *                        "<name>.f32" tensors: float32 copies of every bf16 GEMM weight (same layout; "L{i}.conv.pw1.w.f32" /
  *                        ".b.f32" in NeMo's own row order, values then gates) and "pos.table.f32"; rs_workspace_bytes
  *                        accounts for the mode once they are registered.  ~20x slower; front-end and decode are float32 in
- *                        both modes. */
+ *                        both modes.
+ *   "k2_cnx_fused", "k2_conv2_fused"   (Zipformer contexts; default 1) the encoder_embed's ConvNeXt pointwise pair as one kernel /
+ *                        its 32 -> 128 convolution with the patches gathered into LDS; 0 = the GEMM launches they replace.  Both
+ *                        forms give the same bits (tests/test_gpu_k2.py): the switch exists for that comparison. */
 int rs_set_option(rs_ctx* ctx, const char* key, int value);
 
 /* Parity taps (tests only; no reference counterpart — NeMo exposes intermediate activations through
