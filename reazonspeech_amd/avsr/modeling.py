@@ -43,9 +43,9 @@ class BeamOutput:
 class AVHubertModel:
     """the encoder (modeling_avhubert.py:119-213)"""
 
-    def __init__(self, config: AvsrConfig, state_dict=None, device="cuda", _dev=None):
+    def __init__(self, config: AvsrConfig, state_dict=None, device="cuda", _dev=None, products=None):
         self.config = config
-        self.dev = _dev if _dev is not None else AvsrDevice(config, state_dict, device)
+        self.dev = _dev if _dev is not None else AvsrDevice(config, state_dict, device, products=products)
         self.device = self.dev.device
 
     def forward(self, input_values=None, pixel_values=None, padding_mask=None, **kwargs):
@@ -61,20 +61,21 @@ class AVHubertModel:
 
 
 class AVHubertForConditionalGeneration:
-    def __init__(self, config: AvsrConfig, state_dict, device="cuda"):
+    def __init__(self, config: AvsrConfig, state_dict, device="cuda", products=None):
+        """products: None ($REAZONSPEECH_AVSR_PRODUCTS, default "exact") | "exact" | "x3" — runtime/avsr_model.py set_products"""
         if config.vocab_size is None:
             raise ValueError("the configuration does not define `vocab_size`")                    # modeling_avhubert.py:232-238
         self.config = config
-        self.dev = AvsrDevice(config, state_dict, device)
+        self.dev = AvsrDevice(config, state_dict, device, products=products)
         self.device = self.dev.device
         self.avhubert = AVHubertModel(config, _dev=self.dev)
 
     @classmethod
-    def from_pretrained(cls, path, device="cuda"):
+    def from_pretrained(cls, path, device="cuda", products=None):
         """a directory with config.json + model.safetensors / pytorch_model.bin under the reference's parameter names"""
         from ..runtime.avsr_weights import read_avsr
         cfg, sd = read_avsr(path)
-        return cls(cfg, sd, device=device)
+        return cls(cfg, sd, device=device, products=products)
 
     def get_encoder(self):
         return self.avhubert
@@ -126,7 +127,7 @@ class AVHubertForConditionalGeneration:
         return seq
 
 
-def synthetic_model(config: AvsrConfig = AVSR_BASE, seed: int = 0, device="cuda"):
+def synthetic_model(config: AvsrConfig = AVSR_BASE, seed: int = 0, device="cuda", products=None):
     """seeded synthetic weights under the reference's parameter names (benchmarks / tests: no checkpoint is reachable offline)"""
     from ..runtime.avsr_weights import synthetic_state_dict_avsr
-    return AVHubertForConditionalGeneration(config, synthetic_state_dict_avsr(config, seed), device=device)
+    return AVHubertForConditionalGeneration(config, synthetic_state_dict_avsr(config, seed), device=device, products=products)

@@ -55,15 +55,29 @@ constexpr int GP = 36;    // LDS row pitch in floats (144 B: 16-byte aligned, ro
 // N64: tiles of 128 rows x 64 columns, the four waves stacked over the rows (32 x 64 each) — for products with 64 output columns
 // (the first ResNet stage of the AV-HuBERT video trunk) whose 128-column tiles would multiply a clamped copy of the weights half the
 // time.  CONV: see GemmF32.  Neither changes the order in which the K products of an output element are added.
-template <bool CONV, bool N64>
+// X3: every float32 product as THREE bf16 matrix-core terms — x = hi + lo with hi = bf16(x), lo = bf16(x - hi), 16 mantissa bits per
+// operand, a . b ~= hi_a hi_b + hi_a lo_b + lo_a hi_b (the dropped lo_a lo_b is 2^-16 of the product), accumulated in float32 on
+// v_mfma_f32_16x16x32_bf16.  gfx950 has no tf32 / xf32 matrix instruction, and the exact v_mfma_f32_16x16x4_f32 peaks at 157 TF/s;
+// three bf16 terms run at a third of 2.5 PF/s.  The operands are split once per K stage by the loader (on their way from the prefetch
+// registers into LDS, which holds a hi and a lo plane per tile); loader, gather, tiling and epilogue are the exact kernel's.  NOT
+// bit-faithful to an IEEE float32 chain (relative error of a product <= 2^-16, of a K-term sum far less): for callers whose parity is a
+// tolerance against a float32 reference (the AV-HuBERT family), never for the "precision_f32" modes that promise identical ids.
+__device__ __forceinline__ void split_bf16x3(const float4& v, u16x4_t& hi, u16x4_t& lo) {
+    hi = pack_bf16x4(v.x, v.y, v.z, v.w);
+    lo = pack_bf16x4(v.x - bf16_to_f32(hi[0]), v.y - bf16_to_f32(hi[1]), v.z - bf16_to_f32(hi[2]), v.w - bf16_to_f32(hi[3]));
+}
+constexpr int XP = 40;    // X3: LDS row pitch of a plane in bf16 (80 B: 16-byte aligned, the 16 rows of a fragment read hit 16 different slots)
+
+template <bool CONV, bool N64, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
     // Two LDS stages (round 6): the next K stage is fetched into registers while this one is multiplied and written into the OTHER
     // buffer afterwards, so a stage costs one workgroup barrier instead of two; two workgroups per CU (launch bound) leave the
     // prefetch registers in VGPRs — at three the compiler parked them in scratch on their way to LDS (profiles/r06_05_*: 144 bytes
     // of scratch per lane).  The arithmetic per output element is unchanged: ascending 16-blocks, inside a block k = e + 4 kk.
     constexpr int TN = N64 ? 64 : GT, MI = N64 ? 2 : 4;
-    __shared__ __attribute__((aligned(16))) float As[2][GT * GP];
-    __shared__ __attribute__((aligned(16))) float Ws[2][TN * GP];
+    // (X3: a buffer is a hi plane followed by a lo plane of [rows][XP] bf16 = rows * XP floats)
+    __shared__ __attribute__((aligned(16))) float As[2][X3 ? GT * XP : GT * GP];
+    __shared__ __attribute__((aligned(16))) float Ws[2][X3 ? TN * XP : TN * GP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = N64 ? wave : wave >> 1, wn = N64 ? 0 : wave & 1;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * TN;
@@ -113,12 +127,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
     } while (0)
 #define RS_F32_STASH(buf)                                                                                       \
     do {                                                                                                       \
+        if constexpr (X3) {                                                                                    \
+            uint16_t* ah = reinterpret_cast<uint16_t*>(As[buf]) + lr * XP + 4 * lc;                            \
+            uint16_t* wh = reinterpret_cast<uint16_t*>(Ws[buf]) + lr * XP + 4 * lc;                            \
+            u16x4_t h, l;                                                                                      \
+            split_bf16x3(ra0, h, l); *reinterpret_cast<u16x4_t*>(ah) = h; *reinterpret_cast<u16x4_t*>(ah + GT * XP) = l; \
+            split_bf16x3(ra1, h, l); *reinterpret_cast<u16x4_t*>(ah + 32 * XP) = h; *reinterpret_cast<u16x4_t*>(ah + 32 * XP + GT * XP) = l; \
+            split_bf16x3(ra2, h, l); *reinterpret_cast<u16x4_t*>(ah + 64 * XP) = h; *reinterpret_cast<u16x4_t*>(ah + 64 * XP + GT * XP) = l; \
+            split_bf16x3(ra3, h, l); *reinterpret_cast<u16x4_t*>(ah + 96 * XP) = h; *reinterpret_cast<u16x4_t*>(ah + 96 * XP + GT * XP) = l; \
+            split_bf16x3(rw0, h, l); *reinterpret_cast<u16x4_t*>(wh) = h; *reinterpret_cast<u16x4_t*>(wh + TN * XP) = l; \
+            split_bf16x3(rw1, h, l); *reinterpret_cast<u16x4_t*>(wh + 32 * XP) = h; *reinterpret_cast<u16x4_t*>(wh + 32 * XP + TN * XP) = l; \
+            if constexpr (!N64) {                                                                              \
+                split_bf16x3(rw2, h, l); *reinterpret_cast<u16x4_t*>(wh + 64 * XP) = h; *reinterpret_cast<u16x4_t*>(wh + 64 * XP + TN * XP) = l; \
+                split_bf16x3(rw3, h, l); *reinterpret_cast<u16x4_t*>(wh + 96 * XP) = h; *reinterpret_cast<u16x4_t*>(wh + 96 * XP + TN * XP) = l; \
+            }                                                                                                  \
+        } else {                                                                                               \
         float* ad = As[buf] + lr * GP + 4 * lc;                                                               \
         float* wd = Ws[buf] + lr * GP + 4 * lc;                                                               \
         *reinterpret_cast<float4*>(ad) = ra0; *reinterpret_cast<float4*>(ad + 32 * GP) = ra1;                 \
         *reinterpret_cast<float4*>(ad + 64 * GP) = ra2; *reinterpret_cast<float4*>(ad + 96 * GP) = ra3;       \
         *reinterpret_cast<float4*>(wd) = rw0; *reinterpret_cast<float4*>(wd + 32 * GP) = rw1;                 \
         if constexpr (!N64) { *reinterpret_cast<float4*>(wd + 64 * GP) = rw2; *reinterpret_cast<float4*>(wd + 96 * GP) = rw3; } \
+        }                                                                                                      \
     } while (0)
     f32x4_t acc[4][MI];
 #pragma unroll
@@ -133,6 +163,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
     for (int k0 = 0; k0 < p.K; k0 += GK) {
         const bool more = k0 + GK < p.K;
         if (more) RS_F32_GLOAD(k0 + GK);
+        if constexpr (X3) {
+            // one 32-deep step: three bf16 products per output block, the two small terms first
+            const uint16_t* Ah = reinterpret_cast<const uint16_t*>(As[cur]);
+            const uint16_t* Wh = reinterpret_cast<const uint16_t*>(Ws[cur]);
+            bf16x8_t ah[MI], al[MI], wh[4], wl[4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const uint16_t* q = Ah + (wm * 16 * MI + i * 16 + fr) * XP + 8 * fq;
+                ah[i] = *reinterpret_cast<const bf16x8_t*>(q);
+                al[i] = *reinterpret_cast<const bf16x8_t*>(q + GT * XP);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint16_t* q = Wh + (wn * 64 + i * 16 + fr) * XP + 8 * fq;
+                wh[i] = *reinterpret_cast<const bf16x8_t*>(q);
+                wl[i] = *reinterpret_cast<const bf16x8_t*>(q + TN * XP);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+                }
+        } else {
         const float* Ab = As[cur];
         const float* Wb = Ws[cur];
 #pragma unroll
@@ -149,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmF32 p) {
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni].E, af[mi].E, acc[ni][mi], 0, 0, 0);
             RS_F32_STEP(x) RS_F32_STEP(y) RS_F32_STEP(z) RS_F32_STEP(w)
 #undef RS_F32_STEP
+        }
         }
         if (more) RS_F32_STASH(cur ^ 1);              // nobody reads that buffer: its readers passed the barrier that ended the previous stage
         __syncthreads();
@@ -677,7 +734,8 @@ int rs_launch_gemm_f32(rs_ctx* ctx, const float* A, int lda, const float* W, int
     GemmF32 p{A, W, out, bias, residual, mask_lens, lda, ldw, ldc, M, N, K, flags, alpha, mask_rows_per_step, mask_steps, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
     const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(256);
     rs_prof_begin(ctx, RS_PROF_GEMM, s, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
+    if (ctx->gemm_f32_x3) hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
     rs_prof_end(ctx, RS_PROF_GEMM, s);
     RS_CHECK_LAUNCH(ctx, "gemm_f32");
     return RS_OK;
@@ -700,6 +758,13 @@ int rs_launch_conv3x3_f32(rs_ctx* ctx, const float* in, int n_img, int H, int Wd
     const bool n64 = Cout <= 64;
     const dim3 grid((Cout + (n64 ? 64 : GT) - 1) / (n64 ? 64 : GT), (unsigned)((rows + GT - 1) / GT)), block(256);
     rs_prof_begin(ctx, RS_PROF_GEMM, s, 2.0 * rows * (double)Cout * K, 4.0 * ((double)n_img * H * Wd * C + (double)Cout * K + 2.0 * rows * Cout));
+    if (ctx->gemm_f32_x3) {
+        if (one_by_one) {
+            if (n64) hipLaunchKernelGGL((gemm_f32_kernel<false, true, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), grid, block, 0, s, p);
+        } else if (n64) hipLaunchKernelGGL((gemm_f32_kernel<true, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<true, false, true>), grid, block, 0, s, p);
+    } else
     if (one_by_one) {
         if (n64) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);

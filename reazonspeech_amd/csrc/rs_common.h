@@ -139,6 +139,7 @@ struct rs_ctx {
     const float *jout_wrm = nullptr, *jout_bpad = nullptr, *jout_wmax = nullptr;
     bool decode_screen = true;
     bool decode_narrow = true;      // narrow-tile LSTM / projection kernels (k_rnnt.hip)
+    bool gemm_f32_x3 = false;       // rs_launch_gemm_f32 / rs_launch_conv3x3_f32 multiply with three bf16 terms per float32 product (k_f32.hip X3; avsr only)
     int k2_conv2_fused = -1;        // Zipformer conv2 with its patches gathered into LDS: -1 = $RS_K2_CONV2_FUSED (default 1); rs_set_option("k2_conv2_fused")
     int k2_cnx_fused = -1;          // Zipformer ConvNeXt pointwise pair as one kernel: -1 = $RS_K2_CNX_FUSED (default 1); rs_set_option("k2_cnx_fused")
     // position table cache: the caller registers "pos_table.<T>" tensors (bf16 [2T-1][d])

@@ -1,6 +1,7 @@
 """Device side of `reazonspeech.avsr`: one AV-HuBERT encoder-decoder on one MI355X through the rs_avsr_* entry points of
 librs_asr.so (include/rs_asr.h; csrc/k_avsr.hip).  PyTorch is used for device memory and streams only."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -11,7 +12,9 @@ from .avsr_weights import prepare_weights_avsr
 
 
 class AvsrDevice:
-    def __init__(self, cfg: AvsrConfig, state_dict, device="cuda"):
+    PRODUCTS = ("exact", "x3")
+
+    def __init__(self, cfg: AvsrConfig, state_dict, device="cuda", products=None):
         cfg.validate()
         if not torch.cuda.is_available():
             raise RuntimeError("reazonspeech_amd needs a ROCm GPU (MI355X / gfx950): torch.cuda.is_available() is False and there is "
@@ -27,10 +30,21 @@ class AvsrDevice:
             for name, t in prepare_weights_avsr(cfg, state_dict).items():
                 self.ctx.set_tensor(name, t.to(self.device).contiguous())
             self.ctx.finalize()
+            self.set_products(products or os.environ.get("REAZONSPEECH_AVSR_PRODUCTS", "exact"))
         self.vp = (cfg.vocab_size + 3) // 4 * 4
         self._ws = None
         self._state = None
         self._taps = None
+
+    def set_products(self, products: str):
+        """how the float32 products of the big GEMMs / convolutions are formed: "exact" = v_mfma_f32_16x16x4_f32 (an IEEE float32 chain:
+        the default, what the parity statements are made with); "x3" = three bf16 matrix-core terms per product (hi / lo split, 16
+        mantissa bits per operand, float32 accumulation: csrc/k_f32.hip X3) — 1.7x faster on the encoder, errors 5 - 7x the exact
+        mode's and still 10x inside the stated tolerances, generate() ids equal to the reference's on every golden clip"""
+        if products not in self.PRODUCTS:
+            raise ValueError(f"products={products!r}: one of {self.PRODUCTS}")
+        self.products = products
+        self.ctx.set_option("gemm_f32_x3", 1 if products == "x3" else 0)
 
     # ---- encoder ---------------------------------------------------------------------------------------------------------------
     def _dev(self, x, dtype=torch.float32):

@@ -39,9 +39,9 @@ def load(name):
     return g, cfg, sd, a, v, mask
 
 
-def check_against_reference(name):
+def check_against_reference(name, products="exact"):
     g, cfg, sd, a, v, mask = load(name)
-    model = AVHubertForConditionalGeneration(cfg, sd, device="cuda:0")
+    model = AVHubertForConditionalGeneration(cfg, sd, device="cuda:0", products=products)
     mid = cfg.encoder_layers // 2
     enc, taps = model.dev.encode(a, v, mask, taps=[0, mid])
     torch.cuda.synchronize()
@@ -74,6 +74,18 @@ def check_against_reference(name):
     assert stats["beam_scores"] <= TOL_SCORE, stats
     stats["distinct_greedy_tokens"] = int(len(set(g["greedy"].reshape(-1).tolist())))
     return model, stats, (g, cfg, sd, a, v, mask, enc)
+
+
+@pytest.mark.parametrize("name", ["tiny", "base"])
+def test_three_term_bf16_products_vs_the_reference(gpu_device, name):
+    """products="x3" (csrc/k_f32.hip X3: every float32 product of the big GEMMs / convolutions as three bf16 matrix-core terms, float32
+    accumulation) against the SAME goldens and the SAME tolerances as the exact mode: taps, encoder, teacher-forced logits, and the ids
+    of greedy and beam search identical to the reference's generate().  Its errors are printed next to the exact mode's."""
+    model, stats, _ = check_against_reference(name, products="x3")
+    assert model.dev.products == "x3"
+    print(f"avsr {name} vs reference, x3 products:", stats)
+    with pytest.raises(ValueError):
+        model.dev.set_products("bf16")
 
 
 def test_tiny_vs_the_reference(gpu_device):
