@@ -227,6 +227,31 @@ def fp32_mode_parity(model, cfg, sd, buf256, audio, lens):
     out["bf16_audit_all_rows"] = s
     del m32, b32
     torch.cuda.empty_cache()
+    # precision="fp32x3": the float32 mode with every float32 product of its GEMMs formed from three bf16 matrix-core terms (csrc/k_f32.hip X3)
+    # — not an IEEE chain; a mode of its own, held to the same golden
+    try:
+        mx = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device=str(model.device), precision="fp32x3")
+        bx = mx.stage([audio[b, :int(lens[b])] for b in range(audio.shape[0])], buf=mx.new_buffers(audio.shape[0], audio.shape[1]))
+        mx.run_device(bx)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        mx.run_device(bx)
+        torch.cuda.synchronize()
+        msx = (time.perf_counter() - t1) * 1e3
+        gotx = mx.collect(bx)
+        projx = (bx.joint_enc @ R).cpu().numpy()
+        perrx = max(float(np.abs(projx[b, :gotx.enc_lens[b]] - gold["equal_proj"][b, :gotx.enc_lens[b]]).max()) for b in range(rows))
+        exactx = [gotx.ids[b] == g_ids[b] and gotx.frames[b] == g_frames[b] for b in range(rows)]
+        out["fp32x3_mode"] = {"what": "float32 weights / activations / accumulation; each float32 product of the GEMMs = hi.hi + hi.lo + lo.hi of a bf16 hi / lo "
+                                      "split (16 mantissa bits per operand) on v_mfma_f32_16x16x32_bf16; same golden as fp32_mode",
+                              "rows": rows, "ids_exact": f"{sum(exactx)}/{rows}", "rows_differing": [b for b in range(rows) if not exactx[b]],
+                              "rows_differing_that_are_near_ties_of_the_golden": [b for b in range(rows) if not exactx[b] and b in near],
+                              "joint_proj_fingerprint_max_err_all_rows": round(perrx, 7),
+                              "ms_per_batch_of_256": round(msx, 1), "rtfx": round(float(lens.sum()) / 16000.0 / (msx * 1e-3), 1)}
+        del mx, bx
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["fp32x3_mode"] = {"error": repr(e)}
     return out
 
 

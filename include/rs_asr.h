@@ -282,11 +282,11 @@ int rs_stream_destroy(void* stream);
  *                        ".b.f32" in NeMo's own row order, values then gates) and "pos.table.f32"; rs_workspace_bytes
  *                        accounts for the mode once they are registered.  ~20x slower; front-end and decode are float32 in
  *                        both modes.
- *   "gemm_f32_x3"        (AV-HuBERT contexts; default 0) 1: the float32 products of the encoder's GEMMs / convolutions are formed from
- *                        three bf16 matrix-core terms (hi / lo split of both operands, float32 accumulation: 16 mantissa bits per
- *                        operand) instead of the exact v_mfma_f32_16x16x4_f32 chain: 1.7x faster, errors 5 - 7x the exact mode's and
- *                        10x inside the family's stated tolerances.  Refused for every other family: their "precision_f32" modes
- *                        promise exact float32 products.
+ *   "gemm_f32_x3"        (default 0) 1: the float32 products of rs_gemm_f32-class launches (the "precision_f32" encoder, the AV-HuBERT
+ *                        encoder) are formed from three bf16 matrix-core terms — hi / lo split of both operands, hi.hi + hi.lo + lo.hi,
+ *                        float32 accumulation: 16 mantissa bits per operand — instead of the exact v_mfma_f32_16x16x4_f32 chain:
+ *                        ~2x faster.  NOT an IEEE float32 chain: a mode of its own (Python: precision="fp32x3", products="x3"),
+ *                        held to the same goldens as the exact mode (tests/test_gpu_*fp32*.py, tests/test_gpu_avsr.py).
  *   "k2_cnx_fused", "k2_conv2_fused"   (Zipformer contexts; default 1) the encoder_embed's ConvNeXt pointwise pair as one kernel /
  *                        its 32 -> 128 convolution with the patches gathered into LDS; 0 = the GEMM launches they replace.  Both
  *                        forms give the same bits (tests/test_gpu_k2.py): the switch exists for that comparison. */

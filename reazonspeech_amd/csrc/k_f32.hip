@@ -60,8 +60,9 @@ constexpr int GP = 36;    // LDS row pitch in floats (144 B: 16-byte aligned, ro
 // v_mfma_f32_16x16x32_bf16.  gfx950 has no tf32 / xf32 matrix instruction, and the exact v_mfma_f32_16x16x4_f32 peaks at 157 TF/s;
 // three bf16 terms run at a third of 2.5 PF/s.  The operands are split once per K stage by the loader (on their way from the prefetch
 // registers into LDS, which holds a hi and a lo plane per tile); loader, gather, tiling and epilogue are the exact kernel's.  NOT
-// bit-faithful to an IEEE float32 chain (relative error of a product <= 2^-16, of a K-term sum far less): for callers whose parity is a
-// tolerance against a float32 reference (the AV-HuBERT family), never for the "precision_f32" modes that promise identical ids.
+// bit-faithful to an IEEE float32 chain (relative error of a product <= 2^-16, of a K-term sum far less): the AV-HuBERT family's option
+// products="x3" and the "fp32x3" precision of the transducer families — a mode of its own next to the exact "fp32", measured against
+// the same goldens (every id of the three 256-row goldens identical: profiles/r06_19_*), never silently substituted for it.
 __device__ __forceinline__ void split_bf16x3(const float4& v, u16x4_t& hi, u16x4_t& lo) {
     hi = pack_bf16x4(v.x, v.y, v.z, v.w);
     lo = pack_bf16x4(v.x - bf16_to_f32(hi[0]), v.y - bf16_to_f32(hi[1]), v.z - bf16_to_f32(hi[2]), v.w - bf16_to_f32(hi[3]));

@@ -327,9 +327,8 @@ int rs_set_option(rs_ctx* ctx, const char* key, int value) {
         ctx->precision_f32 = value != 0;
         return RS_OK;
     }
-    if (!strcmp(key, "gemm_f32_x3")) {             // AV-HuBERT contexts: float32 products as three bf16 matrix-core terms (k_f32.hip X3)
-        if (!ctx->avsr) return rs_fail(ctx, RS_EINVAL, "option 'gemm_f32_x3' applies to an AV-HuBERT context only (the precision_f32 modes promise exact float32 products)");
-        ctx->gemm_f32_x3 = value != 0;
+    if (!strcmp(key, "gemm_f32_x3")) {             // float32 products as three bf16 matrix-core terms (k_f32.hip X3): the AV-HuBERT family, and the
+        ctx->gemm_f32_x3 = value != 0;             // "precision_f32" mode of the others ("fp32x3": not an IEEE chain; held to the same goldens)
         return RS_OK;
     }
     if (!strcmp(key, "k2_conv2_fused")) {          // conv2 with its patches gathered into LDS (1, default) or as patch matrix + GEMM launch (0): same bits

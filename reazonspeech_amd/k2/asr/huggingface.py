@@ -73,6 +73,7 @@ def load_model(device=None, precision="fp32", language="ja", checkpoint=None, co
       compute (str): "bf16" (default): the throughput mode — bf16 matrix-core operands, float32 accumulation and residual stream,
         exact float32 decode.  "fp32": the parity mode — float32 weights, activations and arithmetic end to end, i.e. what
         onnxruntime computes from the reference's default float32 graphs; greedy ids identical to the float32 oracle, ~6x slower.
+        "fp32x3": the float32 mode with its products formed from three bf16 matrix-core terms (2x faster; same 256-row golden, ids identical).
         (`precision` keeps the reference's meaning: WHICH files are read.)
 
     A real icefall export has never been read by runtime/k2_onnx.py (no file is reachable from the build environment): the reader
@@ -94,8 +95,8 @@ def load_model(device=None, precision="fp32", language="ja", checkpoint=None, co
                            "(use the reference package for those)")
     if not torch.cuda.is_available():
         raise RuntimeError("reazonspeech_amd needs a ROCm GPU: torch.cuda.is_available() is False")
-    if compute not in ("bf16", "fp32"):
-        raise ValueError(f"compute must be 'bf16' or 'fp32', not {compute!r}")
+    if compute not in ("bf16", "fp32", "fp32x3"):
+        raise ValueError(f"compute must be 'bf16', 'fp32' or 'fp32x3', not {compute!r}")
     want_synthetic = config is not None or synthetic or os.environ.get(SYNTHETIC_ENV, "0") not in ("", "0")
     if want_synthetic and not checkpoint:
         basedir, files = None, None

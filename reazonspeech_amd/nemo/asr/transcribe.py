@@ -80,6 +80,9 @@ def load_model(device=None, checkpoint=None, config=None, seed=0, pos_cap=None, 
         residual stream, exact float32 decode.  "fp32": the parity mode — float32 weights, activations and arithmetic end
         to end, i.e. what the reference computes (transcribe.py:26-28, :48-53 run NeMo in float32 without autocast; the
         same keyword as `reazonspeech.k2.asr.load_model(precision=...)`, pkg/k2-asr/src/huggingface.py:16); ~20x slower.
+        "fp32x3": the float32 mode with every float32 PRODUCT of its GEMMs formed from three bf16 matrix-core terms (hi / lo split,
+        float32 accumulation): twice the float32 mode's speed; not an IEEE chain, but every id of the 256-row float32-oracle goldens
+        is reproduced (tests/test_gpu_fullsize.py).
       pos_cap (int): encoder frames (80 ms each) the resident relative-position tables cover at load time
         (default 1024, about 82 s); longer utterances grow the tables on first use.
 

@@ -136,9 +136,28 @@ def run32(gpu_device, gold, bench_waves):
 
 
 def test_120m_fp32_mode_every_row_vs_fp32_oracle_golden(gold, run32):
+    check_rows(gold, run32, "espnet_fp32_mode")
+
+
+def test_120m_fp32x3_mode_every_row_vs_fp32_oracle_golden(gpu_device, gold, bench_waves):
+    """precision="fp32x3": the float32 mode with every float32 product of its GEMMs formed from three bf16 matrix-core terms
+    (csrc/k_f32.hip X3) against the SAME golden and assertions: rows without a near-tie identical, the joint projection and the
+    CTC posteriors inside the float32 tolerance (round 6 measured 255 / 256, the one differing row a near-tie of the golden)"""
+    cfg = ESPNET_CONFORMER_120M
+    sd = synthetic_state_dict_espnet(cfg, 0)
+    model = EspnetModel(cfg, sd, synthetic_token_list(cfg.vocab_size, 0), device="cuda:0", precision="fp32x3")
+    assert model.am.x3
+    buf, probs, blank, got = run_with_ctc(model, bench_waves)
+    out = (got, buf.joint_enc.clone(), blank.clone(), probs[:, :, :cfg.n_logits].argmax(-1).to(torch.int16).cpu().numpy())
+    del model, buf, probs
+    torch.cuda.empty_cache()
+    check_rows(gold, out, "espnet_fp32x3_mode")
+
+
+def check_rows(gold, run, key):
     cfg = ESPNET_CONFORMER_120M
     rows = int(gold["rows"])
-    got, f_dev, blank, ctc_argmax = run32
+    got, f_dev, blank, ctc_argmax = run
     assert got.enc_lens[:rows] == gold["enc_lens"].tolist()
     g = torch.Generator().manual_seed(int(gold["proj_seed"]))
     R = (torch.randn((cfg.joint_hidden, 8), generator=g, dtype=torch.float32) / cfg.joint_hidden ** 0.5).to(f_dev.device)
@@ -162,7 +181,7 @@ def test_120m_fp32_mode_every_row_vs_fp32_oracle_golden(gold, run32):
     near = set(int(b) for b in np.nonzero(gold["min_margin"] < float(gold["near_tie"]))[0])
     differ = [b for b in range(rows) if got.ids[b] != g_ids[b] or got.frames[b] != g_frames[b]]
     assert not [b for b in differ if b not in near], f"rows {differ} differ from the float32 oracle without a near-tie"
-    report("espnet_fp32_mode", {"rows": rows, "ids_and_frames_exact": f"{rows - len(differ)}/{rows}", "near_tie_rows_in_golden": len(near),
+    report(key, {"rows": rows, "ids_and_frames_exact": f"{rows - len(differ)}/{rows}", "near_tie_rows_in_golden": len(near),
                                 "differing_rows": differ, "joint_proj_fingerprint_max_err": worst_proj, "joint_enc_rows01_max_err": worst_f,
                                 "ctc_blank_max_err": worst_blank, "ctc_argmax_agreement": agree / max(total, 1), "decisions": int(total)})
 

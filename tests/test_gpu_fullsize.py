@@ -425,17 +425,8 @@ def fp32_runs(full32):
     return out
 
 
-@pytest.mark.parametrize("name", ["equal", "ragged"])
-def test_619m_fp32_mode_every_row_vs_fp32_oracle_golden(full32, fp32_runs, name):
-    """`load_model(precision="fp32")` on ALL 256 rows of the benchmark batch (seed 1234) and of the ragged set (seed 1235)
-    against tests/golden/bench_fp32.npz — the float32 oracle run end to end, one utterance per call with the reference's
-    padding (pkg/nemo-asr/src/transcribe.py:44-53):
-      * encoder lengths identical; the joint projection of EVERY row within 1e-4 (8-dim fingerprint of all rows, the full
-        tensor for rows 0 and 1);
-      * greedy ids AND emission frames IDENTICAL on every row whose float32-oracle decision margins all exceed the
-        generator's near-tie threshold (1e-3, two orders above float32 reassociation noise; the rows below it are named by
-        the golden itself, not by this comparison);
-      * on the near-tie rows: identical too, or the difference starts at a decision whose oracle margin is below 1e-4."""
+def check_fp32_rows(full32, fp32_runs, name, key):
+    """shared by the exact float32 mode and the three-term-product mode: see test_619m_fp32_mode_every_row_vs_fp32_oracle_golden"""
     from oracle import audit
     gold = np.load(BENCH_GOLD)
     rows = int(gold["rows"])
@@ -468,10 +459,48 @@ def test_619m_fp32_mode_every_row_vs_fp32_oracle_golden(full32, fp32_runs, name)
             explained.append({"row": b, "golden_min_margin": float(gold[name + "_min_margin"][b]),
                               "margin_at_first_difference": None if first is None else first["margin_ref"]})
             assert first is not None and first["margin_ref"] <= 1e-4, (b, first)
-    report(f"fp32_mode_{name}", {"rows": rows, "ids_and_frames_exact": f"{rows - len(differ)}/{rows}",
+    report(f"{key}_{name}", {"rows": rows, "ids_and_frames_exact": f"{rows - len(differ)}/{rows}",
                                  "near_tie_rows_in_golden": len(near), "differing_rows": explained,
                                  "joint_proj_fingerprint_max_err": worst_proj, "joint_enc_rows01_max_err": worst_f,
                                  "decisions": int(gold[name + "_n_decisions"].sum())})
+
+
+
+
+@pytest.mark.parametrize("name", ["equal", "ragged"])
+def test_619m_fp32_mode_every_row_vs_fp32_oracle_golden(full32, fp32_runs, name):
+    """`load_model(precision="fp32")` on ALL 256 rows of the benchmark batch (seed 1234) and of the ragged set (seed 1235)
+    against tests/golden/bench_fp32.npz — the float32 oracle run end to end, one utterance per call with the reference's
+    padding (pkg/nemo-asr/src/transcribe.py:44-53):
+      * encoder lengths identical; the joint projection of EVERY row within 1e-4 (8-dim fingerprint of all rows, the full
+        tensor for rows 0 and 1);
+      * greedy ids AND emission frames IDENTICAL on every row whose float32-oracle decision margins all exceed the
+        generator's near-tie threshold (1e-3, two orders above float32 reassociation noise; the rows below it are named by
+        the golden itself, not by this comparison);
+      * on the near-tie rows: identical too, or the difference starts at a decision whose oracle margin is below 1e-4."""
+    check_fp32_rows(full32, fp32_runs, name, "fp32_mode")
+
+
+def test_619m_fp32x3_mode_every_row_vs_fp32_oracle_golden(full):
+    """`load_model(precision="fp32x3")`: the float32 mode with every float32 product of its GEMMs formed from three bf16 matrix-core
+    terms (csrc/k_f32.hip X3; 2x the float32 mode's speed) — the SAME golden, the same assertions as the exact mode, both sets:
+    every row whose oracle margins exceed the near-tie threshold identical, a differing near-tie row explained by a margin
+    below 1e-4 on this side (round 6 measured 256 / 256 on both sets)."""
+    _, sd = full
+    cfg = FASTCONFORMER_619M
+    model = AsrModel(cfg, sd, SyntheticTokenizer(cfg.vocab_size), device="cuda:0", precision="fp32x3")
+    assert model.x3 and model.precision == "fp32"
+    gold = np.load(BENCH_GOLD)
+    for name, kw in SETS.items():
+        audio, lens = synthetic_batch(256, 10.0, **kw)
+        buf = model.stage([audio[b, :lens[b]] for b in range(256)], buf=model.new_buffers(256, 160000))
+        model.run_device(buf)
+        torch.cuda.synchronize()
+        runs = {name: (audio, lens, model.collect(buf), buf.joint_enc.clone())}
+        check_fp32_rows(model, runs, name, "fp32x3_mode")
+        del buf
+    del model
+    torch.cuda.empty_cache()
 
 
 def full32_sd(model):

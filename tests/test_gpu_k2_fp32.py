@@ -126,12 +126,10 @@ def bench_waves(gold):
     return [np.pad(audio[b, :lens[b]], PAD) for b in range(256)]
 
 
-@pytest.fixture(scope="module")
-def run32(gpu_device, gold, bench_waves):
-    """the float32 mode over the whole benchmark batch -> (DecodedBatch, joint projection, features on the device, row 0 alone)"""
+def run_mode(bench_waves, precision):
     cfg = ZIPFORMER_159M
     sd = synthetic_state_dict_k2(cfg, 0)
-    model = K2Model(cfg, sd, synthetic_tokens(cfg.vocab_size, 0), device="cuda:0", precision="fp32")
+    model = K2Model(cfg, sd, synthetic_tokens(cfg.vocab_size, 0), device="cuda:0", precision=precision)
     buf, _, _, enc, got = run(model, bench_waves)
     out = [got, buf.joint_enc.clone(), buf.feats.clone()]
     del buf, enc
@@ -142,7 +140,23 @@ def run32(gpu_device, gold, bench_waves):
     return out
 
 
+@pytest.fixture(scope="module")
+def run32(gpu_device, gold, bench_waves):
+    """the float32 mode over the whole benchmark batch -> (DecodedBatch, joint projection, features on the device, row 0 alone)"""
+    return run_mode(bench_waves, "fp32")
+
+
 def test_159m_fp32_mode_every_row_vs_fp32_oracle_golden(gold, run32):
+    check_rows(gold, run32, "k2_fp32_mode")
+
+
+def test_159m_fp32x3_mode_every_row_vs_fp32_oracle_golden(gpu_device, gold, bench_waves):
+    """compute="fp32x3": the float32 mode with every float32 product of its GEMMs formed from three bf16 matrix-core terms
+    (csrc/k_f32.hip X3) against the SAME golden and assertions, batch invariance included (round 6 measured 256 / 256)"""
+    check_rows(gold, run_mode(bench_waves, "fp32x3"), "k2_fp32x3_mode")
+
+
+def check_rows(gold, run32, key):
     cfg = ZIPFORMER_159M
     rows = int(gold["rows"])
     got, f_dev, feats, alone, f_alone = run32
@@ -169,7 +183,7 @@ def test_159m_fp32_mode_every_row_vs_fp32_oracle_golden(gold, run32):
     # batch invariance at B = 256, bits: row 0 alone == row 0 inside the batch
     n0 = alone.enc_lens[0]
     assert n0 == got.enc_lens[0] and torch.equal(f_alone[0, :n0], f_dev[0, :n0]) and alone.ids[0] == got.ids[0] and alone.frames[0] == got.frames[0]
-    report("k2_fp32_mode", {"rows": rows, "ids_and_frames_exact": f"{rows - len(differ)}/{rows}", "near_tie_rows_in_golden": len(near), "differing_rows": differ,
+    report(key, {"rows": rows, "ids_and_frames_exact": f"{rows - len(differ)}/{rows}", "near_tie_rows_in_golden": len(near), "differing_rows": differ,
                             "joint_proj_fingerprint_max_err": worst_proj, "joint_enc_rows01_max_err": worst_f, "fbank_fingerprint_max_err": worst_feat,
                             "decisions": int(sum(got.enc_lens[:rows])), "tokens": int(sum(len(x) for x in g_ids)),
                             "golden_min_margin": float(gold["min_margin"].min()), "alone_equals_inside_b256_bits": True})
