@@ -1,4 +1,5 @@
-"""One float32-mode pass of a model family over its benchmark batch (for rocprofv3 --kernel-trace): python scripts/family_f32_run.py nemo|espnet|k2|avsr"""
+"""One float32-mode pass of a model family over its benchmark batch (for rocprofv3 --kernel-trace): python scripts/family_f32_run.py nemo|espnet|k2|avsr
+($RS_F32_PRECISION=fp32x3 / $REAZONSPEECH_AVSR_PRODUCTS=x3: the three-term-product forms)"""
 import os
 import sys
 import time
@@ -9,6 +10,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from reazonspeech_amd.runtime.synth import synthetic_batch          # noqa: E402
+
+
+PREC = os.environ.get("RS_F32_PRECISION", "fp32")          # "fp32x3": the three-term-product form of the same mode
 
 
 def main(which):
@@ -32,20 +36,20 @@ def main(which):
         from reazonspeech_amd.runtime.k2_config import ZIPFORMER_159M as cfg
         from reazonspeech_amd.runtime.k2_weights import synthetic_state_dict_k2
         from reazonspeech_amd.k2.asr.model import K2Model, synthetic_tokens
-        am = K2Model(cfg, synthetic_state_dict_k2(cfg, 0), synthetic_tokens(cfg.vocab_size, 0), device="cuda:0", precision="fp32").am
+        am = K2Model(cfg, synthetic_state_dict_k2(cfg, 0), synthetic_tokens(cfg.vocab_size, 0), device="cuda:0", precision=PREC).am
         pad = (int(0.9 * 16000),) * 2
     elif which == "espnet":
         from reazonspeech_amd.runtime.config import ESPNET_CONFORMER_120M as cfg
         from reazonspeech_amd.runtime.weights_espnet import synthetic_state_dict_espnet
         from reazonspeech_amd.espnet.asr.model import EspnetModel, synthetic_token_list, PADDING
-        am = EspnetModel(cfg, synthetic_state_dict_espnet(cfg, 0), synthetic_token_list(cfg.vocab_size, 0), device="cuda:0", precision="fp32").am
+        am = EspnetModel(cfg, synthetic_state_dict_espnet(cfg, 0), synthetic_token_list(cfg.vocab_size, 0), device="cuda:0", precision=PREC).am
         pad = PADDING
     else:
         from reazonspeech_amd.runtime.config import FASTCONFORMER_619M as cfg
         from reazonspeech_amd.runtime.model import AsrModel
         from reazonspeech_amd.runtime.tokenizer import SyntheticTokenizer
         from reazonspeech_amd.runtime.weights import synthetic_state_dict
-        am = AsrModel(cfg, synthetic_state_dict(cfg, 0), SyntheticTokenizer(cfg.vocab_size), device="cuda:0", precision="fp32")
+        am = AsrModel(cfg, synthetic_state_dict(cfg, 0), SyntheticTokenizer(cfg.vocab_size), device="cuda:0", precision=PREC)
         pad = (0, 0)
     audio, lens = synthetic_batch(256, 10.0, seed=4242 if which != "nemo" else 1234)
     waves = [np.pad(audio[b, :lens[b]], pad) for b in range(256)]
